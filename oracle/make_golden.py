@@ -1,0 +1,118 @@
+"""TEST INFRASTRUCTURE -- generates tests/golden/*.npz by running the REAL reference
+(imported from /root/reference through oracle/ref_harness.py) on seeded inputs.
+Run in the build container only:   python oracle/make_golden.py
+
+Each fixture holds: the reference model's state_dict, the inputs (src/tgt/lengths/image
+rows/eps), forward intermediates + loss statistics from the reference's *monolithic* loss
+path (as-executed H1 image term), parameter gradients from the reference's *sharded
+training* path (`loss.div(B).backward()`, with shims s6/s7 => image-term semantic "A"),
+and the parameters after one `onmt.Optim.step()` (clip 5 + Adam lr 0.002).
+Fixtures are data (inputs + expected outputs) -- no reference source text is stored.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_harness as RH          # noqa: E402
+from oracle import vi1_oracle as O            # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+CASES = {
+    # name: (cfg kwargs, B, S, T, fixed_len)
+    "tiny_uni_l2": (dict(vs=37, vt=41, emb=12, hid=16, z=8, layers=2, brnn=False), 5, 7, 9, False),
+    "tiny_bi_l1":  (dict(vs=37, vt=41, emb=12, hid=16, z=8, layers=1, brnn=True), 5, 7, 9, False),
+    "tiny_bi_l2":  (dict(vs=53, vt=47, emb=20, hid=24, z=12, layers=2, brnn=True), 6, 9, 8, False),
+    "small_fixed": (dict(vs=211, vt=307, emb=40, hid=64, z=32, layers=1, brnn=True), 8, 10, 11, True),
+}
+
+
+def run_case(name, ck, B, S, T, fixed):
+    onmt, _ = RH.import_reference()
+    c = O.Cfg(**ck)
+    opt = RH.make_opt(src_word_vec_size=c.emb, tgt_word_vec_size=c.emb, rnn_size=c.hid, z_latent_dim=c.z,
+                      enc_layers=c.layers, dec_layers=c.layers, encoder_type="brnn" if c.brnn else "rnn",
+                      dropout=0.0)
+    model, fields = RH.build_model(opt, c.vs, c.vt, seed=0)
+    model.train()
+    for k, v in model.named_parameters():          # large tensors: formula values (not stored in the fixture)
+        if v.numel() > O.BIG:
+            v.data.copy_(O.formula_param(k, tuple(v.shape)))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    bt = O.synth_batch(c, B, S, T, n_img=16, seed=4321 + len(name), fixed_len=fixed)
+    img = bt["table"][bt["indices"]]
+    src3, tgt3 = bt["src"].unsqueeze(2), bt["tgt"].unsqueeze(2)
+    out = {}
+    # ---- forward + monolithic loss (as-executed values) --------------------------------
+    vloss = RH.make_loss(model, fields, opt, training=False)
+    with RH.inject_eps(bt["eps"]):
+        outputs, attns, _ = model(src3, tgt3, bt["src_len"], bt["tgt_len"], img.clone())
+    batch = RH.Batch(bt["src"], bt["src_len"], bt["tgt"], bt["tgt_len"], bt["indices"])
+    batch.tgt = batch.tgt[0]
+    with torch.no_grad():
+        stats = vloss.monolithic_compute_loss(batch, outputs, {k: v for k, v in attns.items()})
+    out["f_out"] = outputs
+    out["f_attn"] = attns["std"]
+    out["f_mu"], out["f_sigma"] = attns["z_latent"][0].params()
+    out["f_z"] = attns["z0_sample"][0]
+    # NB: monolithic loss normalised p_v / img in place (H1) -> re-run the image net for the raw mean
+    with torch.no_grad():
+        out["f_mu_v"] = model.inf_net_image(out["f_z"], None, None)[0].params()[0]
+    for k in ("nmt_loss", "td_kl_before", "td_kl_after", "image_feats_loss", "image_feats_cos", "elbo_loss"):
+        out["s_" + k] = torch.as_tensor(float(getattr(stats, k)))
+    out["s_n_words"] = torch.as_tensor(int(stats.n_words))
+    out["s_n_correct"] = torch.as_tensor(int(stats.n_correct))
+    # encoder internals
+    with torch.no_grad():
+        enc_hidden, context = model.encoder(src3, bt["src_len"])
+    out["f_context"], out["f_enc_h"], out["f_enc_c"] = context, enc_hidden[0], enc_hidden[1]
+    # ---- sharded training loss + backward + one optimiser step -----------------------
+    tloss = RH.make_loss(model, fields, opt, training=True)
+    optim = onmt.Optim("adam", 0.002, 5.0, lr_decay=0.5, start_decay_at=8)
+    optim.set_parameters(model.parameters())
+    model.zero_grad()
+    with RH.inject_eps(bt["eps"]), RH.training_shims():
+        outputs, attns, _ = model(src3, tgt3, bt["src_len"], bt["tgt_len"], img.clone())
+        batch = RH.Batch(bt["src"], bt["src_len"], bt["tgt"], bt["tgt_len"], bt["indices"])
+        batch.tgt = batch.tgt[0]
+        tstats = tloss.sharded_compute_loss(batch, outputs, attns, 0, T, 32, B)
+    out["t_elbo"] = torch.as_tensor(float(tstats.elbo_loss))
+    out["t_img_logprob_A"] = torch.as_tensor(float(tstats.image_feats_loss))
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            out["g_" + k] = v.grad.detach().clone()
+    optim.step()
+    for k, v in model.state_dict().items():
+        out["p1_" + k] = v.detach().clone()
+    arrs = {"in_" + k: v.numpy() for k, v in bt.items()}
+    arrs.update({"p0_" + k: v.numpy() for k, v in sd.items()})
+    arrs.update({k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})
+    arrs["cfg"] = np.array([c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, int(c.brnn), B, S, T], dtype=np.int64)
+    os.makedirs(OUT, exist_ok=True)
+    # the image MLP's fc2 is 2048x2048 (x2, 33 MB): store fp16-exact-free? no -- keep fp32 but drop the dead
+    # scale branch (never read by forward/loss; H6) to keep fixtures small
+    arrs = {k: v for k, v in arrs.items() if "inf_net_image.scale" not in k}
+    for k in list(arrs):
+        if k[:3] in ("p0_", "p1_") or k[:2] == "g_":
+            if arrs[k].size > O.BIG:
+                t = torch.from_numpy(arrs.pop(k))
+                if k[:3] == "p0_":
+                    continue                       # regenerated by O.formula_param in the tests
+                sub, s1, s2 = O.sample_big(t)
+                arrs["big_" + k] = sub.numpy()
+                arrs["bigsum_" + k] = np.array([float(s1), float(s2)])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print(name, "elbo", float(out["s_elbo_loss"]), "nmt", float(out["s_nmt_loss"]), "kl", float(out["s_td_kl_before"]),
+          "img", float(out["s_image_feats_loss"]), "words", int(out["s_n_words"]))
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for n, (ck, B, S, T, fx) in CASES.items():
+        if only and n not in only:
+            continue
+        run_case(n, ck, B, S, T, fx)

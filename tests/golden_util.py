@@ -1,0 +1,29 @@
+"""Loading of tests/golden/*.npz (made by oracle/make_golden.py from the real reference)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import vi1_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["tiny_uni_l2", "tiny_bi_l1", "tiny_bi_l2", "small_fixed"]
+
+
+def load(name, dtype=torch.float32):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    vs, vt, emb, hid, zd, img, layers, brnn, B, S, T = [int(x) for x in z["cfg"]]
+    c = O.Cfg(vs=vs, vt=vt, emb=emb, hid=hid, z=zd, img=img, layers=layers, brnn=bool(brnn))
+    p = {}
+    for k, shp in O.param_shapes(c).items():
+        if "p0_" + k in z.files:
+            p[k] = torch.from_numpy(z["p0_" + k]).to(dtype)
+        elif "inf_net_image.scale" in k and int(np.prod(shp)) <= O.BIG:
+            p[k] = torch.zeros(*shp, dtype=dtype)       # dead branch (H6), dropped from the fixture
+        else:
+            p[k] = O.formula_param(k, shp, dtype)
+        assert tuple(p[k].shape) == tuple(shp), k
+    bt = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    for k in ("table", "eps"):
+        bt[k] = bt[k].to(dtype)
+    return c, p, bt, z, (B, S, T)

@@ -1,0 +1,76 @@
+"""Pins the CPU oracle (oracle/vi1_oracle.py) against golden vectors produced by the REAL reference
+(oracle/make_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vi1_oracle as O
+from tests.golden_util import CASES, load
+
+
+def _close(a, b, rtol=2e-5, atol=2e-6, what=""):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    tol = atol + rtol * b.abs().max().item() if b.numel() else atol
+    assert err <= tol, "%s: max abs err %.3e > %.3e" % (what, err, tol)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_and_stats(name):
+    c, p, bt, z, (B, S, T) = load(name)
+    img = bt["table"][bt["indices"]]
+    r = O.forward(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], training=True)
+    _close(r["context"], z["f_context"], what="context")
+    _close(r["enc_h_n"], z["f_enc_h"], what="h_n")
+    _close(r["enc_c_n"], z["f_enc_c"], what="c_n")
+    _close(r["mu"], z["f_mu"], what="mu")
+    _close(r["sigma"], z["f_sigma"], what="sigma")
+    _close(r["z"], z["f_z"], what="z")
+    _close(r["attn"], z["f_attn"], what="attn")
+    _close(r["out"], z["f_out"], what="out")
+    _close(r["mu_v"], z["f_mu_v"], what="mu_v", rtol=1e-4)
+    L = O.loss(p, c, r, bt["tgt"], img)                    # semantic "B" == as-executed forward
+    _close(L["nll"], z["s_nmt_loss"], what="nll", rtol=1e-5)
+    _close(L["kl_before"], z["s_td_kl_before"], what="kl")
+    _close(L["kl_after"], z["s_td_kl_after"], what="kl_after")
+    _close(L["img_logprob"], z["s_image_feats_loss"], what="img logprob (H1 as executed)", rtol=1e-6)
+    _close(L["img_cos"], z["s_image_feats_cos"], what="cos", rtol=1e-4, atol=1e-6)
+    _close(L["elbo"], z["s_elbo_loss"], what="elbo", rtol=1e-5)
+    assert L["n_words"] == int(z["s_n_words"])
+    assert L["n_correct"] == int(z["s_n_correct"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gradients_and_adam_step(name):
+    """Reference training path (sharded loss, loss/B backward) == oracle autograd, image term semantic 'A'
+    (the only one torch>=0.4 can differentiate in the reference, H1), then one clipped Adam step."""
+    c, p, bt, z, (B, S, T) = load(name)
+    img = bt["table"][bt["indices"]]
+    r, L, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], img_semantic="A")
+    _close(L["elbo"], z["t_elbo"], what="elbo(A)", rtol=1e-5)
+    ref_keys = [k[2:] for k in z.files if k.startswith("g_")] + [k[6:] for k in z.files if k.startswith("big_g_")]
+    assert sorted(ref_keys) == sorted(g.keys())
+    assert not any("inf_net_image.scale" in k for k in g)          # H6
+    for k in g:
+        if "g_" + k in z.files:
+            _close(g[k], z["g_" + k], what="grad " + k, rtol=2e-4, atol=1e-7)
+        else:
+            sub, s1, s2 = O.sample_big(g[k])
+            _close(sub, z["big_g_" + k], what="grad(sample) " + k, rtol=2e-4, atol=1e-7)
+            _close(s2, z["bigsum_g_" + k][1], what="grad sumsq " + k, rtol=1e-3)
+    new, norm = O.clip_and_adam(p, g, {}, lr=0.002, max_grad_norm=5.0)
+    for k in new:
+        if "p1_" + k in z.files:
+            _close(new[k], z["p1_" + k], what="adam " + k, rtol=1e-5, atol=2e-6)
+        elif "big_p1_" + k in z.files:
+            _close(O.sample_big(new[k])[0], z["big_p1_" + k], what="adam(sample) " + k, rtol=1e-5, atol=2e-6)
+
+
+def test_fp64_matches_fp32():
+    c, p, bt, z, _ = load("tiny_bi_l2", torch.float64)
+    img = bt["table"][bt["indices"]]
+    r = O.forward(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
+    L = O.loss(p, c, r, bt["tgt"], img)
+    _close(L["elbo"], z["s_elbo_loss"], what="elbo", rtol=1e-5)
