@@ -1,0 +1,199 @@
+/* vmmt.h -- C-ABI of libvmmt.so: hand-written HIP kernels (gfx950 / MI355X) for ONE hot path of
+ * iacercalixto/variational_mmt: the VI_Model1 training step
+ *   (onmt/TrainerMultimodal.py:625-718 -> onmt/Models.py:850-1011 -> onmt/VILoss.py:217-513 -> onmt/Optim.py:78-96).
+ *
+ * The reference is pure Python on torch 0.3.1 and has no FFI of its own; the device work it gets from torch
+ * (cuDNN LSTM, cuBLAS addmm/bmm, embedding gather/scatter, softmax, NLL, Adam) is what
+ * these entry points replace.  Each entry point cites the reference lines whose arithmetic it performs.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every buffer is CALLER-OWNED device memory (e.g. a PyTorch-ROCm tensor's
+ *     data_ptr()); nothing is allocated, freed or synchronised inside; launches are asynchronous on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream) and are hipGraph-capturable.
+ *   - return value: 0 = VMMT_OK, 1 = invalid argument, 2 = launch failure (hipGetLastError).
+ *   - `dtype` selects the storage/compute type "T" of activations and weight shadows:
+ *       VMMT_F32  : fp32 storage, v_mfma_f32_32x32x2_f32 (exact fp32; parity mode)
+ *       VMMT_BF16 : bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 accumulate (throughput mode)
+ *     Buffers documented as "T" hold that type; "f32" buffers are always float.
+ *   - leading dimensions (ld*) are in ELEMENTS.  Any value is accepted; rows that start 16-byte aligned take the
+ *     vector path, others a scalar path.
+ *   - thread-compatible: no global state.
+ */
+#ifndef VMMT_H
+#define VMMT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMMT_F32 0
+#define VMMT_BF16 1
+
+#define VMMT_ACT_NONE 0
+#define VMMT_ACT_RELU 1
+#define VMMT_ACT_TANH 2
+#define VMMT_ACT_SOFTPLUS 3 /* nn.Softplus(beta=1, threshold=20): NormalVariationalEncoder.py:42 */
+#define VMMT_ACT_SIGMOID 4
+
+#define VMMT_GEMM_NT 0 /* A[M][K] k-contiguous, B[N][K] k-contiguous   : y = x W^T (nn.Linear forward)        */
+#define VMMT_GEMM_TN 1 /* A stored [K][M], B stored [K][N]             : dW = dY^T X (reduction over tokens)   */
+#define VMMT_GEMM_NN 2 /* A[M][K] k-contiguous, B stored [K][N]        : dx = dY W                              */
+
+int vmmt_version(void);
+
+/* ---- generic fused GEMM --------------------------------------------------------------------------------------
+ * C[m][n] (+)= act(alpha * sum_k A(m,k) B(n,k) + addend(m,n)).
+ * Replaces every nn.Linear / addmm on the path: LSTM input projections (Models.py:124-129, VI_Model1.py:149-152),
+ * attention linear_in / linear_out (GlobalAttention.py:106-110,187-190), LocationLayer/ScaleLayer fc1/fc2
+ * (NormalVariationalEncoder.py:12-43) and all their backward products.
+ *   addend: add_rows = 1 -> bias row; add_rows = R > 1 -> addend[(m % R)][n] (z W_z^T broadcast over time steps,
+ *           VI_Model1.py:99-100 without the materialised repeat); add_rows = -1 -> addend[m][n].
+ *   a_kmod / b_kmod (K-strided operands only): reduction index taken modulo this (0 = off).
+ *   scatter_ids != NULL: out_f32 must be 1; C row = scatter_ids[m] (int64), atomic add, rows with id == pad_id are
+ *           dropped: the embedding-gradient scatter-add with padding_idx (modules/Embeddings.py:118). */
+typedef struct vmmt_gemm_args {
+  int dtype, layout;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  int M, N, K;
+  int a_kmod, b_kmod;
+  const void* addend; int64_t ld_add; int add_rows; int add_is_T;
+  int act; int out_f32; int accumulate; float alpha;
+  const int64_t* scatter_ids; int pad_id;
+  int tile; /* 0 = auto, 64, 128 */
+} vmmt_gemm_args;
+int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
+
+/* ---- LSTM time steps ------------------------------------------------------------------------------------------
+ * One launch per time step (both directions of a bidirectional layer in the same launch).  The input projection
+ * gx = x W_ih^T + b_ih + b_hh of the whole sequence is a vmmt_gemm; a step computes
+ *   gates = gx[t] + h_prev W_hh^T ; i,f,o = sigmoid, g = tanh ; c = f c_prev + i g ; h = o tanh(c)
+ * (torch nn.LSTM, gate order i,f,g,o -- encoder onmt/Models.py:124-129,140-147 incl. pack_padded_sequence
+ * semantics via `lens`; decoder onmt/VI_Model1.py:106,149-152 with lens = NULL).
+ * Column layout of gx / gates / dgates: gate-major, g*H + u (== torch's weight row order). */
+typedef struct vmmt_lstm_dir_fwd {
+  const void* h_prev; int64_t ld_hprev;  /* T   [B][ld]  state entering the step                               */
+  const void* c_prev; int64_t ld_cprev;  /* f32 [B][ld]  (NULL = zeros)                                         */
+  const void* w_hh;   int64_t ld_w;      /* T   [4H][ld] recurrent weight, k contiguous                         */
+  const void* gx;     int64_t ld_gx;     /* f32 [B][ld]  row block of step t                                    */
+  void* gates;        int64_t ld_gates;  /* T   [B][ld]  out: post-activation i,f,g,o (saved for backward)      */
+  void* c_out;        int64_t ld_c;      /* f32 [B][ld]  out: cell state (frozen at padded positions)           */
+  void* h_out;        int64_t ld_h;      /* T   [B][ld]  out: h (zero at padded positions)                      */
+  void* h_n;          int64_t ld_hn;     /* T   [B][ld]  out (optional): final state, see `capture`             */
+  void* c_n;          int64_t ld_cn;     /* f32 [B][ld]                                                         */
+  int t;                                 /* time index (compared with lens[b])                                  */
+  int capture;                           /* 0 none; 1 if t == lens[b]-1; 2 if t == 0; 3 always                  */
+} vmmt_lstm_dir_fwd;
+int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* dirs, const int64_t* lens, int B, int H,
+                       void* stream);
+
+/* backward of one step (autograd of the above).  mode 0: dh = dgates_next W_hh + dh_above (+ dh_n when injected);
+ * writes dgates_out (gate pre-activation gradients, T) and updates dc_carry in place.  mode 1: only
+ * dh0_out = dgates_next W_hh (gradient of the initial hidden state). */
+typedef struct vmmt_lstm_dir_bwd {
+  const void* dgates_next; int64_t ld_dgn; /* T [B][ld] of the step processed just before (NULL = none)         */
+  const void* w_hh_t;      int64_t ld_wt;  /* T [H][ld]: W_hh transposed (k = gate row index contiguous)         */
+  const void* dh_above;    int64_t ld_dha; /* T [B][ld] or NULL                                                  */
+  const void* gates;       int64_t ld_gates;
+  const void* c_t;         int64_t ld_ct;  /* f32 */
+  const void* c_prev;      int64_t ld_cp;  /* f32, NULL = zeros */
+  void* dc_carry;          int64_t ld_dcc; /* f32 in/out */
+  void* dgates_out;        int64_t ld_dgo; /* T */
+  const void* dh_n;        int64_t ld_dhn; /* f32 or NULL: gradient of the captured final h */
+  const void* dc_n;        int64_t ld_dcn; /* f32 */
+  void* dh0_out;           int64_t ld_dh0; /* f32, mode 1 */
+  int t;
+  int inject;                              /* 0 none; 1 if t == lens[b]-1; 2 if t == 0; 3 always */
+} vmmt_lstm_dir_bwd;
+int vmmt_lstm_step_bwd(int dtype, int ndir, const vmmt_lstm_dir_bwd* dirs, const int64_t* lens, int B, int H,
+                       int mode, void* stream);
+
+/* ---- statistics vector (f32[VMMT_STAT_COUNT], device memory, zeroed by the caller before each step) ------------
+ * sums that VIStatistics needs (onmt/TrainerMultimodal.py:32-228, filled at onmt/VILoss.py:483-497). */
+#define VMMT_STAT_NLL 0          /* sum of token NLL over non-pad targets                                       */
+#define VMMT_STAT_NWORDS 1       /* number of non-pad targets                                                    */
+#define VMMT_STAT_NCORRECT 2     /* argmax == target, non-pad                                                    */
+#define VMMT_STAT_KL_SUM 3       /* sum_b KL(q(z|x_b) || p(z))  (batch mean = / B)                               */
+#define VMMT_STAT_IMG_LOGPROB 4  /* image log-prob as executed (H1): sum over batch of the per-sentence mean over D */
+#define VMMT_STAT_IMG_COS 5      /* sum_b cosine(mu_v_b, v_b)   (reported value = / B)                           */
+#define VMMT_STAT_GRAD_SUMSQ 6   /* ||g||^2 (written by vmmt_sumsq when pointed here)                            */
+#define VMMT_STAT_COUNT 8
+
+/* ---- attention ("general" Luong), one workgroup per sentence, source memory staged in LDS --------------------
+ * forward: onmt/modules/GlobalAttention.py:113 (bmm), :171-176 (mask), :179-180 (softmax), :184 (bmm).
+ *   q    T [Tp*B][ldq]   rows t*B+b: W_a r (linear_in already applied by vmmt_gemm)
+ *   ctx  T [S*B][ldc]    rows s*B+b: encoder memory ; lens int64 [B]
+ *   cat  T [Tp*B][ldcat] out: context vectors, columns [0,H) of the [c ; r] concat buffer (GlobalAttention.py:187)
+ *   probs f32 [Tp][B][S] out: attention distributions (attns["std"])
+ * limits: S <= 64, H <= 1024. */
+int vmmt_attn_fwd(int dtype, const void* q, int64_t ldq, const void* ctx, int64_t ldc, const int64_t* lens, void* cat,
+                  int64_t ldcat, float* probs, int Tp, int B, int S, int H, void* stream);
+/* backward: dcat columns [0,H) hold dL/dc; writes dq (T [Tp*B][lddq]) and dctx (T [S*B][lddx], zero at pads). */
+int vmmt_attn_bwd(int dtype, const void* dcat, int64_t lddc, const float* probs, const void* q, int64_t ldq,
+                  const void* ctx, int64_t ldc, const int64_t* lens, void* dq, int64_t lddq, void* dctx, int64_t lddx,
+                  int Tp, int B, int S, int H, void* stream);
+/* hbar[b] = mean_{s<len_b} ctx[s][b]  (GlobalInferenceNetwork.encode_seq, modules/NormalVariationalEncoder.py:65-84) */
+int vmmt_masked_mean(int dtype, const void* ctx, int64_t ldc, const int64_t* lens, void* out, int64_t ldo, int B, int S,
+                     int H, void* stream);
+
+/* ---- fused vocabulary projection + log-softmax + NLL ------------------------------------------------------------
+ * generator Linear(H,V)+LogSoftmax (onmt/ModelConstructor.py:583-585), NLLLoss(weight[pad]=0, sum)
+ * (onmt/Loss.py:163-165), accuracy (onmt/VILoss.py:515-531).  Logits are never written to memory in the forward.
+ *   W T [V][ldw], bias f32 [V], O T [M][ldo] (M = Tp*B rows t*B+b), y int64 [M] = tgt[1:]
+ *   workspaces: part_max/part_sum f32 [vmmt_gen_npart(V)][M], part_idx int32 same, tgt_logit f32 [M]
+ *   out: lse f32 [M], tok_nll f32 [M]; stats[NLL,NWORDS,NCORRECT] += sums. */
+int vmmt_gen_npart(int V);
+int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
+                      const int64_t* y, int M, int V, int K, int pad, float* part_max, float* part_sum, int* part_idx,
+                      float* tgt_logit, float* lse, float* tok_nll, float* stats, void* stream);
+/* backward seed: GT[v][m] = (exp(logit - lse[m]) - [v == y_m]) * (y_m != pad) * inv_norm   (T [V][ldgt], ldgt >= M).
+ * The weight / input gradients are then vmmt_gemm calls: dWg = GT O (NN), dO = GT^T Wg (TN). */
+int vmmt_gen_loss_bwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
+                      const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm, void* GT,
+                      int64_t ldgt, void* stream);
+
+/* ---- row gathers / small fused kernels -------------------------------------------------------------------------- */
+/* out[r][0:D] = table[ids[r]][0:D]; table f32 (embedding master weights: modules/Embeddings.py:181; or the HBM-resident
+ * image-feature table: TrainerMultimodal.py:632-639), out f32 or bf16 per out_dtype. */
+int vmmt_gather_rows(int out_dtype, const float* table, int64_t ldt, const int64_t* ids, void* out, int64_t ldo, int R,
+                     int D, void* stream);
+/* out[c] += sum_r X[r][c]  (bias gradients) */
+int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream);
+/* scaled dropout mask: 1/(1-p) with prob 1-p else 0 (counter-based RNG; VI_Model1.py:132, Models.py:124-129) */
+int vmmt_dropout_mask(int dtype, void* mask, int64_t n, float p, uint64_t seed, void* stream);
+int vmmt_randn(float* out, int64_t n, uint64_t seed, void* stream);
+int vmmt_mul(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int R, int C,
+             void* stream);
+/* out = dy * mask * act'(y) with act' expressed through the activation output y (mask / y may be NULL) */
+int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* mask,
+                 int64_t ldm, void* out, int64_t ldo, int R, int C, void* stream);
+/* fused mu/sigma -> sample -> KL: z = mu + sigma*eps (training) | mu (eval)  (Models.py:933, Dists.py:21-26, H2);
+ * kl_b[b] = sum_k 0.5(mu^2+sigma^2-1) - log sigma (VILoss.py:446-456); stats[KL_SUM] += sum_b kl_b. */
+int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT, int64_t ldz,
+                    float* kl_b, float* stats, int B, int Z, int training, void* stream);
+/* d/d(mu, pre-softplus scale) of max(mult * KL_mean, margin) * inv_norm  (VILoss.py:460-473, Loss.py:129) */
+int vmmt_latent_bwd(int dtype, const float* mu, const float* sigma, const float* kl_sum, float batch_global, float mult,
+                    int use_freebits, float margin, float inv_norm, void* dmu, int64_t ld1, void* dpre, int64_t ld2, int B,
+                    int Z, void* stream);
+/* image-network gate (modules/NormalVariationalEncoder.py:286-293) */
+int vmmt_gate_fwd(int dtype, const float* z, const float* w, const float* bias, float* g, void* zt, int64_t ldzt, int B,
+                  int Z, void* stream);
+int vmmt_gate_bwd(const float* dzt, int64_t ldd, const float* z, const float* g, float* dw, float* db, int B, int Z,
+                  void* stream);
+/* image term of the ELBO as executed (H1: VILoss.py:39-44,321-331,408-415) + its gradient w.r.t. mu_v (dmu may be NULL) */
+int vmmt_image_loss(int dtype, const float* mu_v, int64_t ldm, const float* img, int64_t ldi, int B, int D, float inv_norm,
+                    void* dmu, int64_t ldd, float* stats, void* stream);
+/* fp32 master weight [R][C] -> compute shadow T (optionally transposed; src2 optional second addend, e.g. b_ih + b_hh) */
+int vmmt_pack(int dtype, const float* src, const float* src2, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C,
+              int transpose, void* stream);
+
+/* ---- optimiser: clip_grad_norm + Adam over a flat fp32 arena (onmt/Optim.py:68-70,94-96) -------------------------- */
+int vmmt_sumsq(const float* g, int64_t n, float* out /* += */, void* stream);
+int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   int step, float max_norm, const float* sumsq, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

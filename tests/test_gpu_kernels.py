@@ -1,0 +1,145 @@
+"""GPU tests (MI355X): individual libvmmt kernels through the C-ABI vs plain fp32/fp64 torch-CPU math."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from variational_mmt_amd import _lib as L
+    return L, L.lib()
+
+
+def _dev(t, dt):
+    return t.to(device="cuda", dtype=dt).contiguous()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("layout", ["NT", "TN", "NN"])
+@pytest.mark.parametrize("shape", [(70, 45, 33, 0), (130, 257, 100, 128), (64, 64, 64, 64), (5, 500, 2048, 0), (300, 1, 77, 64)])
+def test_gemm_layouts(dtype, layout, shape):
+    L, lib = _lib()
+    M, N, K, tile = shape
+    torch.manual_seed(M * 7 + N * 3 + K)
+    T = torch.float32 if dtype == "f32" else torch.bfloat16
+    code = L.F32 if dtype == "f32" else L.BF16
+    a = (torch.randn(M, K) * 0.5).to(T)
+    b = (torch.randn(N, K) * 0.5).to(T)
+    ref = a.double() @ b.double().t()
+    ld_pad = 8
+    if layout == "NT":
+        A = torch.zeros(M, K + ld_pad, dtype=T); A[:, :K] = a
+        Bm = torch.zeros(N, K + ld_pad, dtype=T); Bm[:, :K] = b
+        lay = L.GEMM_NT
+    elif layout == "TN":
+        A = torch.zeros(K, M + ld_pad, dtype=T); A[:, :M] = a.t()
+        Bm = torch.zeros(K, N + ld_pad, dtype=T); Bm[:, :N] = b.t()
+        lay = L.GEMM_TN
+    else:
+        A = torch.zeros(M, K + ld_pad, dtype=T); A[:, :K] = a
+        Bm = torch.zeros(K, N + ld_pad, dtype=T); Bm[:, :N] = b.t()
+        lay = L.GEMM_NN
+    Ad, Bd = A.cuda(), Bm.cuda()
+    Cd = torch.full((M, N + 3), 7.0, dtype=torch.float32, device="cuda")
+    bias = torch.randn(N)
+    biasd = bias.cuda()
+    args = L.GemmArgs(code, lay, Ad.data_ptr(), Ad.stride(0), Bd.data_ptr(), Bd.stride(0), Cd.data_ptr(), Cd.stride(0), M, N, K,
+                      0, 0, biasd.data_ptr(), N, 1, 0, L.ACT_NONE, 1, 0, 1.0, None, 1, tile)
+    L.check(lib.vmmt_gemm(C.byref(args), None), "gemm")
+    torch.cuda.synchronize()
+    out = Cd.cpu()
+    assert torch.all(out[:, N:] == 7.0), "wrote outside the valid columns"
+    want = ref + bias.double()
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    err = (out[:, :N].double() - want).abs().max().item()
+    assert err <= tol * max(1.0, want.abs().max().item()), err
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gemm_epilogues(dtype):
+    L, lib = _lib()
+    T = torch.float32 if dtype == "f32" else torch.bfloat16
+    code = L.F32 if dtype == "f32" else L.BF16
+    torch.manual_seed(3)
+    M, N, K, R = 96, 80, 48, 12
+    a, b = (torch.randn(M, K) * 0.3).to(T), (torch.randn(N, K) * 0.3).to(T)
+    add = torch.randn(R, N)
+    ref = a.double() @ b.double().t() + add.double()[torch.arange(M) % R]
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    for act, fn in ((L.ACT_RELU, torch.relu), (L.ACT_TANH, torch.tanh), (L.ACT_SOFTPLUS, torch.nn.functional.softplus),
+                    (L.ACT_SIGMOID, torch.sigmoid)):
+        Ad, Bd, addd = a.cuda(), b.cuda(), add.cuda()
+        Cd = torch.zeros(M, N, dtype=T, device="cuda")
+        args = L.GemmArgs(code, L.GEMM_NT, Ad.data_ptr(), K, Bd.data_ptr(), K, Cd.data_ptr(), N, M, N, K, 0, 0, addd.data_ptr(), N, R,
+                          0, act, 0, 0, 1.0, None, 1, 0)
+        L.check(lib.vmmt_gemm(C.byref(args), None), "gemm")
+        err = (Cd.cpu().double() - fn(ref)).abs().max().item()
+        assert err <= tol * 3, (act, err)
+    # scatter-add epilogue (embedding gradient) with padding rows dropped
+    ids = torch.randint(0, 10, (M,))
+    ids[::7] = 1
+    table = torch.zeros(10, N, dtype=torch.float32, device="cuda")
+    Ad, Bd, idd = a.cuda(), b.cuda(), ids.cuda()
+    args = L.GemmArgs(code, L.GEMM_NT, Ad.data_ptr(), K, Bd.data_ptr(), K, table.data_ptr(), N, M, N, K, 0, 0, None, 0, 0, 0, 0, 1, 0, 1.0,
+                      idd.data_ptr(), 1, 0)
+    L.check(lib.vmmt_gemm(C.byref(args), None), "gemm")
+    want = torch.zeros(10, N, dtype=torch.float64)
+    prod = a.double() @ b.double().t()
+    for m in range(M):
+        if ids[m] != 1:
+            want[ids[m]] += prod[m]
+    assert (table.cpu().double() - want).abs().max().item() <= tol * 5
+
+
+def test_adam_and_sumsq():
+    L, lib = _lib()
+    torch.manual_seed(0)
+    n = 100003
+    p, g = torch.randn(n), torch.randn(n) * 3
+    m, v = torch.rand(n) * 0.1, torch.rand(n) * 0.01
+    pd, gd, md, vd = [x.clone().cuda() for x in (p, g, m, v)]
+    # arena pointers must be 16-byte aligned: torch allocations are
+    ss = torch.zeros(4, device="cuda")
+    L.check(lib.vmmt_sumsq(gd.data_ptr(), n, ss.data_ptr(), None), "sumsq")
+    tot = float((g.double() ** 2).sum())
+    assert abs(ss[0].item() - tot) <= 1e-4 * tot
+    L.check(lib.vmmt_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 0.002, 0.9, 0.999, 1e-9, 3, 5.0,
+                               ss.data_ptr(), 1.0, None), "adam")
+    coef = min(1.0, 5.0 / (tot ** 0.5 + 1e-6))
+    gg = g.double() * coef
+    m2 = 0.9 * m.double() + 0.1 * gg
+    v2 = 0.999 * v.double() + 0.001 * gg * gg
+    p2 = p.double() - 0.002 / (1 - 0.9 ** 3) * m2 / (v2.sqrt() / (1 - 0.999 ** 3) ** 0.5 + 1e-9)
+    assert (pd.cpu().double() - p2).abs().max().item() < 1e-5
+    assert (md.cpu().double() - m2).abs().max().item() < 1e-6
+    assert (vd.cpu().double() - v2).abs().max().item() < 1e-6
+
+
+def test_gather_rows_and_image_loss():
+    L, lib = _lib()
+    torch.manual_seed(1)
+    N, D, B = 50, 2048, 9
+    table = torch.rand(N, D)
+    idx = torch.randint(0, N, (B,))
+    td, idd = table.cuda(), idx.cuda()
+    out = torch.zeros(B, D, device="cuda")
+    L.check(lib.vmmt_gather_rows(L.F32, td.data_ptr(), D, idd.data_ptr(), out.data_ptr(), D, B, D, None), "gather")
+    assert torch.equal(out.cpu(), table[idx])
+    mu = torch.randn(B, D)
+    stats = torch.zeros(8, device="cuda")
+    dmu = torch.zeros(B, D, device="cuda")
+    mud = mu.cuda()
+    L.check(lib.vmmt_image_loss(L.F32, mud.data_ptr(), D, out.data_ptr(), D, B, D, 1.0 / B, dmu.data_ptr(), D, stats.data_ptr(), None), "img")
+    muq = mu.double().requires_grad_(True)
+    v = table[idx].double()
+    a = muq / muq.pow(2).sum(1, keepdim=True).sqrt()
+    vh = v / v.pow(2).sum(1, keepdim=True).sqrt()
+    import math
+    logp = (-0.5 * (vh - a) ** 2 - 0.5 * math.log(2 * math.pi)).sum(0).mean(0)
+    (-logp / B).backward()
+    s = stats.cpu()
+    assert abs(s[L.STAT_IMG_LOGPROB].item() - logp.item()) < 1e-4
+    assert abs(s[L.STAT_IMG_COS].item() - (a * vh).sum(1).sum().item()) < 1e-4
+    assert (dmu.cpu().double() - muq.grad).abs().max().item() < 1e-9 + 1e-4 * muq.grad.abs().max().item()

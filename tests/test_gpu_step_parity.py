@@ -1,0 +1,133 @@
+"""GPU parity tests proper: the HIP training step (through the C-ABI, driven by variational_mmt_amd.engine) against the
+CPU oracle on the committed golden inputs, and against the golden outputs of the real reference.
+
+Tolerances (stated per north_star):
+  fp32 mode (v_mfma_f32_32x32x2_f32, exact fp32 products, different summation order than the CPU):
+      ELBO / NLL / KL rel 2e-5, activations abs 2e-5, gradients 2e-4 of the tensor's max.
+  bf16 mode (bf16 storage + MFMA inputs, fp32 accumulate): ELBO / NLL rel 5e-3, KL rel 2e-2, activations abs 3e-2,
+      gradients 6e-2 of the tensor's max (bf16 has 8 significant bits; the error compounds through the 2x20 LSTM steps).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vi1_oracle as O
+from tests.golden_util import CASES, load
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": dict(act=2e-5, loss=2e-5, kl=2e-5, grad=2e-4, adam=2e-5),
+       "bf16": dict(act=3e-2, loss=5e-3, kl=2e-2, grad=6e-2, adam=2.1e-3)}
+
+
+def _engine(c, p, dtype, dropout=0.0):
+    from variational_mmt_amd.engine import Dims, Engine
+    d = Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, dropout)
+    e = Engine(d, dtype=dtype, device="cuda", seed=1)
+    e.load_state_dict(p)
+    return e
+
+
+def _cmp(name, got, want, tol, rel_to_max=True):
+    got, want = torch.as_tensor(got).detach().cpu().double(), torch.as_tensor(want).detach().cpu().double()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = max(want.abs().max().item(), 1e-30) if rel_to_max else 1.0
+    err = (got - want).abs().max().item()
+    assert err <= tol * max(scale, 1e-6) + 1e-12, "%s: max err %.3e (scale %.3e, tol %.1e)" % (name, err, scale, tol)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", CASES)
+def test_step_matches_oracle_and_reference(name, dtype):
+    c, p, bt, z, (B, S, T) = load(name)
+    tol = TOL[dtype]
+    e = _engine(c, p, dtype)
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+    torch.cuda.synchronize()
+    img = bt["table"][bt["indices"]]
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], img_semantic="B")
+    H, Tp = c.hid, T - 1
+    _cmp("context", ws.enc_out[-1].view().float().view(S, B, H), r["context"], tol["act"], False)
+    _cmp("mu", ws.mu.view(), r["mu"], tol["act"], False)
+    _cmp("sigma", ws.sigma.view(), r["sigma"], tol["act"], False)
+    _cmp("z", ws.z32.view(), r["z"], tol["act"] * 3, False)
+    _cmp("rnn_out", ws.cat.view()[:, H:].float().reshape(Tp, B, H), r["rnn_out"], tol["act"], False)
+    _cmp("attn", ws.probs.view(Tp, B, S), r["attn"], tol["act"], False)
+    _cmp("attn_h", ws.AH.view().float().view(Tp, B, H), r["attn_h"], tol["act"], False)
+    _cmp("mu_v", ws.mu_v.view(), r["mu_v"], tol["act"] * 4, False)
+    # also against the real reference's forward values
+    _cmp("ref out", ws.AH.view().float().view(Tp, B, H), z["f_out"], tol["act"], False)
+    _cmp("ref attn", ws.probs.view(Tp, B, S), z["f_attn"], tol["act"], False)
+    e.loss_backward(ws, normalization=B)
+    torch.cuda.synchronize()
+    st = e.read_stats(ws)
+    assert abs(st["nmt"] - float(Lo["nll"])) <= tol["loss"] * abs(float(Lo["nll"]))
+    assert abs(st["td_kl_before"] - float(Lo["kl_before"])) <= tol["kl"] * abs(float(Lo["kl_before"]))
+    assert abs(st["elbo"] - float(Lo["elbo"])) <= tol["loss"] * abs(float(Lo["elbo"]))
+    assert abs(st["img_feats_loss"] - float(Lo["img_logprob"])) <= 1e-4 * abs(float(Lo["img_logprob"]))
+    _cmp("tok_nll", ws.tok_nll.view(Tp, B), Lo["tok_nll"], tol["loss"] * 2 if dtype == "f32" else 5e-2, False)
+    # golden (real reference) statistics
+    assert abs(st["nmt"] - float(z["s_nmt_loss"])) <= tol["loss"] * abs(float(z["s_nmt_loss"]))
+    assert abs(st["elbo"] - float(z["s_elbo_loss"])) <= tol["loss"] * abs(float(z["s_elbo_loss"]))
+    assert abs(st["td_kl_before"] - float(z["s_td_kl_before"])) <= tol["kl"] * abs(float(z["s_td_kl_before"]))
+    assert abs(st["img_feats_loss"] - float(z["s_image_feats_loss"])) <= 1e-4 * abs(float(z["s_image_feats_loss"]))
+    assert st["n_words"] == int(z["s_n_words"])
+    if dtype == "f32":
+        assert st["n_correct"] == int(z["s_n_correct"])
+    # gradients (every parameter; H6: the dead scale branch has none)
+    assert sorted(g.keys()) == sorted(e.grads.keys())
+    bad = []
+    for k in g:
+        got, want = e.grads[k].detach().cpu().double(), g[k].double()
+        scale = max(want.abs().max().item(), 1e-12)
+        err = (got - want).abs().max().item()
+        if err > tol["grad"] * scale + 1e-9:
+            bad.append((k, err, scale))
+    assert not bad, bad
+    # gradients of the text path also against the real reference (image-net grads differ by design: H1 semantic A vs B)
+    for k in g:
+        if "inf_net_image" in k or ("g_" + k) not in z.files:
+            continue
+        _cmp("ref grad " + k, e.grads[k], z["g_" + k], tol["grad"])
+    # one clipped Adam step
+    new, _ = O.clip_and_adam(p, g, {}, lr=0.002, max_grad_norm=5.0)
+    e.optim_step(lr=0.002, max_grad_norm=5.0)
+    torch.cuda.synchronize()
+    for k in new:
+        if k in e.grads:
+            _cmp("adam " + k, e.params[k], new[k], tol["adam"], False)
+
+
+@pytest.mark.parametrize("dtype", ["f32"])
+def test_dropout_masks_and_eval_mode(dtype):
+    """dropout 0.5 with the masks the GPU generated injected into the oracle; eval mode uses z = mu."""
+    c, p, bt, z, (B, S, T) = load("tiny_bi_l2")
+    e = _engine(c, p, dtype, dropout=0.5)
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+    e.loss_backward(ws, normalization=B)
+    torch.cuda.synchronize()
+    H, Tp = c.hid, T - 1
+    masks = {"dec_out": ws.out_mask.view().float().cpu().view(Tp, B, H)}
+    for l in range(c.layers - 1):
+        masks["enc_l%d" % l] = ws.enc_mask[l].view().float().cpu().view(S, B, H)
+        masks["dec_l%d" % l] = ws.dec_mask[l].view().float().cpu().view(Tp, B, H)
+    keep = masks["dec_out"].ne(0).float().mean().item()
+    assert 0.3 < keep < 0.7
+    assert set(masks["dec_out"].unique().tolist()) <= {0.0, 2.0}
+    img = bt["table"][bt["indices"]]
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], masks=masks)
+    st = e.read_stats(ws)
+    assert abs(st["elbo"] - float(Lo["elbo"])) <= 2e-5 * abs(float(Lo["elbo"]))
+    for k in g:
+        _cmp("grad " + k, e.grads[k], g[k], 2e-4)
+    # eval: z = mu, no dropout, statistics only
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=False)
+    e.loss(ws)
+    torch.cuda.synchronize()
+    r = O.forward(p, c, bt["src"], bt["src_len"], bt["tgt"], img, None, training=False)
+    Lo = O.loss(p, c, r, bt["tgt"], img)
+    st = e.read_stats(ws)
+    assert abs(st["elbo"] - float(Lo["elbo"])) <= 2e-5 * abs(float(Lo["elbo"]))
+    _cmp("z eval", ws.z32.view(), r["mu"], 2e-5, False)

@@ -1,0 +1,238 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels of the VI_Model1 training step.
+// Wave = 64 lanes.  MFMA shapes used: v_mfma_f32_32x32x16_bf16 (bf16 storage) and
+// v_mfma_f32_32x32x2_f32 (fp32 storage, exact fp32 "parity" mode).  Both share one C/D layout:
+//   col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), reg in [0,16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vmmt {
+
+typedef uint16_t bf16_t;  // raw bf16 storage
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(uint16_t, b);
+}
+template <class T> __device__ __forceinline__ float to_f(T x);
+template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return bf2f(x); }
+template <class T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return f2bf(x); }
+
+template <class T> struct Traits;
+template <> struct Traits<float> {
+  static constexpr int VEC = 4;     // elements per 16-byte vector
+  static constexpr int KSTEP = 2;   // K per MFMA
+  static constexpr int PAD = 4;     // LDS row padding (elements), keeps rows 16-byte aligned
+};
+template <> struct Traits<bf16_t> {
+  static constexpr int VEC = 8;
+  static constexpr int KSTEP = 16;
+  static constexpr int PAD = 8;     // 80-byte rows: ds_read_b128 by 16 consecutive rows is conflict-free
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // accurate enough for fp32 parity (1e-6) and cheap: tanh(x) = 1 - 2/(exp(2x)+1)
+  float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Row maps: translate a tile-local row index into a global row index (or -1 = out of range).
+// ----------------------------------------------------------------------------------------------
+struct LinearMap {   // rows base .. limit-1
+  int base, limit;
+  __device__ __forceinline__ int operator()(int r) const { int g = base + r; return g < limit ? g : -1; }
+};
+struct GateMap {     // LSTM gate rows: local n = g * BU + u  ->  g * H + u0 + u   (g = i,f,g,o)
+  int u0, H, BU;
+  __device__ __forceinline__ int operator()(int r) const {
+    int g = r / BU, u = u0 + (r - g * BU);
+    return u < H ? g * H + u : -1;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// Tile staging: global -> registers (16-byte vectors when aligned and in range, scalar otherwise)
+// -> LDS image [rows][BK + PAD] (k contiguous), whatever the global layout.
+//   KC = true : operand stored [row][k] (k contiguous), element (row,k) at P[row*ld + k]
+//   KC = false: operand stored [k][row] (row contiguous), element (row,k) at P[kmap(k)*ld + row]
+//               (kmod > 0: k index taken modulo kmod -- used to broadcast z over time steps)
+// ----------------------------------------------------------------------------------------------
+template <class T, int ROWS, int BK, int NT, bool KC>
+struct Stager {
+  static constexpr int VEC = Traits<T>::VEC;
+  static constexpr int STRIDE = BK + Traits<T>::PAD;
+  static constexpr int NVEC = ROWS * BK / VEC;
+  static constexpr int PER = (NVEC + NT - 1) / NT;
+  static_assert(ROWS % VEC == 0 && BK % VEC == 0, "tile");
+  T regs[PER][VEC];
+
+  template <class Map>
+  __device__ __forceinline__ void load(const T* __restrict__ P, long ld, const Map& map, int k0, int K, int kmod,
+                                       int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int v = tid + i * NT;
+      if (NVEC % NT != 0 && v >= NVEC) break;
+      if constexpr (KC) {
+        int row = v / (BK / VEC), kk = (v % (BK / VEC)) * VEC;
+        int g = map(row);
+        int k = k0 + kk;
+        const T* src = P + (long)g * ld + k;
+        if (g >= 0 && k + VEC <= K && ((uintptr_t)src & 15) == 0) {
+          *reinterpret_cast<u32x4*>(regs[i]) = *reinterpret_cast<const u32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) regs[i][e] = (g >= 0 && k + e < K) ? src[e] : T(0);
+        }
+      } else {
+        int kk = v / (ROWS / VEC), row = (v % (ROWS / VEC)) * VEC;
+        int k = k0 + kk;
+        int g0 = map(row), g1 = map(row + VEC - 1);
+        long kr = kmod > 0 ? (k % kmod) : k;
+        const T* src = P + kr * ld + g0;
+        if (k < K && g0 >= 0 && g1 == g0 + VEC - 1 && ((uintptr_t)src & 15) == 0) {
+          *reinterpret_cast<u32x4*>(regs[i]) = *reinterpret_cast<const u32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            int ge = map(row + e);
+            regs[i][e] = (k < K && ge >= 0) ? P[kr * ld + ge] : T(0);
+          }
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(T* __restrict__ S, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int v = tid + i * NT;
+      if (NVEC % NT != 0 && v >= NVEC) break;
+      if constexpr (KC) {
+        int row = v / (BK / VEC), kk = (v % (BK / VEC)) * VEC;
+        *reinterpret_cast<u32x4*>(S + row * STRIDE + kk) = *reinterpret_cast<const u32x4*>(regs[i]);
+      } else {
+        int kk = v / (ROWS / VEC), row = (v % (ROWS / VEC)) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) S[(row + e) * STRIDE + kk] = regs[i][e];
+      }
+    }
+  }
+};
+
+// One BK-deep slab of MFMAs for a wave: TI x TJ tiles of 32x32.
+template <class T, int BK, int TI, int TJ>
+__device__ __forceinline__ void mfma_slab(const T* __restrict__ As, const T* __restrict__ Bs, const int (&aoff)[TI],
+                                          const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], int lane) {
+  constexpr int STRIDE = BK + Traits<T>::PAD;
+  const int r = lane & 31, h = lane >> 5;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a[TI], b[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(As + (aoff[i] + r) * STRIDE + ks * 16 + 8 * h);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(Bs + (boff[j] + r) * STRIDE + ks * 16 + 8 * h);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  } else {
+#pragma unroll 4
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float a[TI], b[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a[i] = As[(aoff[i] + r) * STRIDE + ks * 2 + h];
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) b[j] = Bs[(boff[j] + r) * STRIDE + ks * 2 + h];
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
+// Block-level main loop: C_tile += A_tile(BM x K) * B_tile(BN x K)^T, staged through LDS with a register
+// prefetch of the next K slab (global loads for slab k+1 are in flight while slab k is multiplied).
+template <class T, int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, int TI, int TJ, class AMap, class BMap>
+__device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda, const AMap& amap,
+                                              const T* __restrict__ B, long ldb, const BMap& bmap, int K, int a_kmod,
+                                              int b_kmod, const int (&aoff)[TI], const int (&boff)[TJ],
+                                              f32x16 (&acc)[TI][TJ], T* __restrict__ smem) {
+  constexpr int STRIDE = BK + Traits<T>::PAD;
+  T* As = smem;
+  T* Bs = smem + BM * STRIDE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  Stager<T, BM, BK, NT, A_KC> sa;
+  Stager<T, BN, BK, NT, B_KC> sb;
+  if (K <= 0) return;
+  sa.load(A, lda, amap, 0, K, a_kmod, tid);
+  sb.load(B, ldb, bmap, 0, K, b_kmod, tid);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+    __syncthreads();
+    if (k0 + BK < K) {
+      sa.load(A, lda, amap, k0 + BK, K, a_kmod, tid);
+      sb.load(B, ldb, bmap, k0 + BK, K, b_kmod, tid);
+    }
+    mfma_slab<T, BK, TI, TJ>(As, Bs, aoff, boff, acc, lane);
+    __syncthreads();
+  }
+}
+
+template <class T, int BM, int BN, int BK>
+constexpr int gemm_smem_elems() { return (BM + BN) * (BK + Traits<T>::PAD); }
+
+// accumulator element -> (row, col) inside a 32x32 tile
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
+
+// counter-based RNG (for dropout masks and eps): 32-bit mix of (seed, index)
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t rng32(uint64_t seed, uint64_t idx) {
+  uint32_t a = hash32((uint32_t)idx ^ (uint32_t)seed);
+  uint32_t b = hash32((uint32_t)(idx >> 32) + 0x9e3779b9U + (uint32_t)(seed >> 32) + a);
+  return hash32(a ^ (b * 0x85ebca6bU));
+}
+__device__ __forceinline__ float u01(uint32_t r) { return ((r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+#define VMMT_OK 0
+#define VMMT_EINVAL 1
+#define VMMT_ELAUNCH 2
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VMMT_OK : VMMT_ELAUNCH;
+}
+
+}  // namespace vmmt

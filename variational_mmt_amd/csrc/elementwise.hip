@@ -1,0 +1,335 @@
+// Small HBM-bound kernels of the VI_Model1 step: row gathers (embedding lookup, image-feature rows), column sums
+// (bias gradients), dropout masks, activation backward, the fused mu/sigma -> sample -> KL kernel, the image-network
+// gate and the (as-executed, H1) image term of the ELBO.
+#include "common.hpp"
+#include "vmmt.h"
+
+namespace vmmt {
+
+// out[r][:] = table[ids[r]][:]   (one wave per row: 16-byte loads, fully coalesced 8 KB image rows / 2 KB embedding rows)
+// Embedding lookup: onmt/modules/Embeddings.py:181; image rows: onmt/TrainerMultimodal.py:632-639 (host fancy-index + H2D
+// in the reference; here the table stays resident in HBM).
+template <class TO>
+__global__ void gather_rows_kernel(const float* __restrict__ table, long ldt, const long long* __restrict__ ids,
+                                   TO* __restrict__ out, long ldo, int R, int D) {
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= R) return;
+  const float* src = table + ids[wave] * ldt;
+  TO* dst = out + (long)wave * ldo;
+  bool vec = ((((uintptr_t)src) & 15) == 0) && (D % 4 == 0);
+  if (vec) {
+    for (int c = lane * 4; c < D; c += 256) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[c + e] = from_f<TO>(v[e]);
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) dst[c] = from_f<TO>(src[c]);
+  }
+}
+
+// out[c] += sum_r X[r][c]   (bias gradients; out must be pre-zeroed or hold a partial sum)
+template <class T>
+__global__ void colsum_kernel(const T* __restrict__ X, long ld, int R, int C, float* __restrict__ out, int rows_per_block) {
+  int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  int w = threadIdx.x >> 6;
+  int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float a = 0.f;
+  if (c < C)
+    for (int r = r0 + w; r < r1; r += 4) a += to_f<T>(X[(long)r * ld + c]);
+  __shared__ float red[4][64];
+  red[w][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (w == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <class T>
+__global__ void dropout_mask_kernel(T* __restrict__ mask, long n, float p, unsigned long long seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float u = u01(rng32(seed, (unsigned long long)i));
+  mask[i] = from_f<T>(u >= p ? 1.f / (1.f - p) : 0.f);
+}
+
+__global__ void randn_kernel(float* __restrict__ out, long n, unsigned long long seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float u1 = u01(rng32(seed, 2ull * i)), u2 = u01(rng32(seed, 2ull * i + 1));
+  out[i] = sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+}
+
+// out = a * b (2-D with leading dimensions; mask multiply for dropout)
+template <class T>
+__global__ void mul_kernel(const T* __restrict__ a, long lda, const T* __restrict__ b, long ldb, T* __restrict__ out,
+                           long ldo, int R, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * C) return;
+  int r = i / C, c = i - (long)r * C;
+  out[(long)r * ldo + c] = from_f<T>(to_f<T>(a[(long)r * lda + c]) * to_f<T>(b[(long)r * ldb + c]));
+}
+
+// out = dy * mask * act'(y), with act' expressed through the activation OUTPUT y
+template <class T>
+__global__ void act_bwd_kernel(int act, const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
+                               const T* __restrict__ mask, long ldm, T* __restrict__ out, long ldo, int R, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * C) return;
+  int r = i / C, c = i - (long)r * C;
+  float g = to_f<T>(dy[(long)r * lddy + c]);
+  if (mask) g *= to_f<T>(mask[(long)r * ldm + c]);
+  float yy = y ? to_f<T>(y[(long)r * ldy + c]) : 0.f;
+  switch (act) {
+    case VMMT_ACT_RELU: g = yy > 0.f ? g : 0.f; break;
+    case VMMT_ACT_TANH: g *= 1.f - yy * yy; break;
+    case VMMT_ACT_SOFTPLUS: g *= 1.f - __expf(-yy); break;
+    case VMMT_ACT_SIGMOID: g *= yy * (1.f - yy); break;
+    default: break;
+  }
+  out[(long)r * ldo + c] = from_f<T>(g);
+}
+
+// ---- fused mu/sigma -> sample -> KL -------------------------------------------------------------------------
+// z = mu + sigma * eps (training; detached, H2) or mu (eval)          onmt/Models.py:933, modules/Dists.py:21-26
+// KL_b = sum_k 0.5 (mu^2 + sigma^2 - 1) - log sigma  (prior N(0,1))     onmt/VILoss.py:446-456
+template <class T>
+__global__ void latent_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma,
+                                  const float* __restrict__ eps, float* __restrict__ z32, T* __restrict__ zT, long ldz,
+                                  float* __restrict__ kl_b, float* __restrict__ stats, int B, int Z, int training) {
+  int b = blockIdx.x;
+  float kl = 0.f;
+  for (int k = threadIdx.x; k < Z; k += blockDim.x) {
+    float m = mu[(long)b * Z + k], s = sigma[(long)b * Z + k];
+    float z = training ? m + s * eps[(long)b * Z + k] : m;
+    z32[(long)b * Z + k] = z;
+    zT[(long)b * ldz + k] = from_f<T>(z);
+    kl += 0.5f * (m * m + s * s - 1.f) - logf(s);
+  }
+  kl = wave_sum(kl);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    kl_b[b] = t;
+    atomicAdd(stats + VMMT_STAT_KL_SUM, t);
+  }
+}
+
+// gradient of (kl_after / norm) w.r.t. mu and the pre-softplus scale output; kl_after = max(mult * KL_mean, margin)
+// (annealing before free bits: onmt/VILoss.py:463-473).  kl_sum is read from device memory (no host sync).
+template <class T>
+__global__ void latent_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma,
+                                  const float* __restrict__ kl_sum, float batch_global, float mult, int use_freebits,
+                                  float margin, float inv_norm, T* __restrict__ dmu, long ld1, T* __restrict__ dpre,
+                                  long ld2, int B, int Z) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * Z) return;
+  int b = i / Z, k = i - (long)b * Z;
+  float gs = mult / batch_global * inv_norm;
+  if (use_freebits && mult * (*kl_sum) / batch_global < margin) gs = 0.f;
+  float m = mu[i], s = sigma[i];
+  dmu[(long)b * ld1 + k] = from_f<T>(gs * m);
+  dpre[(long)b * ld2 + k] = from_f<T>(gs * (s - 1.f / s) * (1.f - __expf(-s)));   // d softplus = 1 - exp(-y)
+}
+
+// ---- image network gate: g = sigmoid(w.z + b), zt = z * g      onmt/modules/NormalVariationalEncoder.py:286-293
+template <class T>
+__global__ void gate_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ bias,
+                                float* __restrict__ g, T* __restrict__ zt, long ldzt, int B, int Z) {
+  int b = blockIdx.x;
+  float a = 0.f;
+  for (int k = threadIdx.x; k < Z; k += 64) a += z[(long)b * Z + k] * w[k];
+  a = wave_sum(a);
+  float gg = sigmoidf_(a + bias[0]);
+  if (threadIdx.x == 0) g[b] = gg;
+  for (int k = threadIdx.x; k < Z; k += 64) zt[(long)b * ldzt + k] = from_f<T>(z[(long)b * Z + k] * gg);
+}
+__global__ void gate_bwd_kernel(const float* __restrict__ dzt, long ldd, const float* __restrict__ z,
+                                const float* __restrict__ g, float* __restrict__ dw, float* __restrict__ db, int B, int Z) {
+  int b = blockIdx.x;
+  float a = 0.f;
+  for (int k = threadIdx.x; k < Z; k += 64) a += dzt[(long)b * ldd + k] * z[(long)b * Z + k];
+  a = wave_sum(a);
+  float gg = g[b];
+  float dp = a * gg * (1.f - gg);
+  for (int k = threadIdx.x; k < Z; k += 64) atomicAdd(dw + k, dp * z[(long)b * Z + k]);
+  if (threadIdx.x == 0) atomicAdd(db, dp);
+}
+
+// ---- image term of the ELBO, as executed by the reference (hazard H1) ------------------------------------------
+// compute_cosine normalises prediction AND observation in place (onmt/VILoss.py:39-44, called at :408-411) before the
+// unit-scale Normal log-prob that is summed over the batch and averaged over D (onmt/VILoss.py:321-331):
+//   a = mu_v/|mu_v|, vh = v/|v| ; logp = (1/D) sum_b sum_d [ -0.5 (vh - a)^2 - 0.5 log 2 pi ] ; cos = mean_b a.vh
+// backward: true derivative of that forward through the normalisation.
+template <class T>
+__global__ void image_loss_kernel(const float* __restrict__ mu_v, long ldm, const float* __restrict__ img, long ldi,
+                                  int D, float inv_norm, T* __restrict__ dmu, long ldd, float* __restrict__ stats) {
+  int b = blockIdx.x;
+  const float* m = mu_v + (long)b * ldm;
+  const float* v = img + (long)b * ldi;
+  float nm = 0.f, nv = 0.f, dt = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) { float x = m[d], y = v[d]; nm += x * x; nv += y * y; dt += x * y; }
+  __shared__ float red[3][4];
+  nm = wave_sum(nm); nv = wave_sum(nv); dt = wave_sum(dt);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = nm; red[1][w] = nv; red[2][w] = dt; }
+  __syncthreads();
+  nm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  nv = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  dt = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+  float rm = rsqrtf(nm), rv = rsqrtf(nv);
+  float cosb = dt * rm * rv;                       // a . vh  (both unit vectors)
+  // sum_d (vh - a)^2 = 2 - 2 cos
+  float logp = (-0.5f * (2.f - 2.f * cosb) - 0.5f * 1.8378770664093453f * (float)D) / (float)D;
+  if (threadIdx.x == 0) { atomicAdd(stats + VMMT_STAT_IMG_LOGPROB, logp); atomicAdd(stats + VMMT_STAT_IMG_COS, cosb); }
+  if (dmu) {
+    // g = d(-logp)/da = (a - vh)/D ; d/dmu = (g - a (a.g)) / |mu| ; a.g = (1 - cos)/D
+    float ag = (1.f - cosb) / (float)D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+      float a = m[d] * rm, vh = v[d] * rv;
+      float g = (a - vh) / (float)D;
+      dmu[(long)b * ldd + d] = from_f<T>((g - a * ag) * rm * inv_norm);
+    }
+  }
+}
+
+// f32 [R][C] (natural layout, ld = lds) -> T shadow (optionally transposed, optionally + second source, e.g. b_ih + b_hh)
+template <class T>
+__global__ void pack_kernel(const float* __restrict__ src, const float* __restrict__ src2, long lds_, T* __restrict__ dst,
+                            long ldd, int R, int C, int transpose) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * C) return;
+  if (!transpose) {
+    int r = i / C, c = i - (long)r * C;
+    float v = src[(long)r * lds_ + c] + (src2 ? src2[(long)r * lds_ + c] : 0.f);
+    dst[(long)r * ldd + c] = from_f<T>(v);
+  } else {
+    int c = i / R, r = i - (long)c * R;     // consecutive threads -> consecutive r -> coalesced dst[c][r]
+    float v = src[(long)r * lds_ + c] + (src2 ? src2[(long)r * lds_ + c] : 0.f);
+    dst[(long)c * ldd + r] = from_f<T>(v);
+  }
+}
+
+}  // namespace vmmt
+
+using namespace vmmt;
+#define ST ((hipStream_t)stream)
+#define BLOCKS(n, t) dim3((unsigned)(((n) + (t)-1) / (t)))
+
+extern "C" int vmmt_gather_rows(int out_dtype, const float* table, int64_t ldt, const int64_t* ids, void* out, int64_t ldo,
+                                int R, int D, void* stream) {
+  if (!table || !ids || !out || R < 0 || D <= 0) return VMMT_EINVAL;
+  if (R == 0) return VMMT_OK;
+  dim3 grid((R + 3) / 4), block(256);
+  if (out_dtype == VMMT_F32)
+    hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, ST, table, (long)ldt, (const long long*)ids, (float*)out, (long)ldo, R, D);
+  else if (out_dtype == VMMT_BF16)
+    hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, ST, table, (long)ldt, (const long long*)ids, (bf16_t*)out, (long)ldo, R, D);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream) {
+  if (!X || !out || R < 0 || C <= 0) return VMMT_EINVAL;
+  if (R == 0) return VMMT_OK;
+  int rpb = 256;
+  dim3 grid((C + 63) / 64, (R + rpb - 1) / rpb);
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST, (const float*)X, (long)ld, R, C, out, rpb);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)X, (long)ld, R, C, out, rpb);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_dropout_mask(int dtype, void* mask, int64_t n, float p, uint64_t seed, void* stream) {
+  if (!mask || n < 0 || p < 0.f || p >= 1.f) return VMMT_EINVAL;
+  if (n == 0) return VMMT_OK;
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(dropout_mask_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, (float*)mask, (long)n, p, (unsigned long long)seed);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(dropout_mask_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, (bf16_t*)mask, (long)n, p, (unsigned long long)seed);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_randn(float* out, int64_t n, uint64_t seed, void* stream) {
+  if (!out || n < 0) return VMMT_EINVAL;
+  if (n == 0) return VMMT_OK;
+  hipLaunchKernelGGL(randn_kernel, BLOCKS(n, 256), dim3(256), 0, ST, out, (long)n, (unsigned long long)seed);
+  return check_launch();
+}
+
+extern "C" int vmmt_mul(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int R,
+                        int C, void* stream) {
+  if (!a || !b || !out || R < 0 || C < 0) return VMMT_EINVAL;
+  long n = (long)R * C;
+  if (n == 0) return VMMT_OK;
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(mul_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, (const float*)a, (long)lda, (const float*)b, (long)ldb, (float*)out, (long)ldo, R, C);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(mul_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, (const bf16_t*)a, (long)lda, (const bf16_t*)b, (long)ldb, (bf16_t*)out, (long)ldo, R, C);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* mask,
+                            int64_t ldm, void* out, int64_t ldo, int R, int C, void* stream) {
+  if (!dy || !out || R < 0 || C < 0 || (act != VMMT_ACT_NONE && !y)) return VMMT_EINVAL;
+  long n = (long)R * C;
+  if (n == 0) return VMMT_OK;
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const float*)y, (long)ldy, (const float*)mask, (long)ldm, (float*)out, (long)ldo, R, C);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, act, (const bf16_t*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT,
+                               int64_t ldz, float* kl_b, float* stats, int B, int Z, int training, void* stream) {
+  if (!mu || !sigma || !z32 || !zT || !kl_b || !stats || (training && !eps) || B <= 0 || Z <= 0) return VMMT_EINVAL;
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(latent_fwd_kernel<float>, dim3(B), dim3(256), 0, ST, mu, sigma, eps, z32, (float*)zT, (long)ldz, kl_b, stats, B, Z, training);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(latent_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, ST, mu, sigma, eps, z32, (bf16_t*)zT, (long)ldz, kl_b, stats, B, Z, training);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_latent_bwd(int dtype, const float* mu, const float* sigma, const float* kl_sum, float batch_global,
+                               float mult, int use_freebits, float margin, float inv_norm, void* dmu, int64_t ld1,
+                               void* dpre, int64_t ld2, int B, int Z, void* stream) {
+  if (!mu || !sigma || !kl_sum || !dmu || !dpre || B <= 0 || Z <= 0) return VMMT_EINVAL;
+  long n = (long)B * Z;
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(latent_bwd_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, mu, sigma, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, (float*)dmu, (long)ld1, (float*)dpre, (long)ld2, B, Z);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(latent_bwd_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, mu, sigma, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, (bf16_t*)dmu, (long)ld1, (bf16_t*)dpre, (long)ld2, B, Z);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_gate_fwd(int dtype, const float* z, const float* w, const float* bias, float* g, void* zt, int64_t ldzt,
+                             int B, int Z, void* stream) {
+  if (!z || !w || !bias || !g || !zt || B <= 0 || Z <= 0) return VMMT_EINVAL;
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(gate_fwd_kernel<float>, dim3(B), dim3(64), 0, ST, z, w, bias, g, (float*)zt, (long)ldzt, B, Z);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(gate_fwd_kernel<bf16_t>, dim3(B), dim3(64), 0, ST, z, w, bias, g, (bf16_t*)zt, (long)ldzt, B, Z);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_gate_bwd(const float* dzt, int64_t ldd, const float* z, const float* g, float* dw, float* db, int B, int Z,
+                             void* stream) {
+  if (!dzt || !z || !g || !dw || !db || B <= 0 || Z <= 0) return VMMT_EINVAL;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(B), dim3(64), 0, ST, dzt, (long)ldd, z, g, dw, db, B, Z);
+  return check_launch();
+}
+
+extern "C" int vmmt_image_loss(int dtype, const float* mu_v, int64_t ldm, const float* img, int64_t ldi, int B, int D,
+                               float inv_norm, void* dmu, int64_t ldd, float* stats, void* stream) {
+  if (!mu_v || !img || !stats || B <= 0 || D <= 0) return VMMT_EINVAL;
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(image_loss_kernel<float>, dim3(B), dim3(256), 0, ST, mu_v, (long)ldm, img, (long)ldi, D, inv_norm, (float*)dmu, (long)ldd, stats);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(image_loss_kernel<bf16_t>, dim3(B), dim3(256), 0, ST, mu_v, (long)ldm, img, (long)ldi, D, inv_norm, (bf16_t*)dmu, (long)ldd, stats);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_pack(int dtype, const float* src, const float* src2, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C,
+                         int transpose, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0) return VMMT_EINVAL;
+  long n = (long)R * C;
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(pack_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, src, src2, (long)ld_src, (float*)dst, (long)ld_dst, R, C, transpose);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, src, src2, (long)ld_src, (bf16_t*)dst, (long)ld_dst, R, C, transpose);
+  else return VMMT_EINVAL;
+  return check_launch();
+}

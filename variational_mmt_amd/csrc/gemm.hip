@@ -1,0 +1,140 @@
+// Generic LDS-tiled MFMA GEMM for gfx950 with a fused, run-time-configured epilogue.
+//   C[m][n] (+)= act( alpha * sum_k Aop[m][k] * Bop[n][k] + addend )
+// Operand layouts (per operand): K-contiguous ("KC": element (r,k) at P[r*ld + k], e.g. nn.Linear's x and W)
+// or K-strided ("KS": element (r,k) at P[k*ld + r], used for the weight-gradient products dW = dY^T X where the
+// reduction runs over the token dimension).  Replaces the cuBLAS addmm calls behind every nn.Linear / nn.LSTM
+// input projection of the reference hot path.
+#include "common.hpp"
+#include "vmmt.h"
+
+namespace vmmt {
+
+struct GemmEpi {
+  void* C; long ldc;
+  const void* addend; long ld_add; int add_rows; int add_is_T;   // add_rows: 0 none, 1 bias row, >1 row modulus, -1 full
+  int act; int out_f32; int accumulate; float alpha;
+  const long long* scatter_ids; int pad_id;                      // embedding-gradient scatter (atomic add, fp32 C)
+};
+
+// The epilogue runs as a few small, fully unrolled passes over the accumulator registers (static indices only:
+// a run-time-indexed accumulator would be demoted to scratch), with the run-time switches hoisted outside.
+#define VMMT_FOR_ACC(BODY)                                         \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i)                   \
+  _Pragma("unroll") for (int j = 0; j < TJ; ++j)                   \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                 \
+    const int row = m0 + aoff[i] + acc_row(r, lane);               \
+    const int col = n0 + boff[j] + acc_col(lane);                  \
+    float v = acc[i][j][r];                                        \
+    if (row < M && col < N) { BODY }                               \
+    acc[i][j][r] = v;                                              \
+  }
+
+template <class T, int TI, int TJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI][TJ], const int (&aoff)[TI],
+                                              const int (&boff)[TJ], int m0, int n0, int M, int N, int lane) {
+  if (e.alpha != 1.0f) { VMMT_FOR_ACC(v *= e.alpha;) }
+  if (e.add_rows != 0) {
+    if (e.add_is_T) {
+      const T* ad = reinterpret_cast<const T*>(e.addend);
+      VMMT_FOR_ACC(long ar = e.add_rows == -1 ? row : (e.add_rows == 1 ? 0 : row % e.add_rows);
+                   v += to_f<T>(ad[ar * e.ld_add + col]);)
+    } else {
+      const float* ad = reinterpret_cast<const float*>(e.addend);
+      VMMT_FOR_ACC(long ar = e.add_rows == -1 ? row : (e.add_rows == 1 ? 0 : row % e.add_rows);
+                   v += ad[ar * e.ld_add + col];)
+    }
+  }
+  if (e.act == VMMT_ACT_RELU) { VMMT_FOR_ACC(v = fmaxf(v, 0.f);) }
+  else if (e.act == VMMT_ACT_TANH) { VMMT_FOR_ACC(v = tanhf_(v);) }
+  else if (e.act == VMMT_ACT_SOFTPLUS) { VMMT_FOR_ACC(v = v > 20.f ? v : log1pf(__expf(v));) }  // nn.Softplus(1, 20)
+  else if (e.act == VMMT_ACT_SIGMOID) { VMMT_FOR_ACC(v = sigmoidf_(v);) }
+  if (e.scatter_ids) {
+    float* C = reinterpret_cast<float*>(e.C);
+    VMMT_FOR_ACC(long long id = e.scatter_ids[row]; if (id != e.pad_id) atomicAdd(C + id * e.ldc + col, v);)
+  } else if (e.out_f32) {
+    float* C = reinterpret_cast<float*>(e.C);
+    if (e.accumulate) { VMMT_FOR_ACC(C[(long)row * e.ldc + col] += v;) }
+    else { VMMT_FOR_ACC(C[(long)row * e.ldc + col] = v;) }
+  } else {
+    T* C = reinterpret_cast<T*>(e.C);
+    if (e.accumulate) { VMMT_FOR_ACC(T* p = C + (long)row * e.ldc + col; *p = from_f<T>(to_f<T>(*p) + v);) }
+    else { VMMT_FOR_ACC(C[(long)row * e.ldc + col] = from_f<T>(v);) }
+  }
+}
+
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
+gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int M, int N, int K, int a_kmod,
+            int b_kmod, int tiles_n, GemmEpi epi) {
+  constexpr int BK = 32;
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr int TI = WM / 32, TJ = WN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int tile = blockIdx.x;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / (BN / WN), wn = wave % (BN / WN);
+  int aoff[TI], boff[TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) aoff[i] = wm * WM + i * 32;
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) boff[j] = wn * WN + j * 32;
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  LinearMap amap{m0, M}, bmap{n0, N};
+  gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ>(A, lda, amap, B, ldb, bmap, K, a_kmod, b_kmod, aoff, boff, acc,
+                                                        smem);
+  gemm_epilogue<T, TI, TJ>(epi, acc, aoff, boff, m0, n0, M, N, lane);
+}
+
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
+  size_t smem = gemm_smem_elems<T, BM, BN, 32>() * sizeof(T);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC>), dim3(tm * tn), dim3(NT), smem, st,
+                     (const T*)a->A, (long)a->lda, (const T*)a->B, (long)a->ldb, a->M, a->N, a->K, a->a_kmod,
+                     a->b_kmod, tn, epi);
+  return check_launch();
+}
+
+template <class T, bool A_KC, bool B_KC>
+static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
+  long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+  if (a->tile == 128 || (a->tile == 0 && t128 >= 192)) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st);
+  return launch_cfg<T, 64, 64, 32, 32, A_KC, B_KC>(a, epi, st);
+}
+
+template <class T>
+static int launch_dtype(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
+  switch (a->layout) {
+    case VMMT_GEMM_NT: return launch_layout<T, true, true>(a, epi, st);
+    case VMMT_GEMM_TN: return launch_layout<T, false, false>(a, epi, st);
+    case VMMT_GEMM_NN: return launch_layout<T, true, false>(a, epi, st);
+    default: return VMMT_EINVAL;
+  }
+}
+
+}  // namespace vmmt
+
+extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
+  using namespace vmmt;
+  if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N < 0 || a->K < 0) return VMMT_EINVAL;
+  if (a->M == 0 || a->N == 0) return VMMT_OK;
+  if (a->scatter_ids && !a->out_f32) return VMMT_EINVAL;
+  GemmEpi e;
+  e.C = a->C; e.ldc = a->ldc; e.addend = a->addend; e.ld_add = a->ld_add; e.add_rows = a->addend ? a->add_rows : 0;
+  e.add_is_T = a->add_is_T; e.act = a->act; e.out_f32 = a->out_f32; e.accumulate = a->accumulate;
+  e.alpha = a->alpha; e.scatter_ids = (const long long*)a->scatter_ids; e.pad_id = a->pad_id;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dtype == VMMT_F32) return launch_dtype<float>(a, e, st);
+  if (a->dtype == VMMT_BF16) return launch_dtype<bf16_t>(a, e, st);
+  return VMMT_EINVAL;
+}

@@ -1,0 +1,188 @@
+// Fused vocabulary projection + log-softmax + NLL (forward statistics and backward seed) for gfx950.
+//
+// Reference: generator = Sequential(Linear(H, V), LogSoftmax) (onmt/ModelConstructor.py:583-585), criterion =
+// NLLLoss(weight[pad] = 0, sum) (onmt/Loss.py:163-165), argmax accuracy (onmt/VILoss.py:515-531); the reference
+// materialises the [T'B, V] fp32 log-probabilities and re-reads them >= 4 times.  Here the logits never reach HBM
+// in the forward pass: the GEMM is computed TRANSPOSED (rows = vocabulary entries, columns = tokens), so that a
+// lane owns one token and its vocabulary entries sit in that lane's accumulator registers -- the running
+// max / sum-exp / argmax over the vocabulary are lane-local (no cross-lane reduction).  Pass 1 emits per-token
+// partial statistics per 64-row vocabulary block, a tiny combine kernel produces logsumexp / NLL / accuracy, and
+// pass 2 recomputes the logits tile and writes the loss gradient G^T[v][m] = (softmax - onehot) * w_m / norm
+// directly in the storage type, coalesced along tokens.  dO = G Wg and dWg = G^T O are then plain GEMMs.
+#include "common.hpp"
+#include "vmmt.h"
+
+namespace vmmt {
+
+struct GenArgs {
+  const void* W; long ldw;            // T [V][ldw] generator weight (k contiguous)
+  const float* bias;                  // f32 [V]
+  const void* O; long ldo;            // T [M][ldo] decoder outputs (after dropout)
+  const long long* y;                 // [M] target ids (tgt[1:], flattened t*B+b)
+  int M, V, K, pad;
+  // pass 1
+  float* part_max; float* part_sum; int* part_idx; float* tgt_logit;   // [NPART][M], [M]
+  // pass 2
+  const float* lse; float inv_norm; void* GT; long ldgt;               // T [V][ldgt]
+};
+
+template <class T, int MODE>
+__global__ void __launch_bounds__(256) gen_kernel(GenArgs a, int tiles_m) {
+  constexpr int BK = 32, NT = 256, BMV = 128, BNM = 128, TI = 2, TJ = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int tile = blockIdx.x;
+  const int tv = tile / tiles_m, tm = tile % tiles_m;
+  const int v0 = tv * BMV, m0 = tm * BNM;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = wave >> 1, wm = wave & 1;
+  int aoff[TI] = {wv * 64, wv * 64 + 32};
+  int boff[TJ] = {wm * 64, wm * 64 + 32};
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  LinearMap amap{v0, a.V}, bmap{m0, a.M};
+  gemm_mainloop<T, BMV, BNM, BK, NT, true, true, TI, TJ>((const T*)a.W, a.ldw, amap, (const T*)a.O, a.ldo, bmap, a.K,
+                                                          0, 0, aoff, boff, acc, smem);
+  // bias add; rows past V -> -inf
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int v = v0 + aoff[i] + acc_row(r, lane);
+      float bv = v < a.V ? a.bias[v] : -INFINITY;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[i][j][r] = v < a.V ? acc[i][j][r] + bv : -INFINITY;
+    }
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int m = m0 + boff[j] + (lane & 31);
+    const bool mv = m < a.M;
+    const long long ym = mv ? a.y[m] : -1;
+    if constexpr (MODE == 0) {
+      float mx = -INFINITY;
+      int mi = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int v = v0 + aoff[i] + acc_row(r, lane);
+          float x = acc[i][j][r];
+          if (x > mx) { mx = x; mi = v; }          // rows visited in increasing v per lane-half: first max wins
+          if (v == ym) a.tgt_logit[m] = x;
+        }
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += (mx == -INFINITY) ? 0.f : __expf(acc[i][j][r] - mx);
+      // combine with the other half-wave (same token column, interleaved rows)
+      float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
+      int omi = __shfl_xor(mi, 32, 64);
+      float nm = fmaxf(mx, omx);
+      float ns = (nm == -INFINITY) ? 0.f : sm * __expf(mx - nm) + osm * __expf(omx - nm);
+      int ni = (omx > mx || (omx == mx && omi < mi)) ? omi : mi;
+      if (mv && lane < 32) {
+        long p = (long)(tv * 2 + wv) * a.M + m;
+        a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
+      }
+    } else {
+      const float l = mv ? a.lse[m] : 0.f;
+      const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
+      T* GT = reinterpret_cast<T*>(a.GT);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int v = v0 + aoff[i] + acc_row(r, lane);
+          if (mv && v < a.V) {
+            float g = (__expf(acc[i][j][r] - l) - (v == ym ? 1.f : 0.f)) * sc;
+            GT[(long)v * a.ldgt + m] = from_f<T>(g);
+          }
+        }
+    }
+  }
+}
+
+// per token: logsumexp, NLL, argmax-correct; block-reduced sums are added to stats[0..2]
+__global__ void gen_combine_kernel(const float* __restrict__ part_max, const float* __restrict__ part_sum,
+                                   const int* __restrict__ part_idx, const float* __restrict__ tgt_logit,
+                                   const long long* __restrict__ y, int M, int npart, int pad, float* __restrict__ lse,
+                                   float* __restrict__ tok_nll, float* __restrict__ stats) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  float nll = 0.f, nw = 0.f, nc = 0.f;
+  if (m < M) {
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int p = 0; p < npart; ++p) {
+      float x = part_max[(long)p * M + m];
+      int xi = part_idx[(long)p * M + m];
+      if (x > mx || (x == mx && xi < mi)) { mx = x; mi = xi; }
+    }
+    float s = 0.f;
+    for (int p = 0; p < npart; ++p) s += part_sum[(long)p * M + m] * __expf(part_max[(long)p * M + m] - mx);
+    float l = mx + logf(s);
+    lse[m] = l;
+    long long ym = y[m];
+    bool w = ym != pad;
+    nll = w ? l - tgt_logit[m] : 0.f;
+    tok_nll[m] = nll;
+    nw = w ? 1.f : 0.f;
+    nc = (w && mi == (int)ym) ? 1.f : 0.f;
+  }
+  nll = wave_sum(nll); nw = wave_sum(nw); nc = wave_sum(nc);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(stats + VMMT_STAT_NLL, nll);
+    atomicAdd(stats + VMMT_STAT_NWORDS, nw);
+    atomicAdd(stats + VMMT_STAT_NCORRECT, nc);
+  }
+}
+
+template <class T, int MODE>
+static int launch_gen(const GenArgs& a, hipStream_t st) {
+  int tv = (a.V + 127) / 128, tm = (a.M + 127) / 128;
+  size_t sm = gemm_smem_elems<T, 128, 128, 32>() * sizeof(T);
+  hipLaunchKernelGGL((gen_kernel<T, MODE>), dim3(tv * tm), dim3(256), sm, st, a, tm);
+  return check_launch();
+}
+
+}  // namespace vmmt
+
+extern "C" int vmmt_gen_npart(int V) { return ((V + 127) / 128) * 2; }
+
+extern "C" int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
+                                 const int64_t* y, int M, int V, int K, int pad, float* part_max, float* part_sum,
+                                 int* part_idx, float* tgt_logit, float* lse, float* tok_nll, float* stats,
+                                 void* stream) {
+  using namespace vmmt;
+  if (!W || !bias || !O || !y || !part_max || !part_sum || !part_idx || !tgt_logit || !lse || !tok_nll || !stats ||
+      M <= 0 || V <= 0 || K <= 0)
+    return VMMT_EINVAL;
+  GenArgs a{};
+  a.W = W; a.ldw = ldw; a.bias = bias; a.O = O; a.ldo = ldo; a.y = (const long long*)y; a.M = M; a.V = V; a.K = K;
+  a.pad = pad; a.part_max = part_max; a.part_sum = part_sum; a.part_idx = part_idx; a.tgt_logit = tgt_logit;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dtype == VMMT_F32 ? launch_gen<float, 0>(a, st) : dtype == VMMT_BF16 ? launch_gen<bf16_t, 0>(a, st)
+                                                                                 : VMMT_EINVAL;
+  if (rc) return rc;
+  hipLaunchKernelGGL(gen_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part_max, part_sum, part_idx,
+                     tgt_logit, (const long long*)y, M, vmmt_gen_npart(V), pad, lse, tok_nll, stats);
+  return check_launch();
+}
+
+extern "C" int vmmt_gen_loss_bwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
+                                 const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm,
+                                 void* GT, int64_t ldgt, void* stream) {
+  using namespace vmmt;
+  if (!W || !bias || !O || !y || !lse || !GT || M <= 0 || V <= 0 || K <= 0 || ldgt < M) return VMMT_EINVAL;
+  GenArgs a{};
+  a.W = W; a.ldw = ldw; a.bias = bias; a.O = O; a.ldo = ldo; a.y = (const long long*)y; a.M = M; a.V = V; a.K = K;
+  a.pad = pad; a.lse = lse; a.inv_norm = inv_norm; a.GT = GT; a.ldgt = ldgt;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == VMMT_F32 ? launch_gen<float, 1>(a, st) : dtype == VMMT_BF16 ? launch_gen<bf16_t, 1>(a, st)
+                                                                               : VMMT_EINVAL;
+}

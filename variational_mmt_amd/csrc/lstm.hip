@@ -1,0 +1,231 @@
+// LSTM time-step kernels (forward and backward) for gfx950.
+//
+// The reference runs nn.LSTM through cuDNN (encoder: onmt/Models.py:124-129,140-147 with packed sequences;
+// decoder: onmt/VI_Model1.py:106,149-152).  Here the input projections x W_ih^T + b are one big GEMM per layer
+// (gemm.hip) and only the sequential part runs per time step: one launch per step, cut at the all-to-all seam
+// (every hidden unit of step t needs all of h_{t-1}); a launch boundary (~1.5 us) is cheaper on this chip than an
+// in-kernel grid barrier (~4-5 us).  Each step is a fused [B x H] x [H x 4H] MFMA GEMM + gate non-linearities +
+// state update; the four gate tiles (i,f,g,o) of a hidden unit land in the same lane, so the cell update is
+// lane-local.  Both directions of a bidirectional layer run in one launch (blockIdx.z).
+//
+// Packed-sequence semantics (pack_padded_sequence, Models.py:140-147) are reproduced by masking: a sentence's
+// state is not updated and its output is zero at positions >= its length; the reverse direction starts from the
+// zero state at the sentence's last token.
+#include "common.hpp"
+#include "vmmt.h"
+
+namespace vmmt {
+
+struct StepDirF {
+  const void* h_prev; long ld_hprev;     // T [B][ld]   (out[t-1] / out[t+1] / h0)
+  const float* c_prev; long ld_cprev;    // f32 [B][ld]
+  const void* w_hh; long ld_w;           // T [4H][ld] (k contiguous)
+  const float* gx; long ld_gx;           // f32 [B][ld]: x_t W_ih^T + b_ih + b_hh (gate-major columns g*H+u)
+  void* gates; long ld_gates;            // T [B][ld]: saved post-activation i,f,g,o
+  float* c_out; long ld_c;               // f32 [B][ld]
+  void* h_out; long ld_h;                // T [B][ld] (masked output)
+  void* h_n; long ld_hn;                 // T [B][ld] or null: final state capture
+  float* c_n; long ld_cn;
+  int t;                                 // time index of this step (for masking)
+  int capture;                           // 0 none, 1 when t == len-1, 2 when t == 0, 3 always
+};
+struct StepArgsF {
+  StepDirF d[2];
+  const long long* lens;                 // [B] or null (decoder: no masking)
+  int B, H;
+};
+
+template <class T>
+__global__ void __launch_bounds__(128) lstm_step_fwd_kernel(StepArgsF a) {
+  constexpr int BK = 32, NT = 128, BM = 64, BU = 32, BN = 4 * BU;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const StepDirF& d = a.d[blockIdx.z];
+  const int B = a.B, H = a.H;
+  const int m0 = blockIdx.x * BM, u0 = blockIdx.y * BU;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int aoff[1] = {wave * 32};
+  int boff[4] = {0, BU, 2 * BU, 3 * BU};
+  f32x16 acc[1][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][g][r] = 0.f;
+  LinearMap amap{m0, B};
+  GateMap bmap{u0, H, BU};
+  gemm_mainloop<T, BM, BN, BK, NT, true, true, 1, 4>((const T*)d.h_prev, d.ld_hprev, amap, (const T*)d.w_hh, d.ld_w,
+                                                      bmap, H, 0, 0, aoff, boff, acc, smem);
+  const int u = u0 + (lane & 31);
+  if (u >= H) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int b = m0 + aoff[0] + acc_row(r, lane);
+    if (b >= B) continue;
+    const float* gx = d.gx + (long)b * d.ld_gx + u;
+    float pi = acc[0][0][r] + gx[0];
+    float pf = acc[0][1][r] + gx[H];
+    float pg = acc[0][2][r] + gx[2 * H];
+    float po = acc[0][3][r] + gx[3 * (long)H];
+    float i = sigmoidf_(pi), f = sigmoidf_(pf), g = tanhf_(pg), o = sigmoidf_(po);
+    float cp = d.c_prev ? d.c_prev[(long)b * d.ld_cprev + u] : 0.f;
+    float c = f * cp + i * g;
+    float h = o * tanhf_(c);
+    bool valid = true;
+    long long len = 0;
+    if (a.lens) { len = a.lens[b]; valid = d.t < len; }
+    T* gs = reinterpret_cast<T*>(d.gates) + (long)b * d.ld_gates + u;
+    gs[0] = from_f<T>(i); gs[H] = from_f<T>(f); gs[2 * H] = from_f<T>(g); gs[3 * (long)H] = from_f<T>(o);
+    d.c_out[(long)b * d.ld_c + u] = valid ? c : cp;          // frozen state at pads
+    reinterpret_cast<T*>(d.h_out)[(long)b * d.ld_h + u] = from_f<T>(valid ? h : 0.f);
+    bool cap = d.capture == 3 || (d.capture == 1 && d.t == len - 1) || (d.capture == 2 && d.t == 0);
+    if (cap && d.h_n) {
+      reinterpret_cast<T*>(d.h_n)[(long)b * d.ld_hn + u] = from_f<T>(h);
+      d.c_n[(long)b * d.ld_cn + u] = c;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward step: dh_rec = dgates_next W_hh (GEMM over 4H), then the cell backward for step t, lane-local.
+// ------------------------------------------------------------------------------------------------------------
+struct StepDirB {
+  const void* dgates_next; long ld_dgn;  // T [B][ld] or null (first processed step: no recurrent term)
+  const void* w_hh_t; long ld_wt;        // T [H][ld]: W_hh^T shadow (k = gate index contiguous)
+  const void* dh_above; long ld_dha;     // T [B][ld] or null: gradient arriving at this step's output
+  const void* gates; long ld_gates;      // T saved activations of step t
+  const float* c_t; long ld_ct;          // f32 c after step t
+  const float* c_prev; long ld_cp;       // f32 c before step t (null = zeros)
+  float* dc_carry; long ld_dcc;          // f32 [B][ld] in/out: dL/dc flowing to the previous step
+  void* dgates_out; long ld_dgo;         // T [B][ld]: dL/d(gate pre-activations) of step t
+  const float* dh_n; long ld_dhn;        // f32 [B][ld] or null: gradient of the captured final state
+  const float* dc_n; long ld_dcn;
+  float* dh0_out; long ld_dh0;           // mode 1 only: f32 [B][ld] receives dgates_next W_hh
+  int t, inject;                         // inject: 0 none, 1 when t == len-1, 2 when t == 0, 3 always
+};
+struct StepArgsB {
+  StepDirB d[2];
+  const long long* lens;
+  int B, H, mode;                        // mode 0: GEMM + cell backward; 1: GEMM only -> dh0_out
+};
+
+template <class T>
+__global__ void __launch_bounds__(256) lstm_step_bwd_kernel(StepArgsB a) {
+  constexpr int BK = 32, NT = 256, BM = 64, BN = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const StepDirB& d = a.d[blockIdx.z];
+  const int B = a.B, H = a.H;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int aoff[1] = {(wave >> 1) * 32};
+  int boff[1] = {(wave & 1) * 32};
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  if (d.dgates_next) {
+    LinearMap amap{m0, B}, bmap{n0, H};
+    gemm_mainloop<T, BM, BN, BK, NT, true, true, 1, 1>((const T*)d.dgates_next, d.ld_dgn, amap, (const T*)d.w_hh_t,
+                                                        d.ld_wt, bmap, 4 * H, 0, 0, aoff, boff, acc, smem);
+  }
+  const int u = n0 + boff[0] + (lane & 31);
+  if (u >= H) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int b = m0 + aoff[0] + acc_row(r, lane);
+    if (b >= B) continue;
+    float dh = acc[0][0][r];
+    if (a.mode == 1) { d.dh0_out[(long)b * d.ld_dh0 + u] = dh; continue; }
+    long long len = 0;
+    bool valid = true;
+    if (a.lens) { len = a.lens[b]; valid = d.t < len; }
+    T* dgo = reinterpret_cast<T*>(d.dgates_out) + (long)b * d.ld_dgo + u;
+    float* dcc = d.dc_carry + (long)b * d.ld_dcc + u;
+    if (!valid) {
+      dgo[0] = T(0); dgo[H] = T(0); dgo[2 * H] = T(0); dgo[3 * (long)H] = T(0);
+      *dcc = 0.f;
+      continue;
+    }
+    float dc = *dcc;
+    if (d.dh_above) dh += to_f<T>(reinterpret_cast<const T*>(d.dh_above)[(long)b * d.ld_dha + u]);
+    bool inj = d.inject == 3 || (d.inject == 1 && d.t == len - 1) || (d.inject == 2 && d.t == 0);
+    if (inj && d.dh_n) { dh += d.dh_n[(long)b * d.ld_dhn + u]; dc += d.dc_n[(long)b * d.ld_dcn + u]; }
+    const T* gs = reinterpret_cast<const T*>(d.gates) + (long)b * d.ld_gates + u;
+    float i = to_f<T>(gs[0]), f = to_f<T>(gs[H]), g = to_f<T>(gs[2 * H]), o = to_f<T>(gs[3 * (long)H]);
+    float c = d.c_t[(long)b * d.ld_ct + u];
+    float cp = d.c_prev ? d.c_prev[(long)b * d.ld_cp + u] : 0.f;
+    float tc = tanhf_(c);
+    float d_o = dh * tc;
+    dc += dh * o * (1.f - tc * tc);
+    float d_i = dc * g, d_f = dc * cp, d_g = dc * i;
+    dgo[0] = from_f<T>(d_i * i * (1.f - i));
+    dgo[H] = from_f<T>(d_f * f * (1.f - f));
+    dgo[2 * H] = from_f<T>(d_g * (1.f - g * g));
+    dgo[3 * (long)H] = from_f<T>(d_o * o * (1.f - o));
+    *dcc = dc * f;
+  }
+}
+
+static void fill_f(StepDirF& o, const vmmt_lstm_dir_fwd& i) {
+  o.h_prev = i.h_prev; o.ld_hprev = i.ld_hprev; o.c_prev = (const float*)i.c_prev; o.ld_cprev = i.ld_cprev;
+  o.w_hh = i.w_hh; o.ld_w = i.ld_w; o.gx = (const float*)i.gx; o.ld_gx = i.ld_gx; o.gates = i.gates;
+  o.ld_gates = i.ld_gates; o.c_out = (float*)i.c_out; o.ld_c = i.ld_c; o.h_out = i.h_out; o.ld_h = i.ld_h;
+  o.h_n = i.h_n; o.ld_hn = i.ld_hn; o.c_n = (float*)i.c_n; o.ld_cn = i.ld_cn; o.t = i.t; o.capture = i.capture;
+}
+static void fill_b(StepDirB& o, const vmmt_lstm_dir_bwd& i) {
+  o.dgates_next = i.dgates_next; o.ld_dgn = i.ld_dgn; o.w_hh_t = i.w_hh_t; o.ld_wt = i.ld_wt;
+  o.dh_above = i.dh_above; o.ld_dha = i.ld_dha; o.gates = i.gates; o.ld_gates = i.ld_gates;
+  o.c_t = (const float*)i.c_t; o.ld_ct = i.ld_ct; o.c_prev = (const float*)i.c_prev; o.ld_cp = i.ld_cp;
+  o.dc_carry = (float*)i.dc_carry; o.ld_dcc = i.ld_dcc; o.dgates_out = i.dgates_out; o.ld_dgo = i.ld_dgo;
+  o.dh_n = (const float*)i.dh_n; o.ld_dhn = i.ld_dhn; o.dc_n = (const float*)i.dc_n; o.ld_dcn = i.ld_dcn;
+  o.dh0_out = (float*)i.dh0_out; o.ld_dh0 = i.ld_dh0; o.t = i.t; o.inject = i.inject;
+}
+
+}  // namespace vmmt
+
+extern "C" int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* dirs, const int64_t* lens, int B,
+                                  int H, void* stream) {
+  using namespace vmmt;
+  if (ndir < 1 || ndir > 2 || !dirs || B <= 0 || H <= 0) return VMMT_EINVAL;
+  StepArgsF a;
+  for (int k = 0; k < ndir; ++k) {
+    if (!dirs[k].h_prev || !dirs[k].w_hh || !dirs[k].gx || !dirs[k].gates || !dirs[k].c_out || !dirs[k].h_out)
+      return VMMT_EINVAL;
+    fill_f(a.d[k], dirs[k]);
+  }
+  if (ndir == 1) a.d[1] = a.d[0];
+  a.lens = (const long long*)lens; a.B = B; a.H = H;
+  dim3 grid((B + 63) / 64, (H + 31) / 32, ndir);
+  if (dtype == VMMT_F32) {
+    size_t sm = gemm_smem_elems<float, 64, 128, 32>() * sizeof(float);
+    hipLaunchKernelGGL(lstm_step_fwd_kernel<float>, grid, dim3(128), sm, (hipStream_t)stream, a);
+  } else if (dtype == VMMT_BF16) {
+    size_t sm = gemm_smem_elems<bf16_t, 64, 128, 32>() * sizeof(bf16_t);
+    hipLaunchKernelGGL(lstm_step_fwd_kernel<bf16_t>, grid, dim3(128), sm, (hipStream_t)stream, a);
+  } else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_lstm_step_bwd(int dtype, int ndir, const vmmt_lstm_dir_bwd* dirs, const int64_t* lens, int B,
+                                  int H, int mode, void* stream) {
+  using namespace vmmt;
+  if (ndir < 1 || ndir > 2 || !dirs || B <= 0 || H <= 0 || mode < 0 || mode > 1) return VMMT_EINVAL;
+  StepArgsB a;
+  for (int k = 0; k < ndir; ++k) {
+    const vmmt_lstm_dir_bwd& i = dirs[k];
+    if (mode == 1 && (!i.dgates_next || !i.dh0_out)) return VMMT_EINVAL;
+    if (mode == 0 && (!i.gates || !i.c_t || !i.dc_carry || !i.dgates_out)) return VMMT_EINVAL;
+    if (i.dgates_next && !i.w_hh_t) return VMMT_EINVAL;
+    fill_b(a.d[k], i);
+  }
+  if (ndir == 1) a.d[1] = a.d[0];
+  a.lens = (const long long*)lens; a.B = B; a.H = H; a.mode = mode;
+  dim3 grid((B + 63) / 64, (H + 63) / 64, ndir);
+  if (dtype == VMMT_F32) {
+    size_t sm = gemm_smem_elems<float, 64, 64, 32>() * sizeof(float);
+    hipLaunchKernelGGL(lstm_step_bwd_kernel<float>, grid, dim3(256), sm, (hipStream_t)stream, a);
+  } else if (dtype == VMMT_BF16) {
+    size_t sm = gemm_smem_elems<bf16_t, 64, 64, 32>() * sizeof(bf16_t);
+    hipLaunchKernelGGL(lstm_step_bwd_kernel<bf16_t>, grid, dim3(256), sm, (hipStream_t)stream, a);
+  } else return VMMT_EINVAL;
+  return check_launch();
+}

@@ -1,0 +1,789 @@
+"""VI_Model1 training-step engine: owns the HBM layout (parameter arena, compute shadows, per-shape workspace)
+and drives the libvmmt.so kernels.  PyTorch is used for device memory, streams and (in dp.py) torch.distributed --
+no torch operator computes anything on the hot path.
+
+Reference path (all under /root/reference): TrainerMultimodal._gradient_accumulation
+(onmt/TrainerMultimodal.py:625-718) -> NMTVIModel.forward (onmt/Models.py:850-1011) ->
+NMTVIModel1LossCompute.sharded_compute_loss (onmt/Loss.py:88-132, onmt/VILoss.py:217-513) -> Optim.step
+(onmt/Optim.py:78-96).
+
+HBM layout
+  * arena: ONE flat fp32 buffer for all master parameters (views carry the reference's state-dict names,
+    SURVEY.md Appendix B), one for gradients, two for Adam moments.  Parameters that never receive a gradient
+    (inf_net_image.scale.*, hazard H6) sit at the tail, outside the optimiser / all-reduce range.  The order is
+    the order in which backward finishes gradients (generator first, embeddings last) so that data-parallel
+    buckets can be reduced while backward is still running.
+  * shadows: compute copies of the 2-D weights in the storage type T (bf16 or fp32), leading dimension padded
+    to 16 bytes, refreshed by vmmt_pack after each optimiser step.
+  * workspace: activations saved for backward, per (B, S, T') shape, time-major rows (t*B + b).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+PAD = 1  # '<blank>' (onmt/io/DatasetBase.py:7-11)
+
+
+class Dims(object):
+    def __init__(self, vs, vt, emb=500, hid=500, z=500, img=2048, layers=2, brnn=False, dropout=0.0):
+        self.vs, self.vt, self.emb, self.hid, self.z, self.img = vs, vt, emb, hid, z, img
+        self.layers, self.brnn, self.dropout = layers, bool(brnn), float(dropout)
+        self.dirs = 2 if brnn else 1
+        assert hid % self.dirs == 0
+        self.hd = hid // self.dirs
+        assert hid <= 1024, "attention kernel limit (H <= 1024)"
+
+    def param_shapes(self):
+        """name -> shape, in ARENA order (reverse of backward completion is not needed: order == completion)."""
+        d = self
+        s = []
+        s += [("generator.0.weight", (d.vt, d.hid)), ("generator.0.bias", (d.vt,))]
+        s += [("decoder.attn.linear_out.weight", (d.hid, 2 * d.hid)), ("decoder.attn.linear_in.weight", (d.hid, d.hid))]
+        for l in reversed(range(d.layers)):
+            i = d.emb + d.z if l == 0 else d.hid
+            s += [("decoder.rnn.weight_ih_l%d" % l, (4 * d.hid, i)), ("decoder.rnn.weight_hh_l%d" % l, (4 * d.hid, d.hid)),
+                  ("decoder.rnn.bias_ih_l%d" % l, (4 * d.hid,)), ("decoder.rnn.bias_hh_l%d" % l, (4 * d.hid,))]
+        s += [("decoder.embeddings.make_embedding.emb_luts.0.weight", (d.vt, d.emb))]
+        for l in reversed(range(d.layers)):
+            i = d.emb if l == 0 else d.hid
+            for suf in ([""] + (["_reverse"] if d.brnn else [])):
+                s += [("encoder.rnn.weight_ih_l%d%s" % (l, suf), (4 * d.hd, i)),
+                      ("encoder.rnn.weight_hh_l%d%s" % (l, suf), (4 * d.hd, d.hd)),
+                      ("encoder.rnn.bias_ih_l%d%s" % (l, suf), (4 * d.hd,)),
+                      ("encoder.rnn.bias_hh_l%d%s" % (l, suf), (4 * d.hd,))]
+        s += [("encoder.embeddings.make_embedding.emb_luts.0.weight", (d.vs, d.emb))]
+        s += [("inf_net_image.location.fc2.weight", (d.img, d.img)), ("inf_net_image.location.fc2.bias", (d.img,)),
+              ("inf_net_image.location.fc1.weight", (d.img, d.z)), ("inf_net_image.location.fc1.bias", (d.img,)),
+              ("inf_net_image.gate_affine_transform.weight", (1, d.z)), ("inf_net_image.gate_affine_transform.bias", (1,))]
+        for br in ("location", "scale"):
+            s += [("inf_net_global.%s.fc2.weight" % br, (d.z, d.z)), ("inf_net_global.%s.fc2.bias" % br, (d.z,)),
+                  ("inf_net_global.%s.fc1.weight" % br, (d.z, d.hid)), ("inf_net_global.%s.fc1.bias" % br, (d.z,))]
+        nograd = [("inf_net_image.scale.fc1.weight", (d.img, d.z)), ("inf_net_image.scale.fc1.bias", (d.img,)),
+                  ("inf_net_image.scale.fc2.weight", (d.img, d.img)), ("inf_net_image.scale.fc2.bias", (d.img,))]
+        return s, nograd
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class Buf(object):
+    """2-D device buffer [rows][ld] (ld >= cols, 16-byte aligned rows)."""
+
+    def __init__(self, rows, cols, dtype, device, ld=None, fill=None):
+        esz = torch.empty((), dtype=dtype).element_size()
+        self.ld = ld if ld is not None else _ru(max(cols, 1), 16 // esz if esz <= 16 else 1)
+        self.rows, self.cols, self.esz = rows, cols, esz
+        self.t = torch.zeros(max(rows, 1), self.ld, dtype=dtype, device=device)
+        if fill is not None:
+            self.t.fill_(fill)
+
+    def p(self, r=0, c=0):
+        return self.t.data_ptr() + (r * self.ld + c) * self.esz
+
+    def view(self):
+        return self.t[:self.rows, :self.cols]
+
+
+class Engine(object):
+    def __init__(self, dims, dtype="bf16", device="cuda", seed=0, param_init=0.1, batch_global=None):
+        self.d = dims
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("variational_mmt_amd needs a GPU (MI355X); there is no CPU path")
+        self.lib = L.lib()
+        self.dt = L.BF16 if dtype in ("bf16", torch.bfloat16) else L.F32
+        self.T = torch.bfloat16 if self.dt == L.BF16 else torch.float32
+        self.tsz = 2 if self.dt == L.BF16 else 4
+        self._build_arena(seed, param_init)
+        self._build_shadows()
+        self.ws = {}
+        self.shadows_dirty = True
+        self.step_count = 0          # Adam step counter
+        self.rng_counter = 1234567 + seed
+        self.reparam_grad = False    # H2: as executed (sample detached)
+        self.stats_host = None
+
+    # ------------------------------------------------------------------------------------------------ arena
+    def _build_arena(self, seed, param_init):
+        wg, ng = self.d.param_shapes()
+        self.names_grad = [n for n, _ in wg]
+        self.names_nograd = [n for n, _ in ng]
+        off = 0
+        self.offsets = {}
+        for n, shp in wg + ng:
+            if n == ng[0][0]:
+                self.n_opt = off                       # optimiser / all-reduce range = [0, n_opt)
+            self.offsets[n] = (off, shp)
+            off += _ru(int(math.prod(shp)), 64)
+        self.n_total = off
+        dev = self.dev
+        self.flat_p = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
+        self.params, self.grads = {}, {}
+        g = torch.Generator().manual_seed(seed)
+        for n, (o, shp) in self.offsets.items():
+            k = int(math.prod(shp))
+            self.params[n] = self.flat_p[o:o + k].view(*shp)
+            if o < self.n_opt:
+                self.grads[n] = self.flat_g[o:o + k].view(*shp)
+            if param_init:                             # ModelConstructor.py:598-603 (H7: every parameter)
+                self.params[n].copy_(((torch.rand(*shp, generator=g) * 2 - 1) * param_init))
+
+    def pp(self, name, r=0, c=0):
+        o, shp = self.offsets[name]
+        ld = shp[1] if len(shp) > 1 else 0
+        return self.flat_p.data_ptr() + (o + r * ld + c) * 4
+
+    def gp(self, name, r=0, c=0):
+        o, shp = self.offsets[name]
+        ld = shp[1] if len(shp) > 1 else 0
+        return self.flat_g.data_ptr() + (o + r * ld + c) * 4
+
+    def load_state_dict(self, sd):
+        for n, t in sd.items():
+            if n in self.params:
+                self.params[n].copy_(t.to(torch.float32))
+        self.shadows_dirty = True
+
+    def state_dict(self):
+        return {n: v.detach().clone() for n, v in self.params.items()}
+
+    # ------------------------------------------------------------------------------------------------ shadows
+    def _build_shadows(self):
+        d, T, dev = self.d, self.T, self.dev
+        self.sh = {}
+        self.pack_calls = []
+
+        def shadow(key, rows, cols, src, c0=0, ncols=None, transpose=False, dtype=None, src2=None, row_off=0):
+            dt = dtype if dtype is not None else T
+            code = L.F32 if dt == torch.float32 else L.BF16
+            _, shp = self.offsets[src]
+            ld_src = shp[1] if len(shp) > 1 else shp[0]
+            R = shp[0] if len(shp) > 1 else 1
+            Cc = ncols if ncols is not None else (shp[1] if len(shp) > 1 else shp[0])
+            if key not in self.sh:
+                self.sh[key] = Buf(rows, cols, dt, dev)
+            b = self.sh[key]
+            dst = b.p(row_off, 0) if not transpose else b.p(0, row_off)
+            s2 = self.pp(src2) if src2 else None
+            self.pack_calls.append((code, self.pp(src, 0, c0), s2, ld_src, dst, b.ld, R, Cc, 1 if transpose else 0))
+
+        for l in range(d.layers):
+            i = d.emb if l == 0 else d.hid
+            for k, suf in enumerate([""] + (["_reverse"] if d.brnn else [])):
+                # concatenated over directions: rows k*4Hd ..
+                shadow("enc_wih_l%d" % l, d.dirs * 4 * d.hd, i, "encoder.rnn.weight_ih_l%d%s" % (l, suf), row_off=k * 4 * d.hd)
+                shadow("enc_b_l%d" % l, 1, d.dirs * 4 * d.hd, "encoder.rnn.bias_ih_l%d%s" % (l, suf), dtype=torch.float32,
+                       src2="encoder.rnn.bias_hh_l%d%s" % (l, suf), transpose=False, row_off=0, c0=0)
+                # bias: place at column offset k*4Hd -> patch destination pointer
+                code, sp, s2, lds, dst, ldd, R, Cc, tr = self.pack_calls[-1]
+                self.pack_calls[-1] = (code, sp, s2, lds, self.sh["enc_b_l%d" % l].p(0, k * 4 * d.hd), ldd, R, Cc, tr)
+                shadow("enc_whh_l%d_d%d" % (l, k), 4 * d.hd, d.hd, "encoder.rnn.weight_hh_l%d%s" % (l, suf))
+                shadow("enc_whhT_l%d_d%d" % (l, k), d.hd, 4 * d.hd, "encoder.rnn.weight_hh_l%d%s" % (l, suf), transpose=True)
+        for l in range(d.layers):
+            if l == 0:
+                shadow("dec_wih_l0_e", 4 * d.hid, d.emb, "decoder.rnn.weight_ih_l0", c0=0, ncols=d.emb)
+                shadow("dec_wih_l0_z", 4 * d.hid, d.z, "decoder.rnn.weight_ih_l0", c0=d.emb, ncols=d.z)
+            else:
+                shadow("dec_wih_l%d" % l, 4 * d.hid, d.hid, "decoder.rnn.weight_ih_l%d" % l)
+            shadow("dec_b_l%d" % l, 1, 4 * d.hid, "decoder.rnn.bias_ih_l%d" % l, dtype=torch.float32,
+                   src2="decoder.rnn.bias_hh_l%d" % l)
+            shadow("dec_whh_l%d" % l, 4 * d.hid, d.hid, "decoder.rnn.weight_hh_l%d" % l)
+            shadow("dec_whhT_l%d" % l, d.hid, 4 * d.hid, "decoder.rnn.weight_hh_l%d" % l, transpose=True)
+        shadow("wa", d.hid, d.hid, "decoder.attn.linear_in.weight")
+        shadow("wo", d.hid, 2 * d.hid, "decoder.attn.linear_out.weight")
+        for br in ("location", "scale"):
+            shadow("q_%s_w1" % br, d.z, d.hid, "inf_net_global.%s.fc1.weight" % br)
+            shadow("q_%s_w2" % br, d.z, d.z, "inf_net_global.%s.fc2.weight" % br)
+        shadow("iv_w1", d.img, d.z, "inf_net_image.location.fc1.weight")
+        shadow("iv_w2", d.img, d.img, "inf_net_image.location.fc2.weight")
+        shadow("wg", d.vt, d.hid, "generator.0.weight")
+
+    def refresh_shadows(self, stream):
+        if not self.shadows_dirty:
+            return
+        f = self.lib.vmmt_pack
+        for (code, sp, s2, lds, dst, ldd, R, Cc, tr) in self.pack_calls:
+            L.check(f(code, sp, s2, lds, dst, ldd, R, Cc, tr, stream), "vmmt_pack")
+        self.shadows_dirty = False
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
+              act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0):
+        a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
+                       add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile)
+        plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a))
+
+    def _call(self, plan, fn, *args):
+        plan.append((fn, args, fn.__name__, None))
+
+    @staticmethod
+    def _run(plan, stream):
+        for fn, args, name, _keep in plan:
+            rc = fn(*args, stream)
+            if rc != 0:
+                L.check(rc, name)
+
+    # ------------------------------------------------------------------------------------------------ workspace
+    def workspace(self, B, S, Tp):
+        key = (B, S, Tp)
+        if key not in self.ws:
+            self.ws[key] = Workspace(self, B, S, Tp)
+        return self.ws[key]
+
+
+class Workspace(object):
+    """All per-shape device buffers + the launch plans for (B sentences, S source positions, T' decoder steps)."""
+
+    def __init__(self, eng, B, S, Tp):
+        self.e, self.B, self.S, self.Tp = eng, B, S, Tp
+        d, T, dev = eng.d, eng.T, eng.dev
+        f32, i64 = torch.float32, torch.int64
+        H, Hd, E, Z, D, V, Lyr, dirs = d.hid, d.hd, d.emb, d.z, d.img, d.vt, d.layers, d.dirs
+        M, MS = Tp * B, S * B
+        self.M, self.MS = M, MS
+        nb = lambda r, c, dt=T, **kw: Buf(r, c, dt, dev, **kw)
+        # inputs
+        self.src = torch.zeros(MS, dtype=i64, device=dev)
+        self.tgt_in = torch.zeros(M, dtype=i64, device=dev)
+        self.y = torch.zeros(M, dtype=i64, device=dev)
+        self.src_len = torch.zeros(B, dtype=i64, device=dev)
+        self.img_idx = torch.zeros(B, dtype=i64, device=dev)
+        self.img = nb(B, D, f32)
+        self.eps = nb(B, Z, f32, ld=Z)
+        self.stats = torch.zeros(L.STAT_COUNT, dtype=f32, device=dev)
+        # encoder
+        self.Xs = nb(MS, E)
+        self.enc_gx = [nb(MS, dirs * 4 * Hd, f32) for _ in range(Lyr)]
+        self.enc_gates = [nb(MS, dirs * 4 * Hd) for _ in range(Lyr)]
+        self.enc_c = [nb(MS, H, f32) for _ in range(Lyr)]
+        self.enc_out = [nb(MS, H) for _ in range(Lyr)]
+        self.enc_mask = [nb(MS, H) if (d.dropout > 0 and l < Lyr - 1) else None for l in range(Lyr)]
+        self.enc_xdrop = [nb(MS, H) if (d.dropout > 0 and l < Lyr - 1) else None for l in range(Lyr)]
+        self.hn = [nb(B, H) for _ in range(Lyr)]
+        self.cn = [nb(B, H, f32) for _ in range(Lyr)]
+        # q(z|x)
+        self.hbar = nb(B, H)
+        self.q_h1 = {br: nb(B, Z) for br in ("location", "scale")}
+        self.mu = nb(B, Z, f32, ld=Z)
+        self.sigma = nb(B, Z, f32, ld=Z)
+        self.z32 = nb(B, Z, f32, ld=Z)
+        self.zT = nb(B, Z)
+        self.kl_b = torch.zeros(B, dtype=f32, device=dev)
+        # decoder
+        self.Xt = nb(M, E)
+        self.zx = nb(B, 4 * H, f32)
+        self.dec_gx = [nb(M, 4 * H, f32) for _ in range(Lyr)]
+        self.dec_gates = [nb(M, 4 * H) for _ in range(Lyr)]
+        self.dec_c = [nb(M, H, f32) for _ in range(Lyr)]
+        self.dec_out = [nb(M, H) for _ in range(Lyr - 1)]
+        self.dec_mask = [nb(M, H) if d.dropout > 0 else None for _ in range(Lyr - 1)]
+        self.dec_xdrop = [nb(M, H) if d.dropout > 0 else None for _ in range(Lyr - 1)]
+        self.cat = nb(M, 2 * H)
+        self.Q = nb(M, H)
+        self.probs = torch.zeros(M * S, dtype=f32, device=dev)
+        self.AH = nb(M, H)
+        self.out_mask = nb(M, H) if d.dropout > 0 else None
+        self.O = nb(M, H) if d.dropout > 0 else self.AH
+        # image network
+        self.gate = torch.zeros(B, dtype=f32, device=dev)
+        self.zt = nb(B, Z)
+        self.h1v = nb(B, D)
+        self.mu_v = nb(B, D, f32)
+        # loss
+        self.npart = eng.lib.vmmt_gen_npart(V)
+        self.part_max = torch.zeros(self.npart * M, dtype=f32, device=dev)
+        self.part_sum = torch.zeros(self.npart * M, dtype=f32, device=dev)
+        self.part_idx = torch.zeros(self.npart * M, dtype=torch.int32, device=dev)
+        self.tgt_logit = torch.zeros(M, dtype=f32, device=dev)
+        self.lse = torch.zeros(M, dtype=f32, device=dev)
+        self.tok_nll = torch.zeros(M, dtype=f32, device=dev)
+        # backward
+        self.GT = nb(V, M)
+        self.dO = nb(M, H)
+        self.dPre = nb(M, H)
+        self.dcat = nb(M, 2 * H)
+        self.dQ = nb(M, H)
+        self.dctx = nb(MS, H)
+        self.dR = nb(M, H)
+        self.dec_dgates = [nb(M, 4 * H) for _ in range(Lyr)]
+        self.dec_dcc = [nb(B, H, f32) for _ in range(Lyr)]
+        self.dec_dh0 = [nb(B, H, f32) for _ in range(Lyr)]
+        self.dec_dx = [nb(M, H) for _ in range(Lyr - 1)]
+        self.enc_dgates = [nb(MS, dirs * 4 * Hd) for _ in range(Lyr)]
+        self.enc_dcc = [nb(B, H, f32) for _ in range(Lyr)]
+        self.enc_dx = [nb(MS, H) for _ in range(Lyr - 1)]
+        self.q_dmu = nb(B, Z)
+        self.q_dpre = nb(B, Z)
+        self.q_dh1 = {br: nb(B, Z) for br in ("location", "scale")}
+        self.dmu_v = nb(B, D)
+        self.dh1v = nb(B, D)
+        self.dzt = nb(B, Z, f32)
+        self._keep = []
+        self.plan_fwd_train = self._plan_forward(True)
+        self.plan_fwd_eval = self._plan_forward(False)
+        self.plan_loss = self._plan_loss()
+        self.plan_bwd = None
+        self._bwd_key = None
+
+    # ---------------------------------------------------------------------------------------------- forward plan
+    def _plan_forward(self, training):
+        e, d, lib = self.e, self.e.d, self.e.lib
+        B, S, Tp, M, MS = self.B, self.S, self.Tp, self.M, self.MS
+        H, Hd, E, Z, D, V, Lyr, dirs = d.hid, d.hd, d.emb, d.z, d.img, d.vt, d.layers, d.dirs
+        dt = e.dt
+        P = []
+        drop = training and d.dropout > 0
+        # a1 image rows (TrainerMultimodal.py:632-639) -- table pointer is patched in at run time (set_image_table)
+        self._img_call_index = len(P)
+        e._call(P, lib.vmmt_gather_rows, L.F32, None, D, self.img_idx.data_ptr(), self.img.p(), self.img.ld, B, D)
+        # a2 source embeddings
+        e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
+        # a3 encoder
+        x, xcols = self.Xs, E
+        for l in range(Lyr):
+            wih, bsum = e.sh["enc_wih_l%d" % l], e.sh["enc_b_l%d" % l]
+            e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hd,
+                    xcols, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+            for step in range(S):
+                arr = (L.LstmDirFwd * 2)()
+                for k in range(dirs):
+                    t = step if k == 0 else S - 1 - step
+                    tp = (t - 1) if k == 0 else (t + 1)
+                    first = step == 0
+                    whh = e.sh["enc_whh_l%d_d%d" % (l, k)]
+                    a = arr[k]
+                    a.h_prev = self.enc_out[l].p(tp * B, k * Hd) if not first else self.enc_out[l].p(t * B, k * Hd)
+                    a.ld_hprev = self.enc_out[l].ld
+                    a.c_prev = None if first else self.enc_c[l].p(tp * B, k * Hd)
+                    a.ld_cprev = self.enc_c[l].ld
+                    a.w_hh, a.ld_w = whh.p(), whh.ld
+                    a.gx, a.ld_gx = self.enc_gx[l].p(t * B, k * 4 * Hd), self.enc_gx[l].ld
+                    a.gates, a.ld_gates = self.enc_gates[l].p(t * B, k * 4 * Hd), self.enc_gates[l].ld
+                    a.c_out, a.ld_c = self.enc_c[l].p(t * B, k * Hd), self.enc_c[l].ld
+                    a.h_out, a.ld_h = self.enc_out[l].p(t * B, k * Hd), self.enc_out[l].ld
+                    a.h_n, a.ld_hn = self.hn[l].p(0, k * Hd), self.hn[l].ld
+                    a.c_n, a.ld_cn = self.cn[l].p(0, k * Hd), self.cn[l].ld
+                    a.t = t
+                    a.capture = 1 if k == 0 else 2
+                self._keep.append(arr)
+                if step == 0:
+                    # first step: h_prev must read zeros -> point at the (zeroed) hzero buffer
+                    if not hasattr(self, "hzero"):
+                        self.hzero = Buf(B, H, e.T, e.dev)
+                    for k in range(dirs):
+                        arr[k].h_prev, arr[k].ld_hprev = self.hzero.p(0, k * Hd), self.hzero.ld
+                e._call(P, lib.vmmt_lstm_step_fwd, dt, dirs, arr, self.src_len.data_ptr(), B, Hd)
+            x, xcols = self.enc_out[l], H
+            if l < Lyr - 1 and drop:
+                e._call(P, lib.vmmt_mul, dt, self.enc_out[l].p(), self.enc_out[l].ld, self.enc_mask[l].p(), self.enc_mask[l].ld,
+                        self.enc_xdrop[l].p(), self.enc_xdrop[l].ld, MS, H)
+                x = self.enc_xdrop[l]
+        ctx = self.enc_out[Lyr - 1]
+        # a4 q(z|x): masked mean of the detached memory, two 2-layer MLPs
+        e._call(P, lib.vmmt_masked_mean, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.hbar.p(), self.hbar.ld, B, S, H)
+        for br, outb, act in (("location", self.mu, L.ACT_NONE), ("scale", self.sigma, L.ACT_SOFTPLUS)):
+            w1, w2 = e.sh["q_%s_w1" % br], e.sh["q_%s_w2" % br]
+            e._gemm(P, L.GEMM_NT, self.hbar.p(), self.hbar.ld, w1.p(), w1.ld, self.q_h1[br].p(), self.q_h1[br].ld, B, Z, H,
+                    addend=e.pp("inf_net_global.%s.fc1.bias" % br), ld_add=Z, add_rows=1, act=L.ACT_RELU)
+            e._gemm(P, L.GEMM_NT, self.q_h1[br].p(), self.q_h1[br].ld, w2.p(), w2.ld, outb.p(), outb.ld, B, Z, Z,
+                    addend=e.pp("inf_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
+        # a5 fused mu/sigma -> sample -> KL
+        e._call(P, lib.vmmt_latent_fwd, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
+                self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
+        # a6 decoder
+        e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
+        wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
+        e._gemm(P, L.GEMM_NT, self.zT.p(), self.zT.ld, wz.p(), wz.ld, self.zx.p(), self.zx.ld, B, 4 * H, Z,
+                addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+        x, xcols = self.Xt, E
+        for l in range(Lyr):
+            if l == 0:
+                we = e.sh["dec_wih_l0_e"]
+                e._gemm(P, L.GEMM_NT, x.p(), x.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * H, E,
+                        addend=self.zx.p(), ld_add=self.zx.ld, add_rows=B, out_f32=1)
+            else:
+                wi, bs = e.sh["dec_wih_l%d" % l], e.sh["dec_b_l%d" % l]
+                e._gemm(P, L.GEMM_NT, x.p(), x.ld, wi.p(), wi.ld, self.dec_gx[l].p(), self.dec_gx[l].ld, M, 4 * H, H,
+                        addend=bs.p(), ld_add=bs.ld, add_rows=1, out_f32=1)
+            last = l == Lyr - 1
+            outb, ocol = (self.cat, H) if last else (self.dec_out[l], 0)
+            whh = e.sh["dec_whh_l%d" % l]
+            for t in range(Tp):
+                arr = (L.LstmDirFwd * 2)()
+                a = arr[0]
+                if t == 0:
+                    a.h_prev, a.ld_hprev = self.hn[l].p(), self.hn[l].ld
+                    a.c_prev, a.ld_cprev = self.cn[l].p(), self.cn[l].ld
+                else:
+                    a.h_prev, a.ld_hprev = outb.p((t - 1) * B, ocol), outb.ld
+                    a.c_prev, a.ld_cprev = self.dec_c[l].p((t - 1) * B), self.dec_c[l].ld
+                a.w_hh, a.ld_w = whh.p(), whh.ld
+                a.gx, a.ld_gx = self.dec_gx[l].p(t * B), self.dec_gx[l].ld
+                a.gates, a.ld_gates = self.dec_gates[l].p(t * B), self.dec_gates[l].ld
+                a.c_out, a.ld_c = self.dec_c[l].p(t * B), self.dec_c[l].ld
+                a.h_out, a.ld_h = outb.p(t * B, ocol), outb.ld
+                a.h_n, a.c_n, a.t, a.capture = None, None, t, 0
+                self._keep.append(arr)
+                e._call(P, lib.vmmt_lstm_step_fwd, dt, 1, arr, None, B, H)
+            if not last:
+                x, xcols = self.dec_out[l], H
+                if drop:
+                    e._call(P, lib.vmmt_mul, dt, self.dec_out[l].p(), self.dec_out[l].ld, self.dec_mask[l].p(), self.dec_mask[l].ld,
+                            self.dec_xdrop[l].p(), self.dec_xdrop[l].ld, M, H)
+                    x = self.dec_xdrop[l]
+        # a7 attention
+        wa, wo = e.sh["wa"], e.sh["wo"]
+        e._gemm(P, L.GEMM_NT, self.cat.p(0, H), self.cat.ld, wa.p(), wa.ld, self.Q.p(), self.Q.ld, M, H, H)
+        e._call(P, lib.vmmt_attn_fwd, dt, self.Q.p(), self.Q.ld, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.cat.p(), self.cat.ld,
+                self.probs.data_ptr(), Tp, B, S, H)
+        e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * H, act=L.ACT_TANH)
+        if drop:
+            e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
+        # a8 image network (location branch only; the scale branch is dead, H6 / VILoss.py:321)
+        e._call(P, lib.vmmt_gate_fwd, dt, self.z32.p(), e.pp("inf_net_image.gate_affine_transform.weight"),
+                e.pp("inf_net_image.gate_affine_transform.bias"), self.gate.data_ptr(), self.zt.p(), self.zt.ld, B, Z)
+        w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
+        e._gemm(P, L.GEMM_NT, self.zt.p(), self.zt.ld, w1.p(), w1.ld, self.h1v.p(), self.h1v.ld, B, D, Z,
+                addend=e.pp("inf_net_image.location.fc1.bias"), ld_add=D, add_rows=1, act=L.ACT_RELU)
+        e._gemm(P, L.GEMM_NT, self.h1v.p(), self.h1v.ld, w2.p(), w2.ld, self.mu_v.p(), self.mu_v.ld, B, D, D,
+                addend=e.pp("inf_net_image.location.fc2.bias"), ld_add=D, add_rows=1, out_f32=1)
+        return P
+
+    def _plan_loss(self):
+        """forward part of NMTVIModel1LossCompute._compute_loss (VILoss.py:217-513): statistics only."""
+        e, d, lib = self.e, self.e.d, self.e.lib
+        P = []
+        wg = e.sh["wg"]
+        e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
+                self.M, d.vt, d.hid, PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), self.part_idx.data_ptr(),
+                self.tgt_logit.data_ptr(), self.lse.data_ptr(), self.tok_nll.data_ptr(), self.stats.data_ptr())
+        return P
+
+    # ---------------------------------------------------------------------------------------------- backward plan
+    def _plan_backward(self, inv_norm, batch_global, kl_mult, use_freebits, margin, training_dropout):
+        e, d, lib = self.e, self.e.d, self.e.lib
+        B, S, Tp, M, MS = self.B, self.S, self.Tp, self.M, self.MS
+        H, Hd, E, Z, D, V, Lyr, dirs = d.hid, d.hd, d.emb, d.z, d.img, d.vt, d.layers, d.dirs
+        dt = e.dt
+        P = []
+        drop = training_dropout and d.dropout > 0
+        wg = e.sh["wg"]
+        # --- image term + its network (no dependence on the text path: z is detached) -------------------------
+        e._call(P, lib.vmmt_image_loss, dt, self.mu_v.p(), self.mu_v.ld, self.img.p(), self.img.ld, B, D, inv_norm,
+                self.dmu_v.p(), self.dmu_v.ld, self.stats.data_ptr())
+        w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
+        e._gemm(P, L.GEMM_TN, self.dmu_v.p(), self.dmu_v.ld, self.h1v.p(), self.h1v.ld, e.gp("inf_net_image.location.fc2.weight"), D,
+                D, D, B, out_f32=1)
+        e._call(P, lib.vmmt_colsum, dt, self.dmu_v.p(), self.dmu_v.ld, B, D, e.gp("inf_net_image.location.fc2.bias"))
+        e._gemm(P, L.GEMM_NN, self.dmu_v.p(), self.dmu_v.ld, w2.p(), w2.ld, self.dh1v.p(), self.dh1v.ld, B, D, D)
+        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.dh1v.p(), self.dh1v.ld, self.h1v.p(), self.h1v.ld, None, 0,
+                self.dh1v.p(), self.dh1v.ld, B, D)
+        e._gemm(P, L.GEMM_TN, self.dh1v.p(), self.dh1v.ld, self.zt.p(), self.zt.ld, e.gp("inf_net_image.location.fc1.weight"), Z,
+                D, Z, B, out_f32=1)
+        e._call(P, lib.vmmt_colsum, dt, self.dh1v.p(), self.dh1v.ld, B, D, e.gp("inf_net_image.location.fc1.bias"))
+        e._gemm(P, L.GEMM_NN, self.dh1v.p(), self.dh1v.ld, w1.p(), w1.ld, self.dzt.p(), self.dzt.ld, B, Z, D, out_f32=1)
+        e._call(P, lib.vmmt_gate_bwd, self.dzt.p(), self.dzt.ld, self.z32.p(), self.gate.data_ptr(),
+                e.gp("inf_net_image.gate_affine_transform.weight"), e.gp("inf_net_image.gate_affine_transform.bias"), B, Z)
+        # --- KL term -> q(z|x) networks (mu, sigma receive gradient only through the KL: H2) ------------------
+        self._latent_bwd_index = len(P)
+        e._call(P, lib.vmmt_latent_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
+        for br, dy in (("location", self.q_dmu), ("scale", self.q_dpre)):
+            w2q = e.sh["q_%s_w2" % br]
+            pre = "inf_net_global.%s" % br
+            e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1)
+            e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"))
+            e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2q.p(), w2q.ld, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, Z)
+            e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.q_dh1[br].p(), self.q_dh1[br].ld, self.q_h1[br].p(), self.q_h1[br].ld,
+                    None, 0, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z)
+            e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, self.hbar.p(), self.hbar.ld, e.gp(pre + ".fc1.weight"), H,
+                    Z, H, B, out_f32=1)
+            e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"))
+        # --- generator: G^T, dWg = G^T O, db = rowsum(G^T), dO = G Wg ---------------------------------------------
+        e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
+                M, V, H, PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
+        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1)
+        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.ones_col().p(), self.ones_col().ld, e.gp("generator.0.bias"), 1,
+                V, 1, M, out_f32=1, tile=64)
+        e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO.p(), self.dO.ld, M, H, V)
+        # --- dropout + tanh backward, linear_out ---------------------------------------------------------------
+        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_TANH, self.dO.p(), self.dO.ld, self.AH.p(), self.AH.ld,
+                self.out_mask.p() if drop else None, self.out_mask.ld if drop else 0, self.dPre.p(), self.dPre.ld, M, H)
+        wo, wa = e.sh["wo"], e.sh["wa"]
+        e._gemm(P, L.GEMM_TN, self.dPre.p(), self.dPre.ld, self.cat.p(), self.cat.ld, e.gp("decoder.attn.linear_out.weight"), 2 * H,
+                H, 2 * H, M, out_f32=1)
+        e._gemm(P, L.GEMM_NN, self.dPre.p(), self.dPre.ld, wo.p(), wo.ld, self.dcat.p(), self.dcat.ld, M, 2 * H, H)
+        ctx = self.enc_out[Lyr - 1]
+        e._call(P, lib.vmmt_attn_bwd, dt, self.dcat.p(), self.dcat.ld, self.probs.data_ptr(), self.Q.p(), self.Q.ld, ctx.p(), ctx.ld,
+                self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, H)
+        e._gemm(P, L.GEMM_TN, self.dQ.p(), self.dQ.ld, self.cat.p(0, H), self.cat.ld, e.gp("decoder.attn.linear_in.weight"), H,
+                H, H, M, out_f32=1)
+        e._gemm(P, L.GEMM_NN, self.dQ.p(), self.dQ.ld, wa.p(), wa.ld, self.dR.p(), self.dR.ld, M, H, H,
+                addend=self.dcat.p(0, H), ld_add=self.dcat.ld, add_rows=-1, add_is_T=1)
+        # --- decoder LSTM backward -------------------------------------------------------------------------------
+        dh_above = self.dR
+        for l in reversed(range(Lyr)):
+            last = l == Lyr - 1
+            outb, ocol = (self.cat, H) if last else (self.dec_out[l], 0)
+            whhT = e.sh["dec_whhT_l%d" % l]
+            dg = self.dec_dgates[l]
+            e._call(P, _memset, self.dec_dcc[l].t)
+            for t in reversed(range(Tp)):
+                arr = (L.LstmDirBwd * 2)()
+                a = arr[0]
+                if t < Tp - 1:
+                    a.dgates_next, a.ld_dgn = dg.p((t + 1) * B), dg.ld
+                a.w_hh_t, a.ld_wt = whhT.p(), whhT.ld
+                a.dh_above, a.ld_dha = dh_above.p(t * B), dh_above.ld
+                a.gates, a.ld_gates = self.dec_gates[l].p(t * B), self.dec_gates[l].ld
+                a.c_t, a.ld_ct = self.dec_c[l].p(t * B), self.dec_c[l].ld
+                if t > 0:
+                    a.c_prev, a.ld_cp = self.dec_c[l].p((t - 1) * B), self.dec_c[l].ld
+                else:
+                    a.c_prev, a.ld_cp = self.cn[l].p(), self.cn[l].ld
+                a.dc_carry, a.ld_dcc = self.dec_dcc[l].p(), self.dec_dcc[l].ld
+                a.dgates_out, a.ld_dgo = dg.p(t * B), dg.ld
+                a.t, a.inject = t, 0
+                self._keep.append(arr)
+                e._call(P, lib.vmmt_lstm_step_bwd, dt, 1, arr, None, B, H, 0)
+            arr = (L.LstmDirBwd * 2)()
+            a = arr[0]
+            a.dgates_next, a.ld_dgn = dg.p(0), dg.ld
+            a.w_hh_t, a.ld_wt = whhT.p(), whhT.ld
+            a.dh0_out, a.ld_dh0 = self.dec_dh0[l].p(), self.dec_dh0[l].ld
+            self._keep.append(arr)
+            e._call(P, lib.vmmt_lstm_step_bwd, dt, 1, arr, None, B, H, 1)
+            # weight gradients
+            gw = "decoder.rnn.weight_hh_l%d" % l
+            if Tp > 1:
+                e._gemm(P, L.GEMM_TN, dg.p(B), dg.ld, outb.p(0, ocol), outb.ld, e.gp(gw), H, 4 * H, H, (Tp - 1) * B, out_f32=1)
+            e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * H, H, B, out_f32=1,
+                    accumulate=1 if Tp > 1 else 0)
+            e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_ih_l%d" % l))
+            e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_hh_l%d" % l))
+            gi = "decoder.rnn.weight_ih_l%d" % l
+            if l == 0:
+                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * H, E, M, out_f32=1)
+                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * H, Z, M, out_f32=1, b_kmod=B)
+                we = e.sh["dec_wih_l0_e"]
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                        M, E, 4 * H, out_f32=1, scatter_ids=self.tgt_in.data_ptr())
+            else:
+                xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
+                wi = e.sh["dec_wih_l%d" % l]
+                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1)
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wi.p(), wi.ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H, 4 * H)
+                if drop:
+                    e._call(P, lib.vmmt_mul, dt, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, self.dec_mask[l - 1].p(),
+                            self.dec_mask[l - 1].ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H)
+                dh_above = self.dec_dx[l - 1]
+        # --- encoder LSTM backward ---------------------------------------------------------------------------------
+        dh_above = self.dctx
+        for l in reversed(range(Lyr)):
+            dg = self.enc_dgates[l]
+            e._call(P, _memset, self.enc_dcc[l].t)
+            for step in range(S):
+                arr = (L.LstmDirBwd * 2)()
+                for k in range(dirs):
+                    # backward visits the steps in the reverse of the forward order of that direction
+                    t = (S - 1 - step) if k == 0 else step
+                    tn = (t + 1) if k == 0 else (t - 1)        # step processed just before (its dgates feed the GEMM)
+                    tp = (t - 1) if k == 0 else (t + 1)        # forward predecessor (c_prev)
+                    a = arr[k]
+                    whhT = e.sh["enc_whhT_l%d_d%d" % (l, k)]
+                    if step > 0:
+                        a.dgates_next, a.ld_dgn = dg.p(tn * B, k * 4 * Hd), dg.ld
+                    a.w_hh_t, a.ld_wt = whhT.p(), whhT.ld
+                    a.dh_above, a.ld_dha = dh_above.p(t * B, k * Hd), dh_above.ld
+                    a.gates, a.ld_gates = self.enc_gates[l].p(t * B, k * 4 * Hd), self.enc_gates[l].ld
+                    a.c_t, a.ld_ct = self.enc_c[l].p(t * B, k * Hd), self.enc_c[l].ld
+                    if 0 <= tp < S:
+                        a.c_prev, a.ld_cp = self.enc_c[l].p(tp * B, k * Hd), self.enc_c[l].ld
+                    a.dc_carry, a.ld_dcc = self.enc_dcc[l].p(0, k * Hd), self.enc_dcc[l].ld
+                    a.dgates_out, a.ld_dgo = dg.p(t * B, k * 4 * Hd), dg.ld
+                    a.dh_n, a.ld_dhn = self.dec_dh0[l].p(0, k * Hd), self.dec_dh0[l].ld
+                    a.dc_n, a.ld_dcn = self.dec_dcc[l].p(0, k * Hd), self.dec_dcc[l].ld
+                    a.t = t
+                    a.inject = 1 if k == 0 else 2
+                self._keep.append(arr)
+                e._call(P, lib.vmmt_lstm_step_bwd, dt, dirs, arr, self.src_len.data_ptr(), B, Hd, 0)
+            xin = (self.Xs if l == 0 else (self.enc_xdrop[l - 1] if drop else self.enc_out[l - 1]))
+            xcols = E if l == 0 else H
+            for k, suf in enumerate([""] + (["_reverse"] if d.brnn else [])):
+                gw = "encoder.rnn.weight_hh_l%d%s" % (l, suf)
+                if S > 1:
+                    if k == 0:   # h_prev[t] = out[t-1]
+                        e._gemm(P, L.GEMM_TN, dg.p(B, k * 4 * Hd), dg.ld, self.enc_out[l].p(0, k * Hd), self.enc_out[l].ld, e.gp(gw), Hd,
+                                4 * Hd, Hd, (S - 1) * B, out_f32=1)
+                    else:        # h_prev[t] = out[t+1]
+                        e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, self.enc_out[l].p(B, k * Hd), self.enc_out[l].ld, e.gp(gw), Hd,
+                                4 * Hd, Hd, (S - 1) * B, out_f32=1)
+                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)))
+                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
+                e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, xin.p(), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)), xcols,
+                        4 * Hd, xcols, MS, out_f32=1)
+            wih = e.sh["enc_wih_l%d" % l]
+            if l == 0:
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                        MS, E, dirs * 4 * Hd, out_f32=1, scatter_ids=self.src.data_ptr())
+            else:
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H, dirs * 4 * Hd)
+                if drop:
+                    e._call(P, lib.vmmt_mul, dt, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, self.enc_mask[l - 1].p(),
+                            self.enc_mask[l - 1].ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H)
+                dh_above = self.enc_dx[l - 1]
+        return P
+
+    def _latent_bwd_args(self, batch_global, kl_mult, use_freebits, margin, inv_norm):
+        return (self.e.dt, self.mu.p(), self.sigma.p(), self.stats.data_ptr() + 4 * L.STAT_KL_SUM, float(batch_global),
+                float(kl_mult), 1 if use_freebits else 0, float(margin), float(inv_norm), self.q_dmu.p(), self.q_dmu.ld,
+                self.q_dpre.p(), self.q_dpre.ld, self.B, self.e.d.z)
+
+    def backward_plan(self, inv_norm, batch_global, kl_mult, use_freebits, margin, drop):
+        key = (float(inv_norm), float(batch_global), bool(drop))
+        if self._bwd_key != key:
+            self.plan_bwd = self._plan_backward(inv_norm, batch_global, kl_mult, use_freebits, margin, drop)
+            self._bwd_key = key
+        fn, _, name, keep = self.plan_bwd[self._latent_bwd_index]
+        self.plan_bwd[self._latent_bwd_index] = (fn, self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm),
+                                                 name, keep)
+        return self.plan_bwd
+
+    def ones_col(self):
+        if not hasattr(self, "_ones"):
+            self._ones = Buf(self.M, 1, self.e.T, self.e.dev, fill=1.0)
+        return self._ones
+
+
+def _memset(t, stream):
+    """plan entry: zero a torch tensor on the current stream (hipMemsetAsync through torch)."""
+    t.zero_()
+    return 0
+
+
+_memset.__name__ = "memset"
+
+
+# ======================================================================================================= step API
+def _engine_methods():
+    def set_image_table(self, table):
+        """`table`: fp32 [N, D] image-feature array (numpy or tensor); kept resident in HBM
+        (reference: host numpy + per-step fancy-index + H2D copy, TrainerMultimodal.py:632-639)."""
+        t = torch.as_tensor(table)
+        self.img_table = t.to(device=self.dev, dtype=torch.float32).contiguous()
+        assert self.img_table.shape[1] == self.d.img
+
+    def stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def forward(self, src, src_len, tgt, img_indices, training=True, eps=None, masks=None, table=None):
+        """NMTVIModel.forward (Models.py:850-1011).  src [S,B] int64, src_len [B], tgt [T,B] (incl. <s>, </s>),
+        img_indices [B] rows of the resident image table.  Returns the Workspace holding every activation."""
+        S, B = int(src.shape[0]), int(src.shape[1])
+        Tp = int(tgt.shape[0]) - 1
+        if S > 64:
+            raise RuntimeError("source length %d > 64 not supported by the attention kernel" % S)
+        ws = self.workspace(B, S, Tp)
+        st = self.stream()
+        self.refresh_shadows(st)
+        dev = self.dev
+        ws.src.copy_(src.reshape(-1), non_blocking=True)
+        ws.tgt_in.copy_(tgt[:-1].reshape(-1), non_blocking=True)      # Models.py:867
+        ws.y.copy_(tgt[1:].reshape(-1), non_blocking=True)            # VILoss.py:205
+        ws.src_len.copy_(src_len.reshape(-1), non_blocking=True)
+        ws.img_idx.copy_(torch.as_tensor(img_indices).reshape(-1), non_blocking=True)
+        ws.stats.zero_()
+        tab = table if table is not None else getattr(self, "img_table", None)
+        if tab is None:
+            raise RuntimeError("no image-feature table: call set_image_table() first")
+        d = self.d
+        if training:
+            if eps is not None:
+                ws.eps.t.copy_(eps.to(device=dev, dtype=torch.float32))
+            else:
+                self.rng_counter += 1
+                L.check(self.lib.vmmt_randn(ws.eps.p(), B * d.z, self.rng_counter, st), "vmmt_randn")
+            if d.dropout > 0:
+                mk = [("dec_out", ws.out_mask)] + [("enc_l%d" % l, ws.enc_mask[l]) for l in range(d.layers - 1)] + \
+                     [("dec_l%d" % l, ws.dec_mask[l]) for l in range(d.layers - 1)]
+                for name, buf in mk:
+                    if masks is not None and name in masks:
+                        buf.view().copy_(masks[name].reshape(buf.rows, buf.cols).to(device=dev, dtype=self.T))
+                    else:
+                        self.rng_counter += 1
+                        # the mask is generated over the padded buffer (pad columns are never read)
+                        L.check(self.lib.vmmt_dropout_mask(self.dt, buf.p(), buf.rows * buf.ld, d.dropout, self.rng_counter, st),
+                                "vmmt_dropout_mask")
+        plan = ws.plan_fwd_train if training else ws.plan_fwd_eval
+        fn, args, name, keep = plan[ws._img_call_index]
+        plan[ws._img_call_index] = (fn, (L.F32, tab.data_ptr(), tab.shape[1]) + tuple(args[3:]), name, keep)
+        self._run(plan, st)
+        ws.training = training
+        return ws
+
+    def loss(self, ws):
+        """statistics of _compute_loss without backward (monolithic_compute_loss, Loss.py:68-86)."""
+        st = self.stream()
+        self._run(ws.plan_loss, st)
+        L.check(self.lib.vmmt_image_loss(self.dt, ws.mu_v.p(), ws.mu_v.ld, ws.img.p(), ws.img.ld, ws.B, self.d.img, 0.0, None, 0,
+                                         ws.stats.data_ptr(), st), "vmmt_image_loss")
+        return ws
+
+    def loss_backward(self, ws, normalization=None, batch_global=None, kl_mult=1.0, use_freebits=False, margin=0.0,
+                      zero_grad=True):
+        """sharded_compute_loss (Loss.py:88-132): loss statistics + `loss.div(normalization).backward()`
+        through the whole model into the gradient arena.  H3: all T' rows are used (monolithic semantics)."""
+        st = self.stream()
+        B = ws.B
+        norm = float(normalization if normalization is not None else B)
+        bg = float(batch_global if batch_global is not None else B)
+        if zero_grad:
+            self.flat_g.zero_()
+        self._run(ws.plan_loss, st)
+        plan = ws.backward_plan(1.0 / norm, bg, kl_mult, use_freebits, margin, bool(ws.training))
+        self._run(plan, st)
+        return ws
+
+    def read_stats(self, ws, batch_global=None, kl_mult=1.0, use_freebits=False, margin=0.0):
+        """One D2H copy of the statistics vector -> the reference's loss_data dict (VILoss.py:483-497)."""
+        s = ws.stats.tolist()
+        B = float(batch_global if batch_global is not None else ws.B)
+        kl_before = s[L.STAT_KL_SUM] / B
+        kl_after = kl_before * kl_mult
+        if use_freebits:
+            kl_after = max(kl_after, margin)
+        img_logprob = s[L.STAT_IMG_LOGPROB]
+        nmt = s[L.STAT_NLL]
+        return dict(nmt=nmt, td_kl_before=kl_before, td_kl_after=kl_after, td_kl_multiplier=kl_mult,
+                    img_feats_loss=img_logprob, img_feats_cos=s[L.STAT_IMG_COS] / float(ws.B),
+                    elbo=nmt - img_logprob + kl_after, n_words=int(round(s[L.STAT_NWORDS])),
+                    n_correct=int(round(s[L.STAT_NCORRECT])))
+
+    def optim_step(self, lr=0.002, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-9, grad_scale=1.0):
+        """Optim.step (Optim.py:78-96): global-norm clip + Adam over the arena, then shadows are stale."""
+        st = self.stream()
+        if not hasattr(self, "_sumsq"):
+            self._sumsq = torch.zeros(4, dtype=torch.float32, device=self.dev)
+        self._sumsq.zero_()
+        if max_grad_norm:
+            L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), st), "vmmt_sumsq")
+        self.step_count += 1
+        L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                        self.n_opt, lr, beta1, beta2, eps, self.step_count, float(max_grad_norm or 0.0),
+                                        self._sumsq.data_ptr(), grad_scale, st), "vmmt_adam_step")
+        self.shadows_dirty = True
+
+    for k, v in list(locals().items()):
+        if callable(v):
+            setattr(Engine, k, v)
+
+
+_engine_methods()
