@@ -328,7 +328,8 @@ class Workspace(object):
         self._keep = []
         self.plan_fwd_train = self._plan_forward(True)
         self.plan_fwd_eval = self._plan_forward(False)
-        self.plan_loss = self._plan_loss()
+        self.plan_loss_train = self._plan_loss(True)
+        self.plan_loss_eval = self._plan_loss(False)
         self.plan_bwd = None
         self._bwd_key = None
 
@@ -458,12 +459,13 @@ class Workspace(object):
                 addend=e.pp("inf_net_image.location.fc2.bias"), ld_add=D, add_rows=1, out_f32=1)
         return P
 
-    def _plan_loss(self):
+    def _plan_loss(self, training):
         """forward part of NMTVIModel1LossCompute._compute_loss (VILoss.py:217-513): statistics only."""
         e, d, lib = self.e, self.e.d, self.e.lib
         P = []
         wg = e.sh["wg"]
-        e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
+        O = self.O if (training and d.dropout > 0) else self.AH      # eval: nn.Dropout is the identity
+        e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(),
                 self.M, d.vt, d.hid, PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), self.part_idx.data_ptr(),
                 self.tgt_logit.data_ptr(), self.lse.data_ptr(), self.tok_nll.data_ptr(), self.stats.data_ptr())
         return P
@@ -732,7 +734,7 @@ def _engine_methods():
     def loss(self, ws):
         """statistics of _compute_loss without backward (monolithic_compute_loss, Loss.py:68-86)."""
         st = self.stream()
-        self._run(ws.plan_loss, st)
+        self._run(ws.plan_loss_train if ws.training else ws.plan_loss_eval, st)
         L.check(self.lib.vmmt_image_loss(self.dt, ws.mu_v.p(), ws.mu_v.ld, ws.img.p(), ws.img.ld, ws.B, self.d.img, 0.0, None, 0,
                                          ws.stats.data_ptr(), st), "vmmt_image_loss")
         return ws
@@ -747,7 +749,9 @@ def _engine_methods():
         bg = float(batch_global if batch_global is not None else B)
         if zero_grad:
             self.flat_g.zero_()
-        self._run(ws.plan_loss, st)
+        if not ws.training:
+            raise RuntimeError("loss_backward() after an eval-mode forward")
+        self._run(ws.plan_loss_train, st)
         plan = ws.backward_plan(1.0 / norm, bg, kl_mult, use_freebits, margin, bool(ws.training))
         self._run(plan, st)
         return ws
