@@ -31,11 +31,13 @@ template <> struct Traits<float> {
   static constexpr int VEC = 4;     // elements per 16-byte vector
   static constexpr int KSTEP = 2;   // K per MFMA
   static constexpr int PAD = 4;     // LDS row padding (elements), keeps rows 16-byte aligned
+  static constexpr int PADKS = 4;   // padding of a K-strided image row ([k][rows + PADKS])
 };
 template <> struct Traits<bf16_t> {
   static constexpr int VEC = 8;
   static constexpr int KSTEP = 16;
   static constexpr int PAD = 8;     // 80-byte rows: ds_read_b128 by 16 consecutive rows is conflict-free
+  static constexpr int PADKS = 32;  // [k][rows + 32]: the 4 k-rows of a ds_read_b64_tr_b16 block land 16 banks apart
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -73,7 +75,9 @@ struct GateMap {     // LSTM gate rows: local n = g * BU + u  ->  g * H + u0 + u
 
 // ----------------------------------------------------------------------------------------------
 // Tile staging: global -> registers (16-byte vectors when aligned and in range, scalar otherwise)
-// -> LDS image [rows][BK + PAD] (k contiguous), whatever the global layout.
+// -> LDS image: K-contiguous operands [rows][BK + PAD]; K-strided operands keep their global orientation
+//    [BK][rows + PADKS] (coalesced 16-byte loads and stores) and are transposed on the way to the MFMA operand
+//    registers by ds_read_b64_tr_b16 (bf16) or by plain per-lane reads (fp32).
 //   KC = true : operand stored [row][k] (k contiguous), element (row,k) at P[row*ld + k]
 //   KC = false: operand stored [k][row] (row contiguous), element (row,k) at P[kmap(k)*ld + row]
 //               (kmod > 0: k index taken modulo kmod -- used to broadcast z over time steps)
@@ -81,7 +85,8 @@ struct GateMap {     // LSTM gate rows: local n = g * BU + u  ->  g * H + u0 + u
 template <class T, int ROWS, int BK, int NT, bool KC>
 struct Stager {
   static constexpr int VEC = Traits<T>::VEC;
-  static constexpr int STRIDE = BK + Traits<T>::PAD;
+  static constexpr int STRIDE = KC ? BK + Traits<T>::PAD : ROWS + Traits<T>::PADKS;
+  static constexpr int ELEMS = KC ? ROWS * STRIDE : BK * STRIDE;
   static constexpr int NVEC = ROWS * BK / VEC;
   static constexpr int PER = (NVEC + NT - 1) / NT;
   static_assert(ROWS % VEC == 0 && BK % VEC == 0, "tile");
@@ -134,29 +139,53 @@ struct Stager {
         *reinterpret_cast<u32x4*>(S + row * STRIDE + kk) = *reinterpret_cast<const u32x4*>(regs[i]);
       } else {
         int kk = v / (ROWS / VEC), row = (v % (ROWS / VEC)) * VEC;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) S[(row + e) * STRIDE + kk] = regs[i][e];
+        *reinterpret_cast<u32x4*>(S + kk * STRIDE + row) = *reinterpret_cast<const u32x4*>(regs[i]);
       }
     }
   }
 };
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// MFMA 32x32x16 bf16 operand fragment for tile rows [off, off+32), k-step ks: lane (r = lane&31, h = lane>>5) needs
+// the 8 elements (row off+r, k = 16 ks + 8h .. +7).
+template <int ROWS, int BK, bool KC>
+__device__ __forceinline__ bf16x8 frag_bf16(const bf16_t* __restrict__ img, int off, int ks, int lane) {
+  if constexpr (KC) {
+    constexpr int STRIDE = BK + Traits<bf16_t>::PAD;
+    return *reinterpret_cast<const bf16x8*>(img + (off + (lane & 31)) * STRIDE + ks * 16 + 8 * (lane >> 5));
+  } else {
+    // image [k][row]: each 16-lane group g transposes a 4(k) x 16(row) block per read; lane 4q+p of the group supplies
+    // the address of k-row q, rows 4p..4p+3 and receives row (lane&15) of the block with k = q' in element q'.
+    constexpr int STRIDE = ROWS + Traits<bf16_t>::PADKS;
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const bf16_t* a0 = img + (ks * 16 + 8 * (g >> 1) + q) * STRIDE + off + 16 * (g & 1) + 4 * p;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * STRIDE));
+    s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+template <int ROWS, int BK, bool KC>
+__device__ __forceinline__ float frag_f32(const float* __restrict__ img, int off, int ks, int lane) {
+  if constexpr (KC) return img[(off + (lane & 31)) * (BK + Traits<float>::PAD) + ks * 2 + (lane >> 5)];
+  else return img[(ks * 2 + (lane >> 5)) * (ROWS + Traits<float>::PADKS) + off + (lane & 31)];
+}
+
 // One BK-deep slab of MFMAs for a wave: TI x TJ tiles of 32x32.
-template <class T, int BK, int TI, int TJ>
+template <class T, int BM, int BN, int BK, bool A_KC, bool B_KC, int TI, int TJ>
 __device__ __forceinline__ void mfma_slab(const T* __restrict__ As, const T* __restrict__ Bs, const int (&aoff)[TI],
                                           const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], int lane) {
-  constexpr int STRIDE = BK + Traits<T>::PAD;
-  const int r = lane & 31, h = lane >> 5;
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 a[TI], b[TJ];
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
-        a[i] = *reinterpret_cast<const bf16x8*>(As + (aoff[i] + r) * STRIDE + ks * 16 + 8 * h);
+      for (int i = 0; i < TI; ++i) a[i] = frag_bf16<BM, BK, A_KC>(As, aoff[i], ks, lane);
 #pragma unroll
-      for (int j = 0; j < TJ; ++j)
-        b[j] = *reinterpret_cast<const bf16x8*>(Bs + (boff[j] + r) * STRIDE + ks * 16 + 8 * h);
+      for (int j = 0; j < TJ; ++j) b[j] = frag_bf16<BN, BK, B_KC>(Bs, boff[j], ks, lane);
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -167,9 +196,9 @@ __device__ __forceinline__ void mfma_slab(const T* __restrict__ As, const T* __r
     for (int ks = 0; ks < BK / 2; ++ks) {
       float a[TI], b[TJ];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) a[i] = As[(aoff[i] + r) * STRIDE + ks * 2 + h];
+      for (int i = 0; i < TI; ++i) a[i] = frag_f32<BM, BK, A_KC>(As, aoff[i], ks, lane);
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) b[j] = Bs[(boff[j] + r) * STRIDE + ks * 2 + h];
+      for (int j = 0; j < TJ; ++j) b[j] = frag_f32<BN, BK, B_KC>(Bs, boff[j], ks, lane);
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -185,12 +214,11 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda,
                                               const T* __restrict__ B, long ldb, const BMap& bmap, int K, int a_kmod,
                                               int b_kmod, const int (&aoff)[TI], const int (&boff)[TJ],
                                               f32x16 (&acc)[TI][TJ], T* __restrict__ smem) {
-  constexpr int STRIDE = BK + Traits<T>::PAD;
-  T* As = smem;
-  T* Bs = smem + BM * STRIDE;
-  const int tid = threadIdx.x, lane = tid & 63;
   Stager<T, BM, BK, NT, A_KC> sa;
   Stager<T, BN, BK, NT, B_KC> sb;
+  T* As = smem;
+  T* Bs = smem + ((Stager<T, BM, BK, NT, A_KC>::ELEMS + 7) & ~7);
+  const int tid = threadIdx.x, lane = tid & 63;
   if (K <= 0) return;
   sa.load(A, lda, amap, 0, K, a_kmod, tid);
   sb.load(B, ldb, bmap, 0, K, b_kmod, tid);
@@ -202,13 +230,15 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda,
       sa.load(A, lda, amap, k0 + BK, K, a_kmod, tid);
       sb.load(B, ldb, bmap, k0 + BK, K, b_kmod, tid);
     }
-    mfma_slab<T, BK, TI, TJ>(As, Bs, aoff, boff, acc, lane);
+    mfma_slab<T, BM, BN, BK, A_KC, B_KC, TI, TJ>(As, Bs, aoff, boff, acc, lane);
     __syncthreads();
   }
 }
 
-template <class T, int BM, int BN, int BK>
-constexpr int gemm_smem_elems() { return (BM + BN) * (BK + Traits<T>::PAD); }
+template <class T, int BM, int BN, int BK, bool A_KC = true, bool B_KC = true>
+constexpr int gemm_smem_elems() {
+  return ((Stager<T, BM, BK, 64, A_KC>::ELEMS + 7) & ~7) + Stager<T, BN, BK, 64, B_KC>::ELEMS;
+}
 
 // accumulator element -> (row, col) inside a 32x32 tile
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }

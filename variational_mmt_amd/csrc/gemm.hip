@@ -98,7 +98,7 @@ template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
 static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
-  size_t smem = gemm_smem_elems<T, BM, BN, 32>() * sizeof(T);
+  size_t smem = gemm_smem_elems<T, BM, BN, 32, A_KC, B_KC>() * sizeof(T);
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC>), dim3(tm * tn), dim3(NT), smem, st,
                      (const T*)a->A, (long)a->lda, (const T*)a->B, (long)a->ldb, a->M, a->N, a->K, a->a_kmod,
                      a->b_kmod, tn, epi);

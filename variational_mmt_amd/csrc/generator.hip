@@ -108,34 +108,53 @@ __global__ void __launch_bounds__(256) gen_kernel(GenArgs a, int tiles_m) {
   }
 }
 
-// per token: logsumexp, NLL, argmax-correct; block-reduced sums are added to stats[0..2]
-__global__ void gen_combine_kernel(const float* __restrict__ part_max, const float* __restrict__ part_sum,
+// per token: logsumexp, NLL, argmax-correct; block-reduced sums are added to stats[0..2].
+// Block = 16 waves x 64 tokens: wave w folds partials w, w+16, ... (coalesced along tokens) with an online
+// (max, sum-exp, argmax) merge, then the 16 wave results are merged through LDS.
+__global__ void __launch_bounds__(1024) gen_combine_kernel(const float* __restrict__ part_max, const float* __restrict__ part_sum,
                                    const int* __restrict__ part_idx, const float* __restrict__ tgt_logit,
                                    const long long* __restrict__ y, int M, int npart, int pad, float* __restrict__ lse,
                                    float* __restrict__ tok_nll, float* __restrict__ stats) {
-  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int m = blockIdx.x * 64 + lane;
+  float mx = -INFINITY, s = 0.f;
+  int mi = 0x7fffffff;
+  if (m < M) {
+    for (int p = w; p < npart; p += 16) {
+      float x = part_max[(long)p * M + m], xs = part_sum[(long)p * M + m];
+      int xi = part_idx[(long)p * M + m];
+      if (x > mx || (x == mx && xi < mi)) mi = xi;
+      float nm = fmaxf(mx, x);
+      if (nm != -INFINITY) s = s * __expf(mx - nm) + xs * __expf(x - nm);
+      mx = nm;
+    }
+  }
+  __shared__ float smx[16][64], ssm[16][64];
+  __shared__ int smi[16][64];
+  smx[w][lane] = mx; ssm[w][lane] = s; smi[w][lane] = mi;
+  __syncthreads();
+  if (w != 0) return;
   float nll = 0.f, nw = 0.f, nc = 0.f;
   if (m < M) {
-    float mx = -INFINITY;
-    int mi = 0x7fffffff;
-    for (int p = 0; p < npart; ++p) {
-      float x = part_max[(long)p * M + m];
-      int xi = part_idx[(long)p * M + m];
-      if (x > mx || (x == mx && xi < mi)) { mx = x; mi = xi; }
+    for (int k = 1; k < 16; ++k) {
+      float x = smx[k][lane], xs = ssm[k][lane];
+      int xi = smi[k][lane];
+      if (x > mx || (x == mx && xi < mi)) mi = xi;
+      float nm = fmaxf(mx, x);
+      if (nm != -INFINITY) s = s * __expf(mx - nm) + xs * __expf(x - nm);
+      mx = nm;
     }
-    float s = 0.f;
-    for (int p = 0; p < npart; ++p) s += part_sum[(long)p * M + m] * __expf(part_max[(long)p * M + m] - mx);
     float l = mx + logf(s);
     lse[m] = l;
     long long ym = y[m];
-    bool w = ym != pad;
-    nll = w ? l - tgt_logit[m] : 0.f;
+    bool wv = ym != pad;
+    nll = wv ? l - tgt_logit[m] : 0.f;
     tok_nll[m] = nll;
-    nw = w ? 1.f : 0.f;
-    nc = (w && mi == (int)ym) ? 1.f : 0.f;
+    nw = wv ? 1.f : 0.f;
+    nc = (wv && mi == (int)ym) ? 1.f : 0.f;
   }
   nll = wave_sum(nll); nw = wave_sum(nw); nc = wave_sum(nc);
-  if ((threadIdx.x & 63) == 0) {
+  if (lane == 0) {
     atomicAdd(stats + VMMT_STAT_NLL, nll);
     atomicAdd(stats + VMMT_STAT_NWORDS, nw);
     atomicAdd(stats + VMMT_STAT_NCORRECT, nc);
@@ -169,7 +188,7 @@ extern "C" int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const fl
   int rc = dtype == VMMT_F32 ? launch_gen<float, 0>(a, st) : dtype == VMMT_BF16 ? launch_gen<bf16_t, 0>(a, st)
                                                                                  : VMMT_EINVAL;
   if (rc) return rc;
-  hipLaunchKernelGGL(gen_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part_max, part_sum, part_idx,
+  hipLaunchKernelGGL(gen_combine_kernel, dim3((M + 63) / 64), dim3(1024), 0, st, part_max, part_sum, part_idx,
                      tgt_logit, (const long long*)y, M, vmmt_gen_npart(V), pad, lse, tok_nll, stats);
   return check_launch();
 }
