@@ -49,6 +49,7 @@ int vmmt_version(void);
  *   addend: add_rows = 1 -> bias row; add_rows = R > 1 -> addend[(m % R)][n] (z W_z^T broadcast over time steps,
  *           VI_Model1.py:99-100 without the materialised repeat); add_rows = -1 -> addend[m][n].
  *   a_kmod / b_kmod (K-strided operands only): reduction index taken modulo this (0 = off).
+ *   split_k: see the struct field.
  *   scatter_ids != NULL: out_f32 must be 1; C row = scatter_ids[m] (int64), atomic add, rows with id == pad_id are
  *           dropped: the embedding-gradient scatter-add with padding_idx (modules/Embeddings.py:118). */
 typedef struct vmmt_gemm_args {
@@ -62,6 +63,9 @@ typedef struct vmmt_gemm_args {
   int act; int out_f32; int accumulate; float alpha;
   const int64_t* scatter_ids; int pad_id;
   int tile; /* 0 = auto, 64, 128 */
+  int split_k; /* > 1: the reduction is split over this many workgroups per tile which atomicAdd fp32 partial sums into C
+                  (out_f32 = 1, act = NONE; C must hold zeros or a partial sum) -- for weight gradients dW = dY^T X whose
+                  reduction runs over thousands of tokens while the output is small */
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
 
@@ -165,9 +169,10 @@ int vmmt_dropout_mask(int dtype, void* mask, int64_t n, float p, uint64_t seed, 
 int vmmt_randn(float* out, int64_t n, uint64_t seed, void* stream);
 int vmmt_mul(int dtype, const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int R, int C,
              void* stream);
-/* out = dy * mask * act'(y) with act' expressed through the activation output y (mask / y may be NULL) */
-int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* mask,
-                 int64_t ldm, void* out, int64_t ldo, int R, int C, void* stream);
+/* out = dy * mask * act'(y) with act' expressed through the activation output y (mask / y may be NULL);
+ * dy_f32 != 0: dy is an f32 buffer (a split-K accumulated gradient) whatever `dtype` is */
+int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, int dy_f32, const void* y, int64_t ldy,
+                 const void* mask, int64_t ldm, void* out, int64_t ldo, int R, int C, void* stream);
 /* fused mu/sigma -> sample -> KL: z = mu + sigma*eps (training) | mu (eval)  (Models.py:933, Dists.py:21-26, H2);
  * kl_b[b] = sum_k 0.5(mu^2+sigma^2-1) - log sigma (VILoss.py:446-456); stats[KL_SUM] += sum_b kl_b. */
 int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT, int64_t ldz,

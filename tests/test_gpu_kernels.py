@@ -143,3 +143,32 @@ def test_gather_rows_and_image_loss():
     assert abs(s[L.STAT_IMG_LOGPROB].item() - logp.item()) < 1e-4
     assert abs(s[L.STAT_IMG_COS].item() - (a * vh).sum(1).sum().item()) < 1e-4
     assert (dmu.cpu().double() - muq.grad).abs().max().item() < 1e-9 + 1e-4 * muq.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("layout", ["TN", "NN"])
+def test_gemm_split_k_atomic(dtype, layout):
+    """split-K: partial sums are atomically added into C (which already holds a partial gradient); addend added once."""
+    L, lib = _lib()
+    T = torch.float32 if dtype == "f32" else torch.bfloat16
+    code = L.F32 if dtype == "f32" else L.BF16
+    torch.manual_seed(5)
+    M, N, K = 200, 72, 1000
+    a, b = (torch.randn(M, K) * 0.2).to(T), (torch.randn(N, K) * 0.2).to(T)
+    if layout == "TN":
+        Ad, Bd, lay = a.t().contiguous().cuda(), b.t().contiguous().cuda(), L.GEMM_TN
+        lda, ldb = M, N
+    else:
+        Ad, Bd, lay = a.cuda(), b.t().contiguous().cuda(), L.GEMM_NN
+        lda, ldb = K, N
+    init = torch.randn(M, N)
+    bias = torch.randn(N)
+    for split in (3, 7, 64):
+        Cd = init.clone().cuda()
+        biasd = bias.cuda()
+        args = L.GemmArgs(code, lay, Ad.data_ptr(), lda, Bd.data_ptr(), ldb, Cd.data_ptr(), N, M, N, K, 0, 0, biasd.data_ptr(), N, 1, 0,
+                          L.ACT_NONE, 1, 0, 1.0, None, 1, 0, split)
+        L.check(lib.vmmt_gemm(C.byref(args), None), "gemm")
+        want = init.double() + a.double() @ b.double().t() + bias.double()
+        err = (Cd.cpu().double() - want).abs().max().item()
+        assert err <= (1e-4 if dtype == "f32" else 3e-2), (split, err)

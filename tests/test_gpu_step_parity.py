@@ -146,3 +146,29 @@ def test_dropout_masks_and_eval_mode(dtype):
     st = e.read_stats(ws)
     assert abs(st["elbo"] - float(Lo["elbo"])) <= 2e-5 * abs(float(Lo["elbo"]))
     _cmp("z eval", ws.z32.view(), r["mu"], 2e-5, False)
+
+
+@pytest.mark.parametrize("hid,layers", [(256, 2), (1024, 1)])
+def test_wide_hidden_sizes_bf16(hid, layers):
+    """Exercises the latency-optimised LSTM step kernels incl. their K-chunk loops (K = H > 512 forward, K = 4H backward)
+    against the oracle on a synthetic batch (no golden needed: the oracle itself is pinned to the reference)."""
+    c = O.Cfg(vs=50, vt=60, emb=64, hid=hid, z=32, layers=layers, brnn=True)
+    p = O.init_params(c, seed=3)
+    B, S, T = 37, 6, 7
+    bt = O.synth_batch(c, B, S, T, n_img=40, seed=9, fixed_len=False)
+    e = _engine(c, p, "bf16")
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+    e.loss_backward(ws, normalization=B)
+    torch.cuda.synchronize()
+    img = bt["table"][bt["indices"]]
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
+    st = e.read_stats(ws)
+    assert abs(st["elbo"] - float(Lo["elbo"])) <= 5e-3 * abs(float(Lo["elbo"]))
+    _cmp("context", ws.enc_out[-1].view().float().view(S, B, hid), r["context"], 3e-2, False)
+    _cmp("rnn_out", ws.cat.view()[:, hid:].float().reshape(T - 1, B, hid), r["rnn_out"], 3e-2, False)
+    for k in g:
+        if "inf_net_image.location.fc1" in k or "gate_affine" in k:
+            continue
+        got, want = e.grads[k].cpu().double(), g[k].double()
+        assert (got - want).norm().item() <= 3e-2 * want.norm().item(), (k, (got - want).norm().item() / want.norm().item())

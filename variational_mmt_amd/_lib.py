@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
                 ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("a_kmod", i32), ("b_kmod", i32),
                 ("addend", vp), ("ld_add", i64), ("add_rows", i32), ("add_is_T", i32), ("act", i32),
                 ("out_f32", i32), ("accumulate", i32), ("alpha", f32), ("scatter_ids", vp), ("pad_id", i32),
-                ("tile", i32)]
+                ("tile", i32), ("split_k", i32)]
 
 
 class LstmDirFwd(C.Structure):
@@ -58,7 +58,7 @@ _SIGS = {
     "vmmt_dropout_mask": (i32, [i32, vp, i64, f32, u64, vp]),
     "vmmt_randn": (i32, [vp, i64, u64, vp]),
     "vmmt_mul": (i32, [i32, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
-    "vmmt_act_bwd": (i32, [i32, i32, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
+    "vmmt_act_bwd": (i32, [i32, i32, vp, i64, i32, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_latent_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),
     "vmmt_latent_bwd": (i32, [i32, vp, vp, vp, f32, f32, i32, f32, f32, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_gate_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),

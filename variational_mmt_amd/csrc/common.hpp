@@ -213,16 +213,16 @@ template <class T, int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, int TI,
 __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda, const AMap& amap,
                                               const T* __restrict__ B, long ldb, const BMap& bmap, int K, int a_kmod,
                                               int b_kmod, const int (&aoff)[TI], const int (&boff)[TJ],
-                                              f32x16 (&acc)[TI][TJ], T* __restrict__ smem) {
+                                              f32x16 (&acc)[TI][TJ], T* __restrict__ smem, int kbeg = 0) {
   Stager<T, BM, BK, NT, A_KC> sa;
   Stager<T, BN, BK, NT, B_KC> sb;
   T* As = smem;
   T* Bs = smem + ((Stager<T, BM, BK, NT, A_KC>::ELEMS + 7) & ~7);
   const int tid = threadIdx.x, lane = tid & 63;
-  if (K <= 0) return;
-  sa.load(A, lda, amap, 0, K, a_kmod, tid);
-  sb.load(B, ldb, bmap, 0, K, b_kmod, tid);
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  if (K <= kbeg) return;              // K is the END of this block's reduction range, kbeg its start (split-K)
+  sa.load(A, lda, amap, kbeg, K, a_kmod, tid);
+  sb.load(B, ldb, bmap, kbeg, K, b_kmod, tid);
+  for (int k0 = kbeg; k0 < K; k0 += BK) {
     sa.store(As, tid);
     sb.store(Bs, tid);
     __syncthreads();

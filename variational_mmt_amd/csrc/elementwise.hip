@@ -69,13 +69,13 @@ __global__ void mul_kernel(const T* __restrict__ a, long lda, const T* __restric
 }
 
 // out = dy * mask * act'(y), with act' expressed through the activation OUTPUT y
-template <class T>
-__global__ void act_bwd_kernel(int act, const T* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
+template <class T, class TD>
+__global__ void act_bwd_kernel(int act, const TD* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
                                const T* __restrict__ mask, long ldm, T* __restrict__ out, long ldo, int R, int C) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)R * C) return;
   int r = i / C, c = i - (long)r * C;
-  float g = to_f<T>(dy[(long)r * lddy + c]);
+  float g = to_f<TD>(dy[(long)r * lddy + c]);
   if (mask) g *= to_f<T>(mask[(long)r * ldm + c]);
   float yy = y ? to_f<T>(y[(long)r * ldy + c]) : 0.f;
   switch (act) {
@@ -268,13 +268,14 @@ extern "C" int vmmt_mul(int dtype, const void* a, int64_t lda, const void* b, in
   return check_launch();
 }
 
-extern "C" int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, const void* y, int64_t ldy, const void* mask,
-                            int64_t ldm, void* out, int64_t ldo, int R, int C, void* stream) {
+extern "C" int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, int dy_f32, const void* y, int64_t ldy,
+                            const void* mask, int64_t ldm, void* out, int64_t ldo, int R, int C, void* stream) {
   if (!dy || !out || R < 0 || C < 0 || (act != VMMT_ACT_NONE && !y)) return VMMT_EINVAL;
   long n = (long)R * C;
   if (n == 0) return VMMT_OK;
-  if (dtype == VMMT_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const float*)y, (long)ldy, (const float*)mask, (long)ldm, (float*)out, (long)ldo, R, C);
-  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, act, (const bf16_t*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C);
+  if (dtype == VMMT_F32) hipLaunchKernelGGL((act_bwd_kernel<float, float>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const float*)y, (long)ldy, (const float*)mask, (long)ldm, (float*)out, (long)ldo, R, C);
+  else if (dtype == VMMT_BF16 && dy_f32) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, float>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, bf16_t>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const bf16_t*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C);
   else return VMMT_EINVAL;
   return check_launch();
 }

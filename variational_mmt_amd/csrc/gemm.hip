@@ -14,6 +14,7 @@ struct GemmEpi {
   const void* addend; long ld_add; int add_rows; int add_is_T;   // add_rows: 0 none, 1 bias row, >1 row modulus, -1 full
   int act; int out_f32; int accumulate; float alpha;
   const long long* scatter_ids; int pad_id;                      // embedding-gradient scatter (atomic add, fp32 C)
+  int atomic;                                                    // split-K: fp32 atomicAdd into a pre-zeroed / partial C
 };
 
 // The epilogue runs as a few small, fully unrolled passes over the accumulator registers (static indices only:
@@ -51,6 +52,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
   if (e.scatter_ids) {
     float* C = reinterpret_cast<float*>(e.C);
     VMMT_FOR_ACC(long long id = e.scatter_ids[row]; if (id != e.pad_id) atomicAdd(C + id * e.ldc + col, v);)
+  } else if (e.atomic) {
+    float* C = reinterpret_cast<float*>(e.C);
+    VMMT_FOR_ACC(atomicAdd(C + (long)row * e.ldc + col, v);)
   } else if (e.out_f32) {
     float* C = reinterpret_cast<float*>(e.C);
     if (e.accumulate) { VMMT_FOR_ACC(C[(long)row * e.ldc + col] += v;) }
@@ -65,7 +69,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
 template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int M, int N, int K, int a_kmod,
-            int b_kmod, int tiles_n, GemmEpi epi) {
+            int b_kmod, int tiles_n, int kper, GemmEpi epi) {
   constexpr int BK = 32;
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int TI = WM / 32, TJ = WN / 32;
@@ -89,8 +93,11 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   LinearMap amap{m0, M}, bmap{n0, N};
-  gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ>(A, lda, amap, B, ldb, bmap, K, a_kmod, b_kmod, aoff, boff, acc,
-                                                        smem);
+  const int kbeg = blockIdx.y * kper;                 // split-K: this block reduces over [kbeg, kend)
+  const int kend = min(K, kbeg + kper);
+  gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ>(A, lda, amap, B, ldb, bmap, kend, a_kmod, b_kmod, aoff, boff, acc,
+                                                        smem, kbeg);
+  if (blockIdx.y != 0) epi.add_rows = 0;             // the addend is added once
   gemm_epilogue<T, TI, TJ>(epi, acc, aoff, boff, m0, n0, M, N, lane);
 }
 
@@ -99,15 +106,21 @@ static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t s
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
   size_t smem = gemm_smem_elems<T, BM, BN, 32, A_KC, B_KC>() * sizeof(T);
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC>), dim3(tm * tn), dim3(NT), smem, st,
+  int splits = epi.atomic ? a->split_k : 1;
+  if (splits < 1) splits = 1;
+  int kper = ((a->K + splits - 1) / splits + 31) / 32 * 32;
+  if (kper < 32) kper = 32;
+  splits = (a->K + kper - 1) / kper;
+  if (splits < 1) splits = 1;
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC>), dim3(tm * tn, splits), dim3(NT), smem, st,
                      (const T*)a->A, (long)a->lda, (const T*)a->B, (long)a->ldb, a->M, a->N, a->K, a->a_kmod,
-                     a->b_kmod, tn, epi);
+                     a->b_kmod, tn, kper, epi);
   return check_launch();
 }
 
 template <class T, bool A_KC, bool B_KC>
 static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
-  long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+  long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * (epi.atomic && a->split_k > 1 ? a->split_k : 1);
   if (a->tile == 128 || (a->tile == 0 && t128 >= 192)) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st);
   return launch_cfg<T, 64, 64, 32, 32, A_KC, B_KC>(a, epi, st);
 }
@@ -129,10 +142,12 @@ extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N < 0 || a->K < 0) return VMMT_EINVAL;
   if (a->M == 0 || a->N == 0) return VMMT_OK;
   if (a->scatter_ids && !a->out_f32) return VMMT_EINVAL;
+  if (a->split_k > 1 && (!a->out_f32 || a->act != VMMT_ACT_NONE || a->scatter_ids)) return VMMT_EINVAL;
   GemmEpi e;
   e.C = a->C; e.ldc = a->ldc; e.addend = a->addend; e.ld_add = a->ld_add; e.add_rows = a->addend ? a->add_rows : 0;
   e.add_is_T = a->add_is_T; e.act = a->act; e.out_f32 = a->out_f32; e.accumulate = a->accumulate;
   e.alpha = a->alpha; e.scatter_ids = (const long long*)a->scatter_ids; e.pad_id = a->pad_id;
+  e.atomic = a->split_k > 1 ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (a->dtype == VMMT_F32) return launch_dtype<float>(a, e, st);
   if (a->dtype == VMMT_BF16) return launch_dtype<bf16_t>(a, e, st);

@@ -35,6 +35,30 @@ struct StepArgsF {
   int B, H;
 };
 
+// cell forward for one (batch row b, hidden unit u): lane-local
+template <class T>
+__device__ __forceinline__ void cell_fwd(const StepDirF& d, const long long* lens, int b, int u, int H, float pi, float pf,
+                                         float pg, float po) {
+  const float* gx = d.gx + (long)b * d.ld_gx + u;
+  pi += gx[0]; pf += gx[H]; pg += gx[2 * H]; po += gx[3 * (long)H];
+  float i = sigmoidf_(pi), f = sigmoidf_(pf), g = tanhf_(pg), o = sigmoidf_(po);
+  float cp = d.c_prev ? d.c_prev[(long)b * d.ld_cprev + u] : 0.f;
+  float c = f * cp + i * g;
+  float h = o * tanhf_(c);
+  bool valid = true;
+  long long len = 0;
+  if (lens) { len = lens[b]; valid = d.t < len; }
+  T* gs = reinterpret_cast<T*>(d.gates) + (long)b * d.ld_gates + u;
+  gs[0] = from_f<T>(i); gs[H] = from_f<T>(f); gs[2 * H] = from_f<T>(g); gs[3 * (long)H] = from_f<T>(o);
+  d.c_out[(long)b * d.ld_c + u] = valid ? c : cp;          // frozen state at pads
+  reinterpret_cast<T*>(d.h_out)[(long)b * d.ld_h + u] = from_f<T>(valid ? h : 0.f);
+  bool cap = d.capture == 3 || (d.capture == 1 && d.t == len - 1) || (d.capture == 2 && d.t == 0);
+  if (cap && d.h_n) {
+    reinterpret_cast<T*>(d.h_n)[(long)b * d.ld_hn + u] = from_f<T>(h);
+    d.c_n[(long)b * d.ld_cn + u] = c;
+  }
+}
+
 template <class T>
 __global__ void __launch_bounds__(128) lstm_step_fwd_kernel(StepArgsF a) {
   constexpr int BK = 32, NT = 128, BM = 64, BU = 32, BN = 4 * BU;
@@ -61,27 +85,7 @@ __global__ void __launch_bounds__(128) lstm_step_fwd_kernel(StepArgsF a) {
   for (int r = 0; r < 16; ++r) {
     const int b = m0 + aoff[0] + acc_row(r, lane);
     if (b >= B) continue;
-    const float* gx = d.gx + (long)b * d.ld_gx + u;
-    float pi = acc[0][0][r] + gx[0];
-    float pf = acc[0][1][r] + gx[H];
-    float pg = acc[0][2][r] + gx[2 * H];
-    float po = acc[0][3][r] + gx[3 * (long)H];
-    float i = sigmoidf_(pi), f = sigmoidf_(pf), g = tanhf_(pg), o = sigmoidf_(po);
-    float cp = d.c_prev ? d.c_prev[(long)b * d.ld_cprev + u] : 0.f;
-    float c = f * cp + i * g;
-    float h = o * tanhf_(c);
-    bool valid = true;
-    long long len = 0;
-    if (a.lens) { len = a.lens[b]; valid = d.t < len; }
-    T* gs = reinterpret_cast<T*>(d.gates) + (long)b * d.ld_gates + u;
-    gs[0] = from_f<T>(i); gs[H] = from_f<T>(f); gs[2 * H] = from_f<T>(g); gs[3 * (long)H] = from_f<T>(o);
-    d.c_out[(long)b * d.ld_c + u] = valid ? c : cp;          // frozen state at pads
-    reinterpret_cast<T*>(d.h_out)[(long)b * d.ld_h + u] = from_f<T>(valid ? h : 0.f);
-    bool cap = d.capture == 3 || (d.capture == 1 && d.t == len - 1) || (d.capture == 2 && d.t == 0);
-    if (cap && d.h_n) {
-      reinterpret_cast<T*>(d.h_n)[(long)b * d.ld_hn + u] = from_f<T>(h);
-      d.c_n[(long)b * d.ld_cn + u] = c;
-    }
+    cell_fwd<T>(d, a.lens, b, u, H, acc[0][0][r], acc[0][1][r], acc[0][2][r], acc[0][3][r]);
   }
 }
 
@@ -108,6 +112,39 @@ struct StepArgsB {
   int B, H, mode;                        // mode 0: GEMM + cell backward; 1: GEMM only -> dh0_out
 };
 
+// cell backward for one (b, u) given dh = dgates_next W_hh (recurrent part): lane-local
+template <class T>
+__device__ __forceinline__ void cell_bwd(const StepDirB& d, const long long* lens, int mode, int b, int u, int H, float dh) {
+  if (mode == 1) { d.dh0_out[(long)b * d.ld_dh0 + u] = dh; return; }
+  long long len = 0;
+  bool valid = true;
+  if (lens) { len = lens[b]; valid = d.t < len; }
+  T* dgo = reinterpret_cast<T*>(d.dgates_out) + (long)b * d.ld_dgo + u;
+  float* dcc = d.dc_carry + (long)b * d.ld_dcc + u;
+  if (!valid) {
+    dgo[0] = T(0); dgo[H] = T(0); dgo[2 * H] = T(0); dgo[3 * (long)H] = T(0);
+    *dcc = 0.f;
+    return;
+  }
+  float dc = *dcc;
+  if (d.dh_above) dh += to_f<T>(reinterpret_cast<const T*>(d.dh_above)[(long)b * d.ld_dha + u]);
+  bool inj = d.inject == 3 || (d.inject == 1 && d.t == len - 1) || (d.inject == 2 && d.t == 0);
+  if (inj && d.dh_n) { dh += d.dh_n[(long)b * d.ld_dhn + u]; dc += d.dc_n[(long)b * d.ld_dcn + u]; }
+  const T* gs = reinterpret_cast<const T*>(d.gates) + (long)b * d.ld_gates + u;
+  float i = to_f<T>(gs[0]), f = to_f<T>(gs[H]), g = to_f<T>(gs[2 * H]), o = to_f<T>(gs[3 * (long)H]);
+  float c = d.c_t[(long)b * d.ld_ct + u];
+  float cp = d.c_prev ? d.c_prev[(long)b * d.ld_cp + u] : 0.f;
+  float tc = tanhf_(c);
+  float d_o = dh * tc;
+  dc += dh * o * (1.f - tc * tc);
+  float d_i = dc * g, d_f = dc * cp, d_g = dc * i;
+  dgo[0] = from_f<T>(d_i * i * (1.f - i));
+  dgo[H] = from_f<T>(d_f * f * (1.f - f));
+  dgo[2 * H] = from_f<T>(d_g * (1.f - g * g));
+  dgo[3 * (long)H] = from_f<T>(d_o * o * (1.f - o));
+  *dcc = dc * f;
+}
+
 template <class T>
 __global__ void __launch_bounds__(256) lstm_step_bwd_kernel(StepArgsB a) {
   constexpr int BK = 32, NT = 256, BM = 64, BN = 64;
@@ -133,37 +170,137 @@ __global__ void __launch_bounds__(256) lstm_step_bwd_kernel(StepArgsB a) {
   for (int r = 0; r < 16; ++r) {
     const int b = m0 + aoff[0] + acc_row(r, lane);
     if (b >= B) continue;
-    float dh = acc[0][0][r];
-    if (a.mode == 1) { d.dh0_out[(long)b * d.ld_dh0 + u] = dh; continue; }
-    long long len = 0;
-    bool valid = true;
-    if (a.lens) { len = a.lens[b]; valid = d.t < len; }
-    T* dgo = reinterpret_cast<T*>(d.dgates_out) + (long)b * d.ld_dgo + u;
-    float* dcc = d.dc_carry + (long)b * d.ld_dcc + u;
-    if (!valid) {
-      dgo[0] = T(0); dgo[H] = T(0); dgo[2 * H] = T(0); dgo[3 * (long)H] = T(0);
-      *dcc = 0.f;
-      continue;
-    }
-    float dc = *dcc;
-    if (d.dh_above) dh += to_f<T>(reinterpret_cast<const T*>(d.dh_above)[(long)b * d.ld_dha + u]);
-    bool inj = d.inject == 3 || (d.inject == 1 && d.t == len - 1) || (d.inject == 2 && d.t == 0);
-    if (inj && d.dh_n) { dh += d.dh_n[(long)b * d.ld_dhn + u]; dc += d.dc_n[(long)b * d.ld_dcn + u]; }
-    const T* gs = reinterpret_cast<const T*>(d.gates) + (long)b * d.ld_gates + u;
-    float i = to_f<T>(gs[0]), f = to_f<T>(gs[H]), g = to_f<T>(gs[2 * H]), o = to_f<T>(gs[3 * (long)H]);
-    float c = d.c_t[(long)b * d.ld_ct + u];
-    float cp = d.c_prev ? d.c_prev[(long)b * d.ld_cp + u] : 0.f;
-    float tc = tanhf_(c);
-    float d_o = dh * tc;
-    dc += dh * o * (1.f - tc * tc);
-    float d_i = dc * g, d_f = dc * cp, d_g = dc * i;
-    dgo[0] = from_f<T>(d_i * i * (1.f - i));
-    dgo[H] = from_f<T>(d_f * f * (1.f - f));
-    dgo[2 * H] = from_f<T>(d_g * (1.f - g * g));
-    dgo[3 * (long)H] = from_f<T>(d_o * o * (1.f - o));
-    *dcc = dc * f;
+    cell_bwd<T>(d, a.lens, a.mode, b, u, H, acc[0][0][r]);
   }
 }
+
+// ==============================================================================================================
+// Latency-optimised bf16 step kernels.  A step is a tiny GEMM ([B x K] x [K x N]) on the critical path of the
+// recurrence, so what matters is the number of dependent memory round trips, not FLOPs:
+//   * small tiles (32 batch rows x 16 hidden units forward, 32 x 32 backward): >= 128-256 workgroups, one per CU;
+//   * the operands of a whole K chunk (<= 512) are staged with direct-to-LDS loads (global_load_lds_dwordx4, one
+//     1-KiB row piece per wave instruction, no VGPR round trip), ALL issued before a single wait, so a chunk costs
+//     one memory round trip instead of K/32 dependent ones;
+//   * v_mfma_f32_16x16x32_bf16 straight from LDS (row pitch = chunk bytes + 16: conflict-free ds_read_b128);
+//     its C layout (col = lane&15, row = 4*(lane>>4)+reg) puts the four gates of a hidden unit in one lane.
+// W_hh (2 MB at H = 512) stays L2-resident across the steps; h_{t-1} / dgates are re-read from L2 by the blocks that
+// share them.
+// ==============================================================================================================
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+constexpr int FAST_KCH = 512;                 // K chunk (elements)
+constexpr int FAST_PITCH = FAST_KCH * 2 + 16; // bytes
+
+// stage rows [0, nrows) of a chunk: row r comes from rowptr(r) (null = skip), kbytes valid bytes per row
+template <class RowPtr>
+__device__ __forceinline__ void stage_rows(char* lds, int row0, int nrows, int kbytes, RowPtr rowptr, int wave, int nwaves,
+                                           int lane) {
+  for (int r = wave; r < nrows; r += nwaves) {
+    const char* src = rowptr(r);
+    char* dst = lds + (row0 + r) * FAST_PITCH;                      // wave-uniform
+    if (src != nullptr && lane * 16 < kbytes)
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(src + lane * 16), (lds_void_t*)dst, 16, 0, 0);
+  }
+}
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) lstm_step_fwd_fast(StepArgsF a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const StepDirF& d = a.d[blockIdx.z];
+  const int B = a.B, H = a.H;
+  const int m0 = blockIdx.x * 32, u0 = blockIdx.y * 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave & 1, wk = wave >> 1;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const char* hp = reinterpret_cast<const char*>(d.h_prev);
+  const char* wp = reinterpret_cast<const char*>(d.w_hh);
+  for (int k0 = 0; k0 < H; k0 += FAST_KCH) {
+    const int kc = min(FAST_KCH, H - k0);
+    if (k0 > 0) __syncthreads();
+    stage_rows(lds, 0, 32, kc * 2, [&](int r) { int b = m0 + r; return b < B ? hp + ((long)b * d.ld_hprev + k0) * 2 : nullptr; },
+               wave, 4, lane);
+    stage_rows(lds, 32, 64, kc * 2, [&](int r) { int g = r >> 4, u = u0 + (r & 15);
+                 return wp + (((long)g * H + u) * d.ld_w + k0) * 2; }, wave, 4, lane);
+    __syncthreads();                                                // hipcc drains vmcnt(0) here: all pieces landed
+    const int nks = kc / 32, half = (nks + 1) / 2;
+    const int ks0 = wk == 0 ? 0 : half, ks1 = wk == 0 ? half : nks;
+    const char* arow = lds + (wm * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
+    const char* brow = lds + (32 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
+    for (int ks = ks0; ks < ks1; ++ks) {
+      bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + g * 16 * FAST_PITCH + ks * 64);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[g], 0, 0, 0);
+      }
+    }
+  }
+  // fold the two K halves: waves 2,3 hand their partial tiles to waves 0,1 through LDS
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);
+  if (wk == 1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wm * 4 + g) * 4 + r) * 64 + lane] = acc[g][r];
+  }
+  __syncthreads();
+  if (wk == 1) return;
+  const int u = u0 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = m0 + wm * 16 + (lane >> 4) * 4 + r;
+    if (b >= B) continue;
+    float p[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p[g] = acc[g][r] + red[((wm * 4 + g) * 4 + r) * 64 + lane];
+    cell_fwd<bf16_t>(d, a.lens, b, u, H, p[0], p[1], p[2], p[3]);
+  }
+}
+
+__global__ void __launch_bounds__(256) lstm_step_bwd_fast(StepArgsB a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const StepDirB& d = a.d[blockIdx.z];
+  const int B = a.B, H = a.H, K = 4 * a.H;
+  const int m0 = blockIdx.x * 32, u0 = blockIdx.y * 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int mt = wave & 1, nt = wave >> 1;
+  f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (d.dgates_next) {
+    const char* ap = reinterpret_cast<const char*>(d.dgates_next);
+    const char* wp = reinterpret_cast<const char*>(d.w_hh_t);
+    for (int k0 = 0; k0 < K; k0 += FAST_KCH) {
+      const int kc = min(FAST_KCH, K - k0);
+      if (k0 > 0) __syncthreads();
+      stage_rows(lds, 0, 32, kc * 2, [&](int r) { int b = m0 + r; return b < B ? ap + ((long)b * d.ld_dgn + k0) * 2 : nullptr; },
+                 wave, 4, lane);
+      stage_rows(lds, 32, 32, kc * 2, [&](int r) { int u = u0 + r; return u < H ? wp + ((long)u * d.ld_wt + k0) * 2 : nullptr; },
+                 wave, 4, lane);
+      __syncthreads();
+      const char* arow = lds + (mt * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
+      const char* brow = lds + (32 + nt * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
+      const int nks = kc / 32;
+      for (int ks = 0; ks < nks; ++ks) {
+        bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + ks * 64);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+      }
+    }
+  }
+  const int u = u0 + nt * 16 + (lane & 15);
+  if (u >= H) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = m0 + mt * 16 + (lane >> 4) * 4 + r;
+    if (b >= B) continue;
+    cell_bwd<bf16_t>(d, a.lens, a.mode, b, u, H, acc[r]);
+  }
+}
+
+static bool al16(const void* p, long ld_elems) { return (((uintptr_t)p) & 15) == 0 && (ld_elems * 2) % 16 == 0; }
 
 static void fill_f(StepDirF& o, const vmmt_lstm_dir_fwd& i) {
   o.h_prev = i.h_prev; o.ld_hprev = i.ld_hprev; o.c_prev = (const float*)i.c_prev; o.ld_cprev = i.ld_cprev;
@@ -194,6 +331,17 @@ extern "C" int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* 
   }
   if (ndir == 1) a.d[1] = a.d[0];
   a.lens = (const long long*)lens; a.B = B; a.H = H;
+  if (dtype == VMMT_BF16 && H % 32 == 0) {
+    bool ok = true;
+    for (int k = 0; k < ndir; ++k) ok = ok && al16(dirs[k].h_prev, dirs[k].ld_hprev) && al16(dirs[k].w_hh, dirs[k].ld_w);
+    if (ok) {
+      static bool attr_set = false;
+      size_t sm = (size_t)96 * FAST_PITCH;
+      if (!attr_set) { hipFuncSetAttribute((const void*)lstm_step_fwd_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+      hipLaunchKernelGGL(lstm_step_fwd_fast, dim3((B + 31) / 32, H / 16, ndir), dim3(256), sm, (hipStream_t)stream, a);
+      return check_launch();
+    }
+  }
   dim3 grid((B + 63) / 64, (H + 31) / 32, ndir);
   if (dtype == VMMT_F32) {
     size_t sm = gemm_smem_elems<float, 64, 128, 32>() * sizeof(float);
@@ -219,6 +367,18 @@ extern "C" int vmmt_lstm_step_bwd(int dtype, int ndir, const vmmt_lstm_dir_bwd* 
   }
   if (ndir == 1) a.d[1] = a.d[0];
   a.lens = (const long long*)lens; a.B = B; a.H = H; a.mode = mode;
+  if (dtype == VMMT_BF16 && H % 32 == 0) {
+    bool ok = true;
+    for (int k = 0; k < ndir; ++k)
+      ok = ok && (!dirs[k].dgates_next || (al16(dirs[k].dgates_next, dirs[k].ld_dgn) && al16(dirs[k].w_hh_t, dirs[k].ld_wt)));
+    if (ok) {
+      static bool attr_set = false;
+      size_t sm = (size_t)64 * FAST_PITCH;
+      if (!attr_set) { hipFuncSetAttribute((const void*)lstm_step_bwd_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+      hipLaunchKernelGGL(lstm_step_bwd_fast, dim3((B + 31) / 32, (H + 31) / 32, ndir), dim3(256), sm, (hipStream_t)stream, a);
+      return check_launch();
+    }
+  }
   dim3 grid((B + 63) / 64, (H + 63) / 64, ndir);
   if (dtype == VMMT_F32) {
     size_t sm = gemm_smem_elems<float, 64, 64, 32>() * sizeof(float);

@@ -215,9 +215,15 @@ class Engine(object):
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
-              act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0):
+              act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0):
+        if split_k == -1:
+            # weight-gradient heuristic: enough workgroups to fill 256 CUs a few times, >= 256 reduction steps each
+            tiles = ((M + 63) // 64) * ((N + 63) // 64)
+            split_k = max(1, min(K // 256, (1024 + tiles - 1) // tiles))
+            if split_k == 1:
+                accumulate = 1          # gradients always ACCUMULATE into the arena (zeroed at the start of a step)
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
-                       add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile)
+                       add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k)
         plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a))
 
     def _call(self, plan, fn, *args):
@@ -306,7 +312,7 @@ class Workspace(object):
         self.tok_nll = torch.zeros(M, dtype=f32, device=dev)
         # backward
         self.GT = nb(V, M)
-        self.dO = nb(M, H)
+        self.dO32 = nb(M, H, f32)
         self.dPre = nb(M, H)
         self.dcat = nb(M, 2 * H)
         self.dQ = nb(M, H)
@@ -484,13 +490,13 @@ class Workspace(object):
                 self.dmu_v.p(), self.dmu_v.ld, self.stats.data_ptr())
         w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
         e._gemm(P, L.GEMM_TN, self.dmu_v.p(), self.dmu_v.ld, self.h1v.p(), self.h1v.ld, e.gp("inf_net_image.location.fc2.weight"), D,
-                D, D, B, out_f32=1)
+                D, D, B, out_f32=1, split_k=-1)
         e._call(P, lib.vmmt_colsum, dt, self.dmu_v.p(), self.dmu_v.ld, B, D, e.gp("inf_net_image.location.fc2.bias"))
         e._gemm(P, L.GEMM_NN, self.dmu_v.p(), self.dmu_v.ld, w2.p(), w2.ld, self.dh1v.p(), self.dh1v.ld, B, D, D)
-        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.dh1v.p(), self.dh1v.ld, self.h1v.p(), self.h1v.ld, None, 0,
+        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.dh1v.p(), self.dh1v.ld, 0, self.h1v.p(), self.h1v.ld, None, 0,
                 self.dh1v.p(), self.dh1v.ld, B, D)
         e._gemm(P, L.GEMM_TN, self.dh1v.p(), self.dh1v.ld, self.zt.p(), self.zt.ld, e.gp("inf_net_image.location.fc1.weight"), Z,
-                D, Z, B, out_f32=1)
+                D, Z, B, out_f32=1, split_k=-1)
         e._call(P, lib.vmmt_colsum, dt, self.dh1v.p(), self.dh1v.ld, B, D, e.gp("inf_net_image.location.fc1.bias"))
         e._gemm(P, L.GEMM_NN, self.dh1v.p(), self.dh1v.ld, w1.p(), w1.ld, self.dzt.p(), self.dzt.ld, B, Z, D, out_f32=1)
         e._call(P, lib.vmmt_gate_bwd, self.dzt.p(), self.dzt.ld, self.z32.p(), self.gate.data_ptr(),
@@ -501,33 +507,35 @@ class Workspace(object):
         for br, dy in (("location", self.q_dmu), ("scale", self.q_dpre)):
             w2q = e.sh["q_%s_w2" % br]
             pre = "inf_net_global.%s" % br
-            e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1)
+            e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
             e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"))
             e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2q.p(), w2q.ld, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, Z)
-            e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.q_dh1[br].p(), self.q_dh1[br].ld, self.q_h1[br].p(), self.q_h1[br].ld,
+            e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.q_dh1[br].p(), self.q_dh1[br].ld, 0, self.q_h1[br].p(), self.q_h1[br].ld,
                     None, 0, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z)
             e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, self.hbar.p(), self.hbar.ld, e.gp(pre + ".fc1.weight"), H,
-                    Z, H, B, out_f32=1)
+                    Z, H, B, out_f32=1, split_k=-1)
             e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"))
         # --- generator: G^T, dWg = G^T O, db = rowsum(G^T), dO = G Wg ---------------------------------------------
         e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
                 M, V, H, PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
-        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1)
+        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1, split_k=-1)
         e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.ones_col().p(), self.ones_col().ld, e.gp("generator.0.bias"), 1,
                 V, 1, M, out_f32=1, tile=64)
-        e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO.p(), self.dO.ld, M, H, V)
+        e._call(P, _memset, self.dO32.t)
+        e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
+                split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))), tile=128)
         # --- dropout + tanh backward, linear_out ---------------------------------------------------------------
-        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_TANH, self.dO.p(), self.dO.ld, self.AH.p(), self.AH.ld,
+        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_TANH, self.dO32.p(), self.dO32.ld, 1, self.AH.p(), self.AH.ld,
                 self.out_mask.p() if drop else None, self.out_mask.ld if drop else 0, self.dPre.p(), self.dPre.ld, M, H)
         wo, wa = e.sh["wo"], e.sh["wa"]
         e._gemm(P, L.GEMM_TN, self.dPre.p(), self.dPre.ld, self.cat.p(), self.cat.ld, e.gp("decoder.attn.linear_out.weight"), 2 * H,
-                H, 2 * H, M, out_f32=1)
+                H, 2 * H, M, out_f32=1, split_k=-1)
         e._gemm(P, L.GEMM_NN, self.dPre.p(), self.dPre.ld, wo.p(), wo.ld, self.dcat.p(), self.dcat.ld, M, 2 * H, H)
         ctx = self.enc_out[Lyr - 1]
         e._call(P, lib.vmmt_attn_bwd, dt, self.dcat.p(), self.dcat.ld, self.probs.data_ptr(), self.Q.p(), self.Q.ld, ctx.p(), ctx.ld,
                 self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, H)
         e._gemm(P, L.GEMM_TN, self.dQ.p(), self.dQ.ld, self.cat.p(0, H), self.cat.ld, e.gp("decoder.attn.linear_in.weight"), H,
-                H, H, M, out_f32=1)
+                H, H, M, out_f32=1, split_k=-1)
         e._gemm(P, L.GEMM_NN, self.dQ.p(), self.dQ.ld, wa.p(), wa.ld, self.dR.p(), self.dR.ld, M, H, H,
                 addend=self.dcat.p(0, H), ld_add=self.dcat.ld, add_rows=-1, add_is_T=1)
         # --- decoder LSTM backward -------------------------------------------------------------------------------
@@ -566,22 +574,22 @@ class Workspace(object):
             # weight gradients
             gw = "decoder.rnn.weight_hh_l%d" % l
             if Tp > 1:
-                e._gemm(P, L.GEMM_TN, dg.p(B), dg.ld, outb.p(0, ocol), outb.ld, e.gp(gw), H, 4 * H, H, (Tp - 1) * B, out_f32=1)
-            e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * H, H, B, out_f32=1,
+                e._gemm(P, L.GEMM_TN, dg.p(B), dg.ld, outb.p(0, ocol), outb.ld, e.gp(gw), H, 4 * H, H, (Tp - 1) * B, out_f32=1, split_k=-1)
+            e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * H, H, B, out_f32=1, split_k=-1,
                     accumulate=1 if Tp > 1 else 0)
             e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_ih_l%d" % l))
             e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_hh_l%d" % l))
             gi = "decoder.rnn.weight_ih_l%d" % l
             if l == 0:
-                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * H, E, M, out_f32=1)
-                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * H, Z, M, out_f32=1, b_kmod=B)
+                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * H, E, M, out_f32=1, split_k=-1)
+                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * H, Z, M, out_f32=1, split_k=-1, b_kmod=B)
                 we = e.sh["dec_wih_l0_e"]
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                         M, E, 4 * H, out_f32=1, scatter_ids=self.tgt_in.data_ptr())
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 wi = e.sh["dec_wih_l%d" % l]
-                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1)
+                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wi.p(), wi.ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H, 4 * H)
                 if drop:
                     e._call(P, lib.vmmt_mul, dt, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, self.dec_mask[l - 1].p(),
@@ -624,14 +632,14 @@ class Workspace(object):
                 if S > 1:
                     if k == 0:   # h_prev[t] = out[t-1]
                         e._gemm(P, L.GEMM_TN, dg.p(B, k * 4 * Hd), dg.ld, self.enc_out[l].p(0, k * Hd), self.enc_out[l].ld, e.gp(gw), Hd,
-                                4 * Hd, Hd, (S - 1) * B, out_f32=1)
+                                4 * Hd, Hd, (S - 1) * B, out_f32=1, split_k=-1)
                     else:        # h_prev[t] = out[t+1]
                         e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, self.enc_out[l].p(B, k * Hd), self.enc_out[l].ld, e.gp(gw), Hd,
-                                4 * Hd, Hd, (S - 1) * B, out_f32=1)
+                                4 * Hd, Hd, (S - 1) * B, out_f32=1, split_k=-1)
                 e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)))
                 e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
                 e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, xin.p(), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)), xcols,
-                        4 * Hd, xcols, MS, out_f32=1)
+                        4 * Hd, xcols, MS, out_f32=1, split_k=-1)
             wih = e.sh["enc_wih_l%d" % l]
             if l == 0:
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
