@@ -164,6 +164,8 @@ int vmmt_gather_rows(int out_dtype, const float* table, int64_t ldt, const int64
                      int D, void* stream);
 /* out[c] += sum_r X[r][c]  (bias gradients) */
 int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream);
+/* out[r] += sum_c X[r][c]  (generator bias gradient: row sums of G^T) */
+int vmmt_rowsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream);
 /* scaled dropout mask: 1/(1-p) with prob 1-p else 0 (counter-based RNG; VI_Model1.py:132, Models.py:124-129) */
 int vmmt_dropout_mask(int dtype, void* mask, int64_t n, float p, uint64_t seed, void* stream);
 int vmmt_randn(float* out, int64_t n, uint64_t seed, void* stream);

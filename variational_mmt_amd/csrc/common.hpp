@@ -64,6 +64,10 @@ __device__ __forceinline__ float wave_max(float v) {
 struct LinearMap {   // rows base .. limit-1
   int base, limit;
   __device__ __forceinline__ int operator()(int r) const { int g = base + r; return g < limit ? g : -1; }
+  // true when no 16-byte vector of `vec` consecutive local rows straddles the end of the valid range
+  __device__ __forceinline__ bool vec_ok(int rows, int vec) const { int n = limit - base; return n >= rows || n % vec == 0; }
+  // a 16-byte vector that straddles `limit` may still be LOADED when every stored row is padded to a multiple of vec
+  __device__ __forceinline__ bool pad_ok(long ld, int vec) const { return ld >= (long)((limit + vec - 1) / vec) * vec; }
 };
 struct GateMap {     // LSTM gate rows: local n = g * BU + u  ->  g * H + u0 + u   (g = i,f,g,o)
   int u0, H, BU;
@@ -71,6 +75,8 @@ struct GateMap {     // LSTM gate rows: local n = g * BU + u  ->  g * H + u0 + u
     int g = r / BU, u = u0 + (r - g * BU);
     return u < H ? g * H + u : -1;
   }
+  __device__ __forceinline__ bool vec_ok(int rows, int vec) const { int n = H - u0; return (n >= BU || n % vec == 0) && BU % vec == 0; }
+  __device__ __forceinline__ bool pad_ok(long, int) const { return false; }
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -90,43 +96,90 @@ struct Stager {
   static constexpr int NVEC = ROWS * BK / VEC;
   static constexpr int PER = (NVEC + NT - 1) / NT;
   static_assert(ROWS % VEC == 0 && BK % VEC == 0, "tile");
-  T regs[PER][VEC];
+  u32x4 regs[PER];
+  // per-vector state hoisted out of the K loop.  `ptr` is ALWAYS dereferenceable (out-of-range rows are clamped to
+  // the tile's first row and zeroed by a select), so the fast path has no branch around any load: hipcc then issues
+  // the whole slab's loads back to back instead of waiting for each one (a load inside a per-vector branch is waited
+  // for individually).
+  const T* ptr[PER];
+  int nvalid[PER];        // leading elements of the vector that are in range (0 = clamped dummy load, VEC = all)
+  const T* P_; long ld_; int kmod_;
+  bool fast;              // block-uniform: 16-byte aligned operand, no ragged vector
+  bool raw;               // regs hold unmasked fast-path loads
 
   template <class Map>
-  __device__ __forceinline__ void load(const T* __restrict__ P, long ld, const Map& map, int k0, int K, int kmod,
-                                       int tid) {
+  __device__ __forceinline__ void init(const T* __restrict__ P, long ld, const Map& map, int kmod, int tid) {
+    P_ = P; ld_ = ld; kmod_ = kmod;
+    fast = (((uintptr_t)P) & 15) == 0 && ((ld * (long)sizeof(T)) & 15) == 0 &&
+           (KC || map.vec_ok(ROWS, VEC) || map.pad_ok(ld, VEC));
+    const int g_first = map(0);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int v = tid + i * NT;
-      if (NVEC % NT != 0 && v >= NVEC) break;
+      if (NVEC % NT != 0 && v >= NVEC) v = 0;
       if constexpr (KC) {
-        int row = v / (BK / VEC), kk = (v % (BK / VEC)) * VEC;
+        int row = v / (BK / VEC), kq = (v % (BK / VEC)) * VEC;
         int g = map(row);
-        int k = k0 + kk;
-        const T* src = P + (long)g * ld + k;
-        if (g >= 0 && k + VEC <= K && ((uintptr_t)src & 15) == 0) {
-          *reinterpret_cast<u32x4*>(regs[i]) = *reinterpret_cast<const u32x4*>(src);
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) regs[i][e] = (g >= 0 && k + e < K) ? src[e] : T(0);
-        }
+        nvalid[i] = g >= 0 ? VEC : 0;
+        ptr[i] = P + (long)(g >= 0 ? g : g_first) * ld + kq;
       } else {
-        int kk = v / (ROWS / VEC), row = (v % (ROWS / VEC)) * VEC;
-        int k = k0 + kk;
-        int g0 = map(row), g1 = map(row + VEC - 1);
-        long kr = kmod > 0 ? (k % kmod) : k;
-        const T* src = P + kr * ld + g0;
-        if (k < K && g0 >= 0 && g1 == g0 + VEC - 1 && ((uintptr_t)src & 15) == 0) {
-          *reinterpret_cast<u32x4*>(regs[i]) = *reinterpret_cast<const u32x4*>(src);
-        } else {
+        int row = (v % (ROWS / VEC)) * VEC;
+        int g = map(row);
+        int n = 0;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            int ge = map(row + e);
-            regs[i][e] = (k < K && ge >= 0) ? P[kr * ld + ge] : T(0);
-          }
-        }
+        for (int e = 0; e < VEC; ++e) n += map(row + e) >= 0 ? 1 : 0;     // valid rows are a prefix
+        nvalid[i] = n;
+        ptr[i] = P + (g >= 0 ? g : g_first);
       }
     }
+  }
+
+  // whole slab [k0, k0 + BK) inside [0, K) and `fast`: unconditional 16-byte loads
+  __device__ __forceinline__ void load_fast(int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      u32x4 v;
+      if constexpr (KC) {
+        v = *reinterpret_cast<const u32x4*>(ptr[i] + k0);
+      } else {
+        int kq = (tid + i * NT) / (ROWS / VEC);
+        if (NVEC % NT != 0 && tid + i * NT >= NVEC) kq = 0;
+        int k = k0 + kq;
+        long kr = kmod_ > 0 ? (k % kmod_) : k;
+        v = *reinterpret_cast<const u32x4*>(ptr[i] + kr * ld_);
+      }
+      regs[i] = v;            // NOT consumed here: the zero-select for clamped rows happens in store(), so the loads
+    }                         // stay in flight across the MFMA slab
+    raw = true;
+  }
+
+  // general path: element-wise with full predication (edge tiles, unaligned operands, the K tail)
+  template <class Map>
+  __device__ __forceinline__ void load_slow(const Map& map, int k0, int K, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int v = tid + i * NT;
+      T tmp[VEC];
+      if (NVEC % NT != 0 && v >= NVEC) continue;
+      if constexpr (KC) {
+        int row = v / (BK / VEC), kq = (v % (BK / VEC)) * VEC;
+        int g = map(row);
+        int k = k0 + kq;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) tmp[e] = (g >= 0 && k + e < K) ? P_[(long)g * ld_ + k + e] : T(0);
+      } else {
+        int kq = v / (ROWS / VEC), row = (v % (ROWS / VEC)) * VEC;
+        int k = k0 + kq;
+        long kr = kmod_ > 0 ? (k % kmod_) : k;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          int ge = map(row + e);
+          tmp[e] = (k < K && ge >= 0) ? P_[kr * ld_ + ge] : T(0);
+        }
+      }
+      regs[i] = *reinterpret_cast<const u32x4*>(tmp);
+    }
+    raw = false;
   }
 
   __device__ __forceinline__ void store(T* __restrict__ S, int tid) const {
@@ -134,12 +187,25 @@ struct Stager {
     for (int i = 0; i < PER; ++i) {
       int v = tid + i * NT;
       if (NVEC % NT != 0 && v >= NVEC) break;
+      u32x4 w = regs[i];
+      if (raw && nvalid[i] < VEC) {                       // clamped / ragged vector: keep the valid prefix only
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = e < nvalid[i] ? w[e] : 0u;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uint32_t m = (2 * e + 1 < nvalid[i]) ? 0xffffffffu : (2 * e < nvalid[i] ? 0x0000ffffu : 0u);
+            w[e] &= m;
+          }
+        }
+      }
       if constexpr (KC) {
-        int row = v / (BK / VEC), kk = (v % (BK / VEC)) * VEC;
-        *reinterpret_cast<u32x4*>(S + row * STRIDE + kk) = *reinterpret_cast<const u32x4*>(regs[i]);
+        int row = v / (BK / VEC), kq = (v % (BK / VEC)) * VEC;
+        *reinterpret_cast<u32x4*>(S + row * STRIDE + kq) = w;
       } else {
-        int kk = v / (ROWS / VEC), row = (v % (ROWS / VEC)) * VEC;
-        *reinterpret_cast<u32x4*>(S + kk * STRIDE + row) = *reinterpret_cast<const u32x4*>(regs[i]);
+        int kq = v / (ROWS / VEC), row = (v % (ROWS / VEC)) * VEC;
+        *reinterpret_cast<u32x4*>(S + kq * STRIDE + row) = w;
       }
     }
   }
@@ -207,8 +273,9 @@ __device__ __forceinline__ void mfma_slab(const T* __restrict__ As, const T* __r
   }
 }
 
-// Block-level main loop: C_tile += A_tile(BM x K) * B_tile(BN x K)^T, staged through LDS with a register
-// prefetch of the next K slab (global loads for slab k+1 are in flight while slab k is multiplied).
+// Block-level main loop: C_tile += A_tile(BM x K) * B_tile(BN x K)^T.  Two LDS buffers: while slab k is multiplied
+// out of buffer `cur`, the global loads of slab k+1 are in flight into registers and are written to the other buffer
+// after the MFMAs -- one barrier per slab, and the loads have a whole MFMA phase to land.
 template <class T, int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, int TI, int TJ, class AMap, class BMap>
 __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda, const AMap& amap,
                                               const T* __restrict__ B, long ldb, const BMap& bmap, int K, int a_kmod,
@@ -216,28 +283,55 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda,
                                               f32x16 (&acc)[TI][TJ], T* __restrict__ smem, int kbeg = 0) {
   Stager<T, BM, BK, NT, A_KC> sa;
   Stager<T, BN, BK, NT, B_KC> sb;
-  T* As = smem;
-  T* Bs = smem + ((Stager<T, BM, BK, NT, A_KC>::ELEMS + 7) & ~7);
+  constexpr int AE = (Stager<T, BM, BK, NT, A_KC>::ELEMS + 7) & ~7;
+  constexpr int BE = (Stager<T, BN, BK, NT, B_KC>::ELEMS + 7) & ~7;
   const int tid = threadIdx.x, lane = tid & 63;
   if (K <= kbeg) return;              // K is the END of this block's reduction range, kbeg its start (split-K)
-  sa.load(A, lda, amap, kbeg, K, a_kmod, tid);
-  sb.load(B, ldb, bmap, kbeg, K, b_kmod, tid);
-  for (int k0 = kbeg; k0 < K; k0 += BK) {
-    sa.store(As, tid);
-    sb.store(Bs, tid);
+  sa.init(A, lda, amap, a_kmod, tid);
+  sb.init(B, ldb, bmap, b_kmod, tid);
+  const int nslab = (K - kbeg + BK - 1) / BK;
+  // slabs [0, nfast) are full and both operands take the branch-free vector path; the rest (K tail, ragged or
+  // unaligned tiles) use the predicated element-wise path.  The two phases are SEPARATE loops: a fast/slow choice
+  // inside one loop body makes hipcc wait for operand A's loads before it issues operand B's.
+  const int nfast = (sa.fast && sb.fast) ? (K - kbeg) / BK : 0;
+  if (nfast > 0) { sa.load_fast(kbeg, tid); sb.load_fast(kbeg, tid); }
+  else { sa.load_slow(amap, kbeg, K, tid); sb.load_slow(bmap, kbeg, K, tid); }
+  sa.store(smem, tid);
+  sb.store(smem + AE, tid);
+  __syncthreads();
+  int cur = 0, sidx = 0;
+  for (; sidx + 1 < nfast; ++sidx) {                    // fast phase: next slab is a fast one
+    sa.load_fast(kbeg + (sidx + 1) * BK, tid);
+    sb.load_fast(kbeg + (sidx + 1) * BK, tid);
+    const T* As = smem + cur * (AE + BE);
+    mfma_slab<T, BM, BN, BK, A_KC, B_KC, TI, TJ>(As, As + AE, aoff, boff, acc, lane);
+    T* Ns = smem + (cur ^ 1) * (AE + BE);
+    sa.store(Ns, tid);
+    sb.store(Ns + AE, tid);
     __syncthreads();
-    if (k0 + BK < K) {
-      sa.load(A, lda, amap, k0 + BK, K, a_kmod, tid);
-      sb.load(B, ldb, bmap, k0 + BK, K, b_kmod, tid);
+    cur ^= 1;
+  }
+  for (; sidx < nslab; ++sidx) {                        // remaining slabs: next slab (if any) via the slow path
+    const bool more = sidx + 1 < nslab;
+    if (more) {
+      sa.load_slow(amap, kbeg + (sidx + 1) * BK, K, tid);
+      sb.load_slow(bmap, kbeg + (sidx + 1) * BK, K, tid);
     }
-    mfma_slab<T, BM, BN, BK, A_KC, B_KC, TI, TJ>(As, Bs, aoff, boff, acc, lane);
+    const T* As = smem + cur * (AE + BE);
+    mfma_slab<T, BM, BN, BK, A_KC, B_KC, TI, TJ>(As, As + AE, aoff, boff, acc, lane);
+    if (more) {
+      T* Ns = smem + (cur ^ 1) * (AE + BE);
+      sa.store(Ns, tid);
+      sb.store(Ns + AE, tid);
+    }
     __syncthreads();
+    cur ^= 1;
   }
 }
 
 template <class T, int BM, int BN, int BK, bool A_KC = true, bool B_KC = true>
-constexpr int gemm_smem_elems() {
-  return ((Stager<T, BM, BK, 64, A_KC>::ELEMS + 7) & ~7) + Stager<T, BN, BK, 64, B_KC>::ELEMS;
+constexpr int gemm_smem_elems() {   // two buffers
+  return 2 * (((Stager<T, BM, BK, 64, A_KC>::ELEMS + 7) & ~7) + ((Stager<T, BN, BK, 64, B_KC>::ELEMS + 7) & ~7));
 }
 
 // accumulator element -> (row, col) inside a 32x32 tile

@@ -43,6 +43,30 @@ __global__ void colsum_kernel(const T* __restrict__ X, long ld, int R, int C, fl
   if (w == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// out[r] += sum_c X[r][c]: one wave per row, 16-byte loads (generator bias gradient = row sums of G^T [V][M])
+template <class T>
+__global__ void rowsum_kernel(const T* __restrict__ X, long ld, int R, int C, float* __restrict__ out) {
+  constexpr int VEC = 16 / sizeof(T);
+  int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const T* x = X + (long)row * ld;
+  float a = 0.f;
+  if ((((uintptr_t)x) & 15) == 0) {
+    int c = lane * VEC;
+    for (; c + VEC <= C; c += 64 * VEC) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(x + c);
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) a += to_f<T>(e[k]);
+    }
+    if (c < C) for (int k = c; k < C && k < c + VEC; ++k) a += to_f<T>(x[k]);
+  } else {
+    for (int c = lane; c < C; c += 64) a += to_f<T>(x[c]);
+  }
+  a = wave_sum(a);
+  if (lane == 0) out[row] += a;
+}
+
 template <class T>
 __global__ void dropout_mask_kernel(T* __restrict__ mask, long n, float p, unsigned long long seed) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,6 +261,16 @@ extern "C" int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, f
   dim3 grid((C + 63) / 64, (R + rpb - 1) / rpb);
   if (dtype == VMMT_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST, (const float*)X, (long)ld, R, C, out, rpb);
   else if (dtype == VMMT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)X, (long)ld, R, C, out, rpb);
+  else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_rowsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream) {
+  if (!X || !out || R < 0 || C <= 0) return VMMT_EINVAL;
+  if (R == 0) return VMMT_OK;
+  dim3 grid((R + 3) / 4);
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(rowsum_kernel<float>, grid, dim3(256), 0, ST, (const float*)X, (long)ld, R, C, out);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(rowsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)X, (long)ld, R, C, out);
   else return VMMT_EINVAL;
   return check_launch();
 }

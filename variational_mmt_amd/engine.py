@@ -519,8 +519,7 @@ class Workspace(object):
         e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
                 M, V, H, PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
         e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1, split_k=-1)
-        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.ones_col().p(), self.ones_col().ld, e.gp("generator.0.bias"), 1,
-                V, 1, M, out_f32=1, tile=64)
+        e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
         e._call(P, _memset, self.dO32.t)
         e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
                 split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))), tile=128)
