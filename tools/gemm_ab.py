@@ -1,0 +1,31 @@
+"""In-process interleaved A/B of GEMM tile variants on the step's real shapes (bf16). Run on the GPU box."""
+import ctypes as C, sys, torch
+sys.path.insert(0, '.')
+from variational_mmt_amd import _lib as L
+lib = L.lib()
+torch.manual_seed(0)
+def bench(name, lay, M, N, K, variants, out_f32=1, split=0, rounds=7):
+    T = torch.bfloat16
+    if lay == L.GEMM_NT: A = torch.randn(M, K, device='cuda').to(T); B = torch.randn(N, K, device='cuda').to(T); lda, ldb = K, K
+    elif lay == L.GEMM_TN: A = torch.randn(K, M, device='cuda').to(T); B = torch.randn(K, N, device='cuda').to(T); lda, ldb = M, N
+    else: A = torch.randn(M, K, device='cuda').to(T); B = torch.randn(K, N, device='cuda').to(T); lda, ldb = K, N
+    Cc = torch.zeros(M, N, device='cuda', dtype=torch.float32 if out_f32 else T)
+    res = {v: [] for v in variants}
+    for r in range(rounds):
+        for v in variants:
+            a = L.GemmArgs(L.BF16, lay, A.data_ptr(), lda, B.data_ptr(), ldb, Cc.data_ptr(), N, M, N, K, 0, 0, None, 0, 0, 0, 0, out_f32, 0, 1.0, None, 1, v, split)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(2): L.check(lib.vmmt_gemm(C.byref(a), None), "g")
+            s.record()
+            for _ in range(5): L.check(lib.vmmt_gemm(C.byref(a), None), "g")
+            e.record(); torch.cuda.synchronize()
+            res[v].append(s.elapsed_time(e) / 5 * 1e3)
+    fl = 2.0 * M * N * K
+    print("%-28s" % name, "  ".join("%d: %7.1f us (%5.0f TF)" % (v, sorted(t)[len(t)//2], fl / sorted(t)[len(t)//2] / 1e6) for v, t in res.items()))
+V = [128, 1281, 1282, 1283, 2561, 2562, 2563]
+bench("dWg NN 30000x512x5120", L.GEMM_NN, 30000, 512, 5120, V)
+bench("dO  TN 5120x512x30000 s6", L.GEMM_TN, 5120, 512, 30000, V, split=6)
+bench("gx  NT 5120x2048x512", L.GEMM_NT, 5120, 2048, 512, V, out_f32=1)
+bench("logits NT 30000x5120x512", L.GEMM_NT, 30000, 5120, 512, V, out_f32=0)
+bench("dWhh TN 2048x512x4864 s8", L.GEMM_TN, 2048, 512, 4864, V, split=8)
+bench("dcat NN 5120x1024x512", L.GEMM_NN, 5120, 1024, 512, V, out_f32=0)

@@ -276,7 +276,7 @@ __device__ __forceinline__ void mfma_slab(const T* __restrict__ As, const T* __r
 // Block-level main loop: C_tile += A_tile(BM x K) * B_tile(BN x K)^T.  Two LDS buffers: while slab k is multiplied
 // out of buffer `cur`, the global loads of slab k+1 are in flight into registers and are written to the other buffer
 // after the MFMAs -- one barrier per slab, and the loads have a whole MFMA phase to land.
-template <class T, int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, int TI, int TJ, class AMap, class BMap>
+template <class T, int BM, int BN, int BK, int NT, bool A_KC, bool B_KC, int TI, int TJ, class AMap, class BMap, bool DB = true>
 __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda, const AMap& amap,
                                               const T* __restrict__ B, long ldb, const BMap& bmap, int K, int a_kmod,
                                               int b_kmod, const int (&aoff)[TI], const int (&boff)[TJ],
@@ -305,11 +305,12 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda,
     sb.load_fast(kbeg + (sidx + 1) * BK, tid);
     const T* As = smem + cur * (AE + BE);
     mfma_slab<T, BM, BN, BK, A_KC, B_KC, TI, TJ>(As, As + AE, aoff, boff, acc, lane);
-    T* Ns = smem + (cur ^ 1) * (AE + BE);
+    if constexpr (!DB) __syncthreads();                  // single buffer: everyone done reading before it is refilled
+    T* Ns = smem + (DB ? (cur ^ 1) : 0) * (AE + BE);
     sa.store(Ns, tid);
     sb.store(Ns + AE, tid);
     __syncthreads();
-    cur ^= 1;
+    if constexpr (DB) cur ^= 1;
   }
   for (; sidx < nslab; ++sidx) {                        // remaining slabs: next slab (if any) via the slow path
     const bool more = sidx + 1 < nslab;
@@ -319,19 +320,29 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda,
     }
     const T* As = smem + cur * (AE + BE);
     mfma_slab<T, BM, BN, BK, A_KC, B_KC, TI, TJ>(As, As + AE, aoff, boff, acc, lane);
+    if constexpr (!DB) __syncthreads();
     if (more) {
-      T* Ns = smem + (cur ^ 1) * (AE + BE);
+      T* Ns = smem + (DB ? (cur ^ 1) : 0) * (AE + BE);
       sa.store(Ns, tid);
       sb.store(Ns + AE, tid);
     }
     __syncthreads();
-    cur ^= 1;
+    if constexpr (DB) cur ^= 1;
   }
 }
 
-template <class T, int BM, int BN, int BK, bool A_KC = true, bool B_KC = true>
-constexpr int gemm_smem_elems() {   // two buffers
-  return 2 * (((Stager<T, BM, BK, 64, A_KC>::ELEMS + 7) & ~7) + ((Stager<T, BN, BK, 64, B_KC>::ELEMS + 7) & ~7));
+template <class T, int BM, int BN, int BK, bool A_KC = true, bool B_KC = true, bool DB = true>
+constexpr int gemm_smem_elems() {
+  return (DB ? 2 : 1) * (((Stager<T, BM, BK, 64, A_KC>::ELEMS + 7) & ~7) + ((Stager<T, BN, BK, 64, B_KC>::ELEMS + 7) & ~7));
+}
+
+// XCD-aware workgroup -> tile remap (MI355X: 8 XCDs with private L2s; workgroups are dealt round-robin over the XCDs, so
+// ids b and b+8 share an L2).  Logical tiles [x*cpx, (x+1)*cpx) go to the workgroups of XCD-group x: tiles that are
+// neighbours in the logical order (and share an operand panel) then hit the same L2 instead of 8 different ones.
+// Bijective for any grid size; affects speed only, never results.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
 // accumulator element -> (row, col) inside a 32x32 tile

@@ -66,16 +66,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
   }
 }
 
-template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int M, int N, int K, int a_kmod,
             int b_kmod, int tiles_n, int kper, GemmEpi epi) {
-  constexpr int BK = 32;
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int TI = WM / 32, TJ = WN / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
-  const int tile = blockIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -95,24 +94,29 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb
   LinearMap amap{m0, M}, bmap{n0, N};
   const int kbeg = blockIdx.y * kper;                 // split-K: this block reduces over [kbeg, kend)
   const int kend = min(K, kbeg + kper);
-  gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ>(A, lda, amap, B, ldb, bmap, kend, a_kmod, b_kmod, aoff, boff, acc,
-                                                        smem, kbeg);
+  gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ, LinearMap, LinearMap, DB>(A, lda, amap, B, ldb, bmap, kend, a_kmod,
+                                                                                  b_kmod, aoff, boff, acc, smem, kbeg);
   if (blockIdx.y != 0) epi.add_rows = 0;             // the addend is added once
   gemm_epilogue<T, TI, TJ>(epi, acc, aoff, boff, m0, n0, M, N, lane);
 }
 
-template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true>
 static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
-  size_t smem = gemm_smem_elems<T, BM, BN, 32, A_KC, B_KC>() * sizeof(T);
+  size_t smem = gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
+  if (smem > 64 * 1024) {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
+  }
   int splits = epi.atomic ? a->split_k : 1;
   if (splits < 1) splits = 1;
-  int kper = ((a->K + splits - 1) / splits + 31) / 32 * 32;
-  if (kper < 32) kper = 32;
+  int kper = ((a->K + splits - 1) / splits + BK - 1) / BK * BK;
+  if (kper < BK) kper = BK;
   splits = (a->K + kper - 1) / kper;
   if (splits < 1) splits = 1;
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC>), dim3(tm * tn, splits), dim3(NT), smem, st,
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB>), dim3(tm * tn, splits), dim3(NT), smem, st,
                      (const T*)a->A, (long)a->lda, (const T*)a->B, (long)a->ldb, a->M, a->N, a->K, a->a_kmod,
                      a->b_kmod, tn, kper, epi);
   return check_launch();
@@ -121,7 +125,20 @@ static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t s
 template <class T, bool A_KC, bool B_KC>
 static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
   long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * (epi.atomic && a->split_k > 1 ? a->split_k : 1);
-  if (a->tile == 128 || (a->tile == 0 && t128 >= 192)) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st);
+  if constexpr (sizeof(T) == 2) {     // experimental variants for in-process A/B (tools/gemm_ab.py)
+    if (a->tile == 1281) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 32, true>(a, epi, st);
+    if (a->tile == 1282) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, false>(a, epi, st);
+    if (a->tile == 1283) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 32, false>(a, epi, st);
+    if (a->tile == 2561) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 32, true>(a, epi, st);
+    if (a->tile == 2562) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, false>(a, epi, st);
+    if (a->tile == 2563) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, false>(a, epi, st);
+  }
+  if (a->tile == 128 || (a->tile == 0 && t128 >= 192)) {
+    // bf16: BK = 64 (each row contributes a full 128-byte line per slab) + two LDS buffers: +30 % over BK = 32 on the
+    // long-K gradient GEMMs (tools/gemm_ab.py, interleaved in one process)
+    if constexpr (sizeof(T) == 2) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st);
+    else return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st);
+  }
   return launch_cfg<T, 64, 64, 32, 32, A_KC, B_KC>(a, epi, st);
 }
 

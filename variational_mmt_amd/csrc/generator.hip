@@ -26,16 +26,24 @@ struct GenArgs {
   const float* lse; float inv_norm; void* GT; long ldgt;               // T [V][ldgt]
 };
 
+// Tile: 128 vocabulary rows x 256 tokens, 8 waves (2 along V x 4 along tokens, 64x64 each), BK = 64, one LDS buffer
+// (K = H is short: 8 slabs at H = 512) -- the fastest of the shapes tried on [30000 x 5120 x 512] (tools/gemm_ab.py).
+template <class T> struct GenCfg {
+  static constexpr int BMV = 128, BNM = 256, BK = sizeof(T) == 2 ? 64 : 32, NT = 512, TI = 2, TJ = 2;
+  static constexpr bool DB = false;
+};
+
 template <class T, int MODE>
-__global__ void __launch_bounds__(256) gen_kernel(GenArgs a, int tiles_m) {
-  constexpr int BK = 32, NT = 256, BMV = 128, BNM = 128, TI = 2, TJ = 2;
+__global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
+  using Cf = GenCfg<T>;
+  constexpr int BK = Cf::BK, NT = Cf::NT, BMV = Cf::BMV, BNM = Cf::BNM, TI = Cf::TI, TJ = Cf::TJ;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
-  const int tile = blockIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tv = tile / tiles_m, tm = tile % tiles_m;
   const int v0 = tv * BMV, m0 = tm * BNM;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wv = wave >> 1, wm = wave & 1;
+  const int wv = wave >> 2, wm = wave & 3;
   int aoff[TI] = {wv * 64, wv * 64 + 32};
   int boff[TJ] = {wm * 64, wm * 64 + 32};
   f32x16 acc[TI][TJ];
@@ -46,40 +54,58 @@ __global__ void __launch_bounds__(256) gen_kernel(GenArgs a, int tiles_m) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   LinearMap amap{v0, a.V}, bmap{m0, a.M};
-  gemm_mainloop<T, BMV, BNM, BK, NT, true, true, TI, TJ>((const T*)a.W, a.ldw, amap, (const T*)a.O, a.ldo, bmap, a.K,
-                                                          0, 0, aoff, boff, acc, smem);
-  // bias add; rows past V -> -inf
+  gemm_mainloop<T, BMV, BNM, BK, NT, true, true, TI, TJ, LinearMap, LinearMap, Cf::DB>(
+      (const T*)a.W, a.ldw, amap, (const T*)a.O, a.ldo, bmap, a.K, 0, 0, aoff, boff, acc, smem);
+  // A lane owns token columns m_j and, per 32-row tile i, the vocabulary rows vb_i + 8q + s (q, s = 0..3) where
+  // vb_i = v0 + aoff[i] + 4*(lane>>5): four consecutive rows per register group q -> one 16-byte bias load per group.
+  const int hi4 = 4 * (lane >> 5);
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int v = v0 + aoff[i] + acc_row(r, lane);
-      float bv = v < a.V ? a.bias[v] : -INFINITY;
+    for (int q = 0; q < 4; ++q) {
+      const int vb = v0 + aoff[i] + hi4 + 8 * q;
+      f32x4 bv;
+      if (vb + 3 < a.V && ((((uintptr_t)(a.bias + vb)) & 15) == 0)) bv = *reinterpret_cast<const f32x4*>(a.bias + vb);
+      else {
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) acc[i][j][r] = v < a.V ? acc[i][j][r] + bv : -INFINITY;
+        for (int s_ = 0; s_ < 4; ++s_) bv[s_] = vb + s_ < a.V ? a.bias[vb + s_] : 0.f;
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const bool ok = vb + s_ < a.V;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j][4 * q + s_] = ok ? acc[i][j][4 * q + s_] + bv[s_] : -INFINITY;
+      }
     }
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int m = m0 + boff[j] + (lane & 31);
     const bool mv = m < a.M;
-    const long long ym = mv ? a.y[m] : -1;
+    const int ym = mv ? (int)a.y[m] : -1;
     if constexpr (MODE == 0) {
-      float mx = -INFINITY;
+      float mx = -INFINITY, tl = 0.f;
       int mi = 0x7fffffff;
+      bool hit = false;
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          int v = v0 + aoff[i] + acc_row(r, lane);
-          float x = acc[i][j][r];
-          if (x > mx) { mx = x; mi = v; }          // rows visited in increasing v per lane-half: first max wins
-          if (v == ym) a.tgt_logit[m] = x;
+          const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
+          const float x = acc[i][j][r];
+          const bool gt = x > mx;                    // rows visited in increasing v per lane: first max wins
+          mi = gt ? v : mi;
+          mx = gt ? x : mx;
+          const bool h = v == ym;
+          tl = h ? x : tl;
+          hit = hit || h;
         }
       float sm = 0.f;
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sm += (mx == -INFINITY) ? 0.f : __expf(acc[i][j][r] - mx);
+        for (int r = 0; r < 16; ++r) sm += __expf(acc[i][j][r] - mx);      // exp(-inf - finite) = 0; all -inf handled below
+      if (mx == -INFINITY) sm = 0.f;
+      if (hit) a.tgt_logit[m] = tl;
       // combine with the other half-wave (same token column, interleaved rows)
       float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
       int omi = __shfl_xor(mi, 32, 64);
@@ -93,17 +119,21 @@ __global__ void __launch_bounds__(256) gen_kernel(GenArgs a, int tiles_m) {
     } else {
       const float l = mv ? a.lse[m] : 0.f;
       const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
-      T* GT = reinterpret_cast<T*>(a.GT);
+      if (mv) {
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i) {
+          const int vb = v0 + aoff[i] + hi4;
+          T* gp = reinterpret_cast<T*>(a.GT) + (long)vb * a.ldgt + m;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int v = v0 + aoff[i] + acc_row(r, lane);
-          if (mv && v < a.V) {
-            float g = (__expf(acc[i][j][r] - l) - (v == ym ? 1.f : 0.f)) * sc;
-            GT[(long)v * a.ldgt + m] = from_f<T>(g);
+          for (int r = 0; r < 16; ++r) {
+            const int dv = (r & 3) + 8 * (r >> 2);
+            if (vb + dv < a.V) {
+              float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
+              gp[(long)dv * a.ldgt] = from_f<T>(g);
+            }
           }
         }
+      }
     }
   }
 }
@@ -163,9 +193,14 @@ __global__ void __launch_bounds__(1024) gen_combine_kernel(const float* __restri
 
 template <class T, int MODE>
 static int launch_gen(const GenArgs& a, hipStream_t st) {
-  int tv = (a.V + 127) / 128, tm = (a.M + 127) / 128;
-  size_t sm = gemm_smem_elems<T, 128, 128, 32>() * sizeof(T);
-  hipLaunchKernelGGL((gen_kernel<T, MODE>), dim3(tv * tm), dim3(256), sm, st, a, tm);
+  using Cf = GenCfg<T>;
+  int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + Cf::BNM - 1) / Cf::BNM;
+  size_t sm = gemm_smem_elems<T, Cf::BMV, Cf::BNM, Cf::BK, true, true, Cf::DB>() * sizeof(T);
+  if (sm > 64 * 1024) {
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute((const void*)gen_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done = true; }
+  }
+  hipLaunchKernelGGL((gen_kernel<T, MODE>), dim3(tv * tm), dim3(Cf::NT), sm, st, a, tm);
   return check_launch();
 }
 
