@@ -205,6 +205,34 @@ __device__ __forceinline__ void stage_rows(char* lds, int row0, int nrows, int k
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// epilogue operands of the forward cell, fetched BEFORE the staging wait so that their latency hides behind it
+struct CellInF { float gx[4]; float cp; long long len; };
+__device__ __forceinline__ CellInF cell_fwd_load(const StepDirF& d, const long long* lens, int b, int u, int H, int B) {
+  CellInF in;
+  const bool ok = b < B;
+  const float* gx = d.gx + (long)(ok ? b : 0) * d.ld_gx + u;
+  in.gx[0] = gx[0]; in.gx[1] = gx[H]; in.gx[2] = gx[2 * H]; in.gx[3] = gx[3 * (long)H];
+  in.cp = d.c_prev ? d.c_prev[(long)(ok ? b : 0) * d.ld_cprev + u] : 0.f;
+  in.len = lens ? lens[ok ? b : 0] : 0;
+  return in;
+}
+__device__ __forceinline__ void cell_fwd_apply(const StepDirF& d, bool has_lens, const CellInF& in, int b, int u, int H,
+                                               float pi, float pf, float pg, float po) {
+  float i = sigmoidf_(pi + in.gx[0]), f = sigmoidf_(pf + in.gx[1]), g = tanhf_(pg + in.gx[2]), o = sigmoidf_(po + in.gx[3]);
+  float c = f * in.cp + i * g;
+  float h = o * tanhf_(c);
+  const bool valid = !has_lens || d.t < in.len;
+  bf16_t* gs = reinterpret_cast<bf16_t*>(d.gates) + (long)b * d.ld_gates + u;
+  gs[0] = f2bf(i); gs[H] = f2bf(f); gs[2 * H] = f2bf(g); gs[3 * (long)H] = f2bf(o);
+  d.c_out[(long)b * d.ld_c + u] = valid ? c : in.cp;
+  reinterpret_cast<bf16_t*>(d.h_out)[(long)b * d.ld_h + u] = f2bf(valid ? h : 0.f);
+  const bool cap = d.capture == 3 || (d.capture == 1 && d.t == in.len - 1) || (d.capture == 2 && d.t == 0);
+  if (cap && d.h_n) {
+    reinterpret_cast<bf16_t*>(d.h_n)[(long)b * d.ld_hn + u] = f2bf(h);
+    d.c_n[(long)b * d.ld_cn + u] = c;
+  }
+}
+
 __global__ void __launch_bounds__(256) lstm_step_fwd_fast(StepArgsF a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const StepDirF& d = a.d[blockIdx.z];
@@ -212,6 +240,11 @@ __global__ void __launch_bounds__(256) lstm_step_fwd_fast(StepArgsF a) {
   const int m0 = blockIdx.x * 32, u0 = blockIdx.y * 16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave & 1, wk = wave >> 1;
+  const int u = u0 + (lane & 15);
+  // this wave finishes rows r = 2*wk, 2*wk+1 of its 16-row tile (both K halves are folded through LDS)
+  const int brow0 = m0 + wm * 16 + (lane >> 4) * 4 + 2 * wk;
+  CellInF in0 = cell_fwd_load(d, a.lens, brow0, u, H, B);
+  CellInF in1 = cell_fwd_load(d, a.lens, brow0 + 1, u, H, B);
   f32x4_t acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -222,13 +255,14 @@ __global__ void __launch_bounds__(256) lstm_step_fwd_fast(StepArgsF a) {
     if (k0 > 0) __syncthreads();
     stage_rows(lds, 0, 32, kc * 2, [&](int r) { int b = m0 + r; return b < B ? hp + ((long)b * d.ld_hprev + k0) * 2 : nullptr; },
                wave, 4, lane);
-    stage_rows(lds, 32, 64, kc * 2, [&](int r) { int g = r >> 4, u = u0 + (r & 15);
-                 return wp + (((long)g * H + u) * d.ld_w + k0) * 2; }, wave, 4, lane);
+    stage_rows(lds, 32, 64, kc * 2, [&](int r) { int g = r >> 4, uu = u0 + (r & 15);
+                 return wp + (((long)g * H + uu) * d.ld_w + k0) * 2; }, wave, 4, lane);
     __syncthreads();                                                // hipcc drains vmcnt(0) here: all pieces landed
     const int nks = kc / 32, half = (nks + 1) / 2;
     const int ks0 = wk == 0 ? 0 : half, ks1 = wk == 0 ? half : nks;
     const char* arow = lds + (wm * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
     const char* brow = lds + (32 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
+#pragma unroll 2
     for (int ks = ks0; ks < ks1; ++ks) {
       bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
 #pragma unroll
@@ -238,27 +272,64 @@ __global__ void __launch_bounds__(256) lstm_step_fwd_fast(StepArgsF a) {
       }
     }
   }
-  // fold the two K halves: waves 2,3 hand their partial tiles to waves 0,1 through LDS
+  // fold the two K halves through LDS: every wave publishes its partial tile, then finishes 2 of the 4 rows
   __syncthreads();
-  float* red = reinterpret_cast<float*>(lds);
-  if (wk == 1) {
+  float* red = reinterpret_cast<float*>(lds);                      // [wk][wm][g][r][lane]
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wm * 4 + g) * 4 + r) * 64 + lane] = acc[g][r];
-  }
+    for (int r = 0; r < 4; ++r) red[(((wk * 2 + wm) * 4 + g) * 4 + r) * 64 + lane] = acc[g][r];
   __syncthreads();
-  if (wk == 1) return;
-  const int u = u0 + (lane & 15);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int b = m0 + wm * 16 + (lane >> 4) * 4 + r;
+  for (int rr = 0; rr < 2; ++rr) {
+    const int r = 2 * wk + rr;
+    const int b = brow0 + rr;
     if (b >= B) continue;
     float p[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) p[g] = acc[g][r] + red[((wm * 4 + g) * 4 + r) * 64 + lane];
-    cell_fwd<bf16_t>(d, a.lens, b, u, H, p[0], p[1], p[2], p[3]);
+    for (int g = 0; g < 4; ++g)
+      p[g] = red[(((0 * 2 + wm) * 4 + g) * 4 + r) * 64 + lane] + red[(((1 * 2 + wm) * 4 + g) * 4 + r) * 64 + lane];
+    cell_fwd_apply(d, a.lens != nullptr, rr == 0 ? in0 : in1, b, u, H, p[0], p[1], p[2], p[3]);
   }
+}
+
+struct CellInB { float i, f, g, o, c, cp, dha, dcc, dhn, dcn; long long len; };
+__device__ __forceinline__ CellInB cell_bwd_load(const StepDirB& d, const long long* lens, int b, int u, int H, int B) {
+  CellInB in;
+  const long bb = b < B ? b : 0;
+  const bf16_t* gs = reinterpret_cast<const bf16_t*>(d.gates) + bb * d.ld_gates + u;
+  in.i = bf2f(gs[0]); in.f = bf2f(gs[H]); in.g = bf2f(gs[2 * H]); in.o = bf2f(gs[3 * (long)H]);
+  in.c = d.c_t[bb * d.ld_ct + u];
+  in.cp = d.c_prev ? d.c_prev[bb * d.ld_cp + u] : 0.f;
+  in.dha = d.dh_above ? bf2f(reinterpret_cast<const bf16_t*>(d.dh_above)[bb * d.ld_dha + u]) : 0.f;
+  in.dcc = d.dc_carry[bb * d.ld_dcc + u];
+  in.dhn = d.dh_n ? d.dh_n[bb * d.ld_dhn + u] : 0.f;
+  in.dcn = d.dh_n ? d.dc_n[bb * d.ld_dcn + u] : 0.f;
+  in.len = lens ? lens[bb] : 0;
+  return in;
+}
+__device__ __forceinline__ void cell_bwd_apply(const StepDirB& d, bool has_lens, const CellInB& in, int b, int u, int H, float dh) {
+  const bool valid = !has_lens || d.t < in.len;
+  bf16_t* dgo = reinterpret_cast<bf16_t*>(d.dgates_out) + (long)b * d.ld_dgo + u;
+  float* dcc = d.dc_carry + (long)b * d.ld_dcc + u;
+  if (!valid) {
+    dgo[0] = 0; dgo[H] = 0; dgo[2 * H] = 0; dgo[3 * (long)H] = 0;
+    *dcc = 0.f;
+    return;
+  }
+  float dc = in.dcc;
+  dh += in.dha;
+  const bool inj = d.inject == 3 || (d.inject == 1 && d.t == in.len - 1) || (d.inject == 2 && d.t == 0);
+  if (inj) { dh += in.dhn; dc += in.dcn; }
+  float tc = tanhf_(in.c);
+  float d_o = dh * tc;
+  dc += dh * in.o * (1.f - tc * tc);
+  float d_i = dc * in.g, d_f = dc * in.cp, d_g = dc * in.i;
+  dgo[0] = f2bf(d_i * in.i * (1.f - in.i));
+  dgo[H] = f2bf(d_f * in.f * (1.f - in.f));
+  dgo[2 * H] = f2bf(d_g * (1.f - in.g * in.g));
+  dgo[3 * (long)H] = f2bf(d_o * in.o * (1.f - in.o));
+  *dcc = dc * in.f;
 }
 
 __global__ void __launch_bounds__(256) lstm_step_bwd_fast(StepArgsB a) {
@@ -268,35 +339,56 @@ __global__ void __launch_bounds__(256) lstm_step_bwd_fast(StepArgsB a) {
   const int m0 = blockIdx.x * 32, u0 = blockIdx.y * 32;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mt = wave & 1, nt = wave >> 1;
+  const int u = u0 + nt * 16 + (lane & 15);
+  const int b0 = m0 + mt * 16 + (lane >> 4) * 4;
+  const bool uok = u < H;
+  CellInB in[4];
+  if (a.mode == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) in[r] = cell_bwd_load(d, a.lens, b0 + r, uok ? u : 0, H, B);
+  }
   f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (d.dgates_next) {
     const char* ap = reinterpret_cast<const char*>(d.dgates_next);
     const char* wp = reinterpret_cast<const char*>(d.w_hh_t);
-    for (int k0 = 0; k0 < K; k0 += FAST_KCH) {
-      const int kc = min(FAST_KCH, K - k0);
+    constexpr int BUF = 64 * FAST_PITCH;                            // one K chunk: 32 dgates rows + 32 W_hh^T rows
+    for (int k0 = 0; k0 < K; k0 += 2 * FAST_KCH) {                  // two chunks per memory round trip
       if (k0 > 0) __syncthreads();
-      stage_rows(lds, 0, 32, kc * 2, [&](int r) { int b = m0 + r; return b < B ? ap + ((long)b * d.ld_dgn + k0) * 2 : nullptr; },
-                 wave, 4, lane);
-      stage_rows(lds, 32, 32, kc * 2, [&](int r) { int u = u0 + r; return u < H ? wp + ((long)u * d.ld_wt + k0) * 2 : nullptr; },
-                 wave, 4, lane);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int kk = k0 + c * FAST_KCH;
+        const int kc = min(FAST_KCH, K - kk);
+        if (kc <= 0) break;
+        stage_rows(lds + c * BUF, 0, 32, kc * 2, [&](int r) { int b = m0 + r; return b < B ? ap + ((long)b * d.ld_dgn + kk) * 2 : nullptr; },
+                   wave, 4, lane);
+        stage_rows(lds + c * BUF, 32, 32, kc * 2, [&](int r) { int uu = u0 + r; return uu < H ? wp + ((long)uu * d.ld_wt + kk) * 2 : nullptr; },
+                   wave, 4, lane);
+      }
       __syncthreads();
-      const char* arow = lds + (mt * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
-      const char* brow = lds + (32 + nt * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
-      const int nks = kc / 32;
-      for (int ks = 0; ks < nks; ++ks) {
-        bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
-        bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + ks * 64);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int kk = k0 + c * FAST_KCH;
+        const int kc = min(FAST_KCH, K - kk);
+        if (kc <= 0) break;
+        const char* arow = lds + c * BUF + (mt * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
+        const char* brow = lds + c * BUF + (32 + nt * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
+        const int nks = kc / 32;
+#pragma unroll 4
+        for (int ks = 0; ks < nks; ++ks) {
+          bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
+          bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + ks * 64);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+        }
       }
     }
   }
-  const int u = u0 + nt * 16 + (lane & 15);
-  if (u >= H) return;
+  if (!uok) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int b = m0 + mt * 16 + (lane >> 4) * 4 + r;
+    const int b = b0 + r;
     if (b >= B) continue;
-    cell_bwd<bf16_t>(d, a.lens, a.mode, b, u, H, acc[r]);
+    if (a.mode == 1) d.dh0_out[(long)b * d.ld_dh0 + u] = acc[r];
+    else cell_bwd_apply(d, a.lens != nullptr, in[r], b, u, H, acc[r]);
   }
 }
 
@@ -373,7 +465,7 @@ extern "C" int vmmt_lstm_step_bwd(int dtype, int ndir, const vmmt_lstm_dir_bwd* 
       ok = ok && (!dirs[k].dgates_next || (al16(dirs[k].dgates_next, dirs[k].ld_dgn) && al16(dirs[k].w_hh_t, dirs[k].ld_wt)));
     if (ok) {
       static bool attr_set = false;
-      size_t sm = (size_t)64 * FAST_PITCH;
+      size_t sm = (size_t)128 * FAST_PITCH;
       if (!attr_set) { hipFuncSetAttribute((const void*)lstm_step_bwd_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
       hipLaunchKernelGGL(lstm_step_bwd_fast, dim3((B + 31) / 32, (H + 31) / 32, ndir), dim3(256), sm, (hipStream_t)stream, a);
       return check_launch();
