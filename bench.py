@@ -130,7 +130,7 @@ def main():
     dom = {"gen_fwd": [], "gen_bwd": []}
 
     def wrap(plan, index, key):
-        fn, args, name, keep = plan[index]
+        fn, args, name, keep, sid = plan[index]
 
         def timed_fn(*x):
             if not dom.get("on"):
@@ -142,14 +142,14 @@ def main():
             dom[key].append((s, e_))
             return rc
         timed_fn.__name__ = name
-        plan[index] = (timed_fn, args, name, keep)
+        plan[index] = (timed_fn, args, name, keep, sid)
 
     wrap(ws0.plan_loss_train, 0, "gen_fwd")
 
     for i in range(a.warmup):
         step(i)
     # backward plan exists now: hook the gen_loss_bwd entry
-    for j, (fn, args, name, keep) in enumerate(ws0.plan_bwd):
+    for j, (fn, args, name, keep, sid) in enumerate(ws0.plan_bwd):
         if name == "vmmt_gen_loss_bwd":
             wrap(ws0.plan_bwd, j, "gen_bwd")
     torch.cuda.synchronize()

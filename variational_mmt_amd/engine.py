@@ -106,6 +106,9 @@ class Engine(object):
         self.rng_counter = 1234567 + seed
         self.reparam_grad = False    # H2: as executed (sample detached)
         self.stats_host = None
+        self._sid = 0
+        self.side_stream = torch.cuda.Stream(device=self.dev)
+        self.use_side_stream = True
 
     # ------------------------------------------------------------------------------------------------ arena
     def _build_arena(self, seed, param_init):
@@ -224,17 +227,46 @@ class Engine(object):
                 accumulate = 1          # gradients always ACCUMULATE into the arena (zeroed at the start of a step)
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
                        add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k)
-        plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a))
+        plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
 
     def _call(self, plan, fn, *args):
-        plan.append((fn, args, fn.__name__, None))
+        plan.append((fn, args, fn.__name__, None, self._sid))
 
-    @staticmethod
-    def _run(plan, stream):
-        for fn, args, name, _keep in plan:
-            rc = fn(*args, stream)
-            if rc != 0:
-                L.check(rc, name)
+    # -- two-stream plans: entries carry a stream id (0 = main = torch's current stream, 1 = side stream); EV_RECORD /
+    #    EV_WAIT entries fork and join them.  Work that is off the critical path of the step (weight-gradient GEMMs, bias
+    #    sums, the image / q(z|x) networks' backward) runs on the side stream underneath the latency-bound LSTM steps.
+    def _record(self, plan, ev):
+        plan.append((None, ev, "EV_RECORD", None, self._sid))
+
+    def _wait(self, plan, ev):
+        plan.append((None, ev, "EV_WAIT", None, self._sid))
+
+    def _run(self, plan, events=None):
+        main = torch.cuda.current_stream(self.dev)
+        side = self.side_stream if self.use_side_stream else main
+        ts = (main, side)
+        hs = (main.cuda_stream, side.cuda_stream)
+        for fn, args, name, _keep, sid in plan:
+            if fn is None:
+                if side is main:
+                    continue
+                if name == "EV_RECORD":
+                    ev = events.get(args)
+                    if ev is None:
+                        ev = events[args] = torch.cuda.Event()
+                    ev.record(ts[sid])
+                else:
+                    ts[sid].wait_event(events[args])
+            elif name == "memset":
+                if sid == 0 or side is main:
+                    args[0].zero_()
+                else:
+                    with torch.cuda.stream(side):
+                        args[0].zero_()
+            else:
+                rc = fn(*args, hs[sid])
+                if rc != 0:
+                    L.check(rc, name)
 
     # ------------------------------------------------------------------------------------------------ workspace
     def workspace(self, B, S, Tp):
@@ -332,6 +364,7 @@ class Workspace(object):
         self.dh1v = nb(B, D)
         self.dzt = nb(B, Z, f32)
         self._keep = []
+        self.events = {}
         self.plan_fwd_train = self._plan_forward(True)
         self.plan_fwd_eval = self._plan_forward(False)
         self.plan_loss_train = self._plan_loss(True)
@@ -478,6 +511,9 @@ class Workspace(object):
 
     # ---------------------------------------------------------------------------------------------- backward plan
     def _plan_backward(self, inv_norm, batch_global, kl_mult, use_freebits, margin, training_dropout):
+        """Backward of loss/normalization through the whole model.  Stream 0 carries the critical path
+        (G^T -> dO -> attention -> decoder LSTM -> encoder LSTM); stream 1 carries everything that only produces
+        parameter gradients (image / q(z|x) networks, dWg, dW_o, dW_a, LSTM weight/bias gradients, embedding scatters)."""
         e, d, lib = self.e, self.e.d, self.e.lib
         B, S, Tp, M, MS = self.B, self.S, self.Tp, self.M, self.MS
         H, Hd, E, Z, D, V, Lyr, dirs = d.hid, d.hd, d.emb, d.z, d.img, d.vt, d.layers, d.dirs
@@ -485,7 +521,12 @@ class Workspace(object):
         P = []
         drop = training_dropout and d.dropout > 0
         wg = e.sh["wg"]
-        # --- image term + its network (no dependence on the text path: z is detached) -------------------------
+        MAIN, SIDE = 0, 1
+        e._sid = MAIN
+        e._record(P, "bwd_begin")
+        # ================= side: image term + its network (z is detached: independent of the text path) =========
+        e._sid = SIDE
+        e._wait(P, "bwd_begin")
         e._call(P, lib.vmmt_image_loss, dt, self.mu_v.p(), self.mu_v.ld, self.img.p(), self.img.ld, B, D, inv_norm,
                 self.dmu_v.p(), self.dmu_v.ld, self.stats.data_ptr())
         w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
@@ -515,31 +556,43 @@ class Workspace(object):
             e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, self.hbar.p(), self.hbar.ld, e.gp(pre + ".fc1.weight"), H,
                     Z, H, B, out_f32=1, split_k=-1)
             e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"))
-        # --- generator: G^T, dWg = G^T O, db = rowsum(G^T), dO = G Wg ---------------------------------------------
+        # ================= main: generator backward seed G^T, dO = G Wg ================================================
+        e._sid = MAIN
         e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
                 M, V, H, PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
-        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1, split_k=-1)
-        e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
+        e._record(P, "GT")
         e._call(P, _memset, self.dO32.t)
         e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
                 split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))), tile=128)
-        # --- dropout + tanh backward, linear_out ---------------------------------------------------------------
+        # side: dWg = G^T O, db = rowsum(G^T)
+        e._sid = SIDE
+        e._wait(P, "GT")
+        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1, split_k=-1)
+        e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
+        # main: dropout + tanh backward, linear_out
+        e._sid = MAIN
         e._call(P, lib.vmmt_act_bwd, dt, L.ACT_TANH, self.dO32.p(), self.dO32.ld, 1, self.AH.p(), self.AH.ld,
                 self.out_mask.p() if drop else None, self.out_mask.ld if drop else 0, self.dPre.p(), self.dPre.ld, M, H)
+        e._record(P, "dPre")
         wo, wa = e.sh["wo"], e.sh["wa"]
-        e._gemm(P, L.GEMM_TN, self.dPre.p(), self.dPre.ld, self.cat.p(), self.cat.ld, e.gp("decoder.attn.linear_out.weight"), 2 * H,
-                H, 2 * H, M, out_f32=1, split_k=-1)
         e._gemm(P, L.GEMM_NN, self.dPre.p(), self.dPre.ld, wo.p(), wo.ld, self.dcat.p(), self.dcat.ld, M, 2 * H, H)
         ctx = self.enc_out[Lyr - 1]
         e._call(P, lib.vmmt_attn_bwd, dt, self.dcat.p(), self.dcat.ld, self.probs.data_ptr(), self.Q.p(), self.Q.ld, ctx.p(), ctx.ld,
                 self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, H)
-        e._gemm(P, L.GEMM_TN, self.dQ.p(), self.dQ.ld, self.cat.p(0, H), self.cat.ld, e.gp("decoder.attn.linear_in.weight"), H,
-                H, H, M, out_f32=1, split_k=-1)
+        e._record(P, "dQ")
         e._gemm(P, L.GEMM_NN, self.dQ.p(), self.dQ.ld, wa.p(), wa.ld, self.dR.p(), self.dR.ld, M, H, H,
                 addend=self.dcat.p(0, H), ld_add=self.dcat.ld, add_rows=-1, add_is_T=1)
-        # --- decoder LSTM backward -------------------------------------------------------------------------------
+        e._sid = SIDE
+        e._wait(P, "dPre")
+        e._gemm(P, L.GEMM_TN, self.dPre.p(), self.dPre.ld, self.cat.p(), self.cat.ld, e.gp("decoder.attn.linear_out.weight"), 2 * H,
+                H, 2 * H, M, out_f32=1, split_k=-1)
+        e._wait(P, "dQ")
+        e._gemm(P, L.GEMM_TN, self.dQ.p(), self.dQ.ld, self.cat.p(0, H), self.cat.ld, e.gp("decoder.attn.linear_in.weight"), H,
+                H, H, M, out_f32=1, split_k=-1)
+        # ================= decoder LSTM backward (main) + its parameter gradients (side) ==========================
         dh_above = self.dR
         for l in reversed(range(Lyr)):
+            e._sid = MAIN
             last = l == Lyr - 1
             outb, ocol = (self.cat, H) if last else (self.dec_out[l], 0)
             whhT = e.sh["dec_whhT_l%d" % l]
@@ -563,6 +616,7 @@ class Workspace(object):
                 a.t, a.inject = t, 0
                 self._keep.append(arr)
                 e._call(P, lib.vmmt_lstm_step_bwd, dt, 1, arr, None, B, H, 0)
+            e._record(P, "dec_dg%d" % l)
             arr = (L.LstmDirBwd * 2)()
             a = arr[0]
             a.dgates_next, a.ld_dgn = dg.p(0), dg.ld
@@ -570,12 +624,20 @@ class Workspace(object):
             a.dh0_out, a.ld_dh0 = self.dec_dh0[l].p(), self.dec_dh0[l].ld
             self._keep.append(arr)
             e._call(P, lib.vmmt_lstm_step_bwd, dt, 1, arr, None, B, H, 1)
-            # weight gradients
+            if l > 0:       # gradient w.r.t. the layer input stays on the critical path
+                wi = e.sh["dec_wih_l%d" % l]
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wi.p(), wi.ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H, 4 * H)
+                if drop:
+                    e._call(P, lib.vmmt_mul, dt, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, self.dec_mask[l - 1].p(),
+                            self.dec_mask[l - 1].ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H)
+                dh_above = self.dec_dx[l - 1]
+            # ---- side: parameter gradients of this layer
+            e._sid = SIDE
+            e._wait(P, "dec_dg%d" % l)
             gw = "decoder.rnn.weight_hh_l%d" % l
             if Tp > 1:
                 e._gemm(P, L.GEMM_TN, dg.p(B), dg.ld, outb.p(0, ocol), outb.ld, e.gp(gw), H, 4 * H, H, (Tp - 1) * B, out_f32=1, split_k=-1)
-            e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * H, H, B, out_f32=1, split_k=-1,
-                    accumulate=1 if Tp > 1 else 0)
+            e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * H, H, B, out_f32=1, split_k=-1)
             e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_ih_l%d" % l))
             e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_hh_l%d" % l))
             gi = "decoder.rnn.weight_ih_l%d" % l
@@ -587,16 +649,11 @@ class Workspace(object):
                         M, E, 4 * H, out_f32=1, scatter_ids=self.tgt_in.data_ptr())
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
-                wi = e.sh["dec_wih_l%d" % l]
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wi.p(), wi.ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H, 4 * H)
-                if drop:
-                    e._call(P, lib.vmmt_mul, dt, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, self.dec_mask[l - 1].p(),
-                            self.dec_mask[l - 1].ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H)
-                dh_above = self.dec_dx[l - 1]
-        # --- encoder LSTM backward ---------------------------------------------------------------------------------
+        # ================= encoder LSTM backward (main) + its parameter gradients (side) ==========================
         dh_above = self.dctx
         for l in reversed(range(Lyr)):
+            e._sid = MAIN
             dg = self.enc_dgates[l]
             e._call(P, _memset, self.enc_dcc[l].t)
             for step in range(S):
@@ -624,6 +681,16 @@ class Workspace(object):
                     a.inject = 1 if k == 0 else 2
                 self._keep.append(arr)
                 e._call(P, lib.vmmt_lstm_step_bwd, dt, dirs, arr, self.src_len.data_ptr(), B, Hd, 0)
+            e._record(P, "enc_dg%d" % l)
+            wih = e.sh["enc_wih_l%d" % l]
+            if l > 0:
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H, dirs * 4 * Hd)
+                if drop:
+                    e._call(P, lib.vmmt_mul, dt, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, self.enc_mask[l - 1].p(),
+                            self.enc_mask[l - 1].ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H)
+                dh_above = self.enc_dx[l - 1]
+            e._sid = SIDE
+            e._wait(P, "enc_dg%d" % l)
             xin = (self.Xs if l == 0 else (self.enc_xdrop[l - 1] if drop else self.enc_out[l - 1]))
             xcols = E if l == 0 else H
             for k, suf in enumerate([""] + (["_reverse"] if d.brnn else [])):
@@ -639,16 +706,14 @@ class Workspace(object):
                 e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
                 e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, xin.p(), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)), xcols,
                         4 * Hd, xcols, MS, out_f32=1, split_k=-1)
-            wih = e.sh["enc_wih_l%d" % l]
             if l == 0:
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                         MS, E, dirs * 4 * Hd, out_f32=1, scatter_ids=self.src.data_ptr())
-            else:
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H, dirs * 4 * Hd)
-                if drop:
-                    e._call(P, lib.vmmt_mul, dt, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, self.enc_mask[l - 1].p(),
-                            self.enc_mask[l - 1].ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H)
-                dh_above = self.enc_dx[l - 1]
+        # join
+        e._sid = SIDE
+        e._record(P, "side_done")
+        e._sid = MAIN
+        e._wait(P, "side_done")
         return P
 
     def _latent_bwd_args(self, batch_global, kl_mult, use_freebits, margin, inv_norm):
@@ -661,9 +726,9 @@ class Workspace(object):
         if self._bwd_key != key:
             self.plan_bwd = self._plan_backward(inv_norm, batch_global, kl_mult, use_freebits, margin, drop)
             self._bwd_key = key
-        fn, _, name, keep = self.plan_bwd[self._latent_bwd_index]
+        fn, _, name, keep, sid = self.plan_bwd[self._latent_bwd_index]
         self.plan_bwd[self._latent_bwd_index] = (fn, self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm),
-                                                 name, keep)
+                                                 name, keep, sid)
         return self.plan_bwd
 
     def ones_col(self):
@@ -672,8 +737,8 @@ class Workspace(object):
         return self._ones
 
 
-def _memset(t, stream):
-    """plan entry: zero a torch tensor on the current stream (hipMemsetAsync through torch)."""
+def _memset(t, stream=None):
+    """plan entry: zero a torch tensor (hipMemsetAsync through torch) -- executed by Engine._run on the entry's stream."""
     t.zero_()
     return 0
 
@@ -732,16 +797,16 @@ def _engine_methods():
                         L.check(self.lib.vmmt_dropout_mask(self.dt, buf.p(), buf.rows * buf.ld, d.dropout, self.rng_counter, st),
                                 "vmmt_dropout_mask")
         plan = ws.plan_fwd_train if training else ws.plan_fwd_eval
-        fn, args, name, keep = plan[ws._img_call_index]
-        plan[ws._img_call_index] = (fn, (L.F32, tab.data_ptr(), tab.shape[1]) + tuple(args[3:]), name, keep)
-        self._run(plan, st)
+        fn, args, name, keep, sid = plan[ws._img_call_index]
+        plan[ws._img_call_index] = (fn, (L.F32, tab.data_ptr(), tab.shape[1]) + tuple(args[3:]), name, keep, sid)
+        self._run(plan, ws.events)
         ws.training = training
         return ws
 
     def loss(self, ws):
         """statistics of _compute_loss without backward (monolithic_compute_loss, Loss.py:68-86)."""
         st = self.stream()
-        self._run(ws.plan_loss_train if ws.training else ws.plan_loss_eval, st)
+        self._run(ws.plan_loss_train if ws.training else ws.plan_loss_eval, ws.events)
         L.check(self.lib.vmmt_image_loss(self.dt, ws.mu_v.p(), ws.mu_v.ld, ws.img.p(), ws.img.ld, ws.B, self.d.img, 0.0, None, 0,
                                          ws.stats.data_ptr(), st), "vmmt_image_loss")
         return ws
@@ -758,9 +823,9 @@ def _engine_methods():
             self.flat_g.zero_()
         if not ws.training:
             raise RuntimeError("loss_backward() after an eval-mode forward")
-        self._run(ws.plan_loss_train, st)
+        self._run(ws.plan_loss_train, ws.events)
         plan = ws.backward_plan(1.0 / norm, bg, kl_mult, use_freebits, margin, bool(ws.training))
-        self._run(plan, st)
+        self._run(plan, ws.events)
         return ws
 
     def read_stats(self, ws, batch_global=None, kl_mult=1.0, use_freebits=False, margin=0.0):
