@@ -81,6 +81,7 @@ typedef struct vmmt_lstm_dir_fwd {
   const void* c_prev; int64_t ld_cprev;  /* f32 [B][ld]  (NULL = zeros)                                         */
   const void* w_hh;   int64_t ld_w;      /* T   [4H][ld] recurrent weight, k contiguous                         */
   const void* gx;     int64_t ld_gx;     /* f32 [B][ld]  row block of step t                                    */
+  const void* gx2;    int64_t ld_gx2;    /* f32 [B][ld]  optional per-sentence addend (z W_z^T + b; VI_Model1.py:99-100) */
   void* gates;        int64_t ld_gates;  /* T   [B][ld]  out: post-activation i,f,g,o (saved for backward)      */
   void* c_out;        int64_t ld_c;      /* f32 [B][ld]  out: cell state (frozen at padded positions)           */
   void* h_out;        int64_t ld_h;      /* T   [B][ld]  out: h (zero at padded positions)                      */
@@ -194,6 +195,16 @@ int vmmt_image_loss(int dtype, const float* mu_v, int64_t ldm, const float* img,
 /* fp32 master weight [R][C] -> compute shadow T (optionally transposed; src2 optional second addend, e.g. b_ih + b_hh) */
 int vmmt_pack(int dtype, const float* src, const float* src2, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C,
               int transpose, void* stream);
+
+/* many vmmt_pack operations in ONE launch.  `descs` is a device array of n vmmt_pack_desc; `total_chunks` the sum of
+ * their `chunks` (2048 elements each); chunk_start must be the exclusive prefix sum of `chunks`. */
+typedef struct vmmt_pack_desc {
+  const float* src; const float* src2; void* dst;
+  int64_t ld_src, ld_dst;
+  int R, C, transpose, dtype;
+  int chunk_start, chunks;
+} vmmt_pack_desc;
+int vmmt_pack_multi(const vmmt_pack_desc* descs, int n, int total_chunks, void* stream);
 
 /* ---- optimiser: clip_grad_norm + Adam over a flat fp32 arena (onmt/Optim.py:68-70,94-96) -------------------------- */
 int vmmt_sumsq(const float* g, int64_t n, float* out /* += */, void* stream);

@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
 
 class LstmDirFwd(C.Structure):
     _fields_ = [("h_prev", vp), ("ld_hprev", i64), ("c_prev", vp), ("ld_cprev", i64), ("w_hh", vp), ("ld_w", i64),
-                ("gx", vp), ("ld_gx", i64), ("gates", vp), ("ld_gates", i64), ("c_out", vp), ("ld_c", i64),
+                ("gx", vp), ("ld_gx", i64), ("gx2", vp), ("ld_gx2", i64), ("gates", vp), ("ld_gates", i64), ("c_out", vp), ("ld_c", i64),
                 ("h_out", vp), ("ld_h", i64), ("h_n", vp), ("ld_hn", i64), ("c_n", vp), ("ld_cn", i64),
                 ("t", i32), ("capture", i32)]
 
@@ -40,6 +40,11 @@ class LstmDirBwd(C.Structure):
                 ("ld_cp", i64), ("dc_carry", vp), ("ld_dcc", i64), ("dgates_out", vp), ("ld_dgo", i64),
                 ("dh_n", vp), ("ld_dhn", i64), ("dc_n", vp), ("ld_dcn", i64), ("dh0_out", vp), ("ld_dh0", i64),
                 ("t", i32), ("inject", i32)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", vp), ("src2", vp), ("dst", vp), ("ld_src", i64), ("ld_dst", i64), ("R", i32), ("C", i32),
+                ("transpose", i32), ("dtype", i32), ("chunk_start", i32), ("chunks", i32)]
 
 
 _SIGS = {
@@ -66,6 +71,7 @@ _SIGS = {
     "vmmt_gate_bwd": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, vp]),
     "vmmt_image_loss": (i32, [i32, vp, i64, vp, i64, i32, i32, f32, vp, i64, vp, vp]),
     "vmmt_pack": (i32, [i32, vp, vp, i64, vp, i64, i32, i32, i32, vp]),
+    "vmmt_pack_multi": (i32, [vp, i32, i32, vp]),
     "vmmt_sumsq": (i32, [vp, i64, vp, vp]),
     "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, vp]),
 }

@@ -235,6 +235,30 @@ __global__ void pack_kernel(const float* __restrict__ src, const float* __restri
   }
 }
 
+// all shadow refreshes of a step in one launch: block -> (descriptor, 2048-element chunk)
+__global__ void pack_multi_kernel(const vmmt_pack_desc* __restrict__ descs, int n) {
+  const int chunk = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {                       // last descriptor with chunk_start <= chunk
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].chunk_start <= chunk) lo = mid; else hi = mid - 1;
+  }
+  const vmmt_pack_desc d = descs[lo];
+  const long n_el = (long)d.R * d.C;
+  const long base = (long)(chunk - d.chunk_start) * 2048;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    long i = base + k * 256 + threadIdx.x;
+    if (i >= n_el) break;
+    int r, c;
+    if (!d.transpose) { r = i / d.C; c = i - (long)r * d.C; } else { c = i / d.R; r = i - (long)c * d.R; }
+    float v = d.src[(long)r * d.ld_src + c] + (d.src2 ? d.src2[(long)r * d.ld_src + c] : 0.f);
+    long o = d.transpose ? (long)c * d.ld_dst + r : (long)r * d.ld_dst + c;
+    if (d.dtype == VMMT_F32) reinterpret_cast<float*>(d.dst)[o] = v;
+    else reinterpret_cast<bf16_t*>(d.dst)[o] = f2bf(v);
+  }
+}
+
 }  // namespace vmmt
 
 using namespace vmmt;
@@ -366,5 +390,11 @@ extern "C" int vmmt_pack(int dtype, const float* src, const float* src2, int64_t
   if (dtype == VMMT_F32) hipLaunchKernelGGL(pack_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, src, src2, (long)ld_src, (float*)dst, (long)ld_dst, R, C, transpose);
   else if (dtype == VMMT_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, src, src2, (long)ld_src, (bf16_t*)dst, (long)ld_dst, R, C, transpose);
   else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_pack_multi(const vmmt_pack_desc* descs, int n, int total_chunks, void* stream) {
+  if (!descs || n <= 0 || total_chunks <= 0) return VMMT_EINVAL;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(total_chunks), dim3(256), 0, ST, descs, n);
   return check_launch();
 }

@@ -21,6 +21,7 @@ struct StepDirF {
   const float* c_prev; long ld_cprev;    // f32 [B][ld]
   const void* w_hh; long ld_w;           // T [4H][ld] (k contiguous)
   const float* gx; long ld_gx;           // f32 [B][ld]: x_t W_ih^T + b_ih + b_hh (gate-major columns g*H+u)
+  const float* gx2; long ld_gx2;         // f32 [B][ld] or null: per-sentence addend (z W_z^T + b, constant over time)
   void* gates; long ld_gates;            // T [B][ld]: saved post-activation i,f,g,o
   float* c_out; long ld_c;               // f32 [B][ld]
   void* h_out; long ld_h;                // T [B][ld] (masked output)
@@ -41,6 +42,10 @@ __device__ __forceinline__ void cell_fwd(const StepDirF& d, const long long* len
                                          float pg, float po) {
   const float* gx = d.gx + (long)b * d.ld_gx + u;
   pi += gx[0]; pf += gx[H]; pg += gx[2 * H]; po += gx[3 * (long)H];
+  if (d.gx2) {
+    const float* g2 = d.gx2 + (long)b * d.ld_gx2 + u;
+    pi += g2[0]; pf += g2[H]; pg += g2[2 * H]; po += g2[3 * (long)H];
+  }
   float i = sigmoidf_(pi), f = sigmoidf_(pf), g = tanhf_(pg), o = sigmoidf_(po);
   float cp = d.c_prev ? d.c_prev[(long)b * d.ld_cprev + u] : 0.f;
   float c = f * cp + i * g;
@@ -212,6 +217,10 @@ __device__ __forceinline__ CellInF cell_fwd_load(const StepDirF& d, const long l
   const bool ok = b < B;
   const float* gx = d.gx + (long)(ok ? b : 0) * d.ld_gx + u;
   in.gx[0] = gx[0]; in.gx[1] = gx[H]; in.gx[2] = gx[2 * H]; in.gx[3] = gx[3 * (long)H];
+  if (d.gx2) {
+    const float* g2 = d.gx2 + (long)(ok ? b : 0) * d.ld_gx2 + u;
+    in.gx[0] += g2[0]; in.gx[1] += g2[H]; in.gx[2] += g2[2 * H]; in.gx[3] += g2[3 * (long)H];
+  }
   in.cp = d.c_prev ? d.c_prev[(long)(ok ? b : 0) * d.ld_cprev + u] : 0.f;
   in.len = lens ? lens[ok ? b : 0] : 0;
   return in;
@@ -396,7 +405,8 @@ static bool al16(const void* p, long ld_elems) { return (((uintptr_t)p) & 15) ==
 
 static void fill_f(StepDirF& o, const vmmt_lstm_dir_fwd& i) {
   o.h_prev = i.h_prev; o.ld_hprev = i.ld_hprev; o.c_prev = (const float*)i.c_prev; o.ld_cprev = i.ld_cprev;
-  o.w_hh = i.w_hh; o.ld_w = i.ld_w; o.gx = (const float*)i.gx; o.ld_gx = i.ld_gx; o.gates = i.gates;
+  o.w_hh = i.w_hh; o.ld_w = i.ld_w; o.gx = (const float*)i.gx; o.ld_gx = i.ld_gx; o.gx2 = (const float*)i.gx2;
+  o.ld_gx2 = i.ld_gx2; o.gates = i.gates;
   o.ld_gates = i.ld_gates; o.c_out = (float*)i.c_out; o.ld_c = i.ld_c; o.h_out = i.h_out; o.ld_h = i.ld_h;
   o.h_n = i.h_n; o.ld_hn = i.ld_hn; o.c_n = (float*)i.c_n; o.ld_cn = i.ld_cn; o.t = i.t; o.capture = i.capture;
 }

@@ -209,11 +209,21 @@ class Engine(object):
         shadow("wg", d.vt, d.hid, "generator.0.weight")
 
     def refresh_shadows(self, stream):
+        """fp32 master -> compute shadows, all tensors in ONE launch (vmmt_pack_multi)."""
         if not self.shadows_dirty:
             return
-        f = self.lib.vmmt_pack
-        for (code, sp, s2, lds, dst, ldd, R, Cc, tr) in self.pack_calls:
-            L.check(f(code, sp, s2, lds, dst, ldd, R, Cc, tr, stream), "vmmt_pack")
+        if not hasattr(self, "_pack_table"):
+            n = len(self.pack_calls)
+            arr = (L.PackDesc * n)()
+            start = 0
+            for k, (code, sp, s2, lds, dst, ldd, R, Cc, tr) in enumerate(self.pack_calls):
+                ch = (R * Cc + 2047) // 2048
+                arr[k] = L.PackDesc(sp, s2, dst, lds, ldd, R, Cc, tr, code, start, ch)
+                start += ch
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._pack_table = host.to(self.dev)
+            self._pack_n, self._pack_chunks = n, start
+        L.check(self.lib.vmmt_pack_multi(self._pack_table.data_ptr(), self._pack_n, self._pack_chunks, stream), "vmmt_pack_multi")
         self.shadows_dirty = False
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -380,8 +390,25 @@ class Workspace(object):
         dt = e.dt
         P = []
         drop = training and d.dropout > 0
+        MAIN, SIDE = 0, 1
+        e._sid = MAIN
+        e._record(P, "fwd_begin")
+        # ---- side stream, underneath the encoder: zero the gradient arena (every gradient writer of the backward plan
+        #      runs on the side stream), target embeddings and the time-parallel part of the decoder input projection
+        e._sid = SIDE
+        e._wait(P, "fwd_begin")
+        if training:
+            e._call(P, _memset, e.flat_g)
+        e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
+        we = e.sh["dec_wih_l0_e"]
+        e._gemm(P, L.GEMM_NT, self.Xt.p(), self.Xt.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * H, E, out_f32=1)
+        e._record(P, "dec_gx")
+        e._sid = MAIN
         # a1 image rows (TrainerMultimodal.py:632-639) -- table pointer is patched in at run time (set_image_table)
-        self._img_call_index = len(P)
+        if not hasattr(self, '_img_idx'):
+            self._img_idx = {}
+        self._img_idx[bool(training)] = len(P)
         e._call(P, lib.vmmt_gather_rows, L.F32, None, D, self.img_idx.data_ptr(), self.img.p(), self.img.ld, B, D)
         # a2 source embeddings
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
@@ -438,18 +465,27 @@ class Workspace(object):
         # a5 fused mu/sigma -> sample -> KL
         e._call(P, lib.vmmt_latent_fwd, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
                 self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
-        # a6 decoder
-        e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
+        # a8 image network (location branch only; the scale branch is dead, H6 / VILoss.py:321): side stream, under the decoder
+        e._record(P, "z_ready")
+        e._sid = SIDE
+        e._wait(P, "z_ready")
+        e._call(P, lib.vmmt_gate_fwd, dt, self.z32.p(), e.pp("inf_net_image.gate_affine_transform.weight"),
+                e.pp("inf_net_image.gate_affine_transform.bias"), self.gate.data_ptr(), self.zt.p(), self.zt.ld, B, Z)
+        w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
+        e._gemm(P, L.GEMM_NT, self.zt.p(), self.zt.ld, w1.p(), w1.ld, self.h1v.p(), self.h1v.ld, B, D, Z,
+                addend=e.pp("inf_net_image.location.fc1.bias"), ld_add=D, add_rows=1, act=L.ACT_RELU)
+        e._gemm(P, L.GEMM_NT, self.h1v.p(), self.h1v.ld, w2.p(), w2.ld, self.mu_v.p(), self.mu_v.ld, B, D, D,
+                addend=e.pp("inf_net_image.location.fc2.bias"), ld_add=D, add_rows=1, out_f32=1)
+        e._record(P, "img_fwd")
+        e._sid = MAIN
+        # a6 decoder: gx[t] = emb(y_t) W_e^T (side stream, above) ; zx = z W_z^T + b is added inside the step kernel
         wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
         e._gemm(P, L.GEMM_NT, self.zT.p(), self.zT.ld, wz.p(), wz.ld, self.zx.p(), self.zx.ld, B, 4 * H, Z,
                 addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
         x, xcols = self.Xt, E
         for l in range(Lyr):
             if l == 0:
-                we = e.sh["dec_wih_l0_e"]
-                e._gemm(P, L.GEMM_NT, x.p(), x.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * H, E,
-                        addend=self.zx.p(), ld_add=self.zx.ld, add_rows=B, out_f32=1)
+                e._wait(P, "dec_gx")
             else:
                 wi, bs = e.sh["dec_wih_l%d" % l], e.sh["dec_b_l%d" % l]
                 e._gemm(P, L.GEMM_NT, x.p(), x.ld, wi.p(), wi.ld, self.dec_gx[l].p(), self.dec_gx[l].ld, M, 4 * H, H,
@@ -468,6 +504,8 @@ class Workspace(object):
                     a.c_prev, a.ld_cprev = self.dec_c[l].p((t - 1) * B), self.dec_c[l].ld
                 a.w_hh, a.ld_w = whh.p(), whh.ld
                 a.gx, a.ld_gx = self.dec_gx[l].p(t * B), self.dec_gx[l].ld
+                if l == 0:
+                    a.gx2, a.ld_gx2 = self.zx.p(), self.zx.ld
                 a.gates, a.ld_gates = self.dec_gates[l].p(t * B), self.dec_gates[l].ld
                 a.c_out, a.ld_c = self.dec_c[l].p(t * B), self.dec_c[l].ld
                 a.h_out, a.ld_h = outb.p(t * B, ocol), outb.ld
@@ -488,14 +526,7 @@ class Workspace(object):
         e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * H, act=L.ACT_TANH)
         if drop:
             e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
-        # a8 image network (location branch only; the scale branch is dead, H6 / VILoss.py:321)
-        e._call(P, lib.vmmt_gate_fwd, dt, self.z32.p(), e.pp("inf_net_image.gate_affine_transform.weight"),
-                e.pp("inf_net_image.gate_affine_transform.bias"), self.gate.data_ptr(), self.zt.p(), self.zt.ld, B, Z)
-        w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
-        e._gemm(P, L.GEMM_NT, self.zt.p(), self.zt.ld, w1.p(), w1.ld, self.h1v.p(), self.h1v.ld, B, D, Z,
-                addend=e.pp("inf_net_image.location.fc1.bias"), ld_add=D, add_rows=1, act=L.ACT_RELU)
-        e._gemm(P, L.GEMM_NT, self.h1v.p(), self.h1v.ld, w2.p(), w2.ld, self.mu_v.p(), self.mu_v.ld, B, D, D,
-                addend=e.pp("inf_net_image.location.fc2.bias"), ld_add=D, add_rows=1, out_f32=1)
+        e._wait(P, "img_fwd")            # join: the loss plans read mu_v
         return P
 
     def _plan_loss(self, training):
@@ -524,6 +555,14 @@ class Workspace(object):
         MAIN, SIDE = 0, 1
         e._sid = MAIN
         e._record(P, "bwd_begin")
+        # ================= main: generator backward seed G^T, dO = G Wg ================================================
+        e._sid = MAIN
+        e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
+                M, V, H, PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
+        e._record(P, "GT")
+        e._call(P, _memset, self.dO32.t)
+        e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
+                split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))), tile=128)
         # ================= side: image term + its network (z is detached: independent of the text path) =========
         e._sid = SIDE
         e._wait(P, "bwd_begin")
@@ -556,14 +595,6 @@ class Workspace(object):
             e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, self.hbar.p(), self.hbar.ld, e.gp(pre + ".fc1.weight"), H,
                     Z, H, B, out_f32=1, split_k=-1)
             e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"))
-        # ================= main: generator backward seed G^T, dO = G Wg ================================================
-        e._sid = MAIN
-        e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
-                M, V, H, PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
-        e._record(P, "GT")
-        e._call(P, _memset, self.dO32.t)
-        e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
-                split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))), tile=128)
         # side: dWg = G^T O, db = rowsum(G^T)
         e._sid = SIDE
         e._wait(P, "GT")
@@ -691,10 +722,18 @@ class Workspace(object):
                 dh_above = self.enc_dx[l - 1]
             e._sid = SIDE
             e._wait(P, "enc_dg%d" % l)
+            tail_toggle = [SIDE]
+
+            def alt():
+                # the encoder chain is the END of the critical path: spread its parameter gradients over both streams
+                if l == 0:
+                    tail_toggle[0] = MAIN if tail_toggle[0] == SIDE else SIDE
+                    e._sid = tail_toggle[0]
             xin = (self.Xs if l == 0 else (self.enc_xdrop[l - 1] if drop else self.enc_out[l - 1]))
             xcols = E if l == 0 else H
             for k, suf in enumerate([""] + (["_reverse"] if d.brnn else [])):
                 gw = "encoder.rnn.weight_hh_l%d%s" % (l, suf)
+                alt()
                 if S > 1:
                     if k == 0:   # h_prev[t] = out[t-1]
                         e._gemm(P, L.GEMM_TN, dg.p(B, k * 4 * Hd), dg.ld, self.enc_out[l].p(0, k * Hd), self.enc_out[l].ld, e.gp(gw), Hd,
@@ -704,9 +743,11 @@ class Workspace(object):
                                 4 * Hd, Hd, (S - 1) * B, out_f32=1, split_k=-1)
                 e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)))
                 e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
+                alt()
                 e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, xin.p(), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)), xcols,
                         4 * Hd, xcols, MS, out_f32=1, split_k=-1)
             if l == 0:
+                e._sid = MAIN
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                         MS, E, dirs * 4 * Hd, out_f32=1, scatter_ids=self.src.data_ptr())
         # join
@@ -797,8 +838,9 @@ def _engine_methods():
                         L.check(self.lib.vmmt_dropout_mask(self.dt, buf.p(), buf.rows * buf.ld, d.dropout, self.rng_counter, st),
                                 "vmmt_dropout_mask")
         plan = ws.plan_fwd_train if training else ws.plan_fwd_eval
-        fn, args, name, keep, sid = plan[ws._img_call_index]
-        plan[ws._img_call_index] = (fn, (L.F32, tab.data_ptr(), tab.shape[1]) + tuple(args[3:]), name, keep, sid)
+        ii = ws._img_idx[bool(training)]
+        fn, args, name, keep, sid = plan[ii]
+        plan[ii] = (fn, (L.F32, tab.data_ptr(), tab.shape[1]) + tuple(args[3:]), name, keep, sid)
         self._run(plan, ws.events)
         ws.training = training
         return ws
@@ -819,8 +861,7 @@ def _engine_methods():
         B = ws.B
         norm = float(normalization if normalization is not None else B)
         bg = float(batch_global if batch_global is not None else B)
-        if zero_grad:
-            self.flat_g.zero_()
+        # the gradient arena was zeroed by the training forward plan (side stream); zero_grad=False is meaningless here
         if not ws.training:
             raise RuntimeError("loss_backward() after an eval-mode forward")
         self._run(ws.plan_loss_train, ws.events)
