@@ -135,6 +135,172 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dca
   }
 }
 
+// ==============================================================================================================
+// MFMA attention for bf16 (T' <= 32, S <= 32, H % 32 == 0): one workgroup per sentence.  Q_b [T' x H] and the
+// sentence's source memory Hs_b [S x H] are staged once in LDS (zero-padded to 32 rows);
+//   scores = Q Hs^T          32x32 tile, K = H split over the 4 waves, partials folded through LDS
+//   softmax over s < len     in registers (32-lane rows)
+//   context = P Hs           K = s: Hs is read K-strided with ds_read_b64_tr_b16 straight from the same LDS image
+// backward reuses the structure: dP = dC Hs^T, dS = P (dP - sum P dP), dQ = dS Hs, dHs = P^T dC + dS^T Q.
+// ==============================================================================================================
+typedef short as16x4 __attribute__((ext_vector_type(4)));
+typedef short as16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 afragKC(const bf16_t* img, int stride, int row0, int kbase, int lane) {
+  return *reinterpret_cast<const bf16x8*>(img + (row0 + (lane & 31)) * stride + kbase + 8 * (lane >> 5));
+}
+__device__ __forceinline__ bf16x8 afragKS(const bf16_t* img, int stride, int row0, int kbase, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const bf16_t* a0 = img + (kbase + 8 * (g >> 1) + q) * stride + row0 + 16 * (g & 1) + 4 * p;
+  typedef __attribute__((address_space(3))) as16x4 lds_v;
+  as16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(a0));
+  as16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(a0 + 4 * stride));
+  as16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+// stage `nrows` rows (row r from src + r*rstride, H elements each) into a [32][pitch] image; rows >= nrows are zeroed
+__device__ __forceinline__ void astage(bf16_t* img, int pitch, const bf16_t* src, long rstride, int nrows, int H) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  for (int r = wave; r < 32; r += 4) {
+    const bf16_t* g = src + (long)r * rstride;
+    const bool vec = (((uintptr_t)g) & 15) == 0;
+    for (int c = lane * 8; c < H; c += 512) {
+      u32x4 v = zero;
+      if (r < nrows) {
+        if (vec) v = *reinterpret_cast<const u32x4*>(g + c);
+        else { bf16_t t[8]; for (int e = 0; e < 8; ++e) t[e] = g[c + e]; v = *reinterpret_cast<const u32x4*>(t); }
+      }
+      *reinterpret_cast<u32x4*>(img + r * pitch + c) = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_fwd_fast(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ ctx,
+                                                     long ldc, const long long* __restrict__ lens, bf16_t* __restrict__ cat,
+                                                     long ldcat, float* __restrict__ probs, int Tp, int B, int S, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int P = H + 8;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Hs = Qs + 32 * P;
+  float* Sc = reinterpret_cast<float*>(Hs + 32 * P);          // [4][32][33]
+  bf16_t* Pb = reinterpret_cast<bf16_t*>(Sc + 4 * 32 * 33);   // [32][40]
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int len = (int)lens[b];
+  len = len < S ? len : S;
+  astage(Qs, P, q + (long)b * ldq, (long)B * ldq, Tp, H);
+  astage(Hs, P, ctx + (long)b * ldc, (long)B * ldc, S, H);
+  __syncthreads();
+  {   // scores: this wave's K quarter
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nks = H / 16, per = (nks + 3) / 4;
+    const int k0 = wave * per, k1 = min(nks, k0 + per);
+    for (int ks = k0; ks < k1; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKC(Qs, P, 0, ks * 16, lane), afragKC(Hs, P, 0, ks * 16, lane), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Sc[(wave * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {   // softmax: wave handles rows 8w .. 8w+7, two rows per pass
+    const int t = 8 * wave + 2 * rr + (lane >> 5), s_ = lane & 31;
+    float v = Sc[(0 * 32 + t) * 33 + s_] + Sc[(1 * 32 + t) * 33 + s_] + Sc[(2 * 32 + t) * 33 + s_] + Sc[(3 * 32 + t) * 33 + s_];
+    v = s_ < len ? v : -INFINITY;
+    float m = v;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float e = s_ < len ? __expf(v - m) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    float p = e / sum;
+    if (t < Tp && s_ < S) probs[((long)t * B + b) * S + s_] = p;
+    Pb[t * 40 + s_] = f2bf(t < Tp ? p : 0.f);
+  }
+  __syncthreads();
+  for (int tile = wave; tile < H / 32; tile += 4) {   // context: 32 hidden units per tile
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKC(Pb, 40, 0, ks * 16, lane), afragKS(Hs, P, 32 * tile, ks * 16, lane), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = acc_row(r, lane);
+      if (t < Tp) cat[((long)t * B + b) * ldcat + 32 * tile + (lane & 31)] = f2bf(acc[r]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_fast(const bf16_t* __restrict__ dcat, long lddc, const float* __restrict__ probs,
+                                                     const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ ctx,
+                                                     long ldc, const long long* __restrict__ lens, bf16_t* __restrict__ dq,
+                                                     long lddq, bf16_t* __restrict__ dctx, long lddx, int Tp, int B, int S, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int P = H + 8;
+  bf16_t* dCs = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Qs = dCs + 32 * P;
+  bf16_t* Hs = Qs + 32 * P;
+  float* Sc = reinterpret_cast<float*>(Hs + 32 * P);          // [4][32][33]
+  bf16_t* Pb = reinterpret_cast<bf16_t*>(Sc + 4 * 32 * 33);   // [32][40]
+  bf16_t* dSb = Pb + 32 * 40;                                 // [32][40]
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int len = (int)lens[b];
+  len = len < S ? len : S;
+  astage(dCs, P, dcat + (long)b * lddc, (long)B * lddc, Tp, H);
+  astage(Qs, P, q + (long)b * ldq, (long)B * ldq, Tp, H);
+  astage(Hs, P, ctx + (long)b * ldc, (long)B * ldc, S, H);
+  __syncthreads();
+  {   // dP = dC Hs^T, K quarter per wave
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nks = H / 16, per = (nks + 3) / 4;
+    const int k0 = wave * per, k1 = min(nks, k0 + per);
+    for (int ks = k0; ks < k1; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKC(dCs, P, 0, ks * 16, lane), afragKC(Hs, P, 0, ks * 16, lane), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Sc[(wave * 32 + acc_row(r, lane)) * 33 + (lane & 31)] = acc[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {   // softmax backward
+    const int t = 8 * wave + 2 * rr + (lane >> 5), s_ = lane & 31;
+    float dp = Sc[(0 * 32 + t) * 33 + s_] + Sc[(1 * 32 + t) * 33 + s_] + Sc[(2 * 32 + t) * 33 + s_] + Sc[(3 * 32 + t) * 33 + s_];
+    float p = (t < Tp && s_ < len) ? probs[((long)t * B + b) * S + s_] : 0.f;
+    float dot = p * dp;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    float ds = p * (dp - dot);
+    Pb[t * 40 + s_] = f2bf(p);
+    dSb[t * 40 + s_] = f2bf(ds);
+  }
+  __syncthreads();
+  for (int tile = wave; tile < H / 32; tile += 4) {
+    f32x16 aq, ah;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ah[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // dQ[t][h] += dS[t][s] Hs[s][h]        (k = s)
+      aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKC(dSb, 40, 0, ks * 16, lane), afragKS(Hs, P, 32 * tile, ks * 16, lane), aq, 0, 0, 0);
+      // dHs[s][h] += P[t][s] dC[t][h] + dS[t][s] Q[t][h]      (k = t: both operands K-strided)
+      ah = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKS(Pb, 40, 0, ks * 16, lane), afragKS(dCs, P, 32 * tile, ks * 16, lane), ah, 0, 0, 0);
+      ah = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKS(dSb, 40, 0, ks * 16, lane), afragKS(Qs, P, 32 * tile, ks * 16, lane), ah, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane), h = 32 * tile + (lane & 31);
+      if (row < Tp) dq[((long)row * B + b) * lddq + h] = f2bf(aq[r]);
+      if (row < S) dctx[((long)row * B + b) * lddx + h] = f2bf(row < len ? ah[r] : 0.f);
+    }
+  }
+}
+
+static size_t attn_fast_lds(int H, int nimg) { return (size_t)nimg * 32 * (H + 8) * 2 + 4 * 32 * 33 * 4 + 2 * 32 * 40 * 2; }
+
 // masked mean over time of the (detached) encoder memory: hbar[b] = sum_{s<len} ctx[s][b] / len
 // (GlobalInferenceNetwork.encode_seq, onmt/modules/NormalVariationalEncoder.py:65-84)
 template <class T>
@@ -157,6 +323,14 @@ extern "C" int vmmt_attn_fwd(int dtype, const void* q, int64_t ldq, const void* 
   using namespace vmmt;
   if (!q || !ctx || !lens || !cat || !probs || S > ATT_MAXS || H > 64 * ATT_MAXJ || Tp <= 0 || B <= 0)
     return VMMT_EINVAL;
+  if (dtype == VMMT_BF16 && Tp <= 32 && S <= 32 && H % 32 == 0 && attn_fast_lds(H, 2) <= 150 * 1024) {
+    size_t sm = attn_fast_lds(H, 2);
+    static size_t attr = 0;
+    if (sm > attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr = sm; }
+    hipLaunchKernelGGL(attn_fwd_fast, dim3(B), dim3(256), sm, (hipStream_t)stream, (const bf16_t*)q, (long)ldq, (const bf16_t*)ctx,
+                       (long)ldc, (const long long*)lens, (bf16_t*)cat, (long)ldcat, probs, Tp, B, S, H);
+    return check_launch();
+  }
   size_t esz = dtype == VMMT_F32 ? 4 : 2;
   size_t need = (size_t)S * H * esz;
   int use_lds = need <= 60 * 1024;   // default dynamic-LDS limit without hipFuncSetAttribute
@@ -179,6 +353,15 @@ extern "C" int vmmt_attn_bwd(int dtype, const void* dcat, int64_t lddc, const fl
   using namespace vmmt;
   if (!dcat || !probs || !q || !ctx || !lens || !dq || !dctx || S > ATT_MAXS || H > 64 * ATT_MAXJ || Tp <= 0 || B <= 0)
     return VMMT_EINVAL;
+  if (dtype == VMMT_BF16 && Tp <= 32 && S <= 32 && H % 32 == 0 && attn_fast_lds(H, 3) <= 150 * 1024) {
+    size_t sm = attn_fast_lds(H, 3);
+    static size_t attr = 0;
+    if (sm > attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr = sm; }
+    hipLaunchKernelGGL(attn_bwd_fast, dim3(B), dim3(256), sm, (hipStream_t)stream, (const bf16_t*)dcat, (long)lddc, probs,
+                       (const bf16_t*)q, (long)ldq, (const bf16_t*)ctx, (long)ldc, (const long long*)lens, (bf16_t*)dq, (long)lddq,
+                       (bf16_t*)dctx, (long)lddx, Tp, B, S, H);
+    return check_launch();
+  }
   size_t esz = dtype == VMMT_F32 ? 4 : 2;
   size_t base = (size_t)2 * Tp * ATT_MAXS * sizeof(float);
   size_t need = (size_t)S * H * esz;
