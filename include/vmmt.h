@@ -163,8 +163,8 @@ int vmmt_gen_loss_bwd(int dtype, const void* W, int64_t ldw, const float* bias, 
  * image-feature table: TrainerMultimodal.py:632-639), out f32 or bf16 per out_dtype. */
 int vmmt_gather_rows(int out_dtype, const float* table, int64_t ldt, const int64_t* ids, void* out, int64_t ldo, int R,
                      int D, void* stream);
-/* out[c] += sum_r X[r][c]  (bias gradients) */
-int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream);
+/* out[c] += sum_r X[r][c], and out2[c] likewise when not NULL (bias gradients; b_ih and b_hh share one) */
+int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, float* out2, void* stream);
 /* out[r] += sum_c X[r][c]  (generator bias gradient: row sums of G^T) */
 int vmmt_rowsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream);
 /* scaled dropout mask: 1/(1-p) with prob 1-p else 0 (counter-based RNG; VI_Model1.py:132, Models.py:124-129) */

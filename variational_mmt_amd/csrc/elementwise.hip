@@ -28,19 +28,46 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, long ldt, co
   }
 }
 
-// out[c] += sum_r X[r][c]   (bias gradients; out must be pre-zeroed or hold a partial sum)
+// out[c] += sum_r X[r][c] (and out2[c] likewise: b_ih and b_hh of an LSTM receive the same gradient).
+// A workgroup covers 64 lanes x VEC columns and a chunk of rows split over its 4 waves: 16-byte loads, LDS fold,
+// one fp32 atomic per column and chunk.
 template <class T>
-__global__ void colsum_kernel(const T* __restrict__ X, long ld, int R, int C, float* __restrict__ out, int rows_per_block) {
-  int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  int w = threadIdx.x >> 6;
-  int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  float a = 0.f;
-  if (c < C)
-    for (int r = r0 + w; r < r1; r += 4) a += to_f<T>(X[(long)r * ld + c]);
-  __shared__ float red[4][64];
-  red[w][threadIdx.x & 63] = a;
+__global__ void colsum_kernel(const T* __restrict__ X, long ld, int R, int C, float* __restrict__ out, float* __restrict__ out2,
+                              int rows_per_block) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + lane) * VEC;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float a[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+  const bool vec = c0 + VEC <= C && ((((uintptr_t)X) & 15) == 0) && ((ld * (long)sizeof(T)) & 15) == 0;
+  if (vec) {
+    for (int r = r0 + w; r < r1; r += 4) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(X + (long)r * ld + c0);
+      const T* e_ = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) a[e] += to_f<T>(e_[e]);
+    }
+  } else if (c0 < C) {
+    for (int r = r0 + w; r < r1; r += 4)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) if (c0 + e < C) a[e] += to_f<T>(X[(long)r * ld + c0 + e]);
+  }
+  __shared__ float red[4][64][VEC + 1];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[w][lane][e] = a[e];
   __syncthreads();
-  if (w == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (w == 0) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      if (c0 + e < C) {
+        float t = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
+        atomicAdd(out + c0 + e, t);
+        if (out2) atomicAdd(out2 + c0 + e, t);
+      }
+    }
+  }
 }
 
 // out[r] += sum_c X[r][c]: one wave per row, 16-byte loads (generator bias gradient = row sums of G^T [V][M])
@@ -278,13 +305,16 @@ extern "C" int vmmt_gather_rows(int out_dtype, const float* table, int64_t ldt, 
   return check_launch();
 }
 
-extern "C" int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream) {
+extern "C" int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, float* out2, void* stream) {
   if (!X || !out || R < 0 || C <= 0) return VMMT_EINVAL;
   if (R == 0) return VMMT_OK;
-  int rpb = 256;
-  dim3 grid((C + 63) / 64, (R + rpb - 1) / rpb);
-  if (dtype == VMMT_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST, (const float*)X, (long)ld, R, C, out, rpb);
-  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)X, (long)ld, R, C, out, rpb);
+  int vec = dtype == VMMT_F32 ? 4 : 8;
+  int gx = (C + 64 * vec - 1) / (64 * vec);
+  int rpb = 128;
+  while (rpb < R && (long)gx * ((R + rpb - 1) / rpb) > 1024) rpb *= 2;
+  dim3 grid(gx, (R + rpb - 1) / rpb);
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST, (const float*)X, (long)ld, R, C, out, out2, rpb);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)X, (long)ld, R, C, out, out2, rpb);
   else return VMMT_EINVAL;
   return check_launch();
 }

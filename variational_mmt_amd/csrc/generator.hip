@@ -39,8 +39,15 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
   constexpr int BK = Cf::BK, NT = Cf::NT, BMV = Cf::BMV, BNM = Cf::BNM, TI = Cf::TI, TJ = Cf::TJ;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
+  // L2-friendly order: an XCD walks groups of 8 vocabulary tiles x all token tiles with the vocabulary tile index
+  // fastest, so the ~64 workgroups resident on an XCD share 8 Wg tiles (1 MB) and 8 O tiles (2 MB) inside its 4 MB L2
+  // instead of streaming the whole O matrix from the Infinity Cache for every vocabulary tile.
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tv = tile / tiles_m, tm = tile % tiles_m;
+  const int tiles_v = (a.V + BMV - 1) / BMV;
+  constexpr int GV = 8;
+  const int group = tile / (GV * tiles_m), in_g = tile - group * (GV * tiles_m);
+  const int gv = min(GV, tiles_v - group * GV);
+  const int tv = group * GV + in_g % gv, tm = in_g / gv;
   const int v0 = tv * BMV, m0 = tm * BNM;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wv = wave >> 2, wm = wave & 3;

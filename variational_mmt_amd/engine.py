@@ -571,13 +571,13 @@ class Workspace(object):
         w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
         e._gemm(P, L.GEMM_TN, self.dmu_v.p(), self.dmu_v.ld, self.h1v.p(), self.h1v.ld, e.gp("inf_net_image.location.fc2.weight"), D,
                 D, D, B, out_f32=1, split_k=-1)
-        e._call(P, lib.vmmt_colsum, dt, self.dmu_v.p(), self.dmu_v.ld, B, D, e.gp("inf_net_image.location.fc2.bias"))
+        e._call(P, lib.vmmt_colsum, dt, self.dmu_v.p(), self.dmu_v.ld, B, D, e.gp("inf_net_image.location.fc2.bias"), None)
         e._gemm(P, L.GEMM_NN, self.dmu_v.p(), self.dmu_v.ld, w2.p(), w2.ld, self.dh1v.p(), self.dh1v.ld, B, D, D)
         e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.dh1v.p(), self.dh1v.ld, 0, self.h1v.p(), self.h1v.ld, None, 0,
                 self.dh1v.p(), self.dh1v.ld, B, D)
         e._gemm(P, L.GEMM_TN, self.dh1v.p(), self.dh1v.ld, self.zt.p(), self.zt.ld, e.gp("inf_net_image.location.fc1.weight"), Z,
                 D, Z, B, out_f32=1, split_k=-1)
-        e._call(P, lib.vmmt_colsum, dt, self.dh1v.p(), self.dh1v.ld, B, D, e.gp("inf_net_image.location.fc1.bias"))
+        e._call(P, lib.vmmt_colsum, dt, self.dh1v.p(), self.dh1v.ld, B, D, e.gp("inf_net_image.location.fc1.bias"), None)
         e._gemm(P, L.GEMM_NN, self.dh1v.p(), self.dh1v.ld, w1.p(), w1.ld, self.dzt.p(), self.dzt.ld, B, Z, D, out_f32=1)
         e._call(P, lib.vmmt_gate_bwd, self.dzt.p(), self.dzt.ld, self.z32.p(), self.gate.data_ptr(),
                 e.gp("inf_net_image.gate_affine_transform.weight"), e.gp("inf_net_image.gate_affine_transform.bias"), B, Z)
@@ -588,13 +588,13 @@ class Workspace(object):
             w2q = e.sh["q_%s_w2" % br]
             pre = "inf_net_global.%s" % br
             e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"))
+            e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"), None)
             e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2q.p(), w2q.ld, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, Z)
             e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.q_dh1[br].p(), self.q_dh1[br].ld, 0, self.q_h1[br].p(), self.q_h1[br].ld,
                     None, 0, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z)
             e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, self.hbar.p(), self.hbar.ld, e.gp(pre + ".fc1.weight"), H,
                     Z, H, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"))
+            e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
         # side: dWg = G^T O, db = rowsum(G^T)
         e._sid = SIDE
         e._wait(P, "GT")
@@ -669,8 +669,7 @@ class Workspace(object):
             if Tp > 1:
                 e._gemm(P, L.GEMM_TN, dg.p(B), dg.ld, outb.p(0, ocol), outb.ld, e.gp(gw), H, 4 * H, H, (Tp - 1) * B, out_f32=1, split_k=-1)
             e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * H, H, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_ih_l%d" % l))
-            e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_hh_l%d" % l))
+            e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_ih_l%d" % l), e.gp("decoder.rnn.bias_hh_l%d" % l))
             gi = "decoder.rnn.weight_ih_l%d" % l
             if l == 0:
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * H, E, M, out_f32=1, split_k=-1)
@@ -741,8 +740,8 @@ class Workspace(object):
                     else:        # h_prev[t] = out[t+1]
                         e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, self.enc_out[l].p(B, k * Hd), self.enc_out[l].ld, e.gp(gw), Hd,
                                 4 * Hd, Hd, (S - 1) * B, out_f32=1, split_k=-1)
-                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)))
-                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
+                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)),
+                        e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
                 alt()
                 e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, xin.p(), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)), xcols,
                         4 * Hd, xcols, MS, out_f32=1, split_k=-1)
