@@ -1,0 +1,134 @@
+"""Mirror of onmt.Optim (reference: onmt/Optim.py:34-114): same constructor, `set_parameters`, `step`,
+`update_learning_rate`, `.lr`, `.optimizer`; for method 'adam' (every reference recipe) the update is ONE fused HIP
+kernel over the engine's flat arena (global-norm clip + Adam, eps = 1e-9).  Pickles like the reference's object
+(checkpoint['optim']); `.optimizer.state_dict()` has torch.optim.Adam's layout."""
+import torch
+
+
+class _ArenaAdam(object):
+    """stands where torch.optim.Adam stands in the reference's Optim: param_groups / state_dict / load_state_dict"""
+
+    def __init__(self, lr, betas, eps=1e-9):
+        self.param_groups = [{"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False}]
+        self._saved = None        # a loaded state dict waiting for set_parameters()
+        self._optim = None
+
+    def bind(self, optim):
+        self._optim = optim
+
+    def state_dict(self):
+        o = self._optim
+        if o is None or o.engine is None:
+            return self._saved or {"state": {}, "param_groups": self.param_groups}
+        e = o.engine
+        state = {}
+        for i, p in enumerate(o.params):
+            name = getattr(p, "_vmmt_name", None)
+            if name is None or name not in e.grads or e.step_count == 0:
+                continue                      # parameters that never received a gradient have no Adam state (H6)
+            off, shp = e.offsets[name]
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(e.step_count)),
+                        "exp_avg": e.flat_m[off:off + n].view(*shp).detach().cpu().clone(),
+                        "exp_avg_sq": e.flat_v[off:off + n].view(*shp).detach().cpu().clone()}
+        groups = [dict(self.param_groups[0], params=list(range(len(o.params))))]
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        self._saved = sd
+        if self._optim is not None and self._optim.engine is not None:
+            self._optim._push_state(sd)
+
+
+class Optim(object):
+    def __init__(self, method, lr, max_grad_norm, lr_decay=1, start_decay_at=None, beta1=0.9, beta2=0.999,
+                 adagrad_accum=0.0, decay_method=None, warmup_steps=4000, model_size=None):
+        self.last_ppl = None
+        self.lr = lr
+        self.original_lr = lr
+        self.max_grad_norm = max_grad_norm
+        self.method = method
+        self.lr_decay = lr_decay
+        self.start_decay_at = start_decay_at
+        self.start_decay = False
+        self._step = 0
+        self.betas = [beta1, beta2]
+        self.adagrad_accum = adagrad_accum
+        self.decay_method = decay_method
+        self.warmup_steps = warmup_steps
+        self.model_size = model_size
+        self.engine = None
+        self.params = []
+        self.optimizer = None
+
+    def set_parameters(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        engines = {id(getattr(p, "_vmmt_engine", None)): getattr(p, "_vmmt_engine", None) for p in self.params}
+        engines.pop(id(None), None)
+        if len(engines) != 1:
+            raise RuntimeError("Optim.set_parameters expects the parameters of one variational_mmt_amd model")
+        self.engine = list(engines.values())[0]
+        if self.method == "adam":
+            saved = self.optimizer._saved if isinstance(self.optimizer, _ArenaAdam) else None
+            self.optimizer = _ArenaAdam(self.lr, self.betas)
+            self.optimizer.bind(self)
+            if saved is not None:
+                self._push_state(saved)
+        elif self.method in ("sgd", "adagrad", "adadelta"):
+            # not on the hot path (every reference recipe uses adam): thin delegation to torch on the arena views
+            cls = {"sgd": torch.optim.SGD, "adagrad": torch.optim.Adagrad, "adadelta": torch.optim.Adadelta}[self.method]
+            self.optimizer = cls(self.params, lr=self.lr)
+        else:
+            raise RuntimeError("Invalid optim method: " + self.method)
+
+    def _push_state(self, sd):
+        e = self.engine
+        step = 0
+        for i, st in sd.get("state", {}).items():
+            p = self.params[int(i)]
+            off, shp = e.offsets[p._vmmt_name]
+            n = p.numel()
+            e.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            e.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            step = max(step, int(float(st["step"])))
+        e.step_count = step
+
+    def _set_rate(self, lr):
+        self.lr = lr
+        self.optimizer.param_groups[0]["lr"] = self.lr
+
+    def step(self):
+        self._step += 1
+        if self.decay_method == "noam":
+            self._set_rate(self.original_lr * (self.model_size ** (-0.5) *
+                                               min(self._step ** (-0.5), self._step * self.warmup_steps ** (-1.5))))
+        if self.method == "adam":
+            self.engine.optim_step(lr=self.lr, max_grad_norm=self.max_grad_norm or 0.0, beta1=self.betas[0], beta2=self.betas[1],
+                                   eps=1e-9)
+        else:
+            if self.max_grad_norm:
+                torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
+            self.optimizer.step()
+            self.engine.shadows_dirty = True
+
+    def update_learning_rate(self, ppl, epoch):
+        if self.start_decay_at is not None and epoch >= self.start_decay_at:
+            self.start_decay = True
+        if self.last_ppl is not None and ppl > self.last_ppl:
+            self.start_decay = True
+        if self.start_decay:
+            self.lr = self.lr * self.lr_decay
+            print("Decaying learning rate to %g" % self.lr)
+        self.last_ppl = ppl
+        self.optimizer.param_groups[0]["lr"] = self.lr
+
+    # checkpoint['optim'] is this object pickled (TrainerMultimodal.py:586): keep it small and engine-free
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["params"] = []
+        d["engine"] = None
+        if isinstance(self.optimizer, _ArenaAdam):
+            frozen = _ArenaAdam(self.lr, self.betas)
+            frozen._saved = self.optimizer.state_dict()
+            d["optimizer"] = frozen
+        return d

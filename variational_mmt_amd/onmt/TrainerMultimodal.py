@@ -1,0 +1,232 @@
+"""Mirror of onmt.TrainerMultimodal / VIStatistics (reference: onmt/TrainerMultimodal.py:32-718).
+
+Differences that do not change results: the image-feature arrays are uploaded to HBM once and rows are gathered on the
+device from `batch.indices` (reference: host fancy-index + H2D per step, :632-639); statistics stay on the device and
+are read back only when they are printed or queried (reference: `.data.clone()` syncs every step)."""
+import math
+import os
+import sys
+import tempfile
+import time
+
+import torch
+import torch.nn as nn
+
+from . import io
+from .Trainer import Statistics  # noqa: F401
+from .Utils import MODEL_TYPES
+
+_FIELDS = ("nmt_loss", "elbo_loss", "td_kl_before", "td_kl_after", "image_feats_loss", "image_feats_cos", "n_words", "n_correct")
+
+
+class VIStatistics(object):
+    """Accumulator with the reference's fields; values produced by the kernels are kept as device vectors (`pending`)
+    until a field is read."""
+
+    def __init__(self, multimodal_model_type, loss_data=None, n_words=0, n_correct=0, pending=None):
+        assert multimodal_model_type in MODEL_TYPES
+        self.multimodal_model_type = multimodal_model_type
+        self.progress_state_train, self.progress_state_valid = [], []
+        self.two_step_image_prediction = False
+        self.image_loss_type = "logprob"
+        self._v = dict.fromkeys(_FIELDS, 0.0)
+        self._v["n_words"], self._v["n_correct"] = n_words, n_correct
+        self.image_pixels_loss = self.image_pixels_acc = self.img_pixels_acc = 0.0
+        self.te_kl = self.td_kl = 0.0
+        self.td_kl_multiplier = 1.0
+        if loss_data is not None:
+            self._v.update(nmt_loss=loss_data["nmt"], elbo_loss=loss_data["elbo"], td_kl_before=loss_data["td_kl_before"],
+                           td_kl_after=loss_data["td_kl_after"], image_feats_loss=loss_data.get("img_feats_loss", 0.0),
+                           image_feats_cos=loss_data.get("img_feats_cos", 0.0))
+            self.td_kl_multiplier = loss_data.get("td_kl_multiplier", 1.0)
+        self._pending = [pending] if pending is not None else []
+        if pending is not None:
+            self.td_kl_multiplier = pending[3]
+        self.n_src_words = 0
+        self.n_updates = 0
+        self.start_time = time.time()
+
+    def _materialise(self):
+        if not self._pending:
+            return
+        from .. import _lib as L
+        vals = torch.stack([p[0] for p in self._pending]).tolist()          # one D2H copy
+        for s, (_t, B, Bg, mult, fb, margin) in zip(vals, self._pending):
+            kl_before = s[L.STAT_KL_SUM] / Bg
+            kl_after = max(kl_before * mult, margin) if fb else kl_before * mult
+            v = self._v
+            v["nmt_loss"] += s[L.STAT_NLL]
+            v["td_kl_before"] += kl_before
+            v["td_kl_after"] += kl_after
+            v["image_feats_loss"] += s[L.STAT_IMG_LOGPROB]
+            v["image_feats_cos"] += s[L.STAT_IMG_COS] / B
+            v["elbo_loss"] += s[L.STAT_NLL] - s[L.STAT_IMG_LOGPROB] + kl_after
+            v["n_words"] += int(round(s[L.STAT_NWORDS]))
+            v["n_correct"] += int(round(s[L.STAT_NCORRECT]))
+        self._pending = []
+
+    def __getattr__(self, k):
+        if k in _FIELDS:
+            self._materialise()
+            return self._v[k]
+        raise AttributeError(k)
+
+    def update(self, stat):
+        if isinstance(stat, VIStatistics):
+            self._pending.extend(stat._pending)
+            for k in _FIELDS:
+                self._v[k] += stat._v[k]
+            self.td_kl_multiplier = stat.td_kl_multiplier
+        self.n_updates += 1
+
+    def accuracy(self):
+        return 100 * (self.n_correct / self.n_words)
+
+    def ppl(self):
+        return math.exp(min(self.nmt_loss / self.n_words, 100))
+
+    def elapsed_time(self):
+        return time.time() - self.start_time
+
+    def output(self, epoch, batch, n_batches, start):
+        t = self.elapsed_time()
+        n = max(self.n_updates, 1)
+        print(("Epoch %2d, %5d/%5d; acc: %6.2f; ppl: %6.2f; td-kl-before (avg.): %6.2f; td-kl-after (avg.): %6.2f; "
+               "td-kl-multiplier: %2.2f;img-feats-loss (avg.): %6.2f; img-feats-cos (avg.): %6.2f; elbo (avg.): %6.2f; "
+               "%3.0f src tok/s; %3.0f tgt tok/s; %6.0f s elapsed") %
+              (epoch, batch, n_batches, self.accuracy(), self.ppl(), self.td_kl_before / n, self.td_kl_after / n,
+               self.td_kl_multiplier, self.image_feats_loss / n, self.image_feats_cos / n, self.elbo_loss / n,
+               self.n_src_words / (t + 1e-5), self.n_words / (t + 1e-5), time.time() - start))
+        self.n_updates = 0
+        sys.stdout.flush()
+
+    def save_progress(self, lr, model_updates, epoch, split):
+        """The reference appends a dict per update (unbounded, with a device sync each time); here one entry per call
+        without forcing a read-back of pending device statistics."""
+        assert split in ("train", "valid")
+        rec = {"epoch": epoch, "model_updates": model_updates, "elapsed_time": self.elapsed_time(), "lr": lr}
+        (self.progress_state_train if split == "train" else self.progress_state_valid).append(rec)
+
+
+class _NoEarlyStop(object):
+    """BLEU/METEOR early stopping (onmt/EarlyStop.py) spawns translate + perl/java subprocesses: out of scope
+    (SURVEY.md 8f-4).  Perplexity-driven learning-rate decay (Optim.update_learning_rate) is unaffected."""
+
+    def __init__(self, criteria, every):
+        self.early_stop_criteria = criteria
+        self.evaluate_every_nupdates = every
+        self.signal_early_stopping = False
+
+
+class TrainerMultimodal(object):
+    def __init__(self, model, train_loss, valid_loss, optim, trunc_size=0, shard_size=32, data_type="text",
+                 norm_method="sents", grad_accum_count=1, train_img_feats=None, valid_img_feats=None, train_img_vecs=None,
+                 valid_img_vecs=None, multimodal_model_type=None, model_updates=0, model_opt=None, fields=None):
+        self.model, self.train_loss, self.valid_loss, self.optim = model, train_loss, valid_loss, optim
+        self.trunc_size, self.shard_size, self.data_type, self.norm_method = trunc_size, shard_size, data_type, norm_method
+        self.grad_accum_count = grad_accum_count
+        self.multimodal_model_type = multimodal_model_type
+        self.model_updates = model_updates
+        self.model_opt, self.fields = model_opt, fields
+        crit = getattr(model_opt, "early_stopping_criteria", "perplexity") if model_opt is not None else "perplexity"
+        if crit not in (None, "perplexity"):
+            raise NotImplementedError("early stopping on %s needs the translate/BLEU pipeline (SURVEY.md 8f-4)" % crit)
+        self.early_stop = _NoEarlyStop(crit, getattr(model_opt, "evaluate_every_n_model_updates", 500) if model_opt else 500)
+        self.n_model_updates = 0
+        self._epoch = 0
+        assert train_img_feats is not None and valid_img_feats is not None, "Must provide training/validation image features!"
+        assert multimodal_model_type in (None, "vi-model1")
+        assert grad_accum_count == 1, "gradient accumulation is not on the hot path (reference default 1)"
+        assert trunc_size == 0, "truncated BPTT is not on the hot path (reference recipes use 0)"
+        self.train_img_feats, self.valid_img_feats = train_img_feats, valid_img_feats
+        self.model.set_image_tables(train=train_img_feats, valid=valid_img_feats)
+        from .. import dp
+        self.dp = dp.GradSync(self.model.engine)          # no-op unless torch.distributed is initialised with > 1 rank
+        self.model.train()
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _prep(self, batch):
+        src = io.make_features(batch, "src", self.data_type)
+        _, src_lengths = batch.src
+        tgt = io.make_features(batch, "tgt")
+        _, tgt_lengths = batch.tgt
+        batch.tgt = batch.tgt[0]          # the reference mutates the batch the same way (TrainerMultimodal.py:677)
+        return src, src_lengths, tgt, tgt_lengths
+
+    def train(self, train_iter, epoch, report_func=None):
+        total_stats = VIStatistics(self.multimodal_model_type)
+        report_stats = VIStatistics(self.multimodal_model_type)
+        try:
+            num_batches = len(train_iter)
+        except (NotImplementedError, TypeError):
+            num_batches = -1
+        for idx, batch in enumerate(train_iter):
+            if hasattr(train_iter, "get_cur_dataset"):
+                self.train_loss.cur_dataset = train_iter.get_cur_dataset()
+            if self.norm_method == "tokens":
+                normalization = int(batch.tgt[0][1:].ne(self.train_loss.padding_idx).sum())
+            else:
+                normalization = batch.batch_size
+            self._gradient_accumulation([batch], total_stats, report_stats, normalization)
+            if report_func is not None:
+                report_stats = report_func(epoch, idx, num_batches, total_stats.start_time, self.optim.lr, report_stats,
+                                           self.multimodal_model_type)
+            self.n_model_updates += 1
+        return total_stats
+
+    def validate(self, valid_iter):
+        self.model.eval()
+        stats = VIStatistics(self.multimodal_model_type)
+        for batch in valid_iter:
+            if hasattr(valid_iter, "get_cur_dataset"):
+                self.valid_loss.cur_dataset = valid_iter.get_cur_dataset()
+            src, src_lengths, tgt, tgt_lengths = self._prep(batch)
+            outputs, attns, _ = self.model(src, tgt, src_lengths, tgt_lengths, None, img_indices=batch.indices,
+                                           img_table=self.model._tables["valid"], padding_token=self.train_loss.padding_idx)
+            stats.update(self.valid_loss.monolithic_compute_loss(batch, outputs, attns))
+        stats.save_progress(self.optim.lr, self.model_updates, self._epoch, "valid")
+        self.model.train()
+        return stats
+
+    def epoch_step(self, ppl, epoch):
+        return self.optim.update_learning_rate(ppl, epoch)
+
+    def _gradient_accumulation(self, true_batchs, total_stats, report_stats, normalization):
+        for batch in true_batchs:
+            src, src_lengths, tgt, tgt_lengths = self._prep(batch)
+            report_stats.n_src_words += int(src.shape[0] * src.shape[1])   # upper bound without a device sync
+            world = self.dp.world
+            self.train_loss.batch_global = self.dp.global_batch(batch.batch_size)
+            outputs, attns, _ = self.model(src, tgt, src_lengths, tgt_lengths, None, img_indices=batch.indices,
+                                           img_table=self.model._tables["train"], padding_token=self.train_loss.padding_idx)
+            norm = normalization if world == 1 else self.dp.global_batch(normalization)
+            batch_stats = self.train_loss.sharded_compute_loss(batch, outputs, attns, 0, tgt.shape[0], self.shard_size, norm)
+            self.model_updates += 1
+            self.dp.all_reduce()
+            self.optim.step()
+            total_stats.update(batch_stats)
+            report_stats.update(batch_stats)
+
+    def drop_checkpoint(self, opt, epoch, fields, valid_stats, train_stats=None, overwrite=False, checkpoint_type="last",
+                        temporary=False):
+        """Same checkpoint dict as the reference (TrainerMultimodal.py:554-622): keys model / generator / vocab / opt /
+        epoch / optim; parameter names per SURVEY.md Appendix B."""
+        assert checkpoint_type in ("last", "best")
+        sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+        model_sd = {k: v for k, v in sd.items() if "generator" not in k}
+        gen_sd = {k[len("generator."):]: v for k, v in sd.items() if k.startswith("generator.")}
+        checkpoint = {"model": model_sd, "generator": gen_sd, "vocab": io.save_fields_to_vocab(fields), "opt": opt,
+                      "epoch": epoch, "optim": self.optim}
+        if not overwrite:
+            fname = "%s_acc_%.2f_ppl_%.2f_e%d.pt" % (opt.save_model, valid_stats.accuracy(), valid_stats.ppl(), epoch)
+        elif checkpoint_type == "best":
+            raise NotImplementedError("best-model checkpoints belong to BLEU/METEOR early stopping (SURVEY.md 8f-4)")
+        else:
+            fname = "%s_MostCurrentModel.pt" % opt.save_model
+        if temporary:
+            tf = tempfile.NamedTemporaryFile(delete=False)
+            tf.close()
+            torch.save(checkpoint, tf.name)
+            return tf.name, fname
+        torch.save(checkpoint, fname)
+        return fname
