@@ -115,6 +115,8 @@ def main():
     eng.set_image_table(torch.rand(n_img, d.img, generator=gt))
     batches = make_batches(d, B, S, T, n_img, 8, dev, 1234 + rank)
     Bg = B * world
+    from variational_mmt_amd.dp import GradSync
+    sync = GradSync(eng)          # attaches itself to the engine when torch.distributed runs with > 1 rank
 
     ev = {}
 
@@ -122,8 +124,7 @@ def main():
         src, sl, tgt, idx = batches[i % len(batches)]
         ws = eng.forward(src, sl, tgt, idx, training=True)
         eng.loss_backward(ws, normalization=Bg, batch_global=Bg)
-        if dist is not None:
-            dist.all_reduce(eng.flat_g)
+        sync.all_reduce()          # waits for the segment all-reduces the backward plan issued behind each segment
         eng.optim_step(lr=0.002, max_grad_norm=5.0)
         return ws
 

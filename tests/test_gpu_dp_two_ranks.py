@@ -1,0 +1,57 @@
+"""GPU: two data-parallel ranks (two processes sharing the one GPU of the test box, gloo backend on CUDA tensors) run the HIP
+step on halves of a batch; the overlapped segment all-reduces issued by the backward plan must leave every rank with the
+gradient of the single-process step on the whole batch (incl. the KL 1/B_g weighting), and identical parameters after Adam."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import vi1_oracle as O
+    from variational_mmt_amd.dp import GradSync
+    from variational_mmt_amd.engine import Dims, Engine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = O.Cfg(vs=41, vt=43, emb=16, hid=32, z=8, img=2048, layers=1, brnn=True)
+    p = O.init_params(c, seed=6)
+    Bg = 10
+    bt = O.synth_batch(c, Bg, 6, 7, n_img=16, seed=8, fixed_len=False)
+    sl = slice(rank * Bg // world, (rank + 1) * Bg // world)
+    e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda:0")
+    e.load_state_dict(p)
+    e.set_image_table(bt["table"])
+    sync = GradSync(e)
+    assert sync.world == world and e.dp is sync
+    ws = e.forward(bt["src"][:, sl], bt["src_len"][sl], bt["tgt"][:, sl], bt["indices"][sl], training=True, eps=bt["eps"][sl])
+    e.loss_backward(ws, normalization=Bg, batch_global=Bg)
+    sync.all_reduce()
+    torch.cuda.synchronize()
+    g_gpu = {k: v.detach().cpu().clone() for k, v in e.grads.items()}
+    e.optim_step(lr=0.002, max_grad_norm=5.0)
+    torch.cuda.synchronize()
+    flat_p = e.flat_p.cpu().clone()
+    gathered = [torch.zeros_like(flat_p) for _ in range(world)]
+    dist.all_gather(gathered, flat_p)
+    if rank == 0:
+        img = bt["table"][bt["indices"]]
+        _, _, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
+        worst = max(((g_gpu[k] - g[k]).abs().max() / g[k].abs().max()).item() for k in g)
+        torch.save({"worst": worst, "same_params": bool(torch.equal(gathered[0], gathered[1]))}, out)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 23000 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["worst"] < 3e-4, r
+    assert r["same_params"]

@@ -23,6 +23,8 @@ class GradSync(object):
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 self.dist = dist
                 self.world = dist.get_world_size()
+                if engine is not None:
+                    engine.dp = self
         except Exception:
             pass
 
@@ -43,7 +45,14 @@ class GradSync(object):
         return [(o, min(n, o + self.bucket_elems)) for o in range(0, n, self.bucket_elems)]
 
     def all_reduce(self):
+        """Engine path: the backward plan already issued one asynchronous all-reduce per arena segment (inference
+        networks, generator, attention+decoder, encoder) right behind the kernels that produced it, so that the
+        collectives overlap the rest of backward; here the compute stream only waits for them.  A bare flat tensor
+        (no engine) is reduced bucket by bucket."""
         if self.world == 1:
+            return
+        if self.engine is not None:
+            self.engine.finish_allreduce()
             return
         for o, e in self.buckets():
             self.dist.all_reduce(self.flat[o:e])

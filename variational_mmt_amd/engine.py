@@ -109,6 +109,8 @@ class Engine(object):
         self._sid = 0
         self.side_stream = torch.cuda.Stream(device=self.dev)
         self.use_side_stream = True
+        self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
+        self._works = []
 
     # ------------------------------------------------------------------------------------------------ arena
     def _build_arena(self, seed, param_init):
@@ -251,6 +253,19 @@ class Engine(object):
     def _wait(self, plan, ev):
         plan.append((None, ev, "EV_WAIT", None, self._sid))
 
+    def _allreduce(self, plan, first_name, end_name):
+        """plan entry: sum the arena range [offset(first_name), offset(end_name)) over the data-parallel ranks, issued on
+        the entry's stream right behind the kernels that produced it (no-op for a single process)."""
+        lo = self.offsets[first_name][0]
+        hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
+        plan.append((None, (lo, min(hi, self.n_opt)), "ALLREDUCE", None, self._sid))
+
+    def finish_allreduce(self):
+        """make the current stream wait for every outstanding gradient all-reduce (call before optim_step)"""
+        for w in self._works:
+            w.wait()
+        self._works = []
+
     def _run(self, plan, events=None):
         main = torch.cuda.current_stream(self.dev)
         side = self.side_stream if self.use_side_stream else main
@@ -258,6 +273,12 @@ class Engine(object):
         hs = (main.cuda_stream, side.cuda_stream)
         for fn, args, name, _keep, sid in plan:
             if fn is None:
+                if name == "ALLREDUCE":
+                    if self.dp is not None and self.dp.world > 1:
+                        lo, hi = args
+                        with torch.cuda.stream(ts[sid]):
+                            self._works.append(self.dp.dist.all_reduce(self.flat_g[lo:hi], async_op=True))
+                    continue
                 if side is main:
                     continue
                 if name == "EV_RECORD":
@@ -595,11 +616,13 @@ class Workspace(object):
             e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, self.hbar.p(), self.hbar.ld, e.gp(pre + ".fc1.weight"), H,
                     Z, H, B, out_f32=1, split_k=-1)
             e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
+        e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
         # side: dWg = G^T O, db = rowsum(G^T)
         e._sid = SIDE
         e._wait(P, "GT")
         e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1, split_k=-1)
         e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
+        e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
         # main: dropout + tanh backward, linear_out
         e._sid = MAIN
         e._call(P, lib.vmmt_act_bwd, dt, L.ACT_TANH, self.dO32.p(), self.dO32.ld, 1, self.AH.p(), self.AH.ld,
@@ -680,6 +703,8 @@ class Workspace(object):
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
+        e._sid = SIDE
+        e._allreduce(P, "decoder.attn.linear_out.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
         # ================= encoder LSTM backward (main) + its parameter gradients (side) ==========================
         dh_above = self.dctx
         for l in reversed(range(Lyr)):
@@ -754,6 +779,7 @@ class Workspace(object):
         e._record(P, "side_done")
         e._sid = MAIN
         e._wait(P, "side_done")
+        e._allreduce(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
         return P
 
     def _latent_bwd_args(self, batch_global, kl_mult, use_freebits, margin, inv_norm):
