@@ -31,6 +31,7 @@ struct GenArgs {
 template <class T> struct GenCfg {
   static constexpr int BMV = 128, BNM = 256, BK = sizeof(T) == 2 ? 64 : 32, NT = 512, TI = 2, TJ = 2;
   static constexpr bool DB = false;
+  static constexpr int PP = 64 + 16 / sizeof(T);     // pitch (elements) of a wave's 64 x 64 output patch in LDS
 };
 
 template <class T, int MODE>
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
   LinearMap amap{v0, a.V}, bmap{m0, a.M};
   gemm_mainloop<T, BMV, BNM, BK, NT, true, true, TI, TJ, LinearMap, LinearMap, Cf::DB>(
       (const T*)a.W, a.ldw, amap, (const T*)a.O, a.ldo, bmap, a.K, 0, 0, aoff, boff, acc, smem);
+  if constexpr (MODE == 1) __syncthreads();     // the staging buffers are reused as per-wave output patches
   // A lane owns token columns m_j and, per 32-row tile i, the vocabulary rows vb_i + 8q + s (q, s = 0..3) where
   // vb_i = v0 + aoff[i] + 4*(lane>>5): four consecutive rows per register group q -> one 16-byte bias load per group.
   const int hi4 = 4 * (lane >> 5);
@@ -124,22 +126,39 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
         a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
       }
     } else {
+      // gradient values -> this wave's 64(v) x 64(m) patch of an LDS image [v][m] (bf16/f32), written back below as
+      // whole 16-byte row segments (a lane-per-token 2-byte store per element is store-issue bound)
       const float l = mv ? a.lse[m] : 0.f;
       const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
-      if (mv) {
+      T* patch = smem + wave * (64 * GenCfg<T>::PP);
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          const int vb = v0 + aoff[i] + hi4;
-          T* gp = reinterpret_cast<T*>(a.GT) + (long)vb * a.ldgt + m;
+      for (int i = 0; i < TI; ++i) {
+        const int vb = v0 + aoff[i] + hi4;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dv = (r & 3) + 8 * (r >> 2);
-            if (vb + dv < a.V) {
-              float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
-              gp[(long)dv * a.ldgt] = from_f<T>(g);
-            }
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int dv = (r & 3) + 8 * (r >> 2);
+          float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
+          patch[(i * 32 + hi4 + dv) * GenCfg<T>::PP + j * 32 + (lane & 31)] = from_f<T>(g);
         }
+      }
+    }
+  }
+  if constexpr (MODE == 1) {
+    // each wave owns its patch: no workgroup barrier needed between its own LDS writes and reads, but the staging
+    // buffers of the main loop are being reused -> one barrier before the first write (below) is required
+    constexpr int VEC = 16 / sizeof(T), PP = GenCfg<T>::PP;
+    const T* patch = smem + wave * (64 * PP);
+    const int vbase = v0 + wv * 64, mbase = m0 + wm * 64;
+    constexpr int CH = 64 / VEC;                       // 16-byte chunks per 64-token row
+#pragma unroll
+    for (int it = 0; it < (64 * CH) / 64; ++it) {
+      const int idx = it * 64 + lane, row = idx / CH, ch = idx % CH;
+      const int v = vbase + row, mm = mbase + ch * VEC;
+      if (v < a.V && mm < a.M) {
+        T* dst = reinterpret_cast<T*>(a.GT) + (long)v * a.ldgt + mm;
+        const T* srcp = patch + row * PP + ch * VEC;
+        if (mm + VEC <= a.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);
+        else for (int e = 0; e < VEC && mm + e < a.M; ++e) dst[e] = srcp[e];
       }
     }
   }
@@ -203,6 +222,7 @@ static int launch_gen(const GenArgs& a, hipStream_t st) {
   using Cf = GenCfg<T>;
   int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + Cf::BNM - 1) / Cf::BNM;
   size_t sm = gemm_smem_elems<T, Cf::BMV, Cf::BNM, Cf::BK, true, true, Cf::DB>() * sizeof(T);
+  if (MODE == 1 && sm < (size_t)8 * 64 * Cf::PP * sizeof(T)) sm = (size_t)8 * 64 * Cf::PP * sizeof(T);
   if (sm > 64 * 1024) {
     static bool done = false;
     if (!done) { (void)hipFuncSetAttribute((const void*)gen_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done = true; }
