@@ -206,10 +206,17 @@ typedef struct vmmt_pack_desc {
 } vmmt_pack_desc;
 int vmmt_pack_multi(const vmmt_pack_desc* descs, int n, int total_chunks, void* stream);
 
+/* batch preparation in one launch: ids -> workspace, tgt[:-1] / tgt[1:] (Models.py:867, VILoss.py:205), lengths, image row
+ * indices, statistics reset, optional eps ~ N(0,I) (eps may be NULL).  src [S][B], tgt [T][B], all int64 device arrays. */
+int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const int64_t* src_len, const int64_t* idx, int S, int T, int B,
+                       int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len, int64_t* o_idx, float* stats, float* eps,
+                       int64_t n_eps, uint64_t seed, void* stream);
+
 /* ---- optimiser: clip_grad_norm + Adam over a flat fp32 arena (onmt/Optim.py:68-70,94-96) -------------------------- */
 int vmmt_sumsq(const float* g, int64_t n, float* out /* += */, void* stream);
+/* max_blocks > 0 caps the grid (grid-stride loop): used for the half of the update that runs in the background */
 int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                   int step, float max_norm, const float* sumsq, float grad_scale, void* stream);
+                   int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -106,7 +106,7 @@ def test_adam_and_sumsq():
     tot = float((g.double() ** 2).sum())
     assert abs(ss[0].item() - tot) <= 1e-4 * tot
     L.check(lib.vmmt_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 0.002, 0.9, 0.999, 1e-9, 3, 5.0,
-                               ss.data_ptr(), 1.0, None), "adam")
+                               ss.data_ptr(), 1.0, 0, None), "adam")
     coef = min(1.0, 5.0 / (tot ** 0.5 + 1e-6))
     gg = g.double() * coef
     m2 = 0.9 * m.double() + 0.1 * gg

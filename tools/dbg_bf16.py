@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import vi1_oracle as O
 from tests.golden_util import load
 from variational_mmt_amd.engine import Dims, Engine

@@ -1,6 +1,6 @@
 """In-process interleaved A/B of GEMM tile variants on the step's real shapes (bf16). Run on the GPU box."""
 import ctypes as C, sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from variational_mmt_amd import _lib as L
 lib = L.lib()
 torch.manual_seed(0)

@@ -68,6 +68,7 @@ struct LinearMap {   // rows base .. limit-1
   __device__ __forceinline__ bool vec_ok(int rows, int vec) const { int n = limit - base; return n >= rows || n % vec == 0; }
   // a 16-byte vector that straddles `limit` may still be LOADED when every stored row is padded to a multiple of vec
   __device__ __forceinline__ bool pad_ok(long ld, int vec) const { return ld >= (long)((limit + vec - 1) / vec) * vec; }
+  __device__ __forceinline__ bool full(int rows) const { return limit - base >= rows; }   // every tile row is in range
 };
 struct GateMap {     // LSTM gate rows: local n = g * BU + u  ->  g * H + u0 + u   (g = i,f,g,o)
   int u0, H, BU;
@@ -77,6 +78,7 @@ struct GateMap {     // LSTM gate rows: local n = g * BU + u  ->  g * H + u0 + u
   }
   __device__ __forceinline__ bool vec_ok(int rows, int vec) const { int n = H - u0; return (n >= BU || n % vec == 0) && BU % vec == 0; }
   __device__ __forceinline__ bool pad_ok(long, int) const { return false; }
+  __device__ __forceinline__ bool full(int) const { return H - u0 >= BU; }
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -106,12 +108,14 @@ struct Stager {
   const T* P_; long ld_; int kmod_;
   bool fast;              // block-uniform: 16-byte aligned operand, no ragged vector
   bool raw;               // regs hold unmasked fast-path loads
+  bool edge;              // block-uniform: some tile rows are out of range (only then store() masks anything)
 
   template <class Map>
   __device__ __forceinline__ void init(const T* __restrict__ P, long ld, const Map& map, int kmod, int tid) {
     P_ = P; ld_ = ld; kmod_ = kmod;
     fast = (((uintptr_t)P) & 15) == 0 && ((ld * (long)sizeof(T)) & 15) == 0 &&
            (KC || map.vec_ok(ROWS, VEC) || map.pad_ok(ld, VEC));
+    edge = !map.full(ROWS);
     const int g_first = map(0);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -188,7 +192,7 @@ struct Stager {
       int v = tid + i * NT;
       if (NVEC % NT != 0 && v >= NVEC) break;
       u32x4 w = regs[i];
-      if (raw && nvalid[i] < VEC) {                       // clamped / ragged vector: keep the valid prefix only
+      if (edge && raw && nvalid[i] < VEC) {               // clamped / ragged vector: keep the valid prefix only
         if constexpr (sizeof(T) == 4) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) w[e] = e < nvalid[i] ? w[e] : 0u;
@@ -300,6 +304,23 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, long lda,
   sb.store(smem + AE, tid);
   __syncthreads();
   int cur = 0, sidx = 0;
+  if constexpr (DB) {
+    // fast phase, two slabs per trip so that both LDS buffer addresses are compile-time constants
+    for (; sidx + 2 < nfast; sidx += 2) {
+      sa.load_fast(kbeg + (sidx + 1) * BK, tid);
+      sb.load_fast(kbeg + (sidx + 1) * BK, tid);
+      mfma_slab<T, BM, BN, BK, A_KC, B_KC, TI, TJ>(smem, smem + AE, aoff, boff, acc, lane);
+      sa.store(smem + (AE + BE), tid);
+      sb.store(smem + (AE + BE) + AE, tid);
+      __syncthreads();
+      sa.load_fast(kbeg + (sidx + 2) * BK, tid);
+      sb.load_fast(kbeg + (sidx + 2) * BK, tid);
+      mfma_slab<T, BM, BN, BK, A_KC, B_KC, TI, TJ>(smem + (AE + BE), smem + (AE + BE) + AE, aoff, boff, acc, lane);
+      sa.store(smem, tid);
+      sb.store(smem + AE, tid);
+      __syncthreads();
+    }
+  }
   for (; sidx + 1 < nfast; ++sidx) {                    // fast phase: next slab is a fast one
     sa.load_fast(kbeg + (sidx + 1) * BK, tid);
     sb.load_fast(kbeg + (sidx + 1) * BK, tid);

@@ -262,6 +262,26 @@ __global__ void pack_kernel(const float* __restrict__ src, const float* __restri
   }
 }
 
+// One launch per step for everything the reference does on the host / in separate tiny ops before the forward:
+// token ids into the step workspace, the input/target shift tgt[:-1] / tgt[1:] (Models.py:867, VILoss.py:205), lengths and
+// image row indices, statistics reset, and eps ~ N(0, I) for the latent sample.
+__global__ void prepare_batch_kernel(const long long* __restrict__ src, const long long* __restrict__ tgt,
+                                     const long long* __restrict__ src_len, const long long* __restrict__ idx, int S, int T, int B,
+                                     long long* __restrict__ o_src, long long* __restrict__ o_tin, long long* __restrict__ o_y,
+                                     long long* __restrict__ o_len, long long* __restrict__ o_idx, float* __restrict__ stats,
+                                     float* __restrict__ eps, long n_eps, unsigned long long seed) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nS = (long)S * B, nT = (long)(T - 1) * B;
+  if (i < nS) o_src[i] = src[i];
+  if (i < nT) { o_tin[i] = tgt[i]; o_y[i] = tgt[i + B]; }
+  if (i < B) { o_len[i] = src_len[i]; o_idx[i] = idx[i]; }
+  if (i < VMMT_STAT_COUNT) stats[i] = 0.f;
+  if (eps && i < n_eps) {
+    float u1 = u01(rng32(seed, 2ull * i)), u2 = u01(rng32(seed, 2ull * i + 1));
+    eps[i] = sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+  }
+}
+
 // all shadow refreshes of a step in one launch: block -> (descriptor, 2048-element chunk)
 __global__ void pack_multi_kernel(const vmmt_pack_desc* __restrict__ descs, int n) {
   const int chunk = blockIdx.x;
@@ -426,5 +446,20 @@ extern "C" int vmmt_pack(int dtype, const float* src, const float* src2, int64_t
 extern "C" int vmmt_pack_multi(const vmmt_pack_desc* descs, int n, int total_chunks, void* stream) {
   if (!descs || n <= 0 || total_chunks <= 0) return VMMT_EINVAL;
   hipLaunchKernelGGL(pack_multi_kernel, dim3(total_chunks), dim3(256), 0, ST, descs, n);
+  return check_launch();
+}
+
+extern "C" int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const int64_t* src_len, const int64_t* idx, int S, int T,
+                                  int B, int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len, int64_t* o_idx, float* stats,
+                                  float* eps, int64_t n_eps, uint64_t seed, void* stream) {
+  if (!src || !tgt || !src_len || !idx || !o_src || !o_tin || !o_y || !o_len || !o_idx || !stats || S <= 0 || T < 2 || B <= 0)
+    return VMMT_EINVAL;
+  long n = (long)S * B;
+  if ((long)(T - 1) * B > n) n = (long)(T - 1) * B;
+  if (eps && n_eps > n) n = n_eps;
+  if (n < VMMT_STAT_COUNT) n = VMMT_STAT_COUNT;
+  hipLaunchKernelGGL(prepare_batch_kernel, BLOCKS(n, 256), dim3(256), 0, ST, (const long long*)src, (const long long*)tgt,
+                     (const long long*)src_len, (const long long*)idx, S, T, B, (long long*)o_src, (long long*)o_tin, (long long*)o_y,
+                     (long long*)o_len, (long long*)o_idx, stats, eps, (long)n_eps, (unsigned long long)seed);
   return check_launch();
 }

@@ -77,7 +77,8 @@ extern "C" int vmmt_sumsq(const float* g, int64_t n, float* out, void* stream) {
 }
 
 extern "C" int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                              float eps, int step, float max_norm, const float* sumsq, float grad_scale, void* stream) {
+                              float eps, int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks,
+                              void* stream) {
   using namespace vmmt;
   if (!p || !g || !m || !v || n < 0 || step < 1 || (max_norm > 0.f && !sumsq)) return VMMT_EINVAL;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return VMMT_EINVAL;
@@ -86,6 +87,7 @@ extern "C" int vmmt_adam_step(float* p, const float* g, float* m, float* v, int6
   float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;   // throttle: a background update must not saturate HBM
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1,
                      beta2, eps, inv_sqrt_bc2, max_norm, sumsq, grad_scale);

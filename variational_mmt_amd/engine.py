@@ -107,8 +107,23 @@ class Engine(object):
         self.reparam_grad = False    # H2: as executed (sample detached)
         self.stats_host = None
         self._sid = 0
-        self.side_stream = torch.cuda.Stream(device=self.dev)
+        # the side stream carries bulk work that is off the critical path: lowest hardware priority, so that small
+        # critical-path kernels on the main stream are dispatched ahead of its queued workgroups
+        try:
+            pr = torch.cuda.Stream.priority_range()
+            lo_pri, hi_pri = max(pr), min(pr)
+        except Exception:
+            lo_pri, hi_pri = 0, 0
+        self.side_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
+        #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
+        self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
         self.use_side_stream = True
+        self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
+        self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
+        self.bg_adam_blocks = 0      # grid cap of the background half of Adam (it has ~0.4 ms of slack under the encoder)
+        self._sumsq = torch.zeros(4, dtype=torch.float32, device=self.dev)
+        self._sumsq_by_plan = False
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
         self._works = []
 
@@ -125,6 +140,7 @@ class Engine(object):
             self.offsets[n] = (off, shp)
             off += _ru(int(math.prod(shp)), 64)
         self.n_total = off
+        self.first_enc_name = "encoder.rnn.weight_ih_l%d" % (self.d.layers - 1)     # arena: [generator|attn|decoder|dec emb][encoder|enc emb|inference nets]
         dev = self.dev
         self.flat_p = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
@@ -210,22 +226,36 @@ class Engine(object):
         shadow("iv_w2", d.img, d.img, "inf_net_image.location.fc2.weight")
         shadow("wg", d.vt, d.hid, "generator.0.weight")
 
+    def _pack_tables(self):
+        """two descriptor tables for vmmt_pack_multi: part 0 = shadows the forward needs first (encoder + inference
+        networks), part 1 = decoder / attention / generator (refreshed on the side stream under the encoder phase)"""
+        if not hasattr(self, "_pack_tab"):
+            self._pack_tab = []
+            enc_lo = self.offsets[self.first_enc_name][0]
+            base = self.flat_p.data_ptr()
+            for part in (0, 1):
+                sel = [c for c in self.pack_calls if ((c[1] - base) // 4 >= enc_lo) == (part == 0)]
+                arr = (L.PackDesc * max(1, len(sel)))()
+                start = 0
+                for k, (code, sp, s2, lds, dst, ldd, R, Cc, tr) in enumerate(sel):
+                    ch = (R * Cc + 2047) // 2048
+                    arr[k] = L.PackDesc(sp, s2, dst, lds, ldd, R, Cc, tr, code, start, ch)
+                    start += ch
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                self._pack_tab.append((host.to(self.dev), len(sel), start))
+        return self._pack_tab
+
+    def _pack_part(self, part, stream):
+        tab, n, chunks = self._pack_tables()[part]
+        if n:
+            L.check(self.lib.vmmt_pack_multi(tab.data_ptr(), n, chunks, stream), "vmmt_pack_multi")
+
     def refresh_shadows(self, stream):
-        """fp32 master -> compute shadows, all tensors in ONE launch (vmmt_pack_multi)."""
+        """fp32 master -> compute shadows (after load_state_dict / first use; optim_step refreshes them itself)."""
         if not self.shadows_dirty:
             return
-        if not hasattr(self, "_pack_table"):
-            n = len(self.pack_calls)
-            arr = (L.PackDesc * n)()
-            start = 0
-            for k, (code, sp, s2, lds, dst, ldd, R, Cc, tr) in enumerate(self.pack_calls):
-                ch = (R * Cc + 2047) // 2048
-                arr[k] = L.PackDesc(sp, s2, dst, lds, ldd, R, Cc, tr, code, start, ch)
-                start += ch
-            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self._pack_table = host.to(self.dev)
-            self._pack_n, self._pack_chunks = n, start
-        L.check(self.lib.vmmt_pack_multi(self._pack_table.data_ptr(), self._pack_n, self._pack_chunks, stream), "vmmt_pack_multi")
+        self._pack_part(0, stream)
+        self._pack_part(1, stream)
         self.shadows_dirty = False
 
     # ------------------------------------------------------------------------------------------------ helpers
@@ -260,6 +290,12 @@ class Engine(object):
         hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
         plan.append((None, (lo, min(hi, self.n_opt)), "ALLREDUCE", None, self._sid))
 
+    def _sumsq_entry(self, plan, first_name, end_name):
+        """plan entry: accumulate ||g||^2 of an arena range into the step's norm scalar (behind that range's all-reduce)"""
+        lo = self.offsets[first_name][0]
+        hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
+        plan.append((None, (lo, min(hi, self.n_opt)), "SUMSQ", None, self._sid))
+
     def finish_allreduce(self):
         """make the current stream wait for every outstanding gradient all-reduce (call before optim_step)"""
         for w in self._works:
@@ -273,6 +309,16 @@ class Engine(object):
         hs = (main.cuda_stream, side.cuda_stream)
         for fn, args, name, _keep, sid in plan:
             if fn is None:
+                if name == "SUMSQ":
+                    lo, hi = args
+                    if self._works:
+                        with torch.cuda.stream(ts[sid]):
+                            for w in self._works:
+                                w.wait()
+                        self._works = []
+                    L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), hs[sid]), "vmmt_sumsq")
+                    self._sumsq_by_plan = True
+                    continue
                 if name == "ALLREDUCE":
                     if self.dp is not None and self.dp.world > 1:
                         lo, hi = args
@@ -287,7 +333,9 @@ class Engine(object):
                         ev = events[args] = torch.cuda.Event()
                     ev.record(ts[sid])
                 else:
-                    ts[sid].wait_event(events[args])
+                    ev = events.get(args) if args in events else self.global_events.get(args)
+                    if ev is not None:
+                        ts[sid].wait_event(ev)
             elif name == "memset":
                 if sid == 0 or side is main:
                     args[0].zero_()
@@ -420,6 +468,12 @@ class Workspace(object):
         e._wait(P, "fwd_begin")
         if training:
             e._call(P, _memset, e.flat_g)
+        self._mask_entries = getattr(self, "_mask_entries", {})
+        if drop:
+            # output dropout mask (VI_Model1.py:132): only needed after the decoder -> generated in the background
+            self._mask_entries["dec_out"] = (len(P), self.out_mask)
+            e._call(P, lib.vmmt_dropout_mask, dt, self.out_mask.p(), self.out_mask.rows * self.out_mask.ld, d.dropout, 0)
+            e._record(P, "out_mask")
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                 self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
         we = e.sh["dec_wih_l0_e"]
@@ -500,6 +554,7 @@ class Workspace(object):
         e._record(P, "img_fwd")
         e._sid = MAIN
         # a6 decoder: gx[t] = emb(y_t) W_e^T (side stream, above) ; zx = z W_z^T + b is added inside the step kernel
+        e._wait(P, "opt_side_done")      # decoder / attention / generator parameters + shadows of the previous update
         wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
         e._gemm(P, L.GEMM_NT, self.zT.p(), self.zT.ld, wz.p(), wz.ld, self.zx.p(), self.zx.ld, B, 4 * H, Z,
                 addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
@@ -546,6 +601,7 @@ class Workspace(object):
                 self.probs.data_ptr(), Tp, B, S, H)
         e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * H, act=L.ACT_TANH)
         if drop:
+            e._wait(P, "out_mask")
             e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
         e._wait(P, "img_fwd")            # join: the loss plans read mu_v
         return P
@@ -575,6 +631,7 @@ class Workspace(object):
         wg = e.sh["wg"]
         MAIN, SIDE = 0, 1
         e._sid = MAIN
+        e._call(P, _memset, e._sumsq)
         e._record(P, "bwd_begin")
         # ================= main: generator backward seed G^T, dO = G Wg ================================================
         e._sid = MAIN
@@ -705,6 +762,10 @@ class Workspace(object):
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
         e._sid = SIDE
         e._allreduce(P, "decoder.attn.linear_out.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
+        # gradient norm of everything that is final by now (generator, attention, decoder, inference networks): off the
+        # critical path, underneath the encoder chain
+        e._sumsq_entry(P, "generator.0.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
+        e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None)
         # ================= encoder LSTM backward (main) + its parameter gradients (side) ==========================
         dh_above = self.dctx
         for l in reversed(range(Lyr)):
@@ -780,6 +841,7 @@ class Workspace(object):
         e._sid = MAIN
         e._wait(P, "side_done")
         e._allreduce(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
+        e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
         return P
 
     def _latent_bwd_args(self, batch_global, kl_mult, use_freebits, margin, inv_norm):
@@ -835,24 +897,27 @@ def _engine_methods():
         st = self.stream()
         self.refresh_shadows(st)
         dev = self.dev
-        ws.src.copy_(src.reshape(-1), non_blocking=True)
-        ws.tgt_in.copy_(tgt[:-1].reshape(-1), non_blocking=True)      # Models.py:867
-        ws.y.copy_(tgt[1:].reshape(-1), non_blocking=True)            # VILoss.py:205
-        ws.src_len.copy_(src_len.reshape(-1), non_blocking=True)
-        ws.img_idx.copy_(torch.as_tensor(img_indices).reshape(-1), non_blocking=True)
-        ws.stats.zero_()
         tab = table if table is not None else getattr(self, "img_table", None)
         if tab is None:
             raise RuntimeError("no image-feature table: call set_image_table() first")
         d = self.d
+
+        def dev64(t):
+            t = torch.as_tensor(t)
+            return t.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous()
+        src_d, tgt_d, len_d, idx_d = dev64(src), dev64(tgt), dev64(src_len).reshape(-1), dev64(img_indices).reshape(-1)
+        gen_eps = training and eps is None
+        self.rng_counter += 1
+        L.check(self.lib.vmmt_prepare_batch(src_d.data_ptr(), tgt_d.data_ptr(), len_d.data_ptr(), idx_d.data_ptr(), S, Tp + 1, B,
+                                            ws.src.data_ptr(), ws.tgt_in.data_ptr(), ws.y.data_ptr(), ws.src_len.data_ptr(),
+                                            ws.img_idx.data_ptr(), ws.stats.data_ptr(), ws.eps.p() if gen_eps else None,
+                                            B * d.z if gen_eps else 0, self.rng_counter, st), "vmmt_prepare_batch")
+        ws._inputs_keepalive = (src_d, tgt_d, len_d, idx_d)
         if training:
             if eps is not None:
                 ws.eps.t.copy_(eps.to(device=dev, dtype=torch.float32))
-            else:
-                self.rng_counter += 1
-                L.check(self.lib.vmmt_randn(ws.eps.p(), B * d.z, self.rng_counter, st), "vmmt_randn")
             if d.dropout > 0:
-                mk = [("dec_out", ws.out_mask)] + [("enc_l%d" % l, ws.enc_mask[l]) for l in range(d.layers - 1)] + \
+                mk = [("enc_l%d" % l, ws.enc_mask[l]) for l in range(d.layers - 1)] + \
                      [("dec_l%d" % l, ws.dec_mask[l]) for l in range(d.layers - 1)]
                 for name, buf in mk:
                     if masks is not None and name in masks:
@@ -862,6 +927,16 @@ def _engine_methods():
                         # the mask is generated over the padded buffer (pad columns are never read)
                         L.check(self.lib.vmmt_dropout_mask(self.dt, buf.p(), buf.rows * buf.ld, d.dropout, self.rng_counter, st),
                                 "vmmt_dropout_mask")
+                # the output mask is a plan entry on the side stream: give it this step's seed, or turn it into a no-op
+                # when the caller injects the mask (tests)
+                ii, buf = ws._mask_entries["dec_out"]
+                fn, args, name, keep, sid = ws.plan_fwd_train[ii]
+                self.rng_counter += 1
+                if masks is not None and "dec_out" in masks:
+                    buf.view().copy_(masks["dec_out"].reshape(buf.rows, buf.cols).to(device=dev, dtype=self.T))
+                    ws.plan_fwd_train[ii] = (fn, (args[0], args[1], 0, args[3], self.rng_counter), name, keep, sid)
+                else:
+                    ws.plan_fwd_train[ii] = (fn, (args[0], args[1], buf.rows * buf.ld, args[3], self.rng_counter), name, keep, sid)
         plan = ws.plan_fwd_train if training else ws.plan_fwd_eval
         ii = ws._img_idx[bool(training)]
         fn, args, name, keep, sid = plan[ii]
@@ -910,18 +985,40 @@ def _engine_methods():
                     n_correct=int(round(s[L.STAT_NCORRECT])))
 
     def optim_step(self, lr=0.002, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-9, grad_scale=1.0):
-        """Optim.step (Optim.py:78-96): global-norm clip + Adam over the arena, then shadows are stale."""
-        st = self.stream()
-        if not hasattr(self, "_sumsq"):
-            self._sumsq = torch.zeros(4, dtype=torch.float32, device=self.dev)
-        self._sumsq.zero_()
-        if max_grad_norm:
+        """Optim.step (Optim.py:78-96): global-norm clip + Adam over the arena, then the compute shadows are refreshed.
+        The arena is updated in two halves: [encoder | inference networks] on the current stream (the next forward needs
+        them first), [generator | attention | decoder] on the side stream, where it overlaps the next step's encoder
+        phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights."""
+        main = torch.cuda.current_stream(self.dev)
+        st = main.cuda_stream
+        if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
+            self._sumsq.zero_()
             L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), st), "vmmt_sumsq")
+        self._sumsq_by_plan = False
         self.step_count += 1
-        L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
-                                        self.n_opt, lr, beta1, beta2, eps, self.step_count, float(max_grad_norm or 0.0),
-                                        self._sumsq.data_ptr(), grad_scale, st), "vmmt_adam_step")
-        self.shadows_dirty = True
+        split = self.offsets[self.first_enc_name][0]
+
+        def adam(lo, hi, stream, max_blocks=0):
+            L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
+                                            self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, lr, beta1, beta2,
+                                            eps, self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
+                                            max_blocks, stream), "vmmt_adam_step")
+        if self.use_side_stream and self.split_optim:
+            # both halves are HBM-bound: the critical half runs alone at full bandwidth, the other one starts behind it
+            adam(split, self.n_opt, st)
+            ev = self.global_events.setdefault("adam_main_done", torch.cuda.Event())
+            ev.record(main)
+            self._pack_part(0, st)
+            side = self.side_stream
+            side.wait_event(ev)
+            adam(0, split, side.cuda_stream, max_blocks=self.bg_adam_blocks)
+            self._pack_part(1, side.cuda_stream)
+            self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
+        else:
+            adam(0, self.n_opt, st)
+            self._pack_part(0, st)
+            self._pack_part(1, st)
+        self.shadows_dirty = False
 
     for k, v in list(locals().items()):
         if callable(v):

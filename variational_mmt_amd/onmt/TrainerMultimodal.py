@@ -160,6 +160,9 @@ class TrainerMultimodal(object):
             num_batches = len(train_iter)
         except (NotImplementedError, TypeError):
             num_batches = -1
+        return self._train_loop(train_iter, epoch, report_func, total_stats, report_stats, num_batches)
+
+    def _train_loop(self, train_iter, epoch, report_func, total_stats, report_stats, num_batches):
         for idx, batch in enumerate(train_iter):
             if hasattr(train_iter, "get_cur_dataset"):
                 self.train_loss.cur_dataset = train_iter.get_cur_dataset()
