@@ -149,6 +149,8 @@ int vmmt_masked_mean(int dtype, const void* ctx, int64_t ldc, const int64_t* len
  *   workspaces: part_max/part_sum f32 [vmmt_gen_npart(V)][M], part_idx int32 same, tgt_logit f32 [M]
  *   out: lse f32 [M], tok_nll f32 [M]; stats[NLL,NWORDS,NCORRECT] += sums. */
 int vmmt_gen_npart(int V);
+/* tuning hook (tools/gen_ab.py): -1 automatic, 0 register-staged, 1 LDS-DMA one buffer, 2 LDS-DMA two buffers */
+int vmmt_gen_set_variant(int v);
 int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
                       const int64_t* y, int M, int V, int K, int pad, float* part_max, float* part_sum, int* part_idx,
                       float* tgt_logit, float* lse, float* tok_nll, float* stats, void* stream);

@@ -5,6 +5,7 @@
 // reduction runs over the token dimension).  Replaces the cuBLAS addmm calls behind every nn.Linear / nn.LSTM
 // input projection of the reference hot path.
 #include "common.hpp"
+#include "glds_gemm.hpp"
 #include "vmmt.h"
 
 namespace vmmt {
@@ -66,7 +67,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
   }
 }
 
-template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true>
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, bool GL = false>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int M, int N, int K, int a_kmod,
             int b_kmod, int tiles_n, int kper, GemmEpi epi) {
@@ -94,20 +95,24 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb
   LinearMap amap{m0, M}, bmap{n0, N};
   const int kbeg = blockIdx.y * kper;                 // split-K: this block reduces over [kbeg, kend)
   const int kend = min(K, kbeg + kper);
-  gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ, LinearMap, LinearMap, DB>(A, lda, amap, B, ldb, bmap, kend, a_kmod,
-                                                                                  b_kmod, aoff, boff, acc, smem, kbeg);
+  if constexpr (GL) {   // LDS-DMA main loop (glds_gemm.hpp); preconditions checked by launch_layout
+    gemm_mainloop_glds<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
+  } else {
+    gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ, LinearMap, LinearMap, DB>(A, lda, amap, B, ldb, bmap, kend, a_kmod,
+                                                                                    b_kmod, aoff, boff, acc, smem, kbeg);
+  }
   if (blockIdx.y != 0) epi.add_rows = 0;             // the addend is added once
   gemm_epilogue<T, TI, TJ>(epi, acc, aoff, boff, m0, n0, M, N, lane);
 }
 
-template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true>
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, bool GL = false>
 static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
-  size_t smem = gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
+  size_t smem = GL ? (size_t)glds_smem_bytes<BM, BN>() : gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
   if (smem > 64 * 1024) {
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB>,
+    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB, GL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
   }
   int splits = epi.atomic ? a->split_k : 1;
@@ -116,7 +121,7 @@ static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t s
   if (kper < BK) kper = BK;
   splits = (a->K + kper - 1) / kper;
   if (splits < 1) splits = 1;
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB>), dim3(tm * tn, splits), dim3(NT), smem, st,
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB, GL>), dim3(tm * tn, splits), dim3(NT), smem, st,
                      (const T*)a->A, (long)a->lda, (const T*)a->B, (long)a->ldb, a->M, a->N, a->K, a->a_kmod,
                      a->b_kmod, tn, kper, epi);
   return check_launch();
@@ -126,18 +131,30 @@ template <class T, bool A_KC, bool B_KC>
 static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
   long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * (epi.atomic && a->split_k > 1 ? a->split_k : 1);
   if constexpr (sizeof(T) == 2) {     // experimental variants for in-process A/B (tools/gemm_ab.py)
+    if (a->tile == 1280) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st);   // register-staged loop
     if (a->tile == 1281) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 32, true>(a, epi, st);
     if (a->tile == 1282) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, false>(a, epi, st);
     if (a->tile == 1283) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 32, false>(a, epi, st);
     if (a->tile == 2561) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 32, true>(a, epi, st);
     if (a->tile == 2562) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, false>(a, epi, st);
     if (a->tile == 2563) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, false>(a, epi, st);
+    // LDS-DMA main loop: 16-byte aligned operands, K in whole 64-slabs, no k-modulus
+    const bool gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
+                       ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
+    if (a->tile == 1284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
+    if (a->tile == 2564 && gl_ok) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
+    if (a->tile == 2565 && gl_ok) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
   }
   if (a->tile == 128 || (a->tile == 0 && t128 >= 192)) {
     // bf16: BK = 64 (each row contributes a full 128-byte line per slab) + two LDS buffers: +30 % over BK = 32 on the
     // long-K gradient GEMMs (tools/gemm_ab.py, interleaved in one process)
-    if constexpr (sizeof(T) == 2) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st);
-    else return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st);
+    if constexpr (sizeof(T) == 2) {
+      // LDS-DMA main loop when its preconditions hold (+10..15 % over the register-staged loop, tools/gemm_ab.py)
+      const bool gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
+                         ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
+      if (gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
+      return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st);
+    } else return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st);
   }
   return launch_cfg<T, 64, 64, 32, 32, A_KC, B_KC>(a, epi, st);
 }

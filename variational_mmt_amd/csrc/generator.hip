@@ -10,6 +10,7 @@
 // pass 2 recomputes the logits tile and writes the loss gradient G^T[v][m] = (softmax - onehot) * w_m / norm
 // directly in the storage type, coalesced along tokens.  dO = G Wg and dWg = G^T O are then plain GEMMs.
 #include "common.hpp"
+#include "glds_gemm.hpp"
 #include "vmmt.h"
 
 namespace vmmt {
@@ -34,7 +35,8 @@ template <class T> struct GenCfg {
   static constexpr int PP = 64 + 16 / sizeof(T);     // pitch (elements) of a wave's 64 x 64 output patch in LDS
 };
 
-template <class T, int MODE>
+// GL: 0 = register-staged main loop (any dtype / alignment), 1 = LDS-DMA main loop with one buffer, 2 = with two buffers
+template <class T, int MODE, int GL>
 __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
   using Cf = GenCfg<T>;
   constexpr int BK = Cf::BK, NT = Cf::NT, BMV = Cf::BMV, BNM = Cf::BNM, TI = Cf::TI, TJ = Cf::TJ;
@@ -62,8 +64,13 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   LinearMap amap{v0, a.V}, bmap{m0, a.M};
-  gemm_mainloop<T, BMV, BNM, BK, NT, true, true, TI, TJ, LinearMap, LinearMap, Cf::DB>(
-      (const T*)a.W, a.ldw, amap, (const T*)a.O, a.ldo, bmap, a.K, 0, 0, aoff, boff, acc, smem);
+  if constexpr (GL != 0) {
+    gemm_mainloop_glds<BMV, BNM, NT / 64, true, true, TI, TJ, GL == 2>((const bf16_t*)a.W, a.ldw, v0, a.V, (const bf16_t*)a.O, a.ldo,
+                                                                     m0, a.M, 0, a.K, aoff, boff, acc, smem_raw);
+  } else {
+    gemm_mainloop<T, BMV, BNM, BK, NT, true, true, TI, TJ, LinearMap, LinearMap, Cf::DB>(
+        (const T*)a.W, a.ldw, amap, (const T*)a.O, a.ldo, bmap, a.K, 0, 0, aoff, boff, acc, smem);
+  }
   if constexpr (MODE == 1) __syncthreads();     // the staging buffers are reused as per-wave output patches
   // A lane owns token columns m_j and, per 32-row tile i, the vocabulary rows vb_i + 8q + s (q, s = 0..3) where
   // vb_i = v0 + aoff[i] + 4*(lane>>5): four consecutive rows per register group q -> one 16-byte bias load per group.
@@ -217,23 +224,40 @@ __global__ void __launch_bounds__(1024) gen_combine_kernel(const float* __restri
   }
 }
 
-template <class T, int MODE>
-static int launch_gen(const GenArgs& a, hipStream_t st) {
+int g_gen_variant = -1;   // -1: automatic; 0/1/2 force a main loop (tools/gen_ab.py via vmmt_gen_set_variant)
+
+template <class T, int MODE, int GL>
+static int launch_gen_v(const GenArgs& a, hipStream_t st) {
   using Cf = GenCfg<T>;
   int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + Cf::BNM - 1) / Cf::BNM;
-  size_t sm = gemm_smem_elems<T, Cf::BMV, Cf::BNM, Cf::BK, true, true, Cf::DB>() * sizeof(T);
+  size_t sm = GL ? (size_t)glds_smem_bytes<Cf::BMV, Cf::BNM, GL == 2>()
+                 : gemm_smem_elems<T, Cf::BMV, Cf::BNM, Cf::BK, true, true, Cf::DB>() * sizeof(T);
   if (MODE == 1 && sm < (size_t)8 * 64 * Cf::PP * sizeof(T)) sm = (size_t)8 * 64 * Cf::PP * sizeof(T);
   if (sm > 64 * 1024) {
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gen_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done = true; }
+    if (!done) { (void)hipFuncSetAttribute((const void*)gen_kernel<T, MODE, GL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done = true; }
   }
-  hipLaunchKernelGGL((gen_kernel<T, MODE>), dim3(tv * tm), dim3(Cf::NT), sm, st, a, tm);
+  hipLaunchKernelGGL((gen_kernel<T, MODE, GL>), dim3(tv * tm), dim3(Cf::NT), sm, st, a, tm);
   return check_launch();
+}
+
+template <class T, int MODE>
+static int launch_gen(const GenArgs& a, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    // LDS-DMA main loop: 16-byte aligned operands, K in whole 64-slabs (callers round K up over zero-padded rows)
+    const bool ok = a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldo % 8 == 0 && ((((uintptr_t)a.W) | ((uintptr_t)a.O)) & 15) == 0;
+    int v = g_gen_variant < 0 ? 2 : g_gen_variant;   // two buffers: -13 % vs one buffer or register staging (tools/gen_ab.py)
+    if (ok && v == 1) return launch_gen_v<T, MODE, 1>(a, st);
+    if (ok && v == 2) return launch_gen_v<T, MODE, 2>(a, st);
+  }
+  return launch_gen_v<T, MODE, 0>(a, st);
 }
 
 }  // namespace vmmt
 
 extern "C" int vmmt_gen_npart(int V) { return ((V + 127) / 128) * 2; }
+
+extern "C" int vmmt_gen_set_variant(int v) { vmmt::g_gen_variant = v; return VMMT_OK; }
 
 extern "C" int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
                                  const int64_t* y, int M, int V, int K, int pad, float* part_max, float* part_sum,

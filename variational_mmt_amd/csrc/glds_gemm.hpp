@@ -1,0 +1,188 @@
+// LDS-DMA GEMM main loop for the bf16 fast path (gfx950).
+//
+// Differences to gemm_mainloop (common.hpp), which remains the general / fp32 / edge-case path:
+//   * operand slabs (BK = 64) go HBM/L2 -> LDS directly with global_load_lds_dwordx4: no VGPR staging, no ds_write, and the
+//     instruction stream of a K step shrinks to 2 x (ROWS/8)/NW DMA issues + fragment reads + MFMAs;
+//   * the LDS images are LINEAR (an LDS-DMA instruction writes base + lane*16 B), so bank conflicts are removed by an XOR
+//     swizzle of the 16-byte chunk index that is applied to the per-lane SOURCE address and again to the fragment reads
+//     (K-contiguous image: 128-byte rows, chunk ^= (row >> 1) & 7; K-strided image: 256-byte k-rows, chunk ^= 4 * (k & 3),
+//     which spreads the four k-rows of a ds_read_b64_tr_b16 block over all 64 banks);
+//   * every fragment address is a per-lane constant + immediate: no address arithmetic inside the loop;
+//   * two LDS buffers, the loop is unrolled by two so that buffer offsets are immediates; hipcc drains vmcnt(0) at the
+//     workgroup barrier, i.e. slab t+1 is in flight while slab t is multiplied.
+// Preconditions (checked by the callers, otherwise they use gemm_mainloop): bf16, base pointers 16-byte aligned, leading
+// dimensions multiples of 8 elements, K a multiple of 64, every K index < K readable for all tile rows (callers round K up to
+// 64 over zero-padded buffers), no k-modulus.  Rows outside [0, limit) are CLAMPED, not masked: they only feed output elements
+// that the epilogue never stores.
+#pragma once
+#include "common.hpp"
+
+namespace vmmt {
+
+typedef __attribute__((address_space(3))) void g_lds_void_t;
+typedef __attribute__((address_space(1))) const void g_glb_cvoid_t;
+
+constexpr int GBK = 64;   // K slab
+
+// stages one operand tile per call: ROWS tile rows (KC: ROWS x 64 elements, KS: 64 k-rows x ROWS elements) = ROWS/8 pieces of 1 KiB
+template <int ROWS, bool KC, int NW>
+struct GldsOperand {
+  static constexpr int NP = ROWS / 8;            // 1-KiB pieces per slab
+  static constexpr int PER = NP / NW;            // pieces per wave
+  static_assert(NP % NW == 0, "pieces must divide over the waves");
+  static constexpr int BYTES = ROWS * GBK * 2;
+  const char* src[PER];                          // per-lane source address of each of this wave's pieces (advanced every slab)
+  long step;                                     // bytes per K slab
+
+  __device__ __forceinline__ void init(const bf16_t* P, long ld, int row0, int limit, int k0, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int piece = wave * PER + j;
+      if constexpr (KC) {
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int g = row0 + row;
+        g = g < limit ? g : limit - 1;
+        src[j] = reinterpret_cast<const char*>(P + (long)g * ld + k0 + chunk * 8);
+      } else {
+        // ROWS > 128: side-by-side sub-images of [64 k-rows][128 columns] (16 KiB each), 16 pieces per sub-image
+        const int sub = piece >> 4;
+        const int krow = (piece & 15) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ ((krow & 3) * 4);
+        int col = row0 + sub * 128 + chunk * 8;
+        const int cmax = ((limit - 1) / 8) * 8;
+        col = col < cmax ? col : cmax;           // last chunk that holds a valid column; clamped chunks only feed unstored outputs
+        src[j] = reinterpret_cast<const char*>(P + (long)(k0 + krow) * ld + col);
+      }
+    }
+    step = KC ? (long)GBK * 2 : (long)GBK * ld * 2;
+  }
+  __device__ __forceinline__ void issue(char* lds, int wave) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      char* dst = lds + (wave * PER + j) * 1024;                  // wave-uniform; hardware adds lane * 16
+      __builtin_amdgcn_global_load_lds((g_glb_cvoid_t*)src[j], (g_lds_void_t*)dst, 16, 0, 0);
+      src[j] += step;
+    }
+  }
+};
+
+// per-lane fragment base offsets (bytes) into an operand image; tile t of the wave adds an immediate
+template <bool KC, int NT_>   // NT_: number of 32-row tiles of this operand per wave
+struct GldsFrag {
+  int off[KC ? 4 : NT_];
+  __device__ __forceinline__ void init(const int (&toff)[NT_], int lane) {
+    if constexpr (KC) {
+      // image [row][8 chunks of 16 B]; lane (r, h) reads chunk c = 2 ks + h of row toff + r at chunk ^ ((row >> 1) & 7)
+      const int r = lane & 31, h = lane >> 5, s = (r >> 1) & 7;      // toff multiples of 32 do not change the swizzle key
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) off[ks] = r * 128 + (((2 * ks + h) ^ s) * 16);
+    } else {
+      // image [k-row][16 chunks of 16 B]; transposed read of a 4(k) x 16(row) block per 16-lane group
+      const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) {
+        const int chunk = ((toff[t] & 127) >> 3) + 2 * (g & 1) + (p >> 1);
+        off[t] = (toff[t] >> 7) * 16384 + (8 * (g >> 1) + q) * 256 + ((chunk ^ (q * 4)) * 16) + (p & 1) * 8;
+      }
+    }
+  }
+};
+
+typedef short gs16x4 __attribute__((ext_vector_type(4)));
+typedef short gs16x8 __attribute__((ext_vector_type(8)));
+
+template <bool KC, int NT_>
+__device__ __forceinline__ bf16x8 glds_frag(const char* img, const GldsFrag<KC, NT_>& f, const int (&toff)[NT_], int t, int ks) {
+  if constexpr (KC) {
+    return *reinterpret_cast<const bf16x8*>(img + f.off[ks] + toff[t] * 128);
+  } else {
+    typedef __attribute__((address_space(3))) gs16x4 lds_v;
+    const char* a0 = img + f.off[t] + ks * 16 * 256;
+    gs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(a0));
+    gs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(a0 + 4 * 256));
+    gs16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int TI, int TJ>
+__device__ __forceinline__ void glds_slab(const char* As, const char* Bs, const GldsFrag<A_KC, TI>& fa, const GldsFrag<B_KC, TJ>& fb,
+                                          const int (&aoff)[TI], const int (&boff)[TJ], f32x16 (&acc)[TI][TJ]) {
+  // fragments of K-step ks+1 are requested before the MFMAs of K-step ks (register double buffer)
+  bf16x8 a[2][TI], b[2][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) a[0][i] = glds_frag<A_KC, TI>(As, fa, aoff, i, 0);
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) b[0][j] = glds_frag<B_KC, TJ>(Bs, fb, boff, j, 0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if (ks < 3) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a[(ks + 1) & 1][i] = glds_frag<A_KC, TI>(As, fa, aoff, i, ks + 1);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) b[(ks + 1) & 1][j] = glds_frag<B_KC, TJ>(Bs, fb, boff, j, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (hipcc otherwise re-serialises them)
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+  }
+}
+
+template <int BM, int BN, bool DBUF = true>
+constexpr int glds_smem_bytes() { return (DBUF ? 2 : 1) * (BM + BN) * GBK * 2; }
+
+// C_tile += A_tile * B_tile^T over k in [kbeg, kend), kend - kbeg a positive multiple of 64.
+template <int BM, int BN, int NW, bool A_KC, bool B_KC, int TI, int TJ, bool DBUF = true>
+__device__ __forceinline__ void gemm_mainloop_glds(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
+                                                   long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
+                                                   const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem) {
+  constexpr int ABYTES = BM * GBK * 2, BBYTES = BN * GBK * 2, BUF = ABYTES + BBYTES;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  GldsOperand<BM, A_KC, NW> ga;
+  GldsOperand<BN, B_KC, NW> gb;
+  ga.init(A, lda, m0, M, kbeg, wave, lane);
+  gb.init(B, ldb, n0, N, kbeg, wave, lane);
+  GldsFrag<A_KC, TI> fa;
+  GldsFrag<B_KC, TJ> fb;
+  fa.init(aoff, lane);
+  fb.init(boff, lane);
+  const int nslab = (kend - kbeg) / GBK;
+  if (nslab <= 0) return;
+  if constexpr (!DBUF) {   // one buffer: short K, several workgroups per CU overlap each other's load and multiply phases
+    for (int s = 0; s < nslab; ++s) {
+      ga.issue(smem, wave);
+      gb.issue(smem + ABYTES, wave);
+      __syncthreads();
+      glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem, smem + ABYTES, fa, fb, aoff, boff, acc);
+      __syncthreads();
+    }
+    return;
+  }
+  ga.issue(smem, wave);
+  gb.issue(smem + ABYTES, wave);
+  __syncthreads();
+  int s = 0;
+  for (; s + 2 <= nslab; s += 2) {
+    // slab s in buffer 0, slab s+1 into buffer 1
+    ga.issue(smem + BUF, wave);
+    gb.issue(smem + BUF + ABYTES, wave);
+    glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem, smem + ABYTES, fa, fb, aoff, boff, acc);
+    __syncthreads();
+    if (s + 2 < nslab) {
+      ga.issue(smem, wave);
+      gb.issue(smem + ABYTES, wave);
+    }
+    glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem + BUF, smem + BUF + ABYTES, fa, fb, aoff, boff, acc);
+    __syncthreads();
+  }
+  if (s < nslab) {   // odd count: the last slab sits in buffer 0
+    glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem, smem + ABYTES, fa, fb, aoff, boff, acc);
+    __syncthreads();
+  }
+}
+
+}  // namespace vmmt

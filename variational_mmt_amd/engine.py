@@ -70,16 +70,22 @@ def _ru(x, m):
     return (x + m - 1) // m * m
 
 
+KPAD = 64          # GEMM reduction slab (elements)
+
+
 class Buf(object):
-    """2-D device buffer [rows][ld] (ld >= cols, 16-byte aligned rows)."""
+    """2-D device buffer [rows][ld].  Rows and (unless `ld` is given) columns are zero-padded to whole 64-element GEMM
+    slabs plus one spare slab of rows, so that a GEMM may round its reduction length K up to a multiple of 64 whichever
+    way the buffer is traversed (K-contiguous or K-strided, also from a row / column offset): the padding contributes
+    exact zeros.  Nothing ever writes the padding."""
 
     def __init__(self, rows, cols, dtype, device, ld=None, fill=None):
         esz = torch.empty((), dtype=dtype).element_size()
-        self.ld = ld if ld is not None else _ru(max(cols, 1), 16 // esz if esz <= 16 else 1)
+        self.ld = ld if ld is not None else _ru(max(cols, 1), KPAD)
         self.rows, self.cols, self.esz = rows, cols, esz
-        self.t = torch.zeros(max(rows, 1), self.ld, dtype=dtype, device=device)
+        self.t = torch.zeros(_ru(max(rows, 1), KPAD) + KPAD, self.ld, dtype=dtype, device=device)
         if fill is not None:
-            self.t.fill_(fill)
+            self.t[:rows, :cols].fill_(fill)
 
     def p(self, r=0, c=0):
         return self.t.data_ptr() + (r * self.ld + c) * self.esz
@@ -267,6 +273,8 @@ class Engine(object):
             split_k = max(1, min(K // 256, (1024 + tiles - 1) // tiles))
             if split_k == 1:
                 accumulate = 1          # gradients always ACCUMULATE into the arena (zeroed at the start of a step)
+        if a_kmod == 0 and b_kmod == 0:
+            K = _ru(K, KPAD)            # operands are Bufs: zero-padded to whole slabs (see Buf)
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
                        add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k)
         plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
@@ -613,7 +621,7 @@ class Workspace(object):
         wg = e.sh["wg"]
         O = self.O if (training and d.dropout > 0) else self.AH      # eval: nn.Dropout is the identity
         e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(),
-                self.M, d.vt, d.hid, PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), self.part_idx.data_ptr(),
+                self.M, d.vt, _ru(d.hid, KPAD), PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), self.part_idx.data_ptr(),
                 self.tgt_logit.data_ptr(), self.lse.data_ptr(), self.tok_nll.data_ptr(), self.stats.data_ptr())
         return P
 
@@ -636,7 +644,7 @@ class Workspace(object):
         # ================= main: generator backward seed G^T, dO = G Wg ================================================
         e._sid = MAIN
         e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
-                M, V, H, PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
+                M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
         e._record(P, "GT")
         e._call(P, _memset, self.dO32.t)
         e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
@@ -915,7 +923,7 @@ def _engine_methods():
         ws._inputs_keepalive = (src_d, tgt_d, len_d, idx_d)
         if training:
             if eps is not None:
-                ws.eps.t.copy_(eps.to(device=dev, dtype=torch.float32))
+                ws.eps.view().copy_(eps.to(device=dev, dtype=torch.float32))
             if d.dropout > 0:
                 mk = [("enc_l%d" % l, ws.enc_mask[l]) for l in range(d.layers - 1)] + \
                      [("dec_l%d" % l, ws.dec_mask[l]) for l in range(d.layers - 1)]
