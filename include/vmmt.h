@@ -41,6 +41,14 @@ extern "C" {
 
 int vmmt_version(void);
 
+/* ---- streams ---------------------------------------------------------------------------------------------------
+ * A HIP stream whose kernels may only occupy the compute units set in `mask` (`words` x 32 bits, bit i = CU i as
+ * hipExtStreamCreateWithCUMask numbers them).  Used for the step's bulk side stream so that a share of the CUs stays
+ * free for the latency-critical kernels of the main stream (the reference serialises everything on one CUDA stream:
+ * onmt/TrainerMultimodal.py:624-705). */
+int vmmt_stream_create_masked(const uint32_t* mask, int words, int priority, void** stream);
+int vmmt_stream_destroy(void* stream);
+
 /* ---- generic fused GEMM --------------------------------------------------------------------------------------
  * C[m][n] (+)= act(alpha * sum_k A(m,k) B(n,k) + addend(m,n)).
  * Replaces every nn.Linear / addmm on the path: LSTM input projections (Models.py:124-129, VI_Model1.py:149-152),
@@ -90,6 +98,9 @@ typedef struct vmmt_lstm_dir_fwd {
   int t;                                 /* time index (compared with lens[b])                                  */
   int capture;                           /* 0 none; 1 if t == lens[b]-1; 2 if t == 0; 3 always                  */
 } vmmt_lstm_dir_fwd;
+/* tuning hook for the bf16 fast path (tools/probe/lstm_probe.hip): staging variant, 0 = default */
+int vmmt_lstm_set_variant(int v);
+
 int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* dirs, const int64_t* lens, int B, int H,
                        void* stream);
 

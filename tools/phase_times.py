@@ -1,0 +1,36 @@
+"""Main-stream phase timing WITHOUT the profiler: timing events recorded at every change of kernel name on the main
+stream of a steady-state step (host far ahead of the GPU). Run on the GPU box."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from variational_mmt_amd.engine import Dims, Engine
+import bench
+d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.5)
+eng = Engine(d, dtype="bf16", device="cuda", seed=0)
+eng.set_image_table(torch.rand(29000, d.img))
+eng.use_side_stream = os.environ.get("SIDE", "1") == "1"
+bs = bench.make_batches(d, 256, 20, 21, 29000, 4, "cuda", 1)
+def step(i):
+    src, sl, tgt, idx = bs[i % 4]
+    ws = eng.forward(src, sl, tgt, idx, training=True)
+    eng.loss_backward(ws, normalization=256, batch_global=256)
+    eng.optim_step()
+for i in range(8): step(i)
+torch.cuda.synchronize()
+acc = {}
+N = 6
+for r in range(N):
+    for i in range(3): step(i)          # let the host run ahead
+    eng.trace = []
+    step(3)
+    tr, eng.trace = eng.trace, None
+    end = torch.cuda.Event(enable_timing=True); end.record()
+    torch.cuda.synchronize()
+    tr.append(("END", end))
+    for k in range(len(tr) - 1):
+        key = (k, tr[k][0])
+        acc.setdefault(key, []).append(tr[k][1].elapsed_time(tr[k + 1][1]) * 1e3)
+tot = 0.0
+for (k, name), v in sorted(acc.items()):
+    m = sorted(v)[len(v) // 2]
+    tot += m
+    print("%3d %-28s %8.1f us   (cum %8.1f)" % (k, name, m, tot))

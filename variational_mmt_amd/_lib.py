@@ -49,6 +49,8 @@ class PackDesc(C.Structure):
 
 _SIGS = {
     "vmmt_version": (i32, []),
+    "vmmt_stream_create_masked": (i32, [vp, i32, i32, vp]),
+    "vmmt_stream_destroy": (i32, [vp]),
     "vmmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "vmmt_lstm_step_fwd": (i32, [i32, i32, C.POINTER(LstmDirFwd), vp, i32, i32, vp]),
     "vmmt_lstm_step_bwd": (i32, [i32, i32, C.POINTER(LstmDirBwd), vp, i32, i32, i32, vp]),
@@ -57,6 +59,7 @@ _SIGS = {
     "vmmt_masked_mean": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "vmmt_gen_npart": (i32, [i32]),
     "vmmt_gen_set_variant": (i32, [i32]),
+    "vmmt_lstm_set_variant": (i32, [i32]),
     "vmmt_gen_loss_fwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "vmmt_gen_loss_bwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp]),
     "vmmt_gather_rows": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, vp]),

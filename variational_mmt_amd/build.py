@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libvmmt.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result"]
-SOURCES = ["gemm.hip", "lstm.hip", "attention.hip", "generator.hip", "elementwise.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "lstm.hip", "attention.hip", "generator.hip", "elementwise.hip", "optim.hip", "runtime.hip"]
 
 
 def _stale(out, deps):
@@ -25,7 +25,7 @@ def _stale(out, deps):
 def build(force=False, verbose=True):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    common = [os.path.join(CSRC, "common.hpp"), os.path.join(ROOT, "include", "vmmt.h")]
+    common = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "glds_gemm.hpp"), os.path.join(ROOT, "include", "vmmt.h")]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -144,6 +144,9 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
     if (a->tile == 1284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
     if (a->tile == 2564 && gl_ok) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
     if (a->tile == 2565 && gl_ok) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
+    if (a->tile == 2566 && gl_ok) return launch_cfg<T, 256, 128, 128, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
+    if (a->tile == 2567 && gl_ok) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
+    if (a->tile == 2568 && gl_ok) return launch_cfg<T, 128, 256, 64, 128, A_KC, B_KC, 64, true, true>(a, epi, st);
   }
   if (a->tile == 128 || (a->tile == 0 && t128 >= 192)) {
     // bf16: BK = 64 (each row contributes a full 128-byte line per slab) + two LDS buffers: +30 % over BK = 32 on the

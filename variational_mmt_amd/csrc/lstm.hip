@@ -181,36 +181,37 @@ __global__ void __launch_bounds__(256) lstm_step_bwd_kernel(StepArgsB a) {
 
 // ==============================================================================================================
 // Latency-optimised bf16 step kernels.  A step is a tiny GEMM ([B x K] x [K x N]) on the critical path of the
-// recurrence, so what matters is the number of dependent memory round trips, not FLOPs:
-//   * small tiles (32 batch rows x 16 hidden units forward, 32 x 32 backward): >= 128-256 workgroups, one per CU;
-//   * the operands of a whole K chunk (<= 512) are staged with direct-to-LDS loads (global_load_lds_dwordx4, one
-//     1-KiB row piece per wave instruction, no VGPR round trip), ALL issued before a single wait, so a chunk costs
-//     one memory round trip instead of K/32 dependent ones;
+// recurrence, so what matters is the number of dependent memory round trips and the issue time of the loads:
+//   * tiles of 32 batch rows x 16 hidden units: 256 workgroups at B = 256, H = 512 (one per CU);
+//   * the operands of a whole K chunk are staged with direct-to-LDS loads (global_load_lds_dwordx4, one row piece per
+//     wave instruction, no VGPR round trip), ALL issued before a single wait.  In-kernel timestamps (tools/probe/
+//     lstm_probe.hip) showed that the first version spent 110 ns PER PIECE in address arithmetic and branches (2.7 us of
+//     a 5 us forward step, 7 us of a 14 us backward step): here every piece address is a wave-uniform base (scalar
+//     registers, rows clamped instead of skipped) plus one per-lane offset, fully unrolled;
 //   * v_mfma_f32_16x16x32_bf16 straight from LDS (row pitch = chunk bytes + 16: conflict-free ds_read_b128);
-//     its C layout (col = lane&15, row = 4*(lane>>4)+reg) puts the four gates of a hidden unit in one lane.
+//     its C layout (col = lane&15, row = 4*(lane>>4)+reg) puts the four gates of a hidden unit in one lane;
+//   * the four waves split the tile as 2 row halves x 2 K halves; the K halves are folded through LDS and every wave
+//     finishes two of its four accumulator rows, so the cell epilogue's loads and stores are spread over all lanes.
 // W_hh (2 MB at H = 512) stays L2-resident across the steps; h_{t-1} / dgates are re-read from L2 by the blocks that
 // share them.
 // ==============================================================================================================
+#ifdef VMMT_PROBE
+__device__ unsigned long long vmmt_probe_ts[64 * 16];
+#define VMMT_TS(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) \
+    vmmt_probe_ts[(blockIdx.x & 63) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define VMMT_TS(i) do {} while (0)
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_cvoid_t;
-constexpr int FAST_KCH = 512;                 // K chunk (elements)
-constexpr int FAST_PITCH = FAST_KCH * 2 + 16; // bytes
-
-// stage rows [0, nrows) of a chunk: row r comes from rowptr(r) (null = skip), kbytes valid bytes per row
-template <class RowPtr>
-__device__ __forceinline__ void stage_rows(char* lds, int row0, int nrows, int kbytes, RowPtr rowptr, int wave, int nwaves,
-                                           int lane) {
-  for (int r = wave; r < nrows; r += nwaves) {
-    const char* src = rowptr(r);
-    char* dst = lds + (row0 + r) * FAST_PITCH;                      // wave-uniform
-    if (src != nullptr && lane * 16 < kbytes)
-      __builtin_amdgcn_global_load_lds((glb_cvoid_t*)(src + lane * 16), (lds_void_t*)dst, 16, 0, 0);
-  }
-}
-
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-// epilogue operands of the forward cell, fetched BEFORE the staging wait so that their latency hides behind it
+__device__ __forceinline__ void dma16(const char* src, char* dst_uniform) {
+  __builtin_amdgcn_global_load_lds((glb_cvoid_t*)src, (lds_void_t*)dst_uniform, 16, 0, 0);
+}
+
+// epilogue operands of the forward cell, fetched right behind the staging loads so that their latency hides behind them
 struct CellInF { float gx[4]; float cp; long long len; };
 __device__ __forceinline__ CellInF cell_fwd_load(const StepDirF& d, const long long* lens, int b, int u, int H, int B) {
   CellInF in;
@@ -242,53 +243,118 @@ __device__ __forceinline__ void cell_fwd_apply(const StepDirF& d, bool has_lens,
   }
 }
 
-__global__ void __launch_bounds__(256) lstm_step_fwd_fast(StepArgsF a) {
+template <int KC> struct FastCfg {
+  static constexpr int PITCH = KC * 2 + 16;     // bytes per staged row
+  static constexpr int NKS = KC / 32;           // MFMA K steps per chunk
+  static constexpr int HALF = (NKS + 1) / 2;    // K steps of wave K-half 0
+};
+
+// Forward: gates[32 x (4 x 16)] += h_prev[32 x H] W_hh[(4 x 16) x H]^T, K in chunks of KC (H % KC == 0).
+template <int KC, int NW = 4, bool REG = false>
+__global__ void __launch_bounds__(NW * 64) lstm_step_fwd_fast(StepArgsF a) {
+  using Cf = FastCfg<KC>;
+  constexpr int PITCH = Cf::PITCH;
+  constexpr int NA = 32 / NW, NB = 64 / NW;      // rows of h_prev / W_hh staged per wave
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const StepDirF& d = a.d[blockIdx.z];
   const int B = a.B, H = a.H;
   const int m0 = blockIdx.x * 32, u0 = blockIdx.y * 16;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wm = wave & 1, wk = wave >> 1;
   const int u = u0 + (lane & 15);
   // this wave finishes rows r = 2*wk, 2*wk+1 of its 16-row tile (both K halves are folded through LDS)
   const int brow0 = m0 + wm * 16 + (lane >> 4) * 4 + 2 * wk;
-  CellInF in0 = cell_fwd_load(d, a.lens, brow0, u, H, B);
-  CellInF in1 = cell_fwd_load(d, a.lens, brow0 + 1, u, H, B);
+  VMMT_TS(0);
   f32x4_t acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const char* hp = reinterpret_cast<const char*>(d.h_prev);
   const char* wp = reinterpret_cast<const char*>(d.w_hh);
-  for (int k0 = 0; k0 < H; k0 += FAST_KCH) {
-    const int kc = min(FAST_KCH, H - k0);
+  const int lane16 = lane * 16;
+  CellInF in0, in1;
+  for (int k0 = 0; k0 < H; k0 += KC) {
     if (k0 > 0) __syncthreads();
-    stage_rows(lds, 0, 32, kc * 2, [&](int r) { int b = m0 + r; return b < B ? hp + ((long)b * d.ld_hprev + k0) * 2 : nullptr; },
-               wave, 4, lane);
-    stage_rows(lds, 32, 64, kc * 2, [&](int r) { int g = r >> 4, uu = u0 + (r & 15);
-                 return wp + (((long)g * H + uu) * d.ld_w + k0) * 2; }, wave, 4, lane);
-    __syncthreads();                                                // hipcc drains vmcnt(0) here: all pieces landed
-    const int nks = kc / 32, half = (nks + 1) / 2;
-    const int ks0 = wk == 0 ? 0 : half, ks1 = wk == 0 ? half : nks;
-    const char* arow = lds + (wm * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
-    const char* brow = lds + (32 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
-#pragma unroll 2
-    for (int ks = ks0; ks < ks1; ++ks) {
-      bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
+    if constexpr (!REG) {
+      if (lane16 < KC * 2) {
+        // rows wave, wave+NW, ...: rows of h_prev (clamped at the batch edge) and of W_hh (gate r>>4, unit u0 + (r & 15))
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + g * 16 * FAST_PITCH + ks * 64);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[g], 0, 0, 0);
+        for (int j = 0; j < NA; ++j) {
+          const int r = wave + NW * j, b = min(m0 + r, B - 1);
+          dma16(hp + ((long)b * d.ld_hprev + k0) * 2 + lane16, lds + r * PITCH);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int r = wave + NW * j;
+          const long row = (long)(r >> 4) * H + u0 + (r & 15);
+          dma16(wp + (row * d.ld_w + k0) * 2 + lane16, lds + (32 + r) * PITCH);
+        }
+      }
+    } else {
+      // register staging: all loads in flight, then one ds_write pass
+      u32x4 va[NA], vb[NB];
+      const bool on = lane16 < KC * 2;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int r = wave + NW * j, b = min(m0 + r, B - 1);
+        if (on) va[j] = *reinterpret_cast<const u32x4*>(hp + ((long)b * d.ld_hprev + k0) * 2 + lane16);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int r = wave + NW * j;
+        const long row = (long)(r >> 4) * H + u0 + (r & 15);
+        if (on) vb[j] = *reinterpret_cast<const u32x4*>(wp + (row * d.ld_w + k0) * 2 + lane16);
+      }
+      if (k0 == 0 && wave < 4) {
+        in0 = cell_fwd_load(d, a.lens, brow0, u, H, B);
+        in1 = cell_fwd_load(d, a.lens, brow0 + 1, u, H, B);
+      }
+#pragma unroll
+      for (int j = 0; j < NA; ++j) if (on) *reinterpret_cast<u32x4*>(lds + (wave + NW * j) * PITCH + lane16) = va[j];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) if (on) *reinterpret_cast<u32x4*>(lds + (32 + wave + NW * j) * PITCH + lane16) = vb[j];
+    }
+    if (!REG && k0 == 0 && wave < 4) {
+      in0 = cell_fwd_load(d, a.lens, brow0, u, H, B);
+      in1 = cell_fwd_load(d, a.lens, brow0 + 1, u, H, B);
+    }
+    VMMT_TS(1);
+    __syncthreads();                                                // hipcc drains vmcnt(0) here: all pieces landed
+    VMMT_TS(2);
+    const char* arow = lds + (wm * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
+    const char* brow = lds + (32 + (lane & 15)) * PITCH + (lane >> 4) * 16;
+    if (wave >= 4) {
+    } else if (wk == 0) {
+#pragma unroll
+      for (int ks = 0; ks < Cf::HALF; ++ks) {
+        bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, *reinterpret_cast<const bf16x8*>(brow + g * 16 * PITCH + ks * 64),
+                                                           acc[g], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = Cf::HALF; ks < Cf::NKS; ++ks) {
+        bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, *reinterpret_cast<const bf16x8*>(brow + g * 16 * PITCH + ks * 64),
+                                                           acc[g], 0, 0, 0);
       }
     }
   }
   // fold the two K halves through LDS: every wave publishes its partial tile, then finishes 2 of the 4 rows
+  VMMT_TS(3);
   __syncthreads();
   float* red = reinterpret_cast<float*>(lds);                      // [wk][wm][g][r][lane]
+  if (wave < 4) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[(((wk * 2 + wm) * 4 + g) * 4 + r) * 64 + lane] = acc[g][r];
+      for (int r = 0; r < 4; ++r) red[(((wk * 2 + wm) * 4 + g) * 4 + r) * 64 + lane] = acc[g][r];
+  }
   __syncthreads();
+  if (wave >= 4) return;
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr) {
     const int r = 2 * wk + rr;
@@ -300,6 +366,7 @@ __global__ void __launch_bounds__(256) lstm_step_fwd_fast(StepArgsF a) {
       p[g] = red[(((0 * 2 + wm) * 4 + g) * 4 + r) * 64 + lane] + red[(((1 * 2 + wm) * 4 + g) * 4 + r) * 64 + lane];
     cell_fwd_apply(d, a.lens != nullptr, rr == 0 ? in0 : in1, b, u, H, p[0], p[1], p[2], p[3]);
   }
+  VMMT_TS(7);
 }
 
 struct CellInB { float i, f, g, o, c, cp, dha, dcc, dhn, dcn; long long len; };
@@ -341,64 +408,139 @@ __device__ __forceinline__ void cell_bwd_apply(const StepDirB& d, bool has_lens,
   *dcc = dc * in.f;
 }
 
-__global__ void __launch_bounds__(256) lstm_step_bwd_fast(StepArgsB a) {
+// Backward: dh[32 x 16] = dgates_next[32 x 4H] W_hh^T[16 x 4H]^T, K = 4H in rounds of two chunks of KC (4H % KC == 0), then the
+// cell backward of step t.  LDS: 2 chunks x 48 rows.
+template <int KC, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) lstm_step_bwd_fast(StepArgsB a) {
+  using Cf = FastCfg<KC>;
+  constexpr int PITCH = Cf::PITCH, BUF = 48 * PITCH;
+  constexpr int NA = 32 / NW, NB = 16 / NW;      // rows of dgates_next / W_hh^T staged per wave and chunk
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const StepDirB& d = a.d[blockIdx.z];
   const int B = a.B, H = a.H, K = 4 * a.H;
-  const int m0 = blockIdx.x * 32, u0 = blockIdx.y * 32;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int mt = wave & 1, nt = wave >> 1;
-  const int u = u0 + nt * 16 + (lane & 15);
-  const int b0 = m0 + mt * 16 + (lane >> 4) * 4;
-  const bool uok = u < H;
-  CellInB in[4];
-  if (a.mode == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) in[r] = cell_bwd_load(d, a.lens, b0 + r, uok ? u : 0, H, B);
-  }
-  f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int m0 = blockIdx.x * 32, u0 = blockIdx.y * 16;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wm = wave & 1, wk = wave >> 1;
+  const int u = u0 + (lane & 15);
+  const int brow0 = m0 + wm * 16 + (lane >> 4) * 4 + 2 * wk;     // this wave finishes rows 2*wk, 2*wk+1 of its accumulator
+  VMMT_TS(0);
+  CellInB in0, in1;
+  f32x4_t acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (d.dgates_next) {
     const char* ap = reinterpret_cast<const char*>(d.dgates_next);
     const char* wp = reinterpret_cast<const char*>(d.w_hh_t);
-    constexpr int BUF = 64 * FAST_PITCH;                            // one K chunk: 32 dgates rows + 32 W_hh^T rows
-    for (int k0 = 0; k0 < K; k0 += 2 * FAST_KCH) {                  // two chunks per memory round trip
+    const int lane16 = lane * 16;
+    for (int k0 = 0; k0 < K; k0 += 2 * KC) {                       // two chunks per memory round trip
       if (k0 > 0) __syncthreads();
+      const bool two = k0 + KC < K;
+      if (lane16 < KC * 2) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int kk = k0 + c * FAST_KCH;
-        const int kc = min(FAST_KCH, K - kk);
-        if (kc <= 0) break;
-        stage_rows(lds + c * BUF, 0, 32, kc * 2, [&](int r) { int b = m0 + r; return b < B ? ap + ((long)b * d.ld_dgn + kk) * 2 : nullptr; },
-                   wave, 4, lane);
-        stage_rows(lds + c * BUF, 32, 32, kc * 2, [&](int r) { int uu = u0 + r; return uu < H ? wp + ((long)uu * d.ld_wt + kk) * 2 : nullptr; },
-                   wave, 4, lane);
-      }
-      __syncthreads();
+        for (int c = 0; c < 2; ++c) {
+          if (c == 1 && !two) break;
+          const int kk = k0 + c * KC;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int kk = k0 + c * FAST_KCH;
-        const int kc = min(FAST_KCH, K - kk);
-        if (kc <= 0) break;
-        const char* arow = lds + c * BUF + (mt * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
-        const char* brow = lds + c * BUF + (32 + nt * 16 + (lane & 15)) * FAST_PITCH + (lane >> 4) * 16;
-        const int nks = kc / 32;
-#pragma unroll 4
-        for (int ks = 0; ks < nks; ++ks) {
-          bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
-          bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + ks * 64);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+          for (int j = 0; j < NA; ++j) {
+            const int r = wave + NW * j, b = min(m0 + r, B - 1);
+            dma16(ap + ((long)b * d.ld_dgn + kk) * 2 + lane16, lds + c * BUF + r * PITCH);
+          }
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const int r = wave + NW * j;
+            dma16(wp + ((long)(u0 + r) * d.ld_wt + kk) * 2 + lane16, lds + c * BUF + (32 + r) * PITCH);
+          }
         }
       }
-    }
-  }
-  if (!uok) return;
+      if (k0 == 0 && a.mode == 0 && wave < 4) {
+        in0 = cell_bwd_load(d, a.lens, brow0, u, H, B);
+        in1 = cell_bwd_load(d, a.lens, brow0 + 1, u, H, B);
+      }
+      VMMT_TS(k0 == 0 ? 1 : 4);
+      __syncthreads();
+      VMMT_TS(k0 == 0 ? 2 : 5);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int b = b0 + r;
-    if (b >= B) continue;
-    if (a.mode == 1) d.dh0_out[(long)b * d.ld_dh0 + u] = acc[r];
-    else cell_bwd_apply(d, a.lens != nullptr, in[r], b, u, H, acc[r]);
+      for (int c = 0; c < 2; ++c) {
+        if (c == 1 && !two) break;
+        const char* arow = lds + c * BUF + (wm * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
+        const char* brow = lds + c * BUF + (32 + (lane & 15)) * PITCH + (lane >> 4) * 16;
+        if (wave >= 4) {
+        } else if (wk == 0) {
+#pragma unroll
+          for (int ks = 0; ks < Cf::HALF; ++ks) {
+            f32x4_t& acc = (ks & 1) ? acc1 : acc0;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(arow + ks * 64),
+                                                          *reinterpret_cast<const bf16x8*>(brow + ks * 64), acc, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int ks = Cf::HALF; ks < Cf::NKS; ++ks) {
+            f32x4_t& acc = (ks & 1) ? acc1 : acc0;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(arow + ks * 64),
+                                                          *reinterpret_cast<const bf16x8*>(brow + ks * 64), acc, 0, 0, 0);
+          }
+        }
+      }
+      VMMT_TS(k0 == 0 ? 3 : 6);
+    }
+  } else if (a.mode == 0 && wave < 4) {
+    in0 = cell_bwd_load(d, a.lens, brow0, u, H, B);
+    in1 = cell_bwd_load(d, a.lens, brow0 + 1, u, H, B);
   }
+  // fold the two K halves through LDS
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);                      // [wk][wm][r][lane]
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wk * 2 + wm) * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
+  }
+  __syncthreads();
+  if (wave >= 4) return;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int r = 2 * wk + rr;
+    const int b = brow0 + rr;
+    if (b >= B) continue;
+    const float dh = red[((0 * 2 + wm) * 4 + r) * 64 + lane] + red[((1 * 2 + wm) * 4 + r) * 64 + lane];
+    if (a.mode == 1) d.dh0_out[(long)b * d.ld_dh0 + u] = dh;
+    else cell_bwd_apply(d, a.lens != nullptr, rr == 0 ? in0 : in1, b, u, H, dh);
+  }
+  VMMT_TS(7);
+}
+
+// largest chunk in {512, 256, 128, 64, 32} that divides K
+static int fast_chunk(int K) { for (int kc = 512; kc >= 32; kc >>= 1) if (K % kc == 0) return kc; return 0; }
+
+int g_lstm_variant = 1;   // tuning hook (tools/probe): 0 = 4 waves LDS-DMA, 1 = 8 waves LDS-DMA (default: -0.3..0.5 us per step), 2 / 3 = 4 / 8 waves register staging (forward only)
+
+template <int KC, int NW, bool REG>
+static int launch_fwd_fast_v(const StepArgsF& a, int ndir, hipStream_t st) {
+  size_t sm = (size_t)96 * FastCfg<KC>::PITCH;
+  if (sm < 8192) sm = 8192;                                         // the K-half fold needs 8 KiB
+  static bool attr_set = false;
+  if (!attr_set && sm > 64 * 1024) { (void)hipFuncSetAttribute((const void*)lstm_step_fwd_fast<KC, NW, REG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+  hipLaunchKernelGGL((lstm_step_fwd_fast<KC, NW, REG>), dim3((a.B + 31) / 32, a.H / 16, ndir), dim3(NW * 64), sm, st, a);
+  return check_launch();
+}
+template <int KC>
+static int launch_fwd_fast(const StepArgsF& a, int ndir, hipStream_t st) {
+  switch (g_lstm_variant) {
+    case 1: return launch_fwd_fast_v<KC, 8, false>(a, ndir, st);
+    case 2: return launch_fwd_fast_v<KC, 4, true>(a, ndir, st);
+    case 3: return launch_fwd_fast_v<KC, 8, true>(a, ndir, st);
+    default: return launch_fwd_fast_v<KC, 4, false>(a, ndir, st);
+  }
+}
+template <int KC, int NW>
+static int launch_bwd_fast_v(const StepArgsB& a, int ndir, hipStream_t st) {
+  size_t sm = (size_t)2 * 48 * FastCfg<KC>::PITCH;
+  if (sm < 4096) sm = 4096;
+  static bool attr_set = false;
+  if (!attr_set && sm > 64 * 1024) { (void)hipFuncSetAttribute((const void*)lstm_step_bwd_fast<KC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+  hipLaunchKernelGGL((lstm_step_bwd_fast<KC, NW>), dim3((a.B + 31) / 32, a.H / 16, ndir), dim3(NW * 64), sm, st, a);
+  return check_launch();
+}
+template <int KC>
+static int launch_bwd_fast(const StepArgsB& a, int ndir, hipStream_t st) {
+  return (g_lstm_variant & 1) ? launch_bwd_fast_v<KC, 8>(a, ndir, st) : launch_bwd_fast_v<KC, 4>(a, ndir, st);
 }
 
 static bool al16(const void* p, long ld_elems) { return (((uintptr_t)p) & 15) == 0 && (ld_elems * 2) % 16 == 0; }
@@ -421,6 +563,8 @@ static void fill_b(StepDirB& o, const vmmt_lstm_dir_bwd& i) {
 
 }  // namespace vmmt
 
+extern "C" int vmmt_lstm_set_variant(int v) { vmmt::g_lstm_variant = v; return VMMT_OK; }
+
 extern "C" int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* dirs, const int64_t* lens, int B,
                                   int H, void* stream) {
   using namespace vmmt;
@@ -437,11 +581,13 @@ extern "C" int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* 
     bool ok = true;
     for (int k = 0; k < ndir; ++k) ok = ok && al16(dirs[k].h_prev, dirs[k].ld_hprev) && al16(dirs[k].w_hh, dirs[k].ld_w);
     if (ok) {
-      static bool attr_set = false;
-      size_t sm = (size_t)96 * FAST_PITCH;
-      if (!attr_set) { hipFuncSetAttribute((const void*)lstm_step_fwd_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
-      hipLaunchKernelGGL(lstm_step_fwd_fast, dim3((B + 31) / 32, H / 16, ndir), dim3(256), sm, (hipStream_t)stream, a);
-      return check_launch();
+      switch (fast_chunk(H)) {
+        case 512: return launch_fwd_fast<512>(a, ndir, (hipStream_t)stream);
+        case 256: return launch_fwd_fast<256>(a, ndir, (hipStream_t)stream);
+        case 128: return launch_fwd_fast<128>(a, ndir, (hipStream_t)stream);
+        case 64: return launch_fwd_fast<64>(a, ndir, (hipStream_t)stream);
+        default: return launch_fwd_fast<32>(a, ndir, (hipStream_t)stream);
+      }
     }
   }
   dim3 grid((B + 63) / 64, (H + 31) / 32, ndir);
@@ -474,11 +620,11 @@ extern "C" int vmmt_lstm_step_bwd(int dtype, int ndir, const vmmt_lstm_dir_bwd* 
     for (int k = 0; k < ndir; ++k)
       ok = ok && (!dirs[k].dgates_next || (al16(dirs[k].dgates_next, dirs[k].ld_dgn) && al16(dirs[k].w_hh_t, dirs[k].ld_wt)));
     if (ok) {
-      static bool attr_set = false;
-      size_t sm = (size_t)128 * FAST_PITCH;
-      if (!attr_set) { hipFuncSetAttribute((const void*)lstm_step_bwd_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
-      hipLaunchKernelGGL(lstm_step_bwd_fast, dim3((B + 31) / 32, (H + 31) / 32, ndir), dim3(256), sm, (hipStream_t)stream, a);
-      return check_launch();
+      switch (fast_chunk(4 * H)) {
+        case 512: return launch_bwd_fast<512>(a, ndir, (hipStream_t)stream);
+        case 256: return launch_bwd_fast<256>(a, ndir, (hipStream_t)stream);
+        default: return launch_bwd_fast<128>(a, ndir, (hipStream_t)stream);
+      }
     }
   }
   dim3 grid((B + 63) / 64, (H + 63) / 64, ndir);

@@ -120,11 +120,13 @@ class Engine(object):
             lo_pri, hi_pri = max(pr), min(pr)
         except Exception:
             lo_pri, hi_pri = 0, 0
-        self.side_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        self.side_stream = self._side_stream_plain = torch.cuda.Stream(device=self.dev, priority=lo_pri)
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
         self.use_side_stream = True
+        self._masked_streams = []
+        self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
         self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
         self.bg_adam_blocks = 0      # grid cap of the background half of Adam (it has ~0.4 ms of slack under the encoder)
@@ -132,6 +134,18 @@ class Engine(object):
         self._sumsq_by_plan = False
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
         self._works = []
+
+    def set_side_cu_mask(self, mask_words):
+        """restrict the side stream to the CUs set in `mask_words` (list of 32-bit words, bit i = CU i); None restores the
+        unrestricted low-priority stream.  Keeps CUs free for the main stream's latency-critical kernels."""
+        if mask_words is None:
+            self.side_stream = self._side_stream_plain
+            return
+        arr = (C.c_uint32 * len(mask_words))(*[int(w) & 0xFFFFFFFF for w in mask_words])
+        out = C.c_void_p()
+        L.check(self.lib.vmmt_stream_create_masked(arr, len(mask_words), 0, C.byref(out)), "vmmt_stream_create_masked")
+        self._masked_streams.append(out.value)
+        self.side_stream = torch.cuda.ExternalStream(out.value, device=self.dev)
 
     # ------------------------------------------------------------------------------------------------ arena
     def _build_arena(self, seed, param_init):
@@ -315,7 +329,13 @@ class Engine(object):
         side = self.side_stream if self.use_side_stream else main
         ts = (main, side)
         hs = (main.cuda_stream, side.cuda_stream)
+        trace, last = self.trace, None
         for fn, args, name, _keep, sid in plan:
+            if trace is not None and sid == 0 and name != last:     # tools/phase_times.py: timing events at phase changes
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(main)
+                trace.append((name, ev))
+                last = name
             if fn is None:
                 if name == "SUMSQ":
                     lo, hi = args
