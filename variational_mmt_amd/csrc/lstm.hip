@@ -243,128 +243,95 @@ __device__ __forceinline__ void cell_fwd_apply(const StepDirF& d, bool has_lens,
   }
 }
 
-template <int KC> struct FastCfg {
-  static constexpr int PITCH = KC * 2 + 16;     // bytes per staged row
-  static constexpr int NKS = KC / 32;           // MFMA K steps per chunk
-  static constexpr int HALF = (NKS + 1) / 2;    // K steps of wave K-half 0
+// W_hh rows are staged UNPADDED (a 64-row x 1-KiB image is exactly 64 KiB, so a 64-KiB GEMM workgroup of the side stream
+// still fits beside a step workgroup on the same CU); bank conflicts of the fragment reads are removed by XOR-ing the
+// 16-byte chunk index with a row key, applied to the per-lane SOURCE address of the LDS-DMA and again to the reads.
+template <int KC> struct FwdCfg {
+  static constexpr int ROWB = KC * 2;                          // bytes per staged row
+  static constexpr int NCH = ROWB / 16;                        // 16-byte chunks per row
+  static constexpr int RPB = ROWB >= 256 ? 1 : 256 / ROWB;     // rows per 256-byte bank row
+  static constexpr int KMASK = (NCH < 16 ? NCH : 16) - 1;
+  static constexpr int LANES = NCH < 64 ? NCH : 64;            // active lanes of a row piece
+  static constexpr int NKS = KC / 32;                          // MFMA K steps per chunk
+  static constexpr int KQ = NKS >= 4 ? NKS / 4 : 1;            // K steps per wave (the 8 waves are 2 row halves x 4 K quarters)
+  static constexpr int LDS = 64 * ROWB > 32768 ? 64 * ROWB : 32768;   // >= the 32-KiB fold buffer
+  static __device__ __forceinline__ int key(int row) { return (row / RPB) & KMASK; }
 };
 
 // Forward: gates[32 x (4 x 16)] += h_prev[32 x H] W_hh[(4 x 16) x H]^T, K in chunks of KC (H % KC == 0).
-template <int KC, int NW = 4, bool REG = false>
-__global__ void __launch_bounds__(NW * 64) lstm_step_fwd_fast(StepArgsF a) {
-  using Cf = FastCfg<KC>;
-  constexpr int PITCH = Cf::PITCH;
-  constexpr int NA = 32 / NW, NB = 64 / NW;      // rows of h_prev / W_hh staged per wave
+// W_hh chunk: LDS-DMA (shared by the two row-half waves); h_prev: each wave needs a private 16-row x K-quarter slice, loaded
+// straight into MFMA A fragments (no LDS round trip, no sharing to exploit).
+template <int KC>
+__global__ void __launch_bounds__(512) lstm_step_fwd_fast(StepArgsF a) {
+  using Cf = FwdCfg<KC>;
+  constexpr int ROWB = Cf::ROWB, KQ = Cf::KQ;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const StepDirF& d = a.d[blockIdx.z];
   const int B = a.B, H = a.H;
   const int m0 = blockIdx.x * 32, u0 = blockIdx.y * 16;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wm = wave & 1, wk = wave >> 1;
-  const int u = u0 + (lane & 15);
-  // this wave finishes rows r = 2*wk, 2*wk+1 of its 16-row tile (both K halves are folded through LDS)
-  const int brow0 = m0 + wm * 16 + (lane >> 4) * 4 + 2 * wk;
+  const int n = lane & 15, kg = lane >> 4;
+  const int u = u0 + n;
+  const int brow = m0 + wm * 16 + kg * 4 + wk;                     // the accumulator row (register wk) this lane finishes
+  const bool kact = wk * KQ < Cf::NKS;
   VMMT_TS(0);
   f32x4_t acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const char* hp = reinterpret_cast<const char*>(d.h_prev);
   const char* wp = reinterpret_cast<const char*>(d.w_hh);
-  const int lane16 = lane * 16;
-  CellInF in0, in1;
+  const char* ap = reinterpret_cast<const char*>(d.h_prev) + ((long)min(m0 + wm * 16 + n, B - 1) * d.ld_hprev + kg * 8) * 2;
+  CellInF in;
   for (int k0 = 0; k0 < H; k0 += KC) {
     if (k0 > 0) __syncthreads();
-    if constexpr (!REG) {
-      if (lane16 < KC * 2) {
-        // rows wave, wave+NW, ...: rows of h_prev (clamped at the batch edge) and of W_hh (gate r>>4, unit u0 + (r & 15))
+    if (lane < Cf::LANES) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-          const int r = wave + NW * j, b = min(m0 + r, B - 1);
-          dma16(hp + ((long)b * d.ld_hprev + k0) * 2 + lane16, lds + r * PITCH);
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          const int r = wave + NW * j;
-          const long row = (long)(r >> 4) * H + u0 + (r & 15);
-          dma16(wp + (row * d.ld_w + k0) * 2 + lane16, lds + (32 + r) * PITCH);
-        }
-      }
-    } else {
-      // register staging: all loads in flight, then one ds_write pass
-      u32x4 va[NA], vb[NB];
-      const bool on = lane16 < KC * 2;
-#pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        const int r = wave + NW * j, b = min(m0 + r, B - 1);
-        if (on) va[j] = *reinterpret_cast<const u32x4*>(hp + ((long)b * d.ld_hprev + k0) * 2 + lane16);
-      }
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int r = wave + NW * j;
+      for (int j = 0; j < 8; ++j) {
+        const int r = wave + 8 * j;                                 // staged row: gate r >> 4, unit u0 + (r & 15)
         const long row = (long)(r >> 4) * H + u0 + (r & 15);
-        if (on) vb[j] = *reinterpret_cast<const u32x4*>(wp + (row * d.ld_w + k0) * 2 + lane16);
+        dma16(wp + (row * d.ld_w + k0) * 2 + ((lane ^ Cf::key(r)) * 16), lds + r * ROWB);
       }
-      if (k0 == 0 && wave < 4) {
-        in0 = cell_fwd_load(d, a.lens, brow0, u, H, B);
-        in1 = cell_fwd_load(d, a.lens, brow0 + 1, u, H, B);
-      }
-#pragma unroll
-      for (int j = 0; j < NA; ++j) if (on) *reinterpret_cast<u32x4*>(lds + (wave + NW * j) * PITCH + lane16) = va[j];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) if (on) *reinterpret_cast<u32x4*>(lds + (32 + wave + NW * j) * PITCH + lane16) = vb[j];
     }
-    if (!REG && k0 == 0 && wave < 4) {
-      in0 = cell_fwd_load(d, a.lens, brow0, u, H, B);
-      in1 = cell_fwd_load(d, a.lens, brow0 + 1, u, H, B);
+    u32x4 af[KQ];
+    if (kact) {
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) af[q] = *reinterpret_cast<const u32x4*>(ap + (long)(k0 + (wk * KQ + q) * 32) * 2);
     }
+    if (k0 == 0) in = cell_fwd_load(d, a.lens, brow, u, H, B);
     VMMT_TS(1);
     __syncthreads();                                                // hipcc drains vmcnt(0) here: all pieces landed
     VMMT_TS(2);
-    const char* arow = lds + (wm * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
-    const char* brow = lds + (32 + (lane & 15)) * PITCH + (lane >> 4) * 16;
-    if (wave >= 4) {
-    } else if (wk == 0) {
+    if (kact) {
 #pragma unroll
-      for (int ks = 0; ks < Cf::HALF; ++ks) {
-        bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
+      for (int q = 0; q < KQ; ++q) {
+        const int c = (wk * KQ + q) * 4 + kg;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, *reinterpret_cast<const bf16x8*>(brow + g * 16 * PITCH + ks * 64),
-                                                           acc[g], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int ks = Cf::HALF; ks < Cf::NKS; ++ks) {
-        bf16x8 av = *reinterpret_cast<const bf16x8*>(arow + ks * 64);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, *reinterpret_cast<const bf16x8*>(brow + g * 16 * PITCH + ks * 64),
-                                                           acc[g], 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+          const int row = g * 16 + n;
+          const bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + row * ROWB + ((c ^ Cf::key(row)) * 16));
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[q]), bv, acc[g], 0, 0, 0);
+        }
       }
     }
   }
-  // fold the two K halves through LDS: every wave publishes its partial tile, then finishes 2 of the 4 rows
+  // fold the four K quarters through LDS; every lane then finishes ONE (row, unit) cell
   VMMT_TS(3);
   __syncthreads();
-  float* red = reinterpret_cast<float*>(lds);                      // [wk][wm][g][r][lane]
-  if (wave < 4) {
+  float* red = reinterpret_cast<float*>(lds);                      // [wk][wm][g][reg][lane]
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(((wk * 2 + wm) * 4 + g) * 4 + r) * 64 + lane] = acc[g][r];
-  }
+    for (int r = 0; r < 4; ++r) red[(((wk * 2 + wm) * 4 + g) * 4 + r) * 64 + lane] = acc[g][r];
   __syncthreads();
-  if (wave >= 4) return;
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int r = 2 * wk + rr;
-    const int b = brow0 + rr;
-    if (b >= B) continue;
+  if (brow < B) {
     float p[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      p[g] = red[(((0 * 2 + wm) * 4 + g) * 4 + r) * 64 + lane] + red[(((1 * 2 + wm) * 4 + g) * 4 + r) * 64 + lane];
-    cell_fwd_apply(d, a.lens != nullptr, rr == 0 ? in0 : in1, b, u, H, p[0], p[1], p[2], p[3]);
+    for (int g = 0; g < 4; ++g) {
+      p[g] = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) p[g] += red[(((w * 2 + wm) * 4 + g) * 4 + wk) * 64 + lane];
+    }
+    cell_fwd_apply(d, a.lens != nullptr, in, brow, u, H, p[0], p[1], p[2], p[3]);
   }
   VMMT_TS(7);
 }
@@ -408,139 +375,102 @@ __device__ __forceinline__ void cell_bwd_apply(const StepDirB& d, bool has_lens,
   *dcc = dc * in.f;
 }
 
-// Backward: dh[32 x 16] = dgates_next[32 x 4H] W_hh^T[16 x 4H]^T, K = 4H in rounds of two chunks of KC (4H % KC == 0), then the
-// cell backward of step t.  LDS: 2 chunks x 48 rows.
-template <int KC, int NW = 4>
-__global__ void __launch_bounds__(NW * 64) lstm_step_bwd_fast(StepArgsB a) {
-  using Cf = FastCfg<KC>;
-  constexpr int PITCH = Cf::PITCH, BUF = 48 * PITCH;
-  constexpr int NA = 32 / NW, NB = 16 / NW;      // rows of dgates_next / W_hh^T staged per wave and chunk
+// Backward: dh[32 x 16] = dgates_next[32 x 4H] W_hh^T[16 x 4H]^T over K = 4H in rounds of KCB (one round up to H = 512), then
+// the cell backward of step t.  W_hh^T rows (16 x up to 4 KiB, unpadded + swizzled as above) by LDS-DMA; the dgates_next slice of a
+// wave (16 rows x a K quarter) straight into MFMA A fragments.
+template <int KCB> struct BwdCfg {
+  static constexpr int ROWB = KCB * 2;
+  static constexpr int PPR = ROWB >= 1024 ? ROWB / 1024 : 1;   // 1-KiB pieces per row
+  static constexpr int LANES = ROWB >= 1024 ? 64 : ROWB / 16;
+  static constexpr int PER = (16 * PPR + 7) / 8;               // pieces per wave
+  static constexpr int NKS = KCB / 32, KQ = NKS / 4;           // KCB >= 128
+  static constexpr int LDS = 16 * ROWB > 8192 ? 16 * ROWB : 8192;
+};
+
+template <int KCB>
+__global__ void __launch_bounds__(512) lstm_step_bwd_fast(StepArgsB a) {
+  using Cf = BwdCfg<KCB>;
+  constexpr int ROWB = Cf::ROWB, KQ = Cf::KQ, PPR = Cf::PPR;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const StepDirB& d = a.d[blockIdx.z];
   const int B = a.B, H = a.H, K = 4 * a.H;
   const int m0 = blockIdx.x * 32, u0 = blockIdx.y * 16;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wm = wave & 1, wk = wave >> 1;
-  const int u = u0 + (lane & 15);
-  const int brow0 = m0 + wm * 16 + (lane >> 4) * 4 + 2 * wk;     // this wave finishes rows 2*wk, 2*wk+1 of its accumulator
+  const int n = lane & 15, kg = lane >> 4;
+  const int u = u0 + n;
+  const int brow = m0 + wm * 16 + kg * 4 + wk;
   VMMT_TS(0);
-  CellInB in0, in1;
+  CellInB in;
   f32x4_t acc0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (d.dgates_next) {
-    const char* ap = reinterpret_cast<const char*>(d.dgates_next);
     const char* wp = reinterpret_cast<const char*>(d.w_hh_t);
-    const int lane16 = lane * 16;
-    for (int k0 = 0; k0 < K; k0 += 2 * KC) {                       // two chunks per memory round trip
+    const char* ap = reinterpret_cast<const char*>(d.dgates_next) + ((long)min(m0 + wm * 16 + n, B - 1) * d.ld_dgn + kg * 8) * 2;
+    for (int k0 = 0; k0 < K; k0 += KCB) {
       if (k0 > 0) __syncthreads();
-      const bool two = k0 + KC < K;
-      if (lane16 < KC * 2) {
+      if (lane < Cf::LANES) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          if (c == 1 && !two) break;
-          const int kk = k0 + c * KC;
-#pragma unroll
-          for (int j = 0; j < NA; ++j) {
-            const int r = wave + NW * j, b = min(m0 + r, B - 1);
-            dma16(ap + ((long)b * d.ld_dgn + kk) * 2 + lane16, lds + c * BUF + r * PITCH);
-          }
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            const int r = wave + NW * j;
-            dma16(wp + ((long)(u0 + r) * d.ld_wt + kk) * 2 + lane16, lds + c * BUF + (32 + r) * PITCH);
+        for (int j = 0; j < Cf::PER; ++j) {
+          const int p = wave + 8 * j;
+          if (p < 16 * PPR) {
+            const int r = p / PPR, sg = p % PPR;
+            dma16(wp + ((long)(u0 + r) * d.ld_wt + k0) * 2 + sg * 1024 + ((lane ^ (r & 15)) * 16), lds + r * ROWB + sg * 1024);
           }
         }
       }
-      if (k0 == 0 && a.mode == 0 && wave < 4) {
-        in0 = cell_bwd_load(d, a.lens, brow0, u, H, B);
-        in1 = cell_bwd_load(d, a.lens, brow0 + 1, u, H, B);
-      }
-      VMMT_TS(k0 == 0 ? 1 : 4);
+      u32x4 af[KQ];
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) af[q] = *reinterpret_cast<const u32x4*>(ap + (long)(k0 + (wk * KQ + q) * 32) * 2);
+      if (k0 == 0 && a.mode == 0) in = cell_bwd_load(d, a.lens, brow, u, H, B);
+      VMMT_TS(1);
       __syncthreads();
-      VMMT_TS(k0 == 0 ? 2 : 5);
+      VMMT_TS(2);
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (c == 1 && !two) break;
-        const char* arow = lds + c * BUF + (wm * 16 + (lane & 15)) * PITCH + (lane >> 4) * 16;
-        const char* brow = lds + c * BUF + (32 + (lane & 15)) * PITCH + (lane >> 4) * 16;
-        if (wave >= 4) {
-        } else if (wk == 0) {
-#pragma unroll
-          for (int ks = 0; ks < Cf::HALF; ++ks) {
-            f32x4_t& acc = (ks & 1) ? acc1 : acc0;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(arow + ks * 64),
-                                                          *reinterpret_cast<const bf16x8*>(brow + ks * 64), acc, 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int ks = Cf::HALF; ks < Cf::NKS; ++ks) {
-            f32x4_t& acc = (ks & 1) ? acc1 : acc0;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(arow + ks * 64),
-                                                          *reinterpret_cast<const bf16x8*>(brow + ks * 64), acc, 0, 0, 0);
-          }
-        }
+      for (int q = 0; q < KQ; ++q) {
+        const int c = (wk * KQ + q) * 4 + kg;
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + n * ROWB + ((c ^ n) * 16));
+        f32x4_t& acc = (q & 1) ? acc1 : acc0;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[q]), bv, acc, 0, 0, 0);
       }
-      VMMT_TS(k0 == 0 ? 3 : 6);
+      VMMT_TS(3);
     }
-  } else if (a.mode == 0 && wave < 4) {
-    in0 = cell_bwd_load(d, a.lens, brow0, u, H, B);
-    in1 = cell_bwd_load(d, a.lens, brow0 + 1, u, H, B);
+  } else if (a.mode == 0) {
+    in = cell_bwd_load(d, a.lens, brow, u, H, B);
   }
-  // fold the two K halves through LDS
+  // fold the four K quarters through LDS; every lane then finishes ONE (row, unit) cell
   __syncthreads();
-  float* red = reinterpret_cast<float*>(lds);                      // [wk][wm][r][lane]
-  if (wave < 4) {
+  float* red = reinterpret_cast<float*>(lds);                      // [wk][wm][reg][lane]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[((wk * 2 + wm) * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
-  }
+  for (int r = 0; r < 4; ++r) red[((wk * 2 + wm) * 4 + r) * 64 + lane] = acc0[r] + acc1[r];
   __syncthreads();
-  if (wave >= 4) return;
+  if (brow < B) {
+    float dh = 0.f;
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int r = 2 * wk + rr;
-    const int b = brow0 + rr;
-    if (b >= B) continue;
-    const float dh = red[((0 * 2 + wm) * 4 + r) * 64 + lane] + red[((1 * 2 + wm) * 4 + r) * 64 + lane];
-    if (a.mode == 1) d.dh0_out[(long)b * d.ld_dh0 + u] = dh;
-    else cell_bwd_apply(d, a.lens != nullptr, rr == 0 ? in0 : in1, b, u, H, dh);
+    for (int w = 0; w < 4; ++w) dh += red[((w * 2 + wm) * 4 + wk) * 64 + lane];
+    if (a.mode == 1) d.dh0_out[(long)brow * d.ld_dh0 + u] = dh;
+    else cell_bwd_apply(d, a.lens != nullptr, in, brow, u, H, dh);
   }
   VMMT_TS(7);
 }
 
-// largest chunk in {512, 256, 128, 64, 32} that divides K
-static int fast_chunk(int K) { for (int kc = 512; kc >= 32; kc >>= 1) if (K % kc == 0) return kc; return 0; }
+// largest chunk in {kmax, kmax/2, ..., kmin} that divides K
+static int fast_chunk(int K, int kmax, int kmin) { for (int kc = kmax; kc >= kmin; kc >>= 1) if (K % kc == 0) return kc; return 0; }
 
-int g_lstm_variant = 1;   // tuning hook (tools/probe): 0 = 4 waves LDS-DMA, 1 = 8 waves LDS-DMA (default: -0.3..0.5 us per step), 2 / 3 = 4 / 8 waves register staging (forward only)
-
-template <int KC, int NW, bool REG>
-static int launch_fwd_fast_v(const StepArgsF& a, int ndir, hipStream_t st) {
-  size_t sm = (size_t)96 * FastCfg<KC>::PITCH;
-  if (sm < 8192) sm = 8192;                                         // the K-half fold needs 8 KiB
-  static bool attr_set = false;
-  if (!attr_set && sm > 64 * 1024) { (void)hipFuncSetAttribute((const void*)lstm_step_fwd_fast<KC, NW, REG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
-  hipLaunchKernelGGL((lstm_step_fwd_fast<KC, NW, REG>), dim3((a.B + 31) / 32, a.H / 16, ndir), dim3(NW * 64), sm, st, a);
-  return check_launch();
-}
 template <int KC>
 static int launch_fwd_fast(const StepArgsF& a, int ndir, hipStream_t st) {
-  switch (g_lstm_variant) {
-    case 1: return launch_fwd_fast_v<KC, 8, false>(a, ndir, st);
-    case 2: return launch_fwd_fast_v<KC, 4, true>(a, ndir, st);
-    case 3: return launch_fwd_fast_v<KC, 8, true>(a, ndir, st);
-    default: return launch_fwd_fast_v<KC, 4, false>(a, ndir, st);
-  }
-}
-template <int KC, int NW>
-static int launch_bwd_fast_v(const StepArgsB& a, int ndir, hipStream_t st) {
-  size_t sm = (size_t)2 * 48 * FastCfg<KC>::PITCH;
-  if (sm < 4096) sm = 4096;
+  constexpr int sm = FwdCfg<KC>::LDS;
   static bool attr_set = false;
-  if (!attr_set && sm > 64 * 1024) { (void)hipFuncSetAttribute((const void*)lstm_step_bwd_fast<KC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
-  hipLaunchKernelGGL((lstm_step_bwd_fast<KC, NW>), dim3((a.B + 31) / 32, a.H / 16, ndir), dim3(NW * 64), sm, st, a);
+  if (!attr_set && sm >= 64 * 1024) { (void)hipFuncSetAttribute((const void*)lstm_step_fwd_fast<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); attr_set = true; }
+  hipLaunchKernelGGL(lstm_step_fwd_fast<KC>, dim3((a.B + 31) / 32, a.H / 16, ndir), dim3(512), sm, st, a);
   return check_launch();
 }
-template <int KC>
+template <int KCB>
 static int launch_bwd_fast(const StepArgsB& a, int ndir, hipStream_t st) {
-  return (g_lstm_variant & 1) ? launch_bwd_fast_v<KC, 8>(a, ndir, st) : launch_bwd_fast_v<KC, 4>(a, ndir, st);
+  constexpr int sm = BwdCfg<KCB>::LDS;
+  static bool attr_set = false;
+  if (!attr_set && sm >= 64 * 1024) { (void)hipFuncSetAttribute((const void*)lstm_step_bwd_fast<KCB>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); attr_set = true; }
+  hipLaunchKernelGGL(lstm_step_bwd_fast<KCB>, dim3((a.B + 31) / 32, a.H / 16, ndir), dim3(512), sm, st, a);
+  return check_launch();
 }
 
 static bool al16(const void* p, long ld_elems) { return (((uintptr_t)p) & 15) == 0 && (ld_elems * 2) % 16 == 0; }
@@ -563,7 +493,7 @@ static void fill_b(StepDirB& o, const vmmt_lstm_dir_bwd& i) {
 
 }  // namespace vmmt
 
-extern "C" int vmmt_lstm_set_variant(int v) { vmmt::g_lstm_variant = v; return VMMT_OK; }
+extern "C" int vmmt_lstm_set_variant(int v) { (void)v; return VMMT_OK; }   // no variants at present
 
 extern "C" int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* dirs, const int64_t* lens, int B,
                                   int H, void* stream) {
@@ -581,7 +511,7 @@ extern "C" int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* 
     bool ok = true;
     for (int k = 0; k < ndir; ++k) ok = ok && al16(dirs[k].h_prev, dirs[k].ld_hprev) && al16(dirs[k].w_hh, dirs[k].ld_w);
     if (ok) {
-      switch (fast_chunk(H)) {
+      switch (fast_chunk(H, 512, 32)) {
         case 512: return launch_fwd_fast<512>(a, ndir, (hipStream_t)stream);
         case 256: return launch_fwd_fast<256>(a, ndir, (hipStream_t)stream);
         case 128: return launch_fwd_fast<128>(a, ndir, (hipStream_t)stream);
@@ -620,7 +550,9 @@ extern "C" int vmmt_lstm_step_bwd(int dtype, int ndir, const vmmt_lstm_dir_bwd* 
     for (int k = 0; k < ndir; ++k)
       ok = ok && (!dirs[k].dgates_next || (al16(dirs[k].dgates_next, dirs[k].ld_dgn) && al16(dirs[k].w_hh_t, dirs[k].ld_wt)));
     if (ok) {
-      switch (fast_chunk(4 * H)) {
+      switch (fast_chunk(4 * H, 2048, 128)) {
+        case 2048: return launch_bwd_fast<2048>(a, ndir, (hipStream_t)stream);
+        case 1024: return launch_bwd_fast<1024>(a, ndir, (hipStream_t)stream);
         case 512: return launch_bwd_fast<512>(a, ndir, (hipStream_t)stream);
         case 256: return launch_bwd_fast<256>(a, ndir, (hipStream_t)stream);
         default: return launch_bwd_fast<128>(a, ndir, (hipStream_t)stream);
