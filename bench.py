@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--breakdown", action="store_true", help="print a per-phase event-timing breakdown to stderr")
+    ap.add_argument("--no-side-stream", action="store_true", help="profiling aid: issue the whole step on one stream")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,6 +110,8 @@ def main():
     B, S, T = a.batch, 20, 21
     Tp = T - 1
     eng = Engine(d, dtype=a.dtype, device=dev, seed=0)
+    if a.no_side_stream:
+        eng.use_side_stream = False
     n_img = 29000
     gt = torch.Generator().manual_seed(11)
     eng.set_image_table(torch.rand(n_img, d.img, generator=gt))

@@ -35,6 +35,10 @@ extern "C" {
 #define VMMT_ACT_SOFTPLUS 3 /* nn.Softplus(beta=1, threshold=20): NormalVariationalEncoder.py:42 */
 #define VMMT_ACT_SIGMOID 4
 
+/* 128 x 128 tiles whose LDS request admits ONE workgroup per CU: for bulk GEMMs of a side stream that must leave room for
+ * the latency-critical kernels of another stream on every CU */
+#define VMMT_TILE_128_ONE_PER_CU 129
+
 #define VMMT_GEMM_NT 0 /* A[M][K] k-contiguous, B[N][K] k-contiguous   : y = x W^T (nn.Linear forward)        */
 #define VMMT_GEMM_TN 1 /* A stored [K][M], B stored [K][N]             : dW = dY^T X (reduction over tokens)   */
 #define VMMT_GEMM_NN 2 /* A[M][K] k-contiguous, B stored [K][N]        : dx = dY W                              */
@@ -70,7 +74,7 @@ typedef struct vmmt_gemm_args {
   const void* addend; int64_t ld_add; int add_rows; int add_is_T;
   int act; int out_f32; int accumulate; float alpha;
   const int64_t* scatter_ids; int pad_id;
-  int tile; /* 0 = auto, 64, 128 */
+  int tile; /* 0 = auto, 64, 128, VMMT_TILE_128_ONE_PER_CU */
   int split_k; /* > 1: the reduction is split over this many workgroups per tile which atomicAdd fp32 partial sums into C
                   (out_f32 = 1, act = NONE; C must hold zeros or a partial sum) -- for weight gradients dW = dY^T X whose
                   reduction runs over thousands of tokens while the output is small */

@@ -32,7 +32,7 @@ def bench(name, lay, M, N, K, variants, out_f32=1, split=0, rounds=7):
             res[v].append(s.elapsed_time(e) / 5 * 1e3)
     fl = 2.0 * M * N * K
     print("%-28s" % name, "  ".join("%d: %7.1f us (%5.0f TF)" % (v, sorted(t)[len(t)//2], fl / sorted(t)[len(t)//2] / 1e6) for v, t in res.items()))
-V = [128, 2566, 2567, 2568]
+V = [128, 2564, 3564, 3565, 3284, 2567]
 bench("dWg NN 30000x512x5120", L.GEMM_NN, 30000, 512, 5120, V)
 bench("dO  TN 5120x512x30000 s6", L.GEMM_TN, 5120, 512, 30000, V, split=6)
 bench("gx  NT 5120x2048x512", L.GEMM_NT, 5120, 2048, 512, V, out_f32=1)

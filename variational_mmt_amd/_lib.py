@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvmmt.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SOFTPLUS, ACT_SIGMOID = 0, 1, 2, 3, 4
 GEMM_NT, GEMM_TN, GEMM_NN = 0, 1, 2
+TILE_128_ONE_PER_CU = 129
 (STAT_NLL, STAT_NWORDS, STAT_NCORRECT, STAT_KL_SUM, STAT_IMG_LOGPROB, STAT_IMG_COS, STAT_GRAD_SUMSQ) = range(7)
 STAT_COUNT = 8
 

@@ -67,7 +67,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
   }
 }
 
-template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, bool GL = false>
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, int GL = 0>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int M, int N, int K, int a_kmod,
             int b_kmod, int tiles_n, int kper, GemmEpi epi) {
@@ -95,7 +95,9 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb
   LinearMap amap{m0, M}, bmap{n0, N};
   const int kbeg = blockIdx.y * kper;                 // split-K: this block reduces over [kbeg, kend)
   const int kend = min(K, kbeg + kper);
-  if constexpr (GL) {   // LDS-DMA main loop (glds_gemm.hpp); preconditions checked by launch_layout
+  if constexpr (GL == 3) {   // LDS-DMA main loops (glds_gemm.hpp); preconditions checked by launch_layout
+    gemm_mainloop_glds3<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
+  } else if constexpr (GL == 1) {
     gemm_mainloop_glds<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
   } else {
     gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ, LinearMap, LinearMap, DB>(A, lda, amap, B, ldb, bmap, kend, a_kmod,
@@ -105,15 +107,16 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb
   gemm_epilogue<T, TI, TJ>(epi, acc, aoff, boff, m0, n0, M, N, lane);
 }
 
-template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, bool GL = false>
-static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, int GL = 0>
+static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st, size_t lds_min = 0) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
-  size_t smem = GL ? (size_t)glds_smem_bytes<BM, BN>() : gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
+  size_t smem = GL == 3 ? (size_t)glds3_smem_bytes<BM, BN>() : GL ? (size_t)glds_smem_bytes<BM, BN>() : gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
+  if (smem < lds_min) smem = lds_min;          // occupancy cap by LDS request (VMMT_TILE_128_ONE_PER_CU)
   if (smem > 64 * 1024) {
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB, GL>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); done = true; }
+    static size_t allowed = 0;
+    if (smem > allowed) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB, GL>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); allowed = smem; }
   }
   int splits = epi.atomic ? a->split_k : 1;
   if (splits < 1) splits = 1;
@@ -141,23 +144,33 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
     // LDS-DMA main loop: 16-byte aligned operands, K in whole 64-slabs, no k-modulus
     const bool gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
                        ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
-    if (a->tile == 1284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
-    if (a->tile == 2564 && gl_ok) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
-    if (a->tile == 2565 && gl_ok) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
-    if (a->tile == 2566 && gl_ok) return launch_cfg<T, 256, 128, 128, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
-    if (a->tile == 2567 && gl_ok) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
-    if (a->tile == 2568 && gl_ok) return launch_cfg<T, 128, 256, 64, 128, A_KC, B_KC, 64, true, true>(a, epi, st);
+    if (a->tile == 1284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
+    if (a->tile == 2564 && gl_ok) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
+    if (a->tile == 2565 && gl_ok) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
+    if (a->tile == 2566 && gl_ok) return launch_cfg<T, 256, 128, 128, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
+    if (a->tile == 2567 && gl_ok) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
+    if (a->tile == 3564 && gl_ok) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
+    if (a->tile == 3565 && gl_ok) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
+    if (a->tile == 3284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
+    if (a->tile == 2568 && gl_ok) return launch_cfg<T, 128, 256, 64, 128, A_KC, B_KC, 64, true, 1>(a, epi, st);
   }
-  if (a->tile == 128 || (a->tile == 0 && t128 >= 192)) {
+  if (a->tile == 128 || a->tile == VMMT_TILE_128_ONE_PER_CU || (a->tile == 0 && t128 >= 192)) {
+    // ONE_PER_CU: an 88-KiB LDS request admits one workgroup per CU (2 x 88 > 160 KiB) and leaves 72 KiB plus half of the
+    // registers for a 64-KiB workgroup of another stream (the LSTM step kernels of the critical path)
+    const size_t lds_min = a->tile == VMMT_TILE_128_ONE_PER_CU ? 88 * 1024 : 0;
     // bf16: BK = 64 (each row contributes a full 128-byte line per slab) + two LDS buffers: +30 % over BK = 32 on the
     // long-K gradient GEMMs (tools/gemm_ab.py, interleaved in one process)
     if constexpr (sizeof(T) == 2) {
       // LDS-DMA main loop when its preconditions hold (+10..15 % over the register-staged loop, tools/gemm_ab.py)
       const bool gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
                          ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
-      if (gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, true>(a, epi, st);
-      return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st);
-    } else return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st);
+      // large problems: 256 x 128 tiles, 8 waves, three LDS stages with counted waits (two slabs in flight): +7..14 % over
+      // the two-stage 128 x 128 loop on the [30000 x 512 x 5120]-class products, equal or worse on small ones (tools/gemm_ab.py)
+      if (gl_ok && lds_min == 0 && a->tile == 0 && t128 >= 768 && a->K >= 512)
+        return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
+      if (gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st, lds_min);
+      return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st, lds_min);
+    } else return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st, lds_min);
   }
   return launch_cfg<T, 64, 64, 32, 32, A_KC, B_KC>(a, epi, st);
 }

@@ -35,7 +35,8 @@ template <class T> struct GenCfg {
   static constexpr int PP = 64 + 16 / sizeof(T);     // pitch (elements) of a wave's 64 x 64 output patch in LDS
 };
 
-// GL: 0 = register-staged main loop (any dtype / alignment), 1 = LDS-DMA main loop with one buffer, 2 = with two buffers
+// GL: 0 = register-staged main loop (any dtype / alignment); LDS-DMA main loops: 1 = one buffer, 2 = two buffers,
+// 3 = three buffers with counted waits (two slabs in flight across the barrier)
 template <class T, int MODE, int GL>
 __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
   using Cf = GenCfg<T>;
@@ -64,7 +65,10 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   LinearMap amap{v0, a.V}, bmap{m0, a.M};
-  if constexpr (GL != 0) {
+  if constexpr (GL == 3) {
+    gemm_mainloop_glds3<BMV, BNM, NT / 64, true, true, TI, TJ>((const bf16_t*)a.W, a.ldw, v0, a.V, (const bf16_t*)a.O, a.ldo, m0, a.M, 0,
+                                                              a.K, aoff, boff, acc, smem_raw);
+  } else if constexpr (GL != 0) {
     gemm_mainloop_glds<BMV, BNM, NT / 64, true, true, TI, TJ, GL == 2>((const bf16_t*)a.W, a.ldw, v0, a.V, (const bf16_t*)a.O, a.ldo,
                                                                      m0, a.M, 0, a.K, aoff, boff, acc, smem_raw);
   } else {
@@ -230,7 +234,7 @@ template <class T, int MODE, int GL>
 static int launch_gen_v(const GenArgs& a, hipStream_t st) {
   using Cf = GenCfg<T>;
   int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + Cf::BNM - 1) / Cf::BNM;
-  size_t sm = GL ? (size_t)glds_smem_bytes<Cf::BMV, Cf::BNM, GL == 2>()
+  size_t sm = GL == 3 ? (size_t)glds3_smem_bytes<Cf::BMV, Cf::BNM>() : GL ? (size_t)glds_smem_bytes<Cf::BMV, Cf::BNM, GL == 2>()
                  : gemm_smem_elems<T, Cf::BMV, Cf::BNM, Cf::BK, true, true, Cf::DB>() * sizeof(T);
   if (MODE == 1 && sm < (size_t)8 * 64 * Cf::PP * sizeof(T)) sm = (size_t)8 * 64 * Cf::PP * sizeof(T);
   if (sm > 64 * 1024) {
@@ -246,9 +250,10 @@ static int launch_gen(const GenArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     // LDS-DMA main loop: 16-byte aligned operands, K in whole 64-slabs (callers round K up over zero-padded rows)
     const bool ok = a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldo % 8 == 0 && ((((uintptr_t)a.W) | ((uintptr_t)a.O)) & 15) == 0;
-    int v = g_gen_variant < 0 ? 2 : g_gen_variant;   // two buffers: -13 % vs one buffer or register staging (tools/gen_ab.py)
+    int v = g_gen_variant < 0 ? 3 : g_gen_variant;   // three stages, counted waits: fastest (tools/gen_ab.py)
     if (ok && v == 1) return launch_gen_v<T, MODE, 1>(a, st);
     if (ok && v == 2) return launch_gen_v<T, MODE, 2>(a, st);
+    if (ok && v == 3) return launch_gen_v<T, MODE, 3>(a, st);
   }
   return launch_gen_v<T, MODE, 0>(a, st);
 }

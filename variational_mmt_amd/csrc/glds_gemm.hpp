@@ -185,4 +185,63 @@ __device__ __forceinline__ void gemm_mainloop_glds(const bf16_t* __restrict__ A,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Three-stage variant: two slabs stay in flight across the workgroup barrier.  `__syncthreads()` would drain them (an
+// LDS-DMA is a pending LDS write on the VM counter, so its fence emits vmcnt(0)); here every wave waits with a COUNTED
+// s_waitcnt for its own pieces of the slab that is needed next and the workgroup meets at a raw s_barrier.  One barrier per
+// slab: it also proves that every wave has finished the multiply of the previous slab, whose buffer is refilled right after.
+template <int N>
+__device__ __forceinline__ void glds_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN>
+constexpr int glds3_smem_bytes() { return 3 * (BM + BN) * GBK * 2; }
+
+template <int BM, int BN, int NW, bool A_KC, bool B_KC, int TI, int TJ>
+__device__ __forceinline__ void gemm_mainloop_glds3(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
+                                                    long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
+                                                    const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem) {
+  constexpr int ABYTES = BM * GBK * 2, BBYTES = BN * GBK * 2, BUF = ABYTES + BBYTES;
+  using GA = GldsOperand<BM, A_KC, NW>;
+  using GB = GldsOperand<BN, B_KC, NW>;
+  constexpr int PW = GA::PER + GB::PER;           // LDS-DMA instructions per wave and slab
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  GA ga;
+  GB gb;
+  ga.init(A, lda, m0, M, kbeg, wave, lane);
+  gb.init(B, ldb, n0, N, kbeg, wave, lane);
+  GldsFrag<A_KC, TI> fa;
+  GldsFrag<B_KC, TJ> fb;
+  fa.init(aoff, lane);
+  fb.init(boff, lane);
+  const int nslab = (kend - kbeg) / GBK;
+  if (nslab <= 0) return;
+  ga.issue(smem, wave);
+  gb.issue(smem + ABYTES, wave);
+  if (nslab > 1) {
+    ga.issue(smem + BUF, wave);
+    gb.issue(smem + BUF + ABYTES, wave);
+  }
+#define VMMT_GLDS3_STEP(CUR, NXT2)                                                                     \
+  {                                                                                                    \
+    if (s + 1 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();                                     \
+    __builtin_amdgcn_s_barrier();                                                                      \
+    if (s + 2 < nslab) {                                                                               \
+      ga.issue(smem + (NXT2) * BUF, wave);                                                             \
+      gb.issue(smem + (NXT2) * BUF + ABYTES, wave);                                                    \
+    }                                                                                                  \
+    glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem + (CUR) * BUF, smem + (CUR) * BUF + ABYTES, fa, fb, aoff, boff, acc); \
+    ++s;                                                                                               \
+  }
+  int s = 0;
+  while (s < nslab) {
+    VMMT_GLDS3_STEP(0, 2)
+    if (s >= nslab) break;
+    VMMT_GLDS3_STEP(1, 0)
+    if (s >= nslab) break;
+    VMMT_GLDS3_STEP(2, 1)
+  }
+#undef VMMT_GLDS3_STEP
+  __builtin_amdgcn_s_barrier();      // the staging buffers may be reused by the caller's epilogue
+}
+
 }  // namespace vmmt

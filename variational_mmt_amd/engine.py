@@ -126,6 +126,7 @@ class Engine(object):
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
         self.use_side_stream = True
         self._masked_streams = []
+        self.side_one_per_cu = False # see _gemm; measured slower (tools/percu_ab.py): a 128 x 128 GEMM at one workgroup per CU runs at half speed (plans are built per workspace: set before the first forward)
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
         self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
@@ -289,6 +290,12 @@ class Engine(object):
                 accumulate = 1          # gradients always ACCUMULATE into the arena (zeroed at the start of a step)
         if a_kmod == 0 and b_kmod == 0:
             K = _ru(K, KPAD)            # operands are Bufs: zero-padded to whole slabs (see Buf)
+        if self._sid == 1 and self.side_one_per_cu and tile == 0:
+            # bulk GEMMs of the side stream run underneath the LSTM step kernels of the main stream: one workgroup per CU, so
+            # that a step workgroup (64 KiB LDS, half of the registers) always finds room on every CU
+            t128 = ((M + 127) // 128) * ((N + 127) // 128) * max(1, split_k)
+            if t128 >= 192:
+                tile = L.TILE_128_ONE_PER_CU
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
                        add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k)
         plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
@@ -668,7 +675,7 @@ class Workspace(object):
         e._record(P, "GT")
         e._call(P, _memset, self.dO32.t)
         e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
-                split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))), tile=128)
+                split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))))
         # ================= side: image term + its network (z is detached: independent of the text path) =========
         e._sid = SIDE
         e._wait(P, "bwd_begin")
