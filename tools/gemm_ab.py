@@ -32,10 +32,15 @@ def bench(name, lay, M, N, K, variants, out_f32=1, split=0, rounds=7):
             res[v].append(s.elapsed_time(e) / 5 * 1e3)
     fl = 2.0 * M * N * K
     print("%-28s" % name, "  ".join("%d: %7.1f us (%5.0f TF)" % (v, sorted(t)[len(t)//2], fl / sorted(t)[len(t)//2] / 1e6) for v, t in res.items()))
-V = [128, 2564, 3564, 3565, 3284, 2567]
-bench("dWg NN 30000x512x5120", L.GEMM_NN, 30000, 512, 5120, V)
-bench("dO  TN 5120x512x30000 s6", L.GEMM_TN, 5120, 512, 30000, V, split=6)
-bench("gx  NT 5120x2048x512", L.GEMM_NT, 5120, 2048, 512, V, out_f32=1)
-bench("logits NT 30000x5120x512", L.GEMM_NT, 30000, 5120, 512, V, out_f32=0)
-bench("dWhh TN 2048x512x4864 s8", L.GEMM_TN, 2048, 512, 4864, V, split=8)
-bench("dcat NN 5120x1024x512", L.GEMM_NN, 5120, 1024, 512, V, out_f32=0)
+V = [64, 128]
+bench("q fc1 NT 256x256x512", L.GEMM_NT, 256, 256, 512, V, out_f32=0)
+bench("q fc2 NT 256x256x256", L.GEMM_NT, 256, 256, 256, V, out_f32=1)
+bench("h1v NT 256x2048x256", L.GEMM_NT, 256, 2048, 256, V, out_f32=0)
+bench("mu_v NT 256x2048x2048", L.GEMM_NT, 256, 2048, 2048, V, out_f32=1)
+bench("dh1v NN 256x2048x2048", L.GEMM_NN, 256, 2048, 2048, V, out_f32=0)
+bench("dzt NN 256x256x2048", L.GEMM_NN, 256, 256, 2048, V, out_f32=1)
+bench("emb NN 5120x512x2048", L.GEMM_NN, 5120, 512, 2048, V, out_f32=1)
+bench("dW2 TN 2048x2048x256", L.GEMM_TN, 2048, 2048, 256, V, out_f32=1)
+bench("dWq TN 256x512x256", L.GEMM_TN, 256, 512, 256, V, out_f32=1)
+bench("Q NT 5120x512x512", L.GEMM_NT, 5120, 512, 512, V, out_f32=0)
+bench("AH NT 5120x512x1024", L.GEMM_NT, 5120, 512, 1024, V, out_f32=0)

@@ -43,7 +43,19 @@ __global__ void colsum_kernel(const T* __restrict__ X, long ld, int R, int C, fl
   for (int e = 0; e < VEC; ++e) a[e] = 0.f;
   const bool vec = c0 + VEC <= C && ((((uintptr_t)X) & 15) == 0) && ((ld * (long)sizeof(T)) & 15) == 0;
   if (vec) {
-    for (int r = r0 + w; r < r1; r += 4) {
+    int r = r0 + w;
+    for (; r + 12 < r1; r += 16) {                       // four independent 16-byte loads in flight per lane
+      u32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const u32x4*>(X + (long)(r + 4 * q) * ld + c0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const T* e_ = reinterpret_cast<const T*>(&v[q]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] += to_f<T>(e_[e]);
+      }
+    }
+    for (; r < r1; r += 4) {
       u32x4 v = *reinterpret_cast<const u32x4*>(X + (long)r * ld + c0);
       const T* e_ = reinterpret_cast<const T*>(&v);
 #pragma unroll
@@ -330,8 +342,9 @@ extern "C" int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, f
   if (R == 0) return VMMT_OK;
   int vec = dtype == VMMT_F32 ? 4 : 8;
   int gx = (C + 64 * vec - 1) / (64 * vec);
-  int rpb = 128;
-  while (rpb < R && (long)gx * ((R + rpb - 1) / rpb) > 1024) rpb *= 2;
+  // the sum is latency-bound: as many workgroups as the matrix allows, but at most 64 row chunks (= atomic adds per column)
+  int rpb = 32;
+  while (rpb < R && ((R + rpb - 1) / rpb > 64 || (long)gx * ((R + rpb - 1) / rpb) > 2048)) rpb *= 2;
   dim3 grid(gx, (R + rpb - 1) / rpb);
   if (dtype == VMMT_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST, (const float*)X, (long)ld, R, C, out, out2, rpb);
   else if (dtype == VMMT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)X, (long)ld, R, C, out, out2, rpb);

@@ -154,20 +154,26 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
     if (a->tile == 3284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
     if (a->tile == 2568 && gl_ok) return launch_cfg<T, 128, 256, 64, 128, A_KC, B_KC, 64, true, 1>(a, epi, st);
   }
-  if (a->tile == 128 || a->tile == VMMT_TILE_128_ONE_PER_CU || (a->tile == 0 && t128 >= 192)) {
+  bool gl_ok = false;
+  if constexpr (sizeof(T) == 2)
+    gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
+            ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
+  // With the LDS-DMA loop a 128 x 128 workgroup retires a 64-deep slab in ~0.55 us against ~0.4 us per 32-deep slab of the
+  // 64 x 64 configuration, so for long reductions it is also the lower-LATENCY choice when there are fewer tiles than CUs
+  // (M = 256 products of the inference networks at K = 2048: 20 us instead of 26-32 us); below K = 1024 the 64 x 64
+  // configuration starts faster (tools/gemm_ab.py).
+  if (a->tile == 128 || a->tile == VMMT_TILE_128_ONE_PER_CU || (a->tile == 0 && (t128 >= 192 || (gl_ok && a->K >= 1024 && t128 >= 8)))) {
     // ONE_PER_CU: an 88-KiB LDS request admits one workgroup per CU (2 x 88 > 160 KiB) and leaves 72 KiB plus half of the
     // registers for a 64-KiB workgroup of another stream (the LSTM step kernels of the critical path)
     const size_t lds_min = a->tile == VMMT_TILE_128_ONE_PER_CU ? 88 * 1024 : 0;
     // bf16: BK = 64 (each row contributes a full 128-byte line per slab) + two LDS buffers: +30 % over BK = 32 on the
     // long-K gradient GEMMs (tools/gemm_ab.py, interleaved in one process)
     if constexpr (sizeof(T) == 2) {
-      // LDS-DMA main loop when its preconditions hold (+10..15 % over the register-staged loop, tools/gemm_ab.py)
-      const bool gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
-                         ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
       // large problems: 256 x 128 tiles, 8 waves, three LDS stages with counted waits (two slabs in flight): +7..14 % over
       // the two-stage 128 x 128 loop on the [30000 x 512 x 5120]-class products, equal or worse on small ones (tools/gemm_ab.py)
       if (gl_ok && lds_min == 0 && a->tile == 0 && t128 >= 768 && a->K >= 512)
         return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
+      // LDS-DMA main loop when its preconditions hold (+10..15 % over the register-staged loop, tools/gemm_ab.py)
       if (gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st, lds_min);
       return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st, lds_min);
     } else return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st, lds_min);

@@ -121,6 +121,9 @@ class Engine(object):
         except Exception:
             lo_pri, hi_pri = 0, 0
         self.side_stream = self._side_stream_plain = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        # third stream: the small, latency-bound backward of the image / q(z|x) networks, independent of the text path
+        self.aux_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        self.use_aux_stream = True
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
@@ -334,8 +337,9 @@ class Engine(object):
     def _run(self, plan, events=None):
         main = torch.cuda.current_stream(self.dev)
         side = self.side_stream if self.use_side_stream else main
-        ts = (main, side)
-        hs = (main.cuda_stream, side.cuda_stream)
+        aux = self.aux_stream if (self.use_side_stream and self.use_aux_stream) else side
+        ts = (main, side, aux)
+        hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream)
         trace, last = self.trace, None
         for fn, args, name, _keep, sid in plan:
             if trace is not None and sid == 0 and name != last:     # tools/phase_times.py: timing events at phase changes
@@ -375,7 +379,7 @@ class Engine(object):
                 if sid == 0 or side is main:
                     args[0].zero_()
                 else:
-                    with torch.cuda.stream(side):
+                    with torch.cuda.stream(ts[sid]):
                         args[0].zero_()
             else:
                 rc = fn(*args, hs[sid])
@@ -502,7 +506,8 @@ class Workspace(object):
         e._sid = SIDE
         e._wait(P, "fwd_begin")
         if training:
-            e._call(P, _memset, e.flat_g)
+            # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
+            e._call(P, _memset, e.flat_g[e.offsets["generator.0.bias"][0]:])
         self._mask_entries = getattr(self, "_mask_entries", {})
         if drop:
             # output dropout mask (VI_Model1.py:132): only needed after the decoder -> generated in the background
@@ -664,7 +669,7 @@ class Workspace(object):
         P = []
         drop = training_dropout and d.dropout > 0
         wg = e.sh["wg"]
-        MAIN, SIDE = 0, 1
+        MAIN, SIDE, AUX = 0, 1, 2
         e._sid = MAIN
         e._call(P, _memset, e._sumsq)
         e._record(P, "bwd_begin")
@@ -676,8 +681,8 @@ class Workspace(object):
         e._call(P, _memset, self.dO32.t)
         e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
                 split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))))
-        # ================= side: image term + its network (z is detached: independent of the text path) =========
-        e._sid = SIDE
+        # ================= aux: image term + its network (z is detached: independent of the text path) ==========
+        e._sid = AUX
         e._wait(P, "bwd_begin")
         e._call(P, lib.vmmt_image_loss, dt, self.mu_v.p(), self.mu_v.ld, self.img.p(), self.img.ld, B, D, inv_norm,
                 self.dmu_v.p(), self.dmu_v.ld, self.stats.data_ptr())
@@ -709,10 +714,12 @@ class Workspace(object):
                     Z, H, B, out_f32=1, split_k=-1)
             e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
         e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
-        # side: dWg = G^T O, db = rowsum(G^T)
+        e._record(P, "aux_done")
+        # side: dWg = G^T O, db = rowsum(G^T) as soon as G^T exists (underneath dO = G Wg of the main stream)
         e._sid = SIDE
+        e._wait(P, "bwd_begin")
         e._wait(P, "GT")
-        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1, split_k=-1)
+        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1)   # plain store
         e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
         e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
         # main: dropout + tanh backward, linear_out
@@ -800,6 +807,7 @@ class Workspace(object):
         # gradient norm of everything that is final by now (generator, attention, decoder, inference networks): off the
         # critical path, underneath the encoder chain
         e._sumsq_entry(P, "generator.0.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
+        e._wait(P, "aux_done")
         e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None)
         # ================= encoder LSTM backward (main) + its parameter gradients (side) ==========================
         dh_above = self.dctx
