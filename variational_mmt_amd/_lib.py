@@ -90,10 +90,10 @@ def lib():
     """Load libvmmt.so (once).  Raises if it is missing or lacks a declared symbol -- never falls back."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        if not os.path.exists(os.environ.get("VMMT_LIB_PATH", LIB_PATH)):
             raise RuntimeError("libvmmt.so not built (%s): run `python -m variational_mmt_amd.build`; "
                                "there is no CPU fallback" % LIB_PATH)
-        h = C.CDLL(LIB_PATH)
+        h = C.CDLL(os.environ.get("VMMT_LIB_PATH", LIB_PATH))      # override: experiment builds (tools/)
         for name, (res, args) in _SIGS.items():
             fn = getattr(h, name)          # AttributeError if the symbol is missing
             fn.restype = res

@@ -58,6 +58,9 @@ struct GldsOperand {
     step = KC ? (long)GBK * 2 : (long)GBK * ld * 2;
   }
   __device__ __forceinline__ void issue(char* lds, int wave) {
+#if defined(VMMT_EXP_NODMA)          // experiment: no operand traffic
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       char* dst = lds + (wave * PER + j) * 1024;                  // wave-uniform; hardware adds lane * 16
@@ -94,6 +97,10 @@ typedef short gs16x8 __attribute__((ext_vector_type(8)));
 
 template <bool KC, int NT_>
 __device__ __forceinline__ bf16x8 glds_frag(const char* img, const GldsFrag<KC, NT_>& f, const int (&toff)[NT_], int t, int ks) {
+#if defined(VMMT_EXP_NOREAD)         // experiment: no LDS fragment reads
+  gs16x8 c = {(short)ks, (short)t, 1, 2, 3, 4, 5, (short)f.off[0]};
+  return __builtin_bit_cast(bf16x8, c);
+#endif
   if constexpr (KC) {
     return *reinterpret_cast<const bf16x8*>(img + f.off[ks] + toff[t] * 128);
   } else {
@@ -127,8 +134,13 @@ __device__ __forceinline__ void glds_slab(const char* As, const char* Bs, const 
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int j = 0; j < TJ; ++j)
+      for (int j = 0; j < TJ; ++j) {
+#if defined(VMMT_EXP_NOMFMA)       // experiment: fragment reads only (results kept alive by a cheap xor into the accumulator)
+        acc[i][j][0] += __builtin_bit_cast(f32x4, a[ks & 1][i])[0] + __builtin_bit_cast(f32x4, b[ks & 1][j])[0];
+#else
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+#endif
+      }
   }
 }
 
