@@ -28,6 +28,9 @@ CASES = {
     "tiny_bi_l1":  (dict(vs=37, vt=41, emb=12, hid=16, z=8, layers=1, brnn=True), 5, 7, 9, False),
     "tiny_bi_l2":  (dict(vs=53, vt=47, emb=20, hid=24, z=12, layers=2, brnn=True), 6, 9, 8, False),
     "small_fixed": (dict(vs=211, vt=307, emb=40, hid=64, z=32, layers=1, brnn=True), 8, 10, 11, True),
+    # --conditional prior: p(z|x) = gen_net_global, q(z|x,y,v) = GlobalFullInferenceNetwork, encoder_tgt
+    "cond_bi_l1":  (dict(vs=37, vt=41, emb=12, hid=16, z=8, layers=1, brnn=True, conditional=True), 5, 7, 9, False),
+    "cond_uni_l2": (dict(vs=43, vt=39, emb=10, hid=12, z=6, layers=2, brnn=False, conditional=True), 6, 8, 7, False),
 }
 
 
@@ -36,7 +39,7 @@ def run_case(name, ck, B, S, T, fixed):
     c = O.Cfg(**ck)
     opt = RH.make_opt(src_word_vec_size=c.emb, tgt_word_vec_size=c.emb, rnn_size=c.hid, z_latent_dim=c.z,
                       enc_layers=c.layers, dec_layers=c.layers, encoder_type="brnn" if c.brnn else "rnn",
-                      dropout=0.0)
+                      dropout=0.0, conditional=bool(c.conditional))
     model, fields = RH.build_model(opt, c.vs, c.vt, seed=0)
     model.train()
     for k, v in model.named_parameters():          # large tensors: formula values (not stored in the fixture)
@@ -59,6 +62,8 @@ def run_case(name, ck, B, S, T, fixed):
     out["f_attn"] = attns["std"]
     out["f_mu"], out["f_sigma"] = attns["z_latent"][0].params()
     out["f_z"] = attns["z0_sample"][0]
+    if c.conditional:
+        out["f_mu_p"], out["f_sigma_p"] = attns["p_latent"][0].params()
     # NB: monolithic loss normalised p_v / img in place (H1) -> re-run the image net for the raw mean
     with torch.no_grad():
         out["f_mu_v"] = model.inf_net_image(out["f_z"], None, None)[0].params()[0]
@@ -91,7 +96,7 @@ def run_case(name, ck, B, S, T, fixed):
     arrs = {"in_" + k: v.numpy() for k, v in bt.items()}
     arrs.update({"p0_" + k: v.numpy() for k, v in sd.items()})
     arrs.update({k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()})
-    arrs["cfg"] = np.array([c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, int(c.brnn), B, S, T], dtype=np.int64)
+    arrs["cfg"] = np.array([c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, int(c.brnn), B, S, T, int(c.conditional)], dtype=np.int64)
     os.makedirs(OUT, exist_ok=True)
     # the image MLP's fc2 is 2048x2048 (x2, 33 MB): store fp16-exact-free? no -- keep fp32 but drop the dead
     # scale branch (never read by forward/loss; H6) to keep fixtures small

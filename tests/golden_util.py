@@ -8,12 +8,14 @@ from oracle import vi1_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["tiny_uni_l2", "tiny_bi_l1", "tiny_bi_l2", "small_fixed"]
+COND_CASES = ["cond_bi_l1", "cond_uni_l2"]          # --conditional prior
 
 
 def load(name, dtype=torch.float32):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    vs, vt, emb, hid, zd, img, layers, brnn, B, S, T = [int(x) for x in z["cfg"]]
-    c = O.Cfg(vs=vs, vt=vt, emb=emb, hid=hid, z=zd, img=img, layers=layers, brnn=bool(brnn))
+    vs, vt, emb, hid, zd, img, layers, brnn, B, S, T = [int(x) for x in z["cfg"][:11]]
+    cond = bool(z["cfg"][11]) if len(z["cfg"]) > 11 else False
+    c = O.Cfg(vs=vs, vt=vt, emb=emb, hid=hid, z=zd, img=img, layers=layers, brnn=bool(brnn), conditional=cond)
     p = {}
     for k, shp in O.param_shapes(c).items():
         if "p0_" + k in z.files:

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import vi1_oracle as O
-from tests.golden_util import CASES, load
+from tests.golden_util import CASES, COND_CASES, load
 
 
 def _close(a, b, rtol=2e-5, atol=2e-6, what=""):
@@ -17,11 +17,14 @@ def _close(a, b, rtol=2e-5, atol=2e-6, what=""):
     assert err <= tol, "%s: max abs err %.3e > %.3e" % (what, err, tol)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + COND_CASES)
 def test_forward_and_stats(name):
     c, p, bt, z, (B, S, T) = load(name)
     img = bt["table"][bt["indices"]]
-    r = O.forward(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], training=True)
+    r = O.forward(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], training=True, tgt_len=bt["tgt_len"])
+    if c.conditional:
+        _close(r["mu_p"], z["f_mu_p"], what="mu_p")
+        _close(r["sigma_p"], z["f_sigma_p"], what="sigma_p")
     _close(r["context"], z["f_context"], what="context")
     _close(r["enc_h_n"], z["f_enc_h"], what="h_n")
     _close(r["enc_c_n"], z["f_enc_c"], what="c_n")
@@ -42,13 +45,13 @@ def test_forward_and_stats(name):
     assert L["n_correct"] == int(z["s_n_correct"])
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + COND_CASES)
 def test_gradients_and_adam_step(name):
     """Reference training path (sharded loss, loss/B backward) == oracle autograd, image term semantic 'A'
     (the only one torch>=0.4 can differentiate in the reference, H1), then one clipped Adam step."""
     c, p, bt, z, (B, S, T) = load(name)
     img = bt["table"][bt["indices"]]
-    r, L, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], img_semantic="A")
+    r, L, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], img_semantic="A", tgt_len=bt["tgt_len"])
     _close(L["elbo"], z["t_elbo"], what="elbo(A)", rtol=1e-5)
     ref_keys = [k[2:] for k in z.files if k.startswith("g_")] + [k[6:] for k in z.files if k.startswith("big_g_")]
     assert sorted(ref_keys) == sorted(g.keys())
