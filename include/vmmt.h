@@ -201,6 +201,26 @@ int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float*
 int vmmt_latent_bwd(int dtype, const float* mu, const float* sigma, const float* kl_sum, float batch_global, float mult,
                     int use_freebits, float margin, float inv_norm, void* dmu, int64_t ld1, void* dpre, int64_t ld2, int B,
                     int Z, void* stream);
+/* ---- conditional-prior variant (--conditional) -------------------------------------------------
+ * p(z|x) = gen_net_global (onmt/Models.py:889), q(z|x,y,v) = GlobalFullInferenceNetwork
+ * (onmt/modules/NormalVariationalEncoder.py:164-228), KL between two diagonal Gaussians (onmt/VILoss.py:437-452).
+ * latent_cond_fwd: z = mu + sigma*eps (training) | mu_p (evaluation, Models.py:913); kl_b / stats[KL_SUM] as vmmt_latent_fwd.
+ * latent_cond_bwd: d/d(mu, pre-softplus scale) of q and of p of max(mult * KL_mean, margin) * inv_norm. */
+int vmmt_latent_cond_fwd(int dtype, const float* mu, const float* sigma, const float* mu_p, const float* sigma_p,
+                         const float* eps, float* z32, void* zT, int64_t ldz, float* kl_b, float* stats, int B, int Z,
+                         int training, void* stream);
+int vmmt_latent_cond_bwd(int dtype, const float* mu, const float* sigma, const float* mu_p, const float* sigma_p,
+                         const float* kl_sum, float batch_global, float mult, int use_freebits, float margin, float inv_norm,
+                         void* dmu, int64_t ld1, void* dpre, int64_t ld2, void* dmu_p, int64_t ld3, void* dpre_p, int64_t ld4,
+                         int B, int Z, void* stream);
+/* masked mean of BATCH-major rows (row b*T + t): the output of encoder_tgt, which the reference runs over the transposed
+ * target (Models.py:892-894, hazard H5); out[b] = mean_{t<len_b} x[b*T+t] (NormalVariationalEncoder.py:65-84) */
+int vmmt_masked_mean_bm(int dtype, const void* x, int64_t ldx, const int64_t* lens, void* out, int64_t ldo, int B, int T, int H,
+                        void* stream);
+/* backward of vmmt_masked_mean (batch_major = 0, rows s*B+b) / vmmt_masked_mean_bm (1): dx[row] (+)= s < len_b ? dh[b]/len_b : 0 */
+int vmmt_masked_mean_bwd(int dtype, const void* dh, int64_t lddh, const int64_t* lens, void* dx, int64_t lddx, int B, int S, int H,
+                         int batch_major, int accumulate, void* stream);
+
 /* image-network gate (modules/NormalVariationalEncoder.py:286-293) */
 int vmmt_gate_fwd(int dtype, const float* z, const float* w, const float* bias, float* g, void* zt, int64_t ldzt, int B,
                   int Z, void* stream);

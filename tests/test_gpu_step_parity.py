@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from oracle import vi1_oracle as O
-from tests.golden_util import CASES, load
+from tests.golden_util import CASES, COND_CASES, load
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +27,7 @@ TOL = {"f32": dict(act=2e-5, loss=2e-5, kl=2e-5, grad=2e-4, adam=2e-5),
 
 def _engine(c, p, dtype, dropout=0.0):
     from variational_mmt_amd.engine import Dims, Engine
-    d = Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, dropout)
+    d = Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, dropout, conditional=c.conditional)
     e = Engine(d, dtype=dtype, device="cuda", seed=1)
     e.load_state_dict(p)
     return e
@@ -112,6 +112,58 @@ def test_step_matches_oracle_and_reference(name, dtype):
                 # elements whose gradient is ~0 can still flip sign: compare where |g| is not tiny
                 m = g[k].abs() > 1e-3 * g[k].abs().max()
                 _cmp("adam " + k, e.params[k].cpu()[m], new[k][m], tol["adam"], False)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", COND_CASES)
+def test_conditional_step_matches_oracle_and_reference(name, dtype):
+    """--conditional prior: p(z|x), q(z|x,y,v), encoder_tgt over the transposed target (H5), two-Gaussian KL"""
+    c, p, bt, z, (B, S, T) = load(name)
+    tol = TOL[dtype]
+    e = _engine(c, p, dtype)
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"], tgt_len=bt["tgt_len"])
+    torch.cuda.synchronize()
+    img = bt["table"][bt["indices"]]
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], img_semantic="B", tgt_len=bt["tgt_len"])
+    H, Tp = c.hid, T - 1
+    tctx = ws.enct_out[-1].view().float().view(B, T, H).transpose(0, 1)          # rows b*T+t -> [T,B,H]
+    _cmp("tgt_context", tctx, r["tgt_context"], tol["act"], False)
+    _cmp("hy", ws.hq.view()[:, H:2 * H], r["hy"], tol["act"], False)
+    _cmp("mu_p", ws.mu_p.view(), r["mu_p"], tol["act"], False)
+    _cmp("sigma_p", ws.sigma_p.view(), r["sigma_p"], tol["act"], False)
+    _cmp("mu", ws.mu.view(), r["mu"], tol["act"] * 2, False)
+    _cmp("sigma", ws.sigma.view(), r["sigma"], tol["act"] * 2, False)
+    _cmp("ref mu_p", ws.mu_p.view(), z["f_mu_p"], tol["act"], False)
+    _cmp("ref mu", ws.mu.view(), z["f_mu"], tol["act"] * 2, False)
+    _cmp("ref out", ws.AH.view().float().view(Tp, B, H), z["f_out"], tol["act"], False)
+    e.loss_backward(ws, normalization=B)
+    torch.cuda.synchronize()
+    st = e.read_stats(ws)
+    for key, ref in (("nmt", "s_nmt_loss"), ("elbo", "s_elbo_loss")):
+        assert abs(st[key] - float(z[ref])) <= tol["loss"] * abs(float(z[ref])), (key, st[key], float(z[ref]))
+    assert abs(st["td_kl_before"] - float(Lo["kl_before"])) <= tol["kl"] * abs(float(Lo["kl_before"]))
+    assert abs(st["td_kl_before"] - float(z["s_td_kl_before"])) <= tol["kl"] * abs(float(z["s_td_kl_before"]))
+    assert sorted(g.keys()) == sorted(e.grads.keys())
+    bad = []
+    for k in g:
+        got, want = e.grads[k].detach().cpu().double(), g[k].double()
+        scale = max(want.abs().max().item(), 1e-12)
+        err = (got - want).abs().max().item()
+        if dtype == "bf16" and ("inf_net_image.location.fc1" in k or "gate_affine_transform" in k):
+            if (got - want).norm().item() > 0.15 * want.norm().item():
+                bad.append((k, "relL2", (got - want).norm().item() / want.norm().item()))
+        elif err > tol["grad"] * scale + 1e-9:
+            bad.append((k, err, scale))
+    assert not bad, bad
+    for k in g:      # text path + both latent networks + encoder_tgt also against the real reference
+        if "inf_net_image" in k or ("g_" + k) not in z.files:
+            continue
+        _cmp("ref grad " + k, e.grads[k], z["g_" + k], tol["grad"])
+    # evaluation mode: z = E[p(z|x)] (Models.py:913)
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=False, tgt_len=bt["tgt_len"])
+    torch.cuda.synchronize()
+    _cmp("eval z = mu_p", ws.z32.view(), r["mu_p"], tol["act"] * 2, False)
 
 
 @pytest.mark.parametrize("dtype", ["f32"])

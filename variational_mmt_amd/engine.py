@@ -28,9 +28,13 @@ PAD = 1  # '<blank>' (onmt/io/DatasetBase.py:7-11)
 
 
 class Dims(object):
-    def __init__(self, vs, vt, emb=500, hid=500, z=500, img=2048, layers=2, brnn=False, dropout=0.0):
+    def __init__(self, vs, vt, emb=500, hid=500, z=500, img=2048, layers=2, brnn=False, dropout=0.0, conditional=False):
         self.vs, self.vt, self.emb, self.hid, self.z, self.img = vs, vt, emb, hid, z, img
         self.layers, self.brnn, self.dropout = layers, bool(brnn), float(dropout)
+        self.conditional = bool(conditional)       # --conditional prior (ModelConstructor.py:435-460)
+        self.ht = hid // 2                          # encoder_tgt is always bidirectional (ModelConstructor.py:456-457)
+        self.qin = 2 * hid + img if conditional else hid
+        assert not conditional or hid % 2 == 0
         self.dirs = 2 if brnn else 1
         assert hid % self.dirs == 0
         self.hd = hid // self.dirs
@@ -55,12 +59,23 @@ class Dims(object):
                       ("encoder.rnn.bias_ih_l%d%s" % (l, suf), (4 * d.hd,)),
                       ("encoder.rnn.bias_hh_l%d%s" % (l, suf), (4 * d.hd,))]
         s += [("encoder.embeddings.make_embedding.emb_luts.0.weight", (d.vs, d.emb))]
+        if d.conditional:
+            for br in ("location", "scale"):       # p(z|x)
+                s += [("gen_net_global.%s.fc2.weight" % br, (d.z, d.z)), ("gen_net_global.%s.fc2.bias" % br, (d.z,)),
+                      ("gen_net_global.%s.fc1.weight" % br, (d.z, d.hid)), ("gen_net_global.%s.fc1.bias" % br, (d.z,))]
+            for l in reversed(range(d.layers)):    # encoder_tgt (shares the decoder's embedding table)
+                i = d.emb if l == 0 else d.hid
+                for suf in ("", "_reverse"):
+                    s += [("encoder_tgt.rnn.weight_ih_l%d%s" % (l, suf), (4 * d.ht, i)),
+                          ("encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf), (4 * d.ht, d.ht)),
+                          ("encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf), (4 * d.ht,)),
+                          ("encoder_tgt.rnn.bias_hh_l%d%s" % (l, suf), (4 * d.ht,))]
         s += [("inf_net_image.location.fc2.weight", (d.img, d.img)), ("inf_net_image.location.fc2.bias", (d.img,)),
               ("inf_net_image.location.fc1.weight", (d.img, d.z)), ("inf_net_image.location.fc1.bias", (d.img,)),
               ("inf_net_image.gate_affine_transform.weight", (1, d.z)), ("inf_net_image.gate_affine_transform.bias", (1,))]
         for br in ("location", "scale"):
             s += [("inf_net_global.%s.fc2.weight" % br, (d.z, d.z)), ("inf_net_global.%s.fc2.bias" % br, (d.z,)),
-                  ("inf_net_global.%s.fc1.weight" % br, (d.z, d.hid)), ("inf_net_global.%s.fc1.bias" % br, (d.z,))]
+                  ("inf_net_global.%s.fc1.weight" % br, (d.z, d.qin)), ("inf_net_global.%s.fc1.bias" % br, (d.z,))]
         nograd = [("inf_net_image.scale.fc1.weight", (d.img, d.z)), ("inf_net_image.scale.fc1.bias", (d.img,)),
                   ("inf_net_image.scale.fc2.weight", (d.img, d.img)), ("inf_net_image.scale.fc2.bias", (d.img,))]
         return s, nograd
@@ -197,7 +212,10 @@ class Engine(object):
         self.shadows_dirty = True
 
     def state_dict(self):
-        return {n: v.detach().clone() for n, v in self.params.items()}
+        sd = {n: v.detach().clone() for n, v in self.params.items()}
+        if self.d.conditional:      # encoder_tgt shares the decoder's table; the reference's state dict lists it under both names
+            sd["encoder_tgt.embeddings.make_embedding.emb_luts.0.weight"] = sd["decoder.embeddings.make_embedding.emb_luts.0.weight"]
+        return sd
 
     # ------------------------------------------------------------------------------------------------ shadows
     def _build_shadows(self):
@@ -244,8 +262,22 @@ class Engine(object):
         shadow("wa", d.hid, d.hid, "decoder.attn.linear_in.weight")
         shadow("wo", d.hid, 2 * d.hid, "decoder.attn.linear_out.weight")
         for br in ("location", "scale"):
-            shadow("q_%s_w1" % br, d.z, d.hid, "inf_net_global.%s.fc1.weight" % br)
+            shadow("q_%s_w1" % br, d.z, d.qin, "inf_net_global.%s.fc1.weight" % br)
             shadow("q_%s_w2" % br, d.z, d.z, "inf_net_global.%s.fc2.weight" % br)
+        if d.conditional:
+            for br in ("location", "scale"):
+                shadow("p_%s_w1" % br, d.z, d.hid, "gen_net_global.%s.fc1.weight" % br)
+                shadow("p_%s_w2" % br, d.z, d.z, "gen_net_global.%s.fc2.weight" % br)
+            for l in range(d.layers):
+                i = d.emb if l == 0 else d.hid
+                for k, suf in enumerate(("", "_reverse")):
+                    shadow("enct_wih_l%d" % l, 2 * 4 * d.ht, i, "encoder_tgt.rnn.weight_ih_l%d%s" % (l, suf), row_off=k * 4 * d.ht)
+                    shadow("enct_b_l%d" % l, 1, 2 * 4 * d.ht, "encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf), dtype=torch.float32,
+                           src2="encoder_tgt.rnn.bias_hh_l%d%s" % (l, suf))
+                    code, sp, s2, lds, dst, ldd, R, Cc, tr = self.pack_calls[-1]
+                    self.pack_calls[-1] = (code, sp, s2, lds, self.sh["enct_b_l%d" % l].p(0, k * 4 * d.ht), ldd, R, Cc, tr)
+                    shadow("enct_whh_l%d_d%d" % (l, k), 4 * d.ht, d.ht, "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf))
+                    shadow("enct_whhT_l%d_d%d" % (l, k), d.ht, 4 * d.ht, "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf), transpose=True)
         shadow("iv_w1", d.img, d.z, "inf_net_image.location.fc1.weight")
         shadow("iv_w2", d.img, d.img, "inf_net_image.location.fc2.weight")
         shadow("wg", d.vt, d.hid, "generator.0.weight")
@@ -481,6 +513,8 @@ class Workspace(object):
         self.dmu_v = nb(B, D)
         self.dh1v = nb(B, D)
         self.dzt = nb(B, Z, f32)
+        if d.conditional:
+            self._cond_alloc()
         self._keep = []
         self.events = {}
         self.plan_fwd_train = self._plan_forward(True)
@@ -505,6 +539,7 @@ class Workspace(object):
         #      runs on the side stream), target embeddings and the time-parallel part of the decoder input projection
         e._sid = SIDE
         e._wait(P, "fwd_begin")
+        e._record(P, "side_fwd")
         if training:
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             e._call(P, _memset, e.flat_g[e.offsets["generator.0.bias"][0]:])
@@ -569,17 +604,24 @@ class Workspace(object):
                         self.enc_xdrop[l].p(), self.enc_xdrop[l].ld, MS, H)
                 x = self.enc_xdrop[l]
         ctx = self.enc_out[Lyr - 1]
+        if d.conditional:
+            self._cond_forward(P, training, ctx)
         # a4 q(z|x): masked mean of the detached memory, two 2-layer MLPs
-        e._call(P, lib.vmmt_masked_mean, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.hbar.p(), self.hbar.ld, B, S, H)
-        for br, outb, act in (("location", self.mu, L.ACT_NONE), ("scale", self.sigma, L.ACT_SOFTPLUS)):
+        if not d.conditional:
+            e._call(P, lib.vmmt_masked_mean, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.hbar.p(), self.hbar.ld, B, S, H)
+        for br, outb, act in (() if d.conditional else (("location", self.mu, L.ACT_NONE), ("scale", self.sigma, L.ACT_SOFTPLUS))):
             w1, w2 = e.sh["q_%s_w1" % br], e.sh["q_%s_w2" % br]
             e._gemm(P, L.GEMM_NT, self.hbar.p(), self.hbar.ld, w1.p(), w1.ld, self.q_h1[br].p(), self.q_h1[br].ld, B, Z, H,
                     addend=e.pp("inf_net_global.%s.fc1.bias" % br), ld_add=Z, add_rows=1, act=L.ACT_RELU)
             e._gemm(P, L.GEMM_NT, self.q_h1[br].p(), self.q_h1[br].ld, w2.p(), w2.ld, outb.p(), outb.ld, B, Z, Z,
                     addend=e.pp("inf_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
         # a5 fused mu/sigma -> sample -> KL
-        e._call(P, lib.vmmt_latent_fwd, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
-                self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
+        if d.conditional:
+            e._call(P, lib.vmmt_latent_cond_fwd, dt, self.mu.p(), self.sigma.p(), self.mu_p.p(), self.sigma_p.p(), self.eps.p(),
+                    self.z32.p(), self.zT.p(), self.zT.ld, self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
+        else:
+            e._call(P, lib.vmmt_latent_fwd, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
+                    self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
         # a8 image network (location branch only; the scale branch is dead, H6 / VILoss.py:321): side stream, under the decoder
         e._record(P, "z_ready")
         e._sid = SIDE
@@ -701,8 +743,13 @@ class Workspace(object):
                 e.gp("inf_net_image.gate_affine_transform.weight"), e.gp("inf_net_image.gate_affine_transform.bias"), B, Z)
         # --- KL term -> q(z|x) networks (mu, sigma receive gradient only through the KL: H2) ------------------
         self._latent_bwd_index = len(P)
-        e._call(P, lib.vmmt_latent_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
-        for br, dy in (("location", self.q_dmu), ("scale", self.q_dpre)):
+        if d.conditional:
+            e._call(P, lib.vmmt_latent_cond_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
+            self._cond_backward(P, drop)
+        else:
+            e._call(P, lib.vmmt_latent_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
+        qx = self.hq if d.conditional else self.hbar        # input of the q network's first layer
+        for i, (br, dy) in enumerate((("location", self.q_dmu), ("scale", self.q_dpre))):
             w2q = e.sh["q_%s_w2" % br]
             pre = "inf_net_global.%s" % br
             e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
@@ -710,9 +757,15 @@ class Workspace(object):
             e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2q.p(), w2q.ld, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, Z)
             e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.q_dh1[br].p(), self.q_dh1[br].ld, 0, self.q_h1[br].p(), self.q_h1[br].ld,
                     None, 0, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z)
-            e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, self.hbar.p(), self.hbar.ld, e.gp(pre + ".fc1.weight"), H,
-                    Z, H, B, out_f32=1, split_k=-1)
+            e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, qx.p(), qx.ld, e.gp(pre + ".fc1.weight"), d.qin,
+                    Z, d.qin, B, out_f32=1, split_k=-1)
             e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
+            if d.conditional:   # d h_y = d h_q[:, H:2H] (h_x is detached, v is data): columns [H, 2H) of W1
+                w1q = e.sh["q_%s_w1" % br]
+                e._gemm(P, L.GEMM_NN, self.q_dh1[br].p(), self.q_dh1[br].ld, w1q.p(0, H), w1q.ld, self.dhy.p(), self.dhy.ld, B, H, Z,
+                        accumulate=1 if i else 0)
+        if d.conditional:
+            self._cond_backward_tgt(P, drop)
         e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
         e._record(P, "aux_done")
         # side: dWg = G^T O, db = rowsum(G^T) as soon as G^T exists (underneath dO = G Wg of the main stream)
@@ -803,6 +856,8 @@ class Workspace(object):
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
         e._sid = SIDE
+        if d.conditional:
+            e._wait(P, "aux_done")      # encoder_tgt scatters into the (shared) target embedding gradient on the aux stream
         e._allreduce(P, "decoder.attn.linear_out.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
         # gradient norm of everything that is final by now (generator, attention, decoder, inference networks): off the
         # critical path, underneath the encoder chain
@@ -810,6 +865,11 @@ class Workspace(object):
         e._wait(P, "aux_done")
         e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None)
         # ================= encoder LSTM backward (main) + its parameter gradients (side) ==========================
+        if d.conditional:   # p(z|x) reads the NON-detached memory (Models.py:889): d context[s,b] += d hbar_p[b] / len_b
+            e._sid = MAIN
+            e._wait(P, "dhbar_p")
+            e._call(P, lib.vmmt_masked_mean_bwd, dt, self.dhbar_p.p(), self.dhbar_p.ld, self.src_len.data_ptr(), self.dctx.p(),
+                    self.dctx.ld, B, S, H, 0, 1)
         dh_above = self.dctx
         for l in reversed(range(Lyr)):
             e._sid = MAIN
@@ -887,7 +947,196 @@ class Workspace(object):
         e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
         return P
 
+    # ------------------------------------------------------------------------------- conditional-prior variant (8f-1)
+    def _cond_alloc(self):
+        """buffers of the conditional branch: p(z|x), q(z|x,y,v) input [h_x ; h_y ; v], encoder_tgt (rows b*T + t: the
+        reference runs it over the transposed target, so its recurrence walks the batch axis -- hazard H5)"""
+        e, d = self.e, self.e.d
+        T, dev = e.T, e.dev
+        f32, i64 = torch.float32, torch.int64
+        B, H, ht, E, Z, Lyr = self.B, d.hid, d.ht, d.emb, d.z, d.layers
+        Tn = self.Tp + 1
+        MT = B * Tn
+        self.Tn, self.MT = Tn, MT
+        nb = lambda r, c, dt=T, **kw: Buf(r, c, dt, dev, **kw)
+        self.tgt_bt = torch.zeros(MT, dtype=i64, device=dev)
+        self.tgt_len = torch.zeros(B, dtype=i64, device=dev)
+        self.Yt = nb(MT, E)
+        self.enct_gx = [nb(MT, 8 * ht, f32) for _ in range(Lyr)]
+        self.enct_gates = [nb(MT, 8 * ht) for _ in range(Lyr)]
+        self.enct_c = [nb(MT, H, f32) for _ in range(Lyr)]
+        self.enct_out = [nb(MT, H) for _ in range(Lyr)]
+        self.enct_mask = [nb(MT, H) if (d.dropout > 0 and l < Lyr - 1) else None for l in range(Lyr)]
+        self.enct_xdrop = [nb(MT, H) if (d.dropout > 0 and l < Lyr - 1) else None for l in range(Lyr)]
+        self.enct_hzero = nb(Tn, H)
+        self.hq = nb(B, d.qin)
+        self.mu_p = nb(B, Z, f32, ld=Z)
+        self.sigma_p = nb(B, Z, f32, ld=Z)
+        self.p_h1 = {br: nb(B, Z) for br in ("location", "scale")}
+        self.p_dmu = nb(B, Z)
+        self.p_dpre = nb(B, Z)
+        self.p_dh1 = {br: nb(B, Z) for br in ("location", "scale")}
+        self.dhbar_p = nb(B, H)
+        self.dhy = nb(B, H)
+        self.enct_dout = nb(MT, H)
+        self.enct_dgates = [nb(MT, 8 * ht) for _ in range(Lyr)]
+        self.enct_dcc = [nb(Tn, H, f32) for _ in range(Lyr)]
+        self.enct_dx = [nb(MT, H) for _ in range(Lyr - 1)]
+
+    def _cond_forward(self, P, training, ctx):
+        """aux stream: encoder_tgt over the transposed target (B recurrent steps with T rows each);
+        main stream: h_x, h_y, v -> p(z|x) and q(z|x,y,v)  (Models.py:883-914)"""
+        e, d, lib = self.e, self.e.d, self.e.lib
+        B, S, H, ht, E, Z, D, Lyr = self.B, self.S, d.hid, d.ht, d.emb, d.z, d.img, d.layers
+        Tn, MT = self.Tn, self.MT
+        dt = e.dt
+        drop = training and d.dropout > 0
+        MAIN, AUX = 0, 2
+        e._sid = AUX
+        e._wait(P, "fwd_begin")
+        e._wait(P, "side_fwd")           # the shared target embedding table is updated by the side half of Adam
+        e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                self.tgt_bt.data_ptr(), self.Yt.p(), self.Yt.ld, MT, E)
+        x, xcols = self.Yt, E
+        for l in range(Lyr):
+            wih, bsum = e.sh["enct_wih_l%d" % l], e.sh["enct_b_l%d" % l]
+            e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enct_gx[l].p(), self.enct_gx[l].ld, MT, 8 * ht, xcols,
+                    addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+            for step in range(B):
+                arr = (L.LstmDirFwd * 2)()
+                for k in range(2):
+                    t = step if k == 0 else B - 1 - step           # "time" = sentence index (H5)
+                    tp = (t - 1) if k == 0 else (t + 1)
+                    first = step == 0
+                    whh = e.sh["enct_whh_l%d_d%d" % (l, k)]
+                    a = arr[k]
+                    if first:
+                        a.h_prev, a.ld_hprev = self.enct_hzero.p(0, k * ht), self.enct_hzero.ld
+                    else:
+                        a.h_prev, a.ld_hprev = self.enct_out[l].p(tp * Tn, k * ht), self.enct_out[l].ld
+                        a.c_prev = self.enct_c[l].p(tp * Tn, k * ht)
+                    a.ld_cprev = self.enct_c[l].ld
+                    a.w_hh, a.ld_w = whh.p(), whh.ld
+                    a.gx, a.ld_gx = self.enct_gx[l].p(t * Tn, k * 4 * ht), self.enct_gx[l].ld
+                    a.gates, a.ld_gates = self.enct_gates[l].p(t * Tn, k * 4 * ht), self.enct_gates[l].ld
+                    a.c_out, a.ld_c = self.enct_c[l].p(t * Tn, k * ht), self.enct_c[l].ld
+                    a.h_out, a.ld_h = self.enct_out[l].p(t * Tn, k * ht), self.enct_out[l].ld
+                    a.t, a.capture = t, 0
+                self._keep.append(arr)
+                e._call(P, lib.vmmt_lstm_step_fwd, dt, 2, arr, None, Tn, ht)
+            x, xcols = self.enct_out[l], H
+            if l < Lyr - 1 and drop:
+                e._call(P, lib.vmmt_mul, dt, self.enct_out[l].p(), self.enct_out[l].ld, self.enct_mask[l].p(), self.enct_mask[l].ld,
+                        self.enct_xdrop[l].p(), self.enct_xdrop[l].ld, MT, H)
+                x = self.enct_xdrop[l]
+        e._record(P, "enct_done")
+        e._sid = MAIN
+        # [h_x ; h_y ; v]: the two means are written straight into their column ranges of the q-network input
+        e._call(P, lib.vmmt_masked_mean, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.hq.p(0, 0), self.hq.ld, B, S, H)
+        e._call(P, lib.vmmt_pack, dt, self.img.p(), None, self.img.ld, self.hq.p(0, 2 * H), self.hq.ld, B, D, 0)
+        # p(z|x) = gen_net_global(h_x) (the values of h_x are those of the detached copy)
+        for br, outb, act in (("location", self.mu_p, L.ACT_NONE), ("scale", self.sigma_p, L.ACT_SOFTPLUS)):
+            w1, w2 = e.sh["p_%s_w1" % br], e.sh["p_%s_w2" % br]
+            e._gemm(P, L.GEMM_NT, self.hq.p(), self.hq.ld, w1.p(), w1.ld, self.p_h1[br].p(), self.p_h1[br].ld, B, Z, H,
+                    addend=e.pp("gen_net_global.%s.fc1.bias" % br), ld_add=Z, add_rows=1, act=L.ACT_RELU)
+            e._gemm(P, L.GEMM_NT, self.p_h1[br].p(), self.p_h1[br].ld, w2.p(), w2.ld, outb.p(), outb.ld, B, Z, Z,
+                    addend=e.pp("gen_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
+        e._wait(P, "enct_done")
+        e._call(P, lib.vmmt_masked_mean_bm, dt, self.enct_out[Lyr - 1].p(), self.enct_out[Lyr - 1].ld, self.tgt_len.data_ptr(),
+                self.hq.p(0, H), self.hq.ld, B, Tn, H)
+        for br, outb, act in (("location", self.mu, L.ACT_NONE), ("scale", self.sigma, L.ACT_SOFTPLUS)):
+            w1, w2 = e.sh["q_%s_w1" % br], e.sh["q_%s_w2" % br]
+            e._gemm(P, L.GEMM_NT, self.hq.p(), self.hq.ld, w1.p(), w1.ld, self.q_h1[br].p(), self.q_h1[br].ld, B, Z, d.qin,
+                    addend=e.pp("inf_net_global.%s.fc1.bias" % br), ld_add=Z, add_rows=1, act=L.ACT_RELU)
+            e._gemm(P, L.GEMM_NT, self.q_h1[br].p(), self.q_h1[br].ld, w2.p(), w2.ld, outb.p(), outb.ld, B, Z, Z,
+                    addend=e.pp("inf_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
+
+    def _cond_backward(self, P, drop):
+        """aux stream, right behind vmmt_latent_cond_bwd: backward of p(z|x); d h_x goes to the main stream (event dhbar_p)"""
+        e, d, lib = self.e, self.e.d, self.e.lib
+        B, H, Z = self.B, d.hid, d.z
+        dt = e.dt
+        for i, (br, dy) in enumerate((("location", self.p_dmu), ("scale", self.p_dpre))):
+            w1, w2 = e.sh["p_%s_w1" % br], e.sh["p_%s_w2" % br]
+            pre = "gen_net_global.%s" % br
+            e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.p_h1[br].p(), self.p_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
+            e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"), None)
+            e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2.p(), w2.ld, self.p_dh1[br].p(), self.p_dh1[br].ld, B, Z, Z)
+            e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.p_dh1[br].p(), self.p_dh1[br].ld, 0, self.p_h1[br].p(), self.p_h1[br].ld,
+                    None, 0, self.p_dh1[br].p(), self.p_dh1[br].ld, B, Z)
+            e._gemm(P, L.GEMM_TN, self.p_dh1[br].p(), self.p_dh1[br].ld, self.hq.p(), self.hq.ld, e.gp(pre + ".fc1.weight"), H,
+                    Z, H, B, out_f32=1, split_k=-1)
+            e._call(P, lib.vmmt_colsum, dt, self.p_dh1[br].p(), self.p_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
+            e._gemm(P, L.GEMM_NN, self.p_dh1[br].p(), self.p_dh1[br].ld, w1.p(), w1.ld, self.dhbar_p.p(), self.dhbar_p.ld, B, H, Z,
+                    accumulate=1 if i else 0)
+        e._record(P, "dhbar_p")
+
+    def _cond_backward_tgt(self, P, drop):
+        """aux stream: d h_y -> encoder_tgt (BPTT over the B recurrent steps) -> its parameters and the shared target embeddings"""
+        e, d, lib = self.e, self.e.d, self.e.lib
+        B, H, ht, E, Lyr = self.B, d.hid, d.ht, d.emb, d.layers
+        Tn, MT = self.Tn, self.MT
+        dt = e.dt
+        e._call(P, lib.vmmt_masked_mean_bwd, dt, self.dhy.p(), self.dhy.ld, self.tgt_len.data_ptr(), self.enct_dout.p(),
+                self.enct_dout.ld, B, Tn, H, 1, 0)
+        dh_above = self.enct_dout
+        for l in reversed(range(Lyr)):
+            dg = self.enct_dgates[l]
+            e._call(P, _memset, self.enct_dcc[l].t)
+            for step in range(B):
+                arr = (L.LstmDirBwd * 2)()
+                for k in range(2):
+                    t = (B - 1 - step) if k == 0 else step
+                    tn = (t + 1) if k == 0 else (t - 1)
+                    tp = (t - 1) if k == 0 else (t + 1)
+                    a = arr[k]
+                    whhT = e.sh["enct_whhT_l%d_d%d" % (l, k)]
+                    if step > 0:
+                        a.dgates_next, a.ld_dgn = dg.p(tn * Tn, k * 4 * ht), dg.ld
+                    a.w_hh_t, a.ld_wt = whhT.p(), whhT.ld
+                    a.dh_above, a.ld_dha = dh_above.p(t * Tn, k * ht), dh_above.ld
+                    a.gates, a.ld_gates = self.enct_gates[l].p(t * Tn, k * 4 * ht), self.enct_gates[l].ld
+                    a.c_t, a.ld_ct = self.enct_c[l].p(t * Tn, k * ht), self.enct_c[l].ld
+                    if 0 <= tp < B:
+                        a.c_prev, a.ld_cp = self.enct_c[l].p(tp * Tn, k * ht), self.enct_c[l].ld
+                    a.dc_carry, a.ld_dcc = self.enct_dcc[l].p(0, k * ht), self.enct_dcc[l].ld
+                    a.dgates_out, a.ld_dgo = dg.p(t * Tn, k * 4 * ht), dg.ld
+                    a.t, a.inject = t, 0
+                self._keep.append(arr)
+                e._call(P, lib.vmmt_lstm_step_bwd, dt, 2, arr, None, Tn, ht, 0)
+            wih = e.sh["enct_wih_l%d" % l]
+            if l > 0:
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, MT, H, 8 * ht)
+                if drop:
+                    e._call(P, lib.vmmt_mul, dt, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, self.enct_mask[l - 1].p(),
+                            self.enct_mask[l - 1].ld, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, MT, H)
+                dh_above = self.enct_dx[l - 1]
+            xin = (self.Yt if l == 0 else (self.enct_xdrop[l - 1] if drop else self.enct_out[l - 1]))
+            xcols = E if l == 0 else H
+            for k, suf in enumerate(("", "_reverse")):
+                gw = "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf)
+                if B > 1:
+                    if k == 0:   # h_prev[t] = out[t-1]
+                        e._gemm(P, L.GEMM_TN, dg.p(Tn, k * 4 * ht), dg.ld, self.enct_out[l].p(0, k * ht), self.enct_out[l].ld, e.gp(gw), ht,
+                                4 * ht, ht, (B - 1) * Tn, out_f32=1, split_k=-1)
+                    else:        # h_prev[t] = out[t+1]
+                        e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * ht), dg.ld, self.enct_out[l].p(Tn, k * ht), self.enct_out[l].ld, e.gp(gw), ht,
+                                4 * ht, ht, (B - 1) * Tn, out_f32=1, split_k=-1)
+                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * ht), dg.ld, MT, 4 * ht, e.gp("encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf)),
+                        e.gp("encoder_tgt.rnn.bias_hh_l%d%s" % (l, suf)))
+                e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * ht), dg.ld, xin.p(), xin.ld, e.gp("encoder_tgt.rnn.weight_ih_l%d%s" % (l, suf)), xcols,
+                        4 * ht, xcols, MT, out_f32=1, split_k=-1)
+            if l == 0:   # shared table (ModelConstructor.py:456-457): scatter-add next to the decoder's contribution; pad row skipped
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                        MT, E, 8 * ht, out_f32=1, scatter_ids=self.tgt_bt.data_ptr())
+
+
     def _latent_bwd_args(self, batch_global, kl_mult, use_freebits, margin, inv_norm):
+        if self.e.d.conditional:
+            return (self.e.dt, self.mu.p(), self.sigma.p(), self.mu_p.p(), self.sigma_p.p(), self.stats.data_ptr() + 4 * L.STAT_KL_SUM,
+                    float(batch_global), float(kl_mult), 1 if use_freebits else 0, float(margin), float(inv_norm),
+                    self.q_dmu.p(), self.q_dmu.ld, self.q_dpre.p(), self.q_dpre.ld, self.p_dmu.p(), self.p_dmu.ld,
+                    self.p_dpre.p(), self.p_dpre.ld, self.B, self.e.d.z)
         return (self.e.dt, self.mu.p(), self.sigma.p(), self.stats.data_ptr() + 4 * L.STAT_KL_SUM, float(batch_global),
                 float(kl_mult), 1 if use_freebits else 0, float(margin), float(inv_norm), self.q_dmu.p(), self.q_dmu.ld,
                 self.q_dpre.p(), self.q_dpre.ld, self.B, self.e.d.z)
@@ -929,7 +1178,7 @@ def _engine_methods():
     def stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
-    def forward(self, src, src_len, tgt, img_indices, training=True, eps=None, masks=None, table=None):
+    def forward(self, src, src_len, tgt, img_indices, training=True, eps=None, masks=None, table=None, tgt_len=None):
         """NMTVIModel.forward (Models.py:850-1011).  src [S,B] int64, src_len [B], tgt [T,B] (incl. <s>, </s>),
         img_indices [B] rows of the resident image table.  Returns the Workspace holding every activation."""
         S, B = int(src.shape[0]), int(src.shape[1])
@@ -956,12 +1205,19 @@ def _engine_methods():
                                             ws.img_idx.data_ptr(), ws.stats.data_ptr(), ws.eps.p() if gen_eps else None,
                                             B * d.z if gen_eps else 0, self.rng_counter, st), "vmmt_prepare_batch")
         ws._inputs_keepalive = (src_d, tgt_d, len_d, idx_d)
+        if d.conditional:
+            if tgt_len is None:
+                raise RuntimeError("the conditional model needs tgt_lengths (q(z|x,y,v) averages the target encodings)")
+            ws.tgt_len.copy_(dev64(tgt_len).reshape(-1))
+            ws.tgt_bt.copy_(tgt_d.reshape(Tp + 1, B).t().reshape(-1))      # rows b*T + t (encoder_tgt sees the transposed target)
         if training:
             if eps is not None:
                 ws.eps.view().copy_(eps.to(device=dev, dtype=torch.float32))
             if d.dropout > 0:
                 mk = [("enc_l%d" % l, ws.enc_mask[l]) for l in range(d.layers - 1)] + \
                      [("dec_l%d" % l, ws.dec_mask[l]) for l in range(d.layers - 1)]
+                if d.conditional:
+                    mk += [("enct_l%d" % l, ws.enct_mask[l]) for l in range(d.layers - 1)]
                 for name, buf in mk:
                     if masks is not None and name in masks:
                         buf.view().copy_(masks[name].reshape(buf.rows, buf.cols).to(device=dev, dtype=self.T))

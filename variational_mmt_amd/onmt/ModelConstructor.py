@@ -34,7 +34,7 @@ def make_vi_model_mmt(model_opt, fields, gpu, checkpoint=None):
     brnn = getattr(model_opt, "brnn", False) or getattr(model_opt, "encoder_type", "rnn") == "brnn"
     dims = Dims(vs=len(fields["src"].vocab), vt=len(fields["tgt"].vocab), emb=model_opt.src_word_vec_size,
                 hid=model_opt.rnn_size, z=model_opt.z_latent_dim, img=feat, layers=model_opt.enc_layers, brnn=brnn,
-                dropout=model_opt.dropout)
+                dropout=model_opt.dropout, conditional=bool(getattr(model_opt, "conditional", False)))
     dtype = getattr(model_opt, "compute_dtype", "bf16")
     dev = "cuda:%d" % (model_opt.gpuid[0] if getattr(model_opt, "gpuid", None) else torch.cuda.current_device())
     model = NMTVIModel(dims, dtype=dtype, device=dev, param_init=(0.0 if checkpoint is not None else model_opt.param_init),

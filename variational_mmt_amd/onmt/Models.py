@@ -27,18 +27,19 @@ def _attach(root, dotted, param):
 
 
 class NMTVIModel(nn.Module):
-    """encoder + variational decoder + inference networks of VI_Model1 (fixed prior, global image features)."""
+    """encoder + variational decoder + inference networks of VI_Model1 (global image features): fixed prior, or with
+    `conditional` the conditional prior p(z|x) + q(z|x,y,v) + encoder_tgt (Models.py:883-914)."""
 
     def __init__(self, dims, dtype="bf16", device="cuda", param_init=0.1, seed=0, conditional=False,
                  multimodal_model_type="vi-model1", image_loss_type="logprob"):
         super(NMTVIModel, self).__init__()
-        if conditional:
-            raise NotImplementedError("--conditional (SURVEY.md 8f-1) is not built yet")
-        self.conditional = False
+        assert bool(conditional) == bool(dims.conditional)
+        self.conditional = bool(conditional)
         self.multimodal_model_type = multimodal_model_type
         self.image_loss_type = image_loss_type
         self.model_type = "text"
-        self.gen_net_global = None
+        if not conditional:
+            self.gen_net_global = None
         self.dims = dims
         self.engine = Engine(dims, dtype=dtype, device=device, seed=seed, param_init=param_init)
         for name in self.engine.names_grad + self.engine.names_nograd:
@@ -89,7 +90,8 @@ class NMTVIModel(nn.Module):
             img_indices = torch.arange(B, device=e.dev)
         else:
             table = img_table
-        ws = e.forward(src, lengths, tgt, img_indices, training=self.training, eps=eps, masks=masks, table=table)
+        ws = e.forward(src, lengths, tgt, img_indices, training=self.training, eps=eps, masks=masks, table=table,
+                       tgt_len=tgt_lengths if self.conditional else None)
         S, Tp, H = src.shape[0], tgt.shape[0] - 1, self.dims.hid
         ob = ws.O if (self.training and self.dims.dropout > 0) else ws.AH
         out = ob.t.as_strided((Tp, B, H), (B * ob.ld, ob.ld, 1))
@@ -98,7 +100,8 @@ class NMTVIModel(nn.Module):
             "p_global_image_features": [Normal(ws.mu_v.view(), None)],
             "ground_truth_global_image_features": [ws.img.view()],
             "z_latent": [Normal(ws.mu.view(), ws.sigma.view())],
-            "p_latent": [Normal(None, None)],          # standard normal prior (Models.py:936-939), implicit in the KL kernel
+            # fixed prior: standard normal (Models.py:936-939), implicit in the KL kernel; conditional: p(z|x) = gen_net_global
+            "p_latent": [Normal(ws.mu_p.view(), ws.sigma_p.view()) if self.conditional else Normal(None, None)],
             "z0_sample": [ws.z32.view()],
             "zz": [None], "logdet": [None],
             "_ws": ws,
