@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-stream", action="store_true", help="profiling aid: issue the whole step on one stream")
+    ap.add_argument("--conditional", action="store_true", help="the --conditional prior variant (SURVEY.md 8f-1) instead of the fixed prior")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,7 +107,7 @@ def main():
 
     from variational_mmt_amd.engine import Dims, Engine
     from variational_mmt_amd import _lib as L
-    d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=a.dropout)
+    d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=a.dropout, conditional=a.conditional)
     B, S, T = a.batch, 20, 21
     Tp = T - 1
     eng = Engine(d, dtype=a.dtype, device=dev, seed=0)
@@ -117,6 +118,7 @@ def main():
     eng.set_image_table(torch.rand(n_img, d.img, generator=gt))
     batches = make_batches(d, B, S, T, n_img, 8, dev, 1234 + rank)
     Bg = B * world
+    tlen = torch.full((B,), T, dtype=torch.int64, device=dev)
     from variational_mmt_amd.dp import GradSync
     sync = GradSync(eng)          # attaches itself to the engine when torch.distributed runs with > 1 rank
 
@@ -124,7 +126,7 @@ def main():
 
     def step(i, timed=False):
         src, sl, tgt, idx = batches[i % len(batches)]
-        ws = eng.forward(src, sl, tgt, idx, training=True)
+        ws = eng.forward(src, sl, tgt, idx, training=True, tgt_len=tlen if a.conditional else None)
         eng.loss_backward(ws, normalization=Bg, batch_global=Bg)
         sync.all_reduce()          # waits for the segment all-reduces the backward plan issued behind each segment
         eng.optim_step(lr=0.002, max_grad_norm=5.0)
@@ -200,7 +202,7 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE config 2: VI_Model1 training step, batch %d/GPU, src/tgt len 20, V=30000, "
-                                   "1-layer biLSTM 512, z 256, emb 500, 2048-d image feats, dropout %.1f, Adam" % (B, a.dropout),
+                                   "1-layer biLSTM 512, z 256, emb 500, 2048-d image feats, dropout %.1f, Adam%s" % (B, a.dropout, ", --conditional prior" if a.conditional else ""),
                        "global_batch": Bg, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "gen_kernel (vocab projection + log-softmax/NLL pass, slower of fwd/bwd)",
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

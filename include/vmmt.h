@@ -129,6 +129,14 @@ typedef struct vmmt_lstm_dir_bwd {
 int vmmt_lstm_step_bwd(int dtype, int ndir, const vmmt_lstm_dir_bwd* dirs, const int64_t* lens, int B, int H,
                        int mode, void* stream);
 
+/* a whole recurrence in ONE host call: nsteps launches of the step kernel, step i described by dirs[i*ndir .. (i+1)*ndir)
+ * (nn.LSTM's time loop, onmt/Models.py:131-149; same semantics as nsteps calls of vmmt_lstm_step_fwd / _bwd) */
+int vmmt_lstm_chain_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd* dirs, const int64_t* lens, int B, int H,
+                        void* stream);
+int vmmt_lstm_chain_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* dirs, const int64_t* lens, int B, int H,
+                        int mode, void* stream);
+
+
 /* ---- statistics vector (f32[VMMT_STAT_COUNT], device memory, zeroed by the caller before each step) ------------
  * sums that VIStatistics needs (onmt/TrainerMultimodal.py:32-228, filled at onmt/VILoss.py:483-497). */
 #define VMMT_STAT_NLL 0          /* sum of token NLL over non-pad targets                                       */

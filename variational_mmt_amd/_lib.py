@@ -55,6 +55,8 @@ _SIGS = {
     "vmmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "vmmt_lstm_step_fwd": (i32, [i32, i32, C.POINTER(LstmDirFwd), vp, i32, i32, vp]),
     "vmmt_lstm_step_bwd": (i32, [i32, i32, C.POINTER(LstmDirBwd), vp, i32, i32, i32, vp]),
+    "vmmt_lstm_chain_fwd": (i32, [i32, i32, i32, C.POINTER(LstmDirFwd), vp, i32, i32, vp]),
+    "vmmt_lstm_chain_bwd": (i32, [i32, i32, i32, C.POINTER(LstmDirBwd), vp, i32, i32, i32, vp]),
     "vmmt_attn_fwd": (i32, [i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp]),
     "vmmt_attn_bwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "vmmt_masked_mean": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, i32, vp]),

@@ -569,3 +569,27 @@ extern "C" int vmmt_lstm_step_bwd(int dtype, int ndir, const vmmt_lstm_dir_bwd* 
   } else return VMMT_EINVAL;
   return check_launch();
 }
+
+// A whole recurrence in one host call: `nsteps` consecutive launches of the step kernel, step i described by
+// dirs[i*ndir .. i*ndir+ndir).  Same kernels and semantics as nsteps calls of vmmt_lstm_step_*; it only removes the
+// per-launch cost of the host language (the conditional model's encoder_tgt walks the batch axis: 2 x 256 steps per
+// training step at B = 256, which made the Python/ctypes host side the bottleneck).
+extern "C" int vmmt_lstm_chain_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd* dirs, const int64_t* lens, int B,
+                                   int H, void* stream) {
+  if (nsteps < 0 || !dirs) return VMMT_EINVAL;
+  for (int i = 0; i < nsteps; ++i) {
+    int rc = vmmt_lstm_step_fwd(dtype, ndir, dirs + (long)i * ndir, lens, B, H, stream);
+    if (rc != VMMT_OK) return rc;
+  }
+  return VMMT_OK;
+}
+
+extern "C" int vmmt_lstm_chain_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* dirs, const int64_t* lens, int B,
+                                   int H, int mode, void* stream) {
+  if (nsteps < 0 || !dirs) return VMMT_EINVAL;
+  for (int i = 0; i < nsteps; ++i) {
+    int rc = vmmt_lstm_step_bwd(dtype, ndir, dirs + (long)i * ndir, lens, B, H, mode, stream);
+    if (rc != VMMT_OK) return rc;
+  }
+  return VMMT_OK;
+}

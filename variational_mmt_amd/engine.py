@@ -373,50 +373,55 @@ class Engine(object):
         ts = (main, side, aux)
         hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream)
         trace, last = self.trace, None
-        for fn, args, name, _keep, sid in plan:
+        for entry in plan:
+            fn, args, name, _keep, sid = entry
             if trace is not None and sid == 0 and name != last:     # tools/phase_times.py: timing events at phase changes
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(main)
                 trace.append((name, ev))
                 last = name
-            if fn is None:
-                if name == "SUMSQ":
-                    lo, hi = args
-                    if self._works:
-                        with torch.cuda.stream(ts[sid]):
-                            for w in self._works:
-                                w.wait()
-                        self._works = []
-                    L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), hs[sid]), "vmmt_sumsq")
-                    self._sumsq_by_plan = True
-                    continue
-                if name == "ALLREDUCE":
-                    if self.dp is not None and self.dp.world > 1:
-                        lo, hi = args
-                        with torch.cuda.stream(ts[sid]):
-                            self._works.append(self.dp.dist.all_reduce(self.flat_g[lo:hi], async_op=True))
-                    continue
-                if side is main:
-                    continue
-                if name == "EV_RECORD":
-                    ev = events.get(args)
-                    if ev is None:
-                        ev = events[args] = torch.cuda.Event()
-                    ev.record(ts[sid])
-                else:
-                    ev = events.get(args) if args in events else self.global_events.get(args)
-                    if ev is not None:
-                        ts[sid].wait_event(ev)
-            elif name == "memset":
-                if sid == 0 or side is main:
-                    args[0].zero_()
-                else:
+            self._exec(entry, ts, hs, events, side is main)
+
+    def _exec(self, entry, ts, hs, events, single_stream):
+        fn, args, name, _keep, sid = entry
+        if fn is None:
+            if name == "SUMSQ":
+                lo, hi = args
+                if self._works:
                     with torch.cuda.stream(ts[sid]):
-                        args[0].zero_()
+                        for w in self._works:
+                            w.wait()
+                    self._works = []
+                L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), hs[sid]), "vmmt_sumsq")
+                self._sumsq_by_plan = True
+                return
+            if name == "ALLREDUCE":
+                if self.dp is not None and self.dp.world > 1:
+                    lo, hi = args
+                    with torch.cuda.stream(ts[sid]):
+                        self._works.append(self.dp.dist.all_reduce(self.flat_g[lo:hi], async_op=True))
+                return
+            if single_stream:
+                return
+            if name == "EV_RECORD":
+                ev = events.get(args)
+                if ev is None:
+                    ev = events[args] = torch.cuda.Event()
+                ev.record(ts[sid])
             else:
-                rc = fn(*args, hs[sid])
-                if rc != 0:
-                    L.check(rc, name)
+                ev = events.get(args) if args in events else self.global_events.get(args)
+                if ev is not None:
+                    ts[sid].wait_event(ev)
+        elif name == "memset":
+            if sid == 0 or single_stream:
+                args[0].zero_()
+            else:
+                with torch.cuda.stream(ts[sid]):
+                    args[0].zero_()
+        else:
+            rc = fn(*args, hs[sid])
+            if rc != 0:
+                L.check(rc, name)
 
     # ------------------------------------------------------------------------------------------------ workspace
     def workspace(self, B, S, Tp):
@@ -554,6 +559,8 @@ class Workspace(object):
         we = e.sh["dec_wih_l0_e"]
         e._gemm(P, L.GEMM_NT, self.Xt.p(), self.Xt.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * H, E, out_f32=1)
         e._record(P, "dec_gx")
+        if d.conditional:
+            self._cond_forward_aux(P, training)
         e._sid = MAIN
         # a1 image rows (TrainerMultimodal.py:632-639) -- table pointer is patched in at run time (set_image_table)
         if not hasattr(self, '_img_idx'):
@@ -764,9 +771,12 @@ class Workspace(object):
                 w1q = e.sh["q_%s_w1" % br]
                 e._gemm(P, L.GEMM_NN, self.q_dh1[br].p(), self.q_dh1[br].ld, w1q.p(0, H), w1q.ld, self.dhy.p(), self.dhy.ld, B, H, Z,
                         accumulate=1 if i else 0)
-        if d.conditional:
-            self._cond_backward_tgt(P, drop)
         e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
+        if d.conditional:
+            # encoder_tgt's backward: 2 x B dependent launches that only need d h_y, next to everything below.  They scatter
+            # into the shared target-embedding gradient, so the first arena half is finished behind them (finish_first_half
+            # at the end of the plan).  (Issuing them from a helper thread was measured: no gain, removed.)
+            self._cond_backward_tgt(P, drop)
         e._record(P, "aux_done")
         # side: dWg = G^T O, db = rowsum(G^T) as soon as G^T exists (underneath dO = G Wg of the main stream)
         e._sid = SIDE
@@ -856,14 +866,16 @@ class Workspace(object):
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
         e._sid = SIDE
-        if d.conditional:
-            e._wait(P, "aux_done")      # encoder_tgt scatters into the (shared) target embedding gradient on the aux stream
-        e._allreduce(P, "decoder.attn.linear_out.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
-        # gradient norm of everything that is final by now (generator, attention, decoder, inference networks): off the
-        # critical path, underneath the encoder chain
-        e._sumsq_entry(P, "generator.0.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
-        e._wait(P, "aux_done")
-        e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None)
+
+        def finish_first_half():
+            e._allreduce(P, "decoder.attn.linear_out.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
+            # gradient norm of everything that is final by now (generator, attention, decoder, inference networks): off the
+            # critical path, underneath the encoder chain
+            e._sumsq_entry(P, "generator.0.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
+            e._wait(P, "aux_done")
+            e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None)
+        if not d.conditional:
+            finish_first_half()
         # ================= encoder LSTM backward (main) + its parameter gradients (side) ==========================
         if d.conditional:   # p(z|x) reads the NON-detached memory (Models.py:889): d context[s,b] += d hbar_p[b] / len_b
             e._sid = MAIN
@@ -938,6 +950,10 @@ class Workspace(object):
                 e._sid = MAIN
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                         MS, E, dirs * 4 * Hd, out_f32=1, scatter_ids=self.src.data_ptr())
+        if d.conditional:
+            e._sid = SIDE
+            e._wait(P, "aux_done")
+            finish_first_half()
         # join
         e._sid = SIDE
         e._record(P, "side_done")
@@ -983,9 +999,8 @@ class Workspace(object):
         self.enct_dcc = [nb(Tn, H, f32) for _ in range(Lyr)]
         self.enct_dx = [nb(MT, H) for _ in range(Lyr - 1)]
 
-    def _cond_forward(self, P, training, ctx):
-        """aux stream: encoder_tgt over the transposed target (B recurrent steps with T rows each);
-        main stream: h_x, h_y, v -> p(z|x) and q(z|x,y,v)  (Models.py:883-914)"""
+    def _cond_forward_aux(self, P, training):
+        """aux stream: encoder_tgt over the transposed target (B recurrent steps with T rows each; Models.py:892-894)"""
         e, d, lib = self.e, self.e.d, self.e.lib
         B, S, H, ht, E, Z, D, Lyr = self.B, self.S, d.hid, d.ht, d.emb, d.z, d.img, d.layers
         Tn, MT = self.Tn, self.MT
@@ -1002,14 +1017,14 @@ class Workspace(object):
             wih, bsum = e.sh["enct_wih_l%d" % l], e.sh["enct_b_l%d" % l]
             e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enct_gx[l].p(), self.enct_gx[l].ld, MT, 8 * ht, xcols,
                     addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+            arr = (L.LstmDirFwd * (2 * B))()                    # the whole recurrence is ONE host call (vmmt_lstm_chain_fwd)
             for step in range(B):
-                arr = (L.LstmDirFwd * 2)()
                 for k in range(2):
                     t = step if k == 0 else B - 1 - step           # "time" = sentence index (H5)
                     tp = (t - 1) if k == 0 else (t + 1)
                     first = step == 0
                     whh = e.sh["enct_whh_l%d_d%d" % (l, k)]
-                    a = arr[k]
+                    a = arr[2 * step + k]
                     if first:
                         a.h_prev, a.ld_hprev = self.enct_hzero.p(0, k * ht), self.enct_hzero.ld
                     else:
@@ -1022,14 +1037,22 @@ class Workspace(object):
                     a.c_out, a.ld_c = self.enct_c[l].p(t * Tn, k * ht), self.enct_c[l].ld
                     a.h_out, a.ld_h = self.enct_out[l].p(t * Tn, k * ht), self.enct_out[l].ld
                     a.t, a.capture = t, 0
-                self._keep.append(arr)
-                e._call(P, lib.vmmt_lstm_step_fwd, dt, 2, arr, None, Tn, ht)
+            self._keep.append(arr)
+            e._call(P, lib.vmmt_lstm_chain_fwd, dt, 2, B, arr, None, Tn, ht)
             x, xcols = self.enct_out[l], H
             if l < Lyr - 1 and drop:
                 e._call(P, lib.vmmt_mul, dt, self.enct_out[l].p(), self.enct_out[l].ld, self.enct_mask[l].p(), self.enct_mask[l].ld,
                         self.enct_xdrop[l].p(), self.enct_xdrop[l].ld, MT, H)
                 x = self.enct_xdrop[l]
         e._record(P, "enct_done")
+
+    def _cond_forward(self, P, training, ctx):
+        """main stream: h_x, h_y, v -> p(z|x) and q(z|x,y,v)  (Models.py:883-914)"""
+        e, d, lib = self.e, self.e.d, self.e.lib
+        B, S, H, ht, E, Z, D, Lyr = self.B, self.S, d.hid, d.ht, d.emb, d.z, d.img, d.layers
+        Tn, MT = self.Tn, self.MT
+        dt = e.dt
+        MAIN = 0
         e._sid = MAIN
         # [h_x ; h_y ; v]: the two means are written straight into their column ranges of the q-network input
         e._call(P, lib.vmmt_masked_mean, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.hq.p(0, 0), self.hq.ld, B, S, H)
@@ -1083,13 +1106,13 @@ class Workspace(object):
         for l in reversed(range(Lyr)):
             dg = self.enct_dgates[l]
             e._call(P, _memset, self.enct_dcc[l].t)
+            arr = (L.LstmDirBwd * (2 * B))()
             for step in range(B):
-                arr = (L.LstmDirBwd * 2)()
                 for k in range(2):
                     t = (B - 1 - step) if k == 0 else step
                     tn = (t + 1) if k == 0 else (t - 1)
                     tp = (t - 1) if k == 0 else (t + 1)
-                    a = arr[k]
+                    a = arr[2 * step + k]
                     whhT = e.sh["enct_whhT_l%d_d%d" % (l, k)]
                     if step > 0:
                         a.dgates_next, a.ld_dgn = dg.p(tn * Tn, k * 4 * ht), dg.ld
@@ -1102,8 +1125,8 @@ class Workspace(object):
                     a.dc_carry, a.ld_dcc = self.enct_dcc[l].p(0, k * ht), self.enct_dcc[l].ld
                     a.dgates_out, a.ld_dgo = dg.p(t * Tn, k * 4 * ht), dg.ld
                     a.t, a.inject = t, 0
-                self._keep.append(arr)
-                e._call(P, lib.vmmt_lstm_step_bwd, dt, 2, arr, None, Tn, ht, 0)
+            self._keep.append(arr)
+            e._call(P, lib.vmmt_lstm_chain_bwd, dt, 2, B, arr, None, Tn, ht, 0)
             wih = e.sh["enct_wih_l%d" % l]
             if l > 0:
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, MT, H, 8 * ht)
