@@ -224,3 +224,45 @@ def test_wide_hidden_sizes_bf16(hid, layers):
             continue
         got, want = e.grads[k].cpu().double(), g[k].double()
         assert (got - want).norm().item() <= 3e-2 * want.norm().item(), (k, (got - want).norm().item() / want.norm().item())
+
+
+@pytest.mark.parametrize("dtype,S,T,hid,emb,zd,brnn,layers", [
+    ("f32", 64, 61, 40, 28, 20, True, 2),       # S = 64: the attention kernels' maximum; T' = 60 (cfg-5-like lengths)
+    ("bf16", 45, 40, 96, 50, 36, False, 2),     # script-as-written shape class: uni-directional, 2 layers, dims not multiples of 64
+    ("bf16", 33, 34, 128, 64, 64, True, 1),     # just past the 32-position limit of the MFMA attention kernels -> generic path
+])
+def test_long_sequences_and_odd_dims(dtype, S, T, hid, emb, zd, brnn, layers):
+    """Maximum source length, target lengths beyond the fast attention kernels, ragged lengths, dimensions that are not
+    multiples of the GEMM slab (the engine rounds K up over zero-padded buffers): whole step against the oracle."""
+    c = O.Cfg(vs=90, vt=110, emb=emb, hid=hid, z=zd, layers=layers, brnn=brnn)
+    p = O.init_params(c, seed=5)
+    B = 19
+    bt = O.synth_batch(c, B, S, T, n_img=30, seed=21, fixed_len=False)
+    e = _engine(c, p, dtype)
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+    e.loss_backward(ws, normalization=B)
+    torch.cuda.synchronize()
+    img = bt["table"][bt["indices"]]
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
+    st = e.read_stats(ws)
+    tl, ta, tg = (2e-5, 2e-5, 3e-4) if dtype == "f32" else (5e-3, 3e-2, 4e-2)
+    assert abs(st["elbo"] - float(Lo["elbo"])) <= tl * abs(float(Lo["elbo"]))
+    assert st["n_words"] == Lo["n_words"]
+    _cmp("context", ws.enc_out[-1].view().float().view(S, B, hid), r["context"], ta, False)
+    _cmp("attn", ws.probs.view(T - 1, B, S), r["attn"], ta, False)
+    _cmp("attn_h", ws.AH.view().float().view(T - 1, B, hid), r["attn_h"], ta, False)
+    for k in g:
+        if "inf_net_image.location.fc1" in k or "gate_affine" in k:
+            continue
+        got, want = e.grads[k].cpu().double(), g[k].double()
+        assert (got - want).norm().item() <= tg * want.norm().item(), (k, (got - want).norm().item() / want.norm().item())
+
+
+def test_source_longer_than_64_is_rejected():
+    c = O.Cfg(vs=30, vt=30, emb=16, hid=32, z=8, layers=1, brnn=True)
+    e = _engine(c, O.init_params(c, seed=1), "f32")
+    bt = O.synth_batch(c, 3, 65, 5, n_img=4, seed=2)
+    e.set_image_table(bt["table"])
+    with pytest.raises(RuntimeError):
+        e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
