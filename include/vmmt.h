@@ -172,6 +172,9 @@ int vmmt_masked_mean(int dtype, const void* ctx, int64_t ldc, const int64_t* len
  *   workspaces: part_max/part_sum f32 [vmmt_gen_npart(V)][M], part_idx int32 same, tgt_logit f32 [M]
  *   out: lse f32 [M], tok_nll f32 [M]; stats[NLL,NWORDS,NCORRECT] += sums. */
 int vmmt_gen_npart(int V);
+/* arg-max over the vocabulary (and its logit) from the partials written by vmmt_gen_loss_fwd: the next input token of
+ * step-wise decoding with beam size 1 (onmt/translate/TranslatorMultimodalVI.py:185-200); log-prob = out_max - lse */
+int vmmt_gen_argmax(const float* part_max, const int* part_idx, int M, int npart, int64_t* out_idx, float* out_max, void* stream);
 /* tuning hook (tools/gen_ab.py): -1 automatic, 0 register-staged, 1 LDS-DMA one buffer, 2 LDS-DMA two buffers */
 int vmmt_gen_set_variant(int v);
 int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,

@@ -115,8 +115,58 @@ def run_case(name, ck, B, S, T, fixed):
           "img", float(out["s_image_feats_loss"]), "words", int(out["s_n_words"]))
 
 
+GREEDY = {
+    # name: (cfg kwargs, B, S, max_len, weight scale): decoding with beam size 1 through the reference's OWN modules
+    "greedy_bi_l1": (dict(vs=37, vt=41, emb=12, hid=16, z=8, layers=1, brnn=True), 6, 7, 10, 6.0),
+    "greedy_cond_uni_l2": (dict(vs=43, vt=39, emb=10, hid=12, z=6, layers=2, brnn=False, conditional=True), 5, 8, 9, 6.0),
+}
+
+
+def run_greedy(name, ck, B, S, max_len, scale):
+    """tokens of TranslatorMultimodalVI's step loop with beam size 1 (translate/TranslatorMultimodalVI.py:114-200), driven
+    through the reference's encoder / latent network / decoder / generator modules"""
+    onmt, _ = RH.import_reference()
+    c = O.Cfg(**ck)
+    opt = RH.make_opt(src_word_vec_size=c.emb, tgt_word_vec_size=c.emb, rnn_size=c.hid, z_latent_dim=c.z,
+                      enc_layers=c.layers, dec_layers=c.layers, encoder_type="brnn" if c.brnn else "rnn",
+                      dropout=0.0, conditional=bool(c.conditional))
+    model, fields = RH.build_model(opt, c.vs, c.vt, seed=0)
+    model.eval()
+    for k, v in model.named_parameters():           # larger weights than the +-0.1 initialisation: varied arg-max paths
+        if "inf_net_image" not in k:
+            v.data.mul_(scale)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    bt = O.synth_batch(c, B, S, 5, n_img=8, seed=77 + len(name), fixed_len=False)
+    src3 = bt["src"].unsqueeze(2)
+    toks, scores = [], []
+    with torch.no_grad():
+        enc_states, context = model.encoder(src3, bt["src_len"])
+        net = model.gen_net_global if c.conditional else model.inf_net_global
+        q0, _ = net(context.detach(), bt["src_len"])
+        s0 = q0.mean()
+        st = model.decoder.init_decoder_state(src3, context, enc_states)
+        inp = torch.full((1, B, 1), 2, dtype=torch.int64)
+        for _ in range(max_len):
+            dec_out, st, _ = model.decoder(inp, context, st, z_sample=s0, image_features=None, context_lengths=bt["src_len"])
+            out = model.generator.forward(dec_out.squeeze(0))
+            s, nxt = out.max(1)
+            toks.append(nxt); scores.append(s)
+            inp = nxt.view(1, -1, 1)
+    arrs = {"in_src": bt["src"].numpy(), "in_src_len": bt["src_len"].numpy()}
+    arrs.update({"p0_" + k: v.numpy() for k, v in sd.items() if "inf_net_image.scale" not in k and v.numel() <= O.BIG})
+    arrs["tokens"] = torch.stack(toks).numpy()
+    arrs["scores"] = torch.stack(scores).numpy()
+    arrs["cfg"] = np.array([c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, int(c.brnn), B, S, max_len, int(c.conditional)], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print(name, "tokens", arrs["tokens"][:, :3].T.tolist())
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    for n, (ck, B, S, ml, sc) in GREEDY.items():
+        if only and n not in only:
+            continue
+        run_greedy(n, ck, B, S, ml, sc)
     for n, (ck, B, S, T, fx) in CASES.items():
         if only and n not in only:
             continue

@@ -9,6 +9,7 @@ from oracle import vi1_oracle as O
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["tiny_uni_l2", "tiny_bi_l1", "tiny_bi_l2", "small_fixed"]
 COND_CASES = ["cond_bi_l1", "cond_uni_l2"]          # --conditional prior
+GREEDY_CASES = ["greedy_bi_l1", "greedy_cond_uni_l2"]   # step-wise decoding, beam size 1
 
 
 def load(name, dtype=torch.float32):
@@ -27,5 +28,6 @@ def load(name, dtype=torch.float32):
         assert tuple(p[k].shape) == tuple(shp), k
     bt = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
     for k in ("table", "eps"):
-        bt[k] = bt[k].to(dtype)
+        if k in bt:                                     # decoding fixtures carry only the source side
+            bt[k] = bt[k].to(dtype)
     return c, p, bt, z, (B, S, T)

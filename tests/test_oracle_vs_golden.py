@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import vi1_oracle as O
-from tests.golden_util import CASES, COND_CASES, load
+from tests.golden_util import CASES, COND_CASES, GREEDY_CASES, load
 
 
 def _close(a, b, rtol=2e-5, atol=2e-6, what=""):
@@ -77,3 +77,12 @@ def test_fp64_matches_fp32():
     r = O.forward(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
     L = O.loss(p, c, r, bt["tgt"], img)
     _close(L["elbo"], z["s_elbo_loss"], what="elbo", rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", GREEDY_CASES)
+def test_greedy_decode(name):
+    """beam-size-1 decoding through the reference's own modules (fixture) == the restatement"""
+    c, p, bt, z, (B, S, max_len) = load(name)
+    toks, scores = O.greedy_decode(p, c, bt["src"], bt["src_len"], max_len)
+    assert torch.equal(toks, torch.from_numpy(z["tokens"]))
+    _close(scores, z["scores"], what="log-prob of the chosen tokens", rtol=1e-5, atol=1e-5)

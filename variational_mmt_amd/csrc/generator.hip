@@ -245,6 +245,22 @@ static int launch_gen_v(const GenArgs& a, hipStream_t st) {
   return check_launch();
 }
 
+// arg-max over the vocabulary from the partial statistics of pass 0 (step-wise decoding: the next input token)
+__global__ void gen_argmax_kernel(const float* __restrict__ part_max, const int* __restrict__ part_idx, int M, int npart,
+                                  long long* __restrict__ out_idx, float* __restrict__ out_max) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float mx = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int p = 0; p < npart; ++p) {
+    const float x = part_max[(long)p * M + m];
+    const int xi = part_idx[(long)p * M + m];
+    if (x > mx || (x == mx && xi < mi)) { mx = x; mi = xi; }      // ties: lowest vocabulary index
+  }
+  out_idx[m] = mi;
+  if (out_max) out_max[m] = mx;
+}
+
 template <class T, int MODE>
 static int launch_gen(const GenArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
@@ -261,6 +277,15 @@ static int launch_gen(const GenArgs& a, hipStream_t st) {
 }  // namespace vmmt
 
 extern "C" int vmmt_gen_npart(int V) { return ((V + 127) / 128) * 2; }
+
+extern "C" int vmmt_gen_argmax(const float* part_max, const int* part_idx, int M, int npart, int64_t* out_idx, float* out_max,
+                               void* stream) {
+  using namespace vmmt;
+  if (!part_max || !part_idx || !out_idx || M <= 0 || npart <= 0) return VMMT_EINVAL;
+  hipLaunchKernelGGL(gen_argmax_kernel, dim3((M + 127) / 128), dim3(128), 0, (hipStream_t)stream, part_max, part_idx, M, npart,
+                     (long long*)out_idx, out_max);
+  return check_launch();
+}
 
 extern "C" int vmmt_gen_set_variant(int v) { vmmt::g_gen_variant = v; return VMMT_OK; }
 
