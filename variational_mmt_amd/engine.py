@@ -548,6 +548,12 @@ class Workspace(object):
         if training:
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             e._call(P, _memset, e.flat_g[e.offsets["generator.0.bias"][0]:])
+            # small accumulators of the backward plan, zeroed here (off the critical path) instead of in front of their users
+            e._call(P, _memset, e._sumsq)
+            e._call(P, _memset, self.dO32.t)
+            for l in range(Lyr):
+                e._call(P, _memset, self.dec_dcc[l].t)
+                e._call(P, _memset, self.enc_dcc[l].t)
         self._mask_entries = getattr(self, "_mask_entries", {})
         if drop:
             # output dropout mask (VI_Model1.py:132): only needed after the decoder -> generated in the background
@@ -720,14 +726,12 @@ class Workspace(object):
         wg = e.sh["wg"]
         MAIN, SIDE, AUX = 0, 1, 2
         e._sid = MAIN
-        e._call(P, _memset, e._sumsq)
         e._record(P, "bwd_begin")
         # ================= main: generator backward seed G^T, dO = G Wg ================================================
         e._sid = MAIN
         e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
                 M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
         e._record(P, "GT")
-        e._call(P, _memset, self.dO32.t)
         e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
                 split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))))
         # ================= aux: image term + its network (z is detached: independent of the text path) ==========
@@ -813,7 +817,6 @@ class Workspace(object):
             outb, ocol = (self.cat, H) if last else (self.dec_out[l], 0)
             whhT = e.sh["dec_whhT_l%d" % l]
             dg = self.dec_dgates[l]
-            e._call(P, _memset, self.dec_dcc[l].t)
             for t in reversed(range(Tp)):
                 arr = (L.LstmDirBwd * 2)()
                 a = arr[0]
@@ -886,7 +889,6 @@ class Workspace(object):
         for l in reversed(range(Lyr)):
             e._sid = MAIN
             dg = self.enc_dgates[l]
-            e._call(P, _memset, self.enc_dcc[l].t)
             for step in range(S):
                 arr = (L.LstmDirBwd * 2)()
                 for k in range(dirs):
