@@ -187,13 +187,26 @@ __global__ void __launch_bounds__(1024) gen_combine_kernel(const float* __restri
   float mx = -INFINITY, s = 0.f;
   int mi = 0x7fffffff;
   if (m < M) {
-    for (int p = w; p < npart; p += 16) {
-      float x = part_max[(long)p * M + m], xs = part_sum[(long)p * M + m];
-      int xi = part_idx[(long)p * M + m];
-      if (x > mx || (x == mx && xi < mi)) mi = xi;
-      float nm = fmaxf(mx, x);
-      if (nm != -INFINITY) s = s * __expf(mx - nm) + xs * __expf(x - nm);
-      mx = nm;
+    // four partials per round trip (the merge is a dependent chain, the loads are not)
+    for (int p0 = w; p0 < npart; p0 += 64) {
+      float xv[4], sv[4];
+      int iv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = p0 + 16 * q;
+        const bool ok = p < npart;
+        const long o = (long)(ok ? p : p0) * M + m;
+        xv[q] = ok ? part_max[o] : -INFINITY; sv[q] = ok ? part_sum[o] : 0.f; iv[q] = ok ? part_idx[o] : 0x7fffffff;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = xv[q], xs = sv[q];
+        const int xi = iv[q];
+        if (x > mx || (x == mx && xi < mi)) mi = xi;
+        float nm = fmaxf(mx, x);
+        if (nm != -INFINITY) s = s * __expf(mx - nm) + xs * __expf(x - nm);
+        mx = nm;
+      }
     }
   }
   __shared__ float smx[16][64], ssm[16][64];
