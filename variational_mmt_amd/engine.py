@@ -144,6 +144,7 @@ class Engine(object):
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
         self.use_side_stream = True
         self._masked_streams = []
+        self.enc_half_split = False  # see Workspace._plan_backward
         self.side_one_per_cu = False # see _gemm; measured slower (tools/percu_ab.py): a 128 x 128 GEMM at one workgroup per CU runs at half speed (plans are built per workspace: set before the first forward)
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
@@ -886,6 +887,56 @@ class Workspace(object):
             e._call(P, lib.vmmt_masked_mean_bwd, dt, self.dhbar_p.p(), self.dhbar_p.ld, self.src_len.data_ptr(), self.dctx.p(),
                     self.dctx.ld, B, S, H, 0, 1)
         dh_above = self.dctx
+        # half-way split of layer 0's parameter gradients: only when the row counts stay whole GEMM slabs (sub-ranges cannot
+        # lean on the zero padding behind the buffers)
+        # (measured: 2.82 vs 2.58 ms/step at B = 256 -- the early half competes with the chain's own steps -- so it is off by default)
+        half = S // 2 if (e.enc_half_split and S >= 4 and ((S // 2) * B) % KPAD == 0 and ((S - S // 2) * B) % KPAD == 0 and B % KPAD == 0 and
+                         (4 * Hd) % KPAD == 0) else 0
+
+        def enc_param_grads(l, ranges, alternate):
+            """dW_hh, db, dW_ih (and for layer 0 the embedding scatter) of encoder layer l from the time steps [lo, hi) of each
+            direction; every product accumulates into the arena, so ranges may be issued separately"""
+            dg = self.enc_dgates[l]
+            wih = e.sh["enc_wih_l%d" % l]
+            xin = (self.Xs if l == 0 else (self.enc_xdrop[l - 1] if drop else self.enc_out[l - 1]))
+            xcols = E if l == 0 else H
+            tog = [e._sid]
+
+            def alt():
+                if alternate:
+                    tog[0] = MAIN if tog[0] == SIDE else SIDE
+                    e._sid = tog[0]
+            for k, suf in enumerate([""] + (["_reverse"] if d.brnn else [])):
+                lo, hi = ranges[k]
+                gw = "encoder.rnn.weight_hh_l%d%s" % (l, suf)
+                alt()
+                if k == 0:      # h_prev[t] = out[t-1]: t in [max(lo, 1), hi)
+                    t0 = max(lo, 1)
+                    if hi > t0:
+                        e._gemm(P, L.GEMM_TN, dg.p(t0 * B, k * 4 * Hd), dg.ld, self.enc_out[l].p((t0 - 1) * B, k * Hd), self.enc_out[l].ld,
+                                e.gp(gw), Hd, 4 * Hd, Hd, (hi - t0) * B, out_f32=1, split_k=-1)
+                else:           # h_prev[t] = out[t+1]: t in [lo, min(hi, S-1))
+                    t1 = min(hi, S - 1)
+                    if t1 > lo:
+                        e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, self.enc_out[l].p((lo + 1) * B, k * Hd), self.enc_out[l].ld,
+                                e.gp(gw), Hd, 4 * Hd, Hd, (t1 - lo) * B, out_f32=1, split_k=-1)
+                e._call(P, lib.vmmt_colsum, dt, dg.p(lo * B, k * 4 * Hd), dg.ld, (hi - lo) * B, 4 * Hd,
+                        e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)), e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
+                alt()
+                e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, xin.p(lo * B), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)),
+                        xcols, 4 * Hd, xcols, (hi - lo) * B, out_f32=1, split_k=-1)
+                if l == 0 and half:
+                    # embedding gradient of this direction's steps: sum_k dg_k W_ih,k, scattered by token id
+                    alt()
+                    e._gemm(P, L.GEMM_NN, dg.p(lo * B, k * 4 * Hd), dg.ld, wih.p(k * 4 * Hd, 0), wih.ld,
+                            e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E, (hi - lo) * B, E, 4 * Hd, out_f32=1,
+                            scatter_ids=self.src.data_ptr() + 8 * lo * B)
+            if l == 0 and not half:                  # one product over both directions, last on the main stream
+                assert all(r == (0, S) for r in ranges)
+                e._sid = MAIN
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                        MS, E, dirs * 4 * Hd, out_f32=1, scatter_ids=self.src.data_ptr())
+
         for l in reversed(range(Lyr)):
             e._sid = MAIN
             dg = self.enc_dgates[l]
@@ -914,6 +965,15 @@ class Workspace(object):
                     a.inject = 1 if k == 0 else 2
                 self._keep.append(arr)
                 e._call(P, lib.vmmt_lstm_step_bwd, dt, dirs, arr, self.src_len.data_ptr(), B, Hd, 0)
+                if l == 0 and half and step == half - 1:
+                    # The chain ends the critical path and its parameter gradients can only start behind it: the half of
+                    # them that belongs to the steps already finished is issued NOW on the side stream (sums over time
+                    # steps split anywhere), the rest at the end.
+                    e._record(P, "enc_half")
+                    e._sid = SIDE
+                    e._wait(P, "enc_half")
+                    enc_param_grads(l, [(S - half, S), (0, half)][:dirs], False)
+                    e._sid = MAIN
             e._record(P, "enc_dg%d" % l)
             wih = e.sh["enc_wih_l%d" % l]
             if l > 0:
@@ -924,34 +984,10 @@ class Workspace(object):
                 dh_above = self.enc_dx[l - 1]
             e._sid = SIDE
             e._wait(P, "enc_dg%d" % l)
-            tail_toggle = [SIDE]
-
-            def alt():
-                # the encoder chain is the END of the critical path: spread its parameter gradients over both streams
-                if l == 0:
-                    tail_toggle[0] = MAIN if tail_toggle[0] == SIDE else SIDE
-                    e._sid = tail_toggle[0]
-            xin = (self.Xs if l == 0 else (self.enc_xdrop[l - 1] if drop else self.enc_out[l - 1]))
-            xcols = E if l == 0 else H
-            for k, suf in enumerate([""] + (["_reverse"] if d.brnn else [])):
-                gw = "encoder.rnn.weight_hh_l%d%s" % (l, suf)
-                alt()
-                if S > 1:
-                    if k == 0:   # h_prev[t] = out[t-1]
-                        e._gemm(P, L.GEMM_TN, dg.p(B, k * 4 * Hd), dg.ld, self.enc_out[l].p(0, k * Hd), self.enc_out[l].ld, e.gp(gw), Hd,
-                                4 * Hd, Hd, (S - 1) * B, out_f32=1, split_k=-1)
-                    else:        # h_prev[t] = out[t+1]
-                        e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, self.enc_out[l].p(B, k * Hd), self.enc_out[l].ld, e.gp(gw), Hd,
-                                4 * Hd, Hd, (S - 1) * B, out_f32=1, split_k=-1)
-                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * Hd), dg.ld, MS, 4 * Hd, e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)),
-                        e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
-                alt()
-                e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * Hd), dg.ld, xin.p(), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)), xcols,
-                        4 * Hd, xcols, MS, out_f32=1, split_k=-1)
-            if l == 0:
-                e._sid = MAIN
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                        MS, E, dirs * 4 * Hd, out_f32=1, scatter_ids=self.src.data_ptr())
+            if l == 0 and half:
+                enc_param_grads(l, [(0, S - half), (half, S)][:dirs], True)      # the steps finished after the half-way event
+            else:
+                enc_param_grads(l, [(0, S)] * dirs, l == 0)
         if d.conditional:
             e._sid = SIDE
             e._wait(P, "aux_done")
