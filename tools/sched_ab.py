@@ -13,17 +13,15 @@ def step(i):
     eng.loss_backward(ws, normalization=256, batch_global=256)
     eng.optim_step()
 configs = {
-    "base(split,hi)": dict(split_optim=True, bg=0, hi=True, side=True),
-    "nosplit,hi": dict(split_optim=False, bg=0, hi=True, side=True),
-    "split,bg1024,hi": dict(split_optim=True, bg=1024, hi=True, side=True),
-    "split,default-stream": dict(split_optim=True, bg=0, hi=False, side=True),
-    "nosplit,default-stream": dict(split_optim=False, bg=0, hi=False, side=True),
-    "no-side-stream": dict(split_optim=False, bg=0, hi=False, side=False),
+    "default-stream": dict(split_optim=True, bg=0, hi=False, side=True),
+    "hi-priority main": dict(split_optim=True, bg=0, hi=True, side=True),
+    "no aux stream": dict(split_optim=True, bg=0, hi=False, side=True, aux=False),
 }
 res = {k: [] for k in configs}
 for r in range(5):
     for k, c in configs.items():
         eng.split_optim, eng.bg_adam_blocks, eng.use_side_stream = c["split_optim"], c["bg"], c["side"]
+        eng.use_aux_stream = c.get("aux", True)
         torch.cuda.synchronize()
         ctx = torch.cuda.stream(eng.compute_stream) if c["hi"] else torch.cuda.stream(torch.cuda.default_stream())
         with ctx:

@@ -138,7 +138,9 @@ class Engine(object):
         self.side_stream = self._side_stream_plain = torch.cuda.Stream(device=self.dev, priority=lo_pri)
         # third stream: the small, latency-bound backward of the image / q(z|x) networks, independent of the text path
         self.aux_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
-        self.use_aux_stream = True
+        # measured (tools/sched_ab.py, fixed prior): 2.53 ms/step with that work on the side stream vs 2.59 ms on a stream of
+        # its own; the conditional model keeps it (encoder_tgt's 2 x B-step recurrences would otherwise block the side stream)
+        self.use_aux_stream = bool(dims.conditional)
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
