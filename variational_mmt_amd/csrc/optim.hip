@@ -13,6 +13,14 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   long stride = (long)gridDim.x * blockDim.x * 4;
   float a = 0.f;
+  // few workgroups (the reduction runs underneath latency-critical kernels of another stream: leave them wave slots),
+  // four independent 16-byte loads in flight per lane instead
+  for (; i + 3 * stride + 3 < n; i += 4 * stride) {
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(g + i), v1 = *reinterpret_cast<const f32x4*>(g + i + stride);
+    f32x4 v2 = *reinterpret_cast<const f32x4*>(g + i + 2 * stride), v3 = *reinterpret_cast<const f32x4*>(g + i + 3 * stride);
+    a += v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3] + v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2] + v1[3] * v1[3];
+    a += v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2] + v2[3] * v2[3] + v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2] + v3[3] * v3[3];
+  }
   for (; i + 3 < n; i += stride) {
     f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
     a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
@@ -70,7 +78,7 @@ extern "C" int vmmt_sumsq(const float* g, int64_t n, float* out, void* stream) {
   if (!g || !out || n < 0 || (((uintptr_t)g) & 15)) return VMMT_EINVAL;
   if (n == 0) return VMMT_OK;
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 768) blocks = 768;        // 3 workgroups of 4 waves per CU
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, (long)n, out);
   return check_launch();
