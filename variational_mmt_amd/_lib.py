@@ -97,6 +97,10 @@ def lib():
     """Load libvmmt.so (once).  Raises if it is missing or lacks a declared symbol -- never falls back."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64.so.7; it must be the HIP runtime of the process (device pointers and streams come
+        # from torch), so it is loaded FIRST: the loader then binds libvmmt.so to it by soname.  Loading libvmmt.so before
+        # torch would pull /opt/rocm's copy as a second runtime, and every kernel launch on torch's streams would fail.
+        import torch  # noqa: F401
         if not os.path.exists(os.environ.get("VMMT_LIB_PATH", LIB_PATH)):
             raise RuntimeError("libvmmt.so not built (%s): run `python -m variational_mmt_amd.build`; "
                                "there is no CPU fallback" % LIB_PATH)

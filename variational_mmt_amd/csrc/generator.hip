@@ -20,7 +20,7 @@ struct GenArgs {
   const float* bias;                  // f32 [V]
   const void* O; long ldo;            // T [M][ldo] decoder outputs (after dropout)
   const long long* y;                 // [M] target ids (tgt[1:], flattened t*B+b)
-  int M, V, K, pad;
+  int M, V, K, pad, npart;
   // pass 1
   float* part_max; float* part_sum; int* part_idx; float* tgt_logit;   // [NPART][M], [M]
   // pass 2
@@ -29,17 +29,19 @@ struct GenArgs {
 
 // Tile: 128 vocabulary rows x 256 tokens, 8 waves (2 along V x 4 along tokens, 64x64 each), BK = 64, one LDS buffer
 // (K = H is short: 8 slabs at H = 512) -- the fastest of the shapes tried on [30000 x 5120 x 512] (tools/gemm_ab.py).
-template <class T> struct GenCfg {
-  static constexpr int BMV = 128, BNM = 256, BK = sizeof(T) == 2 ? 64 : 32, NT = 512, TI = 2, TJ = 2;
+// BMV_ = 256 (bf16 LDS-DMA path only): 256 x 256 tiles, waves of 128 x 64 -- a third fewer operand bytes per FLOP through the
+// L2 -> LDS path, which is what bounds this kernel (8 slabs of 48 KiB per 128 x 256 tile at ~45 GB/s per CU).
+template <class T, int BMV_ = 128> struct GenCfg {
+  static constexpr int BMV = BMV_, BNM = 256, BK = sizeof(T) == 2 ? 64 : 32, NT = 512, TI = BMV_ / 64, TJ = 2;
   static constexpr bool DB = false;
   static constexpr int PP = 64 + 16 / sizeof(T);     // pitch (elements) of a wave's 64 x 64 output patch in LDS
 };
 
 // GL: 0 = register-staged main loop (any dtype / alignment); LDS-DMA main loops: 1 = one buffer, 2 = two buffers,
 // 3 = three buffers with counted waits (two slabs in flight across the barrier)
-template <class T, int MODE, int GL>
+template <class T, int MODE, int GL, int BMV_ = 128>
 __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
-  using Cf = GenCfg<T>;
+  using Cf = GenCfg<T, BMV_>;
   constexpr int BK = Cf::BK, NT = Cf::NT, BMV = Cf::BMV, BNM = Cf::BNM, TI = Cf::TI, TJ = Cf::TJ;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -55,8 +57,9 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
   const int v0 = tv * BMV, m0 = tm * BNM;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wv = wave >> 2, wm = wave & 3;
-  int aoff[TI] = {wv * 64, wv * 64 + 32};
-  int boff[TJ] = {wm * 64, wm * 64 + 32};
+  int aoff[TI], boff[TJ] = {wm * 64, wm * 64 + 32};
+#pragma unroll
+  for (int i = 0; i < TI; ++i) aoff[i] = wv * (32 * TI) + 32 * i;
   f32x16 acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -97,79 +100,88 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
         for (int j = 0; j < TJ; ++j) acc[i][j][4 * q + s_] = ok ? acc[i][j][4 * q + s_] + bv[s_] : -INFINITY;
       }
     }
+  // The epilogue works in units of 64 vocabulary rows (two 32-row MFMA tiles of a wave): one partial-statistics row (MODE 0)
+  // or one pass through the wave's 64 x 64 output patch (MODE 1) per unit; a wave owns TI / 2 of them.
+  constexpr int NH = TI / 2;
 #pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    const int m = m0 + boff[j] + (lane & 31);
-    const bool mv = m < a.M;
-    const int ym = mv ? (int)a.y[m] : -1;
-    if constexpr (MODE == 0) {
-      float mx = -INFINITY, tl = 0.f;
-      int mi = 0x7fffffff;
-      bool hit = false;
+  for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+    for (int j = 0; j < TJ; ++j) {
+      const int m = m0 + boff[j] + (lane & 31);
+      const bool mv = m < a.M;
+      const int ym = mv ? (int)a.y[m] : -1;
+      if constexpr (MODE == 0) {
+        float mx = -INFINITY, tl = 0.f;
+        int mi = 0x7fffffff;
+        bool hit = false;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
-          const float x = acc[i][j][r];
-          const bool gt = x > mx;                    // rows visited in increasing v per lane: first max wins
-          mi = gt ? v : mi;
-          mx = gt ? x : mx;
-          const bool h = v == ym;
-          tl = h ? x : tl;
-          hit = hit || h;
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = 2 * hf + ii;
+            const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
+            const float x = acc[i][j][r];
+            const bool gt = x > mx;                    // rows visited in increasing v per lane: first max wins
+            mi = gt ? v : mi;
+            mx = gt ? x : mx;
+            const bool h = v == ym;
+            tl = h ? x : tl;
+            hit = hit || h;
+          }
+        float sm = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sm += __expf(acc[2 * hf + ii][j][r] - mx);      // exp(-inf - finite) = 0; all -inf handled below
+        if (mx == -INFINITY) sm = 0.f;
+        if (hit) a.tgt_logit[m] = tl;
+        // combine with the other half-wave (same token column, interleaved rows)
+        float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
+        int omi = __shfl_xor(mi, 32, 64);
+        float nm = fmaxf(mx, omx);
+        float ns = (nm == -INFINITY) ? 0.f : sm * __expf(mx - nm) + osm * __expf(omx - nm);
+        int ni = (omx > mx || (omx == mx && omi < mi)) ? omi : mi;
+        const int prow = (tv * 2 + wv) * NH + hf;                       // partial row = 64-row vocabulary block index
+        if (mv && lane < 32 && prow < a.npart) {                        // (a 256-row tile can reach past vmmt_gen_npart(V) rows)
+          long p = (long)prow * a.M + m;
+          a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
         }
-      float sm = 0.f;
+      } else {
+        // gradient values -> this wave's 64(v) x 64(m) patch of an LDS image [v][m] (bf16/f32), written back below as
+        // whole 16-byte row segments (a lane-per-token 2-byte store per element is store-issue bound)
+        const float l = mv ? a.lse[m] : 0.f;
+        const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
+        T* patch = smem + wave * (64 * Cf::PP);
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = 2 * hf + ii;
+          const int vb = v0 + aoff[i] + hi4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sm += __expf(acc[i][j][r] - mx);      // exp(-inf - finite) = 0; all -inf handled below
-      if (mx == -INFINITY) sm = 0.f;
-      if (hit) a.tgt_logit[m] = tl;
-      // combine with the other half-wave (same token column, interleaved rows)
-      float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
-      int omi = __shfl_xor(mi, 32, 64);
-      float nm = fmaxf(mx, omx);
-      float ns = (nm == -INFINITY) ? 0.f : sm * __expf(mx - nm) + osm * __expf(omx - nm);
-      int ni = (omx > mx || (omx == mx && omi < mi)) ? omi : mi;
-      if (mv && lane < 32) {
-        long p = (long)(tv * 2 + wv) * a.M + m;
-        a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
-      }
-    } else {
-      // gradient values -> this wave's 64(v) x 64(m) patch of an LDS image [v][m] (bf16/f32), written back below as
-      // whole 16-byte row segments (a lane-per-token 2-byte store per element is store-issue bound)
-      const float l = mv ? a.lse[m] : 0.f;
-      const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
-      T* patch = smem + wave * (64 * GenCfg<T>::PP);
-#pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        const int vb = v0 + aoff[i] + hi4;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dv = (r & 3) + 8 * (r >> 2);
-          float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
-          patch[(i * 32 + hi4 + dv) * GenCfg<T>::PP + j * 32 + (lane & 31)] = from_f<T>(g);
+          for (int r = 0; r < 16; ++r) {
+            const int dv = (r & 3) + 8 * (r >> 2);
+            float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
+            patch[(ii * 32 + hi4 + dv) * Cf::PP + j * 32 + (lane & 31)] = from_f<T>(g);
+          }
         }
       }
     }
-  }
-  if constexpr (MODE == 1) {
-    // each wave owns its patch: no workgroup barrier needed between its own LDS writes and reads, but the staging
-    // buffers of the main loop are being reused -> one barrier before the first write (below) is required
-    constexpr int VEC = 16 / sizeof(T), PP = GenCfg<T>::PP;
-    const T* patch = smem + wave * (64 * PP);
-    const int vbase = v0 + wv * 64, mbase = m0 + wm * 64;
-    constexpr int CH = 64 / VEC;                       // 16-byte chunks per 64-token row
+    if constexpr (MODE == 1) {
+      // each wave owns its patch (LDS operations of a wave complete in order): no workgroup barrier between its writes, its
+      // reads and the next unit's writes; the staging buffers of the main loop are being reused -> one barrier in front
+      constexpr int VEC = 16 / sizeof(T), PP = Cf::PP;
+      const T* patch = smem + wave * (64 * PP);
+      const int vbase = v0 + wv * (64 * NH) + hf * 64, mbase = m0 + wm * 64;
+      constexpr int CH = 64 / VEC;                       // 16-byte chunks per 64-token row
 #pragma unroll
-    for (int it = 0; it < (64 * CH) / 64; ++it) {
-      const int idx = it * 64 + lane, row = idx / CH, ch = idx % CH;
-      const int v = vbase + row, mm = mbase + ch * VEC;
-      if (v < a.V && mm < a.M) {
-        T* dst = reinterpret_cast<T*>(a.GT) + (long)v * a.ldgt + mm;
-        const T* srcp = patch + row * PP + ch * VEC;
-        if (mm + VEC <= a.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);
-        else for (int e = 0; e < VEC && mm + e < a.M; ++e) dst[e] = srcp[e];
+      for (int it = 0; it < (64 * CH) / 64; ++it) {
+        const int idx = it * 64 + lane, row = idx / CH, ch = idx % CH;
+        const int v = vbase + row, mm = mbase + ch * VEC;
+        if (v < a.V && mm < a.M) {
+          T* dst = reinterpret_cast<T*>(a.GT) + (long)v * a.ldgt + mm;
+          const T* srcp = patch + row * PP + ch * VEC;
+          if (mm + VEC <= a.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);
+          else for (int e = 0; e < VEC && mm + e < a.M; ++e) dst[e] = srcp[e];
+        }
       }
     }
   }
@@ -243,18 +255,18 @@ __global__ void __launch_bounds__(1024) gen_combine_kernel(const float* __restri
 
 int g_gen_variant = -1;   // -1: automatic; 0/1/2 force a main loop (tools/gen_ab.py via vmmt_gen_set_variant)
 
-template <class T, int MODE, int GL>
+template <class T, int MODE, int GL, int BMV_ = 128>
 static int launch_gen_v(const GenArgs& a, hipStream_t st) {
-  using Cf = GenCfg<T>;
+  using Cf = GenCfg<T, BMV_>;
   int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + Cf::BNM - 1) / Cf::BNM;
   size_t sm = GL == 3 ? (size_t)glds3_smem_bytes<Cf::BMV, Cf::BNM>() : GL ? (size_t)glds_smem_bytes<Cf::BMV, Cf::BNM, GL == 2>()
                  : gemm_smem_elems<T, Cf::BMV, Cf::BNM, Cf::BK, true, true, Cf::DB>() * sizeof(T);
   if (MODE == 1 && sm < (size_t)8 * 64 * Cf::PP * sizeof(T)) sm = (size_t)8 * 64 * Cf::PP * sizeof(T);
   if (sm > 64 * 1024) {
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)gen_kernel<T, MODE, GL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done = true; }
+    if (!done) { (void)hipFuncSetAttribute((const void*)gen_kernel<T, MODE, GL, BMV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done = true; }
   }
-  hipLaunchKernelGGL((gen_kernel<T, MODE, GL>), dim3(tv * tm), dim3(Cf::NT), sm, st, a, tm);
+  hipLaunchKernelGGL((gen_kernel<T, MODE, GL, BMV_>), dim3(tv * tm), dim3(Cf::NT), sm, st, a, tm);
   return check_launch();
 }
 
@@ -283,6 +295,7 @@ static int launch_gen(const GenArgs& a, hipStream_t st) {
     if (ok && v == 1) return launch_gen_v<T, MODE, 1>(a, st);
     if (ok && v == 2) return launch_gen_v<T, MODE, 2>(a, st);
     if (ok && v == 3) return launch_gen_v<T, MODE, 3>(a, st);
+    if (ok && v == 4) return launch_gen_v<T, MODE, 2, 256>(a, st);          // 256 x 256 tiles, two LDS stages (128 KiB)
   }
   return launch_gen_v<T, MODE, 0>(a, st);
 }
@@ -312,7 +325,7 @@ extern "C" int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const fl
     return VMMT_EINVAL;
   GenArgs a{};
   a.W = W; a.ldw = ldw; a.bias = bias; a.O = O; a.ldo = ldo; a.y = (const long long*)y; a.M = M; a.V = V; a.K = K;
-  a.pad = pad; a.part_max = part_max; a.part_sum = part_sum; a.part_idx = part_idx; a.tgt_logit = tgt_logit;
+  a.pad = pad; a.npart = vmmt_gen_npart(V); a.part_max = part_max; a.part_sum = part_sum; a.part_idx = part_idx; a.tgt_logit = tgt_logit;
   hipStream_t st = (hipStream_t)stream;
   int rc = dtype == VMMT_F32 ? launch_gen<float, 0>(a, st) : dtype == VMMT_BF16 ? launch_gen<bf16_t, 0>(a, st)
                                                                                  : VMMT_EINVAL;
