@@ -104,3 +104,44 @@ def test_three_updates_through_the_onmt_surface_and_checkpoint_roundtrip(tmp_pat
     optim2.set_parameters(model2.parameters())
     assert model2.engine.step_count == 3
     assert torch.equal(model2.engine.flat_m.cpu(), eng.flat_m.cpu()) and torch.equal(model2.engine.flat_v.cpu(), eng.flat_v.cpu())
+
+
+def test_conditional_model_through_the_onmt_surface(tmp_path):
+    """--conditional driven through make_vi_model_mmt / TrainerMultimodal: two updates against the oracle,
+    the prior's parameters in attns["p_latent"], and the shared-embedding alias in the state dict"""
+    import variational_mmt_amd
+    onmt = variational_mmt_amd.install_as_onmt()
+    c = O.Cfg(vs=43, vt=47, emb=16, hid=32, z=8, img=2048, layers=1, brnn=True, conditional=True)
+    p = O.init_params(c, seed=4)
+    B, S, T = 7, 6, 8
+    batches = [O.synth_batch(c, B, S, T, n_img=20, seed=200 + i, fixed_len=False) for i in range(2)]
+    table = batches[0]["table"]
+    fields = {"src": types.SimpleNamespace(vocab=_Vocab(c.vs, False)), "tgt": types.SimpleNamespace(vocab=_Vocab(c.vt, True))}
+    opt = _opt(c, tmp_path)
+    opt.conditional = True
+    model = onmt.ModelConstructor.make_vi_model_mmt(opt, fields, True, None)
+    assert model.conditional and hasattr(model, "gen_net_global") and hasattr(model, "encoder_tgt")
+    assert sorted(model.state_dict().keys()) == sorted(O.param_shapes(c).keys())
+    alias = "encoder_tgt.embeddings.make_embedding.emb_luts.0.weight"
+    assert alias in model.engine.state_dict()
+    model.load_state_dict({k: v for k, v in p.items()})
+    train_loss = onmt.VILoss.NMTVIModel1LossCompute(model.generator, fields["tgt"].vocab)
+    optim = onmt.Optim("adam", 0.002, 5.0, lr_decay=0.5, start_decay_at=8)
+    optim.set_parameters(model.parameters())
+    trainer = onmt.TrainerMultimodal(model, train_loss, train_loss, optim, 0, 32, "text", "sents", 1, train_img_feats=table.numpy(),
+                                     valid_img_feats=table.numpy(), multimodal_model_type="vi-model1", model_opt=opt, fields=fields)
+    po, state = {k: v.clone() for k, v in p.items()}, {}
+    eng = model.engine
+    for bt in batches:
+        stats = trainer.train([_Batch(bt, "cuda")], 1, None)
+        ws = eng.workspace(B, S, T - 1)
+        eps = ws.eps.view().cpu().clone()
+        r, Lo, g = O.step_grads(po, c, bt["src"], bt["src_len"], bt["tgt"], table[bt["indices"]], eps, tgt_len=bt["tgt_len"])
+        assert abs(stats.elbo_loss - float(Lo["elbo"])) <= 3e-5 * abs(float(Lo["elbo"]))
+        assert abs(stats.td_kl_before - float(Lo["kl_before"])) <= 5e-5 * abs(float(Lo["kl_before"]))
+        po, _ = O.clip_and_adam(po, g, state, lr=0.002, max_grad_norm=5.0)
+    for k in ("gen_net_global.location.fc1.weight", "encoder_tgt.rnn.weight_hh_l0_reverse", "decoder.rnn.weight_hh_l0"):
+        d = (model.state_dict()[k].cpu() - po[k]).abs().max().item()
+        assert d < 5e-4, (k, d)
+    vs = trainer.validate([_Batch(batches[0], "cuda")])
+    assert np.isfinite(vs.ppl())
