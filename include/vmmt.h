@@ -260,6 +260,11 @@ int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const int64_t* sr
                        int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len, int64_t* o_idx, float* stats, float* eps,
                        int64_t n_eps, uint64_t seed, void* stream);
 
+/* ---- image-feature table ------------------------------------------------------------------------------------------
+ * In-place X[r][c] = (X[r][c] - mean[c]) / std[c] over the HBM-resident fp32 table [R][D] (row stride ld): the
+ * `-use_standardised_image_features` branch, train_mm_vi_model1.py:499-501 (there: numpy on the host, fp32). */
+int vmmt_standardise_rows(float* X, int64_t ld, const float* mean, const float* stdv, int64_t R, int D, void* stream);
+
 /* ---- optimiser: clip_grad_norm + Adam over a flat fp32 arena (onmt/Optim.py:68-70,94-96) -------------------------- */
 int vmmt_sumsq(const float* g, int64_t n, float* out /* += */, void* stream);
 /* max_blocks > 0 caps the grid (grid-stride loop): used for the half of the update that runs in the background */

@@ -69,9 +69,14 @@ class NMTVIModel(nn.Module):
         return out
 
     def set_image_tables(self, train=None, valid=None):
-        """image-feature arrays (numpy, [N, D] fp32) -> HBM-resident tables"""
+        """image-feature arrays -> HBM-resident tables.  Each may be a numpy array [N, D] (the reference's contract,
+        train_mm_vi_model1.py:468-469), a tensor already on the device (features.load_image_table), or the path of an
+        HDF5 file whose `/global_feats` node is streamed into HBM."""
         self._tables = getattr(self, "_tables", {})
         for k, v in (("train", train), ("valid", valid)):
+            if isinstance(v, str):
+                from ..features import load_image_table
+                v = load_image_table(v, "global_feats", device=self.engine.dev)
             if v is not None:
                 self._tables[k] = torch.as_tensor(v).to(device=self.engine.dev, dtype=torch.float32).contiguous()
 
