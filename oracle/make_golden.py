@@ -161,8 +161,87 @@ def run_greedy(name, ck, B, S, max_len, scale):
     print(name, "tokens", arrs["tokens"][:, :3].T.tolist())
 
 
+BEAM = {
+    # name: (cfg kwargs, B, S, max_len, weight scale, </s> bias, beam size, n_best, alpha, beta, min_length): beam search through
+    # the reference's OWN TranslatorMultimodalVI.translate_batch + Beam + GNMTGlobalScorer, one sentence at a time
+    # (translate_mm_vi.py:80-82 forces batch size 1)
+    "beam_bi_l1": (dict(vs=37, vt=41, emb=12, hid=16, z=8, layers=1, brnn=True), 6, 7, 12, 6.0, 0.7, 5, 3, 0.0, -0.0, 0),
+    "beam_cond_uni_l2": (dict(vs=43, vt=39, emb=10, hid=12, z=6, layers=2, brnn=False, conditional=True), 5, 8, 10, 6.0, 0.7,
+                         3, 1, 0.6, 0.2, 3),
+    "beam_bi_l2_alpha": (dict(vs=53, vt=47, emb=20, hid=24, z=12, layers=2, brnn=True), 5, 9, 11, 6.0, 0.9, 4, 2, 1.0, -0.0, 0),
+    "beam_bi_l1_k2": (dict(vs=37, vt=41, emb=12, hid=16, z=8, layers=1, brnn=True), 4, 6, 9, 5.0, 0.6, 2, 2, 0.0, -0.0, 0),
+}
+
+
+def run_beam(name, ck, B, S, max_len, scale, eos_bias, K, n_best, alpha, beta, min_length):
+    import types
+    onmt, _ = RH.import_reference()
+    import onmt.translate
+    c = O.Cfg(**ck)
+    opt = RH.make_opt(src_word_vec_size=c.emb, tgt_word_vec_size=c.emb, rnn_size=c.hid, z_latent_dim=c.z,
+                      enc_layers=c.layers, dec_layers=c.layers, encoder_type="brnn" if c.brnn else "rnn",
+                      dropout=0.0, conditional=bool(c.conditional))
+    model, fields = RH.build_model(opt, c.vs, c.vt, seed=0)
+    model.eval()
+    for k, v in model.named_parameters():
+        if "inf_net_image" not in k:
+            v.data.mul_(scale)
+    model.generator[0].bias.data[3] += eos_bias          # so that </s> reaches the beams after a few positions
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    bt = O.synth_batch(c, B, S, 5, n_img=8, seed=91 + len(name), fixed_len=False)
+    scorer = onmt.translate.GNMTGlobalScorer(alpha, beta)
+    tr = onmt.translate.TranslatorMultimodalVI(model, fields, beam_size=K, n_best=n_best, global_scorer=scorer,
+                                               max_length=max_len, copy_attn=False, cuda=False, min_length=min_length,
+                                               test_img_feats=bt["table"].numpy(), multimodal_model_type="vi-model1")
+    beams = []
+    from_beam = tr._from_beam
+    tr._from_beam = lambda bm: (beams.extend(bm), from_beam(bm))[1]
+    data = types.SimpleNamespace(data_type="text")
+    arrs = {"in_src": bt["src"].numpy(), "in_src_len": bt["src_len"].numpy()}
+    arrs.update({"p0_" + k: v.numpy() for k, v in sd.items() if "inf_net_image.scale" not in k and v.numel() <= O.BIG})
+    pred = -np.ones((B, n_best, max_len), dtype=np.int64)
+    plen = np.zeros((B, n_best), dtype=np.int64)
+    score = np.zeros((B, n_best), dtype=np.float32)
+    attn = np.zeros((B, n_best, max_len, S), dtype=np.float32)
+    steps = np.zeros(B, dtype=np.int64)
+    h_next = -np.ones((B, max_len + 1, K), dtype=np.int64)
+    h_prev = -np.ones((B, max_len, K), dtype=np.int64)
+    h_score = np.zeros((B, max_len, K), dtype=np.float32)
+    import warnings
+    warnings.simplefilter("ignore")
+    with RH.beam_shims(), torch.no_grad():
+        for b in range(B):
+            n = int(bt["src_len"][b])
+            batch = types.SimpleNamespace(src=(bt["src"][:n, b:b + 1], bt["src_len"][b:b + 1]), batch_size=1)
+            ret = tr.translate_batch(batch, data, b)
+            for i in range(n_best):
+                hyp = [int(t) for t in ret["predictions"][0][i]]
+                pred[b, i, :len(hyp)] = hyp
+                plen[b, i] = len(hyp)
+                score[b, i] = float(ret["scores"][0][i])
+                a = ret["attention"][0][i]
+                attn[b, i, :a.shape[0], :a.shape[1]] = a.numpy()
+            bm = beams[b]
+            steps[b] = len(bm.prev_ks)
+            for t, y in enumerate(bm.next_ys):
+                h_next[b, t] = y.numpy()
+            for t, (pk, sc) in enumerate(zip(bm.prev_ks, bm.all_scores[1:] + [bm.scores])):
+                h_prev[b, t] = pk.numpy()
+                h_score[b, t] = sc.numpy()
+    arrs.update(pred=pred, pred_len=plen, score=score, attention=attn, steps=steps, hist_next=h_next, hist_prev=h_prev,
+                hist_score=h_score, beam=np.array([K, n_best, min_length], dtype=np.int64),
+                scorer=np.array([alpha, beta], dtype=np.float64))
+    arrs["cfg"] = np.array([c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, int(c.brnn), B, S, max_len, int(c.conditional)], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print(name, "steps", steps.tolist(), "best", [pred[b, 0, :plen[b, 0]].tolist() for b in range(B)], score[:, 0].tolist())
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    for n, a in BEAM.items():
+        if only and n not in only:
+            continue
+        run_beam(n, *a)
     for n, (ck, B, S, ml, sc) in GREEDY.items():
         if only and n not in only:
             continue

@@ -16,6 +16,7 @@ carry no arithmetic for the training step, so tiny import stand-ins live in
   s5  criterion output reshaped to 1 element                    (onmt/VILoss.py:478,485)
   s6  (training/sharded path only) torch.split -> clones        (onmt/VILoss.py:570-580)
   s7  (training path only) out-of-place compute_cosine          (onmt/VILoss.py:43)   [semantic "A", see H1]
+  s8  (beam search only) integer tensor `/` -> floor division  (onmt/translate/Beam.py:101; torch 0.3 semantics)
 """
 import argparse
 import contextlib
@@ -183,6 +184,23 @@ def training_shims():
     finally:
         torch.split = real_split
         onmt.VILoss.compute_cosine = real_cos
+
+
+@contextlib.contextmanager
+def beam_shims():
+    """s8: `best_scores_id / num_words` on LongTensors was integer division under torch 0.3 (Beam.py:101)."""
+    real = torch.Tensor.__truediv__
+
+    def tdiv(self, other):
+        other_float = isinstance(other, float) or (torch.is_tensor(other) and other.is_floating_point())
+        if not self.is_floating_point() and not other_float:
+            return torch.div(self, other, rounding_mode="floor")
+        return real(self, other)
+    torch.Tensor.__truediv__ = tdiv
+    try:
+        yield
+    finally:
+        torch.Tensor.__truediv__ = real
 
 
 class Batch(object):

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import vi1_oracle as O
-from tests.golden_util import CASES, COND_CASES, GREEDY_CASES, load
+from tests.golden_util import CASES, COND_CASES, BEAM_CASES, GREEDY_CASES, load
 
 
 def _close(a, b, rtol=2e-5, atol=2e-6, what=""):
@@ -86,3 +86,25 @@ def test_greedy_decode(name):
     toks, scores = O.greedy_decode(p, c, bt["src"], bt["src_len"], max_len)
     assert torch.equal(toks, torch.from_numpy(z["tokens"]))
     _close(scores, z["scores"], what="log-prob of the chosen tokens", rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", BEAM_CASES)
+def test_beam_search(name):
+    """the reference's TranslatorMultimodalVI.translate_batch + Beam + GNMTGlobalScorer, one sentence at a time (fixture)
+    == the restatement: same beam contents at every position, same n-best lists, scores and attention"""
+    c, p, bt, z, (B, S, max_len) = load(name)
+    K, n_best, min_length = [int(x) for x in z["beam"]]
+    alpha, beta = [float(x) for x in z["scorer"]]
+    for b in range(B):
+        n = int(bt["src_len"][b])
+        r = O.beam_search(p, c, bt["src"][:n, b], K, n_best=n_best, max_len=max_len, alpha=alpha, beta=beta, min_length=min_length)
+        steps = int(z["steps"][b])
+        assert r["steps"] == steps
+        assert torch.equal(r["hist_next"], torch.from_numpy(z["hist_next"][b, :steps + 1]))
+        assert torch.equal(r["hist_prev"], torch.from_numpy(z["hist_prev"][b, :steps]))
+        _close(r["hist_score"], z["hist_score"][b, :steps], what="beam scores", rtol=1e-5, atol=1e-5)
+        for i in range(n_best):
+            m = int(z["pred_len"][b, i])
+            assert r["pred"][i] == z["pred"][b, i, :m].tolist()
+            assert abs(r["score"][i] - float(z["score"][b, i])) <= 1e-4
+            _close(r["attention"][i], z["attention"][b, i, :m, :n], what="attention", rtol=1e-4, atol=1e-6)
