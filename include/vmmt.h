@@ -260,6 +260,21 @@ int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const int64_t* sr
                        int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len, int64_t* o_idx, float* stats, float* eps,
                        int64_t n_eps, uint64_t seed, void* stream);
 
+/* ---- beam search (translation) --------------------------------------------------------------------------------
+ * One position of Beam.advance (onmt/translate/Beam.py:63-121) for all B sentences of a decoding batch of K*B rows
+ * (row = k*B + b, TranslatorMultimodalVI.py:105-108).  `logits` f32 [K*B][V] (generator output BEFORE log-softmax; the
+ * kernel applies it).  `scores` [B][K] in/out (Beam.scores), `cur_tok` [K*B] the tokens just fed (Beam.next_ys[-1]);
+ * first != 0: only beam 0 is scored (Beam.py:91-92); mask_eos != 0: word_probs[:, eos] = -1e20 (min_length, Beam.py:77-80).
+ * Outputs: next_tok [K*B] (next input rows), sel_rows [K*B] = parent row index prev_k*B + b (for vmmt_rows_select),
+ * and this position's history slots hist_score / hist_prev / hist_next [B][K].  Ties: lowest flat index.  K <= 16. */
+int vmmt_beam_advance(const float* logits, int64_t ld, int B, int K, int V, const int64_t* cur_tok, float* scores, int first,
+                      int mask_eos, int eos, int64_t* next_tok, int64_t* sel_rows, float* hist_score, int* hist_prev,
+                      int64_t* hist_next, void* stream);
+/* dst[r][0:row_bytes] = src[rows[r]][0:row_bytes] (byte strides; row_bytes even): re-orders decoder state rows by parent
+ * beam (RNNDecoderState.beam_update, onmt/Models.py:589-594).  src and dst must not overlap. */
+int vmmt_rows_select(const void* src, int64_t ld_src_bytes, const int64_t* rows, void* dst, int64_t ld_dst_bytes, int R,
+                     int row_bytes, void* stream);
+
 /* ---- image-feature table ------------------------------------------------------------------------------------------
  * In-place X[r][c] = (X[r][c] - mean[c]) / std[c] over the HBM-resident fp32 table [R][D] (row stride ld): the
  * `-use_standardised_image_features` branch, train_mm_vi_model1.py:499-501 (there: numpy on the host, fp32). */

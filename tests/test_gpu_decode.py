@@ -55,4 +55,4 @@ def test_translator_mirror_beam1():
         assert ret["predictions"][b][0] == col[:n]
         assert abs(ret["scores"][b][0] - float(z["scores"][:n, b].sum())) <= 1e-3
     with pytest.raises(NotImplementedError):
-        TranslatorMultimodalVI(model, fields, beam_size=5)
+        TranslatorMultimodalVI(model, fields, beam_size=5, copy_attn=True)

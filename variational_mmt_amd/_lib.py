@@ -85,6 +85,8 @@ _SIGS = {
     "vmmt_pack": (i32, [i32, vp, vp, i64, vp, i64, i32, i32, i32, vp]),
     "vmmt_pack_multi": (i32, [vp, i32, i32, vp]),
     "vmmt_prepare_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, u64, vp]),
+    "vmmt_beam_advance": (i32, [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "vmmt_rows_select": (i32, [vp, i64, vp, vp, i64, i32, i32, vp]),
     "vmmt_standardise_rows": (i32, [vp, i64, vp, vp, i64, i32, vp]),
     "vmmt_sumsq": (i32, [vp, i64, vp, vp]),
     "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp]),

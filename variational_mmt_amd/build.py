@@ -12,7 +12,7 @@ LIB = os.path.join(HERE, "libvmmt.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result"]
-SOURCES = ["gemm.hip", "lstm.hip", "attention.hip", "generator.hip", "elementwise.hip", "optim.hip", "runtime.hip", "conditional.hip", "table.hip"]
+SOURCES = ["gemm.hip", "lstm.hip", "attention.hip", "generator.hip", "elementwise.hip", "optim.hip", "runtime.hip", "conditional.hip", "table.hip", "beam.hip"]
 
 
 def _stale(out, deps):

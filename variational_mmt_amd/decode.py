@@ -1,7 +1,11 @@
-"""Step-wise decoding with beam size 1 on the MI355X kernels (first half): the loop of
-TranslatorMultimodalVI.translate_batch (onmt/translate/TranslatorMultimodalVI.py:114-200) -- encoder, z = E[q(z|x)] (fixed
-prior) or E[p(z|x)] (conditional, :128-131), then one target position at a time: embedding, LSTM step(s), global attention,
-generator, arg-max fed back -- issued through the same C-ABI as the training step.  Beam search proper (Beam.py) is not built."""
+"""Step-wise decoding on the MI355X kernels: the loop of TranslatorMultimodalVI.translate_batch
+(onmt/translate/TranslatorMultimodalVI.py:114-216) -- encoder, z = E[q(z|x)] (fixed prior) or E[p(z|x)] (conditional,
+:128-131), then one target position at a time: embedding, LSTM step(s), global attention, generator -- issued through the
+same C-ABI as the training step.  `greedy_decode`: beam size 1, arg-max fed back.  `beam_decode`: beam search proper; the
+device runs Beam.advance (vmmt_beam_advance) and the beam re-ordering of the decoder state (vmmt_rows_select) for all
+sentences of a batch with no host synchronisation inside a block of positions, and records every position's beam
+(scores, parents, tokens, attention); `onmt/translate/Beam.py` (host mirror) replays the records into the reference's
+bookkeeping (finished list, stopping rule, n-best extraction)."""
 import ctypes as C
 
 import torch
@@ -10,93 +14,204 @@ from . import _lib as L
 from .engine import Buf, KPAD, PAD, _ru
 
 
+class _Stepper(object):
+    """Buffers and launches of one decoder position for R rows (R = B for arg-max decoding, K*B for beam search).
+    State is double-buffered: a position reads set 0 (h of the lower layers, c, right half of cat[0]) and writes set 1."""
+
+    def __init__(self, eng, R, S, ctx, ctx_ld, src_len, zx, zx_ld):
+        self.eng, self.R, self.S = eng, R, S
+        d, dev, T, f32 = eng.d, eng.dev, eng.T, torch.float32
+        H, E, Lyr = d.hid, d.emb, d.layers
+        nb = lambda r, c, t=T: Buf(r, c, t, dev)
+        self.X = nb(R, E)
+        self.gx = [nb(R, 4 * H, f32) for _ in range(Lyr)]
+        self.gates = nb(R, 4 * H)
+        self.c = [[nb(R, H, f32), nb(R, H, f32)] for _ in range(Lyr)]
+        self.h = [[nb(R, H), nb(R, H)] for _ in range(Lyr - 1)]
+        self.cat = [nb(R, 2 * H), nb(R, 2 * H)]
+        self.Q, self.AH = nb(R, H), nb(R, H)
+        self.probs = torch.zeros(R * S, dtype=f32, device=dev)
+        self.ctx, self.ctx_ld, self.src_len, self.zx, self.zx_ld = ctx, ctx_ld, src_len, zx, zx_ld
+
+    def gemm(self, layout, A, lda, Bp, ldb, Cp, ldc, M, N, K, **kw):
+        e = self.eng
+        a = L.GemmArgs(e.dt, layout, A, lda, Bp, ldb, Cp, ldc, M, N, _ru(K, KPAD), 0, 0, kw.get("addend"), kw.get("ld_add", 0),
+                       kw.get("add_rows", 0), 0, kw.get("act", L.ACT_NONE), kw.get("out_f32", 0), 0, 1.0, None, PAD, 0, 0)
+        L.check(e.lib.vmmt_gemm(C.byref(a), e.stream()), "vmmt_gemm")
+
+    def h_buf(self, l, which):
+        """(buffer, column offset) of layer l's hidden state in set `which`"""
+        H = self.eng.d.hid
+        return (self.cat[which], H) if l == self.eng.d.layers - 1 else (self.h[l][which], 0)
+
+    def step(self, tok_ptr, t):
+        """tokens at `tok_ptr` (int64 [R]) -> AH = tanh(W_o [c ; h]) of this position, attention in self.probs; state 0 -> 1"""
+        e = self.eng
+        d, lib, dt, st, R = e.d, e.lib, e.dt, e.stream(), self.R
+        H, E, Lyr = d.hid, d.emb, d.layers
+        L.check(lib.vmmt_gather_rows(dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E, tok_ptr,
+                                     self.X.p(), self.X.ld, R, E, st), "vmmt_gather_rows")
+        x, xoff, xcols = self.X, 0, E
+        for l in range(Lyr):
+            gx = self.gx[l]
+            if l == 0:
+                we = e.sh["dec_wih_l0_e"]
+                self.gemm(L.GEMM_NT, x.p(0, xoff), x.ld, we.p(), we.ld, gx.p(), gx.ld, R, 4 * H, xcols, out_f32=1)
+            else:
+                wi, bs = e.sh["dec_wih_l%d" % l], e.sh["dec_b_l%d" % l]
+                self.gemm(L.GEMM_NT, x.p(0, xoff), x.ld, wi.p(), wi.ld, gx.p(), gx.ld, R, 4 * H, xcols, addend=bs.p(), ld_add=bs.ld,
+                          add_rows=1, out_f32=1)
+            arr = (L.LstmDirFwd * 2)()
+            a = arr[0]
+            hp, ho = self.h_buf(l, 0), self.h_buf(l, 1)
+            whh = e.sh["dec_whh_l%d" % l]
+            a.h_prev, a.ld_hprev = hp[0].p(0, hp[1]), hp[0].ld
+            a.c_prev, a.ld_cprev = self.c[l][0].p(), self.c[l][0].ld
+            a.w_hh, a.ld_w = whh.p(), whh.ld
+            a.gx, a.ld_gx = gx.p(), gx.ld
+            if l == 0:
+                a.gx2, a.ld_gx2 = self.zx, self.zx_ld            # z W_z^T + b_ih + b_hh, constant over the sentence
+            a.gates, a.ld_gates = self.gates.p(), self.gates.ld
+            a.c_out, a.ld_c = self.c[l][1].p(), self.c[l][1].ld
+            a.h_out, a.ld_h = ho[0].p(0, ho[1]), ho[0].ld
+            a.t, a.capture = t, 0
+            L.check(lib.vmmt_lstm_step_fwd(dt, 1, arr, None, R, H, st), "vmmt_lstm_step_fwd")
+            x, xoff, xcols = ho[0], ho[1], H
+        cat = self.cat[1]
+        wa, wo = e.sh["wa"], e.sh["wo"]
+        self.gemm(L.GEMM_NT, cat.p(0, H), cat.ld, wa.p(), wa.ld, self.Q.p(), self.Q.ld, R, H, H)
+        L.check(lib.vmmt_attn_fwd(dt, self.Q.p(), self.Q.ld, self.ctx, self.ctx_ld, self.src_len.data_ptr(), cat.p(), cat.ld,
+                                  self.probs.data_ptr(), 1, R, self.S, H, st), "vmmt_attn_fwd")
+        self.gemm(L.GEMM_NT, cat.p(), cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, R, H, 2 * H, act=L.ACT_TANH)
+
+    def carry(self, rows_ptr=None):
+        """state set 1 -> set 0 for the next position; `rows_ptr` (int64 [R]) selects each row's parent (beam re-ordering,
+        RNNDecoderState.beam_update, onmt/Models.py:589-594), None = identity"""
+        e = self.eng
+        H, Lyr, st = e.d.hid, e.d.layers, e.stream()
+        for l in range(Lyr):
+            pairs = [(self.h_buf(l, 1), self.h_buf(l, 0), e.tsz), ((self.c[l][1], 0), (self.c[l][0], 0), 4)]
+            for (sb, so), (db, do), esz in pairs:
+                if rows_ptr is None:
+                    db.t[:self.R, do:do + H].copy_(sb.t[:self.R, so:so + H])
+                else:
+                    L.check(e.lib.vmmt_rows_select(sb.p(0, so), sb.ld * esz, rows_ptr, db.p(0, do), db.ld * esz, self.R, H * esz, st),
+                            "vmmt_rows_select")
+
+
+def _encode(eng, src, src_len, bos):
+    """encoder + latent mean + z W_z^T: the evaluation-mode forward plan on a dummy 2-token target (its decoder step is ignored)"""
+    d, dev = eng.d, eng.dev
+    B = int(src.shape[1])
+    dummy = torch.tensor([[bos] * B, [3] * B], dtype=torch.int64)
+    tab = getattr(eng, "img_table", None)
+    if tab is None:
+        tab = torch.zeros(1, d.img, dtype=torch.float32, device=dev)        # the image row only feeds the training loss
+    return eng.forward(src, src_len, dummy, torch.zeros(B, dtype=torch.int64), training=False, table=tab,
+                       tgt_len=torch.full((B,), 2, dtype=torch.int64) if d.conditional else None)
+
+
 def greedy_decode(eng, src, src_len, max_len=50, bos=2):
     """src [S,B] int64, src_len [B] (sorted descending).  Returns (tokens [max_len,B] int64, log-probs [max_len,B] f32) on the
     device; every sentence runs max_len steps (cut at the first </s> on the host).  No host synchronisation inside."""
     d, lib, dt, dev = eng.d, eng.lib, eng.dt, eng.dev
     S, B = int(src.shape[0]), int(src.shape[1])
-    H, E, Z, V, Lyr = d.hid, d.emb, d.z, d.vt, d.layers
-    # encoder + latent mean + z W_z^T: the evaluation-mode forward plan on a dummy 2-token target (its decoder step is ignored)
-    dummy = torch.tensor([[bos] * B, [3] * B], dtype=torch.int64)
-    tab = getattr(eng, "img_table", None)
-    if tab is None:
-        tab = torch.zeros(1, d.img, dtype=torch.float32, device=dev)        # the image row only feeds the training loss
-    ws = eng.forward(src, src_len, dummy, torch.zeros(B, dtype=torch.int64), training=False, table=tab,
-                     tgt_len=torch.full((B,), 2, dtype=torch.int64) if d.conditional else None)
+    H, V, Lyr = d.hid, d.vt, d.layers
+    ws = _encode(eng, src, src_len, bos)
     st = eng.stream()
-    T, f32 = eng.T, torch.float32
+    f32 = torch.float32
     key = ("decode", B, S, max_len)
-    bufs = eng.ws.get(key)
-    if bufs is None:
-        nb = lambda r, c, t=T: Buf(r, c, t, dev)
-        bufs = dict(X=nb(B, E), gx=[nb(B, 4 * H, f32) for _ in range(Lyr)], gates=nb(B, 4 * H),
-                    c=[nb(B, H, f32) for _ in range(Lyr)], h=[[nb(B, H), nb(B, H)] for _ in range(Lyr - 1)],
-                    cat=[nb(B, 2 * H), nb(B, 2 * H)], Q=nb(B, H), AH=nb(B, H),
-                    probs=torch.zeros(B * S, dtype=f32, device=dev),
-                    tokens=torch.zeros(max_len + 1, B, dtype=torch.int64, device=dev),
-                    vmax=torch.zeros(max_len, B, dtype=f32, device=dev), lse=torch.zeros(max_len, B, dtype=f32, device=dev),
-                    npart=lib.vmmt_gen_npart(V))
-        n = bufs["npart"] * B
-        bufs.update(pm=torch.zeros(n, dtype=f32, device=dev), ps=torch.zeros(n, dtype=f32, device=dev),
-                    pi=torch.zeros(n, dtype=torch.int32, device=dev), tl=torch.zeros(B, dtype=f32, device=dev),
-                    nll=torch.zeros(B, dtype=f32, device=dev), stats=torch.zeros(L.STAT_COUNT, dtype=f32, device=dev))
-        eng.ws[key] = bufs
-    b = bufs
+    b = eng.ws.get(key)
+    ctx = ws.enc_out[Lyr - 1]
+    if b is None:
+        b = dict(tokens=torch.zeros(max_len + 1, B, dtype=torch.int64, device=dev),
+                 vmax=torch.zeros(max_len, B, dtype=f32, device=dev), lse=torch.zeros(max_len, B, dtype=f32, device=dev),
+                 npart=lib.vmmt_gen_npart(V))
+        n = b["npart"] * B
+        b.update(pm=torch.zeros(n, dtype=f32, device=dev), ps=torch.zeros(n, dtype=f32, device=dev),
+                 pi=torch.zeros(n, dtype=torch.int32, device=dev), tl=torch.zeros(B, dtype=f32, device=dev),
+                 nll=torch.zeros(B, dtype=f32, device=dev), stats=torch.zeros(L.STAT_COUNT, dtype=f32, device=dev))
+        b["stepper"] = _Stepper(eng, B, S, None, 0, None, None, 0)
+        eng.ws[key] = b
+    sp = b["stepper"]
+    sp.ctx, sp.ctx_ld, sp.src_len, sp.zx, sp.zx_ld = ctx.p(), ctx.ld, ws.src_len, ws.zx.p(), ws.zx.ld
     tokens = b["tokens"]
     tokens[0].fill_(bos)
-
-    def gemm(layout, A, lda, Bp, ldb, Cp, ldc, M, N, K, **kw):
-        a = L.GemmArgs(dt, layout, A, lda, Bp, ldb, Cp, ldc, M, N, _ru(K, KPAD), 0, 0, kw.get("addend"), kw.get("ld_add", 0),
-                       kw.get("add_rows", 0), 0, kw.get("act", L.ACT_NONE), kw.get("out_f32", 0), 0, 1.0, None, PAD, 0, 0)
-        L.check(lib.vmmt_gemm(C.byref(a), st), "vmmt_gemm")
-
-    # decoder state: h0 / c0 = encoder final states (Models.py:1158-1165); top layer's h lives in the right half of `cat`
+    # decoder state: h0 / c0 = encoder final states (Models.py:1158-1165)
     for l in range(Lyr):
-        b["c"][l].view().copy_(ws.cn[l].view())
-        (b["cat"][0].view()[:, H:] if l == Lyr - 1 else b["h"][l][0].view()).copy_(ws.hn[l].view())
-    ctx = ws.enc_out[Lyr - 1]
-    wa, wo, wg, we = eng.sh["wa"], eng.sh["wo"], eng.sh["wg"], eng.sh["dec_wih_l0_e"]
-    esz = eng.tsz
+        sp.c[l][0].view().copy_(ws.cn[l].view())
+        hb, ho = sp.h_buf(l, 0)
+        hb.t[:B, ho:ho + H].copy_(ws.hn[l].view())
+    wg = eng.sh["wg"]
     for t in range(max_len):
-        cur, nxt = t & 1, (t + 1) & 1
-        L.check(lib.vmmt_gather_rows(dt, eng.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                                     tokens.data_ptr() + 8 * t * B, b["X"].p(), b["X"].ld, B, E, st), "vmmt_gather_rows")
-        x, xcols = b["X"], E
-        for l in range(Lyr):
-            top = l == Lyr - 1
-            if l == 0:
-                gemm(L.GEMM_NT, x.p(), x.ld, we.p(), we.ld, b["gx"][l].p(), b["gx"][l].ld, B, 4 * H, xcols, out_f32=1)
-            else:
-                wi, bs = eng.sh["dec_wih_l%d" % l], eng.sh["dec_b_l%d" % l]
-                gemm(L.GEMM_NT, x.p(), x.ld, wi.p(), wi.ld, b["gx"][l].p(), b["gx"][l].ld, B, 4 * H, xcols, addend=bs.p(),
-                     ld_add=bs.ld, add_rows=1, out_f32=1)
-            arr = (L.LstmDirFwd * 2)()
-            a = arr[0]
-            hp = (b["cat"][cur], H) if top else (b["h"][l][cur], 0)
-            ho = (b["cat"][nxt], H) if top else (b["h"][l][nxt], 0)
-            whh = eng.sh["dec_whh_l%d" % l]
-            a.h_prev, a.ld_hprev = hp[0].p(0, hp[1]), hp[0].ld
-            a.c_prev, a.ld_cprev = b["c"][l].p(), b["c"][l].ld
-            a.w_hh, a.ld_w = whh.p(), whh.ld
-            a.gx, a.ld_gx = b["gx"][l].p(), b["gx"][l].ld
-            if l == 0:
-                a.gx2, a.ld_gx2 = ws.zx.p(), ws.zx.ld          # z W_z^T + b_ih + b_hh, constant over the sentence
-            a.gates, a.ld_gates = b["gates"].p(), b["gates"].ld
-            a.c_out, a.ld_c = b["c"][l].p(), b["c"][l].ld      # in place: a lane reads its own c_prev before it writes
-            a.h_out, a.ld_h = ho[0].p(0, ho[1]), ho[0].ld
-            a.t, a.capture = t, 0
-            L.check(lib.vmmt_lstm_step_fwd(dt, 1, arr, None, B, H, st), "vmmt_lstm_step_fwd")
-            x, xcols = ho[0], H
-            xoff = ho[1]
-        cat = b["cat"][nxt]
-        gemm(L.GEMM_NT, cat.p(0, H), cat.ld, wa.p(), wa.ld, b["Q"].p(), b["Q"].ld, B, H, H)
-        L.check(lib.vmmt_attn_fwd(dt, b["Q"].p(), b["Q"].ld, ctx.p(), ctx.ld, ws.src_len.data_ptr(), cat.p(), cat.ld,
-                                  b["probs"].data_ptr(), 1, B, S, H, st), "vmmt_attn_fwd")
-        gemm(L.GEMM_NT, cat.p(), cat.ld, wo.p(), wo.ld, b["AH"].p(), b["AH"].ld, B, H, 2 * H, act=L.ACT_TANH)
-        L.check(lib.vmmt_gen_loss_fwd(dt, wg.p(), wg.ld, eng.pp("generator.0.bias"), b["AH"].p(), b["AH"].ld,
+        sp.step(tokens.data_ptr() + 8 * t * B, t)
+        L.check(lib.vmmt_gen_loss_fwd(dt, wg.p(), wg.ld, eng.pp("generator.0.bias"), sp.AH.p(), sp.AH.ld,
                                       tokens.data_ptr() + 8 * t * B, B, V, _ru(H, KPAD), PAD, b["pm"].data_ptr(), b["ps"].data_ptr(),
                                       b["pi"].data_ptr(), b["tl"].data_ptr(), b["lse"].data_ptr() + 4 * t * B, b["nll"].data_ptr(),
                                       b["stats"].data_ptr(), st), "vmmt_gen_loss_fwd")
         L.check(lib.vmmt_gen_argmax(b["pm"].data_ptr(), b["pi"].data_ptr(), B, b["npart"], tokens.data_ptr() + 8 * (t + 1) * B,
                                     b["vmax"].data_ptr() + 4 * t * B, st), "vmmt_gen_argmax")
+        sp.carry()
     return tokens[1:], b["vmax"] - b["lse"]
+
+
+def beam_decode(eng, src, src_len, beam_size, max_len=100, min_length=0, bos=2, eos=3, pad=PAD, stop=None, check_every=8):
+    """Beam search over a batch: src [S,B] int64, src_len [B] (sorted descending).  Runs positions 0 .. max_len-1 on the device
+    (rows k*B + b) and returns the per-position records as HOST tensors:
+        scores [n,B,K] f32, prev [n,B,K] int32, next [n,B,K] int64, attn [n,K*B,S] f32       (n = positions run)
+    `stop(records) -> bool` is consulted every `check_every` positions (one device-to-host copy each time) so that the loop
+    ends once every sentence's beam is done (Beam.done, evaluated by the host mirror)."""
+    d, lib, dt, dev = eng.d, eng.lib, eng.dt, eng.dev
+    S, B, K = int(src.shape[0]), int(src.shape[1]), int(beam_size)
+    if not 1 <= K <= 16:
+        raise ValueError("beam_size %d outside 1..16" % K)
+    H, V, Lyr = d.hid, d.vt, d.layers
+    R = K * B
+    ws = _encode(eng, src, src_len, bos)
+    st = eng.stream()
+    f32, i64 = torch.float32, torch.int64
+    key = ("beam", B, S, K, max_len)
+    b = eng.ws.get(key)
+    if b is None:
+        b = dict(stepper=_Stepper(eng, R, S, None, 0, None, None, 0),
+                 ctx=Buf(S * R, H, eng.T, dev), zx=Buf(R, 4 * H, f32, dev), src_len=torch.zeros(R, dtype=i64, device=dev),
+                 logits=Buf(R, V, f32, dev), tok=torch.zeros(2, R, dtype=i64, device=dev), sel=torch.zeros(R, dtype=i64, device=dev),
+                 scores=torch.zeros(B, K, dtype=f32, device=dev), h_score=torch.zeros(max_len, B, K, dtype=f32, device=dev),
+                 h_prev=torch.zeros(max_len, B, K, dtype=torch.int32, device=dev),
+                 h_next=torch.zeros(max_len, B, K, dtype=i64, device=dev), h_attn=torch.zeros(max_len, R, S, dtype=f32, device=dev))
+        eng.ws[key] = b
+    sp = b["stepper"]
+    # (2) repeat the source-side objects beam_size times (TranslatorMultimodalVI.py:141-157): row k*B + b <- sentence b
+    enc = ws.enc_out[Lyr - 1]
+    b["ctx"].t[:S * R].view(S, K, B, -1).copy_(enc.t[:S * B].view(S, 1, B, -1).expand(S, K, B, enc.ld))
+    b["zx"].t[:R].view(K, B, -1).copy_(ws.zx.t[:B].unsqueeze(0).expand(K, B, ws.zx.ld))
+    b["src_len"].view(K, B).copy_(ws.src_len.view(1, B).expand(K, B))
+    sp.ctx, sp.ctx_ld, sp.src_len, sp.zx, sp.zx_ld = b["ctx"].p(), b["ctx"].ld, b["src_len"], b["zx"].p(), b["zx"].ld
+    for l in range(Lyr):
+        sp.c[l][0].t[:R].view(K, B, -1).copy_(ws.cn[l].t[:B].unsqueeze(0).expand(K, B, ws.cn[l].ld))
+        hb, ho = sp.h_buf(l, 0)
+        hb.t[:R, ho:ho + H].view(K, B, H).copy_(ws.hn[l].view().unsqueeze(0).expand(K, B, H))
+    tok = b["tok"]
+    tok[0].fill_(pad)                         # Beam.__init__: next_ys[0] = [bos, pad, pad, ...] (Beam.py:34-36)
+    tok[0, :B].fill_(bos)
+    b["scores"].zero_()
+    wg, lg = eng.sh["wg"], b["logits"]
+    bias = eng.pp("generator.0.bias")
+    n = 0
+    for t in range(max_len):
+        cur, nxt = tok[t & 1], tok[(t + 1) & 1]
+        sp.step(cur.data_ptr(), t)
+        sp.gemm(L.GEMM_NT, sp.AH.p(), sp.AH.ld, wg.p(), wg.ld, lg.p(), lg.ld, R, V, H, addend=bias, ld_add=0, add_rows=1, out_f32=1)
+        L.check(lib.vmmt_beam_advance(lg.p(), lg.ld, B, K, V, cur.data_ptr(), b["scores"].data_ptr(), int(t == 0),
+                                      int(t + 1 < min_length), eos, nxt.data_ptr(), b["sel"].data_ptr(),
+                                      b["h_score"][t].data_ptr(), b["h_prev"][t].data_ptr(), b["h_next"][t].data_ptr(), st),
+                "vmmt_beam_advance")
+        b["h_attn"][t].view(-1).copy_(sp.probs)
+        sp.carry(b["sel"].data_ptr())
+        n = t + 1
+        if stop is not None and (n % check_every == 0 or n == max_len):
+            rec = dict(scores=b["h_score"][:n].cpu(), prev=b["h_prev"][:n].cpu(), next=b["h_next"][:n].cpu(), attn=None)
+            if stop(rec):
+                break
+    return dict(scores=b["h_score"][:n].cpu(), prev=b["h_prev"][:n].cpu(), next=b["h_next"][:n].cpu(),
+                attn=b["h_attn"][:n].cpu().view(n, K, B, S), src_len=ws.src_len.cpu())
