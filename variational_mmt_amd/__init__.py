@@ -11,7 +11,7 @@ def install_as_onmt():
     pkg = importlib.import_module("variational_mmt_amd.onmt")
     sys.modules["onmt"] = pkg
     for sub in ("io", "Utils", "Loss", "Models", "ModelConstructor", "Optim", "Trainer", "TrainerMultimodal", "VILoss",
-                "modules", "modules.Dists", "translate", "translate.Beam", "translate.TranslatorMultimodalVI", "h5tables"):
+                "modules", "modules.Dists", "translate", "translate.Beam", "translate.TranslatorMultimodalVI", "h5tables", "bleu", "EarlyStop", "translate.translate_file"):
         sys.modules["onmt." + sub] = importlib.import_module("variational_mmt_amd.onmt." + sub)
     for mod, names in (("Optim", ("Optim", "_ArenaAdam")), ("TrainerMultimodal", ("TrainerMultimodal", "VIStatistics")),
                        ("Trainer", ("Statistics",))):

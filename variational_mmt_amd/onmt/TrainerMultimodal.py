@@ -5,6 +5,8 @@ device from `batch.indices` (reference: host fancy-index + H2D per step, :632-63
 are read back only when they are printed or queried (reference: `.data.clone()` syncs every step)."""
 import math
 import os
+import pickle
+import shutil
 import sys
 import tempfile
 import time
@@ -109,13 +111,13 @@ class VIStatistics(object):
 
 
 class _NoEarlyStop(object):
-    """BLEU/METEOR early stopping (onmt/EarlyStop.py) spawns translate + perl/java subprocesses: out of scope
-    (SURVEY.md 8f-4).  Perplexity-driven learning-rate decay (Optim.update_learning_rate) is unaffected."""
+    """stand-in when no model options are given (tests, benchmarks): perplexity criterion, nothing to evaluate"""
 
     def __init__(self, criteria, every):
         self.early_stop_criteria = criteria
         self.evaluate_every_nupdates = every
         self.signal_early_stopping = False
+        self.results_bleu, self.results_meteor = {}, {}
 
 
 class TrainerMultimodal(object):
@@ -129,9 +131,16 @@ class TrainerMultimodal(object):
         self.model_updates = model_updates
         self.model_opt, self.fields = model_opt, fields
         crit = getattr(model_opt, "early_stopping_criteria", "perplexity") if model_opt is not None else "perplexity"
-        if crit not in (None, "perplexity"):
-            raise NotImplementedError("early stopping on %s needs the translate/BLEU pipeline (SURVEY.md 8f-4)" % crit)
-        self.early_stop = _NoEarlyStop(crit, getattr(model_opt, "evaluate_every_n_model_updates", 500) if model_opt else 500)
+        if model_opt is not None and crit not in (None, "perplexity"):
+            # TrainerMultimodal.py:281-288
+            from .EarlyStop import EarlyStop
+            self.early_stop = EarlyStop(model_opt.src, model_opt.tgt, crit, model_opt.start_early_stopping_at,
+                                        model_opt.evaluate_every_n_model_updates, model_opt.patience,
+                                        multimodal_model_type=multimodal_model_type,
+                                        img_fname=model_opt.path_to_valid_img_feats, gpuid=getattr(model_opt, "gpuid", 0))
+            self.early_stop.attach_model(model, fields)
+        else:
+            self.early_stop = _NoEarlyStop(crit, getattr(model_opt, "evaluate_every_n_model_updates", 500) if model_opt else 500)
         self.n_model_updates = 0
         self._epoch = 0
         assert train_img_feats is not None and valid_img_feats is not None, "Must provide training/validation image features!"
@@ -175,6 +184,19 @@ class TrainerMultimodal(object):
                 report_stats = report_func(epoch, idx, num_batches, total_stats.start_time, self.optim.lr, report_stats,
                                            self.multimodal_model_type)
             self.n_model_updates += 1
+            # BLEU / METEOR model selection and early stopping (TrainerMultimodal.py:372-396)
+            if self.early_stop.early_stop_criteria not in (None, "perplexity") and \
+                    self.n_model_updates % self.early_stop.evaluate_every_nupdates == 0:
+                tmp_fname, final_fname = self.drop_checkpoint(self.model_opt, epoch, self.fields, valid_stats=None, overwrite=True,
+                                                              checkpoint_type="best", temporary=True)
+                if self.early_stop.add_run(tmp_fname, self.n_model_updates):
+                    self.drop_metric_scores(self.model_opt, epoch, self.fields, valid_stats=None, overwrite=True,
+                                            checkpoint_type="best")
+                    shutil.move(tmp_fname, final_fname)
+                else:
+                    os.unlink(tmp_fname)
+                if self.early_stop.signal_early_stopping:
+                    break
         return total_stats
 
     def validate(self, valid_iter):
@@ -223,7 +245,10 @@ class TrainerMultimodal(object):
         if not overwrite:
             fname = "%s_acc_%.2f_ppl_%.2f_e%d.pt" % (opt.save_model, valid_stats.accuracy(), valid_stats.ppl(), epoch)
         elif checkpoint_type == "best":
-            raise NotImplementedError("best-model checkpoints belong to BLEU/METEOR early stopping (SURVEY.md 8f-4)")
+            crit = self.early_stop.early_stop_criteria
+            if crit not in ("bleu", "meteor"):
+                raise Exception("Metric not supported.")
+            fname = "%s_BestModel%s.pt" % (opt.save_model, crit.capitalize())
         else:
             fname = "%s_MostCurrentModel.pt" % opt.save_model
         if temporary:
@@ -232,4 +257,33 @@ class TrainerMultimodal(object):
             torch.save(checkpoint, tf.name)
             return tf.name, fname
         torch.save(checkpoint, fname)
+        return fname
+
+
+    def drop_metric_scores(self, opt, epoch, fields, valid_stats, overwrite=False, checkpoint_type="last"):
+        """TrainerMultimodal.py:491-551: pickle of the metric scores next to the checkpoint -- for 'best' the best BLEU / METEOR
+        and the number of model updates that produced it (`<save_model>_BestModel<Metric>.pkl`), for 'last' every score so far
+        (`<save_model>_MostCurrentModel.pkl`)."""
+        assert checkpoint_type in ("last", "best")
+        es = self.early_stop
+        rec = {}
+        if checkpoint_type == "best":
+            if es.early_stop_criteria == "bleu":
+                metric, table, other = "bleu", es.results_bleu, es.results_meteor
+            elif es.early_stop_criteria == "meteor":
+                metric, table, other = "meteor", es.results_meteor, es.results_bleu
+            else:
+                raise Exception("Metric not supported.")
+            n_best, best = sorted(table.items(), key=lambda kv: (kv[1], kv[0]))[-1]
+            rec["n_updates"] = n_best
+            rec[metric] = float(best)
+            rec["meteor" if metric == "bleu" else "bleu"] = float(other[n_best])
+            fname = "%s_BestModel%s.pkl" % (opt.save_model, metric.capitalize())
+        else:
+            fname = "%s_MostCurrentModel.pkl" % opt.save_model
+            rec["n_updates"] = self.n_model_updates
+            rec["bleu"] = list(es.results_bleu.values())
+            rec["meteor"] = list(es.results_meteor.values())
+        with open(fname, "wb") as f:
+            pickle.dump(rec, f, pickle.HIGHEST_PROTOCOL)
         return fname
