@@ -95,6 +95,15 @@ def main():
         f.create_array(f.root, "node_%02d" % i, np.full((2, 3), i, dtype=np.int32))
     f.close()
 
+    # 8. a table of the model's real width (2048) for the end-to-end driver-flow test: coarse values so that zlib + shuffle
+    #    keep the fixture small
+    p = os.path.join(OUT, "pt_feats2048.h5")
+    f = tables.open_file(p, "w")
+    c = f.create_carray(f.root, "global_feats", tables.Float32Atom(), (60, 2048), chunkshape=(16, 2048),
+                        filters=tables.Filters(complevel=9, complib="zlib", shuffle=True))
+    c[:] = (np.random.RandomState(13).randint(0, 48, size=(60, 2048)) / 16.0).astype(np.float32)
+    f.close()
+
     # expected contents through libhdf5's own reader
     for fn in sorted(os.listdir(OUT)):
         if not fn.endswith(".h5"):

@@ -1,5 +1,5 @@
-"""The slice of onmt.io the training step touches: special tokens, make_features, vocab (de)serialisation.
-The torchtext pipeline itself (datasets, iterators) is out of scope."""
+"""The slice of onmt.io the training driver touches: special tokens, make_features, vocab (de)serialisation, and the
+torchtext-free dataset / iterator classes of textdata.py."""
 from collections import defaultdict
 
 import torch
@@ -37,16 +37,18 @@ def save_fields_to_vocab(fields):
     return out
 
 
-class Field(object):
-    """minimal stand-in for a torchtext Field: only `.vocab` is used on this path."""
-
-    def __init__(self, vocab=None):
-        self.vocab = vocab
+from .textdata import (Batch, Example, Field, OrderedIterator, RandomShuffler, TextDataset, Vocab, batch, get_fields,  # noqa: E402,F401
+                       load_dataset, load_vocab, pool)
 
 
 def load_fields_from_vocab(vocab, data_type="text"):
-    fields = {}
-    for k, v in dict(vocab).items():
+    """onmt/io/IO.py:51-66: Field objects for src / tgt / indices with the saved vocabularies attached"""
+    vocab = dict(vocab)
+    fields = get_fields(len([k for k in vocab if k.startswith("src_feat_")]), len([k for k in vocab if k.startswith("tgt_feat_")]))
+    for k, v in vocab.items():
         v.stoi = defaultdict(lambda: 0, v.stoi)
-        fields[k] = Field(v)
+        if k in fields:
+            fields[k].vocab = v
+        else:
+            fields[k] = Field(vocab=v)
     return fields

@@ -1,0 +1,319 @@
+"""The batching side of the training driver without torchtext: what `onmt.io.OrderedIterator` (onmt/io/IO.py:382-393) and
+the torchtext 0.2.3 classes underneath it (requirements.txt: torchtext==0.2.3 -- NOT vendored in the reference, absent from
+this image) do for a text dataset, restated from that release's published source:
+
+  Example      attribute bag (src / tgt token tuples, indices)                      torchtext/data/example.py
+  Vocab        itos / stoi (defaultdict -> <unk> = 0) / freqs                       torchtext/vocab.py + onmt/io/IO.py:17-27
+  Field        pad (+ <s> / </s>), numericalise, lengths                            torchtext/data/field.py  (pad, numericalize)
+  batch, pool  fixed-size or token-budget batches; pools of 100 batches sorted by
+               length, batched, batches shuffled                                    torchtext/data/iterator.py
+  RandomShuffler   a private `random` state, `random.sample(data, len(data))`       torchtext/data/utils.py
+  Iterator / OrderedIterator / Batch                                                torchtext/data/iterator.py, batch.py
+
+Parity is UNPINNED for the torchtext part (no torchtext here to produce golden batches); tests check the restated rules on
+their own terms (tests/test_textdata.py).  The pickle layout of `.train.N.pt` / `.vocab.pt` files IS pinned: a fixture is
+written by the reference's own `onmt.io.TextDataset` / `save_fields_to_vocab` (oracle/make_textdata_golden.py).
+`load_dataset` / `load_vocab` read those files by mapping the pickled class names onto the classes below, so neither
+torchtext nor the reference has to be importable."""
+import math
+import pickle
+import random
+from collections import Counter, defaultdict  # noqa: F401
+from contextlib import contextmanager
+
+import torch
+
+PAD_WORD, UNK_WORD, BOS_WORD, EOS_WORD = "<blank>", "<unk>", "<s>", "</s>"
+
+
+class Example(object):
+    pass
+
+
+def _zero():
+    return 0
+
+
+class Vocab(object):
+    """`stoi` answers 0 (<unk>) for unknown words (onmt/io/IO.py:21-23)."""
+
+    def __init__(self, itos=None, freqs=None):
+        self.itos = list(itos or [])
+        self.freqs = freqs if freqs is not None else Counter()
+        self.stoi = defaultdict(_zero, {w: i for i, w in enumerate(self.itos)})
+        self.vectors = None
+
+    def __getstate__(self):
+        return dict(self.__dict__, stoi=dict(self.stoi))
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.stoi = defaultdict(_zero, self.stoi)
+
+    def __len__(self):
+        return len(self.itos)
+
+
+class Field(object):
+    """The slice of torchtext.data.Field this path uses (sequential text with a vocabulary, or a plain integer per example)."""
+
+    def __init__(self, sequential=True, use_vocab=True, init_token=None, eos_token=None, pad_token="<pad>", include_lengths=False,
+                 vocab=None):
+        self.sequential, self.use_vocab = sequential, use_vocab
+        self.init_token, self.eos_token, self.pad_token = init_token, eos_token, pad_token
+        self.include_lengths = include_lengths
+        if vocab is not None:                     # like torchtext: the attribute exists only once a vocabulary is attached
+            self.vocab = vocab
+
+    def pad(self, minibatch):
+        minibatch = list(minibatch)
+        if not self.sequential:
+            return minibatch
+        max_len = max(len(x) for x in minibatch)
+        padded, lengths = [], []
+        for x in minibatch:
+            row = ([] if self.init_token is None else [self.init_token]) + list(x[:max_len]) + \
+                  ([] if self.eos_token is None else [self.eos_token]) + [self.pad_token] * max(0, max_len - len(x))
+            padded.append(row)
+            lengths.append(len(row) - max(0, max_len - len(x)))
+        return (padded, lengths) if self.include_lengths else padded
+
+    def numericalize(self, arr, device=None):
+        lengths = None
+        if self.include_lengths:
+            arr, lengths = arr
+            lengths = torch.tensor(lengths, dtype=torch.int64)
+        if self.use_vocab:
+            arr = [[self.vocab.stoi[w] for w in ex] for ex in arr] if self.sequential else [self.vocab.stoi[x] for x in arr]
+        t = torch.tensor(arr, dtype=torch.int64)
+        if self.sequential:
+            t = t.t().contiguous()                      # [len, batch]
+        if device is not None and device != -1:
+            t = t.to(device)
+            lengths = lengths.to(device) if lengths is not None else None
+        return (t, lengths) if self.include_lengths else t
+
+    def process(self, batch, device=None, train=True):
+        return self.numericalize(self.pad(batch), device=device)
+
+
+def get_fields(n_src_features=0, n_tgt_features=0):
+    """TextDataset.get_fields (onmt/io/TextDataset.py:180-240) without the copy-attention fields (src_map, alignment)."""
+    if n_src_features or n_tgt_features:
+        raise NotImplementedError("word features are outside the VI_Model1 path")
+    return {"src": Field(pad_token=PAD_WORD, include_lengths=True),
+            "tgt": Field(init_token=BOS_WORD, eos_token=EOS_WORD, pad_token=PAD_WORD, include_lengths=True),
+            "indices": Field(use_vocab=False, sequential=False)}
+
+
+class TextDataset(object):
+    """What a `.train.N.pt` / `.valid.N.pt` file holds (onmt/io/TextDataset.py:16-86, preprocess.py:97-110: `fields` emptied
+    before saving)."""
+    data_type = "text"
+
+    def __init__(self, examples=None, fields=None):
+        self.examples = list(examples or [])
+        self.fields = fields if fields is not None else []
+        self.data_type = "text"
+        self.src_vocabs = []
+        self.n_src_feats = self.n_tgt_feats = 0
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+
+    @staticmethod
+    def sort_key(ex):
+        return len(ex.src)
+
+    def __len__(self):
+        return len(self.examples)
+
+    def __getitem__(self, i):
+        return self.examples[i]
+
+    def __iter__(self):
+        return iter(self.examples)
+
+    def load_fields(self, vocab_dict):
+        """ONMTDatasetBase.load_fields (onmt/io/DatasetBase.py:35-46)"""
+        from . import load_fields_from_vocab
+        fields = load_fields_from_vocab(dict(vocab_dict).items(), self.data_type)
+        self.fields = dict((k, f) for k, f in fields.items() if k in self.examples[0].__dict__)
+
+
+# ---- reading the reference's pickles -----------------------------------------------------------------------------------
+_CLASS_MAP = {
+    ("onmt.io.TextDataset", "TextDataset"): TextDataset,
+    ("onmt.io.DatasetBase", "ONMTDatasetBase"): TextDataset,
+    ("torchtext.data.example", "Example"): Example,
+    ("torchtext.data", "Example"): Example,
+    ("torchtext.vocab", "Vocab"): Vocab,
+    ("torchtext.data.dataset", "Dataset"): TextDataset,
+    ("torchtext.data", "Dataset"): TextDataset,
+}
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        hit = _CLASS_MAP.get((module, name))
+        if hit is not None:
+            return hit
+        if module.startswith("torchtext") or module.startswith("onmt."):
+            raise pickle.UnpicklingError("%s.%s is not part of the text-dataset pickles this loader reads" % (module, name))
+        return super(_Unpickler, self).find_class(module, name)
+
+
+class _PickleModule(object):
+    """the `pickle_module` argument of torch.load (both the legacy and the zip container call .Unpickler / .load)"""
+    __name__ = "pickle"
+    Unpickler = _Unpickler
+    HIGHEST_PROTOCOL = pickle.HIGHEST_PROTOCOL
+
+    @staticmethod
+    def load(f, **kw):
+        return _Unpickler(f, **kw).load()
+
+    @staticmethod
+    def loads(b, **kw):
+        import io
+        return _Unpickler(io.BytesIO(b), **kw).load()
+
+
+def load_dataset(path):
+    """`torch.load(pt_file)` of lazily_load_dataset (train_mm_vi_model1.py:372-376) -> TextDataset"""
+    ds = torch.load(path, map_location="cpu", pickle_module=_PickleModule, weights_only=False)
+    if not isinstance(ds, TextDataset):
+        raise TypeError("%s holds a %s, not a text dataset" % (path, type(ds).__name__))
+    return ds
+
+
+def load_vocab(path):
+    """`torch.load(opt.data + '.vocab.pt')` (train_mm_vi_model1.py:393) -> list of (name, Vocab)"""
+    return torch.load(path, map_location="cpu", pickle_module=_PickleModule, weights_only=False)
+
+
+# ---- batching (torchtext/data/iterator.py, utils.py) -------------------------------------------------------------------
+def batch(data, batch_size, batch_size_fn=None):
+    """consecutive examples until `batch_size_fn` reaches the budget; an example that overshoots opens the next batch"""
+    if batch_size_fn is None:
+        batch_size_fn = lambda new, count, sofar: count      # noqa: E731
+    minibatch, size_so_far = [], 0
+    for ex in data:
+        minibatch.append(ex)
+        size_so_far = batch_size_fn(ex, len(minibatch), size_so_far)
+        if size_so_far == batch_size:
+            yield minibatch
+            minibatch, size_so_far = [], 0
+        elif size_so_far > batch_size:
+            yield minibatch[:-1]
+            minibatch, size_so_far = minibatch[-1:], batch_size_fn(ex, 1, 0)
+    if minibatch:
+        yield minibatch
+
+
+class RandomShuffler(object):
+    """shuffles with a private copy of the `random` module's state (the global state is put back afterwards)"""
+
+    def __init__(self, random_state=None):
+        self._random_state = random_state if random_state is not None else random.getstate()
+
+    @contextmanager
+    def use_internal_state(self):
+        old = random.getstate()
+        random.setstate(self._random_state)
+        yield
+        self._random_state = random.getstate()
+        random.setstate(old)
+
+    @property
+    def random_state(self):
+        return self._random_state
+
+    @random_state.setter
+    def random_state(self, s):
+        self._random_state = s
+
+    def __call__(self, data):
+        with self.use_internal_state():
+            data = list(data)
+            return random.sample(data, len(data))
+
+
+def pool(data, batch_size, key, batch_size_fn=None, random_shuffler=None):
+    """pools of 100 batches: sort each pool by `key`, cut it into batches, shuffle the batches of the pool"""
+    if random_shuffler is None:
+        random_shuffler = lambda x: random.sample(list(x), len(list(x)))      # noqa: E731
+    for p in batch(data, batch_size * 100, batch_size_fn):
+        for b in random_shuffler(list(batch(sorted(p, key=key), batch_size, batch_size_fn))):
+            yield b
+
+
+class Batch(object):
+    """src = (ids [S,B], lengths [B]), tgt = (ids [T,B] with <s> / </s>, lengths [B]), indices [B]"""
+
+    def __init__(self, data=None, dataset=None, device=None, train=True):
+        if data is not None:
+            self.batch_size = len(data)
+            self.dataset = dataset
+            self.train = train
+            for name, field in dataset.fields.items():
+                if field is not None:
+                    setattr(self, name, field.process([x.__dict__[name] for x in data], device=device, train=train))
+
+
+class OrderedIterator(object):
+    """onmt.io.OrderedIterator over torchtext.data.Iterator: training = shuffled data -> pool(); evaluation = the data in
+    order, consecutive batches, each sorted by length; with sort_within_batch every batch is (re)sorted by DEcreasing source
+    length before it is numericalised (what the packed encoder needs)."""
+
+    def __init__(self, dataset, batch_size, sort_key=None, device=None, batch_size_fn=None, train=True, repeat=None, shuffle=None,
+                 sort=None, sort_within_batch=None):
+        self.batch_size, self.train, self.dataset = batch_size, train, dataset
+        self.batch_size_fn = batch_size_fn
+        self.iterations = 0
+        self.repeat = train if repeat is None else repeat
+        self.shuffle = train if shuffle is None else shuffle
+        self.sort = (not train) if sort is None else sort
+        self.sort_within_batch = self.sort if sort_within_batch is None else sort_within_batch
+        self.sort_key = dataset.sort_key if sort_key is None else sort_key
+        self.device = device
+        self.random_shuffler = RandomShuffler()
+        self._iterations_this_epoch = 0
+
+    def data(self):
+        if self.sort:
+            return sorted(self.dataset, key=self.sort_key)
+        if self.shuffle:
+            return [self.dataset[i] for i in self.random_shuffler(range(len(self.dataset)))]
+        return self.dataset
+
+    def create_batches(self):
+        if self.train:
+            self.batches = pool(self.data(), self.batch_size, self.sort_key, self.batch_size_fn,
+                                random_shuffler=self.random_shuffler)
+        else:
+            self.batches = [sorted(b, key=self.sort_key) for b in batch(self.data(), self.batch_size, self.batch_size_fn)]
+
+    def init_epoch(self):
+        self.create_batches()
+        self._iterations_this_epoch = 0
+        if not self.repeat:
+            self.iterations = 0
+
+    def __len__(self):
+        return int(math.ceil(len(self.dataset) / self.batch_size))
+
+    def __iter__(self):
+        while True:
+            self.init_epoch()
+            for minibatch in self.batches:
+                self.iterations += 1
+                self._iterations_this_epoch += 1
+                if self.sort_within_batch:
+                    if self.sort:
+                        minibatch.reverse()
+                    else:
+                        minibatch.sort(key=self.sort_key, reverse=True)
+                yield Batch(minibatch, self.dataset, self.device, self.train)
+            if not self.repeat:
+                return
