@@ -84,6 +84,8 @@ def test_model_takes_a_feature_file_path():
         e.loss_backward(ws, normalization=5)
         torch.cuda.synchronize()
         stats.append(e.read_stats(ws))
-    assert stats[0]["elbo"] == stats[1]["elbo"] and stats[0]["img_feats_loss"] == stats[1]["img_feats_loss"]
+    # same rows either way; the statistics are accumulated with float atomics, so two runs agree to rounding, not bit for bit
+    assert abs(stats[0]["elbo"] - stats[1]["elbo"]) <= 1e-6 * abs(stats[0]["elbo"])
+    assert abs(stats[0]["img_feats_loss"] - stats[1]["img_feats_loss"]) <= 1e-6 * abs(stats[0]["img_feats_loss"])
     r, Lo, _g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], torch.from_numpy(table)[bt["indices"]], bt["eps"])
     assert abs(stats[1]["elbo"] - float(Lo["elbo"])) / abs(float(Lo["elbo"])) < 2e-5
