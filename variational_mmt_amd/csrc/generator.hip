@@ -187,6 +187,241 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent variant (bf16, LDS-DMA, three stages): 128 x 256 tiles need 144 KiB of LDS, so only ONE workgroup fits a CU and
+// nothing hides a tile's prologue (first slabs' L2 latency) and epilogue (exp / max / stores) -- about 40 % of a tile's time at
+// K = 512 (8 slabs).  Here a workgroup walks its share of the tiles and issues the first two slabs of the NEXT tile (buffers 0
+// and 1, free after the last multiply) before it runs the epilogue of the current one; the gradient patches of MODE 1 live in
+// buffer 2 (32-row units: 36 KiB).  Tile order = the L2-friendly order of gen_kernel: XCD x owns a contiguous range of the
+// grouped tile sequence and its workgroups take consecutive tiles of it.
+template <int MODE>
+__global__ void __launch_bounds__(512) gen_kernel_p(GenArgs a, int tiles_m, int ntiles) {
+  using T = bf16_t;
+  using Cf = GenCfg<T, 128>;
+  constexpr int NT = Cf::NT, BMV = Cf::BMV, BNM = Cf::BNM, TI = Cf::TI, TJ = Cf::TJ, NW = NT / 64;
+  constexpr int ABYTES = BMV * GBK * 2, BBYTES = BNM * GBK * 2, BUF = ABYTES + BBYTES;
+  using GA = GldsOperand<BMV, true, NW>;
+  using GB = GldsOperand<BNM, true, NW>;
+  constexpr int PW = GA::PER + GB::PER;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* smem = smem_raw;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wv = wave >> 2, wm = wave & 3;
+  int aoff[TI], boff[TJ] = {wm * 64, wm * 64 + 32};
+#pragma unroll
+  for (int i = 0; i < TI; ++i) aoff[i] = wv * (32 * TI) + 32 * i;
+  GldsFrag<true, TI> fa;
+  GldsFrag<true, TJ> fb;
+  fa.init(aoff, lane);
+  fb.init(boff, lane);
+  // this workgroup's tiles: XCD x = blockIdx % 8 owns [lo, lo + cnt) of the grouped order, slot = blockIdx / 8 strides by per
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int lo = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8, cnt = q8 + (x < r8 ? 1 : 0);
+  const int tiles_v = (a.V + BMV - 1) / BMV;
+  constexpr int GV = 8;
+  auto coords = [&](int tile, int& tv_, int& v0_, int& m0_) {
+    const int group = tile / (GV * tiles_m), in_g = tile - group * (GV * tiles_m);
+    const int gv = min(GV, tiles_v - group * GV);
+    tv_ = group * GV + in_g % gv;
+    v0_ = tv_ * BMV;
+    m0_ = (in_g / gv) * BNM;
+  };
+  int idx = slot;
+  if (idx >= cnt) return;
+  const int nslab = a.K / GBK;
+  int tv, v0, m0;
+  coords(lo + idx, tv, v0, m0);
+  GA ga;
+  GB gb;
+  ga.init((const T*)a.W, a.ldw, v0, a.V, 0, wave, lane);
+  gb.init((const T*)a.O, a.ldo, m0, a.M, 0, wave, lane);
+  ga.issue(smem, wave);
+  gb.issue(smem + ABYTES, wave);
+  if (nslab > 1) {
+    ga.issue(smem + BUF, wave);
+    gb.issue(smem + BUF + ABYTES, wave);
+  }
+  const int hi4 = 4 * (lane >> 5);
+  while (true) {
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#define VMMT_GENP_STEP(CUR, NXT2)                                                                      \
+  {                                                                                                    \
+    if (s + 1 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();                                     \
+    __builtin_amdgcn_s_barrier();                                                                      \
+    if (s + 2 < nslab) {                                                                               \
+      ga.issue(smem + (NXT2) * BUF, wave);                                                             \
+      gb.issue(smem + (NXT2) * BUF + ABYTES, wave);                                                    \
+    }                                                                                                  \
+    glds_slab<BMV, BNM, true, true, TI, TJ>(smem + (CUR) * BUF, smem + (CUR) * BUF + ABYTES, fa, fb, aoff, boff, acc); \
+    ++s;                                                                                               \
+  }
+    int s = 0;
+    while (s < nslab) {
+      VMMT_GENP_STEP(0, 2)
+      if (s >= nslab) break;
+      VMMT_GENP_STEP(1, 0)
+      if (s >= nslab) break;
+      VMMT_GENP_STEP(2, 1)
+    }
+#undef VMMT_GENP_STEP
+    __builtin_amdgcn_s_barrier();        // every wave has finished its last multiply: buffers 0 and 1 are free
+    // ---- epilogue inputs first (a dependent load issued AFTER the prefetch would wait for the prefetch: vmcnt is in order)
+    f32x4 bv[TI][4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int vb = v0 + aoff[i] + hi4 + 8 * q;
+        if (vb + 3 < a.V && ((((uintptr_t)(a.bias + vb)) & 15) == 0)) bv[i][q] = *reinterpret_cast<const f32x4*>(a.bias + vb);
+        else {
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) bv[i][q][s_] = vb + s_ < a.V ? a.bias[vb + s_] : 0.f;
+        }
+      }
+    int ymv[TJ];
+    float lsev[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int m = m0 + boff[j] + (lane & 31);
+      ymv[j] = m < a.M ? (int)a.y[m] : -1;
+      lsev[j] = 0.f;
+      if constexpr (MODE == 1) lsev[j] = m < a.M ? a.lse[m] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- prefetch: first two slabs of the next tile
+    const int nidx = idx + per;
+    const bool has_next = nidx < cnt;
+    int ntv = 0, nv0 = 0, nm0 = 0;
+    if (has_next) {
+      coords(lo + nidx, ntv, nv0, nm0);
+      ga.init((const T*)a.W, a.ldw, nv0, a.V, 0, wave, lane);
+      gb.init((const T*)a.O, a.ldo, nm0, a.M, 0, wave, lane);
+      ga.issue(smem, wave);
+      gb.issue(smem + ABYTES, wave);
+      if (nslab > 1) {
+        ga.issue(smem + BUF, wave);
+        gb.issue(smem + BUF + ABYTES, wave);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue of the current tile
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int vb = v0 + aoff[i] + hi4 + 8 * q;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          const bool ok = vb + s_ < a.V;
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j][4 * q + s_] = ok ? acc[i][j][4 * q + s_] + bv[i][q][s_] : -INFINITY;
+        }
+      }
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int m = m0 + boff[j] + (lane & 31);
+        const bool mv = m < a.M;
+        const int ym = ymv[j];
+        float mx = -INFINITY, tl = 0.f;
+        int mi = 0x7fffffff;
+        bool hit = false;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
+            const float xx = acc[i][j][r];
+            const bool gt = xx > mx;
+            mi = gt ? v : mi;
+            mx = gt ? xx : mx;
+            const bool h = v == ym;
+            tl = h ? xx : tl;
+            hit = hit || h;
+          }
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sm += __expf(acc[i][j][r] - mx);
+        if (mx == -INFINITY) sm = 0.f;
+        if (hit) a.tgt_logit[m] = tl;
+        float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
+        int omi = __shfl_xor(mi, 32, 64);
+        float nm = fmaxf(mx, omx);
+        float ns = (nm == -INFINITY) ? 0.f : sm * __expf(mx - nm) + osm * __expf(omx - nm);
+        int ni = (omx > mx || (omx == mx && omi < mi)) ? omi : mi;
+        const int prow = tv * 2 + wv;
+        if (mv && lane < 32 && prow < a.npart) {
+          long p = (long)prow * a.M + m;
+          a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
+        }
+      }
+    } else {
+      // 32-row units through this wave's patch in buffer 2 (the only staging buffer the prefetch leaves alone)
+      constexpr int PP = Cf::PP, VEC = 8, CH = 64 / VEC;
+      T* patch = reinterpret_cast<T*>(smem + 2 * BUF) + wave * (32 * PP);
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const int vb = v0 + aoff[i] + hi4;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int m = m0 + boff[j] + (lane & 31);
+          const bool mv = m < a.M;
+          const float l = lsev[j];
+          const float sc = (mv && ymv[j] != a.pad) ? a.inv_norm : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dv = (r & 3) + 8 * (r >> 2);
+            float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ymv[j] ? 1.f : 0.f)) * sc;
+            patch[(hi4 + dv) * PP + j * 32 + (lane & 31)] = from_f<T>(g);
+          }
+        }
+        const int vbase = v0 + aoff[i], mbase = m0 + wm * 64;
+#pragma unroll
+        for (int it = 0; it < (32 * CH) / 64; ++it) {
+          const int id2 = it * 64 + lane, row = id2 / CH, ch = id2 % CH;
+          const int v = vbase + row, mm = mbase + ch * VEC;
+          if (v < a.V && mm < a.M) {
+            T* dst = reinterpret_cast<T*>(a.GT) + (long)v * a.ldgt + mm;
+            const T* srcp = patch + row * PP + ch * VEC;
+            if (mm + VEC <= a.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);
+            else for (int e = 0; e < VEC && mm + e < a.M; ++e) dst[e] = srcp[e];
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    idx = nidx; tv = ntv; v0 = nv0; m0 = nm0;
+  }
+}
+
+template <int MODE>
+static int launch_gen_p(const GenArgs& a, hipStream_t st) {
+  using Cf = GenCfg<bf16_t, 128>;
+  const int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + Cf::BNM - 1) / Cf::BNM, ntiles = tv * tm;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return VMMT_ELAUNCH;
+    ncu = pr.multiProcessorCount > 8 ? (pr.multiProcessorCount / 8) * 8 : 8;
+  }
+  const size_t sm = (size_t)glds3_smem_bytes<Cf::BMV, Cf::BNM>();
+  static bool done[2] = {false, false};
+  if (!done[MODE]) { (void)hipFuncSetAttribute((const void*)gen_kernel_p<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done[MODE] = true; }
+  int grid = ncu < ((ntiles + 7) / 8) * 8 ? ncu : ((ntiles + 7) / 8) * 8;      // a multiple of 8: one slot set per XCD
+  hipLaunchKernelGGL((gen_kernel_p<MODE>), dim3(grid), dim3(Cf::NT), sm, st, a, tm, ntiles);
+  return check_launch();
+}
+
 // per token: logsumexp, NLL, argmax-correct; block-reduced sums are added to stats[0..2].
 // Block = 16 waves x 64 tokens: wave w folds partials w, w+16, ... (coalesced along tokens) with an online
 // (max, sum-exp, argmax) merge, then the 16 wave results are merged through LDS.
@@ -296,6 +531,7 @@ static int launch_gen(const GenArgs& a, hipStream_t st) {
     if (ok && v == 2) return launch_gen_v<T, MODE, 2>(a, st);
     if (ok && v == 3) return launch_gen_v<T, MODE, 3>(a, st);
     if (ok && v == 4) return launch_gen_v<T, MODE, 2, 256>(a, st);          // 256 x 256 tiles, two LDS stages (128 KiB)
+    if (ok && v == 5 && a.K >= 128) return launch_gen_p<MODE>(a, st);          // persistent, next tile prefetched under the epilogue
   }
   return launch_gen_v<T, MODE, 0>(a, st);
 }
