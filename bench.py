@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-stream", action="store_true", help="profiling aid: issue the whole step on one stream")
     ap.add_argument("--conditional", action="store_true", help="the --conditional prior variant (SURVEY.md 8f-1) instead of the fixed prior")
+    ap.add_argument("--gen-variant", type=int, default=-1, help="generator main-loop variant (experiments; -1 = library default)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,6 +112,8 @@ def main():
     B, S, T = a.batch, 20, 21
     Tp = T - 1
     eng = Engine(d, dtype=a.dtype, device=dev, seed=0)
+    if a.gen_variant >= 0:
+        L.lib().vmmt_gen_set_variant(a.gen_variant)
     if a.no_side_stream:
         eng.use_side_stream = False
     n_img = 29000

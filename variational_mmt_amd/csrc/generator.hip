@@ -403,6 +403,221 @@ __global__ void __launch_bounds__(512) gen_kernel_p(GenArgs a, int tiles_m, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Half-depth variant (bf16): K slabs of 32, three stages of 24 KiB = 72 KiB of LDS and at most 128 VGPRs, so that TWO
+// workgroups share a CU and one tile's epilogue / barriers overlap the other's MFMAs (profiles/r1_gen_kernel_investigation.txt).
+// LDS images have 64-byte rows (4 chunks of 16 B); a 1-KiB LDS-DMA piece is 16 rows; the chunk index is XOR-swizzled with
+// (row >> 2) & 3 on the source side and in the fragment reads (16 lanes of a ds_read_b128 pass then cover all 64 banks).
+constexpr int HBK = 32;
+
+template <int ROWS, int NW>
+struct HalfOperand {
+  static constexpr int NP = ROWS / 16, PER = NP / NW;
+  static_assert(NP % NW == 0, "pieces must divide over the waves");
+  const char* src[PER];
+  __device__ __forceinline__ void init(const bf16_t* P, long ld, int row0, int limit, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int row = (wave * PER + j) * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      int g = row0 + row;
+      g = g < limit ? g : limit - 1;
+      src[j] = reinterpret_cast<const char*>(P + (long)g * ld + chunk * 8);
+    }
+  }
+  __device__ __forceinline__ void issue(char* lds, int wave) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      __builtin_amdgcn_global_load_lds((g_glb_cvoid_t*)src[j], (g_lds_void_t*)(lds + (wave * PER + j) * 1024), 16, 0, 0);
+      src[j] += HBK * 2;
+    }
+  }
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(512, 4) gen_kernel_h(GenArgs a, int tiles_m) {
+  using T = bf16_t;
+  using Cf = GenCfg<T, 128>;
+  constexpr int NT = Cf::NT, BMV = Cf::BMV, BNM = Cf::BNM, TI = Cf::TI, TJ = Cf::TJ, NW = NT / 64;
+  constexpr int ABYTES = BMV * HBK * 2, BBYTES = BNM * HBK * 2, BUF = ABYTES + BBYTES;       // 8 + 16 = 24 KiB
+  using GA = HalfOperand<BMV, NW>;
+  using GB = HalfOperand<BNM, NW>;
+  constexpr int PW = GA::PER + GB::PER;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* smem = smem_raw;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_v = (a.V + BMV - 1) / BMV;
+  constexpr int GV = 8;
+  const int group = tile / (GV * tiles_m), in_g = tile - group * (GV * tiles_m);
+  const int gv = min(GV, tiles_v - group * GV);
+  const int tv = group * GV + in_g % gv, tm = in_g / gv;
+  const int v0 = tv * BMV, m0 = tm * BNM;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wv = wave >> 2, wm = wave & 3;
+  int aoff[TI], boff[TJ] = {wm * 64, wm * 64 + 32};
+#pragma unroll
+  for (int i = 0; i < TI; ++i) aoff[i] = wv * (32 * TI) + 32 * i;
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  GA ga;
+  GB gb;
+  ga.init((const T*)a.W, a.ldw, v0, a.V, wave, lane);
+  gb.init((const T*)a.O, a.ldo, m0, a.M, wave, lane);
+  // fragment offsets: lane (r, h) reads logical chunk 2 ks + h of row toff + r
+  int foff[2];
+  {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = r * 64 + (((2 * ks + h) ^ sw) * 16);
+  }
+  const int nslab = a.K / HBK;
+  ga.issue(smem, wave);
+  gb.issue(smem + ABYTES, wave);
+  if (nslab > 1) {
+    ga.issue(smem + BUF, wave);
+    gb.issue(smem + BUF + ABYTES, wave);
+  }
+#define VMMT_GENH_STEP(CUR, NXT2)                                                                      \
+  {                                                                                                    \
+    if (s + 1 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();                                     \
+    __builtin_amdgcn_s_barrier();                                                                      \
+    if (s + 2 < nslab) {                                                                               \
+      ga.issue(smem + (NXT2) * BUF, wave);                                                             \
+      gb.issue(smem + (NXT2) * BUF + ABYTES, wave);                                                    \
+    }                                                                                                  \
+    const char* As = smem + (CUR) * BUF;                                                               \
+    const char* Bs = As + ABYTES;                                                                      \
+    bf16x8 fa_[2][TI], fb_[2][TJ];                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                 \
+      _Pragma("unroll") for (int i = 0; i < TI; ++i) fa_[ks][i] = *reinterpret_cast<const bf16x8*>(As + foff[ks] + aoff[i] * 64); \
+      _Pragma("unroll") for (int j = 0; j < TJ; ++j) fb_[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + foff[ks] + boff[j] * 64); \
+    }                                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
+      _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                   \
+        _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                 \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[ks][i], fb_[ks][j], acc[i][j], 0, 0, 0); \
+    ++s;                                                                                               \
+  }
+  int s = 0;
+  while (s < nslab) {
+    VMMT_GENH_STEP(0, 2)
+    if (s >= nslab) break;
+    VMMT_GENH_STEP(1, 0)
+    if (s >= nslab) break;
+    VMMT_GENH_STEP(2, 1)
+  }
+#undef VMMT_GENH_STEP
+  __builtin_amdgcn_s_barrier();        // staging buffers are reused as gradient patches (MODE 1)
+  const int hi4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int vb = v0 + aoff[i] + hi4 + 8 * q;
+      f32x4 bv;
+      if (vb + 3 < a.V && ((((uintptr_t)(a.bias + vb)) & 15) == 0)) bv = *reinterpret_cast<const f32x4*>(a.bias + vb);
+      else {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) bv[s_] = vb + s_ < a.V ? a.bias[vb + s_] : 0.f;
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const bool ok = vb + s_ < a.V;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j][4 * q + s_] = ok ? acc[i][j][4 * q + s_] + bv[s_] : -INFINITY;
+      }
+    }
+  if constexpr (MODE == 0) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int m = m0 + boff[j] + (lane & 31);
+      const bool mv = m < a.M;
+      const int ym = mv ? (int)a.y[m] : -1;
+      float mx = -INFINITY, tl = 0.f;
+      int mi = 0x7fffffff;
+      bool hit = false;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
+          const float xx = acc[i][j][r];
+          const bool gt = xx > mx;
+          mi = gt ? v : mi;
+          mx = gt ? xx : mx;
+          const bool h = v == ym;
+          tl = h ? xx : tl;
+          hit = hit || h;
+        }
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += __expf(acc[i][j][r] - mx);
+      if (mx == -INFINITY) sm = 0.f;
+      if (hit) a.tgt_logit[m] = tl;
+      float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
+      int omi = __shfl_xor(mi, 32, 64);
+      float nm = fmaxf(mx, omx);
+      float ns = (nm == -INFINITY) ? 0.f : sm * __expf(mx - nm) + osm * __expf(omx - nm);
+      int ni = (omx > mx || (omx == mx && omi < mi)) ? omi : mi;
+      const int prow = tv * 2 + wv;
+      if (mv && lane < 32 && prow < a.npart) {
+        long p = (long)prow * a.M + m;
+        a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
+      }
+    }
+  } else {
+    constexpr int PP = Cf::PP, VEC = 8, CH = 64 / VEC;
+    T* patch = reinterpret_cast<T*>(smem) + wave * (32 * PP);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int vb = v0 + aoff[i] + hi4;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int m = m0 + boff[j] + (lane & 31);
+        const bool mv = m < a.M;
+        const int ym = mv ? (int)a.y[m] : -1;
+        const float l = mv ? a.lse[m] : 0.f;
+        const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dv = (r & 3) + 8 * (r >> 2);
+          float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
+          patch[(hi4 + dv) * PP + j * 32 + (lane & 31)] = from_f<T>(g);
+        }
+      }
+      const int vbase = v0 + aoff[i], mbase = m0 + wm * 64;
+#pragma unroll
+      for (int it = 0; it < (32 * CH) / 64; ++it) {
+        const int id2 = it * 64 + lane, row = id2 / CH, ch = id2 % CH;
+        const int v = vbase + row, mm = mbase + ch * VEC;
+        if (v < a.V && mm < a.M) {
+          T* dst = reinterpret_cast<T*>(a.GT) + (long)v * a.ldgt + mm;
+          const T* srcp = patch + row * PP + ch * VEC;
+          *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);      // M % 8 == 0, G^T rows 16-byte aligned (dispatch)
+        }
+      }
+    }
+  }
+}
+
+template <int MODE>
+static int launch_gen_h(const GenArgs& a, hipStream_t st) {
+  using Cf = GenCfg<bf16_t, 128>;
+  const int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + Cf::BNM - 1) / Cf::BNM;
+  const size_t sm = (size_t)3 * (Cf::BMV + Cf::BNM) * HBK * 2;          // 72 KiB
+  static bool done[2] = {false, false};
+  if (!done[MODE]) { (void)hipFuncSetAttribute((const void*)gen_kernel_h<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done[MODE] = true; }
+  hipLaunchKernelGGL((gen_kernel_h<MODE>), dim3(tv * tm), dim3(Cf::NT), sm, st, a, tm);
+  return check_launch();
+}
+
 template <int MODE>
 static int launch_gen_p(const GenArgs& a, hipStream_t st) {
   using Cf = GenCfg<bf16_t, 128>;
@@ -526,12 +741,16 @@ static int launch_gen(const GenArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     // LDS-DMA main loop: 16-byte aligned operands, K in whole 64-slabs (callers round K up over zero-padded rows)
     const bool ok = a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldo % 8 == 0 && ((((uintptr_t)a.W) | ((uintptr_t)a.O)) & 15) == 0;
-    int v = g_gen_variant < 0 ? 3 : g_gen_variant;   // three stages, counted waits: fastest (tools/gen_ab.py)
+    int v = g_gen_variant < 0 ? 7 : g_gen_variant;   // forward: half-depth slabs, two workgroups per CU; backward: three stages, counted waits (tools/gen_ab.py)
     if (ok && v == 1) return launch_gen_v<T, MODE, 1>(a, st);
     if (ok && v == 2) return launch_gen_v<T, MODE, 2>(a, st);
     if (ok && v == 3) return launch_gen_v<T, MODE, 3>(a, st);
     if (ok && v == 4) return launch_gen_v<T, MODE, 2, 256>(a, st);          // 256 x 256 tiles, two LDS stages (128 KiB)
-    if (ok && v == 5 && a.K >= 128) return launch_gen_p<MODE>(a, st);          // persistent, next tile prefetched under the epilogue
+    if (ok && v == 5 && a.K >= 128) return launch_gen_p<MODE>(a, st);
+    if (ok && v == 7 && MODE == 0 && a.K % 32 == 0) return launch_gen_h<MODE>(a, st);
+    if (ok && v == 7) return launch_gen_v<T, MODE, 3>(a, st);
+    if (ok && v == 6 && a.K % 32 == 0 && (MODE == 0 || (a.M % 8 == 0 && a.ldgt % 8 == 0 && (((uintptr_t)a.GT) & 15) == 0)))
+      return launch_gen_h<MODE>(a, st);                        // 32-deep slabs, 72 KiB, two workgroups per CU          // persistent, next tile prefetched under the epilogue
   }
   return launch_gen_v<T, MODE, 0>(a, st);
 }
