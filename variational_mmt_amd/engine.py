@@ -147,6 +147,8 @@ class Engine(object):
         self.use_side_stream = True
         self._masked_streams = []
         self.enc_half_split = False  # see Workspace._plan_backward
+        import os as _os
+        self.q_parallel = _os.environ.get("VMMT_QPAR", "1") == "1"    # q(z|x): scale branch on the side stream next to the location branch
         self.side_one_per_cu = False # see _gemm; measured slower (tools/percu_ab.py): a 128 x 128 GEMM at one workgroup per CU runs at half speed (plans are built per workspace: set before the first forward)
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
@@ -625,12 +627,23 @@ class Workspace(object):
         # a4 q(z|x): masked mean of the detached memory, two 2-layer MLPs
         if not d.conditional:
             e._call(P, lib.vmmt_masked_mean, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.hbar.p(), self.hbar.ld, B, S, H)
+        # the two MLPs are independent and sit on the critical path between encoder and decoder (four latency-bound GEMMs):
+        # the scale branch runs on the side stream (idle at this point) next to the location branch
+        if not d.conditional:
+            e._record(P, "hbar_ready")
         for br, outb, act in (() if d.conditional else (("location", self.mu, L.ACT_NONE), ("scale", self.sigma, L.ACT_SOFTPLUS))):
+            if br == "scale" and e.q_parallel:
+                e._sid = SIDE
+                e._wait(P, "hbar_ready")
             w1, w2 = e.sh["q_%s_w1" % br], e.sh["q_%s_w2" % br]
             e._gemm(P, L.GEMM_NT, self.hbar.p(), self.hbar.ld, w1.p(), w1.ld, self.q_h1[br].p(), self.q_h1[br].ld, B, Z, H,
                     addend=e.pp("inf_net_global.%s.fc1.bias" % br), ld_add=Z, add_rows=1, act=L.ACT_RELU)
             e._gemm(P, L.GEMM_NT, self.q_h1[br].p(), self.q_h1[br].ld, w2.p(), w2.ld, outb.p(), outb.ld, B, Z, Z,
                     addend=e.pp("inf_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
+            if br == "scale" and e.q_parallel:
+                e._record(P, "sigma_ready")
+                e._sid = MAIN
+                e._wait(P, "sigma_ready")
         # a5 fused mu/sigma -> sample -> KL
         if d.conditional:
             e._call(P, lib.vmmt_latent_cond_fwd, dt, self.mu.p(), self.sigma.p(), self.mu_p.p(), self.sigma_p.p(), self.eps.p(),
