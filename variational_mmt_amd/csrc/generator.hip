@@ -607,6 +607,186 @@ __global__ void __launch_bounds__(512, 4) gen_kernel_h(GenArgs a, int tiles_m) {
   }
 }
 
+// 128 x 128 tiles, 4 waves (2 x 2 of 64 x 64), 48 KiB: THREE workgroups per CU at 3 waves per SIMD (170 VGPRs: no spills)
+template <int MODE>
+__global__ void __launch_bounds__(256, 3) gen_kernel_q(GenArgs a, int tiles_m) {
+  using T = bf16_t;
+  using Cf = GenCfg<T, 128>;
+  constexpr int NT = 256, BMV = Cf::BMV, BNM = 128, TI = Cf::TI, TJ = Cf::TJ, NW = NT / 64;
+  constexpr int ABYTES = BMV * HBK * 2, BBYTES = BNM * HBK * 2, BUF = ABYTES + BBYTES;       // 8 + 16 = 24 KiB
+  using GA = HalfOperand<BMV, NW>;
+  using GB = HalfOperand<BNM, NW>;
+  constexpr int PW = GA::PER + GB::PER;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* smem = smem_raw;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles_v = (a.V + BMV - 1) / BMV;
+  constexpr int GV = 8;
+  const int group = tile / (GV * tiles_m), in_g = tile - group * (GV * tiles_m);
+  const int gv = min(GV, tiles_v - group * GV);
+  const int tv = group * GV + in_g % gv, tm = in_g / gv;
+  const int v0 = tv * BMV, m0 = tm * BNM;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wv = wave >> 1, wm = wave & 1;
+  int aoff[TI], boff[TJ] = {wm * 64, wm * 64 + 32};
+#pragma unroll
+  for (int i = 0; i < TI; ++i) aoff[i] = wv * (32 * TI) + 32 * i;
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  GA ga;
+  GB gb;
+  ga.init((const T*)a.W, a.ldw, v0, a.V, wave, lane);
+  gb.init((const T*)a.O, a.ldo, m0, a.M, wave, lane);
+  // fragment offsets: lane (r, h) reads logical chunk 2 ks + h of row toff + r
+  int foff[2];
+  {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = r * 64 + (((2 * ks + h) ^ sw) * 16);
+  }
+  const int nslab = a.K / HBK;
+  ga.issue(smem, wave);
+  gb.issue(smem + ABYTES, wave);
+  if (nslab > 1) {
+    ga.issue(smem + BUF, wave);
+    gb.issue(smem + BUF + ABYTES, wave);
+  }
+  // one loop body, the stage index is a scalar (three macro-expanded bodies made hipcc spill the accumulators)
+  int cur = 0;
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < nslab) {
+      const int nb = cur == 0 ? 2 : cur - 1;
+      ga.issue(smem + nb * BUF, wave);
+      gb.issue(smem + nb * BUF + ABYTES, wave);
+    }
+    const char* As = smem + cur * BUF;
+    const char* Bs = As + ABYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa_[TI], fb_[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fa_[i] = *reinterpret_cast<const bf16x8*>(As + foff[ks] + aoff[i] * 64);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fb_[j] = *reinterpret_cast<const bf16x8*>(Bs + foff[ks] + boff[j] * 64);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  __builtin_amdgcn_s_barrier();        // staging buffers are reused as gradient patches (MODE 1)
+  const int hi4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int vb = v0 + aoff[i] + hi4 + 8 * q;
+      f32x4 bv;
+      if (vb + 3 < a.V && ((((uintptr_t)(a.bias + vb)) & 15) == 0)) bv = *reinterpret_cast<const f32x4*>(a.bias + vb);
+      else {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) bv[s_] = vb + s_ < a.V ? a.bias[vb + s_] : 0.f;
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const bool ok = vb + s_ < a.V;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j][4 * q + s_] = ok ? acc[i][j][4 * q + s_] + bv[s_] : -INFINITY;
+      }
+    }
+  if constexpr (MODE == 0) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int m = m0 + boff[j] + (lane & 31);
+      const bool mv = m < a.M;
+      const int ym = mv ? (int)a.y[m] : -1;
+      float mx = -INFINITY, tl = 0.f;
+      int mi = 0x7fffffff;
+      bool hit = false;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
+          const float xx = acc[i][j][r];
+          const bool gt = xx > mx;
+          mi = gt ? v : mi;
+          mx = gt ? xx : mx;
+          const bool h = v == ym;
+          tl = h ? xx : tl;
+          hit = hit || h;
+        }
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += __expf(acc[i][j][r] - mx);
+      if (mx == -INFINITY) sm = 0.f;
+      if (hit) a.tgt_logit[m] = tl;
+      float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
+      int omi = __shfl_xor(mi, 32, 64);
+      float nm = fmaxf(mx, omx);
+      float ns = (nm == -INFINITY) ? 0.f : sm * __expf(mx - nm) + osm * __expf(omx - nm);
+      int ni = (omx > mx || (omx == mx && omi < mi)) ? omi : mi;
+      const int prow = tv * 2 + wv;
+      if (mv && lane < 32 && prow < a.npart) {
+        long p = (long)prow * a.M + m;
+        a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
+      }
+    }
+  } else {
+    // one 64(v) x 64(m) patch per wave (4 x 9 KiB inside the 48 KiB of staging), written back as 16-byte row segments
+    constexpr int PP = Cf::PP, VEC = 8, CH = 64 / VEC;
+    T* patch = reinterpret_cast<T*>(smem) + wave * (64 * PP);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int m = m0 + boff[j] + (lane & 31);
+      const bool mv = m < a.M;
+      const int ym = mv ? (int)a.y[m] : -1;
+      const float l = mv ? a.lse[m] : 0.f;
+      const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int vb = v0 + aoff[ii] + hi4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dv = (r & 3) + 8 * (r >> 2);
+          float g = (__expf(acc[ii][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
+          patch[(ii * 32 + hi4 + dv) * PP + j * 32 + (lane & 31)] = from_f<T>(g);
+        }
+      }
+    }
+    const int vbase = v0 + wv * 64, mbase = m0 + wm * 64;
+#pragma unroll
+    for (int it = 0; it < (64 * CH) / 64; ++it) {
+      const int id2 = it * 64 + lane, row = id2 / CH, ch = id2 % CH;
+      const int v = vbase + row, mm = mbase + ch * VEC;
+      if (v < a.V && mm < a.M) {
+        T* dst = reinterpret_cast<T*>(a.GT) + (long)v * a.ldgt + mm;
+        const T* srcp = patch + row * PP + ch * VEC;
+        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);      // M % 8 == 0, G^T rows 16-byte aligned (dispatch)
+      }
+    }
+  }
+}
+
+template <int MODE>
+static int launch_gen_q(const GenArgs& a, hipStream_t st) {
+  using Cf = GenCfg<bf16_t, 128>;
+  const int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + 127) / 128;
+  const size_t sm = (size_t)3 * (Cf::BMV + 128) * HBK * 2;          // 48 KiB
+  hipLaunchKernelGGL((gen_kernel_q<MODE>), dim3(tv * tm), dim3(256), sm, st, a, tm);
+  return check_launch();
+}
+
 template <int MODE>
 static int launch_gen_h(const GenArgs& a, hipStream_t st) {
   using Cf = GenCfg<bf16_t, 128>;
@@ -741,16 +921,25 @@ static int launch_gen(const GenArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     // LDS-DMA main loop: 16-byte aligned operands, K in whole 64-slabs (callers round K up over zero-padded rows)
     const bool ok = a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldo % 8 == 0 && ((((uintptr_t)a.W) | ((uintptr_t)a.O)) & 15) == 0;
-    int v = g_gen_variant < 0 ? 7 : g_gen_variant;   // forward: half-depth slabs, two workgroups per CU; backward: three stages, counted waits (tools/gen_ab.py)
-    if (ok && v == 1) return launch_gen_v<T, MODE, 1>(a, st);
-    if (ok && v == 2) return launch_gen_v<T, MODE, 2>(a, st);
-    if (ok && v == 3) return launch_gen_v<T, MODE, 3>(a, st);
-    if (ok && v == 4) return launch_gen_v<T, MODE, 2, 256>(a, st);          // 256 x 256 tiles, two LDS stages (128 KiB)
+    // variants (tools/gen_ab.py; results are bit-identical across them):
+    //   8 (default) 128 x 128 tiles, 32-deep slabs, 48 KiB, three workgroups per CU        fwd 219 us, bwd 221 us
+    //   3           128 x 256 tiles, 64-deep slabs, three stages (144 KiB), one per CU      fwd 259 us, bwd 256 us
+    //   7 / 6       128 x 256 tiles, 32-deep slabs, 72 KiB, two per CU (fwd only / both; the backward instantiation spills)
+    //   5           persistent variant of 3 with the next tile prefetched under the epilogue (no gain)
+    //   1, 2, 4     one / two LDS buffers, 256 x 256 tiles
+    int v = g_gen_variant < 0 ? 8 : g_gen_variant;
+    // the half-depth kernels store G^T as unconditional 16-byte segments
+    const bool gt_ok = MODE == 0 || (a.M % 8 == 0 && a.ldgt % 8 == 0 && (((uintptr_t)a.GT) & 15) == 0);
+    if (v == 8 && !(a.K % 32 == 0 && gt_ok)) v = 3;
+    if (v == 6 && !(a.K % 32 == 0 && gt_ok)) v = 3;
+    if (v == 7 && MODE == 1) v = 3;
+    if (ok && v == 8) return launch_gen_q<MODE>(a, st);
+    if (ok && (v == 6 || v == 7)) return launch_gen_h<MODE>(a, st);
     if (ok && v == 5 && a.K >= 128) return launch_gen_p<MODE>(a, st);
-    if (ok && v == 7 && MODE == 0 && a.K % 32 == 0) return launch_gen_h<MODE>(a, st);
-    if (ok && v == 7) return launch_gen_v<T, MODE, 3>(a, st);
-    if (ok && v == 6 && a.K % 32 == 0 && (MODE == 0 || (a.M % 8 == 0 && a.ldgt % 8 == 0 && (((uintptr_t)a.GT) & 15) == 0)))
-      return launch_gen_h<MODE>(a, st);                        // 32-deep slabs, 72 KiB, two workgroups per CU          // persistent, next tile prefetched under the epilogue
+    if (ok && v == 4) return launch_gen_v<T, MODE, 2, 256>(a, st);
+    if (ok && v == 3) return launch_gen_v<T, MODE, 3>(a, st);
+    if (ok && v == 2) return launch_gen_v<T, MODE, 2>(a, st);
+    if (ok && v == 1) return launch_gen_v<T, MODE, 1>(a, st);
   }
   return launch_gen_v<T, MODE, 0>(a, st);
 }
