@@ -172,3 +172,60 @@ def test_gemm_split_k_atomic(dtype, layout):
         want = init.double() + a.double() @ b.double().t() + bias.double()
         err = (Cd.cpu().double() - want).abs().max().item()
         assert err <= (1e-4 if dtype == "f32" else 3e-2), (split, err)
+
+
+@pytest.mark.parametrize("M,V,H", [(5120, 3000, 512), (200, 1000, 128), (37, 515, 64), (264, 130, 192), (8, 67, 64)])
+def test_generator_kernel_variants_bf16(M, V, H):
+    """fused projection + log-softmax + NLL (vmmt_gen_loss_fwd / _bwd, bf16) against fp64 math on the same bf16-rounded operands,
+    for every main-loop variant: 8 = default (128 x 128 tiles, 32-deep slabs, three workgroups per CU), 3 = 128 x 256 three-stage,
+    6 = 128 x 256 half-depth, 0 = register-staged.  Ragged M / V exercise the clamped edge tiles and the fall-backs (M % 8 != 0)."""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(M + V)
+    T = torch.bfloat16
+    ld = (H + 63) // 64 * 64
+    W = torch.zeros(V + 256, ld, dtype=T)
+    O = torch.zeros(M + 256, ld, dtype=T)
+    W[:V, :H] = (torch.randn(V, H, generator=g) * 0.3).to(T)
+    O[:M, :H] = torch.randn(M, H, generator=g).to(T)
+    bias = torch.randn(V, generator=g) * 0.2
+    y = torch.randint(0, V, (M,), generator=g)
+    y[::5] = 1                                                     # pad targets carry no loss
+    logits = O[:M, :H].double() @ W[:V, :H].double().t() + bias.double()
+    lse_ref = torch.logsumexp(logits, 1)
+    w = (y != 1).double()
+    nll_ref = ((lse_ref - logits.gather(1, y.view(-1, 1)).view(-1)) * w)
+    inv_norm = 1.0 / 7.0
+    G_ref = (torch.softmax(logits, 1) - torch.nn.functional.one_hot(y, V).double()) * (w * inv_norm).view(-1, 1)
+    Wd, Od, bd, yd = W.cuda(), O.cuda(), bias.cuda(), y.cuda()
+    npart = lib.vmmt_gen_npart(V)
+    ldgt = (M + 63) // 64 * 64
+    outs = {}
+    try:
+        for v in (8, 3, 6, 0):
+            lib.vmmt_gen_set_variant(v)
+            pm = torch.zeros(npart * M, device="cuda"); ps = torch.zeros_like(pm)
+            pi = torch.zeros(npart * M, device="cuda", dtype=torch.int32)
+            tl = torch.zeros(M, device="cuda"); lse = torch.zeros(M, device="cuda"); nll = torch.zeros(M, device="cuda")
+            st = torch.zeros(8, device="cuda")
+            GT = torch.zeros(V + 256, ldgt, device="cuda", dtype=T)
+            P = lambda t: C.c_void_p(t.data_ptr())
+            L.check(lib.vmmt_gen_loss_fwd(L.BF16, P(Wd), ld, P(bd), P(Od), ld, P(yd), M, V, ld, 1, P(pm), P(ps), P(pi), P(tl), P(lse), P(nll),
+                                          P(st), None), "gen fwd")
+            L.check(lib.vmmt_gen_loss_bwd(L.BF16, P(Wd), ld, P(bd), P(Od), ld, P(yd), M, V, ld, 1, P(lse), inv_norm, P(GT), ldgt, None), "gen bwd")
+            torch.cuda.synchronize()
+            assert (lse.cpu().double() - lse_ref).abs().max().item() <= 2e-4 * max(1.0, lse_ref.abs().max().item()), v
+            assert (nll.cpu().double() - nll_ref).abs().max().item() <= 5e-4 * max(1.0, nll_ref.abs().max().item()), v
+            s = st.cpu()
+            assert abs(s[L.STAT_NLL].item() - nll_ref.sum().item()) <= 1e-4 * abs(nll_ref.sum().item()) + 1e-3
+            assert int(round(s[L.STAT_NWORDS].item())) == int(w.sum().item())
+            correct = ((logits.argmax(1) == y) & (y != 1)).sum().item()
+            assert abs(int(round(s[L.STAT_NCORRECT].item())) - correct) <= 1          # a near-tie may flip one arg-max
+            Gt = GT[:V, :M].float().cpu().t().double()
+            assert (Gt - G_ref).abs().max().item() <= 4e-3 * inv_norm + 1e-6, v       # bf16 storage of G^T
+            assert (GT[:V, M:] == 0).all() and (GT[V:] == 0).all(), v                 # nothing outside [V][M] is written
+            outs[v] = (lse.clone(), GT.clone())
+        for v in (3, 6, 0):
+            assert torch.equal(outs[v][0], outs[8][0]) and torch.equal(outs[v][1], outs[8][1]), v   # same arithmetic, same bits
+    finally:
+        lib.vmmt_gen_set_variant(-1)
