@@ -12,7 +12,9 @@ LIB = os.path.join(HERE, "libvmmt.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result"]
-SOURCES = ["gemm.hip", "lstm.hip", "attention.hip", "generator.hip", "elementwise.hip", "optim.hip", "runtime.hip", "conditional.hip", "table.hip", "beam.hip"]
+# gemm.hip is compiled three times, one operand layout per object (see the note at the end of that file)
+GEMM_PARTS = 3
+SOURCES = ["lstm.hip", "attention.hip", "generator.hip", "elementwise.hip", "optim.hip", "runtime.hip", "conditional.hip", "table.hip", "beam.hip"]
 
 
 def _stale(out, deps):
@@ -27,25 +29,34 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     common = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "glds_gemm.hpp"), os.path.join(ROOT, "include", "vmmt.h")]
     jobs = []
+    for part in range(GEMM_PARTS):           # the long poles first
+        src = os.path.join(CSRC, "gemm.hip")
+        obj = os.path.join(objdir, "gemm_p%d.o" % part)
+        if force or _stale(obj, [src] + common):
+            jobs.append((src, obj, ["-DVMMT_GEMM_PART=%d" % part]))
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + common):
-            jobs.append((src, obj))
+            jobs.append((src, obj, []))
+    stale_whole = os.path.join(objdir, "gemm.o")          # object of the former single-unit build
+    if os.path.exists(stale_whole):
+        os.remove(stale_whole)
 
     def cc(job):
-        src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        src, obj, extra = job
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
-        return src
+        return obj
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(7, max(1, len(jobs)))) as ex:
         for s in ex.map(cc, jobs):
             if verbose:
                 print("[vmmt build] compiled", os.path.basename(s), flush=True)
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir, "gemm_p%d.o" % part) for part in range(GEMM_PARTS)] + \
+           [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs,
                            capture_output=True, text=True)

@@ -181,18 +181,35 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
   return launch_cfg<T, 64, 64, 32, 32, A_KC, B_KC>(a, epi, st);
 }
 
-template <class T>
-static int launch_dtype(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
-  switch (a->layout) {
-    case VMMT_GEMM_NT: return launch_layout<T, true, true>(a, epi, st);
-    case VMMT_GEMM_TN: return launch_layout<T, false, false>(a, epi, st);
-    case VMMT_GEMM_NN: return launch_layout<T, true, false>(a, epi, st);
-    default: return VMMT_EINVAL;
-  }
+// The three operand layouts are independent sets of template instantiations; build.py compiles this file three times
+// (-DVMMT_GEMM_PART=0/1/2, one layout each, in parallel: the full set takes ~7 minutes in one translation unit).  Without the
+// macro everything lands in one object (tools/exp_build.sh).
+#ifndef VMMT_GEMM_PART
+#define VMMT_GEMM_PART -1
+#endif
+int gemm_launch_nt(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st);
+int gemm_launch_tn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st);
+int gemm_launch_nn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st);
+
+template <bool A_KC, bool B_KC>
+static int launch_by_dtype(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
+  if (a->dtype == VMMT_F32) return launch_layout<float, A_KC, B_KC>(a, epi, st);
+  if (a->dtype == VMMT_BF16) return launch_layout<bf16_t, A_KC, B_KC>(a, epi, st);
+  return VMMT_EINVAL;
 }
+#if VMMT_GEMM_PART == -1 || VMMT_GEMM_PART == 0
+int gemm_launch_nt(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) { return launch_by_dtype<true, true>(a, epi, st); }
+#endif
+#if VMMT_GEMM_PART == -1 || VMMT_GEMM_PART == 1
+int gemm_launch_tn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) { return launch_by_dtype<false, false>(a, epi, st); }
+#endif
+#if VMMT_GEMM_PART == -1 || VMMT_GEMM_PART == 2
+int gemm_launch_nn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) { return launch_by_dtype<true, false>(a, epi, st); }
+#endif
 
 }  // namespace vmmt
 
+#if VMMT_GEMM_PART == -1 || VMMT_GEMM_PART == 0
 extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
   using namespace vmmt;
   if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N < 0 || a->K < 0) return VMMT_EINVAL;
@@ -205,7 +222,11 @@ extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
   e.alpha = a->alpha; e.scatter_ids = (const long long*)a->scatter_ids; e.pad_id = a->pad_id;
   e.atomic = a->split_k > 1 ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
-  if (a->dtype == VMMT_F32) return launch_dtype<float>(a, e, st);
-  if (a->dtype == VMMT_BF16) return launch_dtype<bf16_t>(a, e, st);
-  return VMMT_EINVAL;
+  switch (a->layout) {
+    case VMMT_GEMM_NT: return gemm_launch_nt(a, e, st);
+    case VMMT_GEMM_TN: return gemm_launch_tn(a, e, st);
+    case VMMT_GEMM_NN: return gemm_launch_nn(a, e, st);
+    default: return VMMT_EINVAL;
+  }
 }
+#endif
