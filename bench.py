@@ -99,12 +99,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, "--gpus must equal WORLD_SIZE (launch N > 1 with torch.distributed.run)"
+    # rehearsal knobs (never set by the driver): VMMT_BENCH_ONE_GPU=1 puts every rank on cuda:0 and VMMT_BENCH_BACKEND=gloo
+    # replaces RCCL, so that the N > 1 code path can be run end to end on a one-GPU box (RCCL refuses two ranks on one device)
+    if os.environ.get("VMMT_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VMMT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from variational_mmt_amd.engine import Dims, Engine
     from variational_mmt_amd import _lib as L
