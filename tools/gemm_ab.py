@@ -32,15 +32,16 @@ def bench(name, lay, M, N, K, variants, out_f32=1, split=0, rounds=7):
             res[v].append(s.elapsed_time(e) / 5 * 1e3)
     fl = 2.0 * M * N * K
     print("%-28s" % name, "  ".join("%d: %7.1f us (%5.0f TF)" % (v, sorted(t)[len(t)//2], fl / sorted(t)[len(t)//2] / 1e6) for v, t in res.items()))
-V = [64, 128]
-bench("q fc1 NT 256x256x512", L.GEMM_NT, 256, 256, 512, V, out_f32=0)
-bench("q fc2 NT 256x256x256", L.GEMM_NT, 256, 256, 256, V, out_f32=1)
-bench("h1v NT 256x2048x256", L.GEMM_NT, 256, 2048, 256, V, out_f32=0)
-bench("mu_v NT 256x2048x2048", L.GEMM_NT, 256, 2048, 2048, V, out_f32=1)
-bench("dh1v NN 256x2048x2048", L.GEMM_NN, 256, 2048, 2048, V, out_f32=0)
-bench("dzt NN 256x256x2048", L.GEMM_NN, 256, 256, 2048, V, out_f32=1)
-bench("emb NN 5120x512x2048", L.GEMM_NN, 5120, 512, 2048, V, out_f32=1)
-bench("dW2 TN 2048x2048x256", L.GEMM_TN, 2048, 2048, 256, V, out_f32=1)
-bench("dWq TN 256x512x256", L.GEMM_TN, 256, 512, 256, V, out_f32=1)
-bench("Q NT 5120x512x512", L.GEMM_NT, 5120, 512, 512, V, out_f32=0)
-bench("AH NT 5120x512x1024", L.GEMM_NT, 5120, 512, 1024, V, out_f32=0)
+if __name__ == "__main__":
+    V = [64, 128]
+    bench("q fc1 NT 256x256x512", L.GEMM_NT, 256, 256, 512, V, out_f32=0)
+    bench("q fc2 NT 256x256x256", L.GEMM_NT, 256, 256, 256, V, out_f32=1)
+    bench("h1v NT 256x2048x256", L.GEMM_NT, 256, 2048, 256, V, out_f32=0)
+    bench("mu_v NT 256x2048x2048", L.GEMM_NT, 256, 2048, 2048, V, out_f32=1)
+    bench("dh1v NN 256x2048x2048", L.GEMM_NN, 256, 2048, 2048, V, out_f32=0)
+    bench("dzt NN 256x256x2048", L.GEMM_NN, 256, 256, 2048, V, out_f32=1)
+    bench("emb NN 5120x512x2048", L.GEMM_NN, 5120, 512, 2048, V, out_f32=1)
+    bench("dW2 TN 2048x2048x256", L.GEMM_TN, 2048, 2048, 256, V, out_f32=1)
+    bench("dWq TN 256x512x256", L.GEMM_TN, 256, 512, 256, V, out_f32=1)
+    bench("Q NT 5120x512x512", L.GEMM_NT, 5120, 512, 512, V, out_f32=0)
+    bench("AH NT 5120x512x1024", L.GEMM_NT, 5120, 512, 1024, V, out_f32=0)

@@ -68,7 +68,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
 }
 
 template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, int GL = 0>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, GL == 4 ? 3 : 1)      // GL 4: three workgroups of 4 waves per CU
 gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int M, int N, int K, int a_kmod,
             int b_kmod, int tiles_n, int kper, GemmEpi epi) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -97,6 +97,9 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb
   const int kend = min(K, kbeg + kper);
   if constexpr (GL == 3) {   // LDS-DMA main loops (glds_gemm.hpp); preconditions checked by launch_layout
     gemm_mainloop_glds3<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
+  } else if constexpr (GL == 4) {   // half-depth slabs, both operands K-contiguous (glds_gemm.hpp)
+    static_assert(GL != 4 || (A_KC && B_KC), "the half-depth loop stages K-contiguous operands");
+    gemm_mainloop_hglds3<BM, BN, NT / 64, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
   } else if constexpr (GL == 1) {
     gemm_mainloop_glds<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
   } else {
@@ -111,7 +114,7 @@ template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK 
 static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st, size_t lds_min = 0) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
-  size_t smem = GL == 3 ? (size_t)glds3_smem_bytes<BM, BN>() : GL ? (size_t)glds_smem_bytes<BM, BN>() : gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
+  size_t smem = GL == 4 ? (size_t)hglds3_smem_bytes<BM, BN>() : GL == 3 ? (size_t)glds3_smem_bytes<BM, BN>() : GL ? (size_t)glds_smem_bytes<BM, BN>() : gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
   if (smem < lds_min) smem = lds_min;          // occupancy cap by LDS request (VMMT_TILE_128_ONE_PER_CU)
   if (smem > 64 * 1024) {
     static size_t allowed = 0;
@@ -153,6 +156,9 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
     if (a->tile == 3565 && gl_ok) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
     if (a->tile == 3284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
     if (a->tile == 2568 && gl_ok) return launch_cfg<T, 128, 256, 64, 128, A_KC, B_KC, 64, true, 1>(a, epi, st);
+    if constexpr (A_KC && B_KC) {
+      if (a->tile == 4284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 4>(a, epi, st);
+    }
   }
   bool gl_ok = false;
   if constexpr (sizeof(T) == 2)

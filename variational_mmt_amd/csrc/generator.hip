@@ -408,32 +408,6 @@ __global__ void __launch_bounds__(512) gen_kernel_p(GenArgs a, int tiles_m, int 
 // workgroups share a CU and one tile's epilogue / barriers overlap the other's MFMAs (profiles/r1_gen_kernel_investigation.txt).
 // LDS images have 64-byte rows (4 chunks of 16 B); a 1-KiB LDS-DMA piece is 16 rows; the chunk index is XOR-swizzled with
 // (row >> 2) & 3 on the source side and in the fragment reads (16 lanes of a ds_read_b128 pass then cover all 64 banks).
-constexpr int HBK = 32;
-
-template <int ROWS, int NW>
-struct HalfOperand {
-  static constexpr int NP = ROWS / 16, PER = NP / NW;
-  static_assert(NP % NW == 0, "pieces must divide over the waves");
-  const char* src[PER];
-  __device__ __forceinline__ void init(const bf16_t* P, long ld, int row0, int limit, int wave, int lane) {
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int row = (wave * PER + j) * 16 + (lane >> 2);
-      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-      int g = row0 + row;
-      g = g < limit ? g : limit - 1;
-      src[j] = reinterpret_cast<const char*>(P + (long)g * ld + chunk * 8);
-    }
-  }
-  __device__ __forceinline__ void issue(char* lds, int wave) {
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      __builtin_amdgcn_global_load_lds((g_glb_cvoid_t*)src[j], (g_lds_void_t*)(lds + (wave * PER + j) * 1024), 16, 0, 0);
-      src[j] += HBK * 2;
-    }
-  }
-};
-
 template <int MODE>
 __global__ void __launch_bounds__(512, 4) gen_kernel_h(GenArgs a, int tiles_m) {
   using T = bf16_t;
@@ -466,8 +440,8 @@ __global__ void __launch_bounds__(512, 4) gen_kernel_h(GenArgs a, int tiles_m) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   GA ga;
   GB gb;
-  ga.init((const T*)a.W, a.ldw, v0, a.V, wave, lane);
-  gb.init((const T*)a.O, a.ldo, m0, a.M, wave, lane);
+  ga.init((const T*)a.W, a.ldw, v0, a.V, 0, wave, lane);
+  gb.init((const T*)a.O, a.ldo, m0, a.M, 0, wave, lane);
   // fragment offsets: lane (r, h) reads logical chunk 2 ks + h of row toff + r
   int foff[2];
   {
@@ -640,8 +614,8 @@ __global__ void __launch_bounds__(256, 3) gen_kernel_q(GenArgs a, int tiles_m) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   GA ga;
   GB gb;
-  ga.init((const T*)a.W, a.ldw, v0, a.V, wave, lane);
-  gb.init((const T*)a.O, a.ldo, m0, a.M, wave, lane);
+  ga.init((const T*)a.W, a.ldw, v0, a.V, 0, wave, lane);
+  gb.init((const T*)a.O, a.ldo, m0, a.M, 0, wave, lane);
   // fragment offsets: lane (r, h) reads logical chunk 2 ks + h of row toff + r
   int foff[2];
   {

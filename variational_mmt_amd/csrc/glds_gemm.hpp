@@ -256,4 +256,96 @@ __device__ __forceinline__ void gemm_mainloop_glds3(const bf16_t* __restrict__ A
   __builtin_amdgcn_s_barrier();      // the staging buffers may be reused by the caller's epilogue
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Half-depth variant for K-contiguous operands: K slabs of 32, LDS images with 64-byte rows (4 chunks of 16 B, chunk index
+// XOR (row >> 2) & 3 on the source side and in the fragment reads: the 16 lanes of a ds_read_b128 pass cover all 64 banks),
+// three stages with counted waits.  A 128 x 128 tile needs 3 x 16 KiB = 48 KiB: THREE workgroups of 4 waves share a CU, so
+// that one tile's epilogue and barriers overlap the others' MFMAs (profiles/r1_gen_kernel_investigation.txt).  ONE loop body
+// with a scalar stage index: three macro-expanded bodies made hipcc spill the accumulators.
+constexpr int HBK = 32;
+
+template <int ROWS, int NW>
+struct HalfOperand {
+  static constexpr int NP = ROWS / 16, PER = NP / NW;        // 1-KiB pieces (16 rows) per slab / per wave
+  static_assert(NP % NW == 0, "pieces must divide over the waves");
+  const char* src[PER];
+  __device__ __forceinline__ void init(const bf16_t* P, long ld, int row0, int limit, int k0, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int row = (wave * PER + j) * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      int g = row0 + row;
+      g = g < limit ? g : limit - 1;                         // clamped rows only feed outputs that are never stored
+      src[j] = reinterpret_cast<const char*>(P + (long)g * ld + k0 + chunk * 8);
+    }
+  }
+  __device__ __forceinline__ void issue(char* lds, int wave) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      __builtin_amdgcn_global_load_lds((g_glb_cvoid_t*)src[j], (g_lds_void_t*)(lds + (wave * PER + j) * 1024), 16, 0, 0);
+      src[j] += HBK * 2;
+    }
+  }
+};
+
+template <int BM, int BN>
+constexpr int hglds3_smem_bytes() { return 3 * (BM + BN) * HBK * 2; }
+
+// C_tile += A_tile * B_tile^T over k in [kbeg, kend), kend - kbeg a positive multiple of 32; both operands K-contiguous.
+template <int BM, int BN, int NW, int TI, int TJ>
+__device__ __forceinline__ void gemm_mainloop_hglds3(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
+                                                     long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
+                                                     const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem) {
+  constexpr int ABYTES = BM * HBK * 2, BBYTES = BN * HBK * 2, BUF = ABYTES + BBYTES;
+  using GA = HalfOperand<BM, NW>;
+  using GB = HalfOperand<BN, NW>;
+  constexpr int PW = GA::PER + GB::PER;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  GA ga;
+  GB gb;
+  ga.init(A, lda, m0, M, kbeg, wave, lane);
+  gb.init(B, ldb, n0, N, kbeg, wave, lane);
+  int foff[2];          // lane (r, h) reads logical chunk 2 ks + h of row toff + r (toff a multiple of 32: same swizzle key)
+  {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = r * 64 + (((2 * ks + h) ^ sw) * 16);
+  }
+  const int nslab = (kend - kbeg) / HBK;
+  if (nslab <= 0) return;
+  ga.issue(smem, wave);
+  gb.issue(smem + ABYTES, wave);
+  if (nslab > 1) {
+    ga.issue(smem + BUF, wave);
+    gb.issue(smem + BUF + ABYTES, wave);
+  }
+  int cur = 0;
+  for (int s = 0; s < nslab; ++s) {
+    if (s + 1 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < nslab) {
+      const int nb = cur == 0 ? 2 : cur - 1;
+      ga.issue(smem + nb * BUF, wave);
+      gb.issue(smem + nb * BUF + ABYTES, wave);
+    }
+    const char* As = smem + cur * BUF;
+    const char* Bs = As + ABYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa_[TI], fb_[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fa_[i] = *reinterpret_cast<const bf16x8*>(As + foff[ks] + aoff[i] * 64);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fb_[j] = *reinterpret_cast<const bf16x8*>(Bs + foff[ks] + boff[j] * 64);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  __builtin_amdgcn_s_barrier();      // the staging buffers may be reused by the caller's epilogue
+}
+
 }  // namespace vmmt
