@@ -68,7 +68,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
 }
 
 template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, int GL = 0>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64, GL == 4 ? 3 : 1)      // GL 4: three workgroups of 4 waves per CU
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
 gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int M, int N, int K, int a_kmod,
             int b_kmod, int tiles_n, int kper, GemmEpi epi) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
