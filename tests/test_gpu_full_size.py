@@ -1,0 +1,73 @@
+"""GPU, BASELINE.json config 2 at FULL size (batch 256, src/tgt length 20, 30 k vocabularies, biLSTM 512, z 256, emb 500, 2048-d
+image features): the fp32 parity mode against the CPU oracle's forward + loss (seconds on the host), the bf16 throughput mode against
+the fp32 mode, and size-independent properties of the step: every softmax-gradient column sums to zero (exactly zero for <blank>
+targets), the KL statistic equals its closed form from the device's own mu / sigma, per-token NLL >= 0 and adds up to the statistic,
+log-sum-exp dominates the target logit, padding rows of the image table are never touched, two runs agree to rounding."""
+import pytest
+import torch
+
+from oracle import vi1_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup():
+    c = O.Cfg(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True)
+    p = O.init_params(c, seed=0)
+    bt = O.synth_batch(c, B=256, S=20, T=21, n_img=1000, seed=7, fixed_len=False)
+    return c, p, bt
+
+
+def _run(c, p, bt, dtype):
+    from variational_mmt_amd.engine import Dims, Engine
+    e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype=dtype, device="cuda:0")
+    e.load_state_dict(p)
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+    e.loss_backward(ws, normalization=256)
+    torch.cuda.synchronize()
+    return e, ws, e.read_stats(ws)
+
+
+def test_full_size_parity_and_properties():
+    c, p, bt = _setup()
+    img = bt["table"][bt["indices"]]
+    with torch.no_grad():
+        r = O.forward(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
+        Lo = O.loss(p, c, r, bt["tgt"], img)
+    e32, ws32, s32 = _run(c, p, bt, "f32")
+    # ---- fp32 mode against the oracle (tolerances of the small-shape parity tests, section 2 of DESIGN.md)
+    for k, ok in (("nmt", "nll"), ("td_kl_before", "kl_before"), ("elbo", "elbo"), ("img_feats_loss", "img_logprob")):
+        ref = float(Lo[ok])
+        assert abs(s32[k] - ref) <= 3e-5 * abs(ref), (k, s32[k], ref)
+    assert s32["n_words"] == Lo["n_words"] and abs(s32["n_correct"] - Lo["n_correct"]) <= 1
+    M = 20 * 256
+    y = bt["tgt"][1:].reshape(-1)
+    nonpad = (y != 1)
+    tok = ws32.tok_nll.cpu()
+    assert (tok - Lo["tok_nll"].reshape(-1)).abs().max().item() <= 1e-3
+    # ---- properties (fp32 mode)
+    assert (tok >= -1e-5).all() and (tok[~nonpad] == 0).all()
+    assert abs(float(tok.double().sum()) - s32["nmt"]) <= 1e-5 * s32["nmt"]
+    mu, sg = ws32.mu.view().cpu().double(), ws32.sigma.view().cpu().double()
+    kl = (0.5 * (mu ** 2 + sg ** 2 - 1.0) - torch.log(sg)).sum(1).mean().item()
+    assert abs(kl - s32["td_kl_before"]) <= 1e-5 * abs(kl)
+    GT = ws32.GT.view()[:, :M]
+    col = GT.double().sum(0).cpu()                               # sum over the vocabulary of (softmax - onehot) * w / B
+    assert col.abs().max().item() <= 2e-6
+    assert (GT[:, (~nonpad).cuda()] == 0).all()
+    # ---- bf16 mode against fp32 mode
+    e16, ws16, s16 = _run(c, p, bt, "bf16")
+    for k in ("nmt", "td_kl_before", "elbo"):
+        assert abs(s16[k] - s32[k]) <= 2e-3 * abs(s32[k]), (k, s16[k], s32[k])
+    assert s16["n_words"] == s32["n_words"]
+    g32, g16 = e32.flat_g[:e32.n_opt].double(), e16.flat_g[:e16.n_opt].double()
+    n32, n16 = g32.norm().item(), g16.norm().item()
+    assert abs(n16 - n32) <= 1e-2 * n32
+    assert ((g16 - g32).norm() / g32.norm()).item() <= 2e-2        # whole-arena gradient, relative L2
+    G16 = ws16.GT.view()[:, :M]
+    assert G16.float().sum(0).abs().max().item() <= 3e-4           # bf16 storage of G^T
+    assert (G16[:, (~nonpad).cuda()] == 0).all()
+    # ---- run-to-run: same inputs, same statistics up to the order of float atomics
+    _e, _ws, s16b = _run(c, p, bt, "bf16")
+    assert abs(s16b["elbo"] - s16["elbo"]) <= 1e-6 * abs(s16["elbo"])
