@@ -305,6 +305,31 @@ __global__ void pack_multi_kernel(const vmmt_pack_desc* __restrict__ descs, int 
   const vmmt_pack_desc d = descs[lo];
   const long n_el = (long)d.R * d.C;
   const long base = (long)(chunk - d.chunk_start) * 2048;
+  // row-major copies whose rows are whole groups of four (every large weight matrix): 16-byte loads, 8- / 16-byte stores,
+  // two index divisions per lane instead of eight
+  if (!d.transpose && (d.C & 3) == 0 && (d.ld_src & 3) == 0 && (d.ld_dst & 3) == 0 && ((((uintptr_t)d.src) | ((uintptr_t)d.dst)) & 15) == 0 &&
+      (!d.src2 || (((uintptr_t)d.src2) & 15) == 0)) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const long i = base + k * 1024 + threadIdx.x * 4;
+      if (i >= n_el) break;
+      const int r = (int)(i / d.C), c = (int)(i - (long)r * d.C);
+      f32x4 v = *reinterpret_cast<const f32x4*>(d.src + (long)r * d.ld_src + c);
+      if (d.src2) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(d.src2 + (long)r * d.ld_src + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += w[e];
+      }
+      const long o = (long)r * d.ld_dst + c;
+      if (d.dtype == VMMT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(d.dst) + o) = v;
+      else {
+        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+        us4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<us4*>(reinterpret_cast<bf16_t*>(d.dst) + o) = h;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     long i = base + k * 256 + threadIdx.x;
