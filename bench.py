@@ -168,7 +168,7 @@ def main():
         step(i)
     # backward plan exists now: hook the gen_loss_bwd entry
     for j, (fn, args, name, keep, sid) in enumerate(ws0.plan_bwd):
-        if name == "vmmt_gen_loss_bwd":
+        if name in ("vmmt_gen_loss_bwd", "vmmt_gen_loss_bwd_db"):
             wrap(ws0.plan_bwd, j, "gen_bwd")
     torch.cuda.synchronize()
     if dist is not None:

@@ -186,6 +186,12 @@ int vmmt_gen_loss_bwd(int dtype, const void* W, int64_t ldw, const float* bias, 
                       const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm, void* GT,
                       int64_t ldgt, void* stream);
 
+/* vmmt_gen_loss_bwd plus the generator bias gradient dbias[v] += sum_m G^T[v][m] (f32 [V], accumulated): fused into the bf16
+ * kernel's write-out where that kernel applies, otherwise a row-sum pass over G^T behind it. */
+int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
+                         const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm, void* GT,
+                         int64_t ldgt, float* dbias, void* stream);
+
 /* ---- row gathers / small fused kernels -------------------------------------------------------------------------- */
 /* out[r][0:D] = table[ids[r]][0:D]; table f32 (embedding master weights: modules/Embeddings.py:181; or the HBM-resident
  * image-feature table: TrainerMultimodal.py:632-639), out f32 or bf16 per out_dtype. */

@@ -225,6 +225,15 @@ def test_generator_kernel_variants_bf16(M, V, H):
             assert (Gt - G_ref).abs().max().item() <= 4e-3 * inv_norm + 1e-6, v       # bf16 storage of G^T
             assert (GT[:V, M:] == 0).all() and (GT[V:] == 0).all(), v                 # nothing outside [V][M] is written
             outs[v] = (lse.clone(), GT.clone())
+            # the same pass with the fused bias gradient (vmmt_gen_loss_bwd_db): identical G^T, dbias += row sums of the stored G^T
+            GT2 = torch.zeros_like(GT)
+            db = torch.full((V,), 0.5, device="cuda")
+            L.check(lib.vmmt_gen_loss_bwd_db(L.BF16, P(Wd), ld, P(bd), P(Od), ld, P(yd), M, V, ld, 1, P(lse), inv_norm, P(GT2), ldgt, P(db),
+                                             None), "gen bwd db")
+            torch.cuda.synchronize()
+            assert torch.equal(GT2, GT), v
+            ref_db = 0.5 + GT[:V, :M].float().sum(1)
+            assert (db - ref_db).abs().max().item() <= 1e-5 + 1e-5 * ref_db.abs().max().item(), v
         for v in (3, 6, 0):
             assert torch.equal(outs[v][0], outs[8][0]) and torch.equal(outs[v][1], outs[8][1]), v   # same arithmetic, same bits
     finally:

@@ -70,6 +70,7 @@ _SIGS = {
     "vmmt_lstm_set_variant": (i32, [i32]),
     "vmmt_gen_loss_fwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "vmmt_gen_loss_bwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp]),
+    "vmmt_gen_loss_bwd_db": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp]),
     "vmmt_gather_rows": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, vp]),
     "vmmt_colsum": (i32, [i32, vp, i64, i32, i32, vp, vp, vp]),
     "vmmt_rowsum": (i32, [i32, vp, i64, i32, i32, vp, vp]),

@@ -25,6 +25,7 @@ struct GenArgs {
   float* part_max; float* part_sum; int* part_idx; float* tgt_logit;   // [NPART][M], [M]
   // pass 2
   const float* lse; float inv_norm; void* GT; long ldgt;               // T [V][ldgt]
+  float* dbias;                                                        // optional f32 [V] += row sums of G^T (bias gradient)
 };
 
 // Tile: 128 vocabulary rows x 256 tokens, 8 waves (2 along V x 4 along tokens, 64x64 each), BK = 64, one LDS buffer
@@ -739,15 +740,34 @@ __global__ void __launch_bounds__(256, 3) gen_kernel_q(GenArgs a, int tiles_m) {
       }
     }
     const int vbase = v0 + wv * 64, mbase = m0 + wm * 64;
+    float* rsum = reinterpret_cast<float*>(smem + 4 * 64 * PP * (int)sizeof(T)) + wave * 64;     // behind the four patches
 #pragma unroll
     for (int it = 0; it < (64 * CH) / 64; ++it) {
       const int id2 = it * 64 + lane, row = id2 / CH, ch = id2 % CH;
       const int v = vbase + row, mm = mbase + ch * VEC;
+      const T* srcp = patch + row * PP + ch * VEC;
+      const u32x4 seg = *reinterpret_cast<const u32x4*>(srcp);
       if (v < a.V && mm < a.M) {
         T* dst = reinterpret_cast<T*>(a.GT) + (long)v * a.ldgt + mm;
-        const T* srcp = patch + row * PP + ch * VEC;
-        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);      // M % 8 == 0, G^T rows 16-byte aligned (dispatch)
+        *reinterpret_cast<u32x4*>(dst) = seg;      // M % 8 == 0, G^T rows 16-byte aligned (dispatch)
       }
+      if (a.dbias) {
+        // bias gradient = row sums of G^T (of the stored bf16 values, as the stand-alone row-sum kernel would read them); columns
+        // beyond M hold exact zeros.  The eight lanes of a row fold by shuffles, one atomic per row and wave.
+        float rs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rs += bf2f((bf16_t)(seg[e] & 0xffffu)) + bf2f((bf16_t)(seg[e] >> 16));
+        // (v_dot2_f32_bf16 with a vector of ones would halve these instructions, but its sums did not match: measured, rejected)
+        rs += __shfl_xor(rs, 1, 64);
+        rs += __shfl_xor(rs, 2, 64);
+        rs += __shfl_xor(rs, 4, 64);
+        if (ch == 0) rsum[row] = rs;          // collected in LDS: ONE 64-lane atomic per wave below (atomics cost ~50 ns per instruction)
+      }
+    }
+    if (a.dbias) {                            // same-wave LDS traffic is ordered: no barrier needed
+      const int v = vbase + lane;
+      const float rs = rsum[lane];
+      if (v < a.V) atomicAdd(a.dbias + v, rs);
     }
   }
 }
@@ -890,6 +910,14 @@ __global__ void gen_argmax_kernel(const float* __restrict__ part_max, const int*
   if (out_max) out_max[m] = mx;
 }
 
+// preconditions of the default bf16 kernel (gen_kernel_q) for this call, as launch_gen checks them
+template <int MODE>
+static bool gen_q_applies(const GenArgs& a) {
+  const bool ok = a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldo % 8 == 0 && ((((uintptr_t)a.W) | ((uintptr_t)a.O)) & 15) == 0;
+  const bool gt_ok = MODE == 0 || (a.M % 8 == 0 && a.ldgt % 8 == 0 && (((uintptr_t)a.GT) & 15) == 0);
+  return ok && gt_ok && (g_gen_variant < 0 || g_gen_variant == 8);
+}
+
 template <class T, int MODE>
 static int launch_gen(const GenArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
@@ -951,6 +979,28 @@ extern "C" int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const fl
   hipLaunchKernelGGL(gen_combine_kernel, dim3((M + 63) / 64), dim3(1024), 0, st, part_max, part_sum, part_idx,
                      tgt_logit, (const long long*)y, M, vmmt_gen_npart(V), pad, lse, tok_nll, stats);
   return check_launch();
+}
+
+extern "C" int vmmt_rowsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream);
+
+// vmmt_gen_loss_bwd + the generator bias gradient dbias[v] += sum_m G^T[v][m]: fused into the bf16 default kernel's write-out
+// (saves re-reading G^T), otherwise one vmmt_rowsum launch behind the gradient pass.
+extern "C" int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
+                                    const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm,
+                                    void* GT, int64_t ldgt, float* dbias, void* stream) {
+  using namespace vmmt;
+  if (!W || !bias || !O || !y || !lse || !GT || !dbias || M <= 0 || V <= 0 || K <= 0 || ldgt < M) return VMMT_EINVAL;
+  GenArgs a{};
+  a.W = W; a.ldw = ldw; a.bias = bias; a.O = O; a.ldo = ldo; a.y = (const long long*)y; a.M = M; a.V = V; a.K = K;
+  a.pad = pad; a.lse = lse; a.inv_norm = inv_norm; a.GT = GT; a.ldgt = ldgt;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMMT_BF16 && gen_q_applies<1>(a)) {
+    a.dbias = dbias;
+    return launch_gen_q<1>(a, st);
+  }
+  int rc = dtype == VMMT_F32 ? launch_gen<float, 1>(a, st) : dtype == VMMT_BF16 ? launch_gen<bf16_t, 1>(a, st) : VMMT_EINVAL;
+  if (rc) return rc;
+  return vmmt_rowsum(dtype, GT, ldgt, V, M, dbias, stream);
 }
 
 extern "C" int vmmt_gen_loss_bwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,

@@ -19,6 +19,7 @@ HBM layout
 """
 import ctypes as C
 import math
+from os import environ as _os_env
 
 import torch
 
@@ -745,8 +746,15 @@ class Workspace(object):
         e._record(P, "bwd_begin")
         # ================= main: generator backward seed G^T, dO = G Wg ================================================
         e._sid = MAIN
-        e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
-                M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
+        # (the bias gradient = row sums of G^T comes out of the same kernel; the gradient arena was zeroed on the side stream in
+        #  front of `dec_gx`, which the main stream has waited for)
+        fuse_db = _os_env.get("VMMT_FUSE_DB", "1") == "1"
+        if fuse_db:
+            e._call(P, lib.vmmt_gen_loss_bwd_db, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
+                    M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld, e.gp("generator.0.bias"))
+        else:
+            e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
+                    M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
         e._record(P, "GT")
         e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
                 split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))))
@@ -798,12 +806,13 @@ class Workspace(object):
             # at the end of the plan).  (Issuing them from a helper thread was measured: no gain, removed.)
             self._cond_backward_tgt(P, drop)
         e._record(P, "aux_done")
-        # side: dWg = G^T O, db = rowsum(G^T) as soon as G^T exists (underneath dO = G Wg of the main stream)
+        # side: dWg = G^T O as soon as G^T exists (underneath dO = G Wg of the main stream)
         e._sid = SIDE
         e._wait(P, "bwd_begin")
         e._wait(P, "GT")
         e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1)   # plain store
-        e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
+        if not fuse_db:
+            e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
         e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
         # main: dropout + tanh backward, linear_out
         e._sid = MAIN
