@@ -260,11 +260,21 @@ typedef struct vmmt_pack_desc {
 } vmmt_pack_desc;
 int vmmt_pack_multi(const vmmt_pack_desc* descs, int n, int total_chunks, void* stream);
 
+/* many buffers cleared in ONE launch (the gradient arena and the small accumulators of a step; replaces loss.backward()'s
+ * implicit zero-filled .grad buffers and model.zero_grad(), TrainerMultimodal.py:628-629).  `descs`: device array of n
+ * descriptors; ptr 16-byte aligned, bytes a multiple of 4; chunk_start = exclusive prefix sum of ceil(bytes / 16384);
+ * total_chunks = their sum. */
+typedef struct vmmt_zero_desc {
+  void* ptr; int64_t bytes; int64_t chunk_start;
+} vmmt_zero_desc;
+int vmmt_zero_multi(const vmmt_zero_desc* descs, int n, int total_chunks, void* stream);
+
 /* batch preparation in one launch: ids -> workspace, tgt[:-1] / tgt[1:] (Models.py:867, VILoss.py:205), lengths, image row
- * indices, statistics reset, optional eps ~ N(0,I) (eps may be NULL).  src [S][B], tgt [T][B], all int64 device arrays. */
+ * indices, statistics reset, optional eps ~ N(0,I) (eps may be NULL).  src [S][B], tgt [T][B], all int64 device arrays.
+ * The workspace may hold more positions than the batch (S_ws >= S, T_ws >= T): the rest is filled with `pad`. */
 int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const int64_t* src_len, const int64_t* idx, int S, int T, int B,
-                       int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len, int64_t* o_idx, float* stats, float* eps,
-                       int64_t n_eps, uint64_t seed, void* stream);
+                       int S_ws, int T_ws, int pad, int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len, int64_t* o_idx,
+                       float* stats, float* eps, int64_t n_eps, uint64_t seed, void* stream);
 
 /* ---- beam search (translation) --------------------------------------------------------------------------------
  * One position of Beam.advance (onmt/translate/Beam.py:63-121) for all B sentences of a decoding batch of K*B rows
@@ -287,7 +297,17 @@ int vmmt_rows_select(const void* src, int64_t ld_src_bytes, const int64_t* rows,
 int vmmt_standardise_rows(float* X, int64_t ld, const float* mean, const float* stdv, int64_t R, int D, void* stream);
 
 /* ---- optimiser: clip_grad_norm + Adam over a flat fp32 arena (onmt/Optim.py:68-70,94-96) -------------------------- */
-int vmmt_sumsq(const float* g, int64_t n, float* out /* += */, void* stream);
+/* ||g||^2 of one arena segment into slot `slot` of `scratch` (f32[VMMT_SUMSQ_SCRATCH], zeroed once by the caller):
+ *   scratch[0 .. SLOTS)            slot totals (plain store by the last workgroup of the launch)
+ *   scratch[SLOTS .. 2 SLOTS)      uint32 tickets (self-resetting)
+ *   scratch[2 SLOTS ...]           SLOTS x MAXBLOCKS per-workgroup partials
+ * The partials are added in index order by the last-arriving workgroup: bit-reproducible, and identical on every
+ * data-parallel rank (torch.nn.utils.clip_grad_norm of the reference is a host-side sum: Optim.py:94-95).
+ * vmmt_adam_step's `sumsq` is this scratch: it adds the slot totals in index order. */
+#define VMMT_SUMSQ_SLOTS 8
+#define VMMT_SUMSQ_MAXBLOCKS 768
+#define VMMT_SUMSQ_SCRATCH (2 * VMMT_SUMSQ_SLOTS + VMMT_SUMSQ_SLOTS * VMMT_SUMSQ_MAXBLOCKS)
+int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, void* stream);
 /* max_blocks > 0 caps the grid (grid-stride loop): used for the half of the update that runs in the background */
 int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* stream);

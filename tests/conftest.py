@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Most GPU tests read a workspace's buffers with the batch's exact (S, T') shape; shape bucketing (padding S / T' up to a
+# multiple of Engine.shape_bucket, default 2) is covered by tests/test_gpu_shapes.py, which compares bucketed against exact.
+os.environ.setdefault("VMMT_SHAPE_BUCKET", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `-m gpu`)")
 

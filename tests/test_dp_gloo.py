@@ -51,3 +51,87 @@ def test_dp_sum_of_rank_gradients_equals_single_process(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     err = torch.load(out)["err"]
     assert err < 2e-5, err
+
+
+def _worker_freebits(rank, world, port, out):
+    """free bits under data parallelism (VILoss.py:463-476): max(m * KL_mean_GLOBAL, margin) -- the ranks exchange ONE float (their
+    KL sums) before the KL term is differentiated; checked on both sides of the margin"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import vi1_oracle as O
+    from variational_mmt_amd.dp import GradSync
+    from variational_mmt_amd.engine import Dims
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = O.Cfg(vs=31, vt=37, emb=10, hid=12, z=6, img=2048, layers=1, brnn=True)
+    p = O.init_params(c, seed=2)
+    Bg = 6
+    bt = O.synth_batch(c, Bg, 5, 6, n_img=8, seed=3, fixed_len=False)
+    img = bt["table"][bt["indices"]]
+    sl = slice(rank * Bg // world, (rank + 1) * Bg // world)
+    d = Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn)
+    names = [n for n, _ in d.param_shapes()[0]]
+
+    def reduce_kl(local_sum):
+        t = local_sum.detach().clone().reshape(1)
+        dist.all_reduce(t)
+        return float(t)
+
+    _, L0, _ = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
+    kl_mean = float(L0["kl_before"])
+    res = {}
+    for tag, margin in (("below", kl_mean * 0.5), ("above", kl_mean * 2.0)):     # KL above the margin / clamped to the margin
+        _, Ll, g = O.step_grads(p, c, bt["src"][:, sl], bt["src_len"][sl], bt["tgt"][:, sl], img[sl], bt["eps"][sl], normalization=Bg,
+                                batch_global=Bg, use_freebits=True, freebits=margin, kl_global_sum=reduce_kl)
+        flat = torch.cat([g[n].reshape(-1) if n in g else torch.zeros(int(torch.tensor(shp).prod())) for n, shp in d.param_shapes()[0]])
+        sync = GradSync(flat=flat, bucket_elems=100000)
+        sync.all_reduce()
+        elbo = torch.tensor([float(Ll["elbo"])], dtype=torch.float64)
+        dist.all_reduce(elbo)                       # the ranks' shares add up to the single-process ELBO
+        if rank == 0:
+            _, Lf, gf = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], use_freebits=True, freebits=margin)
+            want = torch.cat([gf[n].reshape(-1) if n in gf else torch.zeros(int(torch.tensor(shp).prod())) for n, shp in d.param_shapes()[0]])
+            res[tag] = ((flat - want).abs().max().item() / want.abs().max().item(), abs(float(elbo) - float(Lf["elbo"])) / abs(float(Lf["elbo"])),
+                        float((want[-100:] ** 2).sum()))
+    if rank == 0:
+        torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_dp_freebits_uses_the_global_kl_mean(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_worker_freebits, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    for tag in ("below", "above"):
+        assert res[tag][0] < 2e-5 and res[tag][1] < 1e-6, (tag, res[tag])
+
+
+def test_sharded_iterator_partitions_every_global_minibatch():
+    """onmt.io.OrderedIterator(dp_rank=, dp_world=): the ranks walk the same global minibatches and take disjoint, sorted,
+    equally sized (+-1) shares; the global batch size / token count ride on the batch (no collective in the trainer)."""
+    from variational_mmt_amd.onmt import io
+    G = os.path.join(ROOT, "tests", "golden", "textdata", "demo")
+    ds = io.load_dataset(G + ".train.1.pt")
+    fields = io.load_fields_from_vocab(io.load_vocab(G + ".vocab.pt"), "text")
+    ds.fields = dict((k, f) for k, f in fields.items() if k in ds.examples[0].__dict__)
+    world, bs = 3, 4
+    its = [io.OrderedIterator(dataset=ds, batch_size=bs, device=None, sort=False, train=True, sort_within_batch=True, repeat=False,
+                              dp_rank=r, dp_world=world, dp_seed=7) for r in range(world)]
+    per_rank = [list(it) for it in its]
+    assert len({len(b) for b in per_rank}) == 1                  # every rank sees the same number of batches
+    seen = []
+    for step in zip(*per_rank):
+        gb = {b.global_batch_size for b in step}
+        assert len(gb) == 1 and sum(b.batch_size for b in step) == gb.pop()
+        assert len({b.global_ntokens for b in step}) == 1
+        assert step[0].global_ntokens == sum(int(b.tgt[0][1:].ne(1).sum()) for b in step)
+        sizes = [b.batch_size for b in step]
+        assert max(sizes) - min(sizes) <= 1
+        for b in step:
+            lens = b.src[1].tolist()
+            assert lens == sorted(lens, reverse=True)            # each share is still sorted by decreasing source length
+            seen += b.indices.tolist()
+    assert len(seen) == len(set(seen))                           # disjoint
+    assert len(ds) - len(seen) < world                           # at most world-1 examples (a tail minibatch) are skipped

@@ -55,3 +55,69 @@ def test_two_ranks_match_single_process(tmp_path):
     r = torch.load(out)
     assert r["worst"] < 3e-4, r
     assert r["same_params"]
+
+
+def _worker_freebits(rank, world, port, out):
+    """free bits + active clipping + three consecutive updates: the KL sum is all-reduced before the latent backward, the norm is
+    a deterministic reduction of the reduced gradients, and the replicas stay bit-identical"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import vi1_oracle as O
+    from variational_mmt_amd.dp import GradSync
+    from variational_mmt_amd.engine import Dims, Engine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = O.Cfg(vs=41, vt=43, emb=16, hid=32, z=8, img=2048, layers=1, brnn=True)
+    p = O.init_params(c, seed=6)
+    Bg = 10
+    bt = O.synth_batch(c, Bg, 6, 7, n_img=16, seed=8, fixed_len=False)
+    img = bt["table"][bt["indices"]]
+    sl = slice(rank * Bg // world, (rank + 1) * Bg // world)
+    _, L0, _ = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
+    kl_mean = float(L0["kl_before"])
+    res = {}
+    for tag, margin in (("kl_above_margin", 0.5 * kl_mean), ("kl_below_margin", 2.0 * kl_mean)):
+        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda:0")
+        rng0 = e.rng_counter
+        e.load_state_dict(p)
+        e.set_image_table(bt["table"])
+        sync = GradSync(e)
+        assert e.rng_counter - rng0 == rank * (1 << 40)          # every replica draws its own eps / dropout stream
+        ws = e.forward(bt["src"][:, sl], bt["src_len"][sl], bt["tgt"][:, sl], bt["indices"][sl], training=True, eps=bt["eps"][sl])
+        e.loss_backward(ws, normalization=Bg, batch_global=Bg, use_freebits=True, margin=margin)
+        sync.all_reduce()
+        torch.cuda.synchronize()
+        g_gpu = {k: v.detach().cpu().clone() for k, v in e.grads.items()}
+        kl_glob = float(ws.kl_global.item())
+        # two more updates with a tiny clip threshold (clipping active on every one), then compare the replicas bit for bit
+        for _ in range(3):
+            e.optim_step(lr=0.01, max_grad_norm=0.05)
+            ws = e.forward(bt["src"][:, sl], bt["src_len"][sl], bt["tgt"][:, sl], bt["indices"][sl], training=True, eps=bt["eps"][sl])
+            e.loss_backward(ws, normalization=Bg, batch_global=Bg, use_freebits=True, margin=margin)
+            sync.all_reduce()
+        e.optim_step(lr=0.01, max_grad_norm=0.05)
+        torch.cuda.synchronize()
+        same = sync.replicas_identical()
+        if rank == 0:
+            _, Lf, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], use_freebits=True, freebits=margin)
+            worst = max(((g_gpu[k] - g[k]).abs().max() / g[k].abs().max()).item() for k in g)
+            qk = "inf_net_global.location.fc2.weight"
+            res[tag] = dict(worst=worst, kl_glob=kl_glob, kl_want=float(Lf["kl_b"].sum()), same=bool(same),
+                            q_grad_zero=bool((g_gpu[qk] == 0).all()), q_want_zero=bool((g[qk] == 0).all()))
+    if rank == 0:
+        torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_freebits_clip_and_replica_identity(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 25000 + (os.getpid() % 2000)
+    mp.spawn(_worker_freebits, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    for tag in ("kl_above_margin", "kl_below_margin"):
+        x = r[tag]
+        assert x["worst"] < 3e-4, (tag, x)
+        assert abs(x["kl_glob"] - x["kl_want"]) <= 1e-5 * abs(x["kl_want"]), (tag, x)
+        assert x["q_grad_zero"] == x["q_want_zero"], (tag, x)
+        assert x["same"], (tag, x)
+    assert r["kl_below_margin"]["q_grad_zero"] and not r["kl_above_margin"]["q_grad_zero"]

@@ -101,10 +101,20 @@ def test_adam_and_sumsq():
     m, v = torch.rand(n) * 0.1, torch.rand(n) * 0.01
     pd, gd, md, vd = [x.clone().cuda() for x in (p, g, m, v)]
     # arena pointers must be 16-byte aligned: torch allocations are
-    ss = torch.zeros(4, device="cuda")
-    L.check(lib.vmmt_sumsq(gd.data_ptr(), n, ss.data_ptr(), None), "sumsq")
+    ss = torch.zeros(L.SUMSQ_SCRATCH, device="cuda")
+    # two arena segments -> two slots; Adam adds the slot totals in index order
+    n0 = 40000
+    L.check(lib.vmmt_sumsq(gd.data_ptr(), n0, ss.data_ptr(), 0, None), "sumsq")
+    L.check(lib.vmmt_sumsq(gd.data_ptr() + 4 * n0, n - n0, ss.data_ptr(), 3, None), "sumsq")
     tot = float((g.double() ** 2).sum())
-    assert abs(ss[0].item() - tot) <= 1e-4 * tot
+    assert abs(ss[:L.SUMSQ_SLOTS].sum().item() - tot) <= 1e-4 * tot
+    # bit-reproducible: the partials are added in index order, whatever order the workgroups arrive in
+    first = ss[:L.SUMSQ_SLOTS].clone()
+    for _ in range(5):
+        ss[:L.SUMSQ_SLOTS].zero_()
+        L.check(lib.vmmt_sumsq(gd.data_ptr(), n0, ss.data_ptr(), 0, None), "sumsq")
+        L.check(lib.vmmt_sumsq(gd.data_ptr() + 4 * n0, n - n0, ss.data_ptr(), 3, None), "sumsq")
+        assert torch.equal(ss[:L.SUMSQ_SLOTS], first)
     L.check(lib.vmmt_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 0.002, 0.9, 0.999, 1e-9, 3, 5.0,
                                ss.data_ptr(), 1.0, 0, None), "adam")
     coef = min(1.0, 5.0 / (tot ** 0.5 + 1e-6))

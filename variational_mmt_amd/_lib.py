@@ -16,6 +16,8 @@ GEMM_NT, GEMM_TN, GEMM_NN = 0, 1, 2
 TILE_128_ONE_PER_CU = 129
 (STAT_NLL, STAT_NWORDS, STAT_NCORRECT, STAT_KL_SUM, STAT_IMG_LOGPROB, STAT_IMG_COS, STAT_GRAD_SUMSQ) = range(7)
 STAT_COUNT = 8
+SUMSQ_SLOTS, SUMSQ_MAXBLOCKS = 8, 768
+SUMSQ_SCRATCH = 2 * SUMSQ_SLOTS + SUMSQ_SLOTS * SUMSQ_MAXBLOCKS      # vmmt.h: VMMT_SUMSQ_SCRATCH
 
 vp, i64, i32, f32, u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
 
@@ -41,6 +43,10 @@ class LstmDirBwd(C.Structure):
                 ("ld_cp", i64), ("dc_carry", vp), ("ld_dcc", i64), ("dgates_out", vp), ("ld_dgo", i64),
                 ("dh_n", vp), ("ld_dhn", i64), ("dc_n", vp), ("ld_dcn", i64), ("dh0_out", vp), ("ld_dh0", i64),
                 ("t", i32), ("inject", i32)]
+
+
+class ZeroDesc(C.Structure):
+    _fields_ = [("ptr", vp), ("bytes", i64), ("chunk_start", i64)]
 
 
 class PackDesc(C.Structure):
@@ -85,11 +91,12 @@ _SIGS = {
     "vmmt_image_loss": (i32, [i32, vp, i64, vp, i64, i32, i32, f32, vp, i64, vp, vp]),
     "vmmt_pack": (i32, [i32, vp, vp, i64, vp, i64, i32, i32, i32, vp]),
     "vmmt_pack_multi": (i32, [vp, i32, i32, vp]),
-    "vmmt_prepare_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, u64, vp]),
+    "vmmt_prepare_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, u64, vp]),
+    "vmmt_zero_multi": (i32, [vp, i32, i32, vp]),
     "vmmt_beam_advance": (i32, [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "vmmt_rows_select": (i32, [vp, i64, vp, vp, i64, i32, i32, vp]),
     "vmmt_standardise_rows": (i32, [vp, i64, vp, vp, i64, i32, vp]),
-    "vmmt_sumsq": (i32, [vp, i64, vp, vp]),
+    "vmmt_sumsq": (i32, [vp, i64, vp, i32, vp]),
     "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp]),
 }
 

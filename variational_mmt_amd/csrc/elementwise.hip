@@ -277,20 +277,45 @@ __global__ void pack_kernel(const float* __restrict__ src, const float* __restri
 // One launch per step for everything the reference does on the host / in separate tiny ops before the forward:
 // token ids into the step workspace, the input/target shift tgt[:-1] / tgt[1:] (Models.py:867, VILoss.py:205), lengths and
 // image row indices, statistics reset, and eps ~ N(0, I) for the latent sample.
+// The workspace may be larger than the batch (S_ws >= S source positions, T_ws >= T target positions: shapes are bucketed so
+// that a bounded set of launch plans serves real data): the extra positions are filled with the pad id, which every consumer
+// already masks (encoder / attention by src_len, the loss by y == pad).
 __global__ void prepare_batch_kernel(const long long* __restrict__ src, const long long* __restrict__ tgt,
                                      const long long* __restrict__ src_len, const long long* __restrict__ idx, int S, int T, int B,
+                                     int S_ws, int T_ws, long long pad,
                                      long long* __restrict__ o_src, long long* __restrict__ o_tin, long long* __restrict__ o_y,
                                      long long* __restrict__ o_len, long long* __restrict__ o_idx, float* __restrict__ stats,
                                      float* __restrict__ eps, long n_eps, unsigned long long seed) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nS = (long)S * B, nT = (long)(T - 1) * B;
-  if (i < nS) o_src[i] = src[i];
-  if (i < nT) { o_tin[i] = tgt[i]; o_y[i] = tgt[i + B]; }
+  if (i < (long)S_ws * B) o_src[i] = i < nS ? src[i] : pad;
+  if (i < (long)(T_ws - 1) * B) { o_tin[i] = i < nT ? tgt[i] : pad; o_y[i] = i < nT ? tgt[i + B] : pad; }
   if (i < B) { o_len[i] = src_len[i]; o_idx[i] = idx[i]; }
   if (i < VMMT_STAT_COUNT) stats[i] = 0.f;
   if (eps && i < n_eps) {
     float u1 = u01(rng32(seed, 2ull * i)), u2 = u01(rng32(seed, 2ull * i + 1));
     eps[i] = sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+  }
+}
+
+// every buffer a step has to clear (gradient arena, accumulators) in ONE launch: block -> (descriptor, 16-KiB chunk)
+__global__ void zero_multi_kernel(const vmmt_zero_desc* __restrict__ descs, int n) {
+  const long chunk = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {                       // last descriptor with chunk_start <= chunk
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].chunk_start <= chunk) lo = mid; else hi = mid - 1;
+  }
+  const vmmt_zero_desc d = descs[lo];
+  char* base = reinterpret_cast<char*>(d.ptr);
+  const long off0 = (chunk - d.chunk_start) * 16384;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long off = off0 + ((long)k * 256 + threadIdx.x) * 16;
+    if (off + 16 <= d.bytes) *reinterpret_cast<f32x4*>(base + off) = z;
+    else
+      for (long o = off; o + 4 <= d.bytes; o += 4) *reinterpret_cast<float*>(base + o) = 0.f;     // tail (bytes % 16 != 0)
   }
 }
 
@@ -481,6 +506,12 @@ extern "C" int vmmt_pack(int dtype, const float* src, const float* src2, int64_t
   return check_launch();
 }
 
+extern "C" int vmmt_zero_multi(const vmmt_zero_desc* descs, int n, int total_chunks, void* stream) {
+  if (!descs || n <= 0 || total_chunks <= 0) return VMMT_EINVAL;
+  hipLaunchKernelGGL(zero_multi_kernel, dim3(total_chunks), dim3(256), 0, ST, descs, n);
+  return check_launch();
+}
+
 extern "C" int vmmt_pack_multi(const vmmt_pack_desc* descs, int n, int total_chunks, void* stream) {
   if (!descs || n <= 0 || total_chunks <= 0) return VMMT_EINVAL;
   hipLaunchKernelGGL(pack_multi_kernel, dim3(total_chunks), dim3(256), 0, ST, descs, n);
@@ -488,16 +519,18 @@ extern "C" int vmmt_pack_multi(const vmmt_pack_desc* descs, int n, int total_chu
 }
 
 extern "C" int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const int64_t* src_len, const int64_t* idx, int S, int T,
-                                  int B, int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len, int64_t* o_idx, float* stats,
-                                  float* eps, int64_t n_eps, uint64_t seed, void* stream) {
-  if (!src || !tgt || !src_len || !idx || !o_src || !o_tin || !o_y || !o_len || !o_idx || !stats || S <= 0 || T < 2 || B <= 0)
+                                  int B, int S_ws, int T_ws, int pad, int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len,
+                                  int64_t* o_idx, float* stats, float* eps, int64_t n_eps, uint64_t seed, void* stream) {
+  if (!src || !tgt || !src_len || !idx || !o_src || !o_tin || !o_y || !o_len || !o_idx || !stats || S <= 0 || T < 2 || B <= 0 ||
+      S_ws < S || T_ws < T)
     return VMMT_EINVAL;
-  long n = (long)S * B;
-  if ((long)(T - 1) * B > n) n = (long)(T - 1) * B;
+  long n = (long)S_ws * B;
+  if ((long)(T_ws - 1) * B > n) n = (long)(T_ws - 1) * B;
   if (eps && n_eps > n) n = n_eps;
   if (n < VMMT_STAT_COUNT) n = VMMT_STAT_COUNT;
   hipLaunchKernelGGL(prepare_batch_kernel, BLOCKS(n, 256), dim3(256), 0, ST, (const long long*)src, (const long long*)tgt,
-                     (const long long*)src_len, (const long long*)idx, S, T, B, (long long*)o_src, (long long*)o_tin, (long long*)o_y,
+                     (const long long*)src_len, (const long long*)idx, S, T, B, S_ws, T_ws, (long long)pad, (long long*)o_src,
+                     (long long*)o_tin, (long long*)o_y,
                      (long long*)o_len, (long long*)o_idx, stats, eps, (long)n_eps, (unsigned long long)seed);
   return check_launch();
 }

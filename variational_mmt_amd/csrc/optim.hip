@@ -9,7 +9,12 @@
 
 namespace vmmt {
 
-__global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+// Deterministic two-stage reduction: every workgroup leaves its partial sum in `partials[blockIdx.x]` (write-through store),
+// takes a ticket, and the workgroup whose ticket is the last one adds the partials in index order.  The result depends only on
+// (g, n, grid), never on the arrival order -- data-parallel ranks that hold bit-identical all-reduced gradients compute
+// bit-identical norms and hence identical clip coefficients (replicas cannot drift apart through the clip).
+__global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partials, unsigned* __restrict__ ticket,
+                             float* __restrict__ total) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   long stride = (long)gridDim.x * blockDim.x * 4;
   float a = 0.f;
@@ -30,9 +35,30 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
     for (long k = i; k < n; ++k) a += g[k] * g[k];
   a = wave_sum(a);
   __shared__ float red[4];
+  __shared__ int is_last;
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    // hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, first table row): sc1 store, drained, then ONE agent-scope
+    // atomic add per workgroup; the workgroup whose add returned last reads every partial with sc1 loads
+    __hip_atomic_store(partials + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  float s = 0.f;
+  for (unsigned k = threadIdx.x; k < gridDim.x; k += blockDim.x)
+    s += __hip_atomic_load(partials + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *total = (red[0] + red[1]) + (red[2] + red[3]);
+    *ticket = 0u;                      // ready for the next step without a memset
+  }
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -40,7 +66,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
                             const float* __restrict__ sumsq, float grad_scale) {
   float coef = grad_scale;
   if (max_norm > 0.f) {
-    float nrm = sqrtf(*sumsq) * grad_scale;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < VMMT_SUMSQ_SLOTS; ++k) ss += sumsq[k];       // slot totals in index order (unused slots hold 0)
+    float nrm = sqrtf(ss) * grad_scale;
     float c = max_norm / (nrm + 1e-6f);
     if (c < 1.f) coef *= c;
   }
@@ -73,14 +102,17 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 }  // namespace vmmt
 
-extern "C" int vmmt_sumsq(const float* g, int64_t n, float* out, void* stream) {
+extern "C" int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, void* stream) {
   using namespace vmmt;
-  if (!g || !out || n < 0 || (((uintptr_t)g) & 15)) return VMMT_EINVAL;
+  if (!g || !scratch || n < 0 || slot < 0 || slot >= VMMT_SUMSQ_SLOTS || (((uintptr_t)g) & 15)) return VMMT_EINVAL;
   if (n == 0) return VMMT_OK;
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 768) blocks = 768;        // 3 workgroups of 4 waves per CU
+  if (blocks > VMMT_SUMSQ_MAXBLOCKS) blocks = VMMT_SUMSQ_MAXBLOCKS;        // 3 workgroups of 4 waves per CU
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, (long)n, out);
+  float* partials = scratch + 2 * VMMT_SUMSQ_SLOTS + (long)slot * VMMT_SUMSQ_MAXBLOCKS;
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch + VMMT_SUMSQ_SLOTS) + slot;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, (long)n, partials, ticket,
+                     scratch + slot);
   return check_launch();
 }
 

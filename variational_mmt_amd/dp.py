@@ -3,11 +3,17 @@
 len(gpuid) > 1, train_mm_vi_model1.py:73-75); the semantics reproduced are those of the single-process reference run on
 the CONCATENATED global batch B_g = sum_r B_r:
 
-    loss / B_g  with  loss = sum NLL + image term + (1/B_g) sum_b KL_b        (VILoss.py:460,478; Loss.py:129)
+    loss / B_g  with  loss = sum NLL + image term + max(m * (1/B_g) sum_b KL_b, margin)        (VILoss.py:460-478; Loss.py:129)
 
 so every rank back-propagates with normalization = B_g and KL batch size = B_g and the gradients are SUMMED (not
-averaged) -- see SURVEY.md section 8e.  The arena is ordered by backward completion (generator first), and it is reduced
-in a few large buckets (xGMI is per-link bound: fewer, larger collectives)."""
+averaged) -- see SURVEY.md section 8e.  What crosses ranks per step:
+
+  * the gradient arena, reduced segment by segment from inside the backward plan (engine.py: ALLREDUCE entries) so that the
+    collectives overlap the rest of backward (xGMI is per-link bound: few, large collectives);
+  * ONE float, the KL sum, before the latent backward (free bits compares the GLOBAL batch-mean KL with the margin);
+  * nothing else: the global batch size / token count come from the loader (`onmt.io.OrderedIterator(dp_rank=, dp_world=)`
+    cuts every global minibatch into the ranks' shares on the host), the gradient norm is a deterministic reduction of the
+    (bit-identical) reduced gradients on every rank, and eps / dropout streams are offset by the rank."""
 import torch
 
 
@@ -18,13 +24,18 @@ class GradSync(object):
         self.bucket_elems = bucket_elems
         self.dist = None
         self.world = 1
+        self.rank = 0
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 self.dist = dist
                 self.world = dist.get_world_size()
-                if engine is not None:
+                self.rank = dist.get_rank()
+                if engine is not None and engine.dp is None:
                     engine.dp = self
+                    # the seed is shared (identical initial parameters); the noise streams must not be: each replica draws
+                    # its own eps ~ N(0, I) and dropout masks (counter-based RNG: disjoint counter ranges per rank)
+                    engine.rng_counter += self.rank * (1 << 40)
         except Exception:
             pass
 
@@ -32,13 +43,18 @@ class GradSync(object):
     def flat(self):
         return self._flat if self._flat is not None else self.engine.flat_g
 
-    def global_batch(self, local_value):
-        """sum of a per-rank integer (batch size / token count) over the ranks"""
+    def global_sizes(self, *local_values):
+        """FALLBACK for loaders that do not shard by rank themselves: sums of per-rank integers (batch size, token count)
+        over the ranks -- ONE blocking all-reduce + device-to-host copy for all of them.  The sharding iterator
+        (`onmt.io.OrderedIterator(dp_rank=, dp_world=)`) knows the global figures on the host and never calls this."""
         if self.world == 1:
-            return local_value
-        t = torch.tensor([float(local_value)], device=self.flat.device)
+            return tuple(float(v) for v in local_values)
+        t = torch.tensor([float(v) for v in local_values], device=self.flat.device, dtype=torch.float64)
         self.dist.all_reduce(t)
-        return float(t.item())
+        return tuple(t.tolist())
+
+    def global_batch(self, local_value):
+        return self.global_sizes(local_value)[0]
 
     def buckets(self):
         n = self.flat.numel()
@@ -56,3 +72,34 @@ class GradSync(object):
             return
         for o, e in self.buckets():
             self.dist.all_reduce(self.flat[o:e])
+
+    def broadcast_replica(self, src=0):
+        """re-synchronise the replicas (parameters + Adam moments) from rank `src`.  Replicas stay bit-identical by
+        construction (identical reduced gradients, deterministic norm); the trainer calls this every few thousand updates as
+        cheap insurance (240 MB x 3 over xGMI) and right after a checkpoint is loaded."""
+        if self.world == 1 or self.engine is None:
+            return
+        e = self.engine
+        for t in (e.flat_p, e.flat_m, e.flat_v):
+            self.dist.broadcast(t, src)
+        e.shadows_dirty = True
+
+    def replicas_identical(self):
+        """debug / test aid: True when every rank holds bit-identical parameters (one 8-byte all-reduce pair)"""
+        if self.world == 1 or self.engine is None:
+            return True
+        p = self.engine.flat_p
+        h = torch.stack([p.double().sum(), p.double().abs().sum()])
+        lo, hi = h.clone(), h.clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        return bool(torch.equal(lo, hi))
+
+    def reduce_stats(self, values):
+        """sum a list of per-rank statistics (floats) over the ranks: every rank's VIStatistics holds its SHARE of the
+        global figures (NLL / words / correct of its sentences, its share of the batch-mean KL and of the image term)"""
+        if self.world == 1:
+            return list(values)
+        t = torch.tensor(list(values), device=self.flat.device, dtype=torch.float64)
+        self.dist.all_reduce(t)
+        return t.tolist()

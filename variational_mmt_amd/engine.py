@@ -17,6 +17,7 @@ HBM layout
     to 16 bytes, refreshed by vmmt_pack after each optimiser step.
   * workspace: activations saved for backward, per (B, S, T') shape, time-major rows (t*B + b).
 """
+import collections
 import ctypes as C
 import math
 from os import environ as _os_env
@@ -95,13 +96,23 @@ class Buf(object):
     way the buffer is traversed (K-contiguous or K-strided, also from a row / column offset): the padding contributes
     exact zeros.  Nothing ever writes the padding."""
 
-    def __init__(self, rows, cols, dtype, device, ld=None, fill=None):
+    def __init__(self, rows, cols, dtype, device, ld=None, fill=None, storage=None):
         esz = torch.empty((), dtype=dtype).element_size()
         self.ld = ld if ld is not None else _ru(max(cols, 1), KPAD)
         self.rows, self.cols, self.esz = rows, cols, esz
-        self.t = torch.zeros(_ru(max(rows, 1), KPAD) + KPAD, self.ld, dtype=dtype, device=device)
+        prow = _ru(max(rows, 1), KPAD) + KPAD
+        if storage is not None:
+            # a view of storage shared between workspaces (Engine.shared_storage): it holds FINITE leftovers of other shapes
+            # instead of zeros; only for buffers whose every reduction partner is zero-padded itself (see Workspace.GT)
+            self.t = storage[:prow * self.ld].view(prow, self.ld)
+        else:
+            self.t = torch.zeros(prow, self.ld, dtype=dtype, device=device)
         if fill is not None:
             self.t[:rows, :cols].fill_(fill)
+
+    @staticmethod
+    def elems(rows, cols):
+        return (_ru(max(rows, 1), KPAD) + KPAD) * _ru(max(cols, 1), KPAD)
 
     def p(self, r=0, c=0):
         return self.t.data_ptr() + (r * self.ld + c) * self.esz
@@ -122,10 +133,18 @@ class Engine(object):
         self.tsz = 2 if self.dt == L.BF16 else 4
         self._build_arena(seed, param_init)
         self._build_shadows()
-        self.ws = {}
+        # per-shape workspaces: a bounded LRU (real data has hundreds of (S, T') pairs per epoch).  Shapes are rounded up to
+        # `shape_bucket` positions (pad positions are masked everywhere), the largest buffer (G^T) is shared between all
+        # workspaces, and the least recently used workspaces are dropped once `ws_budget_bytes` is exceeded.
+        self.ws = collections.OrderedDict()
+        self.shape_bucket = max(1, int(_os_env.get("VMMT_SHAPE_BUCKET", "2")))
+        self.ws_budget_bytes = int(float(_os_env.get("VMMT_WS_BUDGET_GB", "48")) * (1 << 30))
+        self.ws_evictions = 0
+        self._shared = {}
         self.shadows_dirty = True
         self.step_count = 0          # Adam step counter
-        self.rng_counter = 1234567 + seed
+        self.seed = seed
+        self.rng_counter = 1234567 + seed      # dp.GradSync offsets it by the rank: eps / dropout masks differ between replicas
         self.reparam_grad = False    # H2: as executed (sample detached)
         self.stats_host = None
         self._sid = 0
@@ -155,7 +174,7 @@ class Engine(object):
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
         self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
         self.bg_adam_blocks = 0      # grid cap of the background half of Adam (it has ~0.4 ms of slack under the encoder)
-        self._sumsq = torch.zeros(4, dtype=torch.float32, device=self.dev)
+        self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
         self._sumsq_by_plan = False
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
         self._works = []
@@ -344,6 +363,18 @@ class Engine(object):
     def _call(self, plan, fn, *args):
         plan.append((fn, args, fn.__name__, None, self._sid))
 
+    def _zero(self, plan, tensors):
+        """plan entry: clear all `tensors` (contiguous device tensors) with ONE vmmt_zero_multi launch"""
+        arr = (L.ZeroDesc * len(tensors))()
+        start = 0
+        for k, t in enumerate(tensors):
+            nbytes = t.numel() * t.element_size()
+            assert t.is_contiguous() and t.data_ptr() % 16 == 0 and nbytes % 4 == 0
+            arr[k] = L.ZeroDesc(t.data_ptr(), nbytes, start)
+            start += (nbytes + 16383) // 16384
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+        plan.append((self.lib.vmmt_zero_multi, (tab.data_ptr(), len(tensors), start), "vmmt_zero_multi", (tab, tensors), self._sid))
+
     # -- two-stream plans: entries carry a stream id (0 = main = torch's current stream, 1 = side stream); EV_RECORD /
     #    EV_WAIT entries fork and join them.  Work that is off the critical path of the step (weight-gradient GEMMs, bias
     #    sums, the image / q(z|x) networks' backward) runs on the side stream underneath the latency-bound LSTM steps.
@@ -360,11 +391,12 @@ class Engine(object):
         hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
         plan.append((None, (lo, min(hi, self.n_opt)), "ALLREDUCE", None, self._sid))
 
-    def _sumsq_entry(self, plan, first_name, end_name):
-        """plan entry: accumulate ||g||^2 of an arena range into the step's norm scalar (behind that range's all-reduce)"""
+    def _sumsq_entry(self, plan, first_name, end_name, slot):
+        """plan entry: ||g||^2 of an arena range into slot `slot` of the step's norm scratch (behind that range's all-reduce);
+        every range has a slot of its own and Adam adds the slots in index order: the norm is bit-reproducible"""
         lo = self.offsets[first_name][0]
         hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
-        plan.append((None, (lo, min(hi, self.n_opt)), "SUMSQ", None, self._sid))
+        plan.append((None, (lo, min(hi, self.n_opt), slot), "SUMSQ", None, self._sid))
 
     def finish_allreduce(self):
         """make the current stream wait for every outstanding gradient all-reduce (call before optim_step)"""
@@ -392,14 +424,21 @@ class Engine(object):
         fn, args, name, _keep, sid = entry
         if fn is None:
             if name == "SUMSQ":
-                lo, hi = args
+                lo, hi, slot = args
                 if self._works:
                     with torch.cuda.stream(ts[sid]):
                         for w in self._works:
                             w.wait()
                     self._works = []
-                L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), hs[sid]), "vmmt_sumsq")
+                L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq")
                 self._sumsq_by_plan = True
+                return
+            if name == "KL_ALLREDUCE":
+                if self.dp is not None and self.dp.world > 1:
+                    ws = self._cur_ws
+                    with torch.cuda.stream(ts[sid]):
+                        ws.kl_global.copy_(ws.stats[L.STAT_KL_SUM:L.STAT_KL_SUM + 1])
+                        self.dp.dist.all_reduce(ws.kl_global, async_op=True).wait()
                 return
             if name == "ALLREDUCE":
                 if self.dp is not None and self.dp.world > 1:
@@ -418,23 +457,59 @@ class Engine(object):
                 ev = events.get(args) if args in events else self.global_events.get(args)
                 if ev is not None:
                     ts[sid].wait_event(ev)
-        elif name == "memset":
-            if sid == 0 or single_stream:
-                args[0].zero_()
-            else:
-                with torch.cuda.stream(ts[sid]):
-                    args[0].zero_()
         else:
             rc = fn(*args, hs[sid])
             if rc != 0:
                 L.check(rc, name)
 
     # ------------------------------------------------------------------------------------------------ workspace
+    def bucket_shape(self, S, Tp):
+        g = self.shape_bucket
+        return min(_ru(S, g), max(S, 64)), _ru(Tp, g)
+
+    def shared_storage(self, name, elems, dtype):
+        """one device allocation per name, shared by every workspace and grown to the largest request.  Growing it invalidates
+        the pointers baked into the cached launch plans, so every cached workspace is dropped then (rare: a new largest shape)."""
+        cur = self._shared.get(name)
+        if cur is None or cur.numel() < elems or cur.dtype != dtype:
+            if cur is not None:
+                self.drop_workspaces()
+                self._shared[name] = cur = None
+            self._shared[name] = cur = torch.zeros(elems, dtype=dtype, device=self.dev)
+        return cur
+
+    def drop_workspaces(self, keep_last=0):
+        """evict cached training workspaces (oldest first), keeping the `keep_last` most recently used"""
+        keys = [k for k, v in self.ws.items() if isinstance(v, Workspace)]
+        victims = keys[:max(0, len(keys) - keep_last)]
+        if victims:
+            torch.cuda.synchronize(self.dev)      # their buffers may still be in use on the side streams
+            for k in victims:
+                del self.ws[k]
+                self.ws_evictions += 1
+
+    def workspace_bytes(self):
+        return sum(v.nbytes for v in self.ws.values() if isinstance(v, Workspace))
+
     def workspace(self, B, S, Tp):
-        key = (B, S, Tp)
-        if key not in self.ws:
-            self.ws[key] = Workspace(self, B, S, Tp)
-        return self.ws[key]
+        """the workspace (buffers + launch plans) serving B sentences, S source positions, T' decoder steps: shape
+        (B, bucket(S), bucket(T'))"""
+        Sb, Tb = self.bucket_shape(S, Tp)
+        key = (B, Sb, Tb)
+        ws = self.ws.get(key)
+        if ws is not None:
+            self.ws.move_to_end(key)
+            return ws
+        before = torch.cuda.memory_allocated(self.dev)
+        ws = Workspace(self, B, Sb, Tb)
+        ws.nbytes = max(0, torch.cuda.memory_allocated(self.dev) - before)
+        self.ws[key] = ws
+        while self.workspace_bytes() > self.ws_budget_bytes and sum(isinstance(v, Workspace) for v in self.ws.values()) > 1:
+            oldest = next(k for k, v in self.ws.items() if isinstance(v, Workspace))
+            torch.cuda.synchronize(self.dev)
+            del self.ws[oldest]
+            self.ws_evictions += 1
+        return ws
 
 
 class Workspace(object):
@@ -457,6 +532,7 @@ class Workspace(object):
         self.img = nb(B, D, f32)
         self.eps = nb(B, Z, f32, ld=Z)
         self.stats = torch.zeros(L.STAT_COUNT, dtype=f32, device=dev)
+        self.kl_global = torch.zeros(1, dtype=f32, device=dev)
         # encoder
         self.Xs = nb(MS, E)
         self.enc_gx = [nb(MS, dirs * 4 * Hd, f32) for _ in range(Lyr)]
@@ -504,7 +580,10 @@ class Workspace(object):
         self.lse = torch.zeros(M, dtype=f32, device=dev)
         self.tok_nll = torch.zeros(M, dtype=f32, device=dev)
         # backward
-        self.GT = nb(V, M)
+        # G^T [V][T'B] is the largest buffer of a step (307 MB at B 256 / V 30 000 / T' 20): ONE allocation shared by all
+        # workspaces.  Leftovers of another shape are harmless: it is fully rewritten for columns < M by the generator backward
+        # before anything reads it, and its padding only ever meets the zero padding of O (dW_g, K = M) or of W_g (dO, K = V).
+        self.GT = Buf(V, M, T, dev, storage=eng.shared_storage("GT", Buf.elems(V, M), T))
         self.dO32 = nb(M, H, f32)
         self.dPre = nb(M, H)
         self.dcat = nb(M, 2 * H)
@@ -553,13 +632,10 @@ class Workspace(object):
         e._record(P, "side_fwd")
         if training:
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
-            e._call(P, _memset, e.flat_g[e.offsets["generator.0.bias"][0]:])
-            # small accumulators of the backward plan, zeroed here (off the critical path) instead of in front of their users
-            e._call(P, _memset, e._sumsq)
-            e._call(P, _memset, self.dO32.t)
-            for l in range(Lyr):
-                e._call(P, _memset, self.dec_dcc[l].t)
-                e._call(P, _memset, self.enc_dcc[l].t)
+            # ... together with the small accumulators of the backward plan (off the critical path instead of in front of
+            # their users): one launch
+            e._zero(P, [e.flat_g[e.offsets["generator.0.bias"][0]:], e._sumsq[:L.SUMSQ_SLOTS], self.dO32.t] +
+                    [b.t for l in range(Lyr) for b in (self.dec_dcc[l], self.enc_dcc[l])])
         self._mask_entries = getattr(self, "_mask_entries", {})
         if drop:
             # output dropout mask (VI_Model1.py:132): only needed after the decoder -> generated in the background
@@ -749,6 +825,9 @@ class Workspace(object):
         # (the bias gradient = row sums of G^T comes out of the same kernel; the gradient arena was zeroed on the side stream in
         #  front of `dec_gx`, which the main stream has waited for)
         fuse_db = _os_env.get("VMMT_FUSE_DB", "1") == "1"
+        # entries that carry run-time scalars (1 / normalization, KL weights): patched per step by backward_plan(), so that
+        # token normalisation (a different value every batch) does not rebuild the plan
+        self._patch = {"gen": (len(P), 12)}
         if fuse_db:
             e._call(P, lib.vmmt_gen_loss_bwd_db, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
                     M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld, e.gp("generator.0.bias"))
@@ -761,6 +840,7 @@ class Workspace(object):
         # ================= aux: image term + its network (z is detached: independent of the text path) ==========
         e._sid = AUX
         e._wait(P, "bwd_begin")
+        self._patch["img"] = (len(P), 7)
         e._call(P, lib.vmmt_image_loss, dt, self.mu_v.p(), self.mu_v.ld, self.img.p(), self.img.ld, B, D, inv_norm,
                 self.dmu_v.p(), self.dmu_v.ld, self.stats.data_ptr())
         w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
@@ -777,6 +857,9 @@ class Workspace(object):
         e._call(P, lib.vmmt_gate_bwd, self.dzt.p(), self.dzt.ld, self.z32.p(), self.gate.data_ptr(),
                 e.gp("inf_net_image.gate_affine_transform.weight"), e.gp("inf_net_image.gate_affine_transform.bias"), B, Z)
         # --- KL term -> q(z|x) networks (mu, sigma receive gradient only through the KL: H2) ------------------
+        # data parallelism: free bits compares the GLOBAL batch-mean KL with the margin (VILoss.py:463-476), so the KL sum is
+        # all-reduced (one float, on this stream, long after the forward produced it) before the latent backward reads it
+        P.append((None, None, "KL_ALLREDUCE", None, e._sid))
         self._latent_bwd_index = len(P)
         if d.conditional:
             e._call(P, lib.vmmt_latent_cond_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
@@ -899,9 +982,9 @@ class Workspace(object):
             e._allreduce(P, "decoder.attn.linear_out.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
             # gradient norm of everything that is final by now (generator, attention, decoder, inference networks): off the
             # critical path, underneath the encoder chain
-            e._sumsq_entry(P, "generator.0.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
+            e._sumsq_entry(P, "generator.0.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1), 0)
             e._wait(P, "aux_done")
-            e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None)
+            e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None, 2)
         if not d.conditional:
             finish_first_half()
         # ================= encoder LSTM backward (main) + its parameter gradients (side) ==========================
@@ -1022,7 +1105,7 @@ class Workspace(object):
         e._sid = MAIN
         e._wait(P, "side_done")
         e._allreduce(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
-        e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
+        e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight", 1)
         return P
 
     # ------------------------------------------------------------------------------- conditional-prior variant (8f-1)
@@ -1167,7 +1250,7 @@ class Workspace(object):
         dh_above = self.enct_dout
         for l in reversed(range(Lyr)):
             dg = self.enct_dgates[l]
-            e._call(P, _memset, self.enct_dcc[l].t)
+            e._zero(P, [self.enct_dcc[l].t])
             arr = (L.LstmDirBwd * (2 * B))()
             for step in range(B):
                 for k in range(2):
@@ -1216,39 +1299,40 @@ class Workspace(object):
                         MT, E, 8 * ht, out_f32=1, scatter_ids=self.tgt_bt.data_ptr())
 
 
+    def kl_sum_ptr(self):
+        """the KL sum the backward weighs against the free-bits margin: this rank's statistic, or under data parallelism its
+        all-reduced copy (`kl_global`, filled by the KL_ALLREDUCE entry of the backward plan)"""
+        if self.e.dp is not None and self.e.dp.world > 1:
+            return self.kl_global.data_ptr()
+        return self.stats.data_ptr() + 4 * L.STAT_KL_SUM
+
     def _latent_bwd_args(self, batch_global, kl_mult, use_freebits, margin, inv_norm):
         if self.e.d.conditional:
-            return (self.e.dt, self.mu.p(), self.sigma.p(), self.mu_p.p(), self.sigma_p.p(), self.stats.data_ptr() + 4 * L.STAT_KL_SUM,
+            return (self.e.dt, self.mu.p(), self.sigma.p(), self.mu_p.p(), self.sigma_p.p(), self.kl_sum_ptr(),
                     float(batch_global), float(kl_mult), 1 if use_freebits else 0, float(margin), float(inv_norm),
                     self.q_dmu.p(), self.q_dmu.ld, self.q_dpre.p(), self.q_dpre.ld, self.p_dmu.p(), self.p_dmu.ld,
                     self.p_dpre.p(), self.p_dpre.ld, self.B, self.e.d.z)
-        return (self.e.dt, self.mu.p(), self.sigma.p(), self.stats.data_ptr() + 4 * L.STAT_KL_SUM, float(batch_global),
+        return (self.e.dt, self.mu.p(), self.sigma.p(), self.kl_sum_ptr(), float(batch_global),
                 float(kl_mult), 1 if use_freebits else 0, float(margin), float(inv_norm), self.q_dmu.p(), self.q_dmu.ld,
                 self.q_dpre.p(), self.q_dpre.ld, self.B, self.e.d.z)
 
     def backward_plan(self, inv_norm, batch_global, kl_mult, use_freebits, margin, drop):
-        key = (float(inv_norm), float(batch_global), bool(drop))
+        key = bool(drop)                 # the only STRUCTURAL input; every scalar is patched below
         if self._bwd_key != key:
             self.plan_bwd = self._plan_backward(inv_norm, batch_global, kl_mult, use_freebits, margin, drop)
             self._bwd_key = key
-        fn, _, name, keep, sid = self.plan_bwd[self._latent_bwd_index]
-        self.plan_bwd[self._latent_bwd_index] = (fn, self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm),
-                                                 name, keep, sid)
-        return self.plan_bwd
+        P = self.plan_bwd
+        fn, _, name, keep, sid = P[self._latent_bwd_index]
+        P[self._latent_bwd_index] = (fn, self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm), name, keep, sid)
+        for ii, pos in self._patch.values():
+            fn, args, name, keep, sid = P[ii]
+            P[ii] = (fn, args[:pos] + (float(inv_norm),) + args[pos + 1:], name, keep, sid)
+        return P
 
     def ones_col(self):
         if not hasattr(self, "_ones"):
             self._ones = Buf(self.M, 1, self.e.T, self.e.dev, fill=1.0)
         return self._ones
-
-
-def _memset(t, stream=None):
-    """plan entry: zero a torch tensor (hipMemsetAsync through torch) -- executed by Engine._run on the entry's stream."""
-    t.zero_()
-    return 0
-
-
-_memset.__name__ = "memset"
 
 
 # ======================================================================================================= step API
@@ -1286,6 +1370,7 @@ def _engine_methods():
         gen_eps = training and eps is None
         self.rng_counter += 1
         L.check(self.lib.vmmt_prepare_batch(src_d.data_ptr(), tgt_d.data_ptr(), len_d.data_ptr(), idx_d.data_ptr(), S, Tp + 1, B,
+                                            ws.S, ws.Tp + 1, PAD,
                                             ws.src.data_ptr(), ws.tgt_in.data_ptr(), ws.y.data_ptr(), ws.src_len.data_ptr(),
                                             ws.img_idx.data_ptr(), ws.stats.data_ptr(), ws.eps.p() if gen_eps else None,
                                             B * d.z if gen_eps else 0, self.rng_counter, st), "vmmt_prepare_batch")
@@ -1294,7 +1379,9 @@ def _engine_methods():
             if tgt_len is None:
                 raise RuntimeError("the conditional model needs tgt_lengths (q(z|x,y,v) averages the target encodings)")
             ws.tgt_len.copy_(dev64(tgt_len).reshape(-1))
-            ws.tgt_bt.copy_(tgt_d.reshape(Tp + 1, B).t().reshape(-1))      # rows b*T + t (encoder_tgt sees the transposed target)
+            # rows b*T + t (encoder_tgt sees the transposed target); positions beyond the batch's T hold the pad id
+            ws.tgt_bt.fill_(PAD)
+            ws.tgt_bt.view(B, ws.Tn)[:, :Tp + 1].copy_(tgt_d.reshape(Tp + 1, B).t())
         if training:
             if eps is not None:
                 ws.eps.view().copy_(eps.to(device=dev, dtype=torch.float32))
@@ -1350,6 +1437,7 @@ def _engine_methods():
             raise RuntimeError("loss_backward() after an eval-mode forward")
         self._run(ws.plan_loss_train, ws.events)
         plan = ws.backward_plan(1.0 / norm, bg, kl_mult, use_freebits, margin, bool(ws.training))
+        self._cur_ws = ws
         self._run(plan, ws.events)
         return ws
 
@@ -1376,8 +1464,8 @@ def _engine_methods():
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
         if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
-            self._sumsq.zero_()
-            L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), st), "vmmt_sumsq")
+            self._sumsq[:L.SUMSQ_SLOTS].zero_()
+            L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), 0, st), "vmmt_sumsq")
         self._sumsq_by_plan = False
         self.step_count += 1
         split = self.offsets[self.first_enc_name][0]

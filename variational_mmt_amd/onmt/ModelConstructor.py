@@ -44,5 +44,12 @@ def make_vi_model_mmt(model_opt, fields, gpu, checkpoint=None):
         print("Loading model parameters.")
         sd = dict(checkpoint["model"])
         sd.update({"generator." + k: v for k, v in checkpoint["generator"].items()})
-        model.load_state_dict(sd, strict=False)
+        # strict: a missing or misnamed key is an error.  The one known alias: the conditional model's encoder_tgt shares the
+        # decoder's embedding table (ModelConstructor.py:456-457), so the reference's state dict lists that tensor twice.
+        alias = "encoder_tgt.embeddings.make_embedding.emb_luts.0.weight"
+        if alias in sd:
+            if not torch.equal(sd[alias], sd["decoder.embeddings.make_embedding.emb_luts.0.weight"]):
+                raise RuntimeError("checkpoint: encoder_tgt and decoder embeddings differ (they are one shared table)")
+            del sd[alias]
+        model.load_state_dict(sd, strict=True)
     return model

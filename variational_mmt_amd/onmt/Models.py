@@ -101,7 +101,7 @@ class NMTVIModel(nn.Module):
         ob = ws.O if (self.training and self.dims.dropout > 0) else ws.AH
         out = ob.t.as_strided((Tp, B, H), (B * ob.ld, ob.ld, 1))
         attns = {
-            "std": ws.probs.view(Tp, B, S),
+            "std": ws.probs.view(ws.Tp, B, ws.S)[:Tp, :, :S],       # the workspace may be bucketed to a larger (T', S)
             "p_global_image_features": [Normal(ws.mu_v.view(), None)],
             "ground_truth_global_image_features": [ws.img.view()],
             "z_latent": [Normal(ws.mu.view(), ws.sigma.view())],

@@ -53,9 +53,17 @@ class VIStatistics(object):
             return
         from .. import _lib as L
         vals = torch.stack([p[0] for p in self._pending]).tolist()          # one D2H copy
-        for s, (_t, B, Bg, mult, fb, margin) in zip(vals, self._pending):
+        for s, pend in zip(vals, self._pending):
+            _t, B, Bg, mult, fb, margin = pend[:6]
+            has_global = len(pend) > 6 and pend[6]
+            # single process: Bg == B.  Data parallel: this rank's SHARE of the global figures (shares add up over the ranks to
+            # the statistics of the single-process run on the whole minibatch); slot STAT_COUNT-1 carries the all-reduced KL sum
             kl_before = s[L.STAT_KL_SUM] / Bg
-            kl_after = max(kl_before * mult, margin) if fb else kl_before * mult
+            kl_after = kl_before * mult
+            if fb:
+                kl_glob = (s[L.STAT_COUNT - 1] if has_global else s[L.STAT_KL_SUM]) / Bg * mult
+                if kl_glob < margin:
+                    kl_after = margin * B / Bg
             v = self._v
             v["nmt_loss"] += s[L.STAT_NLL]
             v["td_kl_before"] += kl_before
@@ -151,6 +159,7 @@ class TrainerMultimodal(object):
         self.model.set_image_tables(train=train_img_feats, valid=valid_img_feats)
         from .. import dp
         self.dp = dp.GradSync(self.model.engine)          # no-op unless torch.distributed is initialised with > 1 rank
+        self.dp_resync_every = 2000                       # replicas are bit-identical by construction; cheap insurance
         self.model.train()
 
     # ------------------------------------------------------------------------------------------------------------
@@ -175,10 +184,13 @@ class TrainerMultimodal(object):
         for idx, batch in enumerate(train_iter):
             if hasattr(train_iter, "get_cur_dataset"):
                 self.train_loss.cur_dataset = train_iter.get_cur_dataset()
+            # (under data parallelism these are this rank's figures; _gradient_accumulation turns them into the global ones)
             if self.norm_method == "tokens":
-                normalization = int(batch.tgt[0][1:].ne(self.train_loss.padding_idx).sum())
+                normalization = getattr(batch, "global_ntokens", None)
+                if normalization is None:
+                    normalization = int(batch.tgt[0][1:].ne(self.train_loss.padding_idx).sum())
             else:
-                normalization = batch.batch_size
+                normalization = getattr(batch, "global_batch_size", batch.batch_size)
             self._gradient_accumulation([batch], total_stats, report_stats, normalization)
             if report_func is not None:
                 report_stats = report_func(epoch, idx, num_batches, total_stats.start_time, self.optim.lr, report_stats,
@@ -221,14 +233,24 @@ class TrainerMultimodal(object):
             src, src_lengths, tgt, tgt_lengths = self._prep(batch)
             report_stats.n_src_words += int(src.shape[0] * src.shape[1])   # upper bound without a device sync
             world = self.dp.world
-            self.train_loss.batch_global = self.dp.global_batch(batch.batch_size)
+            norm = normalization
+            if world == 1:
+                self.train_loss.batch_global = batch.batch_size
+            elif hasattr(batch, "global_batch_size"):
+                # the sharding iterator (onmt.io.OrderedIterator(dp_rank=, dp_world=)) cut a global minibatch on the host:
+                # the global batch size / token count are known here without any collective or host sync
+                self.train_loss.batch_global = batch.global_batch_size
+            else:
+                # a per-rank loader: ONE blocking all-reduce for both figures (slow path, kept for compatibility)
+                self.train_loss.batch_global, norm = self.dp.global_sizes(batch.batch_size, normalization)
             outputs, attns, _ = self.model(src, tgt, src_lengths, tgt_lengths, None, img_indices=batch.indices,
                                            img_table=self.model._tables["train"], padding_token=self.train_loss.padding_idx)
-            norm = normalization if world == 1 else self.dp.global_batch(normalization)
             batch_stats = self.train_loss.sharded_compute_loss(batch, outputs, attns, 0, tgt.shape[0], self.shard_size, norm)
             self.model_updates += 1
             self.dp.all_reduce()
             self.optim.step()
+            if world > 1 and self.dp_resync_every and self.model_updates % self.dp_resync_every == 0:
+                self.dp.broadcast_replica(0)
             total_stats.update(batch_stats)
             report_stats.update(batch_stats)
 

@@ -40,8 +40,13 @@ class NMTVIModel1LossCompute(LossComputeBase):
         self.n_model_updates += 1
 
     def _stats(self, ws, mult):
-        return VIStatistics(self.multimodal_model_type, pending=(ws.stats.clone(), ws.B, float(self.batch_global or ws.B), mult,
-                                                                 self.use_kl_freebits, self.kl_freebits_margin))
+        st = ws.stats.clone()
+        dp = ws.e.dp
+        has_global = dp is not None and dp.world > 1 and ws.training
+        if has_global:
+            st[-1] = ws.kl_global[0]       # the all-reduced KL sum the backward compared with the free-bits margin (spare slot)
+        return VIStatistics(self.multimodal_model_type, pending=(st, ws.B, float(self.batch_global or ws.B), mult,
+                                                                 self.use_kl_freebits, self.kl_freebits_margin, has_global))
 
     def sharded_compute_loss(self, batch, output, attns, cur_trunc, trunc_size, shard_size, normalization):
         ws = attns["_ws"]

@@ -267,8 +267,17 @@ class OrderedIterator(object):
     length before it is numericalised (what the packed encoder needs)."""
 
     def __init__(self, dataset, batch_size, sort_key=None, device=None, batch_size_fn=None, train=True, repeat=None, shuffle=None,
-                 sort=None, sort_within_batch=None):
-        self.batch_size, self.train, self.dataset = batch_size, train, dataset
+                 sort=None, sort_within_batch=None, dp_rank=0, dp_world=1, dp_seed=1234):
+        """`dp_world` > 1 (an extension; the reference is single-GPU): every rank walks the SAME sequence of global minibatches
+        of `batch_size * dp_world` examples (a shuffler seeded with `dp_seed` on every rank) and numericalises only its share
+        -- the examples `dp_rank, dp_rank + dp_world, ...` of the length-sorted minibatch, so the ranks' shares are disjoint,
+        sorted, equally long (+-1) and of near-equal token count.  A batch carries `global_batch_size` and `global_ntokens`
+        (what the trainer needs to normalise like the single-process run on the whole minibatch) -- no collective, no host
+        sync.  A training minibatch with fewer examples than ranks (the tail of an epoch: < dp_world examples) is skipped so
+        that every rank sees the same number of batches."""
+        self.dp_rank, self.dp_world = int(dp_rank), int(dp_world)
+        assert 0 <= self.dp_rank < self.dp_world
+        self.batch_size, self.train, self.dataset = batch_size * self.dp_world, train, dataset
         self.batch_size_fn = batch_size_fn
         self.iterations = 0
         self.repeat = train if repeat is None else repeat
@@ -277,7 +286,7 @@ class OrderedIterator(object):
         self.sort_within_batch = self.sort if sort_within_batch is None else sort_within_batch
         self.sort_key = dataset.sort_key if sort_key is None else sort_key
         self.device = device
-        self.random_shuffler = RandomShuffler()
+        self.random_shuffler = RandomShuffler(random.Random(dp_seed).getstate()) if self.dp_world > 1 else RandomShuffler()
         self._iterations_this_epoch = 0
 
     def data(self):
@@ -314,6 +323,15 @@ class OrderedIterator(object):
                         minibatch.reverse()
                     else:
                         minibatch.sort(key=self.sort_key, reverse=True)
-                yield Batch(minibatch, self.dataset, self.device, self.train)
+                if self.dp_world == 1:
+                    yield Batch(minibatch, self.dataset, self.device, self.train)
+                    continue
+                if len(minibatch) < self.dp_world:
+                    continue
+                b = Batch(minibatch[self.dp_rank::self.dp_world], self.dataset, self.device, self.train)
+                b.global_batch_size = len(minibatch)
+                # non-pad positions of tgt[1:]: the sentence's tokens + </s>  (normalization == "tokens", TrainerMultimodal.py:336-341)
+                b.global_ntokens = sum(len(getattr(ex, "tgt", ())) + 1 for ex in minibatch)
+                yield b
             if not self.repeat:
                 return
