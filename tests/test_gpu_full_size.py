@@ -96,5 +96,79 @@ def test_full_size_gradients_fp32_against_the_oracle():
     e32.optim_step(lr=0.002, max_grad_norm=5.0)
     torch.cuda.synchronize()
     po, tot = O.clip_and_adam(p, g, {})
+    # (first Adam step: the update is lr * g / (|g| + 1e-9) = +-lr wherever |g| >> 1e-9, so the comparison is exact except where a
+    #  gradient element is itself at rounding level -- there a relative error of the gradient moves the update by up to lr)
     for k in ("generator.0.weight", "decoder.rnn.weight_hh_l0", "encoder.embeddings.make_embedding.emb_luts.0.weight"):
-        assert (e32.params[k].cpu() - po[k]).abs().max().item() <= 2e-5, k
+        err = (e32.params[k].cpu() - po[k]).abs()
+        assert err.max().item() <= 2.1e-3 and (err > 2e-5).float().mean().item() <= 1e-4, (k, err.max().item(), (err > 2e-5).float().mean().item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 (roofline stress): S = T' = 64, V = 50 000, 2-layer 1024, z 512.  Full sequence length, vocabulary, depth and
+# widths; the batch is 16 sentences so that the CPU oracle's autograd finishes in seconds (nothing in the step couples sentences
+# except the batch means, and B = 256 is what `bench.py --config 5` runs).  H3: the loss uses ALL 64 target rows.
+def _setup5(B=16):
+    c = O.Cfg(vs=50000, vt=50000, emb=1024, hid=1024, z=512, img=2048, layers=2, brnn=True)
+    p = O.init_params(c, seed=0)
+    bt = O.synth_batch(c, B=B, S=64, T=65, n_img=100, seed=11, fixed_len=False)
+    return c, p, bt
+
+
+def test_cfg5_fp32_forward_loss_and_gradients_against_the_oracle():
+    from variational_mmt_amd.engine import Dims, Engine
+    c, p, bt = _setup5()
+    B = bt["src"].shape[1]
+    img = bt["table"][bt["indices"]]
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
+    assert Lo["n_words"] > 32 * B // 2                               # more target rows than one reference shard holds (H3)
+    e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda:0")
+    e.load_state_dict(p)
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+    e.loss_backward(ws, normalization=B)
+    torch.cuda.synchronize()
+    st = e.read_stats(ws)
+    for k, ok in (("nmt", "nll"), ("td_kl_before", "kl_before"), ("elbo", "elbo"), ("img_feats_loss", "img_logprob")):
+        ref = float(Lo[ok])
+        assert abs(st[k] - ref) <= 5e-5 * abs(ref), (k, st[k], ref)
+    assert st["n_words"] == Lo["n_words"]
+    H, S, Tp = c.hid, 64, 64
+    assert (ws.enc_out[-1].view().view(S, B, H).cpu() - r["context"]).abs().max().item() <= 5e-5
+    assert (ws.probs.view(Tp, B, S).cpu() - r["attn"]).abs().max().item() <= 5e-5
+    assert (ws.tok_nll.view(Tp, B).cpu() - Lo["tok_nll"]).abs().max().item() <= 2e-3
+    assert set(g) == set(e.grads)
+    for k in g:
+        err = (e.grads[k].cpu().double() - g[k].double()).abs().max().item() / max(g[k].abs().max().item(), 1e-30)
+        tol = 5e-3 if (k.startswith("inf_net_image.location.fc1") or k.startswith("inf_net_image.gate_affine_transform")) else 4e-4
+        assert err <= tol, (k, err)
+
+
+def test_cfg5_bf16_against_fp32_and_properties():
+    """the throughput path at the config-5 shape (MFMA attention with the 64 x 1024 source memory in LDS, LSTM steps with K = 1024 /
+    4096 chunk loops, 2 layers with inter-layer dropout off): against the fp32 mode, plus the size-independent properties"""
+    from variational_mmt_amd.engine import Dims, Engine
+    c, p, bt = _setup5(B=32)
+    B = 32
+    out = {}
+    for dt in ("f32", "bf16"):
+        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype=dt, device="cuda:0")
+        e.load_state_dict(p)
+        e.set_image_table(bt["table"])
+        ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+        e.loss_backward(ws, normalization=B)
+        torch.cuda.synchronize()
+        out[dt] = (e, ws, e.read_stats(ws))
+    (e32, ws32, s32), (e16, ws16, s16) = out["f32"], out["bf16"]
+    for k in ("nmt", "td_kl_before", "elbo"):
+        assert abs(s16[k] - s32[k]) <= 3e-3 * abs(s32[k]), (k, s16[k], s32[k])
+    assert s16["n_words"] == s32["n_words"]
+    pa, pb = ws32.probs.view(64, B, 64), ws16.probs.view(64, B, 64)
+    assert (pa - pb).abs().max().item() <= 3e-2 and (pb.sum(2) - 1).abs().max().item() <= 1e-5
+    g32, g16 = e32.flat_g[:e32.n_opt].double(), e16.flat_g[:e16.n_opt].double()
+    assert ((g16 - g32).norm() / g32.norm()).item() <= 5e-2      # 2 layers x 64 steps of bf16 state (measured 3.3e-2)
+    M = 64 * B
+    G16 = ws16.GT.view()[:, :M]
+    y = bt["tgt"][1:].reshape(-1)
+    assert G16.float().sum(0).abs().max().item() <= 3e-4
+    assert (G16[:, (y == 1).cuda()] == 0).all()

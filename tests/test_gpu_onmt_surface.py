@@ -99,11 +99,22 @@ def test_three_updates_through_the_onmt_surface_and_checkpoint_roundtrip(tmp_pat
     model2 = onmt.ModelConstructor.make_vi_model_mmt(opt, fields, True, ck)
     for k, v in model.state_dict().items():
         assert torch.equal(v.cpu(), model2.state_dict()[k].cpu()), k
+    assert isinstance(ck["optim"].optimizer, torch.optim.Adam) and len(ck["optim"].params) == len(list(model.parameters()))
     optim2 = ck["optim"]
     optim2.optimizer.load_state_dict(ck["optim"].optimizer.state_dict())      # train_mm_vi_model1.py:434-438
     optim2.set_parameters(model2.parameters())
-    assert model2.engine.step_count == 3
-    assert torch.equal(model2.engine.flat_m.cpu(), eng.flat_m.cpu()) and torch.equal(model2.engine.flat_v.cpu(), eng.flat_v.cpu())
+    # AS EXECUTED by the reference, set_parameters builds a NEW Adam (Optim.py:56-70): moments and step counter restart,
+    # lr / _step / decay flags survive
+    assert model2.engine.step_count == 0 and not model2.engine.flat_m.any() and not model2.engine.flat_v.any()
+    assert optim2._step == 3 and optim2.lr == optim.lr
+    # the opt-in extension carries the moments over (matched to the arena by shape + value, not by position)
+    ck2 = torch.load(fname, map_location="cpu", weights_only=False)
+    model3 = onmt.ModelConstructor.make_vi_model_mmt(opt, fields, True, ck2)
+    optim3 = ck2["optim"]
+    optim3.resume_adam_state = True
+    optim3.set_parameters(model3.parameters())
+    assert model3.engine.step_count == 3
+    assert torch.equal(model3.engine.flat_m.cpu(), eng.flat_m.cpu()) and torch.equal(model3.engine.flat_v.cpu(), eng.flat_v.cpu())
 
 
 def test_conditional_model_through_the_onmt_surface(tmp_path):

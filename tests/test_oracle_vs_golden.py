@@ -35,6 +35,8 @@ def test_forward_and_stats(name):
     _close(r["out"], z["f_out"], what="out")
     _close(r["mu_v"], z["f_mu_v"], what="mu_v", rtol=1e-4)
     L = O.loss(p, c, r, bt["tgt"], img)                    # semantic "B" == as-executed forward
+    if "f_tok_nll" in z.files:                             # per-token NLL through the reference's own generator
+        _close(L["tok_nll"], z["f_tok_nll"], what="per-token NLL", rtol=2e-5, atol=2e-5)
     _close(L["nll"], z["s_nmt_loss"], what="nll", rtol=1e-5)
     _close(L["kl_before"], z["s_td_kl_before"], what="kl")
     _close(L["kl_after"], z["s_td_kl_after"], what="kl_after")

@@ -299,6 +299,235 @@ __global__ void __launch_bounds__(256) attn_bwd_fast(const bf16_t* __restrict__ 
   }
 }
 
+
+// ==============================================================================================================
+// MFMA attention for longer sequences / wider memories (bf16, T' <= 64, S <= 64, H % 32 == 0, H <= 1024; BASELINE config 5:
+// S = T' = 64, H = 1024).  One workgroup per sentence, four waves.  The source memory Hs_b [S x H] is the ONLY full operand
+// image in LDS (129 KB at H = 1024: three images as in the kernels above would need 390 KB); queries / incoming gradients
+// are read straight from global memory into MFMA A fragments (16 bytes per lane, rows are K-contiguous), and the products whose
+// reduction runs over t (dHs = P^T dC + dS^T Q, both operands K-strided) stage dC and Q column chunk by column chunk into the
+// region the memory occupied, after its last use.
+//   scores: 2 x 2 tiles of 32 x 32, one per wave, full K = H (no cross-wave fold); softmax row statistics are exchanged through a
+//   64 x 2 float table; context / dQ / dHs: 32 x 32 output tiles dealt round-robin to the waves.
+// ==============================================================================================================
+// stage `rows` rows of `cols` elements (row r from src + r*rstride; rows >= nrows are zero-filled) into a [rows][pitch] image
+__device__ __forceinline__ void astage_n(bf16_t* img, int pitch, const bf16_t* src, long rstride, int nrows, int rows, int cols) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  for (int r = wave; r < rows; r += 4) {
+    const bf16_t* g = src + (long)r * rstride;
+    for (int c = lane * 8; c < cols; c += 512) {
+      u32x4 v = zero;
+      if (r < nrows) v = *reinterpret_cast<const u32x4*>(g + c);
+      *reinterpret_cast<u32x4*>(img + r * pitch + c) = v;
+    }
+  }
+}
+// A fragment of a 32 x 16 slab straight from global memory: row = row0 + (lane & 31) (zeros at rows >= nrows), k = kbase + 8 (lane >> 5) ..
+__device__ __forceinline__ bf16x8 afragG(const bf16_t* base, long rstride, int row0, int nrows, int kbase, int lane) {
+  const int r = row0 + (lane & 31);
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (r < nrows) v = *reinterpret_cast<const u32x4*>(base + (long)r * rstride + kbase + 8 * (lane >> 5));
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ float half_max(float v) {       // over the 32 lanes of this lane's half-wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+constexpr int ATT_PB = 72;       // pitch of the 64 x 64 probability / score-gradient images (bf16 elements)
+
+__global__ void __launch_bounds__(256) attn_fwd_big(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ ctx,
+                                                    long ldc, const long long* __restrict__ lens, bf16_t* __restrict__ cat,
+                                                    long ldcat, float* __restrict__ probs, int Tp, int B, int S, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int P = H + 8;
+  const int rows_s = (S + 15) & ~15, rows_t = (Tp + 15) & ~15;
+  bf16_t* Hs = reinterpret_cast<bf16_t*>(smem_raw);                       // [ru32(S)][P]: score tiles read whole 32-row tiles
+  bf16_t* Pb = Hs + 64 * P;                                               // [64][ATT_PB]
+  float* red = reinterpret_cast<float*>(Pb + 64 * ATT_PB);                // [64][2] row statistics per s-tile
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int len = (int)lens[b];
+  len = len < S ? len : S;
+  astage_n(Hs, P, ctx + (long)b * ldc, (long)B * ldc, S, (S + 31) & ~31, H);
+  __syncthreads();
+  const int tt = wave >> 1, st = wave & 1;
+  const bool active = tt * 32 < Tp && st * 32 < S;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (active) {
+    const bf16_t* qb = q + (long)b * ldq;
+    for (int k0 = 0; k0 < H; k0 += 64) {           // four A fragments in flight
+      bf16x8 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = k0 + 16 * j < H ? afragG(qb, (long)B * ldq, tt * 32, Tp, k0 + 16 * j, lane) : afragG(qb, 0, 0, 0, 0, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k0 + 16 * j < H) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], afragKC(Hs, P, st * 32, k0 + 16 * j, lane), acc, 0, 0, 0);
+    }
+  }
+  const int s_ = st * 32 + (lane & 31);
+  float v[16], m[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    v[r] = s_ < len ? acc[r] : -INFINITY;
+    m[r] = half_max(v[r]);
+    if ((lane & 31) == 0) red[(tt * 32 + acc_row(r, lane)) * 2 + st] = m[r];
+  }
+  __syncthreads();
+  float e[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = tt * 32 + acc_row(r, lane);
+    const float mm = fmaxf(red[t * 2], red[t * 2 + 1]);          // finite: position 0 is never masked (len >= 1)
+    e[r] = s_ < len ? __expf(v[r] - mm) : 0.f;
+    m[r] = half_sum(e[r]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((lane & 31) == 0) red[(tt * 32 + acc_row(r, lane)) * 2 + st] = m[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = tt * 32 + acc_row(r, lane);
+    const float p = t < Tp ? e[r] / (red[t * 2] + red[t * 2 + 1]) : 0.f;
+    if (t < Tp && s_ < S) probs[((long)t * B + b) * S + s_] = p;
+    Pb[t * ATT_PB + s_] = f2bf(p);
+  }
+  __syncthreads();
+  const int nht = H / 32, nks = rows_s / 16;
+  for (int idx = wave; idx < (rows_t + 31) / 32 * nht; idx += 4) {     // context tiles: (t-tile, 32 hidden units)
+    const int t0 = (idx / nht) * 32, h0 = (idx % nht) * 32;
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    for (int ks = 0; ks < nks; ++ks)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKC(Pb, ATT_PB, t0, ks * 16, lane), afragKS(Hs, P, h0, ks * 16, lane), c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = t0 + acc_row(r, lane);
+      if (t < Tp) cat[((long)t * B + b) * ldcat + h0 + (lane & 31)] = f2bf(c[r]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_big(const bf16_t* __restrict__ dcat, long lddc, const float* __restrict__ probs,
+                                                    const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ ctx,
+                                                    long ldc, const long long* __restrict__ lens, bf16_t* __restrict__ dq,
+                                                    long lddq, bf16_t* __restrict__ dctx, long lddx, int Tp, int B, int S, int H,
+                                                    int HC, int big_elems) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int P = H + 8, PC = HC + 8;
+  const int rows_s = (S + 15) & ~15, rows_t = (Tp + 15) & ~15;
+  bf16_t* Hs = reinterpret_cast<bf16_t*>(smem_raw);                       // [rows_s][P]; later dC / Q chunks [rows_t][PC] x 2
+  bf16_t* Pb = Hs + big_elems;                                            // [64][ATT_PB]
+  bf16_t* dSb = Pb + 64 * ATT_PB;                                         // [64][ATT_PB]
+  float* red = reinterpret_cast<float*>(dSb + 64 * ATT_PB);               // [64][2]
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int len = (int)lens[b];
+  len = len < S ? len : S;
+  astage_n(Hs, P, ctx + (long)b * ldc, (long)B * ldc, S, (S + 31) & ~31, H);
+  __syncthreads();
+  const int tt = wave >> 1, st = wave & 1;
+  const bool active = tt * 32 < Tp && st * 32 < S;
+  {   // dP = dC Hs^T (one 32 x 32 tile per wave, full K), softmax backward
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (active) {
+      const bf16_t* db = dcat + (long)b * lddc;
+      for (int k0 = 0; k0 < H; k0 += 64) {
+        bf16x8 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = k0 + 16 * j < H ? afragG(db, (long)B * lddc, tt * 32, Tp, k0 + 16 * j, lane) : afragG(db, 0, 0, 0, 0, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + 16 * j < H) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], afragKC(Hs, P, st * 32, k0 + 16 * j, lane), acc, 0, 0, 0);
+      }
+    }
+    const int s_ = st * 32 + (lane & 31);
+    float p[16], d[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = tt * 32 + acc_row(r, lane);
+      const bool on = t < Tp && s_ < len;             // masked entries never enter the arithmetic (0 x anything)
+      p[r] = on ? probs[((long)t * B + b) * S + s_] : 0.f;
+      acc[r] = on ? acc[r] : 0.f;
+      d[r] = half_sum(p[r] * acc[r]);
+      if ((lane & 31) == 0) red[t * 2 + st] = d[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = tt * 32 + acc_row(r, lane);
+      const float dot = red[t * 2] + red[t * 2 + 1];
+      Pb[t * ATT_PB + s_] = f2bf(p[r]);
+      dSb[t * ATT_PB + s_] = f2bf(p[r] * (acc[r] - dot));
+    }
+  }
+  __syncthreads();
+  const int nht = H / 32;
+  {   // dQ[t][h] = sum_s dS[t][s] Hs[s][h]
+    const int nks = rows_s / 16;
+    for (int idx = wave; idx < (rows_t + 31) / 32 * nht; idx += 4) {
+      const int t0 = (idx / nht) * 32, h0 = (idx % nht) * 32;
+      f32x16 c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+      for (int ks = 0; ks < nks; ++ks)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKC(dSb, ATT_PB, t0, ks * 16, lane), afragKS(Hs, P, h0, ks * 16, lane), c, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = t0 + acc_row(r, lane);
+        if (t < Tp) dq[((long)t * B + b) * lddq + h0 + (lane & 31)] = f2bf(c[r]);
+      }
+    }
+  }
+  // dHs[s][h] = sum_t P[t][s] dC[t][h] + dS[t][s] Q[t][h]: the reduction runs over t, so dC and Q are needed K-strided:
+  // they take the memory's place in LDS, HC columns at a time
+  bf16_t* dCs = Hs;
+  bf16_t* Qs = Hs + 64 * PC;
+  const int nkt = rows_t / 16, nhc = HC / 32;
+  for (int c0 = 0; c0 < H; c0 += HC) {
+    __syncthreads();                                 // everybody is done with the previous occupant of the region
+    astage_n(dCs, PC, dcat + (long)b * lddc + c0, (long)B * lddc, Tp, rows_t, HC);
+    astage_n(Qs, PC, q + (long)b * ldq + c0, (long)B * ldq, Tp, rows_t, HC);
+    __syncthreads();
+    for (int idx = wave; idx < (rows_s + 31) / 32 * nhc; idx += 4) {
+      const int s0 = (idx / nhc) * 32, h0 = (idx % nhc) * 32;
+      f32x16 c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+      for (int ks = 0; ks < nkt; ++ks) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKS(Pb, ATT_PB, s0, ks * 16, lane), afragKS(dCs, PC, h0, ks * 16, lane), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKS(dSb, ATT_PB, s0, ks * 16, lane), afragKS(Qs, PC, h0, ks * 16, lane), c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int srow = s0 + acc_row(r, lane);
+        if (srow < S) dctx[((long)srow * B + b) * lddx + c0 + h0 + (lane & 31)] = f2bf(srow < len ? c[r] : 0.f);
+      }
+    }
+  }
+}
+
+// LDS request of the big kernels; bwd: the large region holds max(memory image, two column-chunk images)
+static int attn_big_chunk(int H) { return (H % 64 == 0 && H > 256) ? H / 2 : H; }
+static size_t attn_big_lds_fwd(int H) { return (size_t)64 * (H + 8) * 2 + 64 * ATT_PB * 2 + 64 * 2 * 4; }
+static size_t attn_big_elems_bwd(int H) {
+  size_t a = (size_t)64 * (H + 8), c = (size_t)2 * 64 * (attn_big_chunk(H) + 8);
+  return a > c ? a : c;
+}
+static size_t attn_big_lds_bwd(int H) { return attn_big_elems_bwd(H) * 2 + 2 * 64 * ATT_PB * 2 + 64 * 2 * 4; }
+
 static size_t attn_fast_lds(int H, int nimg) { return (size_t)nimg * 32 * (H + 8) * 2 + 4 * 32 * 33 * 4 + 2 * 32 * 40 * 2; }
 
 // masked mean over time of the (detached) encoder memory: hbar[b] = sum_{s<len} ctx[s][b] / len
@@ -318,6 +547,8 @@ __global__ void masked_mean_kernel(const T* __restrict__ ctx, long ldc, const lo
 
 }  // namespace vmmt
 
+static bool big_ok(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && ld % 8 == 0; }   // 16-byte row loads
+
 extern "C" int vmmt_attn_fwd(int dtype, const void* q, int64_t ldq, const void* ctx, int64_t ldc, const int64_t* lens,
                              void* cat, int64_t ldcat, float* probs, int Tp, int B, int S, int H, void* stream) {
   using namespace vmmt;
@@ -328,6 +559,14 @@ extern "C" int vmmt_attn_fwd(int dtype, const void* q, int64_t ldq, const void* 
     static size_t attr = 0;
     if (sm > attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr = sm; }
     hipLaunchKernelGGL(attn_fwd_fast, dim3(B), dim3(256), sm, (hipStream_t)stream, (const bf16_t*)q, (long)ldq, (const bf16_t*)ctx,
+                       (long)ldc, (const long long*)lens, (bf16_t*)cat, (long)ldcat, probs, Tp, B, S, H);
+    return check_launch();
+  }
+  if (dtype == VMMT_BF16 && Tp <= 64 && S <= 64 && H % 32 == 0 && attn_big_lds_fwd(H) <= 160 * 1024 && big_ok(q, ldq) && big_ok(ctx, ldc)) {
+    size_t sm = attn_big_lds_fwd(H);
+    static size_t attr = 0;
+    if (sm > attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr = sm; }
+    hipLaunchKernelGGL(attn_fwd_big, dim3(B), dim3(256), sm, (hipStream_t)stream, (const bf16_t*)q, (long)ldq, (const bf16_t*)ctx,
                        (long)ldc, (const long long*)lens, (bf16_t*)cat, (long)ldcat, probs, Tp, B, S, H);
     return check_launch();
   }
@@ -360,6 +599,16 @@ extern "C" int vmmt_attn_bwd(int dtype, const void* dcat, int64_t lddc, const fl
     hipLaunchKernelGGL(attn_bwd_fast, dim3(B), dim3(256), sm, (hipStream_t)stream, (const bf16_t*)dcat, (long)lddc, probs,
                        (const bf16_t*)q, (long)ldq, (const bf16_t*)ctx, (long)ldc, (const long long*)lens, (bf16_t*)dq, (long)lddq,
                        (bf16_t*)dctx, (long)lddx, Tp, B, S, H);
+    return check_launch();
+  }
+  if (dtype == VMMT_BF16 && Tp <= 64 && S <= 64 && H % 32 == 0 && attn_big_lds_bwd(H) <= 160 * 1024 && big_ok(dcat, lddc) && big_ok(q, ldq) &&
+      big_ok(ctx, ldc)) {
+    size_t sm = attn_big_lds_bwd(H);
+    static size_t attr = 0;
+    if (sm > attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr = sm; }
+    hipLaunchKernelGGL(attn_bwd_big, dim3(B), dim3(256), sm, (hipStream_t)stream, (const bf16_t*)dcat, (long)lddc, probs,
+                       (const bf16_t*)q, (long)ldq, (const bf16_t*)ctx, (long)ldc, (const long long*)lens, (bf16_t*)dq, (long)lddq,
+                       (bf16_t*)dctx, (long)lddx, Tp, B, S, H, attn_big_chunk(H), (int)attn_big_elems_bwd(H));
     return check_launch();
   }
   size_t esz = dtype == VMMT_F32 ? 4 : 2;

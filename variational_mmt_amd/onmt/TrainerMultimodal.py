@@ -262,6 +262,7 @@ class TrainerMultimodal(object):
         sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
         model_sd = {k: v for k, v in sd.items() if "generator" not in k}
         gen_sd = {k[len("generator."):]: v for k, v in sd.items() if k.startswith("generator.")}
+        self.optim._ckpt_cpu = sd          # Optim.__getstate__ wraps these same tensors: one copy of each in the file
         checkpoint = {"model": model_sd, "generator": gen_sd, "vocab": io.save_fields_to_vocab(fields), "opt": opt,
                       "epoch": epoch, "optim": self.optim}
         if not overwrite:
