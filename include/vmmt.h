@@ -136,6 +136,20 @@ int vmmt_lstm_chain_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd
 int vmmt_lstm_chain_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* dirs, const int64_t* lens, int B, int H,
                         int mode, void* stream);
 
+/* a whole FORWARD recurrence in ONE LAUNCH (persistent kernel): every workgroup keeps its W_hh slice in LDS for the whole
+ * sequence and the workgroups of a 32-sentence row group hand h_t to each other in-launch as tagged 8-byte granules
+ * ({two bf16 | tag}, one sc1 write-through store each; consumers re-read with sc1 loads until the tags match; bounded spins).
+ * `dirs` = the nsteps x ndir step descriptors in HOST memory (validated here), `dirs_dev` = the same array in DEVICE memory
+ * (read by the kernel); `sync` (vmmt_lstm_seq_sync_words() uint32: launch epoch, finish count, error code -- 0 = every wait
+ * completed) and `xchg` (vmmt_lstm_seq_xchg_bytes() bytes, 16-byte aligned): device scratch private to the call site, zeroed
+ * ONCE when allocated and then left alone.  Same semantics and BITS as vmmt_lstm_chain_fwd, which this call falls back to when
+ * the persistent kernel does not apply (fp32, H not in {64,128,256,512}, more workgroups than CUs, unaligned rows, steps not
+ * chained h_prev[t] == h_out[t-1] / c_prev[t] == c_out[t-1]). */
+int vmmt_lstm_seq_sync_words(void);
+int64_t vmmt_lstm_seq_xchg_bytes(int ndir, int B, int H);
+int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd* dirs, const vmmt_lstm_dir_fwd* dirs_dev,
+                      const int64_t* lens, int B, int H, uint32_t* sync, void* xchg, void* stream);
+
 
 /* ---- statistics vector (f32[VMMT_STAT_COUNT], device memory, zeroed by the caller before each step) ------------
  * sums that VIStatistics needs (onmt/TrainerMultimodal.py:32-228, filled at onmt/VILoss.py:483-497). */
@@ -214,10 +228,17 @@ int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, int dy_f32, c
  * kl_b[b] = sum_k 0.5(mu^2+sigma^2-1) - log sigma (VILoss.py:446-456); stats[KL_SUM] += sum_b kl_b. */
 int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT, int64_t ldz,
                     float* kl_b, float* stats, int B, int Z, int training, void* stream);
-/* d/d(mu, pre-softplus scale) of max(mult * KL_mean, margin) * inv_norm  (VILoss.py:460-473, Loss.py:129) */
+/* d/d(mu, pre-softplus scale) of max(mult * KL_mean, margin) * inv_norm  (VILoss.py:460-473, Loss.py:129).
+ * dz / eps (f32 [B][Z], both or NULL): the reparameterised gradient z = mu + sigma * eps NOT detached -- d mu += dz,
+ * d sigma += dz * eps.  As executed the reference detaches the sample (hazard H2: modules/Dists.py:21-26, Models.py:930-933),
+ * so the default passes NULL. */
 int vmmt_latent_bwd(int dtype, const float* mu, const float* sigma, const float* kl_sum, float batch_global, float mult,
-                    int use_freebits, float margin, float inv_norm, void* dmu, int64_t ld1, void* dpre, int64_t ld2, int B,
-                    int Z, void* stream);
+                    int use_freebits, float margin, float inv_norm, const float* dz, const float* eps, void* dmu, int64_t ld1,
+                    void* dpre, int64_t ld2, int B, int Z, void* stream);
+/* dL/dz of the reparameterised sample: sum_t dzrow[t*B + b] (= dgates_t W_z, the decoder-input path: VI_Model1.py:99-100) plus
+ * the image network's gate path zt = z * sigmoid(w.z + bias) (NormalVariationalEncoder.py:286-293; dzt = dL/dzt). */
+int vmmt_reparam_dz(const float* dzrow, int64_t ldr, int T, const float* dzt, int64_t ldd, const float* z, const float* g,
+                    const float* w, float* out, int B, int Z, void* stream);
 /* ---- conditional-prior variant (--conditional) -------------------------------------------------
  * p(z|x) = gen_net_global (onmt/Models.py:889), q(z|x,y,v) = GlobalFullInferenceNetwork
  * (onmt/modules/NormalVariationalEncoder.py:164-228), KL between two diagonal Gaussians (onmt/VILoss.py:437-452).
@@ -228,8 +249,8 @@ int vmmt_latent_cond_fwd(int dtype, const float* mu, const float* sigma, const f
                          int training, void* stream);
 int vmmt_latent_cond_bwd(int dtype, const float* mu, const float* sigma, const float* mu_p, const float* sigma_p,
                          const float* kl_sum, float batch_global, float mult, int use_freebits, float margin, float inv_norm,
-                         void* dmu, int64_t ld1, void* dpre, int64_t ld2, void* dmu_p, int64_t ld3, void* dpre_p, int64_t ld4,
-                         int B, int Z, void* stream);
+                         const float* dz, const float* eps, void* dmu, int64_t ld1, void* dpre, int64_t ld2, void* dmu_p, int64_t ld3,
+                         void* dpre_p, int64_t ld4, int B, int Z, void* stream);
 /* masked mean of BATCH-major rows (row b*T + t): the output of encoder_tgt, which the reference runs over the transposed
  * target (Models.py:892-894, hazard H5); out[b] = mean_{t<len_b} x[b*T+t] (NormalVariationalEncoder.py:65-84) */
 int vmmt_masked_mean_bm(int dtype, const void* x, int64_t ldx, const int64_t* lens, void* out, int64_t ldo, int B, int T, int H,

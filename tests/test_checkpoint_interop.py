@@ -20,6 +20,19 @@ from oracle import vi1_oracle as O
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt")
 
 
+@pytest.fixture(autouse=True)
+def _restore_modules():
+    """install_as_onmt() registers the mirror as `onmt` (and torchtext stand-ins) process-wide; other CPU tests import the REAL
+    reference under the same names (oracle/ref_harness.py), so put sys.modules back afterwards"""
+    import sys
+    before = {k: v for k, v in sys.modules.items() if k == "onmt" or k.startswith("onmt.") or k == "torchtext" or k.startswith("torchtext.")}
+    yield
+    for k in [k for k in sys.modules if k == "onmt" or k.startswith("onmt.") or k == "torchtext" or k.startswith("torchtext.")]:
+        if k not in before:
+            del sys.modules[k]
+    sys.modules.update(before)
+
+
 def _load_ckpt(tmp_path):
     import variational_mmt_amd
     onmt = variational_mmt_amd.install_as_onmt()

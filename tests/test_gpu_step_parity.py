@@ -299,3 +299,43 @@ def test_half_way_split_of_encoder_gradients(dtype):
             continue
         got, want = e.grads[k].cpu().double(), g[k].double()
         assert (got - want).norm().item() <= tg * want.norm().item(), (k, (got - want).norm().item() / want.norm().item())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["tiny_bi_l2", "small_fixed", "cond_bi_l1"])
+def test_reparameterised_gradient_switch(name, dtype):
+    """Engine.reparam_grad = True (hazard H2 switched off: z = mu + sigma * eps NOT detached -- the estimator of the paper and of
+    north_star): d z flows from the decoder input (every time step) and from the image network's gate into q(z|x) [and, for the
+    conditional model, only into q].  Every gradient against the oracle's autograd with reparam_grad=True; the as-executed default is
+    covered by the tests above."""
+    c, p, bt, z, (B, S, T) = load(name)
+    tol = TOL[dtype]
+    e = _engine(c, p, dtype)
+    e.reparam_grad = True
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"], tgt_len=bt["tgt_len"])
+    e.loss_backward(ws, normalization=B, kl_mult=0.7)
+    torch.cuda.synchronize()
+    img = bt["table"][bt["indices"]]
+    _, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], reparam_grad=True, kl_mult=0.7, tgt_len=bt["tgt_len"])
+    _, _, g_det = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], kl_mult=0.7, tgt_len=bt["tgt_len"])
+    k0 = "inf_net_global.location.fc1.weight"
+    assert (g[k0] - g_det[k0]).abs().max().item() > 1e-3 * g[k0].abs().max().item()        # the switch matters for q(z|x)
+    st = e.read_stats(ws, kl_mult=0.7)
+    assert abs(st["elbo"] - float(Lo["elbo"])) <= tol["loss"] * abs(float(Lo["elbo"]))
+    assert sorted(g.keys()) == sorted(e.grads.keys())
+    bad = []
+    for k in g:
+        got, want = e.grads[k].detach().cpu().double(), g[k].double()
+        if dtype == "bf16" and ("inf_net_image.location.fc1" in k or "gate_affine_transform" in k):
+            if (got - want).norm().item() > 0.15 * want.norm().item():
+                bad.append((k, "relL2"))
+        elif (got - want).abs().max().item() > tol["grad"] * max(want.abs().max().item(), 1e-12) + 1e-9:
+            bad.append((k, (got - want).abs().max().item(), want.abs().max().item()))
+    assert not bad, bad
+    # switching back rebuilds the as-executed plan
+    e.reparam_grad = False
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"], tgt_len=bt["tgt_len"])
+    e.loss_backward(ws, normalization=B, kl_mult=0.7)
+    torch.cuda.synchronize()
+    _cmp("as executed again", e.grads[k0], g_det[k0], tol["grad"])

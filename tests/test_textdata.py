@@ -121,3 +121,62 @@ def test_validation_iterator_keeps_order_of_batches():
         assert sorted(b.indices.tolist()) == list(range(4 * k, min(11, 4 * k + 4)))     # consecutive examples
         assert b.src[1].tolist() == sorted(b.src[1].tolist(), reverse=True)
     assert list(it)[0].indices.tolist() == batches[0].indices.tolist()                  # deterministic
+
+
+def _replay_contract(ds, batch_size, batch_size_fn, seed):
+    """the contract of onmt.io.OrderedIterator.create_batches (onmt/io/IO.py:382-393) for training, replayed independently of
+    textdata.pool(): shuffled data -> pools of 100 batches' worth -> each pool sorted by the dataset's sort key and cut into batches
+    -> the batches of ONE pool in shuffled order; a pool is exhausted before the next one starts"""
+    it = oio.OrderedIterator(dataset=ds, batch_size=batch_size, batch_size_fn=batch_size_fn, device=None, sort=False, train=True,
+                             sort_within_batch=True, repeat=False)
+    it.random_shuffler = T.RandomShuffler(random.Random(seed).getstate())
+    twin = T.RandomShuffler(random.Random(seed).getstate())
+    order = [ds[i] for i in twin(range(len(ds)))]                     # Iterator.data() with shuffle=True
+    got = [b.indices.tolist() for b in it]
+    pools = list(T.batch(order, batch_size * 100, batch_size_fn))
+    pos = 0
+    for p in pools:
+        want = [sorted(ex.indices for ex in b) for b in T.batch(sorted(p, key=ds.sort_key), batch_size, batch_size_fn)]
+        mine = got[pos:pos + len(want)]
+        pos += len(want)
+        assert sorted(sorted(b) for b in mine) == sorted(want)        # exactly this pool's batches, in some (shuffled) order
+        for b in mine:                                                # sort_within_batch: decreasing source length
+            lens = [len(next(e for e in p if e.indices == i).src) for i in b]
+            assert lens == sorted(lens, reverse=True)
+    assert pos == len(got)
+    return got, pools
+
+
+def test_training_iterator_replays_the_reference_contract_over_several_pools():
+    ds, _ = _load("train")
+    big = oio.TextDataset(examples=[], fields=ds.fields)
+    for rep in range(6):                                              # 342 examples: four pools at batch size 1
+        for ex in ds.examples:
+            e2 = T.Example()
+            e2.src, e2.tgt, e2.indices = ex.src, ex.tgt, ex.indices + 57 * rep
+            big.examples.append(e2)
+    got, pools = _replay_contract(big, 1, None, seed=11)
+    assert len(pools) == 4 and len(got) == 342
+    got3, pools3 = _replay_contract(big, 3, None, seed=12)
+    assert len(pools3) == 2 and sum(len(b) for b in got3) == 342
+    # token budget (-batch_type tokens, train_mm_vi_model1.py:197-201)
+    fn = lambda new, count, sofar: sofar + max(len(new.tgt), len(new.src)) + 1      # noqa: E731
+    got_t, _ = _replay_contract(big, 40, fn, seed=13)
+    assert sum(len(b) for b in got_t) == 342
+    for b in got_t:
+        exs = [big.examples[i] for i in b]
+        assert sum(max(len(e.tgt), len(e.src)) + 1 for e in exs) <= 40 or len(exs) == 1
+
+
+def test_evaluation_iterator_replays_the_reference_contract():
+    """IO.py:389-393: not training -> consecutive batches of the data IN ORDER, each sorted by the sort key (then reversed by
+    sort_within_batch to decreasing length: torchtext Iterator.__iter__)"""
+    ds, _ = _load("valid")
+    it = oio.OrderedIterator(dataset=ds, batch_size=3, device=None, sort=False, train=False, sort_within_batch=True, repeat=False)
+    got = [b.indices.tolist() for b in it]
+    want = []
+    for b in T.batch(ds.examples, 3):
+        s = sorted(b, key=ds.sort_key)
+        s.sort(key=ds.sort_key, reverse=True)
+        want.append([e.indices for e in s])
+    assert got == want

@@ -62,6 +62,9 @@ _SIGS = {
     "vmmt_lstm_step_fwd": (i32, [i32, i32, C.POINTER(LstmDirFwd), vp, i32, i32, vp]),
     "vmmt_lstm_step_bwd": (i32, [i32, i32, C.POINTER(LstmDirBwd), vp, i32, i32, i32, vp]),
     "vmmt_lstm_chain_fwd": (i32, [i32, i32, i32, C.POINTER(LstmDirFwd), vp, i32, i32, vp]),
+    "vmmt_lstm_seq_sync_words": (i32, []),
+    "vmmt_lstm_seq_xchg_bytes": (i64, [i32, i32, i32]),
+    "vmmt_lstm_seq_fwd": (i32, [i32, i32, i32, C.POINTER(LstmDirFwd), vp, vp, i32, i32, vp, vp, vp]),
     "vmmt_lstm_chain_bwd": (i32, [i32, i32, i32, C.POINTER(LstmDirBwd), vp, i32, i32, i32, vp]),
     "vmmt_attn_fwd": (i32, [i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp]),
     "vmmt_attn_bwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
@@ -70,7 +73,8 @@ _SIGS = {
     "vmmt_gen_set_variant": (i32, [i32]),
     "vmmt_gen_argmax": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "vmmt_latent_cond_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),
-    "vmmt_latent_cond_bwd": (i32, [i32, vp, vp, vp, vp, vp, f32, f32, i32, f32, f32, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
+    "vmmt_latent_cond_bwd": (i32, [i32, vp, vp, vp, vp, vp, f32, f32, i32, f32, f32, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
+    "vmmt_reparam_dz": (i32, [vp, i64, i32, vp, i64, vp, vp, vp, vp, i32, i32, vp]),
     "vmmt_masked_mean_bm": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "vmmt_masked_mean_bwd": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
     "vmmt_lstm_set_variant": (i32, [i32]),
@@ -85,7 +89,7 @@ _SIGS = {
     "vmmt_mul": (i32, [i32, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_act_bwd": (i32, [i32, i32, vp, i64, i32, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_latent_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),
-    "vmmt_latent_bwd": (i32, [i32, vp, vp, vp, f32, f32, i32, f32, f32, vp, i64, vp, i64, i32, i32, vp]),
+    "vmmt_latent_bwd": (i32, [i32, vp, vp, vp, f32, f32, i32, f32, f32, vp, vp, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_gate_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "vmmt_gate_bwd": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, vp]),
     "vmmt_image_loss": (i32, [i32, vp, i64, vp, i64, i32, i32, f32, vp, i64, vp, vp]),

@@ -47,6 +47,17 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f / (e + 1.0f);
 }
 
+// the LSTM cell of one (sentence, hidden unit) from the four gate pre-activations: shared by the per-step kernels (lstm.hip) and
+// the persistent recurrence (lstm_seq.hip) so that both produce the same bits (the one fused multiply-add is spelled out)
+struct LstmCell { float i, f, g, o, c, h; };
+__device__ __forceinline__ LstmCell lstm_cell_math(float pi, float pf, float pg, float po, float cp) {
+  LstmCell r;
+  r.i = sigmoidf_(pi); r.f = sigmoidf_(pf); r.g = tanhf_(pg); r.o = sigmoidf_(po);
+  r.c = __builtin_fmaf(r.f, cp, r.i * r.g);
+  r.h = r.o * tanhf_(r.c);
+  return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

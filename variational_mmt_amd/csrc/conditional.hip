@@ -43,7 +43,8 @@ __global__ void latent_cond_fwd_kernel(const float* __restrict__ mu, const float
 template <class T>
 __global__ void latent_cond_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, const float* __restrict__ mu_p,
                                        const float* __restrict__ sigma_p, const float* __restrict__ kl_sum, float batch_global,
-                                       float mult, int use_freebits, float margin, float inv_norm, T* __restrict__ dmu, long ld1,
+                                       float mult, int use_freebits, float margin, float inv_norm, const float* __restrict__ dz,
+                                       const float* __restrict__ eps, T* __restrict__ dmu, long ld1,
                                        T* __restrict__ dpre, long ld2, T* __restrict__ dmu_p, long ld3, T* __restrict__ dpre_p, long ld4,
                                        int B, int Z) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,8 +54,10 @@ __global__ void latent_cond_bwd_kernel(const float* __restrict__ mu, const float
   if (use_freebits && mult * (*kl_sum) / batch_global < margin) gs = 0.f;
   float m = mu[i], s = sigma[i], mp = mu_p[i], sp = sigma_p[i];
   float d = m - mp, isp2 = 1.f / (sp * sp);
-  dmu[(long)b * ld1 + k] = from_f<T>(gs * d * isp2);
-  dpre[(long)b * ld2 + k] = from_f<T>(gs * (s * isp2 - 1.f / s) * (1.f - __expf(-s)));          // d softplus = 1 - exp(-y)
+  float gm = gs * d * isp2, gsg = gs * (s * isp2 - 1.f / s);
+  if (dz) { gm += dz[i]; gsg += dz[i] * eps[i]; }               // reparameterised sample not detached (see latent_bwd_kernel)
+  dmu[(long)b * ld1 + k] = from_f<T>(gm);
+  dpre[(long)b * ld2 + k] = from_f<T>(gsg * (1.f - __expf(-s)));          // d softplus = 1 - exp(-y)
   dmu_p[(long)b * ld3 + k] = from_f<T>(-gs * d * isp2);
   dpre_p[(long)b * ld4 + k] = from_f<T>(gs * (1.f / sp - (d * d + s * s) * isp2 / sp) * (1.f - __expf(-sp)));
 }
@@ -107,14 +110,14 @@ extern "C" int vmmt_latent_cond_fwd(int dtype, const float* mu, const float* sig
 
 extern "C" int vmmt_latent_cond_bwd(int dtype, const float* mu, const float* sigma, const float* mu_p, const float* sigma_p,
                                     const float* kl_sum, float batch_global, float mult, int use_freebits, float margin,
-                                    float inv_norm, void* dmu, int64_t ld1, void* dpre, int64_t ld2, void* dmu_p, int64_t ld3,
-                                    void* dpre_p, int64_t ld4, int B, int Z, void* stream) {
+                                    float inv_norm, const float* dz, const float* eps, void* dmu, int64_t ld1, void* dpre, int64_t ld2,
+                                    void* dmu_p, int64_t ld3, void* dpre_p, int64_t ld4, int B, int Z, void* stream) {
   using namespace vmmt;
-  if (!mu || !sigma || !mu_p || !sigma_p || !kl_sum || !dmu || !dpre || !dmu_p || !dpre_p || B <= 0 || Z <= 0) return VMMT_EINVAL;
+  if (!mu || !sigma || !mu_p || !sigma_p || !kl_sum || !dmu || !dpre || !dmu_p || !dpre_p || B <= 0 || Z <= 0 || (dz && !eps)) return VMMT_EINVAL;
   long n = (long)B * Z;
   dim3 grid((unsigned)((n + 255) / 256));
-  if (dtype == VMMT_F32) hipLaunchKernelGGL(latent_cond_bwd_kernel<float>, grid, dim3(256), 0, ST, mu, sigma, mu_p, sigma_p, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, (float*)dmu, (long)ld1, (float*)dpre, (long)ld2, (float*)dmu_p, (long)ld3, (float*)dpre_p, (long)ld4, B, Z);
-  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(latent_cond_bwd_kernel<bf16_t>, grid, dim3(256), 0, ST, mu, sigma, mu_p, sigma_p, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, (bf16_t*)dmu, (long)ld1, (bf16_t*)dpre, (long)ld2, (bf16_t*)dmu_p, (long)ld3, (bf16_t*)dpre_p, (long)ld4, B, Z);
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(latent_cond_bwd_kernel<float>, grid, dim3(256), 0, ST, mu, sigma, mu_p, sigma_p, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, dz, eps, (float*)dmu, (long)ld1, (float*)dpre, (long)ld2, (float*)dmu_p, (long)ld3, (float*)dpre_p, (long)ld4, B, Z);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(latent_cond_bwd_kernel<bf16_t>, grid, dim3(256), 0, ST, mu, sigma, mu_p, sigma_p, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, dz, eps, (bf16_t*)dmu, (long)ld1, (bf16_t*)dpre, (long)ld2, (bf16_t*)dmu_p, (long)ld3, (bf16_t*)dpre_p, (long)ld4, B, Z);
   else return VMMT_EINVAL;
   return check_launch();
 }

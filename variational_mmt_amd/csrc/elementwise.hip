@@ -181,19 +181,40 @@ __global__ void latent_fwd_kernel(const float* __restrict__ mu, const float* __r
 
 // gradient of (kl_after / norm) w.r.t. mu and the pre-softplus scale output; kl_after = max(mult * KL_mean, margin)
 // (annealing before free bits: onmt/VILoss.py:463-473).  kl_sum is read from device memory (no host sync).
+// dz / eps (both or neither): the reparameterised path z = mu + sigma * eps NOT detached (what the paper describes; the
+// reference as executed detaches the sample, H2 -- Dists.py:21-26): d mu += dz, d sigma += dz * eps.
 template <class T>
 __global__ void latent_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma,
                                   const float* __restrict__ kl_sum, float batch_global, float mult, int use_freebits,
-                                  float margin, float inv_norm, T* __restrict__ dmu, long ld1, T* __restrict__ dpre,
-                                  long ld2, int B, int Z) {
+                                  float margin, float inv_norm, const float* __restrict__ dz, const float* __restrict__ eps,
+                                  T* __restrict__ dmu, long ld1, T* __restrict__ dpre, long ld2, int B, int Z) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Z) return;
   int b = i / Z, k = i - (long)b * Z;
   float gs = mult / batch_global * inv_norm;
   if (use_freebits && mult * (*kl_sum) / batch_global < margin) gs = 0.f;
   float m = mu[i], s = sigma[i];
-  dmu[(long)b * ld1 + k] = from_f<T>(gs * m);
-  dpre[(long)b * ld2 + k] = from_f<T>(gs * (s - 1.f / s) * (1.f - __expf(-s)));   // d softplus = 1 - exp(-y)
+  float gm = gs * m, gsg = gs * (s - 1.f / s);
+  if (dz) { gm += dz[i]; gsg += dz[i] * eps[i]; }
+  dmu[(long)b * ld1 + k] = from_f<T>(gm);
+  dpre[(long)b * ld2 + k] = from_f<T>(gsg * (1.f - __expf(-s)));   // d softplus = 1 - exp(-y)
+}
+
+// dL/dz of the reparameterised sample (f32 [B][Z]): through the decoder input (sum over the time steps of dgates_t W_z, given per
+// row in dzrow [T*B][ldr]) and through the image network's gate zt = z * sigmoid(w.z + b) (dzt = dL/dzt)
+__global__ void reparam_dz_kernel(const float* __restrict__ dzrow, long ldr, int Tsteps, const float* __restrict__ dzt, long ldd,
+                                  const float* __restrict__ z, const float* __restrict__ g, const float* __restrict__ w,
+                                  float* __restrict__ out, int B, int Z) {
+  const int b = blockIdx.x;
+  float a = 0.f;
+  for (int k = threadIdx.x; k < Z; k += 64) a += dzt[(long)b * ldd + k] * z[(long)b * Z + k];
+  a = wave_sum(a);
+  const float gg = g[b], dp = a * gg * (1.f - gg);
+  for (int k = threadIdx.x; k < Z; k += 64) {
+    float d = dzt[(long)b * ldd + k] * gg + dp * w[k];
+    for (int t = 0; t < Tsteps; ++t) d += dzrow[((long)t * B + b) * ldr + k];
+    out[(long)b * Z + k] = d;
+  }
 }
 
 // ---- image network gate: g = sigmoid(w.z + b), zt = z * g      onmt/modules/NormalVariationalEncoder.py:286-293
@@ -461,13 +482,20 @@ extern "C" int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, c
 }
 
 extern "C" int vmmt_latent_bwd(int dtype, const float* mu, const float* sigma, const float* kl_sum, float batch_global,
-                               float mult, int use_freebits, float margin, float inv_norm, void* dmu, int64_t ld1,
-                               void* dpre, int64_t ld2, int B, int Z, void* stream) {
-  if (!mu || !sigma || !kl_sum || !dmu || !dpre || B <= 0 || Z <= 0) return VMMT_EINVAL;
+                               float mult, int use_freebits, float margin, float inv_norm, const float* dz, const float* eps,
+                               void* dmu, int64_t ld1, void* dpre, int64_t ld2, int B, int Z, void* stream) {
+  if (!mu || !sigma || !kl_sum || !dmu || !dpre || B <= 0 || Z <= 0 || (dz && !eps)) return VMMT_EINVAL;
   long n = (long)B * Z;
-  if (dtype == VMMT_F32) hipLaunchKernelGGL(latent_bwd_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, mu, sigma, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, (float*)dmu, (long)ld1, (float*)dpre, (long)ld2, B, Z);
-  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(latent_bwd_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, mu, sigma, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, (bf16_t*)dmu, (long)ld1, (bf16_t*)dpre, (long)ld2, B, Z);
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(latent_bwd_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, mu, sigma, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, dz, eps, (float*)dmu, (long)ld1, (float*)dpre, (long)ld2, B, Z);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(latent_bwd_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, mu, sigma, kl_sum, batch_global, mult, use_freebits, margin, inv_norm, dz, eps, (bf16_t*)dmu, (long)ld1, (bf16_t*)dpre, (long)ld2, B, Z);
   else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_reparam_dz(const float* dzrow, int64_t ldr, int T, const float* dzt, int64_t ldd, const float* z, const float* g,
+                               const float* w, float* out, int B, int Z, void* stream) {
+  if (!dzrow || !dzt || !z || !g || !w || !out || B <= 0 || Z <= 0 || T < 0) return VMMT_EINVAL;
+  hipLaunchKernelGGL(reparam_dz_kernel, dim3(B), dim3(64), 0, ST, dzrow, (long)ldr, T, dzt, (long)ldd, z, g, w, out, B, Z);
   return check_launch();
 }
 

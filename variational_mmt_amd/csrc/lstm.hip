@@ -228,9 +228,8 @@ __device__ __forceinline__ CellInF cell_fwd_load(const StepDirF& d, const long l
 }
 __device__ __forceinline__ void cell_fwd_apply(const StepDirF& d, bool has_lens, const CellInF& in, int b, int u, int H,
                                                float pi, float pf, float pg, float po) {
-  float i = sigmoidf_(pi + in.gx[0]), f = sigmoidf_(pf + in.gx[1]), g = tanhf_(pg + in.gx[2]), o = sigmoidf_(po + in.gx[3]);
-  float c = f * in.cp + i * g;
-  float h = o * tanhf_(c);
+  const LstmCell cell = lstm_cell_math(pi + in.gx[0], pf + in.gx[1], pg + in.gx[2], po + in.gx[3], in.cp);
+  const float i = cell.i, f = cell.f, g = cell.g, o = cell.o, c = cell.c, h = cell.h;
   const bool valid = !has_lens || d.t < in.len;
   bf16_t* gs = reinterpret_cast<bf16_t*>(d.gates) + (long)b * d.ld_gates + u;
   gs[0] = f2bf(i); gs[H] = f2bf(f); gs[2 * H] = f2bf(g); gs[3 * (long)H] = f2bf(o);

@@ -1,0 +1,463 @@
+// Persistent LSTM recurrence kernels for gfx950: ONE launch per sequence instead of one per time step.
+//
+// Replaces cuDNN's single-call nn.LSTM of the reference (encoder: onmt/Models.py:124-129,140-147 with packed sequences;
+// decoder: onmt/VI_Model1.py:106,149-152).  The per-step kernels of lstm.hip re-read their W_hh slice (64 KiB per workgroup)
+// from L2 at every step -- 1.6 of the ~5 us a forward step takes -- and pay a launch boundary (~1.5 us) per step.  Here a
+// workgroup keeps its slice in LDS for the whole sequence and the workgroups of a ROW GROUP hand h_t to each other in-launch:
+//
+//   grid  (row groups of 32 sentences) x (H / 16 unit groups) x directions, 4 waves each; every workgroup must be resident at
+//         once (<= 256 workgroups, 81 KiB of LDS: one per CU, and a 64-KiB GEMM workgroup of another stream still fits beside it)
+//   step  every wave sweeps the exchange buffer for the part of h_{t-1} it multiplies (16 rows x half of K) until every granule
+//         carries this step's tag  ->  the granules' data words ARE the MFMA A fragments  ->  v_mfma_f32_16x16x32_bf16 against
+//         the LDS-resident W_hh slice  ->  fold the K quarters through LDS  ->  cell update (c stays in registers)  ->  h tile
+//         through LDS: plain 16-byte stores into the layer's output buffer (for the kernels that follow) and tagged granules
+//         into the exchange buffer (for the other workgroups of the row group).
+//
+// Hand-off protocol (cdna_hip_programming.md Guideline 16, form R2: the data IS the flag): a granule is ONE naturally aligned
+// 8-byte {two bf16 values, 32-bit tag} written by one sc1 (write-through) store; tag = epoch of the launch * 4096 + step + 1, never
+// 0.  Consumers re-read their granules with sc1 loads (L1 bypassed) until every tag matches: no flag, no fence, no drain, no
+// barrier on the hand-off, one memory latency per step.  A first version with sc1 payload + vmcnt drain + one counter per row
+// group + poll + barrier + sc1 loads measured 7 (decoder) to 14 us (encoder) per step -- two more serial memory round trips per
+// hop and 256 pollers on one line.  The exchange buffer is double-buffered by step parity (a producer can only be one step
+// ahead of the slowest consumer of its row group); the launch epoch lives in device memory and is advanced by the last
+// workgroup to finish, so no memset precedes a launch.  Nothing depends on dispatch order or XCD placement.  Spins are
+// bounded: a wave that waits longer than ~2 s sets the error word and stops waiting (the launch then finishes with garbage;
+// Engine.lstm_seq_errors() reports it).
+#include "common.hpp"
+#include "vmmt.h"
+
+namespace vmmt {
+
+struct SeqDirF {      // == vmmt_lstm_dir_fwd (checked below)
+  const void* h_prev; long ld_hprev;
+  const float* c_prev; long ld_cprev;
+  const void* w_hh; long ld_w;
+  const float* gx; long ld_gx;
+  const float* gx2; long ld_gx2;
+  void* gates; long ld_gates;
+  float* c_out; long ld_c;
+  void* h_out; long ld_h;
+  void* h_n; long ld_hn;
+  float* c_n; long ld_cn;
+  int t, capture;
+};
+static_assert(sizeof(SeqDirF) == sizeof(vmmt_lstm_dir_fwd), "descriptor layouts must match");
+
+struct SeqArgsF {
+  const SeqDirF* steps;          // DEVICE array [nsteps][ndir]
+  const long long* lens;
+  unsigned* sync;                // [0] launch epoch, [1] finished-workgroup count, [2] error word
+  unsigned long long* xchg;      // granules [ndir][ngroups][2 slots][32 rows][H / 2]
+  int B, nsteps, ndir, ngroups;
+};
+
+#ifdef VMMT_SEQ_PROBE        // tools/probe/lstm_seq_probe.hip: in-kernel timestamps (100 MHz), [block x][step][stamp]
+__device__ unsigned long long vmmt_seq_ts[8 * 64 * 8];
+__device__ unsigned vmmt_seq_xcc[512];          // [block] = XCC id | transport flag << 8
+#define SEQ_TS(i) do { if (threadIdx.x == 0 && blockIdx.x < 8 && t < 64) \
+    vmmt_seq_ts[(blockIdx.x * 64 + t) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define SEQ_TS(i) do {} while (0)
+#endif
+
+typedef __attribute__((address_space(3))) void lds_void_seq;
+typedef __attribute__((address_space(1))) const void glb_cvoid_seq;
+typedef float f32x4_s __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ u32x4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);          // aux 16 = sc1: served by L2 / memory, never a stale L1 line
+}
+__device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16);             // write-through
+}
+
+// The step descriptors are written by the host before the launch and never change: read them through the constant address
+// space, i.e. with scalar loads into SGPRs (a plain global pointer makes hipcc use vector loads and then waterfall loops around
+// every buffer instruction, because it can no longer prove the descriptor wave-uniform).
+typedef const SeqDirF __attribute__((address_space(4))) * SeqDirFConstPtr;
+__device__ __forceinline__ SeqDirF load_desc(const SeqDirF* steps, long idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return reinterpret_cast<SeqDirFConstPtr>(reinterpret_cast<uintptr_t>(steps))[idx];
+#else
+  return steps[idx];
+#endif
+}
+
+__device__ __forceinline__ bool timed_out(unsigned long long t0) { return wall_clock64() - t0 > 200000000ull; }   // 2 s at 100 MHz
+
+template <int H> struct SeqCfg {
+  static constexpr int ROWB = H * 2;                           // bytes per staged W_hh row (the whole reduction length)
+  static constexpr int NCH = ROWB / 16;
+  static constexpr int RPB = ROWB >= 256 ? 1 : 256 / ROWB;     // rows per 256-byte bank row
+  static constexpr int KMASK = (NCH < 16 ? NCH : 16) - 1;
+  static constexpr int LANES = NCH < 64 ? NCH : 64;
+  static constexpr int PIECES = ROWB > 1024 ? ROWB / 1024 : 1; // 1-KiB pieces per row (LDS-DMA moves 64 x 16 B per instruction)
+  static constexpr int NKS = H / 32;                           // MFMA K steps
+  static constexpr int KQ = NKS >= 4 ? NKS / 4 : 1;            // K steps per QUARTER: the partial sums of lstm_step_fwd_fast's four K
+                                                               // quarters are kept apart and added in its order (same bits)
+  static constexpr int W_BYTES = 64 * ROWB;
+  static constexpr int RED_BYTES = 2 * 2 * 2 * 4 * 2 * 64 * 4; // [row half][writer wave][quarter of the wave][gate][reg pair][lane] f32
+  static constexpr int HT_BYTES = 32 * 16 * 2;                 // h tile [32 rows][16 units] bf16
+  static constexpr int LDS = W_BYTES + RED_BYTES + HT_BYTES;
+  static __device__ __forceinline__ int key(int row) { return (row / RPB) & KMASK; }
+};
+
+template <int H>
+__global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
+  using Cf = SeqCfg<H>;
+  constexpr int ROWB = Cf::ROWB, KQ = Cf::KQ;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* red = reinterpret_cast<float*>(lds + Cf::W_BYTES);
+  bf16_t* htile = reinterpret_cast<bf16_t*>(lds + Cf::W_BYTES + Cf::RED_BYTES);
+  const int B = a.B, ndir = a.ndir;
+  // ---- role of this workgroup: (direction k, row group rg, unit slice).  Workgroups b and b + 8 are observed to share an XCD
+  //      (round-robin dispatch), so when the grid allows it all S = H/16 workgroups of a group are taken from ONE residue class
+  //      b % 8.  That is a speed choice only: which transport a group uses is decided below from the XCC ids the hardware reports.
+  const int S = H / 16, total = gridDim.x;
+  const int bid = blockIdx.x;
+  int grp, slice;
+  if (total % 8 == 0 && (total / 8) % S == 0) { grp = (bid % 8) + 8 * ((bid / 8) / S); slice = (bid / 8) % S; }
+  else { grp = bid / S; slice = bid % S; }
+  const int k = grp / a.ngroups, rg = grp % a.ngroups;
+  const int m0 = rg * 32, u0 = slice * 16;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wm = wave & 1, wk = wave >> 1;
+  const int n = lane & 15, kg = lane >> 4;
+  const int u = u0 + n;
+  unsigned* err = a.sync + 2;
+  // tags of this launch: epoch * 4096 + step + 1 (the epoch word is only written by the LAST workgroup of a launch to finish)
+  const unsigned tag0 = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 4096u;
+  // exchange buffer of my (direction, row group): [2 slots][2 row halves][H/32 k-steps][lo / hi][64 lanes] x 16 bytes, i.e. in
+  // the ORDER THE CONSUMERS' A FRAGMENTS ARE LOADED: lane (row n of the half, k group kg) of a sweeping wave needs units
+  // ks*32 + kg*8 .. +8 of its row = a "lo" and a "hi" piece of two granules each ({units 2j, 2j+1 | tag}); stored this way every
+  // load instruction of the sweep reads 1 KiB contiguous (8 full lines) instead of 16 rows x 64 B (fragment-shaped loads ran the
+  // sweep at 2.3 us per step: the address path, not the bytes, was the limit)
+  char* xg = reinterpret_cast<char*>(a.xchg) + ((long)grp * 2) * (32 * H * 4);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(xg);
+  // ---- transport of my group.  Every member reports the XCC it runs on; once all S have arrived, a group whose members all
+  //      sit on ONE XCD share one L2: its granules are stored with PLAIN stores (they stay in that L2) and the sc1 loads of the
+  //      sweep (L1 bypassed) are served from it -- ~200 cycles and L2 bandwidth instead of a round trip through memory at HBM
+  //      bandwidth (measured: 2.4 of the 5.1 us of a step were the sweep of sc1-stored granules: 16 MB per step chip-wide).
+  //      A group spread over several XCDs keeps the placement-independent form: sc1 (write-through) stores.
+  {
+    int* flag = reinterpret_cast<int*>(lds + Cf::W_BYTES);
+    if (threadIdx.x == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned* arrive = a.sync + 4 + 2 * grp;
+      __hip_atomic_fetch_or(arrive + 1, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = wall_clock64();
+      int f = 0;
+      for (;;) {
+        if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)S) {
+          f = __builtin_popcount(__hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
+          break;
+        }
+        if (timed_out(t0)) { __hip_atomic_store(err, 0x300u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); f = -1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      *flag = f;
+#ifdef VMMT_SEQ_PROBE
+      vmmt_seq_xcc[bid & 511] = (xcc & 15u) | ((unsigned)(f & 3) << 8);
+#endif
+    }
+  }
+  bool alive = true;                                            // false once a wait timed out: stop waiting, finish the launch
+  bool same_xcd = false;
+
+  // ---- W_hh slice -> LDS, once: rows r = gate * 16 + unit, unpadded, 16-byte chunks XOR-swizzled by the row key (conflict-free
+  //      ds_read_b128 fragments); the swizzle is applied to the per-lane SOURCE address of the LDS-DMA
+  {
+    const SeqDirF d0 = load_desc(a.steps, k);
+    const char* wp = reinterpret_cast<const char*>(d0.w_hh);
+    if (lane < Cf::LANES) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int r = wave + 4 * j;
+        const long row = (long)(r >> 4) * H + u0 + (r & 15);
+        __builtin_amdgcn_global_load_lds((glb_cvoid_seq*)(wp + row * d0.ld_w * 2 + ((lane ^ Cf::key(r)) * 16)),
+                                         (lds_void_seq*)(lds + r * ROWB), 16, 0, 0);
+      }
+    }
+  }
+  // the two cells this lane finishes every step: rows 4*kg + 2*wk + e of row half wm, unit u
+  int rows[2];
+  long long len[2];
+  float c_reg[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    rows[e] = m0 + wm * 16 + kg * 4 + 2 * wk + e;
+    const int rr = rows[e] < B ? rows[e] : B - 1;
+    len[e] = a.lens ? a.lens[rr] : 0;
+    c_reg[e] = 0.f;
+  }
+  const int arow = min(m0 + wm * 16 + n, B - 1);                // the h_{t-1} row this lane's A fragments come from (step 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const int f = *reinterpret_cast<volatile int*>(lds + Cf::W_BYTES);
+    same_xcd = f == 1;
+    alive = f >= 0;
+  }
+  __syncthreads();                                              // the flag word is part of the fold buffer
+
+  for (int t = 0; t < a.nsteps; ++t) {
+    const SeqDirF d = load_desc(a.steps, (long)t * ndir + k);
+    SEQ_TS(0);
+    // epilogue operands that do not depend on the recurrence: fetched before the wait
+    float gxv[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int rr = rows[e] < B ? rows[e] : B - 1;
+      const float* gx = d.gx + (long)rr * d.ld_gx + u;
+      gxv[e][0] = gx[0]; gxv[e][1] = gx[H]; gxv[e][2] = gx[2 * H]; gxv[e][3] = gx[3 * (long)H];
+      if (d.gx2) {
+        const float* g2 = d.gx2 + (long)rr * d.ld_gx2 + u;
+        gxv[e][0] += g2[0]; gxv[e][1] += g2[H]; gxv[e][2] += g2[2 * H]; gxv[e][3] += g2[3 * (long)H];
+      }
+      if (t == 0) c_reg[e] = d.c_prev ? d.c_prev[(long)rr * d.ld_cprev + u] : 0.f;
+    }
+    // ---- A fragments of h_{t-1}: this wave = 16 rows x two of the four K quarters (2 * KQ k-steps of 32 units)
+    u32x4 af[2][KQ];
+    if (t == 0) {                                               // the initial state: an ordinary [B][ld] bf16 buffer of an earlier kernel
+      const __amdgpu_buffer_rsrc_t hr = make_rsrc(d.h_prev);
+      const unsigned abase = (unsigned)(((long)arow * d.ld_hprev + kg * 8) * 2);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int ks = (2 * wk + j) * KQ + q;
+          af[j][q] = ks < Cf::NKS ? load16_sc1(hr, abase + (unsigned)(ks * 64)) : u32x4{0u, 0u, 0u, 0u};
+        }
+    } else {
+      // granule sweep: lane (row n of this half, k group kg) needs units ks*32 + kg*8 .. +8 = four granules = 32 contiguous bytes
+      const unsigned want = tag0 + (unsigned)t;                 // tag of step t-1
+      const unsigned gbase = (unsigned)(((((t - 1) & 1) * 2 + wm) * (H / 32) * 2) * 1024 + lane * 16);
+      const unsigned long long t_start = wall_clock64();
+      // cheap poll first: ONE granule per producer workgroup of this wave's K half (row wm*16: every row of this half is stored by
+      // one instruction of one wave of the producer), 8 bytes per lane on H/32 lanes -- the full sweep (16 KiB per wave and pass)
+      // repeated by 1024 waves while they wait would by itself saturate the memory system the hand-off travels through
+      {
+        // producer slice sl = wk * S/2 + lane (16 units: k-step sl >> 1, k groups 2 * (sl & 1) + {0, 1}); its last piece (hi of
+        // the second k group), row 0 of this half
+        const int sl = wk * (S / 2) + lane;
+        const unsigned pbase = (unsigned)(((((t - 1) & 1) * 2 + wm) * (H / 32) * 2 + (sl >> 1) * 2 + 1) * 1024 + ((2 * (sl & 1) + 1) * 16) * 16);
+        while (alive) {
+          unsigned long long g = 0;
+          if (lane < S / 2) {
+            const unsigned long long* gp = reinterpret_cast<const unsigned long long*>(xg + pbase);
+            g = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (__all(lane >= S / 2 || (unsigned)(g >> 32) == want)) break;
+          if (timed_out(t_start)) {
+            if (lane == 0) __hip_atomic_store(err, 0x200u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alive = false;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      SEQ_TS(1);
+      for (;;) {
+        u32x4 lo[2][KQ], hi[2][KQ];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            const int ks = (2 * wk + j) * KQ + q;
+            if (ks < Cf::NKS) {
+              lo[j][q] = load16_sc1(xr, gbase + (unsigned)(ks * 2048));
+              hi[j][q] = load16_sc1(xr, gbase + (unsigned)(ks * 2048 + 1024));
+            } else {
+              lo[j][q] = hi[j][q] = u32x4{0u, want, 0u, want};
+            }
+          }
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            ok = ok && lo[j][q][1] == want && lo[j][q][3] == want && hi[j][q][1] == want && hi[j][q][3] == want;
+            af[j][q] = u32x4{lo[j][q][0], lo[j][q][2], hi[j][q][0], hi[j][q][2]};
+          }
+        if (__all(ok) || !alive) break;
+        if (timed_out(t_start)) {
+          if (lane == 0) __hip_atomic_store(err, 0x100u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          alive = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    SEQ_TS(2);
+    f32x4_s acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[j][g] = f32x4_s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      // all B fragments of a quarter first (KQ x 4 ds_read_b128 in flight), then its MFMAs: one LDS latency per quarter, not per MFMA
+      bf16x8 bv[KQ][4];
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const int ks = (2 * wk + j) * KQ + q;
+        const int c = (ks < Cf::NKS ? ks : 0) * 4 + kg;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = g * 16 + n;
+          bv[q][g] = *reinterpret_cast<const bf16x8*>(lds + row * ROWB + ((c ^ Cf::key(row)) * 16));
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const int ks = (2 * wk + j) * KQ + q;
+        if (ks < Cf::NKS) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            acc[j][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[j][q]), bv[q][g], acc[j][g], 0, 0, 0);
+        }
+      }
+    }
+    // ---- hand the partner wave (same rows, other two quarters) the accumulator rows it finishes
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) red[((((wm * 2 + wk) * 2 + j) * 4 + g) * 2 + e) * 64 + lane] = wk ? acc[j][g][e] : acc[j][g][2 + e];
+    SEQ_TS(3);
+    __syncthreads();
+    SEQ_TS(4);
+    LstmCell cellv[2];
+    bool valid[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      float p[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // the four quarter sums of this cell's gate g: two of this wave (wk = 0: quarters 0, 1; wk = 1: quarters 2, 3), two of the partner
+        const float own0 = wk ? acc[0][g][2 + e] : acc[0][g][e], own1 = wk ? acc[1][g][2 + e] : acc[1][g][e];
+        const float oth0 = red[((((wm * 2 + (1 - wk)) * 2 + 0) * 4 + g) * 2 + e) * 64 + lane];
+        const float oth1 = red[((((wm * 2 + (1 - wk)) * 2 + 1) * 4 + g) * 2 + e) * 64 + lane];
+        const float q0 = wk ? oth0 : own0, q1 = wk ? oth1 : own1, q2 = wk ? own0 : oth0, q3 = wk ? own1 : oth1;
+        p[g] = (((0.f + q0) + q1) + q2) + q3;                   // lstm_step_fwd_fast's fold order
+      }
+      cellv[e] = lstm_cell_math(p[0] + gxv[e][0], p[1] + gxv[e][1], p[2] + gxv[e][2], p[3] + gxv[e][3], c_reg[e]);
+      const float cp = c_reg[e];
+      valid[e] = !a.lens || d.t < len[e];
+      c_reg[e] = valid[e] ? cellv[e].c : cp;                    // frozen state at pads (packed-sequence semantics)
+      htile[(wm * 16 + kg * 4 + 2 * wk + e) * 16 + n] = f2bf(valid[e] ? cellv[e].h : 0.f);
+    }
+    SEQ_TS(5);
+    __syncthreads();
+    SEQ_TS(6);
+    // ---- publish h_t.  Waves 0-1: tagged granules for the row group (one 16-byte store = two granules = four units of a row);
+    //      wave 2: the layer's output buffer (plain 16-byte stores, read by later kernels only)
+    if (wave < 2) {
+      // lane -> (piece, row) with the row fastest: 16 consecutive lanes store 256 contiguous bytes
+      const int l = wave * 64 + lane, piece = l >> 5, r = l & 31;
+      const unsigned* hw = reinterpret_cast<const unsigned*>(htile + r * 16 + piece * 4);
+      const unsigned tg = tag0 + (unsigned)t + 1u;
+      const unsigned off = (unsigned)(((((t & 1) * 2 + (r >> 4)) * (H / 32) * 2 + (u0 >> 5) * 2 + (piece & 1)) * 1024) +
+                                      (((u0 & 16) ? 2 : 0) + (piece >> 1)) * 256 + (r & 15) * 16);
+      const u32x4 v = u32x4{hw[0], tg, hw[1], tg};
+      if (same_xcd) *reinterpret_cast<u32x4*>(xg + off) = v;   // stays in the group's L2
+      else store16_sc1(xr, off, v);                             // write-through: visible to every XCD
+    } else if (wave == 2) {
+      const int r = lane >> 1, half = lane & 1;
+      if (m0 + r < B)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d.h_out) + ((long)(m0 + r)) * d.ld_h + u0 + half * 8) =
+            *reinterpret_cast<const u32x4*>(htile + r * 16 + half * 8);
+    }
+    // ---- what only later kernels read (saved gate activations, cell state, captured final state): behind the publish, so that
+    //      these stores overlap the row group's hand-off instead of delaying it
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int b = rows[e];
+      if (b < B) {
+        const LstmCell& cl = cellv[e];
+        bf16_t* gs = reinterpret_cast<bf16_t*>(d.gates) + (long)b * d.ld_gates + u;
+        gs[0] = f2bf(cl.i); gs[H] = f2bf(cl.f); gs[2 * H] = f2bf(cl.g); gs[3 * (long)H] = f2bf(cl.o);
+        d.c_out[(long)b * d.ld_c + u] = c_reg[e];
+        const bool cap = d.capture == 3 || (d.capture == 1 && d.t == len[e] - 1) || (d.capture == 2 && d.t == 0);
+        if (cap && d.h_n) {
+          reinterpret_cast<bf16_t*>(d.h_n)[(long)b * d.ld_hn + u] = f2bf(cl.h);
+          d.c_n[(long)b * d.ld_cn + u] = cl.c;
+        }
+      }
+    }
+    SEQ_TS(7);
+  }
+  // ---- the last workgroup to finish advances the launch epoch (kernel boundary = visibility for the next launch)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)total - 1) {
+      __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int g2 = 0; g2 < a.ndir * a.ngroups; ++g2) {          // every workgroup is past its handshake: clear it for the next launch
+        __hip_atomic_store(a.sync + 4 + 2 * g2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sync + 5 + 2 * g2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int H>
+static int launch_seq_fwd(const SeqArgsF& a, hipStream_t st) {
+  constexpr int sm = SeqCfg<H>::LDS;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)lstm_seq_fwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); attr_set = true; }
+  hipLaunchKernelGGL(lstm_seq_fwd_kernel<H>, dim3(a.ngroups * (H / 16) * a.ndir), dim3(256), sm, st, a);
+  return check_launch();
+}
+
+static bool al16s(const void* p, long ld_elems) { return (((uintptr_t)p) & 15) == 0 && (ld_elems * 2) % 16 == 0; }
+
+}  // namespace vmmt
+
+// Whole forward recurrence of one LSTM layer (both directions) in ONE launch.  `dirs` / `dirs_dev`: the same nsteps x ndir step
+// descriptors in host and in device memory (step i = [i*ndir, (i+1)*ndir)); `sync` (vmmt_lstm_seq_sync_words() uint32) and `xchg`
+// (vmmt_lstm_seq_xchg_bytes(ndir, B, H) bytes): device scratch private to this call site, zeroed ONCE by the caller when it
+// allocates them and never touched by it again.  Same results as nsteps vmmt_lstm_step_fwd calls -- which is what this function
+// issues when the persistent kernel does not apply (fp32, H not in {64,128,256,512}, more workgroups than CUs, unaligned rows,
+// or steps that are not chained h_prev[t] == h_out[t-1]).
+extern "C" int vmmt_lstm_seq_sync_words(void) { return 4 + 2 * 256; }   // epoch, finish count, error, pad; per group: arrivals, XCC mask
+extern "C" int64_t vmmt_lstm_seq_xchg_bytes(int ndir, int B, int H) {
+  if (ndir < 1 || B < 1 || H < 1) return 0;
+  return (int64_t)ndir * ((B + 31) / 32) * 2 * 32 * H * 4;
+}
+
+extern "C" int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd* dirs, const vmmt_lstm_dir_fwd* dirs_dev,
+                                 const int64_t* lens, int B, int H, uint32_t* sync, void* xchg, void* stream) {
+  using namespace vmmt;
+  if (nsteps < 0 || !dirs || ndir < 1 || ndir > 2 || B <= 0 || H <= 0) return VMMT_EINVAL;
+  if (nsteps == 0) return VMMT_OK;
+  const int ngroups = (B + 31) / 32;
+  bool ok = dtype == VMMT_BF16 && dirs_dev && sync && xchg && (((uintptr_t)xchg) & 15) == 0 && (H == 64 || H == 128 || H == 256 || H == 512) &&
+            (long)ngroups * (H / 16) * ndir <= 256 && nsteps >= 2 && nsteps < 4095;
+  for (int i = 0; ok && i < nsteps; ++i)
+    for (int k = 0; ok && k < ndir; ++k) {
+      const vmmt_lstm_dir_fwd& d = dirs[(long)i * ndir + k];
+      ok = d.h_prev && d.w_hh && d.gx && d.gates && d.c_out && d.h_out && al16s(d.h_prev, d.ld_hprev) && al16s(d.h_out, d.ld_h) &&
+           al16s(d.w_hh, d.ld_w) && d.w_hh == dirs[k].w_hh && d.ld_w == dirs[k].ld_w;
+      if (ok && i > 0) {
+        const vmmt_lstm_dir_fwd& p = dirs[(long)(i - 1) * ndir + k];
+        ok = d.h_prev == p.h_out && d.ld_hprev == p.ld_h && d.c_prev == p.c_out && d.ld_cprev == p.ld_c;
+      }
+    }
+  if (!ok) return vmmt_lstm_chain_fwd(dtype, ndir, nsteps, dirs, lens, B, H, stream);
+  SeqArgsF a;
+  a.steps = reinterpret_cast<const SeqDirF*>(dirs_dev); a.lens = (const long long*)lens; a.sync = sync;
+  a.xchg = reinterpret_cast<unsigned long long*>(xchg);
+  a.B = B; a.nsteps = nsteps; a.ndir = ndir; a.ngroups = ngroups;
+  switch (H) {
+    case 512: return launch_seq_fwd<512>(a, (hipStream_t)stream);
+    case 256: return launch_seq_fwd<256>(a, (hipStream_t)stream);
+    case 128: return launch_seq_fwd<128>(a, (hipStream_t)stream);
+    default: return launch_seq_fwd<64>(a, (hipStream_t)stream);
+  }
+}

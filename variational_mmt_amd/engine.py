@@ -145,7 +145,10 @@ class Engine(object):
         self.step_count = 0          # Adam step counter
         self.seed = seed
         self.rng_counter = 1234567 + seed      # dp.GradSync offsets it by the rank: eps / dropout masks differ between replicas
-        self.reparam_grad = False    # H2: as executed (sample detached)
+        # H2: as executed the reference detaches the latent sample (Dists.py:21-26, Models.py:930-933): mu / sigma get gradient only
+        # through the KL.  True = the reparameterised estimator the paper describes (d z flows from the decoder input and the
+        # image network into q(z|x)); tested against the oracle's reparam_grad=True (tests/test_gpu_step_parity.py)
+        self.reparam_grad = False
         self.stats_host = None
         self._sid = 0
         # the side stream carries bulk work that is off the critical path: lowest hardware priority, so that small
@@ -176,6 +179,8 @@ class Engine(object):
         self.bg_adam_blocks = 0      # grid cap of the background half of Adam (it has ~0.4 ms of slack under the encoder)
         self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
         self._sumsq_by_plan = False
+        self.persistent_lstm = _os_env.get("VMMT_PERSISTENT_LSTM", "1") == "1"     # plans are built per workspace: set before the first forward
+        self.seq_syncs = []
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
         self._works = []
 
@@ -362,6 +367,26 @@ class Engine(object):
 
     def _call(self, plan, fn, *args):
         plan.append((fn, args, fn.__name__, None, self._sid))
+
+    def _lstm_seq_fwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H):
+        """plan entry: a whole forward recurrence (nsteps x ndir step descriptors in `arr`).  persistent_lstm: ONE launch of the
+        persistent kernel (W_hh resident in LDS, in-launch hand-off of h_t: csrc/lstm_seq.hip), which falls back by itself to the
+        per-step kernels where it does not apply; otherwise the per-step kernels issued from one host call."""
+        if self.persistent_lstm:
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+            sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
+            xchg = torch.zeros(max(16, self.lib.vmmt_lstm_seq_xchg_bytes(ndir, B, H)), dtype=torch.uint8, device=self.dev)
+            plan.append((self.lib.vmmt_lstm_seq_fwd, (self.dt, ndir, nsteps, arr, dev.data_ptr(), lens_ptr, B, H, sync.data_ptr(), xchg.data_ptr()),
+                         "vmmt_lstm_seq_fwd", (arr, dev, sync, xchg), self._sid))
+            self.seq_syncs.append(sync)
+        else:
+            plan.append((self.lib.vmmt_lstm_chain_fwd, (self.dt, ndir, nsteps, arr, lens_ptr, B, H), "vmmt_lstm_chain_fwd", arr, self._sid))
+
+    def lstm_seq_errors(self):
+        """error words of the persistent recurrence launches so far (0 = every in-launch wait completed); synchronises"""
+        torch.cuda.synchronize(self.dev)
+        words = self.lib.vmmt_lstm_seq_sync_words()
+        return [int(s[2].item()) for s in self.seq_syncs]            # [launch epoch, finish count, error word]
 
     def _zero(self, plan, tensors):
         """plan entry: clear all `tensors` (contiguous device tensors) with ONE vmmt_zero_multi launch"""
@@ -664,14 +689,16 @@ class Workspace(object):
             wih, bsum = e.sh["enc_wih_l%d" % l], e.sh["enc_b_l%d" % l]
             e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hd,
                     xcols, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+            seq = (L.LstmDirFwd * (S * dirs))()                 # the whole recurrence: step-major, then direction
+            if not hasattr(self, "hzero"):
+                self.hzero = Buf(B, H, e.T, e.dev)              # first step: h_prev reads zeros
             for step in range(S):
-                arr = (L.LstmDirFwd * 2)()
                 for k in range(dirs):
                     t = step if k == 0 else S - 1 - step
                     tp = (t - 1) if k == 0 else (t + 1)
                     first = step == 0
                     whh = e.sh["enc_whh_l%d_d%d" % (l, k)]
-                    a = arr[k]
+                    a = seq[step * dirs + k]
                     a.h_prev = self.enc_out[l].p(tp * B, k * Hd) if not first else self.enc_out[l].p(t * B, k * Hd)
                     a.ld_hprev = self.enc_out[l].ld
                     a.c_prev = None if first else self.enc_c[l].p(tp * B, k * Hd)
@@ -685,14 +712,9 @@ class Workspace(object):
                     a.c_n, a.ld_cn = self.cn[l].p(0, k * Hd), self.cn[l].ld
                     a.t = t
                     a.capture = 1 if k == 0 else 2
-                self._keep.append(arr)
-                if step == 0:
-                    # first step: h_prev must read zeros -> point at the (zeroed) hzero buffer
-                    if not hasattr(self, "hzero"):
-                        self.hzero = Buf(B, H, e.T, e.dev)
-                    for k in range(dirs):
-                        arr[k].h_prev, arr[k].ld_hprev = self.hzero.p(0, k * Hd), self.hzero.ld
-                e._call(P, lib.vmmt_lstm_step_fwd, dt, dirs, arr, self.src_len.data_ptr(), B, Hd)
+                    if first:
+                        a.h_prev, a.ld_hprev = self.hzero.p(0, k * Hd), self.hzero.ld
+            e._lstm_seq_fwd(P, seq, dirs, S, self.src_len.data_ptr(), B, Hd)
             x, xcols = self.enc_out[l], H
             if l < Lyr - 1 and drop:
                 e._call(P, lib.vmmt_mul, dt, self.enc_out[l].p(), self.enc_out[l].ld, self.enc_mask[l].p(), self.enc_mask[l].ld,
@@ -757,9 +779,9 @@ class Workspace(object):
             last = l == Lyr - 1
             outb, ocol = (self.cat, H) if last else (self.dec_out[l], 0)
             whh = e.sh["dec_whh_l%d" % l]
+            seq = (L.LstmDirFwd * Tp)()
             for t in range(Tp):
-                arr = (L.LstmDirFwd * 2)()
-                a = arr[0]
+                a = seq[t]
                 if t == 0:
                     a.h_prev, a.ld_hprev = self.hn[l].p(), self.hn[l].ld
                     a.c_prev, a.ld_cprev = self.cn[l].p(), self.cn[l].ld
@@ -774,8 +796,7 @@ class Workspace(object):
                 a.c_out, a.ld_c = self.dec_c[l].p(t * B), self.dec_c[l].ld
                 a.h_out, a.ld_h = outb.p(t * B, ocol), outb.ld
                 a.h_n, a.c_n, a.t, a.capture = None, None, t, 0
-                self._keep.append(arr)
-                e._call(P, lib.vmmt_lstm_step_fwd, dt, 1, arr, None, B, H)
+            e._lstm_seq_fwd(P, seq, 1, Tp, None, B, H)
             if not last:
                 x, xcols = self.dec_out[l], H
                 if drop:
@@ -856,39 +877,48 @@ class Workspace(object):
         e._gemm(P, L.GEMM_NN, self.dh1v.p(), self.dh1v.ld, w1.p(), w1.ld, self.dzt.p(), self.dzt.ld, B, Z, D, out_f32=1)
         e._call(P, lib.vmmt_gate_bwd, self.dzt.p(), self.dzt.ld, self.z32.p(), self.gate.data_ptr(),
                 e.gp("inf_net_image.gate_affine_transform.weight"), e.gp("inf_net_image.gate_affine_transform.bias"), B, Z)
-        # --- KL term -> q(z|x) networks (mu, sigma receive gradient only through the KL: H2) ------------------
-        # data parallelism: free bits compares the GLOBAL batch-mean KL with the margin (VILoss.py:463-476), so the KL sum is
-        # all-reduced (one float, on this stream, long after the forward produced it) before the latent backward reads it
-        P.append((None, None, "KL_ALLREDUCE", None, e._sid))
-        self._latent_bwd_index = len(P)
-        if d.conditional:
-            e._call(P, lib.vmmt_latent_cond_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
-            self._cond_backward(P, drop)
-        else:
-            e._call(P, lib.vmmt_latent_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
-        qx = self.hq if d.conditional else self.hbar        # input of the q network's first layer
-        for i, (br, dy) in enumerate((("location", self.q_dmu), ("scale", self.q_dpre))):
-            w2q = e.sh["q_%s_w2" % br]
-            pre = "inf_net_global.%s" % br
-            e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"), None)
-            e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2q.p(), w2q.ld, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, Z)
-            e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.q_dh1[br].p(), self.q_dh1[br].ld, 0, self.q_h1[br].p(), self.q_h1[br].ld,
-                    None, 0, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z)
-            e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, qx.p(), qx.ld, e.gp(pre + ".fc1.weight"), d.qin,
-                    Z, d.qin, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
-            if d.conditional:   # d h_y = d h_q[:, H:2H] (h_x is detached, v is data): columns [H, 2H) of W1
-                w1q = e.sh["q_%s_w1" % br]
-                e._gemm(P, L.GEMM_NN, self.q_dh1[br].p(), self.q_dh1[br].ld, w1q.p(0, H), w1q.ld, self.dhy.p(), self.dhy.ld, B, H, Z,
-                        accumulate=1 if i else 0)
-        e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
-        if d.conditional:
-            # encoder_tgt's backward: 2 x B dependent launches that only need d h_y, next to everything below.  They scatter
-            # into the shared target-embedding gradient, so the first arena half is finished behind them (finish_first_half
-            # at the end of the plan).  (Issuing them from a helper thread was measured: no gain, removed.)
-            self._cond_backward_tgt(P, drop)
-        e._record(P, "aux_done")
+        rp = bool(e.reparam_grad)
+        if rp and not hasattr(self, "dzrow"):
+            self.dzrow = Buf(M, Z, torch.float32, e.dev)       # dgates_t W_z per decoder row
+            self.dz = Buf(B, Z, torch.float32, e.dev, ld=Z)    # dL/dz of the reparameterised sample
+
+        def kl_and_q_backward():
+            # --- KL term -> q(z|x) networks (mu, sigma receive gradient only through the KL: H2) ------------------
+            # data parallelism: free bits compares the GLOBAL batch-mean KL with the margin (VILoss.py:463-476), so the KL sum is
+            # all-reduced (one float, on this stream, long after the forward produced it) before the latent backward reads it
+            P.append((None, None, "KL_ALLREDUCE", None, e._sid))
+            self._latent_bwd_index = len(P)
+            if d.conditional:
+                e._call(P, lib.vmmt_latent_cond_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
+                self._cond_backward(P, drop)
+            else:
+                e._call(P, lib.vmmt_latent_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
+            qx = self.hq if d.conditional else self.hbar        # input of the q network's first layer
+            for i, (br, dy) in enumerate((("location", self.q_dmu), ("scale", self.q_dpre))):
+                w2q = e.sh["q_%s_w2" % br]
+                pre = "inf_net_global.%s" % br
+                e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
+                e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"), None)
+                e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2q.p(), w2q.ld, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, Z)
+                e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.q_dh1[br].p(), self.q_dh1[br].ld, 0, self.q_h1[br].p(), self.q_h1[br].ld,
+                        None, 0, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z)
+                e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, qx.p(), qx.ld, e.gp(pre + ".fc1.weight"), d.qin,
+                        Z, d.qin, B, out_f32=1, split_k=-1)
+                e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
+                if d.conditional:   # d h_y = d h_q[:, H:2H] (h_x is detached, v is data): columns [H, 2H) of W1
+                    w1q = e.sh["q_%s_w1" % br]
+                    e._gemm(P, L.GEMM_NN, self.q_dh1[br].p(), self.q_dh1[br].ld, w1q.p(0, H), w1q.ld, self.dhy.p(), self.dhy.ld, B, H, Z,
+                            accumulate=1 if i else 0)
+            e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
+            if d.conditional:
+                # encoder_tgt's backward: 2 x B dependent launches that only need d h_y, next to everything below.  They scatter
+                # into the shared target-embedding gradient, so the first arena half is finished behind them (finish_first_half
+                # at the end of the plan).  (Issuing them from a helper thread was measured: no gain, removed.)
+                self._cond_backward_tgt(P, drop)
+            e._record(P, "aux_done")
+
+        if not rp:
+            kl_and_q_backward()
         # side: dWg = G^T O as soon as G^T exists (underneath dO = G Wg of the main stream)
         e._sid = SIDE
         e._wait(P, "bwd_begin")
@@ -976,6 +1006,17 @@ class Workspace(object):
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
+        if rp:
+            # reparameterised gradient (H2 switched off): dL/dz = sum_t dgates_t W_z (decoder input, VI_Model1.py:99-100) + the image
+            # network's gate path; it joins the KL gradient at mu / sigma, so the q(z|x) networks' backward can only start here,
+            # behind the decoder chain
+            e._sid = AUX
+            e._wait(P, "dec_dg0")
+            dg0, wz = self.dec_dgates[0], e.sh["dec_wih_l0_z"]
+            e._gemm(P, L.GEMM_NN, dg0.p(), dg0.ld, wz.p(), wz.ld, self.dzrow.p(), self.dzrow.ld, M, Z, 4 * H, out_f32=1)
+            e._call(P, lib.vmmt_reparam_dz, self.dzrow.p(), self.dzrow.ld, Tp, self.dzt.p(), self.dzt.ld, self.z32.p(),
+                    self.gate.data_ptr(), e.pp("inf_net_image.gate_affine_transform.weight"), self.dz.p(), B, Z)
+            kl_and_q_backward()
         e._sid = SIDE
 
         def finish_first_half():
@@ -1182,8 +1223,7 @@ class Workspace(object):
                     a.c_out, a.ld_c = self.enct_c[l].p(t * Tn, k * ht), self.enct_c[l].ld
                     a.h_out, a.ld_h = self.enct_out[l].p(t * Tn, k * ht), self.enct_out[l].ld
                     a.t, a.capture = t, 0
-            self._keep.append(arr)
-            e._call(P, lib.vmmt_lstm_chain_fwd, dt, 2, B, arr, None, Tn, ht)
+            e._lstm_seq_fwd(P, arr, 2, B, None, Tn, ht)
             x, xcols = self.enct_out[l], H
             if l < Lyr - 1 and drop:
                 e._call(P, lib.vmmt_mul, dt, self.enct_out[l].p(), self.enct_out[l].ld, self.enct_mask[l].p(), self.enct_mask[l].ld,
@@ -1307,17 +1347,19 @@ class Workspace(object):
         return self.stats.data_ptr() + 4 * L.STAT_KL_SUM
 
     def _latent_bwd_args(self, batch_global, kl_mult, use_freebits, margin, inv_norm):
+        rp = bool(self.e.reparam_grad) and hasattr(self, "dz")
+        dzp, epp = (self.dz.p(), self.eps.p()) if rp else (None, None)
         if self.e.d.conditional:
             return (self.e.dt, self.mu.p(), self.sigma.p(), self.mu_p.p(), self.sigma_p.p(), self.kl_sum_ptr(),
                     float(batch_global), float(kl_mult), 1 if use_freebits else 0, float(margin), float(inv_norm),
-                    self.q_dmu.p(), self.q_dmu.ld, self.q_dpre.p(), self.q_dpre.ld, self.p_dmu.p(), self.p_dmu.ld,
+                    dzp, epp, self.q_dmu.p(), self.q_dmu.ld, self.q_dpre.p(), self.q_dpre.ld, self.p_dmu.p(), self.p_dmu.ld,
                     self.p_dpre.p(), self.p_dpre.ld, self.B, self.e.d.z)
         return (self.e.dt, self.mu.p(), self.sigma.p(), self.kl_sum_ptr(), float(batch_global),
-                float(kl_mult), 1 if use_freebits else 0, float(margin), float(inv_norm), self.q_dmu.p(), self.q_dmu.ld,
+                float(kl_mult), 1 if use_freebits else 0, float(margin), float(inv_norm), dzp, epp, self.q_dmu.p(), self.q_dmu.ld,
                 self.q_dpre.p(), self.q_dpre.ld, self.B, self.e.d.z)
 
     def backward_plan(self, inv_norm, batch_global, kl_mult, use_freebits, margin, drop):
-        key = bool(drop)                 # the only STRUCTURAL input; every scalar is patched below
+        key = (bool(drop), bool(self.e.reparam_grad))      # the only STRUCTURAL inputs; every scalar is patched below
         if self._bwd_key != key:
             self.plan_bwd = self._plan_backward(inv_norm, batch_global, kl_mult, use_freebits, margin, drop)
             self._bwd_key = key

@@ -262,9 +262,12 @@ class Batch(object):
 
 
 class OrderedIterator(object):
-    """onmt.io.OrderedIterator over torchtext.data.Iterator: training = shuffled data -> pool(); evaluation = the data in
-    order, consecutive batches, each sorted by length; with sort_within_batch every batch is (re)sorted by DEcreasing source
-    length before it is numericalised (what the packed encoder needs)."""
+    """onmt.io.OrderedIterator (onmt/io/IO.py:382-393, the part the reference itself holds: `create_batches` = pool() when training,
+    else consecutive batch()es each `sorted(b, key=self.sort_key)`) over torchtext.data.Iterator (its constructor defaults, data(),
+    init_epoch, __len__, __iter__ with sort_within_batch: restated from torchtext 0.2.3, torchtext/data/iterator.py -- PARITY
+    UNPINNED, see the module docstring).  The reference constructs it as OrderedIterator(dataset, batch_size, batch_size_fn,
+    device, sort=False, train=is_train, sort_within_batch=True, repeat=False) (train_mm_vi_model1.py:181-187).
+    tests/test_textdata.py replays that contract independently of pool() on the committed dataset pickles."""
 
     def __init__(self, dataset, batch_size, sort_key=None, device=None, batch_size_fn=None, train=True, repeat=None, shuffle=None,
                  sort=None, sort_within_batch=None, dp_rank=0, dp_world=1, dp_seed=1234):
