@@ -149,6 +149,13 @@ int vmmt_lstm_seq_sync_words(void);
 int64_t vmmt_lstm_seq_xchg_bytes(int ndir, int B, int H);
 int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd* dirs, const vmmt_lstm_dir_fwd* dirs_dev,
                       const int64_t* lens, int B, int H, uint32_t* sync, void* xchg, void* stream);
+/* ... and the BACKWARD recurrence (the mode-0 steps of vmmt_lstm_step_bwd: step 0 has dgates_next == NULL, step t consumes
+ * dgates_out of step t-1; dc_carry is read at the first and written at the last step).  What the row group exchanges is dgates
+ * (4H values per sentence and step).  `xchg`: vmmt_lstm_seq_xchg_bytes_bwd() bytes; otherwise the contract of vmmt_lstm_seq_fwd;
+ * falls back to vmmt_lstm_chain_bwd. */
+int64_t vmmt_lstm_seq_xchg_bytes_bwd(int ndir, int B, int H);
+int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* dirs, const vmmt_lstm_dir_bwd* dirs_dev,
+                      const int64_t* lens, int B, int H, uint32_t* sync, void* xchg, void* stream);
 
 
 /* ---- statistics vector (f32[VMMT_STAT_COUNT], device memory, zeroed by the caller before each step) ------------

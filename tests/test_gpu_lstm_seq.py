@@ -55,3 +55,95 @@ def test_persistent_recurrence_is_bit_identical_to_the_step_kernels(hid, layers,
     for k in outs[1][0]:                                                                    # batch 0 again: same bits as the first time
         for x, y in zip(*(v[k] if isinstance(v[k], list) else [v[k]] for v in (outs[1][0], outs[1][3]))):
             assert torch.equal(x, y), ("re-run differs", k)
+
+
+def _bwd_case(B, H, ndir, T, seed, lens_on):
+    """synthetic backward recurrence: descriptors exactly as the engine chains them (dgates_next[t] = dgates_out[t-1]; both
+    directions walk the time axis in opposite order), random saved activations, ragged lengths, injected final-state gradients"""
+    import ctypes as C
+    from variational_mmt_amd import _lib as L
+    g = torch.Generator().manual_seed(seed)
+    bf = torch.bfloat16
+    dev = "cuda"
+    M = T * B
+    ldg = 4 * H * ndir
+    t_ = dict(
+        whhT=[(torch.randn(H, 4 * H, generator=g) * 0.05).to(bf).to(dev) for _ in range(ndir)],
+        gates=torch.rand(M, ldg, generator=g).to(bf).to(dev),
+        c=(torch.randn(M, H * ndir, generator=g) * 0.5).to(dev),
+        cn=(torch.randn(B, H * ndir, generator=g) * 0.5).to(dev),
+        dha=(torch.randn(M, H * ndir, generator=g) * 0.1).to(bf).to(dev),
+        dhn=(torch.randn(B, H * ndir, generator=g) * 0.1).to(dev),
+        dcn=(torch.randn(B, H * ndir, generator=g) * 0.1).to(dev),
+        dcc0=(torch.randn(B, H * ndir, generator=g) * 0.1).to(dev),
+    )
+    lens = torch.randint(max(1, T // 2), T + 1, (B,), generator=g)
+    lens[0] = T
+    lens, _ = torch.sort(lens, descending=True)
+    t_["lens"] = lens.to(dev) if lens_on else None
+
+    def build(dg, dcc):
+        arr = (L.LstmDirBwd * (T * ndir))()
+        for step in range(T):
+            for k in range(ndir):
+                t = (T - 1 - step) if k == 0 else step
+                tn = (t + 1) if k == 0 else (t - 1)
+                tp = (t - 1) if k == 0 else (t + 1)
+                a = arr[step * ndir + k]
+                esz = 2
+                if step > 0:
+                    a.dgates_next, a.ld_dgn = dg.data_ptr() + (tn * B * ldg + k * 4 * H) * esz, ldg
+                a.w_hh_t, a.ld_wt = t_["whhT"][k].data_ptr(), 4 * H
+                a.dh_above, a.ld_dha = t_["dha"].data_ptr() + (t * B * H * ndir + k * H) * 2, H * ndir
+                a.gates, a.ld_gates = t_["gates"].data_ptr() + (t * B * ldg + k * 4 * H) * 2, ldg
+                a.c_t, a.ld_ct = t_["c"].data_ptr() + (t * B * H * ndir + k * H) * 4, H * ndir
+                if 0 <= tp < T:
+                    a.c_prev, a.ld_cp = t_["c"].data_ptr() + (tp * B * H * ndir + k * H) * 4, H * ndir
+                elif not lens_on:
+                    a.c_prev, a.ld_cp = t_["cn"].data_ptr() + k * H * 4, H * ndir
+                a.dc_carry, a.ld_dcc = dcc.data_ptr() + k * H * 4, H * ndir
+                a.dgates_out, a.ld_dgo = dg.data_ptr() + (t * B * ldg + k * 4 * H) * 2, ldg
+                a.dh_n, a.ld_dhn = t_["dhn"].data_ptr() + k * H * 4, H * ndir
+                a.dc_n, a.ld_dcn = t_["dcn"].data_ptr() + k * H * 4, H * ndir
+                a.t = t
+                a.inject = (1 if k == 0 else 2) if lens_on else 0
+        return arr
+    return t_, build, M, ldg
+
+
+@pytest.mark.parametrize("B,H,ndir,T,lens_on", [(256, 512, 1, 20, False), (256, 256, 2, 20, True), (70, 128, 2, 9, True), (33, 64, 1, 7, False),
+                                                (40, 512, 1, 6, False)])
+def test_persistent_backward_recurrence_is_bit_identical(B, H, ndir, T, lens_on):
+    """vmmt_lstm_seq_bwd against vmmt_lstm_chain_bwd on the same inputs (the training step's own backward inputs carry
+    float-atomic noise, so the comparison is made at the kernel level): dgates of every step and the final dL/dc, bit for bit,
+    over three different input sets through the same exchange buffers and the first one again"""
+    import ctypes as C
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    sync = torch.zeros(lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device="cuda")
+    xchg = torch.zeros(max(16, lib.vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H)), dtype=torch.uint8, device="cuda")
+    first = None
+    for rep, seed in enumerate((11, 12, 13, 11)):
+        t_, build, M, ldg = _bwd_case(B, H, ndir, T, seed, lens_on)
+        outs = []
+        for mode in ("chain", "seq"):
+            dg = torch.full((M + 64, ldg), 3.0, dtype=torch.bfloat16, device="cuda")
+            dcc = t_["dcc0"].clone()
+            arr = build(dg, dcc)
+            lp = t_["lens"].data_ptr() if t_["lens"] is not None else None
+            if mode == "chain":
+                L.check(lib.vmmt_lstm_chain_bwd(L.BF16, ndir, T, arr, lp, B, H, 0, None), "chain bwd")
+            else:
+                dev_arr = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+                L.check(lib.vmmt_lstm_seq_bwd(L.BF16, ndir, T, arr, dev_arr.data_ptr(), lp, B, H, sync.data_ptr(), xchg.data_ptr(), None), "seq bwd")
+            torch.cuda.synchronize()
+            outs.append((dg.clone(), dcc.clone()))
+        assert int(sync[2].item()) == 0                              # every in-launch wait completed
+        assert torch.equal(outs[0][0], outs[1][0]), ("dgates differ", rep, (outs[0][0].float() - outs[1][0].float()).abs().max().item())
+        assert torch.equal(outs[0][1], outs[1][1]), ("dc carry differs", rep)
+        assert (outs[1][0][M:] == 3.0).all()                         # nothing written beyond the rows of the sequence
+        if rep == 0:
+            first = outs[1]
+        if rep == 3:
+            assert torch.equal(first[0], outs[1][0]) and torch.equal(first[1], outs[1][1])
+    assert int(sync[0].item()) == 4                                  # four launches, four epochs

@@ -68,5 +68,59 @@ int main(int argc, char** argv) {
       for (int i = 1; i < 8; ++i) printf(" %s +%.2f", names[i], (double)(x[i] - x[0]) * 0.01);
       printf("   | step period %.2f us\n", (double)(x[0] - ts[(b * 64 + t - 1) * 8]) * 0.01);
     }
+  // ---------------- backward ----------------
+  {
+    void *dg, *whhT, *dha, *gates; float *c, *cn, *dcc; vmmt_lstm_dir_bwd* bdev; void* xb2;
+    CK(hipMalloc(&dg, M * 4 * H * 2 * ndir)); CK(hipMalloc(&whhT, (long)H * 4 * H * 2 * ndir)); CK(hipMalloc(&dha, M * H * 2 * ndir));
+    CK(hipMalloc(&gates, M * 4 * H * 2 * ndir)); CK(hipMalloc(&c, M * H * 4 * ndir)); CK(hipMalloc(&cn, (long)B * H * 4 * ndir));
+    CK(hipMalloc(&dcc, (long)B * H * 4 * ndir));
+    CK(hipMemset(dg, 0, M * 4 * H * 2 * ndir)); CK(hipMemset(whhT, 0, (long)H * 4 * H * 2 * ndir)); CK(hipMemset(dha, 0, M * H * 2 * ndir));
+    CK(hipMemset(gates, 0, M * 4 * H * 2 * ndir)); CK(hipMemset(c, 0, M * H * 4 * ndir)); CK(hipMemset(cn, 0, (long)B * H * 4 * ndir));
+    CK(hipMemset(dcc, 0, (long)B * H * 4 * ndir));
+    const long xbb = vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H);
+    CK(hipMalloc(&xb2, xbb)); CK(hipMemset(xb2, 0, xbb)); CK(hipMemset(sync, 0, 4 * vmmt_lstm_seq_sync_words()));
+    std::vector<vmmt_lstm_dir_bwd> db((size_t)T * ndir);
+    for (int step = 0; step < T; ++step)
+      for (int k = 0; k < ndir; ++k) {
+        const int t = T - 1 - step;
+        vmmt_lstm_dir_bwd& x = db[(size_t)step * ndir + k];
+        x = vmmt_lstm_dir_bwd{};
+        char* dgk = (char*)dg + (long)k * M * 4 * H * 2;
+        x.dgates_next = step > 0 ? dgk + (long)(t + 1) * B * 4 * H * 2 : nullptr; x.ld_dgn = 4 * H;
+        x.w_hh_t = (char*)whhT + (long)k * H * 4 * H * 2; x.ld_wt = 4 * H;
+        x.dh_above = (char*)dha + ((long)k * M + (long)t * B) * H * 2; x.ld_dha = H;
+        x.gates = (char*)gates + ((long)k * M + (long)t * B) * 4 * H * 2; x.ld_gates = 4 * H;
+        x.c_t = c + ((long)k * M + (long)t * B) * H; x.ld_ct = H;
+        x.c_prev = t > 0 ? c + ((long)k * M + (long)(t - 1) * B) * H : cn + (long)k * B * H; x.ld_cp = H;
+        x.dc_carry = dcc + (long)k * B * H; x.ld_dcc = H;
+        x.dgates_out = dgk + (long)t * B * 4 * H * 2; x.ld_dgo = 4 * H;
+        x.t = t; x.inject = 0;
+      }
+    CK(hipMalloc(&bdev, db.size() * sizeof(db[0]))); CK(hipMemcpy(bdev, db.data(), db.size() * sizeof(db[0]), hipMemcpyHostToDevice));
+    for (int mode = 0; mode < 2; ++mode) {
+      auto run = [&](int reps) {
+        for (int r = 0; r < reps; ++r) {
+          int rc = mode ? vmmt_lstm_seq_bwd(VMMT_BF16, ndir, T, db.data(), bdev, nullptr, B, H, sync, xb2, st)
+                        : vmmt_lstm_chain_bwd(VMMT_BF16, ndir, T, db.data(), nullptr, B, H, 0, st);
+          if (rc) { printf("rc %d\n", rc); return; }
+        }
+      };
+      run(3); CK(hipStreamSynchronize(st));
+      CK(hipEventRecord(e0, st)); run(20); CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("BWD %s H=%d ndir=%d: %.2f us per step (%.1f us per %d-step sequence)\n", mode ? "persistent" : "per-step  ", H, ndir,
+             ms * 1e3 / (20 * T), ms * 1e3 / 20, T);
+    }
+    CK(hipMemcpy(sw, sync, 16, hipMemcpyDeviceToHost));
+    printf("sync: epoch %u finish %u err 0x%x\n", sw[0], sw[1], sw[2]);
+    CK(hipMemcpyFromSymbol(ts.data(), HIP_SYMBOL(vmmt::vmmt_seq_ts), ts.size() * 8));
+    const char* nb2[8] = {"top", "polled", "swept+mfma", "fold-wr", "fold-bar", "cell", "tile-bar", "published"};
+    for (int t = 1; t < 5; ++t) {
+      const unsigned long long* x = &ts[(0 * 64 + t) * 8];
+      printf("bwd block 0 step %d:", t);
+      for (int i = 1; i < 8; ++i) printf(" %s +%.2f", nb2[i], (double)(x[i] - x[0]) * 0.01);
+      printf("   | step period %.2f us\n", (double)(x[0] - ts[(0 * 64 + t - 1) * 8]) * 0.01);
+    }
+  }
   return 0;
 }

@@ -57,6 +57,21 @@ __device__ __forceinline__ LstmCell lstm_cell_math(float pi, float pf, float pg,
   r.h = r.o * tanhf_(r.c);
   return r;
 }
+// ... and its backward: gradients of the four gate pre-activations and of c_{t-1}, given dL/dh and the dL/dc arriving from t+1
+struct LstmCellGrad { float di, df, dg, d_o, dc_prev; };
+__device__ __forceinline__ LstmCellGrad lstm_cell_bwd_math(float i, float f, float g, float o, float c, float cp, float dh, float dc) {
+  LstmCellGrad r;
+  const float tc = tanhf_(c);
+  const float d_o = dh * tc;
+  dc = __builtin_fmaf(dh * o, __builtin_fmaf(-tc, tc, 1.f), dc);
+  const float d_i = dc * g, d_f = dc * cp, d_g = dc * i;
+  r.di = d_i * i * (1.f - i);
+  r.df = d_f * f * (1.f - f);
+  r.dg = d_g * __builtin_fmaf(-g, g, 1.f);
+  r.d_o = d_o * o * (1.f - o);
+  r.dc_prev = dc * f;
+  return r;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -363,15 +363,12 @@ __device__ __forceinline__ void cell_bwd_apply(const StepDirB& d, bool has_lens,
   dh += in.dha;
   const bool inj = d.inject == 3 || (d.inject == 1 && d.t == in.len - 1) || (d.inject == 2 && d.t == 0);
   if (inj) { dh += in.dhn; dc += in.dcn; }
-  float tc = tanhf_(in.c);
-  float d_o = dh * tc;
-  dc += dh * in.o * (1.f - tc * tc);
-  float d_i = dc * in.g, d_f = dc * in.cp, d_g = dc * in.i;
-  dgo[0] = f2bf(d_i * in.i * (1.f - in.i));
-  dgo[H] = f2bf(d_f * in.f * (1.f - in.f));
-  dgo[2 * H] = f2bf(d_g * (1.f - in.g * in.g));
-  dgo[3 * (long)H] = f2bf(d_o * in.o * (1.f - in.o));
-  *dcc = dc * in.f;
+  const LstmCellGrad gr = lstm_cell_bwd_math(in.i, in.f, in.g, in.o, in.c, in.cp, dh, dc);
+  dgo[0] = f2bf(gr.di);
+  dgo[H] = f2bf(gr.df);
+  dgo[2 * H] = f2bf(gr.dg);
+  dgo[3 * (long)H] = f2bf(gr.d_o);
+  *dcc = gr.dc_prev;
 }
 
 // Backward: dh[32 x 16] = dgates_next[32 x 4H] W_hh^T[16 x 4H]^T over K = 4H in rounds of KCB (one round up to H = 512), then

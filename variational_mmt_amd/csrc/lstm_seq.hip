@@ -205,20 +205,32 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
   }
   __syncthreads();                                              // the flag word is part of the fold buffer
 
-  for (int t = 0; t < a.nsteps; ++t) {
-    const SeqDirF d = load_desc(a.steps, (long)t * ndir + k);
-    SEQ_TS(0);
-    // epilogue operands that do not depend on the recurrence: fetched before the wait
-    float gxv[2][4];
+  // epilogue operands that do not depend on the recurrence (x W_ih^T + b of the cell's four gates): those of step t+1 are
+  // requested while step t computes, so that no step waits for them (they come from HBM: ~1 us when fetched at the step's top)
+  float gxn[2][4];
+  auto fetch_gx = [&](const SeqDirF& dd) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int rr = rows[e] < B ? rows[e] : B - 1;
-      const float* gx = d.gx + (long)rr * d.ld_gx + u;
-      gxv[e][0] = gx[0]; gxv[e][1] = gx[H]; gxv[e][2] = gx[2 * H]; gxv[e][3] = gx[3 * (long)H];
-      if (d.gx2) {
-        const float* g2 = d.gx2 + (long)rr * d.ld_gx2 + u;
-        gxv[e][0] += g2[0]; gxv[e][1] += g2[H]; gxv[e][2] += g2[2 * H]; gxv[e][3] += g2[3 * (long)H];
+      const float* gx = dd.gx + (long)rr * dd.ld_gx + u;
+      gxn[e][0] = gx[0]; gxn[e][1] = gx[H]; gxn[e][2] = gx[2 * H]; gxn[e][3] = gx[3 * (long)H];
+      if (dd.gx2) {
+        const float* g2 = dd.gx2 + (long)rr * dd.ld_gx2 + u;
+        gxn[e][0] += g2[0]; gxn[e][1] += g2[H]; gxn[e][2] += g2[2 * H]; gxn[e][3] += g2[3 * (long)H];
       }
+    }
+  };
+  fetch_gx(load_desc(a.steps, k));
+
+  for (int t = 0; t < a.nsteps; ++t) {
+    const SeqDirF d = load_desc(a.steps, (long)t * ndir + k);
+    SEQ_TS(0);
+    float gxv[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gxv[e][g] = gxn[e][g];
+      const int rr = rows[e] < B ? rows[e] : B - 1;
       if (t == 0) c_reg[e] = d.c_prev ? d.c_prev[(long)rr * d.ld_cprev + u] : 0.f;
     }
     // ---- A fragments of h_{t-1}: this wave = 16 rows x two of the four K quarters (2 * KQ k-steps of 32 units)
@@ -293,6 +305,7 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
       }
     }
     SEQ_TS(2);
+    if (t + 1 < a.nsteps) fetch_gx(load_desc(a.steps, (long)(t + 1) * ndir + k));
     f32x4_s acc[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -415,6 +428,322 @@ static int launch_seq_fwd(const SeqArgsF& a, hipStream_t st) {
   return check_launch();
 }
 
+// ==============================================================================================================
+// Backward recurrence, same structure: dh_t[32 x 16] = dgates_{t+1}[32 x 4H] W_hh^T slice[16 x 4H]^T, then the cell backward.
+// What the workgroups of a row group exchange is dgates (4H values per sentence and step, 4x the forward's payload), again as
+// tagged granules in the consumers' fragment order; the W_hh^T slice (16 rows of 4H) stays in LDS; dL/dc stays in registers.
+// K quarters, accumulator pairs and fold order are those of lstm_step_bwd_fast (same bits).
+// ==============================================================================================================
+struct SeqDirB {      // == vmmt_lstm_dir_bwd
+  const void* dgates_next; long ld_dgn;
+  const void* w_hh_t; long ld_wt;
+  const void* dh_above; long ld_dha;
+  const void* gates; long ld_gates;
+  const float* c_t; long ld_ct;
+  const float* c_prev; long ld_cp;
+  float* dc_carry; long ld_dcc;
+  void* dgates_out; long ld_dgo;
+  const float* dh_n; long ld_dhn;
+  const float* dc_n; long ld_dcn;
+  float* dh0_out; long ld_dh0;
+  int t, inject;
+};
+static_assert(sizeof(SeqDirB) == sizeof(vmmt_lstm_dir_bwd), "descriptor layouts must match");
+typedef const SeqDirB __attribute__((address_space(4))) * SeqDirBConstPtr;
+__device__ __forceinline__ SeqDirB load_desc_b(const SeqDirB* steps, long idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return reinterpret_cast<SeqDirBConstPtr>(reinterpret_cast<uintptr_t>(steps))[idx];
+#else
+  return steps[idx];
+#endif
+}
+struct SeqArgsB {
+  const SeqDirB* steps;
+  const long long* lens;
+  unsigned* sync;
+  unsigned long long* xchg;      // granules [ndir][ngroups][2 slots][2 row halves][4H / 32 k-steps][lo / hi][64 lanes] x 16 bytes
+  int B, nsteps, ndir, ngroups;
+};
+
+template <int H> struct SeqCfgB {
+  static constexpr int K = 4 * H;
+  static constexpr int ROWB = K * 2;
+  static constexpr int PPR = ROWB >= 1024 ? ROWB / 1024 : 1;   // 1-KiB pieces per W_hh^T row
+  static constexpr int LANES = ROWB >= 1024 ? 64 : ROWB / 16;
+  static constexpr int NKS = K / 32, KQ = NKS / 4;             // K steps per quarter (H >= 64: KQ >= 2)
+  static constexpr int CH = KQ < 8 ? KQ : 8;                   // K steps per sweep chunk
+  static constexpr int W_BYTES = 16 * ROWB;
+  static constexpr int RED_BYTES = 4 * 2 * 2 * 64 * 4;         // [wave][quarter of the wave][reg pair][lane] f32
+  static constexpr int DT_BYTES = 32 * 64 * 2;                 // dgates tile [32 rows][4 gates][16 units] bf16
+  static constexpr int LDS = W_BYTES + RED_BYTES + DT_BYTES;
+};
+
+template <int H>
+__global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
+  using Cf = SeqCfgB<H>;
+  constexpr int ROWB = Cf::ROWB, KQ = Cf::KQ, NKS = Cf::NKS, CH = Cf::CH;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* red = reinterpret_cast<float*>(lds + Cf::W_BYTES);
+  bf16_t* dtile = reinterpret_cast<bf16_t*>(lds + Cf::W_BYTES + Cf::RED_BYTES);
+  const int B = a.B, ndir = a.ndir;
+  const int S = H / 16, total = gridDim.x;
+  const int bid = blockIdx.x;
+  int grp, slice;                                               // role mapping and transport choice: see lstm_seq_fwd_kernel
+  if (total % 8 == 0 && (total / 8) % S == 0) { grp = (bid % 8) + 8 * ((bid / 8) / S); slice = (bid / 8) % S; }
+  else { grp = bid / S; slice = bid % S; }
+  const int k = grp / a.ngroups, rg = grp % a.ngroups;
+  const int m0 = rg * 32, u0 = slice * 16;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wm = wave & 1, wk = wave >> 1;
+  const int n = lane & 15, kg = lane >> 4;
+  const int u = u0 + n;
+  unsigned* err = a.sync + 2;
+  const unsigned tag0 = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 4096u;
+  constexpr long SLOT_BYTES = 2L * NKS * 2048;                  // [2 row halves][NKS][lo / hi][64 lanes x 16 B]
+  char* xg = reinterpret_cast<char*>(a.xchg) + (long)grp * 2 * SLOT_BYTES;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(xg);
+  {
+    int* flag = reinterpret_cast<int*>(lds + Cf::W_BYTES);
+    if (threadIdx.x == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned* arrive = a.sync + 4 + 2 * grp;
+      __hip_atomic_fetch_or(arrive + 1, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = wall_clock64();
+      int f = 0;
+      for (;;) {
+        if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)S) {
+          f = __builtin_popcount(__hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
+          break;
+        }
+        if (timed_out(t0)) { __hip_atomic_store(err, 0x400u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); f = -1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      *flag = f;
+    }
+  }
+  bool alive = true, same_xcd = false;
+  // ---- W_hh^T slice -> LDS, once: 16 rows (units u0 ..) of 4H, 1-KiB pieces, chunk index XOR row (as lstm_step_bwd_fast)
+  {
+    const SeqDirB d0 = load_desc_b(a.steps, k);
+    const char* wp = reinterpret_cast<const char*>(d0.w_hh_t);
+    if (lane < Cf::LANES) {
+#pragma unroll
+      for (int j = 0; j < (16 * Cf::PPR + 3) / 4; ++j) {
+        const int p = wave + 4 * j;
+        if (p < 16 * Cf::PPR) {
+          const int r = p / Cf::PPR, sg = p % Cf::PPR;
+          __builtin_amdgcn_global_load_lds((glb_cvoid_seq*)(wp + ((long)(u0 + r) * d0.ld_wt) * 2 + sg * 1024 + ((lane ^ (r & 15)) * 16)),
+                                           (lds_void_seq*)(lds + r * ROWB + sg * 1024), 16, 0, 0);
+        }
+      }
+    }
+  }
+  int rows[2];
+  long long len[2];
+  float dcc[2];                                                 // dL/dc flowing to the previous step: in registers for the whole sequence
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    rows[e] = m0 + wm * 16 + kg * 4 + 2 * wk + e;
+    const int rr = rows[e] < B ? rows[e] : B - 1;
+    len[e] = a.lens ? a.lens[rr] : 0;
+    dcc[e] = 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const int f = *reinterpret_cast<volatile int*>(lds + Cf::W_BYTES);
+    same_xcd = f == 1;
+    alive = f >= 0;
+  }
+  __syncthreads();
+
+  // everything the cell backward needs besides dh (saved gates, cell states, dh from above, injected final-state gradients) does
+  // not depend on the recurrence: step t+1's values are requested while step t computes
+  float nx[2][9];
+  auto fetch_in = [&](const SeqDirB& dd) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const long bb = rows[e] < B ? rows[e] : B - 1;
+      const bf16_t* gs = reinterpret_cast<const bf16_t*>(dd.gates) + bb * dd.ld_gates + u;
+      nx[e][0] = bf2f(gs[0]); nx[e][1] = bf2f(gs[H]); nx[e][2] = bf2f(gs[2 * H]); nx[e][3] = bf2f(gs[3 * (long)H]);
+      nx[e][4] = dd.c_t[bb * dd.ld_ct + u];
+      nx[e][5] = dd.c_prev ? dd.c_prev[bb * dd.ld_cp + u] : 0.f;
+      nx[e][6] = dd.dh_above ? bf2f(reinterpret_cast<const bf16_t*>(dd.dh_above)[bb * dd.ld_dha + u]) : 0.f;
+      nx[e][7] = dd.dh_n ? dd.dh_n[bb * dd.ld_dhn + u] : 0.f;
+      nx[e][8] = dd.dh_n ? dd.dc_n[bb * dd.ld_dcn + u] : 0.f;
+    }
+  };
+  fetch_in(load_desc_b(a.steps, k));
+
+  for (int t = 0; t < a.nsteps; ++t) {
+    const SeqDirB d = load_desc_b(a.steps, (long)t * ndir + k);
+    SEQ_TS(0);
+    float gi[2], gf[2], gg[2], go[2], cc[2], cpv[2], dha[2], dhn[2], dcn[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      gi[e] = nx[e][0]; gf[e] = nx[e][1]; gg[e] = nx[e][2]; go[e] = nx[e][3]; cc[e] = nx[e][4]; cpv[e] = nx[e][5];
+      dha[e] = nx[e][6]; dhn[e] = nx[e][7]; dcn[e] = nx[e][8];
+      const long bb = rows[e] < B ? rows[e] : B - 1;
+      if (t == 0) dcc[e] = d.dc_carry[bb * d.ld_dcc + u];
+    }
+    f32x4_s acc[2][2];                                          // [quarter of this wave][even / odd K step]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { acc[j][0] = f32x4_s{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4_s{0.f, 0.f, 0.f, 0.f}; }
+    if (d.dgates_next) {
+      const unsigned want = tag0 + (unsigned)t;                 // tag of the step processed just before
+      const unsigned sbase = (unsigned)((((t - 1) & 1) * 2 + wm) * (NKS * 2048));
+      const unsigned long long t_start = wall_clock64();
+      {   // cheap poll: one granule (hi piece of the odd k group, row 0) per 16-unit producer piece of this wave's K half
+        const int ks = wk * (NKS / 2) + (lane >> 1);
+        const unsigned pbase = sbase + (unsigned)((ks * 2 + 1) * 1024 + ((2 * (lane & 1) + 1) * 16) * 16);
+        while (alive) {
+          unsigned long long g = 0;
+          if (lane < NKS) g = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(xg + pbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all(lane >= NKS || (unsigned)(g >> 32) == want)) break;
+          if (timed_out(t_start)) {
+            if (lane == 0) __hip_atomic_store(err, 0x500u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alive = false;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      SEQ_TS(1);
+      // the whole K half of this wave in flight at once (2 * KQ k-steps, a lo and a hi piece each), then tags, then MFMAs
+      u32x4 af[2][KQ];
+      const unsigned gbase = sbase + (unsigned)((2 * wk * KQ) * 2048 + lane * 16);
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          u32x4 lo[KQ], hi[KQ];
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            lo[q] = load16_sc1(xr, gbase + (unsigned)((j * KQ + q) * 2048));
+            hi[q] = load16_sc1(xr, gbase + (unsigned)((j * KQ + q) * 2048 + 1024));
+          }
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            ok = ok && lo[q][1] == want && lo[q][3] == want && hi[q][1] == want && hi[q][3] == want;
+            af[j][q] = u32x4{lo[q][0], lo[q][2], hi[q][0], hi[q][2]};
+          }
+        }
+        if (__all(ok) || !alive) break;
+        if (timed_out(t_start)) {
+          if (lane == 0) __hip_atomic_store(err, 0x600u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          alive = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (t + 1 < a.nsteps) fetch_in(load_desc_b(a.steps, (long)(t + 1) * ndir + k));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c0 = 0; c0 < KQ; c0 += CH) {
+          bf16x8 bv[CH];
+#pragma unroll
+          for (int q = 0; q < CH; ++q) {
+            const int c = (((2 * wk + j) * KQ + c0 + q) * 4 + kg);
+            bv[q] = *reinterpret_cast<const bf16x8*>(lds + n * ROWB + ((c ^ n) * 16));
+          }
+#pragma unroll
+          for (int q = 0; q < CH; ++q)
+            acc[j][(c0 + q) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[j][c0 + q]), bv[q], acc[j][(c0 + q) & 1], 0, 0, 0);
+        }
+    } else if (t + 1 < a.nsteps) {
+      fetch_in(load_desc_b(a.steps, (long)(t + 1) * ndir + k));
+    }
+    SEQ_TS(2);
+    // ---- fold: quarter sums (acc0 + acc1, as lstm_step_bwd_fast) to the partner wave, then ((q0 + q1) + q2) + q3
+    f32x4_s qs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) qs[j][r] = acc[j][0][r] + acc[j][1][r];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) red[((wave * 2 + j) * 2 + e) * 64 + lane] = wk ? qs[j][e] : qs[j][2 + e];
+    SEQ_TS(3);
+    __syncthreads();
+    SEQ_TS(4);
+    const int pw = wm + 2 * (1 - wk);                           // partner wave: same rows, the other two quarters
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float own0 = wk ? qs[0][2 + e] : qs[0][e], own1 = wk ? qs[1][2 + e] : qs[1][e];
+      const float oth0 = red[((pw * 2 + 0) * 2 + e) * 64 + lane], oth1 = red[((pw * 2 + 1) * 2 + e) * 64 + lane];
+      const float q0 = wk ? oth0 : own0, q1 = wk ? oth1 : own1, q2 = wk ? own0 : oth0, q3 = wk ? own1 : oth1;
+      float dh = (((0.f + q0) + q1) + q2) + q3;
+      const bool valid = !a.lens || d.t < len[e];
+      bf16_t* dt = dtile + (wm * 16 + kg * 4 + 2 * wk + e) * 64 + n;
+      if (!valid) {
+        dt[0] = 0; dt[16] = 0; dt[32] = 0; dt[48] = 0;
+        dcc[e] = 0.f;
+      } else {
+        float dc = dcc[e];
+        dh += dha[e];
+        const bool inj = d.inject == 3 || (d.inject == 1 && d.t == len[e] - 1) || (d.inject == 2 && d.t == 0);
+        if (inj) { dh += dhn[e]; dc += dcn[e]; }
+        const LstmCellGrad gr = lstm_cell_bwd_math(gi[e], gf[e], gg[e], go[e], cc[e], cpv[e], dh, dc);
+        dt[0] = f2bf(gr.di); dt[16] = f2bf(gr.df); dt[32] = f2bf(gr.dg); dt[48] = f2bf(gr.d_o);
+        dcc[e] = gr.dc_prev;
+      }
+    }
+    SEQ_TS(5);
+    __syncthreads();
+    SEQ_TS(6);
+    // ---- publish dgates_t: 512 pieces of two granules (gate, row, 4 units) for the row group, then the plain [B][4H] buffer
+    {
+      const unsigned tg = tag0 + (unsigned)t + 1u;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        // piece id -> (gate, piece-of-4-units, row) with the row fastest: 16 consecutive lanes store 256 contiguous bytes
+        const int id = i2 * 256 + threadIdx.x, g = id >> 7, piece = (id >> 5) & 3, r = id & 31;
+        const unsigned* hw = reinterpret_cast<const unsigned*>(dtile + r * 64 + g * 16 + piece * 4);
+        const int ks = (g * H + u0) >> 5;
+        const unsigned off = (unsigned)((((t & 1) * 2 + (r >> 4)) * (NKS * 2048)) + (ks * 2 + (piece & 1)) * 1024 +
+                                        (((u0 & 16) ? 2 : 0) + (piece >> 1)) * 256 + (r & 15) * 16);
+        const u32x4 v = u32x4{hw[0], tg, hw[1], tg};
+        if (same_xcd) *reinterpret_cast<u32x4*>(xg + off) = v;
+        else store16_sc1(xr, off, v);
+      }
+      // plain copy for the kernels that follow (weight gradients, dx): 32 rows x 4 gates x 32 bytes = 256 x 16 bytes
+      const int r = threadIdx.x >> 3, g = (threadIdx.x >> 1) & 3, half = threadIdx.x & 1;
+      if (m0 + r < B)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d.dgates_out) + ((long)(m0 + r)) * d.ld_dgo + (long)g * H + u0 + half * 8) =
+            *reinterpret_cast<const u32x4*>(dtile + r * 64 + g * 16 + half * 8);
+    }
+    if (t == a.nsteps - 1) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (rows[e] < B) d.dc_carry[(long)rows[e] * d.ld_dcc + u] = dcc[e];
+    }
+    SEQ_TS(7);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)total - 1) {
+      __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int g2 = 0; g2 < a.ndir * a.ngroups; ++g2) {
+        __hip_atomic_store(a.sync + 4 + 2 * g2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sync + 5 + 2 * g2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int H>
+static int launch_seq_bwd(const SeqArgsB& a, hipStream_t st) {
+  constexpr int sm = SeqCfgB<H>::LDS;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)lstm_seq_bwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); attr_set = true; }
+  hipLaunchKernelGGL(lstm_seq_bwd_kernel<H>, dim3(a.ngroups * (H / 16) * a.ndir), dim3(256), sm, st, a);
+  return check_launch();
+}
+
 static bool al16s(const void* p, long ld_elems) { return (((uintptr_t)p) & 15) == 0 && (ld_elems * 2) % 16 == 0; }
 
 }  // namespace vmmt
@@ -459,5 +788,47 @@ extern "C" int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lst
     case 256: return launch_seq_fwd<256>(a, (hipStream_t)stream);
     case 128: return launch_seq_fwd<128>(a, (hipStream_t)stream);
     default: return launch_seq_fwd<64>(a, (hipStream_t)stream);
+  }
+}
+
+// Whole BACKWARD recurrence (mode 0 steps of vmmt_lstm_step_bwd) in one launch; same contract as vmmt_lstm_seq_fwd.  `xchg`:
+// vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H) bytes.  Falls back to vmmt_lstm_chain_bwd when the persistent kernel does not apply
+// (fp32, H not in {64,128,256,512}, more workgroups than CUs, unaligned rows, dgates_next[t] != dgates_out[t-1], a dc_carry
+// buffer that changes between steps).
+extern "C" int64_t vmmt_lstm_seq_xchg_bytes_bwd(int ndir, int B, int H) {
+  if (ndir < 1 || B < 1 || H < 1) return 0;
+  return (int64_t)ndir * ((B + 31) / 32) * 2 * 2 * (4 * H / 32) * 2048;
+}
+
+extern "C" int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* dirs, const vmmt_lstm_dir_bwd* dirs_dev,
+                                 const int64_t* lens, int B, int H, uint32_t* sync, void* xchg, void* stream) {
+  using namespace vmmt;
+  if (nsteps < 0 || !dirs || ndir < 1 || ndir > 2 || B <= 0 || H <= 0) return VMMT_EINVAL;
+  if (nsteps == 0) return VMMT_OK;
+  const int ngroups = (B + 31) / 32;
+  bool ok = dtype == VMMT_BF16 && dirs_dev && sync && xchg && (((uintptr_t)xchg) & 15) == 0 && (H == 64 || H == 128 || H == 256 || H == 512) &&
+            (long)ngroups * (H / 16) * ndir <= 256 && nsteps >= 2 && nsteps < 4095;
+  for (int i = 0; ok && i < nsteps; ++i)
+    for (int k = 0; ok && k < ndir; ++k) {
+      const vmmt_lstm_dir_bwd& d = dirs[(long)i * ndir + k];
+      ok = d.w_hh_t && d.gates && d.c_t && d.dc_carry && d.dgates_out && al16s(d.dgates_out, d.ld_dgo) && al16s(d.w_hh_t, d.ld_wt) &&
+           d.w_hh_t == dirs[k].w_hh_t && d.ld_wt == dirs[k].ld_wt && d.dc_carry == dirs[k].dc_carry && d.ld_dcc == dirs[k].ld_dcc &&
+           (!d.dh_n || d.dc_n);
+      if (ok && i == 0) ok = d.dgates_next == nullptr;
+      if (ok && i > 0) {
+        const vmmt_lstm_dir_bwd& p = dirs[(long)(i - 1) * ndir + k];
+        ok = d.dgates_next == p.dgates_out && d.ld_dgn == p.ld_dgo;
+      }
+    }
+  if (!ok) return vmmt_lstm_chain_bwd(dtype, ndir, nsteps, dirs, lens, B, H, 0, stream);
+  SeqArgsB a;
+  a.steps = reinterpret_cast<const SeqDirB*>(dirs_dev); a.lens = (const long long*)lens; a.sync = sync;
+  a.xchg = reinterpret_cast<unsigned long long*>(xchg);
+  a.B = B; a.nsteps = nsteps; a.ndir = ndir; a.ngroups = ngroups;
+  switch (H) {
+    case 512: return launch_seq_bwd<512>(a, (hipStream_t)stream);
+    case 256: return launch_seq_bwd<256>(a, (hipStream_t)stream);
+    case 128: return launch_seq_bwd<128>(a, (hipStream_t)stream);
+    default: return launch_seq_bwd<64>(a, (hipStream_t)stream);
   }
 }

@@ -382,6 +382,18 @@ class Engine(object):
         else:
             plan.append((self.lib.vmmt_lstm_chain_fwd, (self.dt, ndir, nsteps, arr, lens_ptr, B, H), "vmmt_lstm_chain_fwd", arr, self._sid))
 
+    def _lstm_seq_bwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H):
+        """plan entry: a whole backward recurrence (the mode-0 steps), see _lstm_seq_fwd"""
+        if self.persistent_lstm:
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+            sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
+            xchg = torch.zeros(max(16, self.lib.vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H)), dtype=torch.uint8, device=self.dev)
+            plan.append((self.lib.vmmt_lstm_seq_bwd, (self.dt, ndir, nsteps, arr, dev.data_ptr(), lens_ptr, B, H, sync.data_ptr(), xchg.data_ptr()),
+                         "vmmt_lstm_seq_bwd", (arr, dev, sync, xchg), self._sid))
+            self.seq_syncs.append(sync)
+        else:
+            plan.append((self.lib.vmmt_lstm_chain_bwd, (self.dt, ndir, nsteps, arr, lens_ptr, B, H, 0), "vmmt_lstm_chain_bwd", arr, self._sid))
+
     def lstm_seq_errors(self):
         """error words of the persistent recurrence launches so far (0 = every in-launch wait completed); synchronises"""
         torch.cuda.synchronize(self.dev)
@@ -955,9 +967,9 @@ class Workspace(object):
             outb, ocol = (self.cat, H) if last else (self.dec_out[l], 0)
             whhT = e.sh["dec_whhT_l%d" % l]
             dg = self.dec_dgates[l]
-            for t in reversed(range(Tp)):
-                arr = (L.LstmDirBwd * 2)()
-                a = arr[0]
+            seq = (L.LstmDirBwd * Tp)()
+            for i, t in enumerate(reversed(range(Tp))):
+                a = seq[i]
                 if t < Tp - 1:
                     a.dgates_next, a.ld_dgn = dg.p((t + 1) * B), dg.ld
                 a.w_hh_t, a.ld_wt = whhT.p(), whhT.ld
@@ -971,8 +983,7 @@ class Workspace(object):
                 a.dc_carry, a.ld_dcc = self.dec_dcc[l].p(), self.dec_dcc[l].ld
                 a.dgates_out, a.ld_dgo = dg.p(t * B), dg.ld
                 a.t, a.inject = t, 0
-                self._keep.append(arr)
-                e._call(P, lib.vmmt_lstm_step_bwd, dt, 1, arr, None, B, H, 0)
+            e._lstm_seq_bwd(P, seq, 1, Tp, None, B, H)
             e._record(P, "dec_dg%d" % l)
             arr = (L.LstmDirBwd * 2)()
             a = arr[0]
@@ -1038,8 +1049,7 @@ class Workspace(object):
         # half-way split of layer 0's parameter gradients: only when the row counts stay whole GEMM slabs (sub-ranges cannot
         # lean on the zero padding behind the buffers)
         # (measured: 2.82 vs 2.58 ms/step at B = 256 -- the early half competes with the chain's own steps -- so it is off by default)
-        half = S // 2 if (e.enc_half_split and S >= 4 and ((S // 2) * B) % KPAD == 0 and ((S - S // 2) * B) % KPAD == 0 and B % KPAD == 0 and
-                         (4 * Hd) % KPAD == 0) else 0
+        half = 0      # (the recurrence is one launch now: nothing can be issued half-way)
 
         def enc_param_grads(l, ranges, alternate):
             """dW_hh, db, dW_ih (and for layer 0 the embedding scatter) of encoder layer l from the time steps [lo, hi) of each
@@ -1088,14 +1098,14 @@ class Workspace(object):
         for l in reversed(range(Lyr)):
             e._sid = MAIN
             dg = self.enc_dgates[l]
+            seq = (L.LstmDirBwd * (S * dirs))()
             for step in range(S):
-                arr = (L.LstmDirBwd * 2)()
                 for k in range(dirs):
                     # backward visits the steps in the reverse of the forward order of that direction
                     t = (S - 1 - step) if k == 0 else step
                     tn = (t + 1) if k == 0 else (t - 1)        # step processed just before (its dgates feed the GEMM)
                     tp = (t - 1) if k == 0 else (t + 1)        # forward predecessor (c_prev)
-                    a = arr[k]
+                    a = seq[step * dirs + k]
                     whhT = e.sh["enc_whhT_l%d_d%d" % (l, k)]
                     if step > 0:
                         a.dgates_next, a.ld_dgn = dg.p(tn * B, k * 4 * Hd), dg.ld
@@ -1111,17 +1121,7 @@ class Workspace(object):
                     a.dc_n, a.ld_dcn = self.dec_dcc[l].p(0, k * Hd), self.dec_dcc[l].ld
                     a.t = t
                     a.inject = 1 if k == 0 else 2
-                self._keep.append(arr)
-                e._call(P, lib.vmmt_lstm_step_bwd, dt, dirs, arr, self.src_len.data_ptr(), B, Hd, 0)
-                if l == 0 and half and step == half - 1:
-                    # The chain ends the critical path and its parameter gradients can only start behind it: the half of
-                    # them that belongs to the steps already finished is issued NOW on the side stream (sums over time
-                    # steps split anywhere), the rest at the end.
-                    e._record(P, "enc_half")
-                    e._sid = SIDE
-                    e._wait(P, "enc_half")
-                    enc_param_grads(l, [(S - half, S), (0, half)][:dirs], False)
-                    e._sid = MAIN
+            e._lstm_seq_bwd(P, seq, dirs, S, self.src_len.data_ptr(), B, Hd)
             e._record(P, "enc_dg%d" % l)
             wih = e.sh["enc_wih_l%d" % l]
             if l > 0:
@@ -1310,8 +1310,7 @@ class Workspace(object):
                     a.dc_carry, a.ld_dcc = self.enct_dcc[l].p(0, k * ht), self.enct_dcc[l].ld
                     a.dgates_out, a.ld_dgo = dg.p(t * Tn, k * 4 * ht), dg.ld
                     a.t, a.inject = t, 0
-            self._keep.append(arr)
-            e._call(P, lib.vmmt_lstm_chain_bwd, dt, 2, B, arr, None, Tn, ht, 0)
+            e._lstm_seq_bwd(P, arr, 2, B, None, Tn, ht)
             wih = e.sh["enct_wih_l%d" % l]
             if l > 0:
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, MT, H, 8 * ht)
