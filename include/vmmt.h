@@ -152,10 +152,11 @@ int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd* 
 /* ... and the BACKWARD recurrence (the mode-0 steps of vmmt_lstm_step_bwd: step 0 has dgates_next == NULL, step t consumes
  * dgates_out of step t-1; dc_carry is read at the first and written at the last step).  What the row group exchanges is dgates
  * (4H values per sentence and step).  `xchg`: vmmt_lstm_seq_xchg_bytes_bwd() bytes; otherwise the contract of vmmt_lstm_seq_fwd;
- * falls back to vmmt_lstm_chain_bwd. */
+ * falls back to vmmt_lstm_chain_bwd.  with_dh0 != 0: `dirs` holds nsteps + 1 steps, the last one a mode-1 descriptor (dgates_next,
+ * w_hh_t, dh0_out): the gradient of the initial hidden state comes out of the same launch. */
 int64_t vmmt_lstm_seq_xchg_bytes_bwd(int ndir, int B, int H);
 int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* dirs, const vmmt_lstm_dir_bwd* dirs_dev,
-                      const int64_t* lens, int B, int H, uint32_t* sync, void* xchg, void* stream);
+                      const int64_t* lens, int B, int H, int with_dh0, uint32_t* sync, void* xchg, void* stream);
 
 
 /* ---- statistics vector (f32[VMMT_STAT_COUNT], device memory, zeroed by the caller before each step) ------------
@@ -235,6 +236,16 @@ int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, int dy_f32, c
  * kl_b[b] = sum_k 0.5(mu^2+sigma^2-1) - log sigma (VILoss.py:446-456); stats[KL_SUM] += sum_b kl_b. */
 int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT, int64_t ldz,
                     float* kl_b, float* stats, int B, int Z, int training, void* stream);
+/* q(z|x) forward in ONE launch: hbar = masked mean over time of the (detached) encoder memory (NormalVariationalEncoder.py:65-84),
+ * h1 = relu(hbar W1^T + b1), out = h1 W2^T + b2 for the location and the scale network (:12-43; scale: Softplus), then
+ * vmmt_latent_fwd's sample and KL.  bf16 only; H % 128 == 0, Z % 64 == 0, Z <= 256-ish (LDS); returns 1 (invalid argument)
+ * otherwise and the caller issues vmmt_masked_mean + 4 vmmt_gemm + vmmt_latent_fwd instead (same results up to f32 summation
+ * order).  hbar / h1_* are written for the backward pass. */
+int vmmt_qnet_fwd(int dtype, const void* ctx, int64_t ldc, const int64_t* lens, const void* w1_loc, const void* w1_scale, int64_t ldw1,
+                  const float* b1_loc, const float* b1_scale, const void* w2_loc, const void* w2_scale, int64_t ldw2,
+                  const float* b2_loc, const float* b2_scale, const float* eps, void* hbar, int64_t ldh, void* h1_loc, void* h1_scale,
+                  int64_t ldh1, float* mu, float* sigma, float* z32, void* zT, int64_t ldz, float* kl_b, float* stats, int B, int S,
+                  int H, int Z, int training, void* stream);
 /* d/d(mu, pre-softplus scale) of max(mult * KL_mean, margin) * inv_norm  (VILoss.py:460-473, Loss.py:129).
  * dz / eps (f32 [B][Z], both or NULL): the reparameterised gradient z = mu + sigma * eps NOT detached -- d mu += dz,
  * d sigma += dz * eps.  As executed the reference detaches the sample (hazard H2: modules/Dists.py:21-26, Models.py:930-933),

@@ -9,7 +9,7 @@ def test_library_exports_every_declared_symbol():
     B.build(verbose=False)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "vmmt.h")).read()
-    declared = sorted(set(re.findall(r"^int\s+(vmmt_\w+)\s*\(", hdr, flags=re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|int64_t)\s+(vmmt_\w+)\s*\(", hdr, flags=re.M)))
     assert declared, "no declarations parsed"
     assert declared == L.EXPORTS, (set(declared) ^ set(L.EXPORTS))
     h = L.lib()

@@ -82,8 +82,13 @@ def _bwd_case(B, H, ndir, T, seed, lens_on):
     lens, _ = torch.sort(lens, descending=True)
     t_["lens"] = lens.to(dev) if lens_on else None
 
-    def build(dg, dcc):
-        arr = (L.LstmDirBwd * (T * ndir))()
+    def build(dg, dcc, dh0=None):
+        arr = (L.LstmDirBwd * ((T + 1) * ndir))()
+        if dh0 is not None:          # trailing mode-1 step (decoder: gradient of the initial hidden state = dgates of t = 0 times W_hh)
+            a = arr[T * ndir]
+            a.dgates_next, a.ld_dgn = dg.data_ptr(), ldg
+            a.w_hh_t, a.ld_wt = t_["whhT"][0].data_ptr(), 4 * H
+            a.dh0_out, a.ld_dh0 = dh0.data_ptr(), H
         for step in range(T):
             for k in range(ndir):
                 t = (T - 1 - step) if k == 0 else step
@@ -129,18 +134,26 @@ def test_persistent_backward_recurrence_is_bit_identical(B, H, ndir, T, lens_on)
         for mode in ("chain", "seq"):
             dg = torch.full((M + 64, ldg), 3.0, dtype=torch.bfloat16, device="cuda")
             dcc = t_["dcc0"].clone()
-            arr = build(dg, dcc)
+            with_dh0 = ndir == 1 and not lens_on          # the decoder's shape of the call
+            dh0 = torch.full((B, H), -7.0, device="cuda") if with_dh0 else None
+            arr = build(dg, dcc, dh0)
             lp = t_["lens"].data_ptr() if t_["lens"] is not None else None
             if mode == "chain":
                 L.check(lib.vmmt_lstm_chain_bwd(L.BF16, ndir, T, arr, lp, B, H, 0, None), "chain bwd")
+                if with_dh0:
+                    last = C.cast(C.byref(arr, T * ndir * C.sizeof(L.LstmDirBwd)), C.POINTER(L.LstmDirBwd))
+                    L.check(lib.vmmt_lstm_step_bwd(L.BF16, ndir, last, lp, B, H, 1, None), "dh0 step")
             else:
                 dev_arr = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
-                L.check(lib.vmmt_lstm_seq_bwd(L.BF16, ndir, T, arr, dev_arr.data_ptr(), lp, B, H, sync.data_ptr(), xchg.data_ptr(), None), "seq bwd")
+                L.check(lib.vmmt_lstm_seq_bwd(L.BF16, ndir, T, arr, dev_arr.data_ptr(), lp, B, H, 1 if with_dh0 else 0, sync.data_ptr(),
+                                              xchg.data_ptr(), None), "seq bwd")
             torch.cuda.synchronize()
-            outs.append((dg.clone(), dcc.clone()))
+            outs.append((dg.clone(), dcc.clone(), dh0.clone() if with_dh0 else torch.zeros(1)))
         assert int(sync[2].item()) == 0                              # every in-launch wait completed
         assert torch.equal(outs[0][0], outs[1][0]), ("dgates differ", rep, (outs[0][0].float() - outs[1][0].float()).abs().max().item())
         assert torch.equal(outs[0][1], outs[1][1]), ("dc carry differs", rep)
+        assert torch.equal(outs[0][2], outs[1][2]), ("dh0 differs", rep)
+        assert not (outs[1][2] == -7.0).any()
         assert (outs[1][0][M:] == 3.0).all()                         # nothing written beyond the rows of the sequence
         if rep == 0:
             first = outs[1]

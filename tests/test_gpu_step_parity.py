@@ -277,31 +277,6 @@ def test_source_longer_than_64_is_rejected():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_half_way_split_of_encoder_gradients(dtype):
-    """B a multiple of 64 and 4*Hd a multiple of 64: the backward plan issues the encoder's layer-0 parameter gradients in two
-    halves (behind the half-way point of the chain and at its end); ragged lengths; against the oracle."""
-    c = O.Cfg(vs=70, vt=80, emb=48, hid=64, z=16, layers=1, brnn=True)
-    p = O.init_params(c, seed=11)
-    B, S, T = 64, 6, 5
-    bt = O.synth_batch(c, B, S, T, n_img=70, seed=12, fixed_len=False)
-    e = _engine(c, p, dtype)
-    e.enc_half_split = True            # optional schedule (off by default: slower at the benchmark size)
-    e.set_image_table(bt["table"])
-    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
-    e.loss_backward(ws, normalization=B)
-    torch.cuda.synchronize()
-    assert any(n == "EV_RECORD" and a == "enc_half" for _, a, n, _, _ in ws.plan_bwd)       # the split path is the one taken
-    img = bt["table"][bt["indices"]]
-    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
-    tg = 3e-4 if dtype == "f32" else 4e-2
-    for k in g:
-        if "inf_net_image.location.fc1" in k or "gate_affine" in k:
-            continue
-        got, want = e.grads[k].cpu().double(), g[k].double()
-        assert (got - want).norm().item() <= tg * want.norm().item(), (k, (got - want).norm().item() / want.norm().item())
-
-
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("name", ["tiny_bi_l2", "small_fixed", "cond_bi_l1"])
 def test_reparameterised_gradient_switch(name, dtype):
     """Engine.reparam_grad = True (hazard H2 switched off: z = mu + sigma * eps NOT detached -- the estimator of the paper and of

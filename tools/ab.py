@@ -1,0 +1,49 @@
+"""In-process A/B of engine scheduling switches at the benchmark shape (same box, same process, alternating rounds).
+usage (GPU box): python tools/ab.py name1:attr=val,attr=val name2:attr=val ...      e.g.  base: aux:use_aux_stream=1 step:persistent_lstm=0"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from variational_mmt_amd.engine import Dims, Engine
+import bench
+
+cfgs = []
+for a in sys.argv[1:]:
+    name, _, rest = a.partition(":")
+    kv = {}
+    for item in filter(None, rest.split(",")):
+        k, _, v = item.partition("=")
+        kv[k] = (v == "1") if v in ("0", "1") else v
+    cfgs.append((name, kv))
+d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.5)
+table = torch.rand(29000, d.img)
+bs = bench.make_batches(d, 256, 20, 21, 29000, 4, "cuda", 1)
+engs = []
+for name, kv in cfgs:
+    e = Engine(d, dtype="bf16", device="cuda", seed=0)
+    for k, v in kv.items():
+        assert hasattr(e, k), k
+        setattr(e, k, v)
+    e.set_image_table(table)
+    engs.append(e)
+
+def run(e, n):
+    for i in range(n):
+        src, sl, tgt, idx = bs[i % 4]
+        ws = e.forward(src, sl, tgt, idx, training=True)
+        e.loss_backward(ws, normalization=256, batch_global=256)
+        e.optim_step(defer=True)
+
+for e in engs:
+    run(e, 6)
+torch.cuda.synchronize()
+res = {n: [] for n, _ in cfgs}
+for rnd in range(5):
+    for (name, _), e in zip(cfgs, engs):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(e, 20)
+        e.flush_pending()
+        torch.cuda.synchronize()
+        res[name].append((time.perf_counter() - t0) / 20 * 1e3)
+for name, _ in cfgs:
+    v = sorted(res[name])
+    print("%-24s median %.3f ms   min %.3f   max %.3f" % (name, v[len(v) // 2], v[0], v[-1]))

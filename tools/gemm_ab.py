@@ -8,8 +8,12 @@ def bench(name, lay, M, N, K, variants, out_f32=1, split=0, rounds=7):
     T = torch.bfloat16
     K0, K = K, (K + 63) // 64 * 64          # the engine rounds K up over zero-padded buffers
     if lay == L.GEMM_NT: A = torch.randn(M, K, device='cuda').to(T); B = torch.randn(N, K, device='cuda').to(T); A[:, K0:] = 0; B[:, K0:] = 0; lda, ldb = K, K
-    elif lay == L.GEMM_TN: A = torch.randn(K, M, device='cuda').to(T); B = torch.randn(K, N, device='cuda').to(T); A[K0:] = 0; B[K0:] = 0; lda, ldb = M, N
-    else: A = torch.randn(M, K, device='cuda').to(T); B = torch.randn(K, N, device='cuda').to(T); A[:, K0:] = 0; B[K0:] = 0; lda, ldb = K, N
+    elif lay == L.GEMM_TN:
+        Np = (N + 63) // 64 * 64            # the engine's buffers: leading dimension padded to 64 elements
+        A = torch.randn(K, M, device='cuda').to(T); B = torch.randn(K, Np, device='cuda').to(T); A[K0:] = 0; B[K0:] = 0; lda, ldb = M, Np
+    else:
+        Np = (N + 63) // 64 * 64
+        A = torch.randn(M, K, device='cuda').to(T); B = torch.randn(K, Np, device='cuda').to(T); A[:, K0:] = 0; B[K0:] = 0; lda, ldb = K, Np
     Cc = torch.zeros(M, N, device='cuda', dtype=torch.float32 if out_f32 else T)
     res = {v: [] for v in variants}
     ref = None

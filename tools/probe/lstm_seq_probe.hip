@@ -100,7 +100,7 @@ int main(int argc, char** argv) {
     for (int mode = 0; mode < 2; ++mode) {
       auto run = [&](int reps) {
         for (int r = 0; r < reps; ++r) {
-          int rc = mode ? vmmt_lstm_seq_bwd(VMMT_BF16, ndir, T, db.data(), bdev, nullptr, B, H, sync, xb2, st)
+          int rc = mode ? vmmt_lstm_seq_bwd(VMMT_BF16, ndir, T, db.data(), bdev, nullptr, B, H, 0, sync, xb2, st)
                         : vmmt_lstm_chain_bwd(VMMT_BF16, ndir, T, db.data(), nullptr, B, H, 0, st);
           if (rc) { printf("rc %d\n", rc); return; }
         }

@@ -66,7 +66,7 @@ _SIGS = {
     "vmmt_lstm_seq_xchg_bytes": (i64, [i32, i32, i32]),
     "vmmt_lstm_seq_fwd": (i32, [i32, i32, i32, C.POINTER(LstmDirFwd), vp, vp, i32, i32, vp, vp, vp]),
     "vmmt_lstm_seq_xchg_bytes_bwd": (i64, [i32, i32, i32]),
-    "vmmt_lstm_seq_bwd": (i32, [i32, i32, i32, C.POINTER(LstmDirBwd), vp, vp, i32, i32, vp, vp, vp]),
+    "vmmt_lstm_seq_bwd": (i32, [i32, i32, i32, C.POINTER(LstmDirBwd), vp, vp, i32, i32, i32, vp, vp, vp]),
     "vmmt_lstm_chain_bwd": (i32, [i32, i32, i32, C.POINTER(LstmDirBwd), vp, i32, i32, i32, vp]),
     "vmmt_attn_fwd": (i32, [i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp]),
     "vmmt_attn_bwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
@@ -90,6 +90,8 @@ _SIGS = {
     "vmmt_randn": (i32, [vp, i64, u64, vp]),
     "vmmt_mul": (i32, [i32, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_act_bwd": (i32, [i32, i32, vp, i64, i32, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
+    "vmmt_qnet_fwd": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp,
+                            i32, i32, i32, i32, i32, vp]),
     "vmmt_latent_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),
     "vmmt_latent_bwd": (i32, [i32, vp, vp, vp, f32, f32, i32, f32, f32, vp, vp, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_gate_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),

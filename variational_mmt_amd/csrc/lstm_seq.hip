@@ -463,6 +463,7 @@ struct SeqArgsB {
   unsigned* sync;
   unsigned long long* xchg;      // granules [ndir][ngroups][2 slots][2 row halves][4H / 32 k-steps][lo / hi][64 lanes] x 16 bytes
   int B, nsteps, ndir, ngroups;
+  int with_dh0;                  // steps[nsteps] is a mode-1 descriptor: dh0_out = dgates_{first step in time} W_hh, no cell backward
 };
 
 template <int H> struct SeqCfgB {
@@ -577,8 +578,9 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
   };
   fetch_in(load_desc_b(a.steps, k));
 
-  for (int t = 0; t < a.nsteps; ++t) {
+  for (int t = 0; t < a.nsteps + a.with_dh0; ++t) {
     const SeqDirB d = load_desc_b(a.steps, (long)t * ndir + k);
+    const bool dh0_step = t == a.nsteps;                        // the gradient of the initial hidden state: GEMM only
     SEQ_TS(0);
     float gi[2], gf[2], gg[2], go[2], cc[2], cpv[2], dha[2], dhn[2], dcn[2];
 #pragma unroll
@@ -676,6 +678,10 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
       const float oth0 = red[((pw * 2 + 0) * 2 + e) * 64 + lane], oth1 = red[((pw * 2 + 1) * 2 + e) * 64 + lane];
       const float q0 = wk ? oth0 : own0, q1 = wk ? oth1 : own1, q2 = wk ? own0 : oth0, q3 = wk ? own1 : oth1;
       float dh = (((0.f + q0) + q1) + q2) + q3;
+      if (dh0_step) {
+        if (rows[e] < B) d.dh0_out[(long)rows[e] * d.ld_dh0 + u] = dh;
+        continue;
+      }
       const bool valid = !a.lens || d.t < len[e];
       bf16_t* dt = dtile + (wm * 16 + kg * 4 + 2 * wk + e) * 64 + n;
       if (!valid) {
@@ -691,6 +697,7 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
         dcc[e] = gr.dc_prev;
       }
     }
+    if (dh0_step) break;                                        // (uniform) nothing to publish
     SEQ_TS(5);
     __syncthreads();
     SEQ_TS(6);
@@ -801,13 +808,13 @@ extern "C" int64_t vmmt_lstm_seq_xchg_bytes_bwd(int ndir, int B, int H) {
 }
 
 extern "C" int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* dirs, const vmmt_lstm_dir_bwd* dirs_dev,
-                                 const int64_t* lens, int B, int H, uint32_t* sync, void* xchg, void* stream) {
+                                 const int64_t* lens, int B, int H, int with_dh0, uint32_t* sync, void* xchg, void* stream) {
   using namespace vmmt;
   if (nsteps < 0 || !dirs || ndir < 1 || ndir > 2 || B <= 0 || H <= 0) return VMMT_EINVAL;
-  if (nsteps == 0) return VMMT_OK;
+  if (nsteps == 0) return with_dh0 ? VMMT_EINVAL : VMMT_OK;
   const int ngroups = (B + 31) / 32;
   bool ok = dtype == VMMT_BF16 && dirs_dev && sync && xchg && (((uintptr_t)xchg) & 15) == 0 && (H == 64 || H == 128 || H == 256 || H == 512) &&
-            (long)ngroups * (H / 16) * ndir <= 256 && nsteps >= 2 && nsteps < 4095;
+            (long)ngroups * (H / 16) * ndir <= 256 && nsteps >= 2 && nsteps < 4094;
   for (int i = 0; ok && i < nsteps; ++i)
     for (int k = 0; ok && k < ndir; ++k) {
       const vmmt_lstm_dir_bwd& d = dirs[(long)i * ndir + k];
@@ -820,8 +827,18 @@ extern "C" int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lst
         ok = d.dgates_next == p.dgates_out && d.ld_dgn == p.ld_dgo;
       }
     }
-  if (!ok) return vmmt_lstm_chain_bwd(dtype, ndir, nsteps, dirs, lens, B, H, 0, stream);
+  if (ok && with_dh0)
+    for (int k = 0; ok && k < ndir; ++k) {
+      const vmmt_lstm_dir_bwd& d = dirs[(long)nsteps * ndir + k], &p = dirs[(long)(nsteps - 1) * ndir + k];
+      ok = d.dh0_out && d.dgates_next == p.dgates_out && d.ld_dgn == p.ld_dgo && d.w_hh_t == dirs[k].w_hh_t && d.ld_wt == dirs[k].ld_wt;
+    }
+  if (!ok) {
+    int rc = vmmt_lstm_chain_bwd(dtype, ndir, nsteps, dirs, lens, B, H, 0, stream);
+    if (rc == VMMT_OK && with_dh0) rc = vmmt_lstm_step_bwd(dtype, ndir, dirs + (long)nsteps * ndir, lens, B, H, 1, stream);
+    return rc;
+  }
   SeqArgsB a;
+  a.with_dh0 = with_dh0 ? 1 : 0;
   a.steps = reinterpret_cast<const SeqDirB*>(dirs_dev); a.lens = (const long long*)lens; a.sync = sync;
   a.xchg = reinterpret_cast<unsigned long long*>(xchg);
   a.B = B; a.nsteps = nsteps; a.ndir = ndir; a.ngroups = ngroups;

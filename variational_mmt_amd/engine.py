@@ -163,22 +163,22 @@ class Engine(object):
         self.aux_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
         # measured (tools/sched_ab.py, fixed prior): 2.53 ms/step with that work on the side stream vs 2.59 ms on a stream of
         # its own; the conditional model keeps it (encoder_tgt's 2 x B-step recurrences would otherwise block the side stream)
-        self.use_aux_stream = bool(dims.conditional)
+        self.use_aux_stream = _os_env.get("VMMT_AUX_STREAM", "1") == "1"
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
         self.use_side_stream = True
         self._masked_streams = []
-        self.enc_half_split = False  # see Workspace._plan_backward
         import os as _os
         self.q_parallel = _os.environ.get("VMMT_QPAR", "1") == "1"    # q(z|x): scale branch on the side stream next to the location branch
-        self.side_one_per_cu = False # see _gemm; measured slower (tools/percu_ab.py): a 128 x 128 GEMM at one workgroup per CU runs at half speed (plans are built per workspace: set before the first forward)
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
         self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
-        self.bg_adam_blocks = 0      # grid cap of the background half of Adam (it has ~0.4 ms of slack under the encoder)
         self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
         self._sumsq_by_plan = False
+        self.fused_qnet = _os_env.get("VMMT_FUSED_QNET", "1") == "1"
+        self.defer_bg_adam = _os_env.get("VMMT_DEFER_BG_ADAM", "1") == "1"   # see optim_step(defer=True)
+        self._pending_bg = None
         self.persistent_lstm = _os_env.get("VMMT_PERSISTENT_LSTM", "1") == "1"     # plans are built per workspace: set before the first forward
         self.seq_syncs = []
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
@@ -236,12 +236,14 @@ class Engine(object):
         return self.flat_g.data_ptr() + (o + r * ld + c) * 4
 
     def load_state_dict(self, sd):
+        self.flush_pending()
         for n, t in sd.items():
             if n in self.params:
                 self.params[n].copy_(t.to(torch.float32))
         self.shadows_dirty = True
 
     def state_dict(self):
+        self.flush_pending()
         sd = {n: v.detach().clone() for n, v in self.params.items()}
         if self.d.conditional:      # encoder_tgt shares the decoder's table; the reference's state dict lists it under both names
             sd["encoder_tgt.embeddings.make_embedding.emb_luts.0.weight"] = sd["decoder.embeddings.make_embedding.emb_luts.0.weight"]
@@ -355,12 +357,6 @@ class Engine(object):
                 accumulate = 1          # gradients always ACCUMULATE into the arena (zeroed at the start of a step)
         if a_kmod == 0 and b_kmod == 0:
             K = _ru(K, KPAD)            # operands are Bufs: zero-padded to whole slabs (see Buf)
-        if self._sid == 1 and self.side_one_per_cu and tile == 0:
-            # bulk GEMMs of the side stream run underneath the LSTM step kernels of the main stream: one workgroup per CU, so
-            # that a step workgroup (64 KiB LDS, half of the registers) always finds room on every CU
-            t128 = ((M + 127) // 128) * ((N + 127) // 128) * max(1, split_k)
-            if t128 >= 192:
-                tile = L.TILE_128_ONE_PER_CU
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
                        add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k)
         plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
@@ -382,17 +378,21 @@ class Engine(object):
         else:
             plan.append((self.lib.vmmt_lstm_chain_fwd, (self.dt, ndir, nsteps, arr, lens_ptr, B, H), "vmmt_lstm_chain_fwd", arr, self._sid))
 
-    def _lstm_seq_bwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H):
-        """plan entry: a whole backward recurrence (the mode-0 steps), see _lstm_seq_fwd"""
+    def _lstm_seq_bwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H, with_dh0=0):
+        """plan entry: a whole backward recurrence (the mode-0 steps; with_dh0: `arr` ends with one mode-1 step, the gradient of
+        the initial hidden state), see _lstm_seq_fwd"""
         if self.persistent_lstm:
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
             sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
             xchg = torch.zeros(max(16, self.lib.vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H)), dtype=torch.uint8, device=self.dev)
-            plan.append((self.lib.vmmt_lstm_seq_bwd, (self.dt, ndir, nsteps, arr, dev.data_ptr(), lens_ptr, B, H, sync.data_ptr(), xchg.data_ptr()),
-                         "vmmt_lstm_seq_bwd", (arr, dev, sync, xchg), self._sid))
+            plan.append((self.lib.vmmt_lstm_seq_bwd, (self.dt, ndir, nsteps, arr, dev.data_ptr(), lens_ptr, B, H, with_dh0, sync.data_ptr(),
+                                                      xchg.data_ptr()), "vmmt_lstm_seq_bwd", (arr, dev, sync, xchg), self._sid))
             self.seq_syncs.append(sync)
         else:
             plan.append((self.lib.vmmt_lstm_chain_bwd, (self.dt, ndir, nsteps, arr, lens_ptr, B, H, 0), "vmmt_lstm_chain_bwd", arr, self._sid))
+            if with_dh0:
+                last = C.cast(C.byref(arr, nsteps * ndir * C.sizeof(L.LstmDirBwd)), C.POINTER(L.LstmDirBwd))
+                plan.append((self.lib.vmmt_lstm_step_bwd, (self.dt, ndir, last, lens_ptr, B, H, 1), "vmmt_lstm_step_bwd", arr, self._sid))
 
     def lstm_seq_errors(self):
         """error words of the persistent recurrence launches so far (0 = every in-launch wait completed); synchronises"""
@@ -469,6 +469,15 @@ class Engine(object):
                     self._works = []
                 L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq")
                 self._sumsq_by_plan = True
+                return
+            if name == "BG_ADAM":
+                bg, self._pending_bg = self._pending_bg, None
+                if bg is not None:
+                    for ename in args:                     # behind the main stream's progress marks of this forward
+                        ev = events.get(ename)
+                        if ev is not None:
+                            self.side_stream.wait_event(ev)
+                    bg()
                 return
             if name == "KL_ALLREDUCE":
                 if self.dp is not None and self.dp.world > 1:
@@ -639,6 +648,7 @@ class Workspace(object):
         self.q_dh1 = {br: nb(B, Z) for br in ("location", "scale")}
         self.dmu_v = nb(B, D)
         self.dh1v = nb(B, D)
+        self.dh1v32 = nb(B, D, f32)
         self.dzt = nb(B, Z, f32)
         if d.conditional:
             self._cond_alloc()
@@ -665,13 +675,14 @@ class Workspace(object):
         # ---- side stream, underneath the encoder: zero the gradient arena (every gradient writer of the backward plan
         #      runs on the side stream), target embeddings and the time-parallel part of the decoder input projection
         e._sid = SIDE
+        side_lo = len(P)
         e._wait(P, "fwd_begin")
         e._record(P, "side_fwd")
         if training:
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             # ... together with the small accumulators of the backward plan (off the critical path instead of in front of
             # their users): one launch
-            e._zero(P, [e.flat_g[e.offsets["generator.0.bias"][0]:], e._sumsq[:L.SUMSQ_SLOTS], self.dO32.t] +
+            e._zero(P, [e.flat_g[e.offsets["generator.0.bias"][0]:], e._sumsq[:L.SUMSQ_SLOTS], self.dO32.t, self.dh1v32.t, self.dzt.t] +
                     [b.t for l in range(Lyr) for b in (self.dec_dcc[l], self.enc_dcc[l])])
         self._mask_entries = getattr(self, "_mask_entries", {})
         if drop:
@@ -686,12 +697,17 @@ class Workspace(object):
         e._record(P, "dec_gx")
         if d.conditional:
             self._cond_forward_aux(P, training)
-        e._sid = MAIN
-        # a1 image rows (TrainerMultimodal.py:632-639) -- table pointer is patched in at run time (set_image_table)
+        # a1 image rows (TrainerMultimodal.py:632-639) -- table pointer is patched in at run time (set_image_table).  Fixed prior: only
+        # the loss reads them, so the gather runs on the side stream (joined by "img_fwd" at the end of the plan); the conditional
+        # model feeds them to q(z|x,y,v) and keeps it at the head of the main stream
         if not hasattr(self, '_img_idx'):
             self._img_idx = {}
+        if d.conditional:
+            e._sid = MAIN
         self._img_idx[bool(training)] = len(P)
         e._call(P, lib.vmmt_gather_rows, L.F32, None, D, self.img_idx.data_ptr(), self.img.p(), self.img.ld, B, D)
+        side_hi = len(P) if not d.conditional else side_lo      # (conditional: the segment is not moved)
+        e._sid = MAIN
         # a2 source embeddings
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                 self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
@@ -701,6 +717,22 @@ class Workspace(object):
             wih, bsum = e.sh["enc_wih_l%d" % l], e.sh["enc_b_l%d" % l]
             e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hd,
                     xcols, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+            if l == 0 and e.defer_bg_adam and side_hi > side_lo:
+                # deferred background half of Adam: the side-stream segment above (which needs the decoder-side parameters) is issued
+                # HERE, behind the encoder's input projection, with the pending optimiser work in front of it
+                self.has_bg_entry = True
+                e._record(P, "enc_in")
+                seg = P[side_lo:side_hi]
+                moved = len(P) - side_hi
+                del P[side_lo:side_hi]
+                P.append((None, ("enc_in",), "BG_ADAM", None, SIDE))
+                base = len(P)
+                P.extend(seg)
+                shift = base - side_lo
+                if "dec_out" in self._mask_entries and side_lo <= self._mask_entries["dec_out"][0] < side_hi:
+                    self._mask_entries["dec_out"] = (self._mask_entries["dec_out"][0] + shift, self._mask_entries["dec_out"][1])
+                if side_lo <= self._img_idx[bool(training)] < side_hi:
+                    self._img_idx[bool(training)] += shift
             seq = (L.LstmDirFwd * (S * dirs))()                 # the whole recurrence: step-major, then direction
             if not hasattr(self, "hzero"):
                 self.hzero = Buf(B, H, e.T, e.dev)              # first step: h_prev reads zeros
@@ -735,33 +767,46 @@ class Workspace(object):
         ctx = self.enc_out[Lyr - 1]
         if d.conditional:
             self._cond_forward(P, training, ctx)
-        # a4 q(z|x): masked mean of the detached memory, two 2-layer MLPs
-        if not d.conditional:
-            e._call(P, lib.vmmt_masked_mean, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.hbar.p(), self.hbar.ld, B, S, H)
-        # the two MLPs are independent and sit on the critical path between encoder and decoder (four latency-bound GEMMs):
-        # the scale branch runs on the side stream (idle at this point) next to the location branch
-        if not d.conditional:
-            e._record(P, "hbar_ready")
-        for br, outb, act in (() if d.conditional else (("location", self.mu, L.ACT_NONE), ("scale", self.sigma, L.ACT_SOFTPLUS))):
-            if br == "scale" and e.q_parallel:
-                e._sid = SIDE
-                e._wait(P, "hbar_ready")
-            w1, w2 = e.sh["q_%s_w1" % br], e.sh["q_%s_w2" % br]
-            e._gemm(P, L.GEMM_NT, self.hbar.p(), self.hbar.ld, w1.p(), w1.ld, self.q_h1[br].p(), self.q_h1[br].ld, B, Z, H,
-                    addend=e.pp("inf_net_global.%s.fc1.bias" % br), ld_add=Z, add_rows=1, act=L.ACT_RELU)
-            e._gemm(P, L.GEMM_NT, self.q_h1[br].p(), self.q_h1[br].ld, w2.p(), w2.ld, outb.p(), outb.ld, B, Z, Z,
-                    addend=e.pp("inf_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
-            if br == "scale" and e.q_parallel:
-                e._record(P, "sigma_ready")
-                e._sid = MAIN
-                e._wait(P, "sigma_ready")
-        # a5 fused mu/sigma -> sample -> KL
-        if d.conditional:
-            e._call(P, lib.vmmt_latent_cond_fwd, dt, self.mu.p(), self.sigma.p(), self.mu_p.p(), self.sigma_p.p(), self.eps.p(),
-                    self.z32.p(), self.zT.p(), self.zT.ld, self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
+        # a4 + a5 fused: masked mean -> both MLPs -> sample -> KL in ONE launch (csrc/qnet.hip); the separate kernels below remain for
+        # fp32 parity mode, the conditional model and sizes the fused kernel does not take
+        fused_q = (e.fused_qnet and not d.conditional and dt == L.BF16 and H % 256 == 0 and Z % 128 == 0 and
+                   16 * (H + 8) * 2 + 16 * (Z + 8) * 2 + 2 * 16 * Z * 4 <= 64 * 1024)
+        if fused_q:
+            wl1, ws1, wl2, ws2 = e.sh["q_location_w1"], e.sh["q_scale_w1"], e.sh["q_location_w2"], e.sh["q_scale_w2"]
+            e._call(P, lib.vmmt_qnet_fwd, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), wl1.p(), ws1.p(), wl1.ld,
+                    e.pp("inf_net_global.location.fc1.bias"), e.pp("inf_net_global.scale.fc1.bias"), wl2.p(), ws2.p(), wl2.ld,
+                    e.pp("inf_net_global.location.fc2.bias"), e.pp("inf_net_global.scale.fc2.bias"), self.eps.p(), self.hbar.p(),
+                    self.hbar.ld, self.q_h1["location"].p(), self.q_h1["scale"].p(), self.q_h1["location"].ld, self.mu.p(),
+                    self.sigma.p(), self.z32.p(), self.zT.p(), self.zT.ld, self.kl_b.data_ptr(), self.stats.data_ptr(), B, S, H, Z,
+                    1 if training else 0)
         else:
-            e._call(P, lib.vmmt_latent_fwd, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
-                    self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
+            # a4 q(z|x): masked mean of the detached memory, two 2-layer MLPs
+            if not d.conditional:
+                e._call(P, lib.vmmt_masked_mean, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.hbar.p(), self.hbar.ld, B, S, H)
+            # the two MLPs are independent and sit on the critical path between encoder and decoder (four latency-bound GEMMs):
+            # the scale branch runs on the side stream (idle at this point) next to the location branch
+            if not d.conditional:
+                e._record(P, "hbar_ready")
+            for br, outb, act in (() if d.conditional else (("location", self.mu, L.ACT_NONE), ("scale", self.sigma, L.ACT_SOFTPLUS))):
+                if br == "scale" and e.q_parallel:
+                    e._sid = SIDE
+                    e._wait(P, "hbar_ready")
+                w1, w2 = e.sh["q_%s_w1" % br], e.sh["q_%s_w2" % br]
+                e._gemm(P, L.GEMM_NT, self.hbar.p(), self.hbar.ld, w1.p(), w1.ld, self.q_h1[br].p(), self.q_h1[br].ld, B, Z, H,
+                        addend=e.pp("inf_net_global.%s.fc1.bias" % br), ld_add=Z, add_rows=1, act=L.ACT_RELU)
+                e._gemm(P, L.GEMM_NT, self.q_h1[br].p(), self.q_h1[br].ld, w2.p(), w2.ld, outb.p(), outb.ld, B, Z, Z,
+                        addend=e.pp("inf_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
+                if br == "scale" and e.q_parallel:
+                    e._record(P, "sigma_ready")
+                    e._sid = MAIN
+                    e._wait(P, "sigma_ready")
+            # a5 fused mu/sigma -> sample -> KL
+            if d.conditional:
+                e._call(P, lib.vmmt_latent_cond_fwd, dt, self.mu.p(), self.sigma.p(), self.mu_p.p(), self.sigma_p.p(), self.eps.p(),
+                        self.z32.p(), self.zT.p(), self.zT.ld, self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
+            else:
+                e._call(P, lib.vmmt_latent_fwd, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
+                        self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
         # a8 image network (location branch only; the scale branch is dead, H6 / VILoss.py:321): side stream, under the decoder
         e._record(P, "z_ready")
         e._sid = SIDE
@@ -880,13 +925,17 @@ class Workspace(object):
         e._gemm(P, L.GEMM_TN, self.dmu_v.p(), self.dmu_v.ld, self.h1v.p(), self.h1v.ld, e.gp("inf_net_image.location.fc2.weight"), D,
                 D, D, B, out_f32=1, split_k=-1)
         e._call(P, lib.vmmt_colsum, dt, self.dmu_v.p(), self.dmu_v.ld, B, D, e.gp("inf_net_image.location.fc2.bias"), None)
-        e._gemm(P, L.GEMM_NN, self.dmu_v.p(), self.dmu_v.ld, w2.p(), w2.ld, self.dh1v.p(), self.dh1v.ld, B, D, D)
-        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.dh1v.p(), self.dh1v.ld, 0, self.h1v.p(), self.h1v.ld, None, 0,
+        # [B x D] x [D x D] with B = a few hundred rows: 32 tiles of 128 x 128 would leave 7/8 of the chip idle for 100 us, so the
+        # reduction is split over workgroups (f32 atomics into dh1v32, zeroed with the gradient arena) and the ReLU backward reads f32
+        e._gemm(P, L.GEMM_NN, self.dmu_v.p(), self.dmu_v.ld, w2.p(), w2.ld, self.dh1v32.p(), self.dh1v32.ld, B, D, D, out_f32=1,
+                split_k=max(1, min(D // 256, 512 // max(1, ((B + 127) // 128) * ((D + 127) // 128)))))
+        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.dh1v32.p(), self.dh1v32.ld, 1, self.h1v.p(), self.h1v.ld, None, 0,
                 self.dh1v.p(), self.dh1v.ld, B, D)
         e._gemm(P, L.GEMM_TN, self.dh1v.p(), self.dh1v.ld, self.zt.p(), self.zt.ld, e.gp("inf_net_image.location.fc1.weight"), Z,
                 D, Z, B, out_f32=1, split_k=-1)
         e._call(P, lib.vmmt_colsum, dt, self.dh1v.p(), self.dh1v.ld, B, D, e.gp("inf_net_image.location.fc1.bias"), None)
-        e._gemm(P, L.GEMM_NN, self.dh1v.p(), self.dh1v.ld, w1.p(), w1.ld, self.dzt.p(), self.dzt.ld, B, Z, D, out_f32=1)
+        e._gemm(P, L.GEMM_NN, self.dh1v.p(), self.dh1v.ld, w1.p(), w1.ld, self.dzt.p(), self.dzt.ld, B, Z, D, out_f32=1,
+                split_k=max(1, min(D // 256, 256 // max(1, ((B + 63) // 64) * ((Z + 63) // 64)))))
         e._call(P, lib.vmmt_gate_bwd, self.dzt.p(), self.dzt.ld, self.z32.p(), self.gate.data_ptr(),
                 e.gp("inf_net_image.gate_affine_transform.weight"), e.gp("inf_net_image.gate_affine_transform.bias"), B, Z)
         rp = bool(e.reparam_grad)
@@ -931,7 +980,8 @@ class Workspace(object):
 
         if not rp:
             kl_and_q_backward()
-        # side: dWg = G^T O as soon as G^T exists (underneath dO = G Wg of the main stream)
+        # side: dWg = G^T O as soon as G^T exists, underneath dO = G Wg of the main stream (measured, tools/ab.py: issuing it behind dR,
+        # underneath the LSTM backward chains instead, is 3 % slower -- 2.333 vs 2.264 ms)
         e._sid = SIDE
         e._wait(P, "bwd_begin")
         e._wait(P, "GT")
@@ -967,7 +1017,7 @@ class Workspace(object):
             outb, ocol = (self.cat, H) if last else (self.dec_out[l], 0)
             whhT = e.sh["dec_whhT_l%d" % l]
             dg = self.dec_dgates[l]
-            seq = (L.LstmDirBwd * Tp)()
+            seq = (L.LstmDirBwd * (Tp + 1))()                   # Tp cell-backward steps + the dh0 step
             for i, t in enumerate(reversed(range(Tp))):
                 a = seq[i]
                 if t < Tp - 1:
@@ -983,15 +1033,12 @@ class Workspace(object):
                 a.dc_carry, a.ld_dcc = self.dec_dcc[l].p(), self.dec_dcc[l].ld
                 a.dgates_out, a.ld_dgo = dg.p(t * B), dg.ld
                 a.t, a.inject = t, 0
-            e._lstm_seq_bwd(P, seq, 1, Tp, None, B, H)
-            e._record(P, "dec_dg%d" % l)
-            arr = (L.LstmDirBwd * 2)()
-            a = arr[0]
+            a = seq[Tp]                                        # gradient of the initial hidden state: dgates_0 W_hh (mode 1)
             a.dgates_next, a.ld_dgn = dg.p(0), dg.ld
             a.w_hh_t, a.ld_wt = whhT.p(), whhT.ld
             a.dh0_out, a.ld_dh0 = self.dec_dh0[l].p(), self.dec_dh0[l].ld
-            self._keep.append(arr)
-            e._call(P, lib.vmmt_lstm_step_bwd, dt, 1, arr, None, B, H, 1)
+            e._lstm_seq_bwd(P, seq, 1, Tp, None, B, H, with_dh0=1)
+            e._record(P, "dec_dg%d" % l)
             if l > 0:       # gradient w.r.t. the layer input stays on the critical path
                 wi = e.sh["dec_wih_l%d" % l]
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wi.p(), wi.ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H, 4 * H)
@@ -1046,11 +1093,6 @@ class Workspace(object):
             e._call(P, lib.vmmt_masked_mean_bwd, dt, self.dhbar_p.p(), self.dhbar_p.ld, self.src_len.data_ptr(), self.dctx.p(),
                     self.dctx.ld, B, S, H, 0, 1)
         dh_above = self.dctx
-        # half-way split of layer 0's parameter gradients: only when the row counts stay whole GEMM slabs (sub-ranges cannot
-        # lean on the zero padding behind the buffers)
-        # (measured: 2.82 vs 2.58 ms/step at B = 256 -- the early half competes with the chain's own steps -- so it is off by default)
-        half = 0      # (the recurrence is one launch now: nothing can be issued half-way)
-
         def enc_param_grads(l, ranges, alternate):
             """dW_hh, db, dW_ih (and for layer 0 the embedding scatter) of encoder layer l from the time steps [lo, hi) of each
             direction; every product accumulates into the arena, so ranges may be issued separately"""
@@ -1083,13 +1125,7 @@ class Workspace(object):
                 alt()
                 e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, xin.p(lo * B), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)),
                         xcols, 4 * Hd, xcols, (hi - lo) * B, out_f32=1, split_k=-1)
-                if l == 0 and half:
-                    # embedding gradient of this direction's steps: sum_k dg_k W_ih,k, scattered by token id
-                    alt()
-                    e._gemm(P, L.GEMM_NN, dg.p(lo * B, k * 4 * Hd), dg.ld, wih.p(k * 4 * Hd, 0), wih.ld,
-                            e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E, (hi - lo) * B, E, 4 * Hd, out_f32=1,
-                            scatter_ids=self.src.data_ptr() + 8 * lo * B)
-            if l == 0 and not half:                  # one product over both directions, last on the main stream
+            if l == 0:                                # embedding gradient: one product over both directions, last on the main stream
                 assert all(r == (0, S) for r in ranges)
                 e._sid = MAIN
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
@@ -1132,10 +1168,7 @@ class Workspace(object):
                 dh_above = self.enc_dx[l - 1]
             e._sid = SIDE
             e._wait(P, "enc_dg%d" % l)
-            if l == 0 and half:
-                enc_param_grads(l, [(0, S - half), (half, S)][:dirs], True)      # the steps finished after the half-way event
-            else:
-                enc_param_grads(l, [(0, S)] * dirs, l == 0)
+            enc_param_grads(l, [(0, S)] * dirs, l == 0)
         if d.conditional:
             e._sid = SIDE
             e._wait(P, "aux_done")
@@ -1450,6 +1483,8 @@ def _engine_methods():
                 else:
                     ws.plan_fwd_train[ii] = (fn, (args[0], args[1], buf.rows * buf.ld, args[3], self.rng_counter), name, keep, sid)
         plan = ws.plan_fwd_train if training else ws.plan_fwd_eval
+        if not getattr(ws, "has_bg_entry", False):
+            self.flush_pending()          # this plan does not carry the deferred half of Adam (conditional model): issue it now
         ii = ws._img_idx[bool(training)]
         fn, args, name, keep, sid = plan[ii]
         plan[ii] = (fn, (L.F32, tab.data_ptr(), tab.shape[1]) + tuple(args[3:]), name, keep, sid)
@@ -1497,11 +1532,24 @@ def _engine_methods():
                     elbo=nmt - img_logprob + kl_after, n_words=int(round(s[L.STAT_NWORDS])),
                     n_correct=int(round(s[L.STAT_NCORRECT])))
 
-    def optim_step(self, lr=0.002, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-9, grad_scale=1.0):
+    def flush_pending(self):
+        """issue the deferred background half of the last optimiser step now (see optim_step(defer=True)): after this every
+        parameter, moment and compute shadow on the device queues is the updated one"""
+        bg, self._pending_bg = self._pending_bg, None
+        if bg is not None:
+            bg()
+
+    def optim_step(self, lr=0.002, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-9, grad_scale=1.0, defer=False):
         """Optim.step (Optim.py:78-96): global-norm clip + Adam over the arena, then the compute shadows are refreshed.
         The arena is updated in two halves: [encoder | inference networks] on the current stream (the next forward needs
         them first), [generator | attention | decoder] on the side stream, where it overlaps the next step's encoder
-        phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights."""
+        phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights.
+        defer=True (training loops: the trainer mirror, bench.py): that background half is not issued here but by the NEXT forward
+        plan, behind the encoder's input projection, so that the first kernels of the step (token / embedding gathers, input GEMM)
+        do not share HBM with 1.1 GB of optimiser traffic (2.264 -> 2.224 ms/step, tools/ab.py).  Until then the decoder-side
+        parameters on the device are the OLD ones: everything that reads them outside a forward plan (state_dict, checkpoints,
+        replica broadcast, another optim_step) calls flush_pending() first."""
+        self.flush_pending()
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
         if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
@@ -1523,10 +1571,16 @@ def _engine_methods():
             ev.record(main)
             self._pack_part(0, st)
             side = self.side_stream
-            side.wait_event(ev)
-            adam(0, split, side.cuda_stream, max_blocks=self.bg_adam_blocks)
-            self._pack_part(1, side.cuda_stream)
-            self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
+
+            def background():
+                side.wait_event(ev)
+                adam(0, split, side.cuda_stream)
+                self._pack_part(1, side.cuda_stream)
+                self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
+            if defer and self.defer_bg_adam:
+                self._pending_bg = background
+            else:
+                background()
         else:
             adam(0, self.n_opt, st)
             self._pack_part(0, st)
