@@ -303,8 +303,9 @@ def main():
         # dominant kernel = the fused vocabulary projection (+log-softmax+NLL) GEMM passes: 2*M*V*H FLOP per launch
         M = Tp * B
         gen_flop = 2.0 * M * d.vt * d.hid
-        t_f = sum(s.elapsed_time(e_) for s, e_ in dom["gen_fwd"]) / max(1, len(dom["gen_fwd"]))      # ms (fwd incl. combine)
-        t_b = sum(s.elapsed_time(e_) for s, e_ in dom["gen_bwd"]) / max(1, len(dom["gen_bwd"]))
+        # per step: the backward pass may walk the vocabulary in several launches (Engine.gen_chunks); their times add up
+        t_f = sum(s.elapsed_time(e_) for s, e_ in dom["gen_fwd"]) / max(1, a.steps)      # ms (fwd incl. combine)
+        t_b = sum(s.elapsed_time(e_) for s, e_ in dom["gen_bwd"]) / max(1, a.steps)
         t_dom = max(t_f, t_b)
         ach = gen_flop / (t_dom * 1e-3) / 1e12 if t_dom > 0 else 0.0
         traffic = None      # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)

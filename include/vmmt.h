@@ -102,9 +102,6 @@ typedef struct vmmt_lstm_dir_fwd {
   int t;                                 /* time index (compared with lens[b])                                  */
   int capture;                           /* 0 none; 1 if t == lens[b]-1; 2 if t == 0; 3 always                  */
 } vmmt_lstm_dir_fwd;
-/* tuning hook for the bf16 fast path (tools/probe/lstm_probe.hip): staging variant, 0 = default */
-int vmmt_lstm_set_variant(int v);
-
 int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* dirs, const int64_t* lens, int B, int H,
                        void* stream);
 
@@ -192,13 +189,13 @@ int vmmt_masked_mean(int dtype, const void* ctx, int64_t ldc, const int64_t* len
  * (onmt/Loss.py:163-165), accuracy (onmt/VILoss.py:515-531).  Logits are never written to memory in the forward.
  *   W T [V][ldw], bias f32 [V], O T [M][ldo] (M = Tp*B rows t*B+b), y int64 [M] = tgt[1:]
  *   workspaces: part_max/part_sum f32 [vmmt_gen_npart(V)][M], part_idx int32 same, tgt_logit f32 [M]
- *   out: lse f32 [M], tok_nll f32 [M]; stats[NLL,NWORDS,NCORRECT] += sums. */
+ *   out: lse f32 [M], tok_nll f32 [M]; stats[NLL,NWORDS,NCORRECT] += sums.
+ *   part_idx may be NULL (training): no arg-max index is kept, and a token counts as correct when its target's logit
+ *   equals the row maximum; decoding passes part_idx and reads the index back with vmmt_gen_argmax. */
 int vmmt_gen_npart(int V);
 /* arg-max over the vocabulary (and its logit) from the partials written by vmmt_gen_loss_fwd: the next input token of
  * step-wise decoding with beam size 1 (onmt/translate/TranslatorMultimodalVI.py:185-200); log-prob = out_max - lse */
 int vmmt_gen_argmax(const float* part_max, const int* part_idx, int M, int npart, int64_t* out_idx, float* out_max, void* stream);
-/* tuning hook (tools/gen_ab.py): -1 automatic, 0 register-staged, 1 LDS-DMA one buffer, 2 LDS-DMA two buffers */
-int vmmt_gen_set_variant(int v);
 int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
                       const int64_t* y, int M, int V, int K, int pad, float* part_max, float* part_sum, int* part_idx,
                       float* tgt_logit, float* lse, float* tok_nll, float* stats, void* stream);
@@ -209,10 +206,13 @@ int vmmt_gen_loss_bwd(int dtype, const void* W, int64_t ldw, const float* bias, 
                       int64_t ldgt, void* stream);
 
 /* vmmt_gen_loss_bwd plus the generator bias gradient dbias[v] += sum_m G^T[v][m] (f32 [V], accumulated): fused into the bf16
- * kernel's write-out where that kernel applies, otherwise a row-sum pass over G^T behind it. */
+ * kernel's write-out where that kernel applies, otherwise a row-sum pass over G^T behind it.
+ * v_off > 0: the pass covers the vocabulary CHUNK [v_off, v_off + V) only -- W, bias, GT and dbias point at the chunk's first
+ * row, y keeps whole-vocabulary ids (a caller short of memory for G^T [V][M] can walk the vocabulary in chunks of whole
+ * 128-row tiles with a chunk-sized G^T; the results are bit-identical to one pass). */
 int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
                          const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm, void* GT,
-                         int64_t ldgt, float* dbias, void* stream);
+                         int64_t ldgt, float* dbias, int v_off, void* stream);
 
 /* ---- row gathers / small fused kernels -------------------------------------------------------------------------- */
 /* out[r][0:D] = table[ids[r]][0:D]; table f32 (embedding master weights: modules/Embeddings.py:181; or the HBM-resident

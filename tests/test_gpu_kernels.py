@@ -185,10 +185,10 @@ def test_gemm_split_k_atomic(dtype, layout):
 
 
 @pytest.mark.parametrize("M,V,H", [(5120, 3000, 512), (200, 1000, 128), (37, 515, 64), (264, 130, 192), (8, 67, 64)])
-def test_generator_kernel_variants_bf16(M, V, H):
+def test_generator_kernel_bf16(M, V, H):
     """fused projection + log-softmax + NLL (vmmt_gen_loss_fwd / _bwd, bf16) against fp64 math on the same bf16-rounded operands,
-    for every main-loop variant: 8 = default (128 x 128 tiles, 32-deep slabs, three workgroups per CU), 3 = 128 x 256 three-stage,
-    6 = 128 x 256 half-depth, 0 = register-staged.  Ragged M / V exercise the clamped edge tiles and the fall-backs (M % 8 != 0)."""
+    with and without the arg-max index partials (decoding / training).  Ragged M / V exercise the clamped edge tiles, the -inf
+    rows of the last vocabulary tile and the generic kernel behind the backward pass (M % 8 != 0)."""
     from variational_mmt_amd import _lib as L
     lib = L.lib()
     g = torch.Generator().manual_seed(M + V)
@@ -201,6 +201,7 @@ def test_generator_kernel_variants_bf16(M, V, H):
     bias = torch.randn(V, generator=g) * 0.2
     y = torch.randint(0, V, (M,), generator=g)
     y[::5] = 1                                                     # pad targets carry no loss
+    y[1], y[2], y[3] = V - 1, 0, min(V - 1, 127)                   # first / last row of the vocabulary, a tile edge
     logits = O[:M, :H].double() @ W[:V, :H].double().t() + bias.double()
     lse_ref = torch.logsumexp(logits, 1)
     w = (y != 1).double()
@@ -211,40 +212,59 @@ def test_generator_kernel_variants_bf16(M, V, H):
     npart = lib.vmmt_gen_npart(V)
     ldgt = (M + 63) // 64 * 64
     outs = {}
-    try:
-        for v in (8, 3, 6, 0):
-            lib.vmmt_gen_set_variant(v)
-            pm = torch.zeros(npart * M, device="cuda"); ps = torch.zeros_like(pm)
-            pi = torch.zeros(npart * M, device="cuda", dtype=torch.int32)
-            tl = torch.zeros(M, device="cuda"); lse = torch.zeros(M, device="cuda"); nll = torch.zeros(M, device="cuda")
-            st = torch.zeros(8, device="cuda")
-            GT = torch.zeros(V + 256, ldgt, device="cuda", dtype=T)
-            P = lambda t: C.c_void_p(t.data_ptr())
-            L.check(lib.vmmt_gen_loss_fwd(L.BF16, P(Wd), ld, P(bd), P(Od), ld, P(yd), M, V, ld, 1, P(pm), P(ps), P(pi), P(tl), P(lse), P(nll),
-                                          P(st), None), "gen fwd")
-            L.check(lib.vmmt_gen_loss_bwd(L.BF16, P(Wd), ld, P(bd), P(Od), ld, P(yd), M, V, ld, 1, P(lse), inv_norm, P(GT), ldgt, None), "gen bwd")
+    for keep_idx in (True, False):
+        v = keep_idx
+        pm = torch.zeros(npart * M, device="cuda"); ps = torch.zeros_like(pm)
+        pi = torch.full((npart * M,), -7, device="cuda", dtype=torch.int32)
+        tl = torch.zeros(M, device="cuda"); lse = torch.zeros(M, device="cuda"); nll = torch.zeros(M, device="cuda")
+        st = torch.zeros(8, device="cuda")
+        GT = torch.zeros(V + 256, ldgt, device="cuda", dtype=T)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        L.check(lib.vmmt_gen_loss_fwd(L.BF16, P(Wd), ld, P(bd), P(Od), ld, P(yd), M, V, ld, 1, P(pm), P(ps), P(pi) if keep_idx else None,
+                                      P(tl), P(lse), P(nll), P(st), None), "gen fwd")
+        L.check(lib.vmmt_gen_loss_bwd(L.BF16, P(Wd), ld, P(bd), P(Od), ld, P(yd), M, V, ld, 1, P(lse), inv_norm, P(GT), ldgt, None), "gen bwd")
+        torch.cuda.synchronize()
+        assert (lse.cpu().double() - lse_ref).abs().max().item() <= 2e-4 * max(1.0, lse_ref.abs().max().item()), v
+        assert (nll.cpu().double() - nll_ref).abs().max().item() <= 5e-4 * max(1.0, nll_ref.abs().max().item()), v
+        s = st.cpu()
+        assert abs(s[L.STAT_NLL].item() - nll_ref.sum().item()) <= 1e-4 * abs(nll_ref.sum().item()) + 1e-3
+        assert int(round(s[L.STAT_NWORDS].item())) == int(w.sum().item())
+        correct = ((logits.argmax(1) == y) & (y != 1)).sum().item()
+        assert abs(int(round(s[L.STAT_NCORRECT].item())) - correct) <= 1          # a near-tie may flip one arg-max
+        if keep_idx:                                                              # the decoding flavour: arg-max index + its logit
+            oi = torch.zeros(M, device="cuda", dtype=torch.int64); om = torch.zeros(M, device="cuda")
+            L.check(lib.vmmt_gen_argmax(P(pm), P(pi), M, npart, P(oi), P(om), None), "argmax")
             torch.cuda.synchronize()
-            assert (lse.cpu().double() - lse_ref).abs().max().item() <= 2e-4 * max(1.0, lse_ref.abs().max().item()), v
-            assert (nll.cpu().double() - nll_ref).abs().max().item() <= 5e-4 * max(1.0, nll_ref.abs().max().item()), v
-            s = st.cpu()
-            assert abs(s[L.STAT_NLL].item() - nll_ref.sum().item()) <= 1e-4 * abs(nll_ref.sum().item()) + 1e-3
-            assert int(round(s[L.STAT_NWORDS].item())) == int(w.sum().item())
-            correct = ((logits.argmax(1) == y) & (y != 1)).sum().item()
-            assert abs(int(round(s[L.STAT_NCORRECT].item())) - correct) <= 1          # a near-tie may flip one arg-max
-            Gt = GT[:V, :M].float().cpu().t().double()
-            assert (Gt - G_ref).abs().max().item() <= 4e-3 * inv_norm + 1e-6, v       # bf16 storage of G^T
-            assert (GT[:V, M:] == 0).all() and (GT[V:] == 0).all(), v                 # nothing outside [V][M] is written
-            outs[v] = (lse.clone(), GT.clone())
-            # the same pass with the fused bias gradient (vmmt_gen_loss_bwd_db): identical G^T, dbias += row sums of the stored G^T
-            GT2 = torch.zeros_like(GT)
-            db = torch.full((V,), 0.5, device="cuda")
-            L.check(lib.vmmt_gen_loss_bwd_db(L.BF16, P(Wd), ld, P(bd), P(Od), ld, P(yd), M, V, ld, 1, P(lse), inv_norm, P(GT2), ldgt, P(db),
-                                             None), "gen bwd db")
+            top = logits.max(1)
+            assert (om.cpu().double() - top.values).abs().max().item() <= 2e-4 * max(1.0, top.values.abs().max().item())
+            picked = logits.gather(1, oi.cpu().view(-1, 1)).view(-1)
+            assert (picked - top.values).abs().max().item() <= 1e-3              # the index of (a near-tie of) the maximum
+        else:
+            assert (pi == -7).all()                                               # training: the index partials are not touched
+        Gt = GT[:V, :M].float().cpu().t().double()
+        assert (Gt - G_ref).abs().max().item() <= 4e-3 * inv_norm + 1e-6, v       # bf16 storage of G^T
+        assert (GT[:V, M:] == 0).all() and (GT[V:] == 0).all(), v                 # nothing outside [V][M] is written
+        outs[v] = (lse.clone(), nll.clone(), GT.clone())
+        # the same pass with the fused bias gradient (vmmt_gen_loss_bwd_db): identical G^T, dbias += row sums of the stored G^T
+        GT2 = torch.zeros_like(GT)
+        db = torch.full((V,), 0.5, device="cuda")
+        L.check(lib.vmmt_gen_loss_bwd_db(L.BF16, P(Wd), ld, P(bd), P(Od), ld, P(yd), M, V, ld, 1, P(lse), inv_norm, P(GT2), ldgt, P(db),
+                                         0, None), "gen bwd db")
+        torch.cuda.synchronize()
+        assert torch.equal(GT2, GT), v
+        ref_db = 0.5 + GT[:V, :M].float().sum(1)
+        assert (db - ref_db).abs().max().item() <= 1e-5 + 1e-5 * ref_db.abs().max().item(), v
+        # ... and walked in vocabulary chunks (whole 128-row tiles each, as the engine does): the same bits
+        if V > 256:
+            GT3 = torch.zeros_like(GT)
+            db3 = torch.full((V,), 0.5, device="cuda")
+            cuts = [0, 128, 384, V] if V > 384 else [0, 128, V]
+            for v0, v1 in zip(cuts[:-1], cuts[1:]):
+                L.check(lib.vmmt_gen_loss_bwd_db(L.BF16, C.c_void_p(Wd.data_ptr() + 2 * v0 * ld), ld, C.c_void_p(bd.data_ptr() + 4 * v0), P(Od), ld,
+                                                 P(yd), M, v1 - v0, ld, 1, P(lse), inv_norm, C.c_void_p(GT3.data_ptr() + 2 * v0 * ldgt), ldgt,
+                                                 C.c_void_p(db3.data_ptr() + 4 * v0), v0, None), "gen bwd chunk")
             torch.cuda.synchronize()
-            assert torch.equal(GT2, GT), v
-            ref_db = 0.5 + GT[:V, :M].float().sum(1)
-            assert (db - ref_db).abs().max().item() <= 1e-5 + 1e-5 * ref_db.abs().max().item(), v
-        for v in (3, 6, 0):
-            assert torch.equal(outs[v][0], outs[8][0]) and torch.equal(outs[v][1], outs[8][1]), v   # same arithmetic, same bits
-    finally:
-        lib.vmmt_gen_set_variant(-1)
+            assert torch.equal(GT3, GT), v
+            assert (db3 - db).abs().max().item() <= 1e-5 + 1e-5 * ref_db.abs().max().item(), v       # f32 atomics: order of the token tiles
+    for k in range(3):
+        assert torch.equal(outs[True][k], outs[False][k]), k                      # with / without the index: same arithmetic, same bits

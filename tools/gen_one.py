@@ -1,21 +1,37 @@
-"""A few launches of the generator kernels (bf16, BASELINE config 2 shape) for counter collection.  GPU box only."""
-import os, sys, torch
+"""The generator's two passes alone at the bench shape (cfg-2: M = 20 x 256 tokens, V = 30 000, H = 512; `--config 5`: H = 1024,
+M = 50 x 256): timing with HIP events, and the process tools/pmc_gen.sh profiles.  `python tools/gen_one.py [idx]` keeps the
+arg-max index (the decoding flavour of the forward pass)."""
+import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from variational_mmt_amd import _lib as L
 lib = L.lib()
-torch.manual_seed(0)
-M, V, H = 5120, 30000, 512
+H, M = (1024, 50 * 256) if "--config5" in sys.argv else (512, 20 * 256)
+V = 30000
+keep_idx = "idx" in sys.argv
 T = torch.bfloat16
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-W = (torch.randn(V, H, device='cuda') * 0.05).to(T); O = torch.randn(M, H, device='cuda').to(T)
-bias = torch.randn(V, device='cuda') * 0.1
-y = torch.randint(4, V, (M,), device='cuda')
+g = torch.Generator().manual_seed(0)
+Vp = (V + 255) // 256 * 256
+W = (torch.randn(Vp, H, generator=g) * 0.05).to(T).cuda(); W[V:] = 0
+O = torch.randn(M, H, generator=g).to(T).cuda()
+bias = (torch.randn(Vp, generator=g) * 0.1).cuda()
+y = torch.randint(2, V, (M,), generator=g).cuda()
 npart = lib.vmmt_gen_npart(V)
-pm = torch.zeros(npart * M, device='cuda'); ps = torch.zeros_like(pm); pi = torch.zeros(npart * M, device='cuda', dtype=torch.int32)
-tl = torch.zeros(M, device='cuda'); lse = torch.zeros(M, device='cuda'); nll = torch.zeros(M, device='cuda'); st = torch.zeros(8, device='cuda')
-GT = torch.zeros(V, M, device='cuda', dtype=T)
-lib.vmmt_gen_set_variant(variant)
-for _ in range(6):
-    L.check(lib.vmmt_gen_loss_fwd(L.BF16, W.data_ptr(), H, bias.data_ptr(), O.data_ptr(), H, y.data_ptr(), M, V, H, 1, pm.data_ptr(), ps.data_ptr(), pi.data_ptr(), tl.data_ptr(), lse.data_ptr(), nll.data_ptr(), st.data_ptr(), None), "f")
-    L.check(lib.vmmt_gen_loss_bwd(L.BF16, W.data_ptr(), H, bias.data_ptr(), O.data_ptr(), H, y.data_ptr(), M, V, H, 1, lse.data_ptr(), 1.0 / 256, GT.data_ptr(), M, None), "b")
-torch.cuda.synchronize()
+pm = torch.zeros(npart * M, device="cuda"); ps = torch.zeros_like(pm)
+pi = torch.zeros(npart * M, device="cuda", dtype=torch.int32)
+tl = torch.zeros(M, device="cuda"); lse = torch.zeros(M, device="cuda"); nll = torch.zeros(M, device="cuda")
+st = torch.zeros(8, device="cuda"); db = torch.zeros(Vp, device="cuda")
+GT = torch.zeros(Vp, M, device="cuda", dtype=T)
+P = lambda t: C.c_void_p(t.data_ptr())
+def fwd():
+    L.check(lib.vmmt_gen_loss_fwd(L.BF16, P(W), H, P(bias), P(O), H, P(y), M, V, H, 1, P(pm), P(ps), P(pi) if keep_idx else None, P(tl),
+                                  P(lse), P(nll), P(st), None), "fwd")
+def bwd():
+    L.check(lib.vmmt_gen_loss_bwd_db(L.BF16, P(W), H, P(bias), P(O), H, P(y), M, V, H, 1, P(lse), 1.0 / 256, P(GT), M, P(db), 0, None), "bwd")
+for name, fn in (("fwd", fwd), ("bwd", bwd)):
+    for _ in range(3): fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20): fn()
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) / 20 * 1e3
+    print("%s %8.1f us  %6.0f TF/s" % (name, us, 2.0 * M * V * H / us / 1e6))

@@ -11,7 +11,6 @@
 int main(int argc, char** argv) {
   const int B = 256, H = argc > 1 ? atoi(argv[1]) : 512, T = 20, ndir = argc > 2 ? atoi(argv[2]) : 1;
   const long M = (long)T * B;
-  vmmt_lstm_set_variant(argc > 3 ? atoi(argv[3]) : 0);
   void *dg, *whhT, *dha, *gates; float *c, *cn, *dcc;
   CK(hipMalloc(&dg, M * 4 * H * 2 * ndir)); CK(hipMalloc(&whhT, (long)H * 4 * H * 2 * ndir)); CK(hipMalloc(&dha, M * H * 2 * ndir));
   CK(hipMalloc(&gates, M * 4 * H * 2 * ndir)); CK(hipMalloc(&c, M * H * 4 * ndir)); CK(hipMalloc(&cn, (long)B * H * 4 * ndir));

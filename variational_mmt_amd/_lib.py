@@ -72,17 +72,15 @@ _SIGS = {
     "vmmt_attn_bwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     "vmmt_masked_mean": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "vmmt_gen_npart": (i32, [i32]),
-    "vmmt_gen_set_variant": (i32, [i32]),
     "vmmt_gen_argmax": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "vmmt_latent_cond_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),
     "vmmt_latent_cond_bwd": (i32, [i32, vp, vp, vp, vp, vp, f32, f32, i32, f32, f32, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_reparam_dz": (i32, [vp, i64, i32, vp, i64, vp, vp, vp, vp, i32, i32, vp]),
     "vmmt_masked_mean_bm": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "vmmt_masked_mean_bwd": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp]),
-    "vmmt_lstm_set_variant": (i32, [i32]),
     "vmmt_gen_loss_fwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "vmmt_gen_loss_bwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp]),
-    "vmmt_gen_loss_bwd_db": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, vp]),
+    "vmmt_gen_loss_bwd_db": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, i32, vp]),
     "vmmt_gather_rows": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, vp]),
     "vmmt_colsum": (i32, [i32, vp, i64, i32, i32, vp, vp, vp]),
     "vmmt_rowsum": (i32, [i32, vp, i64, i32, i32, vp, vp]),

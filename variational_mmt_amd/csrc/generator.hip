@@ -26,6 +26,7 @@ struct GenArgs {
   // pass 2
   const float* lse; float inv_norm; void* GT; long ldgt;               // T [V][ldgt]
   float* dbias;                                                        // optional f32 [V] += row sums of G^T (bias gradient)
+  int v_off;                                                           // pass 2 over a vocabulary chunk: W/bias/GT/dbias start at this row
 };
 
 // Tile: 128 vocabulary rows x 256 tokens, 8 waves (2 along V x 4 along tokens, 64x64 each), BK = 64, one LDS buffer
@@ -145,13 +146,15 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
         const int prow = (tv * 2 + wv) * NH + hf;                       // partial row = 64-row vocabulary block index
         if (mv && lane < 32 && prow < a.npart) {                        // (a 256-row tile can reach past vmmt_gen_npart(V) rows)
           long p = (long)prow * a.M + m;
-          a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
+          a.part_max[p] = nm; a.part_sum[p] = ns;
+          if (a.part_idx) a.part_idx[p] = ni;
         }
       } else {
         // gradient values -> this wave's 64(v) x 64(m) patch of an LDS image [v][m] (bf16/f32), written back below as
         // whole 16-byte row segments (a lane-per-token 2-byte store per element is store-issue bound)
         const float l = mv ? a.lse[m] : 0.f;
         const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
+        const int yl = ym - a.v_off;                              // target's row inside this vocabulary chunk
         T* patch = smem + wave * (64 * Cf::PP);
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dv = (r & 3) + 8 * (r >> 2);
-            float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
+            float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == yl ? 1.f : 0.f)) * sc;
             patch[(ii * 32 + hi4 + dv) * Cf::PP + j * 32 + (lane & 31)] = from_f<T>(g);
           }
         }
@@ -182,400 +185,6 @@ __global__ void __launch_bounds__(512) gen_kernel(GenArgs a, int tiles_m) {
           const T* srcp = patch + row * PP + ch * VEC;
           if (mm + VEC <= a.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);
           else for (int e = 0; e < VEC && mm + e < a.M; ++e) dst[e] = srcp[e];
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent variant (bf16, LDS-DMA, three stages): 128 x 256 tiles need 144 KiB of LDS, so only ONE workgroup fits a CU and
-// nothing hides a tile's prologue (first slabs' L2 latency) and epilogue (exp / max / stores) -- about 40 % of a tile's time at
-// K = 512 (8 slabs).  Here a workgroup walks its share of the tiles and issues the first two slabs of the NEXT tile (buffers 0
-// and 1, free after the last multiply) before it runs the epilogue of the current one; the gradient patches of MODE 1 live in
-// buffer 2 (32-row units: 36 KiB).  Tile order = the L2-friendly order of gen_kernel: XCD x owns a contiguous range of the
-// grouped tile sequence and its workgroups take consecutive tiles of it.
-template <int MODE>
-__global__ void __launch_bounds__(512) gen_kernel_p(GenArgs a, int tiles_m, int ntiles) {
-  using T = bf16_t;
-  using Cf = GenCfg<T, 128>;
-  constexpr int NT = Cf::NT, BMV = Cf::BMV, BNM = Cf::BNM, TI = Cf::TI, TJ = Cf::TJ, NW = NT / 64;
-  constexpr int ABYTES = BMV * GBK * 2, BBYTES = BNM * GBK * 2, BUF = ABYTES + BBYTES;
-  using GA = GldsOperand<BMV, true, NW>;
-  using GB = GldsOperand<BNM, true, NW>;
-  constexpr int PW = GA::PER + GB::PER;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  char* smem = smem_raw;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wv = wave >> 2, wm = wave & 3;
-  int aoff[TI], boff[TJ] = {wm * 64, wm * 64 + 32};
-#pragma unroll
-  for (int i = 0; i < TI; ++i) aoff[i] = wv * (32 * TI) + 32 * i;
-  GldsFrag<true, TI> fa;
-  GldsFrag<true, TJ> fb;
-  fa.init(aoff, lane);
-  fb.init(boff, lane);
-  // this workgroup's tiles: XCD x = blockIdx % 8 owns [lo, lo + cnt) of the grouped order, slot = blockIdx / 8 strides by per
-  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
-  const int q8 = ntiles >> 3, r8 = ntiles & 7;
-  const int lo = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8, cnt = q8 + (x < r8 ? 1 : 0);
-  const int tiles_v = (a.V + BMV - 1) / BMV;
-  constexpr int GV = 8;
-  auto coords = [&](int tile, int& tv_, int& v0_, int& m0_) {
-    const int group = tile / (GV * tiles_m), in_g = tile - group * (GV * tiles_m);
-    const int gv = min(GV, tiles_v - group * GV);
-    tv_ = group * GV + in_g % gv;
-    v0_ = tv_ * BMV;
-    m0_ = (in_g / gv) * BNM;
-  };
-  int idx = slot;
-  if (idx >= cnt) return;
-  const int nslab = a.K / GBK;
-  int tv, v0, m0;
-  coords(lo + idx, tv, v0, m0);
-  GA ga;
-  GB gb;
-  ga.init((const T*)a.W, a.ldw, v0, a.V, 0, wave, lane);
-  gb.init((const T*)a.O, a.ldo, m0, a.M, 0, wave, lane);
-  ga.issue(smem, wave);
-  gb.issue(smem + ABYTES, wave);
-  if (nslab > 1) {
-    ga.issue(smem + BUF, wave);
-    gb.issue(smem + BUF + ABYTES, wave);
-  }
-  const int hi4 = 4 * (lane >> 5);
-  while (true) {
-    f32x16 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#define VMMT_GENP_STEP(CUR, NXT2)                                                                      \
-  {                                                                                                    \
-    if (s + 1 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();                                     \
-    __builtin_amdgcn_s_barrier();                                                                      \
-    if (s + 2 < nslab) {                                                                               \
-      ga.issue(smem + (NXT2) * BUF, wave);                                                             \
-      gb.issue(smem + (NXT2) * BUF + ABYTES, wave);                                                    \
-    }                                                                                                  \
-    glds_slab<BMV, BNM, true, true, TI, TJ>(smem + (CUR) * BUF, smem + (CUR) * BUF + ABYTES, fa, fb, aoff, boff, acc); \
-    ++s;                                                                                               \
-  }
-    int s = 0;
-    while (s < nslab) {
-      VMMT_GENP_STEP(0, 2)
-      if (s >= nslab) break;
-      VMMT_GENP_STEP(1, 0)
-      if (s >= nslab) break;
-      VMMT_GENP_STEP(2, 1)
-    }
-#undef VMMT_GENP_STEP
-    __builtin_amdgcn_s_barrier();        // every wave has finished its last multiply: buffers 0 and 1 are free
-    // ---- epilogue inputs first (a dependent load issued AFTER the prefetch would wait for the prefetch: vmcnt is in order)
-    f32x4 bv[TI][4];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int vb = v0 + aoff[i] + hi4 + 8 * q;
-        if (vb + 3 < a.V && ((((uintptr_t)(a.bias + vb)) & 15) == 0)) bv[i][q] = *reinterpret_cast<const f32x4*>(a.bias + vb);
-        else {
-#pragma unroll
-          for (int s_ = 0; s_ < 4; ++s_) bv[i][q][s_] = vb + s_ < a.V ? a.bias[vb + s_] : 0.f;
-        }
-      }
-    int ymv[TJ];
-    float lsev[TJ];
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int m = m0 + boff[j] + (lane & 31);
-      ymv[j] = m < a.M ? (int)a.y[m] : -1;
-      lsev[j] = 0.f;
-      if constexpr (MODE == 1) lsev[j] = m < a.M ? a.lse[m] : 0.f;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- prefetch: first two slabs of the next tile
-    const int nidx = idx + per;
-    const bool has_next = nidx < cnt;
-    int ntv = 0, nv0 = 0, nm0 = 0;
-    if (has_next) {
-      coords(lo + nidx, ntv, nv0, nm0);
-      ga.init((const T*)a.W, a.ldw, nv0, a.V, 0, wave, lane);
-      gb.init((const T*)a.O, a.ldo, nm0, a.M, 0, wave, lane);
-      ga.issue(smem, wave);
-      gb.issue(smem + ABYTES, wave);
-      if (nslab > 1) {
-        ga.issue(smem + BUF, wave);
-        gb.issue(smem + BUF + ABYTES, wave);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- epilogue of the current tile
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int vb = v0 + aoff[i] + hi4 + 8 * q;
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-          const bool ok = vb + s_ < a.V;
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j][4 * q + s_] = ok ? acc[i][j][4 * q + s_] + bv[i][q][s_] : -INFINITY;
-        }
-      }
-    if constexpr (MODE == 0) {
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const int m = m0 + boff[j] + (lane & 31);
-        const bool mv = m < a.M;
-        const int ym = ymv[j];
-        float mx = -INFINITY, tl = 0.f;
-        int mi = 0x7fffffff;
-        bool hit = false;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
-            const float xx = acc[i][j][r];
-            const bool gt = xx > mx;
-            mi = gt ? v : mi;
-            mx = gt ? xx : mx;
-            const bool h = v == ym;
-            tl = h ? xx : tl;
-            hit = hit || h;
-          }
-        float sm = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sm += __expf(acc[i][j][r] - mx);
-        if (mx == -INFINITY) sm = 0.f;
-        if (hit) a.tgt_logit[m] = tl;
-        float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
-        int omi = __shfl_xor(mi, 32, 64);
-        float nm = fmaxf(mx, omx);
-        float ns = (nm == -INFINITY) ? 0.f : sm * __expf(mx - nm) + osm * __expf(omx - nm);
-        int ni = (omx > mx || (omx == mx && omi < mi)) ? omi : mi;
-        const int prow = tv * 2 + wv;
-        if (mv && lane < 32 && prow < a.npart) {
-          long p = (long)prow * a.M + m;
-          a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
-        }
-      }
-    } else {
-      // 32-row units through this wave's patch in buffer 2 (the only staging buffer the prefetch leaves alone)
-      constexpr int PP = Cf::PP, VEC = 8, CH = 64 / VEC;
-      T* patch = reinterpret_cast<T*>(smem + 2 * BUF) + wave * (32 * PP);
-#pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        const int vb = v0 + aoff[i] + hi4;
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          const int m = m0 + boff[j] + (lane & 31);
-          const bool mv = m < a.M;
-          const float l = lsev[j];
-          const float sc = (mv && ymv[j] != a.pad) ? a.inv_norm : 0.f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dv = (r & 3) + 8 * (r >> 2);
-            float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ymv[j] ? 1.f : 0.f)) * sc;
-            patch[(hi4 + dv) * PP + j * 32 + (lane & 31)] = from_f<T>(g);
-          }
-        }
-        const int vbase = v0 + aoff[i], mbase = m0 + wm * 64;
-#pragma unroll
-        for (int it = 0; it < (32 * CH) / 64; ++it) {
-          const int id2 = it * 64 + lane, row = id2 / CH, ch = id2 % CH;
-          const int v = vbase + row, mm = mbase + ch * VEC;
-          if (v < a.V && mm < a.M) {
-            T* dst = reinterpret_cast<T*>(a.GT) + (long)v * a.ldgt + mm;
-            const T* srcp = patch + row * PP + ch * VEC;
-            if (mm + VEC <= a.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);
-            else for (int e = 0; e < VEC && mm + e < a.M; ++e) dst[e] = srcp[e];
-          }
-        }
-      }
-    }
-    if (!has_next) break;
-    idx = nidx; tv = ntv; v0 = nv0; m0 = nm0;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Half-depth variant (bf16): K slabs of 32, three stages of 24 KiB = 72 KiB of LDS and at most 128 VGPRs, so that TWO
-// workgroups share a CU and one tile's epilogue / barriers overlap the other's MFMAs (profiles/r1_gen_kernel_investigation.txt).
-// LDS images have 64-byte rows (4 chunks of 16 B); a 1-KiB LDS-DMA piece is 16 rows; the chunk index is XOR-swizzled with
-// (row >> 2) & 3 on the source side and in the fragment reads (16 lanes of a ds_read_b128 pass then cover all 64 banks).
-template <int MODE>
-__global__ void __launch_bounds__(512, 4) gen_kernel_h(GenArgs a, int tiles_m) {
-  using T = bf16_t;
-  using Cf = GenCfg<T, 128>;
-  constexpr int NT = Cf::NT, BMV = Cf::BMV, BNM = Cf::BNM, TI = Cf::TI, TJ = Cf::TJ, NW = NT / 64;
-  constexpr int ABYTES = BMV * HBK * 2, BBYTES = BNM * HBK * 2, BUF = ABYTES + BBYTES;       // 8 + 16 = 24 KiB
-  using GA = HalfOperand<BMV, NW>;
-  using GB = HalfOperand<BNM, NW>;
-  constexpr int PW = GA::PER + GB::PER;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  char* smem = smem_raw;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tiles_v = (a.V + BMV - 1) / BMV;
-  constexpr int GV = 8;
-  const int group = tile / (GV * tiles_m), in_g = tile - group * (GV * tiles_m);
-  const int gv = min(GV, tiles_v - group * GV);
-  const int tv = group * GV + in_g % gv, tm = in_g / gv;
-  const int v0 = tv * BMV, m0 = tm * BNM;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wv = wave >> 2, wm = wave & 3;
-  int aoff[TI], boff[TJ] = {wm * 64, wm * 64 + 32};
-#pragma unroll
-  for (int i = 0; i < TI; ++i) aoff[i] = wv * (32 * TI) + 32 * i;
-  f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  GA ga;
-  GB gb;
-  ga.init((const T*)a.W, a.ldw, v0, a.V, 0, wave, lane);
-  gb.init((const T*)a.O, a.ldo, m0, a.M, 0, wave, lane);
-  // fragment offsets: lane (r, h) reads logical chunk 2 ks + h of row toff + r
-  int foff[2];
-  {
-    const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) foff[ks] = r * 64 + (((2 * ks + h) ^ sw) * 16);
-  }
-  const int nslab = a.K / HBK;
-  ga.issue(smem, wave);
-  gb.issue(smem + ABYTES, wave);
-  if (nslab > 1) {
-    ga.issue(smem + BUF, wave);
-    gb.issue(smem + BUF + ABYTES, wave);
-  }
-#define VMMT_GENH_STEP(CUR, NXT2)                                                                      \
-  {                                                                                                    \
-    if (s + 1 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();                                     \
-    __builtin_amdgcn_s_barrier();                                                                      \
-    if (s + 2 < nslab) {                                                                               \
-      ga.issue(smem + (NXT2) * BUF, wave);                                                             \
-      gb.issue(smem + (NXT2) * BUF + ABYTES, wave);                                                    \
-    }                                                                                                  \
-    const char* As = smem + (CUR) * BUF;                                                               \
-    const char* Bs = As + ABYTES;                                                                      \
-    bf16x8 fa_[2][TI], fb_[2][TJ];                                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                 \
-      _Pragma("unroll") for (int i = 0; i < TI; ++i) fa_[ks][i] = *reinterpret_cast<const bf16x8*>(As + foff[ks] + aoff[i] * 64); \
-      _Pragma("unroll") for (int j = 0; j < TJ; ++j) fb_[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + foff[ks] + boff[j] * 64); \
-    }                                                                                                  \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
-      _Pragma("unroll") for (int i = 0; i < TI; ++i)                                                   \
-        _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                 \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[ks][i], fb_[ks][j], acc[i][j], 0, 0, 0); \
-    ++s;                                                                                               \
-  }
-  int s = 0;
-  while (s < nslab) {
-    VMMT_GENH_STEP(0, 2)
-    if (s >= nslab) break;
-    VMMT_GENH_STEP(1, 0)
-    if (s >= nslab) break;
-    VMMT_GENH_STEP(2, 1)
-  }
-#undef VMMT_GENH_STEP
-  __builtin_amdgcn_s_barrier();        // staging buffers are reused as gradient patches (MODE 1)
-  const int hi4 = 4 * (lane >> 5);
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int vb = v0 + aoff[i] + hi4 + 8 * q;
-      f32x4 bv;
-      if (vb + 3 < a.V && ((((uintptr_t)(a.bias + vb)) & 15) == 0)) bv = *reinterpret_cast<const f32x4*>(a.bias + vb);
-      else {
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) bv[s_] = vb + s_ < a.V ? a.bias[vb + s_] : 0.f;
-      }
-#pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) {
-        const bool ok = vb + s_ < a.V;
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j][4 * q + s_] = ok ? acc[i][j][4 * q + s_] + bv[s_] : -INFINITY;
-      }
-    }
-  if constexpr (MODE == 0) {
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int m = m0 + boff[j] + (lane & 31);
-      const bool mv = m < a.M;
-      const int ym = mv ? (int)a.y[m] : -1;
-      float mx = -INFINITY, tl = 0.f;
-      int mi = 0x7fffffff;
-      bool hit = false;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
-          const float xx = acc[i][j][r];
-          const bool gt = xx > mx;
-          mi = gt ? v : mi;
-          mx = gt ? xx : mx;
-          const bool h = v == ym;
-          tl = h ? xx : tl;
-          hit = hit || h;
-        }
-      float sm = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sm += __expf(acc[i][j][r] - mx);
-      if (mx == -INFINITY) sm = 0.f;
-      if (hit) a.tgt_logit[m] = tl;
-      float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
-      int omi = __shfl_xor(mi, 32, 64);
-      float nm = fmaxf(mx, omx);
-      float ns = (nm == -INFINITY) ? 0.f : sm * __expf(mx - nm) + osm * __expf(omx - nm);
-      int ni = (omx > mx || (omx == mx && omi < mi)) ? omi : mi;
-      const int prow = tv * 2 + wv;
-      if (mv && lane < 32 && prow < a.npart) {
-        long p = (long)prow * a.M + m;
-        a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
-      }
-    }
-  } else {
-    constexpr int PP = Cf::PP, VEC = 8, CH = 64 / VEC;
-    T* patch = reinterpret_cast<T*>(smem) + wave * (32 * PP);
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      const int vb = v0 + aoff[i] + hi4;
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const int m = m0 + boff[j] + (lane & 31);
-        const bool mv = m < a.M;
-        const int ym = mv ? (int)a.y[m] : -1;
-        const float l = mv ? a.lse[m] : 0.f;
-        const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dv = (r & 3) + 8 * (r >> 2);
-          float g = (__expf(acc[i][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
-          patch[(hi4 + dv) * PP + j * 32 + (lane & 31)] = from_f<T>(g);
-        }
-      }
-      const int vbase = v0 + aoff[i], mbase = m0 + wm * 64;
-#pragma unroll
-      for (int it = 0; it < (32 * CH) / 64; ++it) {
-        const int id2 = it * 64 + lane, row = id2 / CH, ch = id2 % CH;
-        const int v = vbase + row, mm = mbase + ch * VEC;
-        if (v < a.V && mm < a.M) {
-          T* dst = reinterpret_cast<T*>(a.GT) + (long)v * a.ldgt + mm;
-          const T* srcp = patch + row * PP + ch * VEC;
-          *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(srcp);      // M % 8 == 0, G^T rows 16-byte aligned (dispatch)
         }
       }
     }
@@ -658,54 +267,77 @@ __global__ void __launch_bounds__(256, 3) gen_kernel_q(GenArgs a, int tiles_m) {
     cur = cur == 2 ? 0 : cur + 1;
   }
   __builtin_amdgcn_s_barrier();        // staging buffers are reused as gradient patches (MODE 1)
+  // ---- epilogue.  A lane owns one token per j and 32 vocabulary rows of it (2 x 16 accumulator registers); ~900 vector
+  //      instructions per wave in the first version of this epilogue held the MFMA pipe at 35 % busy (PMC, profiles/r1_gen_kernel_
+  //      investigation.txt), so everything that is not needed per element has been taken out of the per-element path:
+  //      * the -inf masking of rows >= V only in the last vocabulary tile (uniform branch);
+  //      * no arg-max index in the training pass (accuracy = "the target's logit is the maximum", decided by the combine kernel);
+  //        the decoding pass (part_idx != NULL) still tracks it;
+  //      * the target logit / the one-hot term only in waves whose 64 vocabulary rows contain one of their 64 tokens' targets
+  //        (a wave-uniform branch, taken by ~13 % of the waves at V = 30 000).
   const int hi4 = 4 * (lane >> 5);
+  const bool full_v = v0 + BMV <= a.V;
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int vb = v0 + aoff[i] + hi4 + 8 * q;
       f32x4 bv;
-      if (vb + 3 < a.V && ((((uintptr_t)(a.bias + vb)) & 15) == 0)) bv = *reinterpret_cast<const f32x4*>(a.bias + vb);
+      if (full_v) bv = *reinterpret_cast<const f32x4*>(a.bias + vb);        // bias + 4 * k: 16-byte aligned (hipMalloc'ed arena, offsets % 64)
       else {
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) bv[s_] = vb + s_ < a.V ? a.bias[vb + s_] : 0.f;
+        for (int s_ = 0; s_ < 4; ++s_) bv[s_] = vb + s_ < a.V ? a.bias[vb + s_] : -INFINITY;
       }
 #pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) {
-        const bool ok = vb + s_ < a.V;
+      for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j][4 * q + s_] = ok ? acc[i][j][4 * q + s_] + bv[s_] : -INFINITY;
-      }
+        for (int j = 0; j < TJ; ++j) acc[i][j][4 * q + s_] += bv[s_];      // rows >= V: -inf (their accumulators are finite)
     }
+  const int vlo = v0 + wv * 64;                                   // this wave's 64 vocabulary rows
   if constexpr (MODE == 0) {
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
       const int m = m0 + boff[j] + (lane & 31);
       const bool mv = m < a.M;
       const int ym = mv ? (int)a.y[m] : -1;
-      float mx = -INFINITY, tl = 0.f;
+      float mx = -INFINITY;
       int mi = 0x7fffffff;
-      bool hit = false;
+      if (a.part_idx) {                                           // decoding: arg-max index, ties -> lowest vocabulary index
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
-          const float xx = acc[i][j][r];
-          const bool gt = xx > mx;
-          mi = gt ? v : mi;
-          mx = gt ? xx : mx;
-          const bool h = v == ym;
-          tl = h ? xx : tl;
-          hit = hit || h;
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int v = v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2);
+            const float xx = acc[i][j][r];
+            const bool gt = xx > mx;
+            mi = gt ? v : mi;
+            mx = gt ? xx : mx;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, acc[i][j][r]), acc[i][j][r + 1]);      // v_max3_f32
+      }
+      if (__any(ym >= vlo && ym < vlo + 64)) {                    // some token of this wave has its target in these rows
+        float tl = 0.f;
+        bool hit = false;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool h = (v0 + aoff[i] + hi4 + (r & 3) + 8 * (r >> 2)) == ym;
+            tl = h ? acc[i][j][r] : tl;
+            hit = hit || h;
+          }
+        if (hit) a.tgt_logit[m] = tl;
+      }
       float sm = 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sm += __expf(acc[i][j][r] - mx);
       if (mx == -INFINITY) sm = 0.f;
-      if (hit) a.tgt_logit[m] = tl;
       float omx = __shfl_xor(mx, 32, 64), osm = __shfl_xor(sm, 32, 64);
       int omi = __shfl_xor(mi, 32, 64);
       float nm = fmaxf(mx, omx);
@@ -714,7 +346,8 @@ __global__ void __launch_bounds__(256, 3) gen_kernel_q(GenArgs a, int tiles_m) {
       const int prow = tv * 2 + wv;
       if (mv && lane < 32 && prow < a.npart) {
         long p = (long)prow * a.M + m;
-        a.part_max[p] = nm; a.part_sum[p] = ns; a.part_idx[p] = ni;
+        a.part_max[p] = nm; a.part_sum[p] = ns;
+        if (a.part_idx) a.part_idx[p] = ni;
       }
     }
   } else {
@@ -725,18 +358,29 @@ __global__ void __launch_bounds__(256, 3) gen_kernel_q(GenArgs a, int tiles_m) {
     for (int j = 0; j < TJ; ++j) {
       const int m = m0 + boff[j] + (lane & 31);
       const bool mv = m < a.M;
-      const int ym = mv ? (int)a.y[m] : -1;
+      const int yraw = mv ? (int)a.y[m] : a.pad;
+      const int ym = mv ? yraw - a.v_off : -1;                    // target's row inside this vocabulary chunk (or outside it)
       const float l = mv ? a.lse[m] : 0.f;
-      const float sc = (mv && ym != a.pad) ? a.inv_norm : 0.f;
+      const float sc = (mv && yraw != a.pad) ? a.inv_norm : 0.f;
+      if (__any(ym >= vlo && ym < vlo + 64)) {                    // with the one-hot term (rare)
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii) {
-        const int vb = v0 + aoff[ii] + hi4;
+        for (int ii = 0; ii < 2; ++ii) {
+          const int vb = v0 + aoff[ii] + hi4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dv = (r & 3) + 8 * (r >> 2);
-          float g = (__expf(acc[ii][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
-          patch[(ii * 32 + hi4 + dv) * PP + j * 32 + (lane & 31)] = from_f<T>(g);
+          for (int r = 0; r < 16; ++r) {
+            const int dv = (r & 3) + 8 * (r >> 2);
+            const float g = (__expf(acc[ii][j][r] - l) - ((vb + dv) == ym ? 1.f : 0.f)) * sc;
+            patch[(ii * 32 + hi4 + dv) * PP + j * 32 + (lane & 31)] = from_f<T>(g);
+          }
         }
+      } else {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dv = (r & 3) + 8 * (r >> 2);
+            patch[(ii * 32 + hi4 + dv) * PP + j * 32 + (lane & 31)] = from_f<T>(__expf(acc[ii][j][r] - l) * sc);
+          }
       }
     }
     const int vbase = v0 + wv * 64, mbase = m0 + wm * 64;
@@ -781,37 +425,7 @@ static int launch_gen_q(const GenArgs& a, hipStream_t st) {
   return check_launch();
 }
 
-template <int MODE>
-static int launch_gen_h(const GenArgs& a, hipStream_t st) {
-  using Cf = GenCfg<bf16_t, 128>;
-  const int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + Cf::BNM - 1) / Cf::BNM;
-  const size_t sm = (size_t)3 * (Cf::BMV + Cf::BNM) * HBK * 2;          // 72 KiB
-  static bool done[2] = {false, false};
-  if (!done[MODE]) { (void)hipFuncSetAttribute((const void*)gen_kernel_h<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done[MODE] = true; }
-  hipLaunchKernelGGL((gen_kernel_h<MODE>), dim3(tv * tm), dim3(Cf::NT), sm, st, a, tm);
-  return check_launch();
-}
-
-template <int MODE>
-static int launch_gen_p(const GenArgs& a, hipStream_t st) {
-  using Cf = GenCfg<bf16_t, 128>;
-  const int tv = (a.V + Cf::BMV - 1) / Cf::BMV, tm = (a.M + Cf::BNM - 1) / Cf::BNM, ntiles = tv * tm;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return VMMT_ELAUNCH;
-    ncu = pr.multiProcessorCount > 8 ? (pr.multiProcessorCount / 8) * 8 : 8;
-  }
-  const size_t sm = (size_t)glds3_smem_bytes<Cf::BMV, Cf::BNM>();
-  static bool done[2] = {false, false};
-  if (!done[MODE]) { (void)hipFuncSetAttribute((const void*)gen_kernel_p<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); done[MODE] = true; }
-  int grid = ncu < ((ntiles + 7) / 8) * 8 ? ncu : ((ntiles + 7) / 8) * 8;      // a multiple of 8: one slot set per XCD
-  hipLaunchKernelGGL((gen_kernel_p<MODE>), dim3(grid), dim3(Cf::NT), sm, st, a, tm, ntiles);
-  return check_launch();
-}
-
-// per token: logsumexp, NLL, argmax-correct; block-reduced sums are added to stats[0..2].
+// per token: logsumexp, NLL, argmax-correct; block-reduced sums are added to stats[0..2].  part_idx may be NULL.
 // Block = 16 waves x 64 tokens: wave w folds partials w, w+16, ... (coalesced along tokens) with an online
 // (max, sum-exp, argmax) merge, then the 16 wave results are merged through LDS.
 __global__ void __launch_bounds__(1024) gen_combine_kernel(const float* __restrict__ part_max, const float* __restrict__ part_sum,
@@ -832,7 +446,7 @@ __global__ void __launch_bounds__(1024) gen_combine_kernel(const float* __restri
         const int p = p0 + 16 * q;
         const bool ok = p < npart;
         const long o = (long)(ok ? p : p0) * M + m;
-        xv[q] = ok ? part_max[o] : -INFINITY; sv[q] = ok ? part_sum[o] : 0.f; iv[q] = ok ? part_idx[o] : 0x7fffffff;
+        xv[q] = ok ? part_max[o] : -INFINITY; sv[q] = ok ? part_sum[o] : 0.f; iv[q] = (ok && part_idx) ? part_idx[o] : 0x7fffffff;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -867,7 +481,9 @@ __global__ void __launch_bounds__(1024) gen_combine_kernel(const float* __restri
     nll = wv ? l - tgt_logit[m] : 0.f;
     tok_nll[m] = nll;
     nw = wv ? 1.f : 0.f;
-    nc = (wv && mi == (int)ym) ? 1.f : 0.f;
+    // accuracy (Loss.py:150-160: pred = scores.max(1)[1]; pred.eq(target)).  With the arg-max partials: their index; without
+    // (training pass, part_idx == NULL): the target's logit is the maximum (an exact tie counts as correct)
+    nc = (wv && (part_idx ? mi == (int)ym : tgt_logit[m] >= mx)) ? 1.f : 0.f;
   }
   nll = wave_sum(nll); nw = wave_sum(nw); nc = wave_sum(nc);
   if (lane == 0) {
@@ -876,8 +492,6 @@ __global__ void __launch_bounds__(1024) gen_combine_kernel(const float* __restri
     atomicAdd(stats + VMMT_STAT_NCORRECT, nc);
   }
 }
-
-int g_gen_variant = -1;   // -1: automatic; 0/1/2 force a main loop (tools/gen_ab.py via vmmt_gen_set_variant)
 
 template <class T, int MODE, int GL, int BMV_ = 128>
 static int launch_gen_v(const GenArgs& a, hipStream_t st) {
@@ -910,38 +524,20 @@ __global__ void gen_argmax_kernel(const float* __restrict__ part_max, const int*
   if (out_max) out_max[m] = mx;
 }
 
-// preconditions of the default bf16 kernel (gen_kernel_q) for this call, as launch_gen checks them
+// preconditions of the bf16 throughput kernel (gen_kernel_q): LDS-DMA operands (16-byte aligned rows, K in whole 32-slabs) and,
+// for the gradient pass, G^T rows that take unconditional 16-byte segments; everything else (fp32 parity mode, ragged shapes)
+// runs the register-staged general kernel
 template <int MODE>
 static bool gen_q_applies(const GenArgs& a) {
   const bool ok = a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldo % 8 == 0 && ((((uintptr_t)a.W) | ((uintptr_t)a.O)) & 15) == 0;
   const bool gt_ok = MODE == 0 || (a.M % 8 == 0 && a.ldgt % 8 == 0 && (((uintptr_t)a.GT) & 15) == 0);
-  return ok && gt_ok && (g_gen_variant < 0 || g_gen_variant == 8);
+  return ok && gt_ok;
 }
 
 template <class T, int MODE>
 static int launch_gen(const GenArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
-    // LDS-DMA main loop: 16-byte aligned operands, K in whole 64-slabs (callers round K up over zero-padded rows)
-    const bool ok = a.K % 64 == 0 && a.ldw % 8 == 0 && a.ldo % 8 == 0 && ((((uintptr_t)a.W) | ((uintptr_t)a.O)) & 15) == 0;
-    // variants (tools/gen_ab.py; results are bit-identical across them):
-    //   8 (default) 128 x 128 tiles, 32-deep slabs, 48 KiB, three workgroups per CU        fwd 219 us, bwd 221 us
-    //   3           128 x 256 tiles, 64-deep slabs, three stages (144 KiB), one per CU      fwd 259 us, bwd 256 us
-    //   7 / 6       128 x 256 tiles, 32-deep slabs, 72 KiB, two per CU (fwd only / both; the backward instantiation spills)
-    //   5           persistent variant of 3 with the next tile prefetched under the epilogue (no gain)
-    //   1, 2, 4     one / two LDS buffers, 256 x 256 tiles
-    int v = g_gen_variant < 0 ? 8 : g_gen_variant;
-    // the half-depth kernels store G^T as unconditional 16-byte segments
-    const bool gt_ok = MODE == 0 || (a.M % 8 == 0 && a.ldgt % 8 == 0 && (((uintptr_t)a.GT) & 15) == 0);
-    if (v == 8 && !(a.K % 32 == 0 && gt_ok)) v = 3;
-    if (v == 6 && !(a.K % 32 == 0 && gt_ok)) v = 3;
-    if (v == 7 && MODE == 1) v = 3;
-    if (ok && v == 8) return launch_gen_q<MODE>(a, st);
-    if (ok && (v == 6 || v == 7)) return launch_gen_h<MODE>(a, st);
-    if (ok && v == 5 && a.K >= 128) return launch_gen_p<MODE>(a, st);
-    if (ok && v == 4) return launch_gen_v<T, MODE, 2, 256>(a, st);
-    if (ok && v == 3) return launch_gen_v<T, MODE, 3>(a, st);
-    if (ok && v == 2) return launch_gen_v<T, MODE, 2>(a, st);
-    if (ok && v == 1) return launch_gen_v<T, MODE, 1>(a, st);
+    if (gen_q_applies<MODE>(a)) return launch_gen_q<MODE>(a, st);
   }
   return launch_gen_v<T, MODE, 0>(a, st);
 }
@@ -959,14 +555,12 @@ extern "C" int vmmt_gen_argmax(const float* part_max, const int* part_idx, int M
   return check_launch();
 }
 
-extern "C" int vmmt_gen_set_variant(int v) { vmmt::g_gen_variant = v; return VMMT_OK; }
-
 extern "C" int vmmt_gen_loss_fwd(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
                                  const int64_t* y, int M, int V, int K, int pad, float* part_max, float* part_sum,
                                  int* part_idx, float* tgt_logit, float* lse, float* tok_nll, float* stats,
                                  void* stream) {
   using namespace vmmt;
-  if (!W || !bias || !O || !y || !part_max || !part_sum || !part_idx || !tgt_logit || !lse || !tok_nll || !stats ||
+  if (!W || !bias || !O || !y || !part_max || !part_sum || !tgt_logit || !lse || !tok_nll || !stats ||
       M <= 0 || V <= 0 || K <= 0)
     return VMMT_EINVAL;
   GenArgs a{};
@@ -987,10 +581,11 @@ extern "C" int vmmt_rowsum(int dtype, const void* X, int64_t ld, int R, int C, f
 // (saves re-reading G^T), otherwise one vmmt_rowsum launch behind the gradient pass.
 extern "C" int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo,
                                     const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm,
-                                    void* GT, int64_t ldgt, float* dbias, void* stream) {
+                                    void* GT, int64_t ldgt, float* dbias, int v_off, void* stream) {
   using namespace vmmt;
-  if (!W || !bias || !O || !y || !lse || !GT || !dbias || M <= 0 || V <= 0 || K <= 0 || ldgt < M) return VMMT_EINVAL;
+  if (!W || !bias || !O || !y || !lse || !GT || !dbias || M <= 0 || V <= 0 || K <= 0 || ldgt < M || v_off < 0) return VMMT_EINVAL;
   GenArgs a{};
+  a.v_off = v_off;
   a.W = W; a.ldw = ldw; a.bias = bias; a.O = O; a.ldo = ldo; a.y = (const long long*)y; a.M = M; a.V = V; a.K = K;
   a.pad = pad; a.lse = lse; a.inv_norm = inv_norm; a.GT = GT; a.ldgt = ldgt;
   hipStream_t st = (hipStream_t)stream;

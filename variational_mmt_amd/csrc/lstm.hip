@@ -489,7 +489,6 @@ static void fill_b(StepDirB& o, const vmmt_lstm_dir_bwd& i) {
 
 }  // namespace vmmt
 
-extern "C" int vmmt_lstm_set_variant(int v) { (void)v; return VMMT_OK; }   // no variants at present
 
 extern "C" int vmmt_lstm_step_fwd(int dtype, int ndir, const vmmt_lstm_dir_fwd* dirs, const int64_t* lens, int B,
                                   int H, void* stream) {

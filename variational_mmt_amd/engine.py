@@ -621,7 +621,6 @@ class Workspace(object):
         self.npart = eng.lib.vmmt_gen_npart(V)
         self.part_max = torch.zeros(self.npart * M, dtype=f32, device=dev)
         self.part_sum = torch.zeros(self.npart * M, dtype=f32, device=dev)
-        self.part_idx = torch.zeros(self.npart * M, dtype=torch.int32, device=dev)
         self.tgt_logit = torch.zeros(M, dtype=f32, device=dev)
         self.lse = torch.zeros(M, dtype=f32, device=dev)
         self.tok_nll = torch.zeros(M, dtype=f32, device=dev)
@@ -879,7 +878,7 @@ class Workspace(object):
         wg = e.sh["wg"]
         O = self.O if (training and d.dropout > 0) else self.AH      # eval: nn.Dropout is the identity
         e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(),
-                self.M, d.vt, _ru(d.hid, KPAD), PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), self.part_idx.data_ptr(),
+                self.M, d.vt, _ru(d.hid, KPAD), PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), None,
                 self.tgt_logit.data_ptr(), self.lse.data_ptr(), self.tok_nll.data_ptr(), self.stats.data_ptr())
         return P
 
@@ -905,10 +904,12 @@ class Workspace(object):
         fuse_db = _os_env.get("VMMT_FUSE_DB", "1") == "1"
         # entries that carry run-time scalars (1 / normalization, KL weights): patched per step by backward_plan(), so that
         # token normalisation (a different value every batch) does not rebuild the plan
+        # (walking the vocabulary in 2-6 chunks, so that a chunk of G^T is consumed by dO / dWg while it is still in the Infinity
+        #  Cache, was measured with tools/ab.py: 2.227-2.97 ms against 2.213 ms in one pass -- not kept)
         self._patch = {"gen": (len(P), 12)}
         if fuse_db:
             e._call(P, lib.vmmt_gen_loss_bwd_db, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
-                    M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld, e.gp("generator.0.bias"))
+                    M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld, e.gp("generator.0.bias"), 0)
         else:
             e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
                     M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
