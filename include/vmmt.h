@@ -214,6 +214,25 @@ int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bia
                          const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm, void* GT,
                          int64_t ldgt, float* dbias, int v_off, void* stream);
 
+/* ---- the same loss and BOTH of its gradients without G^T (csrc/generator_fused.hip; bf16, K = 512 or 256) --------
+ * Two flash-attention-shaped passes replace vmmt_gen_loss_fwd + vmmt_gen_loss_bwd_db + the two G^T GEMMs of the training step:
+ *   vmmt_gen_fwd_dO : softmax statistics AND dO = dL/dO in one sweep of Wg per 128-token block (the vocabulary is cut into
+ *                     vmmt-chosen slices whose partial sums a combine kernel folds).  Outputs: lse, tok_nll, tgt_logit f32 [M];
+ *                     stats[NLL,NWORDS,NCORRECT] += sums; dO f32 [M][lddo] = s_m (softmax_m Wg - Wg[y_m]), s_m = [y_m != pad] inv_norm;
+ *                     nl f32 / y32 int32 [(M+31)/32*32]: per-token constants of the second pass (ln s_m - lse_m, -inf at pads and
+ *                     beyond M; target id, -1 there).  ws: vmmt_gen_fused_ws_floats(M, V, K) floats of scratch.
+ *   vmmt_gen_dW     : dWg f32 [V][lddw] (plain store) and dbias f32 [V] (+=) in one sweep of O per 128 vocabulary rows, from
+ *                     nl / y32 of the first pass.
+ * vmmt_gen_fused_applies() tells whether the shape is served (otherwise both return VMMT_EINVAL and the caller uses the
+ * G^T path above).  Reference: the same lines as above (ModelConstructor.py:583-585, Loss.py:129,163-165). */
+int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M, int V, int K);
+int64_t vmmt_gen_fused_ws_floats(int M, int V, int K);
+int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, const int64_t* y,
+                    int M, int V, int K, int pad, float inv_norm, float* ws, float* tgt_logit, float* lse, float* tok_nll,
+                    float* nl, int* y32, float* dO, int64_t lddo, float* stats, void* stream);
+int vmmt_gen_dW(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, int M, int V, int K,
+                const float* nl, const int* y32, float inv_norm, float* dW, int64_t lddw, float* dbias, void* stream);
+
 /* ---- row gathers / small fused kernels -------------------------------------------------------------------------- */
 /* out[r][0:D] = table[ids[r]][0:D]; table f32 (embedding master weights: modules/Embeddings.py:181; or the HBM-resident
  * image-feature table: TrainerMultimodal.py:632-639), out f32 or bf16 per out_dtype. */

@@ -18,9 +18,10 @@ def _setup():
     return c, p, bt
 
 
-def _run(c, p, bt, dtype):
+def _run(c, p, bt, dtype, gen_fused=True):
     from variational_mmt_amd.engine import Dims, Engine
     e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype=dtype, device="cuda:0")
+    e.gen_fused = gen_fused            # False: the G^T path of csrc/generator.hip also where the fused passes would apply
     e.load_state_dict(p)
     e.set_image_table(bt["table"])
     ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
@@ -65,7 +66,22 @@ def test_full_size_parity_and_properties():
     n32, n16 = g32.norm().item(), g16.norm().item()
     assert abs(n16 - n32) <= 1e-2 * n32
     assert ((g16 - g32).norm() / g32.norm()).item() <= 2e-2        # whole-arena gradient, relative L2
-    G16 = ws16.GT.view()[:, :M]
+    # the bf16 step ran the fused generator passes (csrc/generator_fused.hip: no G^T): dL/dO is exactly zero at <blank> targets, and the
+    # bias gradient -- the token sum of the softmax-gradient rows, each of which sums to zero over the vocabulary -- adds up to zero
+    assert ws16.gen_fused and ws16.GT is None
+    dO = ws16.dO32.view()[:M]
+    assert (dO[(~nonpad).cuda()] == 0).all() and dO[nonpad.cuda()].abs().max().item() > 0
+    db = e16.grads["generator.0.bias"].double()
+    assert abs(db.sum().item()) <= 1e-3 * db.abs().sum().item()
+    # ... against the G^T path on the same step: same statistics, same gradients up to the bf16 rounding of the softmax weights
+    e16u, ws16u, s16u = _run(c, p, bt, "bf16", gen_fused=False)
+    assert not ws16u.gen_fused
+    for k in ("nmt", "elbo"):
+        assert abs(s16u[k] - s16[k]) <= 1e-5 * abs(s16[k]), (k, s16u[k], s16[k])
+    assert s16u["n_words"] == s16["n_words"] and abs(s16u["n_correct"] - s16["n_correct"]) <= 1
+    g16u = e16u.flat_g[:e16u.n_opt].double()
+    assert ((g16 - g16u).norm() / g16u.norm()).item() <= 1e-2
+    G16 = ws16u.GT.view()[:, :M]
     assert G16.float().sum(0).abs().max().item() <= 3e-4           # bf16 storage of G^T
     assert (G16[:, (~nonpad).cuda()] == 0).all()
     # ---- run-to-run: same inputs, same statistics up to the order of float atomics

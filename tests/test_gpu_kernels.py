@@ -268,3 +268,64 @@ def test_generator_kernel_bf16(M, V, H):
             assert (db3 - db).abs().max().item() <= 1e-5 + 1e-5 * ref_db.abs().max().item(), v       # f32 atomics: order of the token tiles
     for k in range(3):
         assert torch.equal(outs[True][k], outs[False][k]), k                      # with / without the index: same arithmetic, same bits
+
+
+@pytest.mark.parametrize("M,V,H,ramp", [(5120, 3000, 512, 0.0), (200, 1000, 256, 0.0), (37, 515, 512, 0.0), (264, 130, 256, 0.0),
+                                        (300, 2100, 512, 0.09), (8, 67, 256, 0.0)])
+def test_generator_fused_passes_bf16(M, V, H, ramp):
+    """csrc/generator_fused.hip: vmmt_gen_fwd_dO (softmax statistics + dL/dO in one sweep of Wg) and vmmt_gen_dW (dL/dWg, dL/db in one
+    sweep of O) against fp64 math on the same bf16-rounded operands, and against the G^T path of generator.hip.  `ramp` adds a bias that
+    grows by `ramp` per vocabulary row (190 over 2100 rows): the lazy softmax reference of the forward sweep has to move -- and rescale
+    its accumulators -- several times inside one vocabulary slice."""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(M * 7 + V)
+    T = torch.bfloat16
+    assert lib.vmmt_gen_fused_applies(L.BF16, H, H, M, V, H) == 1
+    W = torch.zeros(V + 256, H, dtype=T)
+    W[:V] = (torch.randn(V, H, generator=g) * 0.3).to(T)
+    O = (torch.randn(M, H, generator=g) * 0.5).to(T)
+    bias = torch.randn(V, generator=g) * 0.2 + ramp * torch.arange(V).float()
+    y = torch.randint(0, V, (M,), generator=g)
+    y[::5] = 1                                                     # pad targets carry no loss
+    y[1], y[2], y[3] = V - 1, 0, min(V - 1, 127)
+    logits = O.double() @ W[:V].double().t() + bias.double()
+    lse_ref = torch.logsumexp(logits, 1)
+    w = (y != 1).double()
+    nll_ref = (lse_ref - logits.gather(1, y.view(-1, 1)).view(-1)) * w
+    inv_norm = 1.0 / 7.0
+    G_ref = (torch.softmax(logits, 1) - torch.nn.functional.one_hot(y, V).double()) * (w * inv_norm).view(-1, 1)
+    dO_ref = G_ref @ W[:V].double()
+    dW_ref = G_ref.t() @ O.double()
+    db_ref = G_ref.sum(0)
+    Wd, Od, bd, yd = W.cuda(), O.cuda(), bias.cuda(), y.cuda()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    ws = torch.zeros(lib.vmmt_gen_fused_ws_floats(M, V, H), device="cuda")
+    Mp = (M + 31) // 32 * 32
+    tl = torch.zeros(M, device="cuda"); lse = torch.zeros(M, device="cuda"); nll = torch.zeros(M, device="cuda")
+    nl = torch.zeros(Mp, device="cuda"); y32 = torch.zeros(Mp, device="cuda", dtype=torch.int32)
+    dO = torch.full((M, H + 4), 7.0, device="cuda"); st = torch.zeros(8, device="cuda")
+    L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, P(bd), P(Od), H, P(yd), M, V, H, 1, inv_norm, P(ws), P(tl), P(lse), P(nll), P(nl), P(y32),
+                                P(dO), H + 4, P(st), None), "gen fwd dO")
+    dW = torch.full((V + 3, H), 7.0, device="cuda"); db = torch.full((V,), 0.5, device="cuda")
+    L.check(lib.vmmt_gen_dW(L.BF16, P(Wd), H, P(bd), P(Od), H, M, V, H, P(nl), P(y32), inv_norm, P(dW), H, P(db), None), "gen dW")
+    torch.cuda.synchronize()
+    assert (lse.cpu().double() - lse_ref).abs().max().item() <= 2e-4 * max(1.0, lse_ref.abs().max().item())
+    assert (nll.cpu().double() - nll_ref).abs().max().item() <= 5e-4 * max(1.0, nll_ref.abs().max().item())
+    s = st.cpu()
+    assert abs(s[L.STAT_NLL].item() - nll_ref.sum().item()) <= 1e-4 * abs(nll_ref.sum().item()) + 1e-3
+    assert int(round(s[L.STAT_NWORDS].item())) == int(w.sum().item())
+    correct = ((logits.argmax(1) == y) & (y != 1)).sum().item()
+    assert abs(int(round(s[L.STAT_NCORRECT].item())) - correct) <= 1
+    assert (dO[:, H:] == 7.0).all() and (dW[V:] == 7.0).all()                      # nothing outside the outputs is written
+    # the softmax weights enter the second MFMA product as bf16 (2^-9 relative each, as the stored G^T of the unfused path does)
+    sc = inv_norm
+    e1 = (dO[:, :H].cpu().double() - dO_ref).abs().max().item()
+    assert e1 <= 6e-3 * sc * max(1.0, W[:V].float().abs().max().item()), e1
+    e2 = (dW[:V].cpu().double() - dW_ref).norm().item() / max(1e-30, dW_ref.norm().item())
+    assert e2 <= 4e-3, e2
+    e2m = (dW[:V].cpu().double() - dW_ref).abs().max().item()
+    assert e2m <= 2e-2 * sc * max(1.0, O.float().abs().max().item()) * max(1.0, (M / 256.0) ** 0.5), e2m
+    e3 = (db.cpu().double() - 0.5 - db_ref).abs().max().item()
+    assert e3 <= 4e-3 * sc * max(1.0, (M / 256.0) ** 0.5), e3
+    assert torch.isinf(nl[M:]).all() and (y32[M:] == -1).all() and (y32[:M].cpu() == torch.where(y == 1, -1, y).int()).all()

@@ -14,7 +14,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.j
          "-Wno-unused-result"]
 # gemm.hip is compiled three times, one operand layout per object (see the note at the end of that file)
 GEMM_PARTS = 3
-SOURCES = ["lstm.hip", "lstm_seq.hip", "qnet.hip", "attention.hip", "generator.hip", "elementwise.hip", "optim.hip", "runtime.hip", "conditional.hip", "table.hip", "beam.hip"]
+SOURCES = ["lstm.hip", "lstm_seq.hip", "qnet.hip", "attention.hip", "generator.hip", "generator_fused.hip", "elementwise.hip", "optim.hip", "runtime.hip", "conditional.hip", "table.hip", "beam.hip"]
 
 
 def _stale(out, deps):

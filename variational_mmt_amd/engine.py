@@ -179,6 +179,7 @@ class Engine(object):
         self.fused_qnet = _os_env.get("VMMT_FUSED_QNET", "1") == "1"
         self.defer_bg_adam = _os_env.get("VMMT_DEFER_BG_ADAM", "1") == "1"   # see optim_step(defer=True)
         self._pending_bg = None
+        self.gen_fused = _os_env.get("VMMT_GEN_FUSED", "1") == "1"       # csrc/generator_fused.hip where it applies (bf16, H = 512 / 256)
         self.persistent_lstm = _os_env.get("VMMT_PERSISTENT_LSTM", "1") == "1"     # plans are built per workspace: set before the first forward
         self.seq_syncs = []
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
@@ -628,8 +629,19 @@ class Workspace(object):
         # G^T [V][T'B] is the largest buffer of a step (307 MB at B 256 / V 30 000 / T' 20): ONE allocation shared by all
         # workspaces.  Leftovers of another shape are harmless: it is fully rewritten for columns < M by the generator backward
         # before anything reads it, and its padding only ever meets the zero padding of O (dW_g, K = M) or of W_g (dO, K = V).
-        self.GT = Buf(V, M, T, dev, storage=eng.shared_storage("GT", Buf.elems(V, M), T))
+        # Fused generator passes (csrc/generator_fused.hip) where they apply: the statistics pass also produces dO, a second pass
+        # dWg / db, and G^T is never formed.  Otherwise the G^T path of csrc/generator.hip.
         self.dO32 = nb(M, H, f32)
+        wg_ld = eng.sh["wg"].ld
+        self.gen_fused = bool(eng.gen_fused and eng.lib.vmmt_gen_fused_applies(eng.dt, wg_ld, self.O.ld, M, V, _ru(H, KPAD)))
+        if self.gen_fused:
+            nws = int(eng.lib.vmmt_gen_fused_ws_floats(M, V, _ru(H, KPAD)))
+            self.gen_ws = eng.shared_storage("gen_ws", nws, f32)          # vocabulary-slice partials: shared by all workspaces
+            self.gen_nl = torch.zeros(_ru(M, 32), dtype=f32, device=dev)
+            self.gen_y32 = torch.zeros(_ru(M, 32), dtype=torch.int32, device=dev)
+            self.GT = None
+        else:
+            self.GT = Buf(V, M, T, dev, storage=eng.shared_storage("GT", Buf.elems(V, M), T))
         self.dPre = nb(M, H)
         self.dcat = nb(M, 2 * H)
         self.dQ = nb(M, H)
@@ -681,7 +693,8 @@ class Workspace(object):
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             # ... together with the small accumulators of the backward plan (off the critical path instead of in front of
             # their users): one launch
-            e._zero(P, [e.flat_g[e.offsets["generator.0.bias"][0]:], e._sumsq[:L.SUMSQ_SLOTS], self.dO32.t, self.dh1v32.t, self.dzt.t] +
+            e._zero(P, [e.flat_g[e.offsets["generator.0.bias"][0]:], e._sumsq[:L.SUMSQ_SLOTS], self.dh1v32.t, self.dzt.t] +
+                    ([] if self.gen_fused else [self.dO32.t]) +       # (fused generator: dO is stored, not accumulated)
                     [b.t for l in range(Lyr) for b in (self.dec_dcc[l], self.enc_dcc[l])])
         self._mask_entries = getattr(self, "_mask_entries", {})
         if drop:
@@ -877,6 +890,17 @@ class Workspace(object):
         P = []
         wg = e.sh["wg"]
         O = self.O if (training and d.dropout > 0) else self.AH      # eval: nn.Dropout is the identity
+        if training:
+            self._loss_patch = None
+        if training and self.gen_fused:
+            # statistics AND dO = dL/dO in one sweep of Wg (1 / normalization is patched in by loss_backward: argument 11)
+            assert O.ld == _ru(d.hid, KPAD)
+            self._loss_patch = (len(P), 11)
+            e._call(P, lib.vmmt_gen_fwd_dO, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(), self.M, d.vt,
+                    _ru(d.hid, KPAD), PAD, 0.0, self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.lse.data_ptr(),
+                    self.tok_nll.data_ptr(), self.gen_nl.data_ptr(), self.gen_y32.data_ptr(), self.dO32.p(), self.dO32.ld,
+                    self.stats.data_ptr())
+            return P
         e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(),
                 self.M, d.vt, _ru(d.hid, KPAD), PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), None,
                 self.tgt_logit.data_ptr(), self.lse.data_ptr(), self.tok_nll.data_ptr(), self.stats.data_ptr())
@@ -906,16 +930,21 @@ class Workspace(object):
         # token normalisation (a different value every batch) does not rebuild the plan
         # (walking the vocabulary in 2-6 chunks, so that a chunk of G^T is consumed by dO / dWg while it is still in the Infinity
         #  Cache, was measured with tools/ab.py: 2.227-2.97 ms against 2.213 ms in one pass -- not kept)
-        self._patch = {"gen": (len(P), 12)}
-        if fuse_db:
+        self._patch = {}
+        if self.gen_fused:
+            pass        # dO32 came out of the loss plan (vmmt_gen_fwd_dO); dWg / db: one pass on the side stream below
+        elif fuse_db:
+            self._patch["gen"] = (len(P), 12)
             e._call(P, lib.vmmt_gen_loss_bwd_db, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
                     M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld, e.gp("generator.0.bias"), 0)
         else:
+            self._patch["gen"] = (len(P), 12)
             e._call(P, lib.vmmt_gen_loss_bwd, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
                     M, V, _ru(H, KPAD), PAD, self.lse.data_ptr(), inv_norm, self.GT.p(), self.GT.ld)
-        e._record(P, "GT")
-        e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
-                split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))))
+        if not self.gen_fused:
+            e._record(P, "GT")
+            e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
+                    split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))))
         # ================= aux: image term + its network (z is detached: independent of the text path) ==========
         e._sid = AUX
         e._wait(P, "bwd_begin")
@@ -985,10 +1014,16 @@ class Workspace(object):
         # underneath the LSTM backward chains instead, is 3 % slower -- 2.333 vs 2.264 ms)
         e._sid = SIDE
         e._wait(P, "bwd_begin")
-        e._wait(P, "GT")
-        e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1)   # plain store
-        if not fuse_db:
-            e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
+        if self.gen_fused:
+            Og = self.O if (training_dropout and d.dropout > 0) else self.AH
+            self._patch["gen"] = (len(P), 11)
+            e._call(P, lib.vmmt_gen_dW, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), Og.p(), Og.ld, M, V, _ru(H, KPAD),
+                    self.gen_nl.data_ptr(), self.gen_y32.data_ptr(), inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"))
+        else:
+            e._wait(P, "GT")
+            e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1)   # plain store
+            if not fuse_db:
+                e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
         e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
         # main: dropout + tanh backward, linear_out
         e._sid = MAIN
@@ -1512,6 +1547,10 @@ def _engine_methods():
         # the gradient arena was zeroed by the training forward plan (side stream); zero_grad=False is meaningless here
         if not ws.training:
             raise RuntimeError("loss_backward() after an eval-mode forward")
+        if ws._loss_patch is not None:          # fused generator: the statistics pass writes dO = dL/dO scaled by 1 / normalization
+            ii, pos = ws._loss_patch
+            fn, args, name, keep, sid = ws.plan_loss_train[ii]
+            ws.plan_loss_train[ii] = (fn, args[:pos] + (float(1.0 / norm),) + args[pos + 1:], name, keep, sid)
         self._run(ws.plan_loss_train, ws.events)
         plan = ws.backward_plan(1.0 / norm, bg, kl_mult, use_freebits, margin, bool(ws.training))
         self._cur_ws = ws
