@@ -276,7 +276,7 @@ def main():
         step(0)                   # the backward plan is built by the first step
     # backward plan exists now: hook the gen_loss_bwd entry
     for j, (fn, args, name, keep, sid) in enumerate(ws0.plan_bwd):
-        if name in ("vmmt_gen_loss_bwd", "vmmt_gen_loss_bwd_db", "vmmt_gen_dW"):
+        if name in ("vmmt_gen_loss_bwd", "vmmt_gen_loss_bwd_db"):
             wrap(ws0.plan_bwd, j, "gen_bwd")
     torch.cuda.synchronize()
     if dist is not None:
@@ -306,8 +306,8 @@ def main():
         # dominant kernel = the fused vocabulary projection (+log-softmax+NLL) GEMM passes: 2*M*V*H FLOP per launch
         M = Tp * B
         fused = bool(getattr(ws0, "gen_fused", False))
-        # per launch: one [M x V x H] product in the G^T path (generator.hip), two in the fused passes (generator_fused.hip:
-        # logits + dO in the forward sweep, logits + dWg in the backward sweep)
+        # per launch: one [M x V x H] product in the G^T path (generator.hip), two in the fused sweep (generator_fused.hip:
+        # logits + dO; its time includes the combine kernel behind it)
         gen_flop = (4.0 if fused else 2.0) * M * d.vt * d.hid
         # per step: the backward pass may walk the vocabulary in several launches (Engine.gen_chunks); their times add up
         t_f = sum(s.elapsed_time(e_) for s, e_ in dom["gen_fwd"]) / max(1, a.steps)      # ms (fwd incl. combine)
@@ -327,7 +327,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (cf["name"] % B) + ", dropout %.1f, Adam%s" % (a.dropout, ", --conditional prior" if a.conditional else ""),
                        "global_batch": Bg, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": ("gen2_kernel (fused vocabulary passes: logits + softmax + dO / dWg, slower of the two sweeps)" if fused else
+            "roofline": {"bound": "mfma", "kernel": ("gen2_kernel (fused vocabulary sweep: logits + softmax statistics + dO, softmax weights stored for the dWg GEMM)" if fused else
                                     "gen_kernel (vocab projection + log-softmax/NLL pass, slower of fwd/bwd)"),
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,

@@ -78,6 +78,9 @@ typedef struct vmmt_gemm_args {
   int split_k; /* > 1: the reduction is split over this many workgroups per tile which atomicAdd fp32 partial sums into C
                   (out_f32 = 1, act = NONE; C must hold zeros or a partial sum) -- for weight gradients dW = dY^T X whose
                   reduction runs over thousands of tokens while the output is small */
+  int b_batch_rows; int64_t b_batch_stride; /* b_batch_rows > 0 (a multiple of 256): output rows [i r, (i + 1) r) use the B operand
+                  at B + i * b_batch_stride elements -- one launch for row blocks that share A's layout but not B (the generator's
+                  weight gradient: one scaled copy of the decoder outputs per vocabulary slice) */
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
 
@@ -214,24 +217,30 @@ int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bia
                          const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm, void* GT,
                          int64_t ldgt, float* dbias, int v_off, void* stream);
 
-/* ---- the same loss and BOTH of its gradients without G^T (csrc/generator_fused.hip; bf16, K = 512 or 256) --------
- * Two flash-attention-shaped passes replace vmmt_gen_loss_fwd + vmmt_gen_loss_bwd_db + the two G^T GEMMs of the training step:
- *   vmmt_gen_fwd_dO : softmax statistics AND dO = dL/dO in one sweep of Wg per 128-token block (the vocabulary is cut into
- *                     vmmt-chosen slices whose partial sums a combine kernel folds).  Outputs: lse, tok_nll, tgt_logit f32 [M];
- *                     stats[NLL,NWORDS,NCORRECT] += sums; dO f32 [M][lddo] = s_m (softmax_m Wg - Wg[y_m]), s_m = [y_m != pad] inv_norm;
- *                     nl f32 / y32 int32 [(M+31)/32*32]: per-token constants of the second pass (ln s_m - lse_m, -inf at pads and
- *                     beyond M; target id, -1 there).  ws: vmmt_gen_fused_ws_floats(M, V, K) floats of scratch.
- *   vmmt_gen_dW     : dWg f32 [V][lddw] (plain store) and dbias f32 [V] (+=) in one sweep of O per 128 vocabulary rows, from
- *                     nl / y32 of the first pass.
- * vmmt_gen_fused_applies() tells whether the shape is served (otherwise both return VMMT_EINVAL and the caller uses the
- * G^T path above).  Reference: the same lines as above (ModelConstructor.py:583-585, Loss.py:129,163-165). */
+/* ---- the same loss with dL/dO in ONE sweep of Wg (csrc/generator_fused.hip; bf16, K = 512 or 256) --------------------
+ * vmmt_gen_fwd_dO replaces vmmt_gen_loss_fwd + vmmt_gen_loss_bwd_db + the dO GEMM of the training step: per 128-token block and
+ * vocabulary slice (vmmt-chosen: vmmt_gen_fused_geometry) a flash-attention-shaped sweep accumulates the softmax statistics and
+ * the un-normalised dO; a combine kernel folds the slices.
+ *   out: lse, tok_nll, tgt_logit f32 [M]; stats[NLL,NWORDS,NCORRECT] += sums; dO f32 [M][lddo] = s_m (softmax_m Wg - Wg[y_m]),
+ *        s_m = [y_m != pad] inv_norm; y32 int32 [(M+31)/32*32]: targets, -1 at pads and beyond M.
+ *   ws : vmmt_gen_fused_ws_floats(M, V, K) floats of scratch.
+ * For dL/dWg it also stores (P != NULL; the training step always asks for them)
+ *   P   T [M][ldp]  (ldp >= V rounded up to 32): un-normalised softmax weights exp(logit - ref_s[m]) of slice s = v / v_per_split;
+ *   cs  f32 [nsplit][mpad]: c_s[m] = s_m exp(ref_s[m] - lse_m), so that dL/dlogit[m][v] = P[m][v] c_s[m] - [v == y_m] s_m;
+ *   Os  T [nsplit][os_stride]: O'_s[m][:] = c_s[m] O[m][:] (rows ld ldos; rows >= M are never written: keep them zero),
+ * so that dWg[v in slice s][:] = sum_m P[m][v] O'_s[m][:] is ONE vmmt_gemm (GEMM_TN, K = M, b_batch_rows = v_per_split,
+ * b_batch_stride = os_stride, plain store) and vmmt_gen_dW_finish adds the bias gradient and the one-hot term.
+ * vmmt_gen_fused_applies() tells whether the shape is served (otherwise VMMT_EINVAL: the caller uses the G^T path above).
+ * Reference: the same lines as above (ModelConstructor.py:583-585, Loss.py:129,163-165). */
 int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M, int V, int K);
 int64_t vmmt_gen_fused_ws_floats(int M, int V, int K);
+int vmmt_gen_fused_geometry(int M, int V, int* nsplit, int* v_per_split, int64_t* mpad);
 int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, const int64_t* y,
                     int M, int V, int K, int pad, float inv_norm, float* ws, float* tgt_logit, float* lse, float* tok_nll,
-                    float* nl, int* y32, float* dO, int64_t lddo, float* stats, void* stream);
-int vmmt_gen_dW(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, int M, int V, int K,
-                const float* nl, const int* y32, float inv_norm, float* dW, int64_t lddw, float* dbias, void* stream);
+                    int* y32, float* dO, int64_t lddo, float* stats, void* P, int64_t ldp, float* cs, void* Os,
+                    int64_t ldos, int64_t os_stride, void* stream);
+int vmmt_gen_dW_finish(int dtype, const void* P, int64_t ldp, const float* cs, const void* O, int64_t ldo, const int* y32, int M, int V,
+                       int K, float inv_norm, float* dW, int64_t lddw, float* dbias, void* stream);
 
 /* ---- row gathers / small fused kernels -------------------------------------------------------------------------- */
 /* out[r][0:D] = table[ids[r]][0:D]; table f32 (embedding master weights: modules/Embeddings.py:181; or the HBM-resident

@@ -272,11 +272,12 @@ def test_generator_kernel_bf16(M, V, H):
 
 @pytest.mark.parametrize("M,V,H,ramp", [(5120, 3000, 512, 0.0), (200, 1000, 256, 0.0), (37, 515, 512, 0.0), (264, 130, 256, 0.0),
                                         (300, 2100, 512, 0.09), (8, 67, 256, 0.0)])
-def test_generator_fused_passes_bf16(M, V, H, ramp):
-    """csrc/generator_fused.hip: vmmt_gen_fwd_dO (softmax statistics + dL/dO in one sweep of Wg) and vmmt_gen_dW (dL/dWg, dL/db in one
-    sweep of O) against fp64 math on the same bf16-rounded operands, and against the G^T path of generator.hip.  `ramp` adds a bias that
-    grows by `ramp` per vocabulary row (190 over 2100 rows): the lazy softmax reference of the forward sweep has to move -- and rescale
-    its accumulators -- several times inside one vocabulary slice."""
+def test_generator_fused_pass_bf16(M, V, H, ramp):
+    """csrc/generator_fused.hip: vmmt_gen_fwd_dO (softmax statistics + dL/dO in one sweep of Wg, softmax weights P stored on the way),
+    dL/dWg as the per-slice product of P with the scaled decoder outputs O'_s, and vmmt_gen_dW_finish (dL/db, one-hot term) against fp64
+    math on the same bf16-rounded operands.  `ramp` adds a bias that grows by `ramp` per vocabulary row (190 over 2100 rows): the lazy
+    softmax reference of the sweep has to move -- rescale its accumulators and rewrite the P it has stored -- several times inside one
+    vocabulary slice."""
     from variational_mmt_amd import _lib as L
     lib = L.lib()
     g = torch.Generator().manual_seed(M * 7 + V)
@@ -303,12 +304,19 @@ def test_generator_fused_passes_bf16(M, V, H, ramp):
     ws = torch.zeros(lib.vmmt_gen_fused_ws_floats(M, V, H), device="cuda")
     Mp = (M + 31) // 32 * 32
     tl = torch.zeros(M, device="cuda"); lse = torch.zeros(M, device="cuda"); nll = torch.zeros(M, device="cuda")
-    nl = torch.zeros(Mp, device="cuda"); y32 = torch.zeros(Mp, device="cuda", dtype=torch.int32)
+    y32 = torch.zeros(Mp, device="cuda", dtype=torch.int32)
     dO = torch.full((M, H + 4), 7.0, device="cuda"); st = torch.zeros(8, device="cuda")
-    L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, P(bd), P(Od), H, P(yd), M, V, H, 1, inv_norm, P(ws), P(tl), P(lse), P(nll), P(nl), P(y32),
-                                P(dO), H + 4, P(st), None), "gen fwd dO")
-    dW = torch.full((V + 3, H), 7.0, device="cuda"); db = torch.full((V,), 0.5, device="cuda")
-    L.check(lib.vmmt_gen_dW(L.BF16, P(Wd), H, P(bd), P(Od), H, M, V, H, P(nl), P(y32), inv_norm, P(dW), H, P(db), None), "gen dW")
+    sc = inv_norm
+    ns, vps, mpad = C.c_int(), C.c_int(), C.c_int64()
+    L.check(lib.vmmt_gen_fused_geometry(M, V, C.byref(ns), C.byref(vps), C.byref(mpad)), "geometry")
+    ns, vps, mpad = ns.value, vps.value, mpad.value
+    ldp = (V + 31) // 32 * 32 + 32
+    Pw = torch.full((M + 2, ldp), 3.0, device="cuda", dtype=T)
+    cs = torch.zeros(ns, mpad, device="cuda")
+    Mk = (M + 63) // 64 * 64
+    Os = torch.zeros(ns, Mk, H, device="cuda", dtype=T)
+    L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, P(bd), P(Od), H, P(yd), M, V, H, 1, inv_norm, P(ws), P(tl), P(lse), P(nll), P(y32),
+                                P(dO), H + 4, P(st), P(Pw), ldp, P(cs), P(Os), H, Mk * H, None), "gen fwd dO")
     torch.cuda.synchronize()
     assert (lse.cpu().double() - lse_ref).abs().max().item() <= 2e-4 * max(1.0, lse_ref.abs().max().item())
     assert (nll.cpu().double() - nll_ref).abs().max().item() <= 5e-4 * max(1.0, nll_ref.abs().max().item())
@@ -317,15 +325,47 @@ def test_generator_fused_passes_bf16(M, V, H, ramp):
     assert int(round(s[L.STAT_NWORDS].item())) == int(w.sum().item())
     correct = ((logits.argmax(1) == y) & (y != 1)).sum().item()
     assert abs(int(round(s[L.STAT_NCORRECT].item())) - correct) <= 1
-    assert (dO[:, H:] == 7.0).all() and (dW[V:] == 7.0).all()                      # nothing outside the outputs is written
+    assert (dO[:, H:] == 7.0).all()                                                # nothing outside the outputs is written
     # the softmax weights enter the second MFMA product as bf16 (2^-9 relative each, as the stored G^T of the unfused path does)
-    sc = inv_norm
     e1 = (dO[:, :H].cpu().double() - dO_ref).abs().max().item()
     assert e1 <= 6e-3 * sc * max(1.0, W[:V].float().abs().max().item()), e1
-    e2 = (dW[:V].cpu().double() - dW_ref).norm().item() / max(1e-30, dW_ref.norm().item())
-    assert e2 <= 4e-3, e2
-    e2m = (dW[:V].cpu().double() - dW_ref).abs().max().item()
-    assert e2m <= 2e-2 * sc * max(1.0, O.float().abs().max().item()) * max(1.0, (M / 256.0) ** 0.5), e2m
-    e3 = (db.cpu().double() - 0.5 - db_ref).abs().max().item()
-    assert e3 <= 4e-3 * sc * max(1.0, (M / 256.0) ** 0.5), e3
-    assert torch.isinf(nl[M:]).all() and (y32[M:] == -1).all() and (y32[:M].cpu() == torch.where(y == 1, -1, y).int()).all()
+    assert (y32[M:] == -1).all() and (y32[:M].cpu() == torch.where(y == 1, -1, y).int()).all()
+    assert (Pw[M:] == 3.0).all() and (Pw[:, (V + 31) // 32 * 32:] == 3.0).all() and (Os[:, M:] == 0).all()
+    dW2 = torch.empty(V, H, device="cuda")
+    for s_ in range(ns):
+        v0, v1 = s_ * vps, min(V, (s_ + 1) * vps)
+        if v0 < v1:
+            dW2[v0:v1] = Pw[:M, v0:v1].float().t() @ Os[s_, :M].float()
+    db2 = torch.full((V,), 0.5, device="cuda")
+    L.check(lib.vmmt_gen_dW_finish(L.BF16, P(Pw), ldp, P(cs), P(Od), H, P(y32), M, V, H, inv_norm, P(dW2), H, P(db2), None), "dW finish")
+    torch.cuda.synchronize()
+    e4 = (dW2.cpu().double() - dW_ref).norm().item() / max(1e-30, dW_ref.norm().item())
+    assert e4 <= 6e-3, e4
+    e4m = (dW2.cpu().double() - dW_ref).abs().max().item()
+    assert e4m <= 2e-2 * sc * max(1.0, O.float().abs().max().item()) * max(1.0, (M / 256.0) ** 0.5), e4m
+    e5 = (db2.cpu().double() - 0.5 - db_ref).abs().max().item()
+    assert e5 <= 4e-3 * max(sc * max(1.0, (M / 256.0) ** 0.5), db_ref.abs().max().item()), e5     # P is rounded to bf16 before the token sum
+
+
+def test_gemm_per_row_block_b_operand():
+    """vmmt_gemm_args.b_batch_rows: output rows [i r, (i + 1) r) multiply with the B operand at B + i * b_batch_stride (the generator's
+    weight gradient: one scaled copy of the decoder outputs per vocabulary slice) -- against one torch product per block."""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(3)
+    T = torch.bfloat16
+    Mr, N, K, r, nb = 1100, 512, 640, 512, 3                      # rows, columns, reduction, rows per block, blocks
+    At = (torch.randn(K, Mr + 4, generator=g) * 0.5).to(T).cuda()          # A^T as stored (GEMM_TN): [K][lda]
+    Bs = (torch.randn(nb, K, N, generator=g) * 0.5).to(T).cuda()
+    Cd = torch.full((Mr, N), 9.0, device="cuda")
+    a = L.GemmArgs(L.BF16, L.GEMM_TN, At.data_ptr(), Mr + 4, Bs.data_ptr(), N, Cd.data_ptr(), N, Mr, N, K, 0, 0, None, 0, 0, 0, L.ACT_NONE,
+                   1, 0, 1.0, None, 1, 0, 0, r, K * N)
+    L.check(lib.vmmt_gemm(C.byref(a), None), "gemm")
+    torch.cuda.synchronize()
+    for i in range(nb):
+        r0, r1 = i * r, min(Mr, (i + 1) * r)
+        want = At[:, r0:r1].float().t() @ Bs[i].float()
+        assert (Cd[r0:r1] - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item()), i
+    bad = L.GemmArgs(L.BF16, L.GEMM_TN, At.data_ptr(), Mr + 4, Bs.data_ptr(), N, Cd.data_ptr(), N, Mr, N, K, 0, 0, None, 0, 0, 0, L.ACT_NONE,
+                     1, 0, 1.0, None, 1, 0, 0, 100, K * N)
+    assert lib.vmmt_gemm(C.byref(bad), None) != 0                   # blocks must be whole tiles (multiples of 256 rows)

@@ -36,33 +36,32 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
     us = s.elapsed_time(e) / 20 * 1e3
     print("%s %8.1f us  %6.0f TF/s" % (name, us, 2.0 * M * V * H / us / 1e6))
 
-# ---- the fused passes (csrc/generator_fused.hip): fwd statistics + dO, then dWg + db
+# ---- the fused pass (csrc/generator_fused.hip): statistics + dO in one sweep of Wg, softmax weights P stored for the dWg GEMM
 if lib.vmmt_gen_fused_applies(L.BF16, H, H, M, V, H):
     ws = torch.zeros(lib.vmmt_gen_fused_ws_floats(M, V, H), device="cuda")
     Mp = (M + 31) // 32 * 32
-    nl = torch.zeros(Mp, device="cuda"); y32 = torch.zeros(Mp, device="cuda", dtype=torch.int32)
-    dO = torch.zeros(M, H, device="cuda"); dW = torch.zeros(Vp, H, device="cuda")
+    y32 = torch.zeros(Mp, device="cuda", dtype=torch.int32)
+    dO = torch.zeros(M, H, device="cuda")
+    with_p = "nop" not in sys.argv
+    ldp = (V + 31) // 32 * 32; Mk = (M + 63) // 64 * 64
+    Pw = torch.zeros(M, ldp, device="cuda", dtype=T); cs_ = torch.zeros(16, (M + 127) // 128 * 128, device="cuda")
+    Os_ = torch.zeros(16, Mk, H, device="cuda", dtype=T)
     def f1():
-        L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(W), H, P(bias), P(O), H, P(y), M, V, H, 1, 1.0 / 256, P(ws), P(tl), P(lse), P(nll), P(nl), P(y32),
-                                    P(dO), H, P(st), None), "fwd dO")
-    def f2():
-        L.check(lib.vmmt_gen_dW(L.BF16, P(W), H, P(bias), P(O), H, M, V, H, P(nl), P(y32), 1.0 / 256, P(dW), H, P(db), None), "dW")
-    for name, fn in (("fused fwd+dO", f1), ("fused dW", f2)):
-        for _ in range(3): fn()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(20): fn()
-        e.record(); torch.cuda.synchronize()
-        us = s.elapsed_time(e) / 20 * 1e3
-        print("%-14s %8.1f us  %6.0f TF/s (2 products)" % (name, us, 4.0 * M * V * H / us / 1e6))
-
+        L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(W), H, P(bias), P(O), H, P(y), M, V, H, 1, 1.0 / 256, P(ws), P(tl), P(lse), P(nll), P(y32),
+                                    P(dO), H, P(st), P(Pw) if with_p else None, ldp, P(cs_), P(Os_), H, Mk * H, None), "fwd dO")
+    for _ in range(3): f1()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20): f1()
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) / 20 * 1e3
+    print("fused fwd+dO (+combine) %8.1f us  %6.0f TF/s (2 products)" % (us, 4.0 * M * V * H / us / 1e6))
     import ctypes
     h = ctypes.CDLL(os.environ["VMMT_LIB_PATH"]) if "VMMT_LIB_PATH" in os.environ else None
-    if h is not None and hasattr(h, "vmmt_g2_probe_read"):       # diagnostic build: tools/exp_build.sh generator_fused.hip G2PROBE
+    if h is not None and hasattr(h, "vmmt_g2_probe_read"):       # diagnostic build: tools/exp_build.sh generator_fused.hip PROBE
         buf = (ctypes.c_ulonglong * 16)()
-        f1(); f2(); torch.cuda.synchronize()
+        f1(); torch.cuda.synchronize()
         h.vmmt_g2_probe_read(buf)
-        for role, nm in ((0, "F"), (1, "G")):
-            v = list(buf[role * 8: role * 8 + 7]); n = max(1, v[6])
-            print("%s: tiles %d; cycles (100 MHz ticks x?) per tile: vmcnt-wait %.0f  barrier %.0f  S-phase %.0f  elementwise %.0f  PV-phase %.0f  loop-tail %.0f"
-                  % (nm, n, v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5] / n))
+        v = list(buf[:8]); n = max(1, v[6])
+        print("tiles %d, in-kernel clock %d MHz; s_memtime ticks per tile: vmcnt-wait %.0f  barrier %.0f  S-phase %.0f  elementwise %.0f  PV-phase %.0f  loop-tail %.0f"
+              % (n, v[7], v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5] / n))

@@ -2,11 +2,11 @@ import csv, sys, glob, collections
 f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# find step boundaries: adam_kernel occurrences
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
-i0, i1 = adam[-3] + 1, adam[-2] + 1           # one full step
+# step boundaries: prepare_batch_kernel is the first kernel of every step's forward plan (the background half of the previous
+# step's Adam runs a little later, underneath the encoder: it belongs to the window it executes in)
+first = [i for i, r in enumerate(rows) if 'prepare_batch_kernel' in r['Kernel_Name']]
+i0, i1 = first[-3], first[-2]                  # one full steady-state step
 step = rows[i0:i1]
-# include pack kernels after adam up to next gather? keep simple
 t0 = int(step[0]['Start_Timestamp'])
 def short(n):
     n = n.replace('void vmmt::', '').replace('vmmt::', '').replace('unsigned short', 'bf16')

@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
                 ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("a_kmod", i32), ("b_kmod", i32),
                 ("addend", vp), ("ld_add", i64), ("add_rows", i32), ("add_is_T", i32), ("act", i32),
                 ("out_f32", i32), ("accumulate", i32), ("alpha", f32), ("scatter_ids", vp), ("pad_id", i32),
-                ("tile", i32), ("split_k", i32)]
+                ("tile", i32), ("split_k", i32), ("b_batch_rows", i32), ("b_batch_stride", i64)]
 
 
 class LstmDirFwd(C.Structure):
@@ -83,8 +83,10 @@ _SIGS = {
     "vmmt_gen_loss_bwd_db": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, i32, vp]),
     "vmmt_gen_fused_applies": (i32, [i32, i64, i64, i32, i32, i32]),
     "vmmt_gen_fused_ws_floats": (i64, [i32, i32, i32]),
-    "vmmt_gen_fwd_dO": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
-    "vmmt_gen_dW": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, i32, vp, vp, f32, vp, i64, vp, vp]),
+    "vmmt_gen_fwd_dO": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp,
+                              i64, i64, vp]),
+    "vmmt_gen_fused_geometry": (i32, [i32, i32, vp, vp, vp]),
+    "vmmt_gen_dW_finish": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, f32, vp, i64, vp, vp]),
     "vmmt_gather_rows": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, vp]),
     "vmmt_colsum": (i32, [i32, vp, i64, i32, i32, vp, vp, vp]),
     "vmmt_rowsum": (i32, [i32, vp, i64, i32, i32, vp, vp]),

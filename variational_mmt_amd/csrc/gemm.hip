@@ -16,6 +16,7 @@ struct GemmEpi {
   int act; int out_f32; int accumulate; float alpha;
   const long long* scatter_ids; int pad_id;                      // embedding-gradient scatter (atomic add, fp32 C)
   int atomic;                                                    // split-K: fp32 atomicAdd into a pre-zeroed / partial C
+  int b_batch_rows; long b_batch_stride;                         // B of output rows [i r, (i + 1) r) starts at B + i * stride (elements)
 };
 
 // The epilogue runs as a few small, fully unrolled passes over the accumulator registers (static indices only:
@@ -69,7 +70,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
 
 template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, int GL = 0>
 __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
-gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb, int M, int N, int K, int a_kmod,
+gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B_, long ldb, int M, int N, int K, int a_kmod,
             int b_kmod, int tiles_n, int kper, GemmEpi epi) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int TI = WM / 32, TJ = WN / 32;
@@ -78,6 +79,8 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B, long ldb
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
+  // per-row-block B (vmmt_gemm_args.b_batch_rows): every row of a tile belongs to one block (checked by vmmt_gemm)
+  const T* __restrict__ B = epi.b_batch_rows > 0 ? B_ + (long)(m0 / epi.b_batch_rows) * epi.b_batch_stride : B_;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / (BN / WN), wn = wave % (BN / WN);
   int aoff[TI], boff[TJ];
@@ -136,30 +139,6 @@ static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t s
 template <class T, bool A_KC, bool B_KC>
 static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
   long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * (epi.atomic && a->split_k > 1 ? a->split_k : 1);
-  if constexpr (sizeof(T) == 2) {     // experimental variants for in-process A/B (tools/gemm_ab.py)
-    if (a->tile == 1280) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st);   // register-staged loop
-    if (a->tile == 1281) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 32, true>(a, epi, st);
-    if (a->tile == 1282) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, false>(a, epi, st);
-    if (a->tile == 1283) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 32, false>(a, epi, st);
-    if (a->tile == 2561) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 32, true>(a, epi, st);
-    if (a->tile == 2562) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, false>(a, epi, st);
-    if (a->tile == 2563) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, false>(a, epi, st);
-    // LDS-DMA main loop: 16-byte aligned operands, K in whole 64-slabs, no k-modulus
-    const bool gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
-                       ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
-    if (a->tile == 1284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
-    if (a->tile == 2564 && gl_ok) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
-    if (a->tile == 2565 && gl_ok) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
-    if (a->tile == 2566 && gl_ok) return launch_cfg<T, 256, 128, 128, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
-    if (a->tile == 2567 && gl_ok) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);
-    if (a->tile == 3564 && gl_ok) return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
-    if (a->tile == 3565 && gl_ok) return launch_cfg<T, 128, 256, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
-    if (a->tile == 3284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
-    if (a->tile == 2568 && gl_ok) return launch_cfg<T, 128, 256, 64, 128, A_KC, B_KC, 64, true, 1>(a, epi, st);
-    if constexpr (A_KC && B_KC) {
-      if (a->tile == 4284 && gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 4>(a, epi, st);
-    }
-  }
   bool gl_ok = false;
   if constexpr (sizeof(T) == 2)
     gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
@@ -227,6 +206,8 @@ extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
   e.add_is_T = a->add_is_T; e.act = a->act; e.out_f32 = a->out_f32; e.accumulate = a->accumulate;
   e.alpha = a->alpha; e.scatter_ids = (const long long*)a->scatter_ids; e.pad_id = a->pad_id;
   e.atomic = a->split_k > 1 ? 1 : 0;
+  e.b_batch_rows = a->b_batch_rows; e.b_batch_stride = (long)a->b_batch_stride;
+  if (a->b_batch_rows < 0 || (a->b_batch_rows > 0 && a->b_batch_rows % 256 != 0)) return VMMT_EINVAL;   // whole tiles (<= 256 rows) per block
   hipStream_t st = (hipStream_t)stream;
   switch (a->layout) {
     case VMMT_GEMM_NT: return gemm_launch_nt(a, e, st);

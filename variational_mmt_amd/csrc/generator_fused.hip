@@ -1,34 +1,39 @@
-// Fused generator passes for the bf16 training step at H = 512 (256): the vocabulary projection + log-softmax + NLL and BOTH of
-// its gradients without ever writing the [V x M] softmax-gradient matrix G^T to memory.
+// Fused generator pass of the bf16 training step at H = 512 (256): the vocabulary projection + log-softmax + NLL AND dL/dO in one
+// sweep of the generator weight, with the softmax weights stored on the way so that dL/dWg is one plain GEMM afterwards.
 //
 // Reference semantics: generator = Linear(H, V) + LogSoftmax (onmt/ModelConstructor.py:583-585), NLLLoss(weight[pad] = 0, sum)
 // (onmt/Loss.py:163-165), loss.div(normalization).backward() (onmt/Loss.py:129); dL/dlogit[m][v] = (softmax_m[v] - [v == y_m]) * s_m with
 // s_m = [y_m != pad] / normalization.
 //
-// The unfused path (generator.hip) makes four GEMM-sized passes: statistics (logits never stored), a recompute that writes G^T
-// (bf16, 307 MB at M = 5120, V = 30000), and two library GEMMs that read it back (dO = G Wg, dWg = G^T O).  Here:
+// The unfused path (generator.hip) makes four GEMM-sized passes, three of them on the critical path of the step: statistics
+// (logits never stored), a recompute that writes G^T = dL/dlogit^T (bf16, 307 MB at M = 5120, V = 30000), dO = G Wg, and dWg = G^T O
+// beside it.  Here the critical path is ONE pass:
 //
-//   pass F (vmmt_gen_fwd_dO):  one workgroup = 128 tokens x one slice of the vocabulary.  Per 64-row tile of Wg:
-//        S^T = Wg_tile O^T  ->  P = exp(S - ref)  ->  acc^T += Wg_tile^T P^T,   l += rowsum P
-//     i.e. the flash-attention forward with K = V = Wg: the un-normalised dO = sum_v P[m][v] Wg[v] accumulates next to the
-//     softmax statistics.  `ref` is a LAZY reference: it starts as the maximum of the first tile and only moves (with a rescale of
-//     the 256 accumulator registers) when a later logit exceeds it by more than 60, which keeps exp() inside f32/bf16 range and
-//     costs nothing in the common case.  A small combine kernel folds the vocabulary slices:
-//        lse = ref* + log l*,   dO[m] = s_m (acc*/l* - Wg[y_m]),   NLL / accuracy statistics.
-//   pass G (vmmt_gen_dW):      one workgroup = 128 vocabulary rows, sweeping all tokens in tiles of 64:
-//        S^T = O_tile Wg^T  ->  G = exp(S + b_v - lse_m + ln s_m) - [v == y_m] s_m  ->  dWg^T += O_tile^T G^T,   db_v += rowsum G
-//     (lse is final here, so there is no running maximum at all).
+//   vmmt_gen_fwd_dO:  one workgroup = 128 tokens x one slice of the vocabulary.  Per 32-row tile of Wg:
+//        S^T = Wg_tile O^T  ->  P = exp(S - ref)  ->  acc^T += Wg_tile^T P^T,   l += rowsum P,   P -> memory (bf16)
+//     i.e. the flash-attention forward with K = V = Wg: the un-normalised dO = sum_v P[m][v] Wg[v] accumulates next to the softmax
+//     statistics.  `ref` is a LAZY reference: it starts as the maximum of the first tile and only moves (with a rescale of the 256
+//     accumulator registers and a rewrite of the slice's stored P) when a later logit exceeds it by more than 60, which keeps exp()
+//     inside f32 / bf16 range and costs nothing in the common case.  A small combine kernel folds the vocabulary slices:
+//        lse = ref* + log l*,   dO[m] = s_m (acc*/l* - Wg[y_m]),   NLL / accuracy statistics,
+//        c_s[m] = s_m exp(ref_s[m] - lse_m)  and  O'_s = diag(c_s) O   for every slice s.
+//   dL/dWg[v in slice s] = sum_m P[m][v] O'_s[m] - (one-hot term): one vmmt_gemm (the B operand switches with the slice:
+//     vmmt_gemm_args.b_batch_rows) on the side stream, where it shares the chip with the LSTM backward chains, followed by
+//     vmmt_gen_dW_finish (bias gradient = weighted column sums of P; one-hot term by atomics).
+//   (A second flash-shaped sweep for dWg -- no P in memory -- was built and measured: 976 TFLOP/s, but its workgroups own whole CUs
+//    (132 KB of LDS, 512 registers per lane), so it serialises with everything else: 2.26 against 2.16 ms per step.  Removed.)
 //
-// Both passes are ONE kernel template: the "row" operand X (128 rows per workgroup, 32 per wave) lives in registers as MFMA
-// B-operand fragments for the whole kernel, the "column" operand Y streams through a two-deep ring of 64-row LDS tiles filled by
-// LDS-DMA, and each tile of Y is used twice: by rows (ds_read_b128) for S^T and by columns (ds_read_b64_tr_b16) for the second
-// product.  S^T is computed with the streamed rows on the MFMA A side, so that a lane's accumulator registers (one row r, 32
-// columns c) are -- after conversion to bf16 -- exactly the B-operand fragments of the second product; the k-order of that product
-// is the accumulator's row order (c = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)), which the transposed reads of Y reproduce.
-// One wave per SIMD, the whole 512-register file: 256 accumulators (acc^T: H x 32 per wave), 128 for X, the rest for S^T / P.
+// Kernel structure: the "row" operand X = O (128 rows per workgroup, 32 per wave) stays resident for the whole kernel as MFMA
+// B-operand fragments (half of the k-steps in registers, half in LDS); the "column" operand Y = Wg streams through a two-deep ring
+// of 32-row LDS tiles filled by LDS-DMA, and each tile is used twice: by rows (ds_read_b128) for S^T and by columns
+// (ds_read_b64_tr_b16) for the second product.  S^T is computed with the streamed rows on the MFMA A side, so that a lane's
+// accumulator registers (one token, 16 vocabulary entries) are -- after conversion to bf16 -- exactly the B-operand fragments of the
+// second product; the k-order of that product is the accumulator's row order (c = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)),
+// which the transposed reads of Y reproduce.  One wave per SIMD: 256 accumulator registers (acc^T: H x 32 per wave) + 64 for X.
 //
-// Per byte fetched from L2 this does 4x the MFMA work of the 128 x 128-tile kernels (a 64 KB tile of Y feeds 2 x 8.4 MFLOP),
+// Per byte fetched from L2 this does 4x the MFMA work of the 128 x 128-tile kernels (a 32 KB tile of Y feeds 2 x 4.2 MFLOP),
 // which is what bounded them.
+#include <type_traits>
 #include "common.hpp"
 #include "vmmt.h"
 
@@ -40,20 +45,23 @@ typedef short fs16x4 __attribute__((ext_vector_type(4)));
 typedef short fs16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef G2_PD
+#define G2_PD 6
+#endif
+#define G2_HB(i) ((i) >> 1)
+#define G2_KK(i) ((i) & 1)
 constexpr float G2_L2E = 1.4426950408889634f;
 constexpr float G2_THR = 60.f;             // lazy-reference slack (natural-log units): exp(60) ~ 1e26 stays far inside bf16 / f32 range
 
 struct Gen2Args {
-  const bf16_t* X; long ldx; int nrows;    // resident operand  (F: O [M][ldo],  G: Wg [V][ldw])
-  const bf16_t* Y; long ldy; int ncols;    // streamed operand  (F: Wg,          G: O)
-  const float* cvec;                       // per-column constants (F: bias [V];  G: nl [Mpad] = ln s_m - lse_m, -inf beyond M / at pads)
-  const int* cy32;                         // G: targets as int32 [Mpad], -1 at pads and beyond M
-  const float* rbias;                      // G: bias [V] (per-row constants)
-  const long long* y;                      // F: targets [M]
-  int tiles_per_split, nsplit;             // F: vocabulary slices
-  float* p_acc; float* p_ref; float* p_l; float* p_max; long mpad;      // F: partials [nsplit][mpad]([D])
-  float* tgt_logit;                        // F: logit of the target [M]
-  float* dW; long lddw; float* db; float inv_norm;                      // G
+  const bf16_t* X; long ldx; int nrows;    // resident operand: O [M][ldo]
+  const bf16_t* Y; long ldy; int ncols;    // streamed operand: Wg [V][ldw]
+  const float* cvec;                       // per-column constants: bias [V]
+  const long long* y;                      // targets [M]
+  int tiles_per_split, nsplit;             // vocabulary slices
+  float* p_acc; float* p_ref; float* p_l; float* p_max; long mpad;      // partials [nsplit][mpad]([D])
+  float* tgt_logit;                        // logit of the target [M]
+  bf16_t* p_out; long ldp;                 // optional: the un-normalised softmax weights P[m][v] = exp(logit - ref), bf16 [M][ldp]
 };
 
 template <int D> struct G2 {
@@ -73,7 +81,9 @@ template <int D> struct G2 {
   static constexpr int XB = 128 * XROWB;
   static constexpr int SMALLB = 4 * 256;           // per ring slot and WAVE: 32 f32 column constants + 32 int32 targets
   static constexpr int XOFF = NSLOT * TILEB, SOFF = XOFF + XB;
-  static constexpr int LDSB = SOFF + NSLOT * SMALLB;
+  static constexpr int POFF = SOFF + NSLOT * SMALLB;   // F with P output: one [32 tokens][32 entries] bf16 patch per wave, 80-byte rows
+  static constexpr int PPITCH = 80, PATCHB = 32 * PPITCH;
+  static constexpr int LDSB = POFF + 4 * PATCHB;
   static_assert(KS / 4 >= PER, "one DMA piece per four MFMAs of the S^T phase");
   static_assert(D % 128 == 0 && D <= 512, "register budget: 256 accumulators per lane at D = 512");
 };
@@ -107,6 +117,37 @@ __device__ __forceinline__ void g2_issue_one(const bf16_t* __restrict__ Y, long 
   }
 }
 
+template <int OFF>
+__device__ __forceinline__ fs16x4 g2_tr_read(unsigned addr) {
+  fs16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+// wait until at most N LDS operations are in flight; the operands tie the wait to the registers the reads fill
+template <int N>
+__device__ __forceinline__ void g2_wait_lgkm(fs16x4& a, fs16x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+template <int OFF>
+__device__ __forceinline__ void g2_lds_write_b64(unsigned addr, fs16x4 v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ u32x4 g2_lds_read_b128(unsigned addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+__device__ __forceinline__ void g2_wait_lgkm0(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+
+template <int I, int N, class F>
+__device__ __forceinline__ void g2_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    g2_static_for<I + 1, N>(f);
+  }
+}
+
 // acc *= f for one accumulator block that lives in the ACCUMULATOR half of the register file.  Written with explicit
 // v_accvgpr moves: a plain `acc[r] *= f` makes the compiler keep all 256 accumulators in the VALU half for the whole tile loop
 // (and spill).  The MFMAs that produced `c` finished a whole S^T phase ago and the next reader is a phase away: no hazard.
@@ -121,27 +162,24 @@ __device__ __forceinline__ void g2_scale_acc(f32x16& c, float f) {
 
 // diagnostic build (tools/exp_build.sh G2PROBE): per-phase cycle counts of wave 0 of workgroup 0, summed over its tiles, in a
 // buffer that nothing else reads.  No stamp exists in the product build.
-#if defined(VMMT_EXP_G2PROBE) || defined(VMMT_EXP_G2PROBE_EW)
+#if defined(VMMT_EXP_PROBE)
 __device__ unsigned long long g2_probe[16];
 #define G2_STAMP(i) do { if (probe) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ps[i] += now_ - last_; last_ = now_; } } while (0)
 #else
 #define G2_STAMP(i) do { } while (0)
 #endif
 
-// ROLE 0: pass F, ROLE 1: pass G (see the file header)
-template <int D, int ROLE>
+template <int D>
 __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   using C = G2<D>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, r31 = lane & 31;
-  const int rt = ROLE == 0 ? (int)blockIdx.x / a.nsplit : (int)blockIdx.x;
-  const int split = ROLE == 0 ? (int)blockIdx.x % a.nsplit : 0;
+  const int rt = (int)blockIdx.x / a.nsplit, split = (int)blockIdx.x % a.nsplit;     // 128-token block, vocabulary slice
   const int R0 = rt * 128 + wave * 32;                      // this wave's 32 rows
   const int row = R0 + r31;
   const int rowc = row < a.nrows ? row : a.nrows - 1;
   const int ntall = (a.ncols + C::BC - 1) / C::BC;
-  const int t0 = ROLE == 0 ? split * a.tiles_per_split : 0;
-  const int t1 = ROLE == 0 ? min(ntall, t0 + a.tiles_per_split) : ntall;
+  const int t0 = split * a.tiles_per_split, t1 = min(ntall, t0 + a.tiles_per_split);
 
   // ring slot 0 <- first tile (issued before the resident operand is fetched: both are in flight together)
   char* const small = smem + C::SOFF;
@@ -155,8 +193,8 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
       g2_issue_one<D>(a.Y, a.ldy, t * C::BC, a.ncols, smem + slot * C::TILEB, wave, lane, j);
     } else {
       int c = t * C::BC + r31;
-      if (ROLE == 0) c = c < a.ncols ? c : a.ncols - 1;     // (G: nl / y32 are padded to whole tiles by the combine kernel)
-      const void* src = (ROLE == 1 && half) ? (const void*)(a.cy32 + c) : (const void*)(a.cvec + c);
+      c = c < a.ncols ? c : a.ncols - 1;
+      const void* src = (const void*)(a.cvec + c);
       __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)src, (f_lds_void_t*)(small + slot * C::SMALLB + wave * 256), 4, 0, 0);
     }
   };
@@ -209,26 +247,32 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
       uh[e] = (4 * half + q + 8) * C::ROWB + (p4 & 1) * 8 + (((4 * e + tw) ^ x_hi) * 16);
     }
   }
-  typedef __attribute__((address_space(3))) fs16x4 lds_v4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of the ring
 
   // role state
   float ref = -INFINITY, nrl = 0.f, lsum = 0.f, rmax = -INFINITY;       // F
   int ym = -1;
-  float brow = 0.f, rs = 0.f;                                           // G
-  if (ROLE == 0) ym = row < a.nrows ? (int)a.y[row] : -1;
-  else brow = a.rbias[rowc];
+  ym = row < a.nrows ? (int)a.y[row] : -1;
+  // (no instruction: makes the compiler wait for these two loads HERE.  First used inside the tile loop, they get their
+  //  s_waitcnt vmcnt(0) there -- in every iteration, in front of the element-wise phase, where it waits out the DMA of the next tile)
+  asm volatile("" : "+v"(ym));
 
-#if defined(VMMT_EXP_G2PROBE) || defined(VMMT_EXP_G2PROBE_EW)
+#if defined(VMMT_EXP_PROBE)
   const bool probe = blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long ps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = last_, r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int t = t0; t < t1; ++t) {
     G2_STAMP(5);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tile t has landed (nothing younger is in flight)
+    // tile t has landed.  vmcnt counts in issue order: the only operations younger than its DMA pieces are the two stores of P behind
+    // the previous tile's element-wise phase, which may stay in flight (waiting for their acknowledgement costs ~0.5 us per tile)
+    if (a.p_out) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2_STAMP(0);
     __syncthreads();                                        // ... for every wave; and every wave is done with tile t-1
     G2_STAMP(1);
-    const int cur = (t - t0) & 1;
+    const int cur = (t - t0) & 1;                           // ring slot (its byte offset is folded into ua / ul / uh: see the loop tail)
+    constexpr int SB = 0;
     const int tn = t + 1 < t1 ? t + 1 : t;                  // (the last tile is fetched once more, into the slot nobody reads again)
     const char* sb = small + cur * C::SMALLB + wave * 256;
     const int c0 = t * C::BC;
@@ -239,16 +283,16 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
     for (int i = 0; i < 4; ++i) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(sb + (8 * i + 4 * half) * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sT[4 * i + e] = ROLE == 0 ? v[e] : v[e] + brow;
+      for (int e = 0; e < 4; ++e) sT[4 * i + e] = v[e];
     }
     // Rolling prefetch: the fragment(s) of k-step ks + PD are requested right before the MFMA of k-step ks; the scheduling barriers
     // pin that order (left alone, the compiler hoists every read of the unrolled loop to the top and spills at one wave per SIMD).
     // The next tile's DMA pieces ride along, one per four MFMAs.
     {
-      constexpr int PD = 6;
+      constexpr int PD = G2_PD;
       bf16x8 fa[PD], fx[PD];
       auto rd = [&](int ks) {
-        fa[ks % PD] = *reinterpret_cast<const bf16x8*>(smem + ua[ks & 7] + (ks >> 3) * 256);
+        fa[ks % PD] = *reinterpret_cast<const bf16x8*>(smem + ua[ks & 7] + (SB + (ks >> 3) * 256));
         if (ks >= C::KR) fx[ks % PD] = *reinterpret_cast<const bf16x8*>(smem + ux[(ks - C::KR) & 7] + ((ks - C::KR) >> 3) * 256);
       };
 #pragma unroll
@@ -260,100 +304,126 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
         else sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks % PD], fx[ks % PD], sT, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (ks + PD < C::KS) rd(ks + PD);
-#if !defined(VMMT_EXP_G2EW) && !defined(VMMT_EXP_G2PROBE_EW)
         if ((ks & 3) == 1 && (ks >> 2) < C::PER) issue_piece(tn, cur ^ 1, ks >> 2);
         if (ks == 3) issue_piece(tn, cur ^ 1, C::PER);
-#endif
       }
     }
 
     G2_STAMP(2);
-#if defined(VMMT_EXP_G2EW) || defined(VMMT_EXP_G2PROBE_EW)
-    issue_tile(tn, cur ^ 1);
-#endif
     // ---- element-wise: S^T -> P^T (bf16 B-operand fragments of the second product: k-step kk = accumulator registers 8 kk .. 8 kk + 7)
     bf16x8 pf[2];
-    if constexpr (ROLE == 0) {
-      if (c0 + C::BC > a.ncols) {                           // last tile of the vocabulary: rows >= V do not exist
+    if (c0 + C::BC > a.ncols) {                           // last tile of the vocabulary: rows >= V do not exist
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (c0 + (r & 3) + 8 * (r >> 2) + 4 * half >= a.ncols) sT[r] = -INFINITY;
-      }
-      float tmax = -INFINITY;
+      for (int r = 0; r < 16; ++r)
+        if (c0 + (r & 3) + 8 * (r >> 2) + 4 * half >= a.ncols) sT[r] = -INFINITY;
+    }
+    float tmax = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sT[r]), sT[r + 1]);
-      rmax = fmaxf(rmax, tmax);
-      if (__any(tmax > ref + G2_THR)) {                     // the reference moves (always in the first tile: ref = -inf; hardly ever later)
-        const float nm = fmaxf(tmax, __shfl_xor(tmax, 32, 64));        // both halves of a token's lanes keep the same reference
-        const bool mv = nm > ref + G2_THR;
-        const float f = mv ? __expf(ref - nm) : 1.f;        // exp(-inf) = 0 in the first tile (accumulators are zero anyway)
-        if (mv) { ref = nm; nrl = -nm * G2_L2E; }
-        lsum *= f;
+    for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sT[r]), sT[r + 1]);
+    rmax = fmaxf(rmax, tmax);
+    if (__any(tmax > ref + G2_THR)) {                     // the reference moves (always in the first tile: ref = -inf; hardly ever later)
+      const float nm = fmaxf(tmax, __shfl_xor(tmax, 32, 64));        // both halves of a token's lanes keep the same reference
+      const bool mv = nm > ref + G2_THR;
+      const float f = mv ? __expf(ref - nm) : 1.f;        // exp(-inf) = 0 in the first tile (accumulators are zero anyway)
+      if (mv) { ref = nm; nrl = -nm * G2_L2E; }
+      lsum *= f;
 #pragma unroll
-        for (int hb = 0; hb < C::HB; ++hb) g2_scale_acc(acc[hb], f);
-      }
-      if (__any(ym >= c0 && ym < c0 + C::BC)) {             // a target of this wave's tokens lies in this tile: keep its logit
-        float tl = 0.f;
-        bool hit = false;
+      for (int hb = 0; hb < C::HB; ++hb) g2_scale_acc(acc[hb], f);
+      if (a.p_out && t > t0) {
+        // (practically never: a logit more than 60 above everything seen so far in this slice)  The weights already stored for
+        // these tokens are in units of the OLD reference: rewrite them.  They were stored by this wave: after its stores have
+        // drained, device-scope loads see them.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (mv && row < a.nrows) {
+          bf16_t* pr = a.p_out + (long)row * a.ldp;
+          for (int v = t0 * C::BC + half * 8; v < c0; v += 16) {
+            uint32_t w[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool h = c0 + (r & 3) + 8 * (r >> 2) + 4 * half == ym;
-          tl = h ? sT[r] : tl;
-          hit = hit || h;
-        }
-        if (hit) a.tgt_logit[row] = tl;
-      }
+            for (int e = 0; e < 4; ++e) w[e] = __hip_atomic_load(reinterpret_cast<uint32_t*>(pr + v) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[r], G2_L2E, nrl));
-        lsum += pv;
-        pf[r >> 3][r & 7] = (__bf16)pv;
-      }
-    } else {
-      // lanes 0..31 look at one token of the tile each: does any target fall into this wave's 32 vocabulary rows?
-      const int yt = *reinterpret_cast<const int*>(sb + 128 + r31 * 4);
-      if (__any(yt >= R0 && yt < R0 + 32)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const i32x4 y4 = *reinterpret_cast<const i32x4*>(sb + 128 + (8 * i + 4 * half) * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float pv = __builtin_amdgcn_exp2f(sT[4 * i + e] * G2_L2E);
-            sT[4 * i + e] = pv - (y4[e] == row ? a.inv_norm : 0.f);
+            for (int e = 0; e < 4; ++e) {
+              const float lo = __uint_as_float(w[e] << 16) * f, hi = __uint_as_float(w[e] & 0xffff0000u) * f;
+              w[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+            }
+            *reinterpret_cast<u32x4*>(pr + v) = u32x4{w[0], w[1], w[2], w[3]};
           }
         }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sT[r] = __builtin_amdgcn_exp2f(sT[r] * G2_L2E);
       }
+    }
+    if (__any(ym >= c0 && ym < c0 + C::BC)) {             // a target of this wave's tokens lies in this tile: keep its logit
+      float tl = 0.f;
+      bool hit = false;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        rs += sT[r];
-        pf[r >> 3][r & 7] = (__bf16)sT[r];
+        const bool h = c0 + (r & 3) + 8 * (r >> 2) + 4 * half == ym;
+        tl = h ? sT[r] : tl;
+        hit = hit || h;
+      }
+      if (hit) a.tgt_logit[row] = tl;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[r], G2_L2E, nrl));
+      lsum += pv;
+      pf[r >> 3][r & 7] = (__bf16)pv;
+    }
+    if (a.p_out) {
+      // P[m][c0 .. c0+31] for this wave's 32 tokens: through a [token][entry] patch in LDS (the lane holds 4 x 4 consecutive entries
+      // of ONE token: registers 4 i .. 4 i + 3 = entries 8 i + 4 half + 0..3), written out as 16-byte row segments
+      // (inline assembly: written as C++ the compiler puts an s_waitcnt vmcnt(0) in front of these LDS accesses -- it cannot tell
+      //  the patch from the ring slot the LDS-DMA of the next tile is filling -- and the wave waits out the DMA it just issued.
+      //  One wave's LDS operations execute in order: the reads below see the writes above without a wait in between.)
+      const unsigned patch = lds0 + C::POFF + wave * C::PATCHB;
+      const unsigned wr = patch + r31 * C::PPITCH + 8 * half;
+      g2_lds_write_b64<0>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[0]), __builtin_bit_cast(fs16x8, pf[0]), 0, 1, 2, 3));
+      g2_lds_write_b64<16>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[0]), __builtin_bit_cast(fs16x8, pf[0]), 4, 5, 6, 7));
+      g2_lds_write_b64<32>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[1]), __builtin_bit_cast(fs16x8, pf[1]), 0, 1, 2, 3));
+      g2_lds_write_b64<48>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[1]), __builtin_bit_cast(fs16x8, pf[1]), 4, 5, 6, 7));
+      u32x4 seg[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = lane + 64 * j;
+        seg[j] = g2_lds_read_b128(patch + (q >> 2) * C::PPITCH + (q & 3) * 16);
+      }
+      g2_wait_lgkm0(seg[0], seg[1]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = lane + 64 * j, prow = q >> 2, ch = q & 3;
+        if (R0 + prow < a.nrows) *reinterpret_cast<u32x4*>(a.p_out + (long)(R0 + prow) * a.ldp + c0 + ch * 8) = seg[j];
       }
     }
 
     G2_STAMP(3);
     // ---- acc^T[h][r] += sum_c Y[c][h] P[r][c]   (A = Y^T by transposed reads, k order = the accumulator row order of S^T)
+    // The transposed reads are written as inline assembly: as a builtin the compiler orders them behind the LDS-DMA of the NEXT tile
+    // (s_waitcnt vmcnt(0) in front of the first one -- also with the loop unrolled by two and compile-time ring slots), which makes
+    // every wave wait out the DMA it has just issued.  The price is that their lgkmcnt bookkeeping is ours: LDS returns in order, and when MFMA i is due the
+    // reads of at most min(PD - 1, NM - 1 - i) younger MFMAs (two each) are in flight.
     {
-      constexpr int PD = 6, NM = C::HB * 2;                 // MFMA i: block hb = i >> 1, k-step kk = i & 1
+      constexpr int PD = G2_PD, NM = C::HB * 2;             // MFMA i: block hb = G2_HB(i), k-step kk = G2_KK(i)
       fs16x4 fl[PD], fh[PD];
-      auto rd = [&](int i) {
-        const int hb = i >> 1, kk = i & 1;
-        fl[i % PD] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(smem + ul[hb & 3] + ((hb >> 2) * 256 + kk * 16 * C::ROWB)));
-        fh[i % PD] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(smem + uh[hb & 3] + ((hb >> 2) * 256 + kk * 16 * C::ROWB)));
+      auto rd = [&](auto ic) {
+        constexpr int i = decltype(ic)::value, hb = G2_HB(i), kk = G2_KK(i);
+        constexpr int off = SB + (hb >> 2) * 256 + kk * 16 * C::ROWB;
+        fl[i % PD] = g2_tr_read<off>(lds0 + ul[hb & 3]);
+        fh[i % PD] = g2_tr_read<off>(lds0 + uh[hb & 3]);
       };
-#pragma unroll
-      for (int i = 0; i < PD; ++i) rd(i);
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_barrier(0);
+      g2_static_for<0, PD>([&](auto ic) { rd(ic); });
+      g2_static_for<0, NM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int inflight = 2 * ((PD - 1) < (NM - 1 - i) ? (PD - 1) : (NM - 1 - i));
+        g2_wait_lgkm<inflight>(fl[i % PD], fh[i % PD]);
         const fs16x8 v = __builtin_shufflevector(fl[i % PD], fh[i % PD], 0, 1, 2, 3, 4, 5, 6, 7);
-        acc[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), pf[i & 1], acc[i >> 1], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (i + PD < NM) rd(i + PD);
-      }
+        acc[G2_HB(i)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), pf[G2_KK(i)], acc[G2_HB(i)], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i + PD < NM) rd(std::integral_constant<int, i + PD>{});
+      });
     }
+    // (no instruction: pins the 256 accumulators to the accumulator half of the register file between tiles; without it the
+    //  allocator parks some of them in the VALU half and spills the resident operand instead)
+#pragma unroll
+    for (int hb = 0; hb < C::HB; ++hb) asm volatile("" : "+a"(acc[hb]));
     G2_STAMP(4);
     // the other ring slot next
 #pragma unroll
@@ -363,25 +433,20 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup's LDS allocation
-#if defined(VMMT_EXP_G2PROBE) || defined(VMMT_EXP_G2PROBE_EW)
+#if defined(VMMT_EXP_PROBE)
   if (probe) {
-    for (int i = 0; i < 6; ++i) g2_probe[ROLE * 8 + i] = ps[i];
-    g2_probe[ROLE * 8 + 6] = (unsigned long long)(t1 - t0);
+    for (int i = 0; i < 6; ++i) g2_probe[i] = ps[i];
+    g2_probe[6] = (unsigned long long)(t1 - t0);
+    // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, reported in MHz
+    g2_probe[7] = (__builtin_amdgcn_s_memtime() - t_begin) * 100ull / (__builtin_amdgcn_s_memrealtime() - r_begin);
   }
 #endif
   // ---- write-out: lane (r31, half) owns row `row` and the columns h = 32 hb + 8 i + 4 half + 0..3 of acc^T
   if (row < a.nrows) {
-    float* dst;
-    if constexpr (ROLE == 0) {
-      const long pr = (long)split * a.mpad + row;
-      dst = a.p_acc + pr * D;
-      const float lt = lsum + __shfl_xor(lsum, 32, 64), mt = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-      if (half == 0) { a.p_ref[pr] = ref; a.p_l[pr] = lt; a.p_max[pr] = mt; }
-    } else {
-      dst = a.dW + (long)row * a.lddw;
-      const float rt_ = rs + __shfl_xor(rs, 32, 64);
-      if (half == 0) a.db[row] += rt_;                      // one lane per vocabulary row in the whole grid: a plain accumulate
-    }
+    const long pr = (long)split * a.mpad + row;
+    float* dst = a.p_acc + pr * D;
+    const float lt = lsum + __shfl_xor(lsum, 32, 64), mt = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    if (half == 0) { a.p_ref[pr] = ref; a.p_l[pr] = lt; a.p_max[pr] = mt; }
 #pragma unroll
     for (int hb = 0; hb < C::HB; ++hb)
 #pragma unroll
@@ -395,17 +460,20 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
 }
 
 // combine of pass F: 8 tokens per workgroup (32 threads per token).  Folds the vocabulary slices' (ref, l, max, acc) and writes
-//   lse, tok_nll, the statistics (NLL, words, correct), nl = ln s_m - lse_m and y32 for pass G (whole 32-token tiles: -inf / -1 beyond M),
+//   lse, tok_nll, the statistics (NLL, words, correct), y32 (targets as int32, -1 at pads; whole 32-token tiles),
 //   dO[m][h] = s_m (sum_s w_s acc_s[m][h] / l* - Wg[y_m][h]),  w_s = exp(ref_s - ref*).
 template <int D>
 __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restrict__ p_acc, const float* __restrict__ p_ref,
                                                            const float* __restrict__ p_l, const float* __restrict__ p_max, long mpad, int nsplit,
                                                            const float* __restrict__ tgt_logit, const long long* __restrict__ y, int M, int pad,
                                                            float inv_norm, const bf16_t* __restrict__ W, long ldw,
-                                                           float* __restrict__ lse, float* __restrict__ tok_nll, float* __restrict__ nl,
-                                                           int* __restrict__ y32, float* __restrict__ dO, long lddo, float* __restrict__ stats) {
+                                                           float* __restrict__ lse, float* __restrict__ tok_nll,
+                                                           int* __restrict__ y32, float* __restrict__ dO, long lddo, float* __restrict__ stats,
+                                                           const bf16_t* __restrict__ O, long ldo, float* __restrict__ cs,
+                                                           bf16_t* __restrict__ Os, long ldos, long os_stride) {
   constexpr int MAXS = 16;
   __shared__ float s_w[8][MAXS];
+  __shared__ float s_c[8][MAXS];
   __shared__ float s_invl[8], s_sc[8];
   __shared__ int s_y[8];
   const int tid = threadIdx.x, m0 = blockIdx.x * 8;
@@ -431,11 +499,16 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
         nw = wv ? 1.f : 0.f;
         nc = (wv && tgt_logit[m] >= mx) ? 1.f : 0.f;         // accuracy: the target's logit is the row maximum (Loss.py:150-160)
         const float sc = wv ? inv_norm : 0.f;
-        nl[m] = wv ? logf(inv_norm) - ls : -INFINITY;
         y32[m] = wv ? (int)ym : -1;
         s_invl[tid] = 1.f / l; s_sc[tid] = sc; s_y[tid] = (int)ym;
+        // slice s stored its softmax weights in units of exp(ref_s): dL/dlogit[m][v] = P[m][v] c_s[m] - [v == y_m] s_m
+        for (int s = 0; s < nsplit; ++s) {
+          const float c = sc * __expf(p_ref[(long)s * mpad + m] - ls);
+          s_c[tid][s] = c;
+          if (cs) cs[(long)s * mpad + m] = c;
+        }
       } else {
-        if (m < ((M + 31) / 32) * 32) { nl[m] = -INFINITY; y32[m] = -1; }
+        if (m < ((M + 31) / 32) * 32) y32[m] = -1;
         s_sc[tid] = 0.f; s_invl[tid] = 0.f; s_y[tid] = 0;
         for (int s = 0; s < nsplit; ++s) s_w[tid][s] = 0.f;
       }
@@ -468,15 +541,77 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = sc * (v[e] * invl - w4[e]);
     *reinterpret_cast<f32x4*>(dO + (long)m * lddo + h) = v;
+    if (Os) {                                               // O'_s[m] = c_s[m] O[m] (bf16): the B operand of dWg = P_s^T O'_s
+      const uint2 ob = *reinterpret_cast<const uint2*>(O + (long)m * ldo + h);
+      const float o4[4] = {__uint_as_float(ob.x << 16), __uint_as_float(ob.x & 0xffff0000u), __uint_as_float(ob.y << 16),
+                           __uint_as_float(ob.y & 0xffff0000u)};
+      for (int s = 0; s < nsplit; ++s) {
+        const float c = s_c[tk][s];
+        uint2 r;
+        r.x = (uint32_t)f2bf(c * o4[0]) | ((uint32_t)f2bf(c * o4[1]) << 16);
+        r.y = (uint32_t)f2bf(c * o4[2]) | ((uint32_t)f2bf(c * o4[3]) << 16);
+        *reinterpret_cast<uint2*>(Os + s * os_stride + (long)m * ldos + h) = r;
+      }
+    }
   }
 }
 
-static int g2_nsplit(int M, int V) {
+// db[v] += sum_m P[m][v] c_s(v)[m]: 512 vocabulary entries x 128 tokens per workgroup, 16-byte loads of P, one atomic per entry and block
+__global__ void __launch_bounds__(256) gen2_db_kernel(const bf16_t* __restrict__ P, long ldp, const float* __restrict__ cs, long mpad,
+                                                      int v_per_split, int M, int V, float* __restrict__ db) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int v0 = (blockIdx.x * 64 + lane) * 8;
+  const int m0 = blockIdx.y * 128, m1 = min(M, m0 + 128);
+  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (v0 < V) {
+    const float* c = cs + (long)(v0 / v_per_split) * mpad;
+    for (int m = m0 + w; m < m1; m += 4) {
+      const u32x4 pw = *reinterpret_cast<const u32x4*>(P + (long)m * ldp + v0);
+      const float cm = c[m];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a8[2 * e] = __builtin_fmaf(__uint_as_float(pw[e] << 16), cm, a8[2 * e]);
+        a8[2 * e + 1] = __builtin_fmaf(__uint_as_float(pw[e] & 0xffff0000u), cm, a8[2 * e + 1]);
+      }
+    }
+  }
+  __shared__ float red[4][64][9];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[w][lane][e] = a8[e];
+  __syncthreads();
+  if (w == 0 && v0 < V) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
+      if (v0 + e < V) atomicAdd(db + v0 + e, t);
+    }
+  }
+}
+
+// the one-hot term of dL/dlogit: dWg[y_m] -= s_m O[m], db[y_m] -= s_m  (one wave per token; after the dWg GEMMs have stored)
+template <int D>
+__global__ void __launch_bounds__(256) gen2_onehot_kernel(const bf16_t* __restrict__ O, long ldo, const int* __restrict__ y32, float inv_norm,
+                                                          int M, float* __restrict__ dW, long lddw, float* __restrict__ db) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const int ym = y32[m];
+  if (ym < 0) return;
+  float* dst = dW + (long)ym * lddw;
+  for (int h = lane; h < D; h += 64) atomicAdd(dst + h, -inv_norm * bf2f(O[(long)m * ldo + h]));
+  if (lane == 0) atomicAdd(db + ym, -inv_norm);
+}
+
+// vocabulary slices of the forward sweep: about 256 workgroups in all, whole groups of 8 tiles (256 rows) per slice so that
+// a slice boundary is also a tile boundary of the dWg GEMM (vmmt_gemm_args.b_batch_rows)
+static int g2_tiles_per_split(int M, int V) {
   const int nmt = (M + 127) / 128, ntiles = (V + 31) / 32;
   int ns = 256 / nmt;
   ns = ns < 1 ? 1 : ns > 16 ? 16 : ns;
   ns = ns > ntiles ? ntiles : ns;
-  const int tps = (ntiles + ns - 1) / ns;
+  return ((ntiles + ns - 1) / ns + 7) / 8 * 8;
+}
+static int g2_nsplit(int M, int V) {
+  const int ntiles = (V + 31) / 32, tps = g2_tiles_per_split(M, V);
   return (ntiles + tps - 1) / tps;
 }
 
@@ -485,21 +620,21 @@ static bool g2_applies(int dtype, const void* W, int64_t ldw, const void* O, int
          ((((uintptr_t)W) | ((uintptr_t)O)) & 15) == 0;
 }
 
-template <int D, int ROLE>
+template <int D>
 static int g2_launch(const Gen2Args& a, int grid, hipStream_t st) {
   static bool done = false;
   if (!done) {
-    if (hipFuncSetAttribute((const void*)gen2_kernel<D, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, G2<D>::LDSB) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gen2_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, G2<D>::LDSB) != hipSuccess)
       return VMMT_ELAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL((gen2_kernel<D, ROLE>), dim3(grid), dim3(256), G2<D>::LDSB, st, a);
+  hipLaunchKernelGGL((gen2_kernel<D>), dim3(grid), dim3(256), G2<D>::LDSB, st, a);
   return check_launch();
 }
 
 }  // namespace vmmt
 
-#if defined(VMMT_EXP_G2PROBE) || defined(VMMT_EXP_G2PROBE_EW)
+#if defined(VMMT_EXP_PROBE)
 extern "C" int vmmt_g2_probe_read(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(vmmt::g2_probe), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
 }
@@ -514,12 +649,24 @@ extern "C" int64_t vmmt_gen_fused_ws_floats(int M, int V, int K) {
   return (int64_t)vmmt::g2_nsplit(M, V) * mpad * (K + 3);
 }
 
+extern "C" int vmmt_gen_fused_geometry(int M, int V, int* nsplit, int* v_per_split, int64_t* mpad) {
+  if (M <= 0 || V <= 0 || !nsplit || !v_per_split || !mpad) return VMMT_EINVAL;
+  *nsplit = vmmt::g2_nsplit(M, V);
+  *v_per_split = vmmt::g2_tiles_per_split(M, V) * 32;
+  *mpad = (int64_t)((M + 127) / 128) * 128;
+  return VMMT_OK;
+}
+
 extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, const int64_t* y,
                                int M, int V, int K, int pad, float inv_norm, float* ws, float* tgt_logit, float* lse, float* tok_nll,
-                               float* nl, int* y32, float* dO, int64_t lddo, float* stats, void* stream) {
+                               int* y32, float* dO, int64_t lddo, float* stats, void* Pw, int64_t ldp, float* cs, void* Os,
+                               int64_t ldos, int64_t os_stride, void* stream) {
   using namespace vmmt;
-  if (!W || !bias || !O || !y || !ws || !tgt_logit || !lse || !tok_nll || !nl || !y32 || !dO || !stats || lddo < K || (lddo & 3) ||
+  if (!W || !bias || !O || !y || !ws || !tgt_logit || !lse || !tok_nll || !y32 || !dO || !stats || lddo < K || (lddo & 3) ||
       (((uintptr_t)dO) & 15))
+    return VMMT_EINVAL;
+  if (Pw && (!cs || !Os || ldp < (V + 31) / 32 * 32 || (ldp & 7) || (((uintptr_t)Pw) & 15) || ldos < K || (ldos & 3) || (((uintptr_t)Os) & 7) ||
+             os_stride < (int64_t)M * ldos))
     return VMMT_EINVAL;
   if (!g2_applies(dtype, W, ldw, O, ldo, M, V, K)) return VMMT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -529,33 +676,43 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const floa
   a.X = (const bf16_t*)O; a.ldx = ldo; a.nrows = M;
   a.Y = (const bf16_t*)W; a.ldy = ldw; a.ncols = V;
   a.cvec = bias; a.y = (const long long*)y;
-  a.nsplit = ns; a.tiles_per_split = (ntiles + ns - 1) / ns;
+  a.nsplit = ns; a.tiles_per_split = g2_tiles_per_split(M, V);
   a.mpad = mpad;
   a.p_acc = ws; a.p_ref = ws + (long)ns * mpad * K; a.p_l = a.p_ref + (long)ns * mpad; a.p_max = a.p_l + (long)ns * mpad;
   a.tgt_logit = tgt_logit;
-  int rc = K == 512 ? g2_launch<512, 0>(a, nmt * ns, st) : g2_launch<256, 0>(a, nmt * ns, st);
+  a.p_out = (bf16_t*)Pw; a.ldp = ldp;
+  int rc = K == 512 ? g2_launch<512>(a, nmt * ns, st) : g2_launch<256>(a, nmt * ns, st);
   if (rc) return rc;
   const int mt = (M + 31) / 32 * 32;
   if (K == 512)
     hipLaunchKernelGGL((gen2_combine_kernel<512>), dim3((mt + 7) / 8), dim3(256), 0, st, a.p_acc, a.p_ref, a.p_l, a.p_max, mpad, ns, tgt_logit,
-                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, nl, y32, dO, (long)lddo, stats);
+                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, stats,
+                       (const bf16_t*)O, (long)ldo, Pw ? cs : nullptr, Pw ? (bf16_t*)Os : nullptr, (long)ldos, (long)os_stride);
   else
     hipLaunchKernelGGL((gen2_combine_kernel<256>), dim3((mt + 7) / 8), dim3(256), 0, st, a.p_acc, a.p_ref, a.p_l, a.p_max, mpad, ns, tgt_logit,
-                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, nl, y32, dO, (long)lddo, stats);
+                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, stats,
+                       (const bf16_t*)O, (long)ldo, Pw ? cs : nullptr, Pw ? (bf16_t*)Os : nullptr, (long)ldos, (long)os_stride);
   return check_launch();
 }
 
-extern "C" int vmmt_gen_dW(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, int M, int V, int K,
-                           const float* nl, const int* y32, float inv_norm, float* dW, int64_t lddw, float* dbias, void* stream) {
+// what the dWg GEMMs (one per vocabulary slice: dWg[slice] = P[:, slice]^T O'_slice, plain vmmt_gemm calls) leave to do:
+//   dbias[v] += sum_m P[m][v] c_s(v)[m]   and the one-hot term   dWg[y_m] -= s_m O[m],  dbias[y_m] -= s_m
+extern "C" int vmmt_gen_dW_finish(int dtype, const void* Pw, int64_t ldp, const float* cs, const void* O, int64_t ldo, const int* y32,
+                                  int M, int V, int K, float inv_norm, float* dW, int64_t lddw, float* dbias, void* stream) {
   using namespace vmmt;
-  if (!W || !bias || !O || !nl || !y32 || !dW || !dbias || lddw < K || (lddw & 3) || (((uintptr_t)dW) & 15)) return VMMT_EINVAL;
-  if (!g2_applies(dtype, W, ldw, O, ldo, M, V, K)) return VMMT_EINVAL;
-  Gen2Args a{};
-  a.X = (const bf16_t*)W; a.ldx = ldw; a.nrows = V;
-  a.Y = (const bf16_t*)O; a.ldy = ldo; a.ncols = M;
-  a.cvec = nl; a.cy32 = y32; a.rbias = bias;
-  a.nsplit = 1; a.tiles_per_split = 0;
-  a.dW = dW; a.lddw = lddw; a.db = dbias; a.inv_norm = inv_norm;
-  const int grid = (V + 127) / 128;
-  return K == 512 ? g2_launch<512, 1>(a, grid, (hipStream_t)stream) : g2_launch<256, 1>(a, grid, (hipStream_t)stream);
+  if (dtype != VMMT_BF16 || !Pw || !cs || !O || !y32 || !dW || !dbias || M <= 0 || V <= 0 || (K != 512 && K != 256) || (ldp & 7) ||
+      (((uintptr_t)Pw) & 15) || lddw < K)
+    return VMMT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long mpad = (long)((M + 127) / 128) * 128;
+  hipLaunchKernelGGL(gen2_db_kernel, dim3((V + 511) / 512, (M + 127) / 128), dim3(256), 0, st, (const bf16_t*)Pw, (long)ldp, cs, mpad,
+                     g2_tiles_per_split(M, V) * 32, M, V, dbias);
+  if (K == 512)
+    hipLaunchKernelGGL((gen2_onehot_kernel<512>), dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)O, (long)ldo, y32, inv_norm, M, dW,
+                       (long)lddw, dbias);
+  else
+    hipLaunchKernelGGL((gen2_onehot_kernel<256>), dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)O, (long)ldo, y32, inv_norm, M, dW,
+                       (long)lddw, dbias);
+  return check_launch();
 }
+

@@ -349,7 +349,8 @@ class Engine(object):
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
-              act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0):
+              act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
+              b_batch_rows=0, b_batch_stride=0):
         if split_k == -1:
             # weight-gradient heuristic: enough workgroups to fill 256 CUs a few times, >= 256 reduction steps each
             tiles = ((M + 63) // 64) * ((N + 63) // 64)
@@ -359,7 +360,7 @@ class Engine(object):
         if a_kmod == 0 and b_kmod == 0:
             K = _ru(K, KPAD)            # operands are Bufs: zero-padded to whole slabs (see Buf)
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
-                       add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k)
+                       add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k, b_batch_rows, b_batch_stride)
         plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
 
     def _call(self, plan, fn, *args):
@@ -637,9 +638,18 @@ class Workspace(object):
         if self.gen_fused:
             nws = int(eng.lib.vmmt_gen_fused_ws_floats(M, V, _ru(H, KPAD)))
             self.gen_ws = eng.shared_storage("gen_ws", nws, f32)          # vocabulary-slice partials: shared by all workspaces
-            self.gen_nl = torch.zeros(_ru(M, 32), dtype=f32, device=dev)
             self.gen_y32 = torch.zeros(_ru(M, 32), dtype=torch.int32, device=dev)
             self.GT = None
+            ns, vps, mpad = C.c_int(), C.c_int(), C.c_int64()
+            L.check(eng.lib.vmmt_gen_fused_geometry(M, V, C.byref(ns), C.byref(vps), C.byref(mpad)), "vmmt_gen_fused_geometry")
+            self.gen_ns, self.gen_vps, self.gen_mpad = ns.value, vps.value, mpad.value
+            Mk = _ru(M, KPAD) + KPAD
+            self.gen_ldp = _ru(V, 32)
+            # P [M][V] bf16 (the forward sweep's softmax weights: 307 MB at B 256 / V 30 000 / T' 20): one allocation shared by all
+            # workspaces; leftovers of other shapes are finite and only ever meet the zero rows of O'_s
+            self.gen_P = eng.shared_storage("gen_P", Mk * self.gen_ldp, T)
+            self.gen_cs = torch.zeros(self.gen_ns * self.gen_mpad, dtype=f32, device=dev)
+            self.gen_Os = torch.zeros(self.gen_ns, Mk, _ru(H, KPAD), dtype=T, device=dev)
         else:
             self.GT = Buf(V, M, T, dev, storage=eng.shared_storage("GT", Buf.elems(V, M), T))
         self.dPre = nb(M, H)
@@ -893,13 +903,15 @@ class Workspace(object):
         if training:
             self._loss_patch = None
         if training and self.gen_fused:
-            # statistics AND dO = dL/dO in one sweep of Wg (1 / normalization is patched in by loss_backward: argument 11)
+            # statistics AND dO = dL/dO in one sweep of Wg (1 / normalization is patched in by loss_backward: argument 11); the softmax
+            # weights P and the per-slice scaled copies O'_s of O it leaves behind feed the dWg GEMM of the backward plan
             assert O.ld == _ru(d.hid, KPAD)
             self._loss_patch = (len(P), 11)
             e._call(P, lib.vmmt_gen_fwd_dO, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(), self.M, d.vt,
                     _ru(d.hid, KPAD), PAD, 0.0, self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.lse.data_ptr(),
-                    self.tok_nll.data_ptr(), self.gen_nl.data_ptr(), self.gen_y32.data_ptr(), self.dO32.p(), self.dO32.ld,
-                    self.stats.data_ptr())
+                    self.tok_nll.data_ptr(), self.gen_y32.data_ptr(), self.dO32.p(), self.dO32.ld, self.stats.data_ptr(),
+                    self.gen_P.data_ptr(), self.gen_ldp, self.gen_cs.data_ptr(), self.gen_Os.data_ptr(), self.gen_Os.shape[2],
+                    self.gen_Os.shape[1] * self.gen_Os.shape[2])
             return P
         e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(),
                 self.M, d.vt, _ru(d.hid, KPAD), PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), None,
@@ -932,7 +944,7 @@ class Workspace(object):
         #  Cache, was measured with tools/ab.py: 2.227-2.97 ms against 2.213 ms in one pass -- not kept)
         self._patch = {}
         if self.gen_fused:
-            pass        # dO32 came out of the loss plan (vmmt_gen_fwd_dO); dWg / db: one pass on the side stream below
+            pass        # dO32 came out of the loss plan (vmmt_gen_fwd_dO); dWg / db: one GEMM + vmmt_gen_dW_finish on the side stream below
         elif fuse_db:
             self._patch["gen"] = (len(P), 12)
             e._call(P, lib.vmmt_gen_loss_bwd_db, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), self.O.p(), self.O.ld, self.y.data_ptr(),
@@ -1015,10 +1027,15 @@ class Workspace(object):
         e._sid = SIDE
         e._wait(P, "bwd_begin")
         if self.gen_fused:
+            # dWg[slice s] = P[:, slice s]^T O'_s: ONE plain GEMM (K = tokens; the B operand switches with the vocabulary slice), then the
+            # bias gradient and the one-hot term
+            Kp = _ru(H, KPAD)
+            e._gemm(P, L.GEMM_TN, self.gen_P.data_ptr(), self.gen_ldp, self.gen_Os.data_ptr(), Kp, e.gp("generator.0.weight"), H,
+                    V, H, M, out_f32=1, b_batch_rows=self.gen_vps, b_batch_stride=self.gen_Os.shape[1] * Kp)
             Og = self.O if (training_dropout and d.dropout > 0) else self.AH
-            self._patch["gen"] = (len(P), 11)
-            e._call(P, lib.vmmt_gen_dW, dt, wg.p(), wg.ld, e.pp("generator.0.bias"), Og.p(), Og.ld, M, V, _ru(H, KPAD),
-                    self.gen_nl.data_ptr(), self.gen_y32.data_ptr(), inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"))
+            self._patch["gen"] = (len(P), 10)
+            e._call(P, lib.vmmt_gen_dW_finish, dt, self.gen_P.data_ptr(), self.gen_ldp, self.gen_cs.data_ptr(), Og.p(), Og.ld,
+                    self.gen_y32.data_ptr(), M, V, Kp, inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"))
         else:
             e._wait(P, "GT")
             e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1)   # plain store
