@@ -1026,7 +1026,7 @@ class Workspace(object):
         # underneath the LSTM backward chains instead, is 3 % slower -- 2.333 vs 2.264 ms)
         e._sid = SIDE
         e._wait(P, "bwd_begin")
-        if self.gen_fused:
+        def gen_dw():
             # dWg[slice s] = P[:, slice s]^T O'_s: ONE plain GEMM (K = tokens; the B operand switches with the vocabulary slice), then the
             # bias gradient and the one-hot term
             Kp = _ru(H, KPAD)
@@ -1036,6 +1036,10 @@ class Workspace(object):
             self._patch["gen"] = (len(P), 10)
             e._call(P, lib.vmmt_gen_dW_finish, dt, self.gen_P.data_ptr(), self.gen_ldp, self.gen_cs.data_ptr(), Og.p(), Og.ld,
                     self.gen_y32.data_ptr(), M, V, Kp, inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"))
+        if self.gen_fused:
+            # right away: issued later (on the aux stream behind the image / q(z|x) backward, i.e. underneath the LSTM backward chains) the
+            # GEMM takes the CUs the persistent LSTM kernels need -- 2.37 against 2.06 ms per step (tools/ab.py)
+            gen_dw()
         else:
             e._wait(P, "GT")
             e._gemm(P, L.GEMM_NN, self.GT.p(), self.GT.ld, self.O.p(), self.O.ld, e.gp("generator.0.weight"), H, V, H, M, out_f32=1)   # plain store
