@@ -268,7 +268,9 @@ def main():
         timed_fn.__name__ = name
         plan[index] = (timed_fn, args, name, keep, sid)
 
-    wrap(ws0.plan_loss_train, 0, "gen_fwd")
+    for j, (fn, args, name, keep, sid) in enumerate(ws0.plan_loss_train):
+        if name in ("vmmt_gen_fwd_dO", "vmmt_gen_loss_fwd"):
+            wrap(ws0.plan_loss_train, j, "gen_fwd")
 
     for i in range(a.warmup):
         step(i)

@@ -23,6 +23,9 @@ for name, kv in cfgs:
         assert hasattr(e, k), k
         setattr(e, k, v)
     e.set_image_table(table)
+    if engs:        # all arms on the SAME streams: a process has few hardware queues, and the streams of a second engine share them
+        for attr in ("side_stream", "_side_stream_plain", "aux_stream", "compute_stream"):
+            setattr(e, attr, getattr(engs[0], attr))
     engs.append(e)
 
 def run(e, n):

@@ -1038,7 +1038,7 @@ class Workspace(object):
                     self.gen_y32.data_ptr(), M, V, Kp, inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"))
         if self.gen_fused:
             # right away: issued later (on the aux stream behind the image / q(z|x) backward, i.e. underneath the LSTM backward chains) the
-            # GEMM takes the CUs the persistent LSTM kernels need -- 2.37 against 2.06 ms per step (tools/ab.py)
+            # GEMM competes with the persistent LSTM kernels for CUs -- 2.20 against 2.11-2.13 ms per step (tools/ab.py, arms on shared streams)
             gen_dw()
         else:
             e._wait(P, "GT")
