@@ -243,7 +243,7 @@ def main():
         ws = eng.forward(src, sl, tgt, idx, training=True, tgt_len=tlen if a.conditional else None)
         eng.loss_backward(ws, normalization=Bg, batch_global=Bg)
         sync.all_reduce()          # waits for the segment all-reduces the backward plan issued behind each segment
-        eng.optim_step(lr=0.002, max_grad_norm=5.0, defer=True)      # training-loop form: see Engine.optim_step
+        eng.optim_step(lr=0.002, max_grad_norm=5.0)
         return ws
 
     # ---- dominant-kernel timing hooks: events on the launch stream around the generator kernels -----------------
@@ -288,7 +288,6 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         ws = step(a.warmup + i)
-    eng.flush_pending()           # the last step's deferred half of Adam belongs to the timed region
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

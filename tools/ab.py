@@ -33,7 +33,7 @@ def run(e, n):
         src, sl, tgt, idx = bs[i % 4]
         ws = e.forward(src, sl, tgt, idx, training=True)
         e.loss_backward(ws, normalization=256, batch_global=256)
-        e.optim_step(defer=True)
+        e.optim_step()
 
 for e in engs:
     run(e, 6)
@@ -44,7 +44,6 @@ for rnd in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(e, 20)
-        e.flush_pending()
         torch.cuda.synchronize()
         res[name].append((time.perf_counter() - t0) / 20 * 1e3)
 for name, _ in cfgs:

@@ -20,8 +20,9 @@
 //   dL/dWg[v in slice s] = sum_m P[m][v] O'_s[m] - (one-hot term): one vmmt_gemm (the B operand switches with the slice:
 //     vmmt_gemm_args.b_batch_rows) on the side stream, where it shares the chip with the LSTM backward chains, followed by
 //     vmmt_gen_dW_finish (bias gradient = weighted column sums of P; one-hot term by atomics).
-//   (A second flash-shaped sweep for dWg -- no P in memory -- was built and measured: 976 TFLOP/s, but its workgroups own whole CUs
-//    (132 KB of LDS, 512 registers per lane), so it serialises with everything else: 2.26 against 2.16 ms per step.  Removed.)
+//   (A second flash-shaped sweep for dWg -- no P in memory -- was built and measured: 976 TFLOP/s in isolation, but its workgroups own
+//    whole CUs (132 KB of LDS, 512 registers per lane), so it serialises with whatever stream it is put on; the step came out the
+//    same within box-to-box noise (2.06-2.19 ms either way).  Removed: the GEMM shares the chip and is 300 lines less.)
 //
 // Kernel structure: the "row" operand X = O (128 rows per workgroup, 32 per wave) stays resident for the whole kernel as MFMA
 // B-operand fragments (half of the k-steps in registers, half in LDS); the "column" operand Y = Wg streams through a two-deep ring

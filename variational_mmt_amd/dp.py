@@ -80,7 +80,6 @@ class GradSync(object):
         if self.world == 1 or self.engine is None:
             return
         e = self.engine
-        e.flush_pending()
         for t in (e.flat_p, e.flat_m, e.flat_v):
             self.dist.broadcast(t, src)
         e.shadows_dirty = True
@@ -89,7 +88,6 @@ class GradSync(object):
         """debug / test aid: True when every rank holds bit-identical parameters (one 8-byte all-reduce pair)"""
         if self.world == 1 or self.engine is None:
             return True
-        self.engine.flush_pending()
         p = self.engine.flat_p
         h = torch.stack([p.double().sum(), p.double().abs().sum()])
         lo, hi = h.clone(), h.clone()

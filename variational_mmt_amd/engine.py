@@ -177,8 +177,6 @@ class Engine(object):
         self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
         self._sumsq_by_plan = False
         self.fused_qnet = _os_env.get("VMMT_FUSED_QNET", "1") == "1"
-        self.defer_bg_adam = _os_env.get("VMMT_DEFER_BG_ADAM", "1") == "1"   # see optim_step(defer=True)
-        self._pending_bg = None
         self.gen_fused = _os_env.get("VMMT_GEN_FUSED", "1") == "1"       # csrc/generator_fused.hip where it applies (bf16, H = 512 / 256)
         self.persistent_lstm = _os_env.get("VMMT_PERSISTENT_LSTM", "1") == "1"     # plans are built per workspace: set before the first forward
         self.seq_syncs = []
@@ -237,14 +235,12 @@ class Engine(object):
         return self.flat_g.data_ptr() + (o + r * ld + c) * 4
 
     def load_state_dict(self, sd):
-        self.flush_pending()
         for n, t in sd.items():
             if n in self.params:
                 self.params[n].copy_(t.to(torch.float32))
         self.shadows_dirty = True
 
     def state_dict(self):
-        self.flush_pending()
         sd = {n: v.detach().clone() for n, v in self.params.items()}
         if self.d.conditional:      # encoder_tgt shares the decoder's table; the reference's state dict lists it under both names
             sd["encoder_tgt.embeddings.make_embedding.emb_luts.0.weight"] = sd["decoder.embeddings.make_embedding.emb_luts.0.weight"]
@@ -472,15 +468,6 @@ class Engine(object):
                 L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq")
                 self._sumsq_by_plan = True
                 return
-            if name == "BG_ADAM":
-                bg, self._pending_bg = self._pending_bg, None
-                if bg is not None:
-                    for ename in args:                     # behind the main stream's progress marks of this forward
-                        ev = events.get(ename)
-                        if ev is not None:
-                            self.side_stream.wait_event(ev)
-                    bg()
-                return
             if name == "KL_ALLREDUCE":
                 if self.dp is not None and self.dp.world > 1:
                     ws = self._cur_ws
@@ -696,7 +683,6 @@ class Workspace(object):
         # ---- side stream, underneath the encoder: zero the gradient arena (every gradient writer of the backward plan
         #      runs on the side stream), target embeddings and the time-parallel part of the decoder input projection
         e._sid = SIDE
-        side_lo = len(P)
         e._wait(P, "fwd_begin")
         e._record(P, "side_fwd")
         if training:
@@ -728,7 +714,6 @@ class Workspace(object):
             e._sid = MAIN
         self._img_idx[bool(training)] = len(P)
         e._call(P, lib.vmmt_gather_rows, L.F32, None, D, self.img_idx.data_ptr(), self.img.p(), self.img.ld, B, D)
-        side_hi = len(P) if not d.conditional else side_lo      # (conditional: the segment is not moved)
         e._sid = MAIN
         # a2 source embeddings
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
@@ -739,22 +724,6 @@ class Workspace(object):
             wih, bsum = e.sh["enc_wih_l%d" % l], e.sh["enc_b_l%d" % l]
             e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hd,
                     xcols, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
-            if l == 0 and e.defer_bg_adam and side_hi > side_lo:
-                # deferred background half of Adam: the side-stream segment above (which needs the decoder-side parameters) is issued
-                # HERE, behind the encoder's input projection, with the pending optimiser work in front of it
-                self.has_bg_entry = True
-                e._record(P, "enc_in")
-                seg = P[side_lo:side_hi]
-                moved = len(P) - side_hi
-                del P[side_lo:side_hi]
-                P.append((None, ("enc_in",), "BG_ADAM", None, SIDE))
-                base = len(P)
-                P.extend(seg)
-                shift = base - side_lo
-                if "dec_out" in self._mask_entries and side_lo <= self._mask_entries["dec_out"][0] < side_hi:
-                    self._mask_entries["dec_out"] = (self._mask_entries["dec_out"][0] + shift, self._mask_entries["dec_out"][1])
-                if side_lo <= self._img_idx[bool(training)] < side_hi:
-                    self._img_idx[bool(training)] += shift
             seq = (L.LstmDirFwd * (S * dirs))()                 # the whole recurrence: step-major, then direction
             if not hasattr(self, "hzero"):
                 self.hzero = Buf(B, H, e.T, e.dev)              # first step: h_prev reads zeros
@@ -1540,8 +1509,6 @@ def _engine_methods():
                 else:
                     ws.plan_fwd_train[ii] = (fn, (args[0], args[1], buf.rows * buf.ld, args[3], self.rng_counter), name, keep, sid)
         plan = ws.plan_fwd_train if training else ws.plan_fwd_eval
-        if not getattr(ws, "has_bg_entry", False):
-            self.flush_pending()          # this plan does not carry the deferred half of Adam (conditional model): issue it now
         ii = ws._img_idx[bool(training)]
         fn, args, name, keep, sid = plan[ii]
         plan[ii] = (fn, (L.F32, tab.data_ptr(), tab.shape[1]) + tuple(args[3:]), name, keep, sid)
@@ -1593,24 +1560,11 @@ def _engine_methods():
                     elbo=nmt - img_logprob + kl_after, n_words=int(round(s[L.STAT_NWORDS])),
                     n_correct=int(round(s[L.STAT_NCORRECT])))
 
-    def flush_pending(self):
-        """issue the deferred background half of the last optimiser step now (see optim_step(defer=True)): after this every
-        parameter, moment and compute shadow on the device queues is the updated one"""
-        bg, self._pending_bg = self._pending_bg, None
-        if bg is not None:
-            bg()
-
-    def optim_step(self, lr=0.002, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-9, grad_scale=1.0, defer=False):
+    def optim_step(self, lr=0.002, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-9, grad_scale=1.0):
         """Optim.step (Optim.py:78-96): global-norm clip + Adam over the arena, then the compute shadows are refreshed.
         The arena is updated in two halves: [encoder | inference networks] on the current stream (the next forward needs
         them first), [generator | attention | decoder] on the side stream, where it overlaps the next step's encoder
-        phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights.
-        defer=True (training loops: the trainer mirror, bench.py): that background half is not issued here but by the NEXT forward
-        plan, behind the encoder's input projection, so that the first kernels of the step (token / embedding gathers, input GEMM)
-        do not share HBM with 1.1 GB of optimiser traffic (2.264 -> 2.224 ms/step, tools/ab.py).  Until then the decoder-side
-        parameters on the device are the OLD ones: everything that reads them outside a forward plan (state_dict, checkpoints,
-        replica broadcast, another optim_step) calls flush_pending() first."""
-        self.flush_pending()
+        phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights."""
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
         if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
@@ -1638,10 +1592,7 @@ def _engine_methods():
                 adam(0, split, side.cuda_stream)
                 self._pack_part(1, side.cuda_stream)
                 self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
-            if defer and self.defer_bg_adam:
-                self._pending_bg = background
-            else:
-                background()
+            background()
         else:
             adam(0, self.n_opt, st)
             self._pack_part(0, st)

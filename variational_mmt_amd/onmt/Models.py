@@ -64,11 +64,9 @@ class NMTVIModel(nn.Module):
         pass          # the gradient arena is zeroed by the training forward plan (side stream)
 
     def state_dict(self, *args, **kwargs):
-        self.engine.flush_pending()          # a deferred background half of the last optimiser step (Engine.optim_step(defer=True))
         return super(NMTVIModel, self).state_dict(*args, **kwargs)
 
     def load_state_dict(self, state_dict, strict=True):
-        self.engine.flush_pending()
         out = super(NMTVIModel, self).load_state_dict(state_dict, strict=strict)
         self.engine.shadows_dirty = True
         return out

@@ -31,7 +31,6 @@ class _ArenaAdam(object):
         if o is None or o.engine is None:
             return self._saved or {"state": {}, "param_groups": self.param_groups}
         e = o.engine
-        e.flush_pending()
         state = {}
         for i, p in enumerate(o.params):
             name = getattr(p, "_vmmt_name", None)
@@ -147,10 +146,8 @@ class Optim(object):
             self._set_rate(self.original_lr * (self.model_size ** (-0.5) *
                                                min(self._step ** (-0.5), self._step * self.warmup_steps ** (-1.5))))
         if self.method == "adam":
-            # defer=True: the decoder-side half of the update is issued by the next forward (Engine.optim_step); whatever reads the
-            # parameters in between goes through model.state_dict() / Engine.flush_pending()
             self.engine.optim_step(lr=self.lr, max_grad_norm=self.max_grad_norm or 0.0, beta1=self.betas[0], beta2=self.betas[1],
-                                   eps=1e-9, defer=True)
+                                   eps=1e-9)
         else:
             if self.max_grad_norm:
                 torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
@@ -177,7 +174,6 @@ class Optim(object):
         if e is None or not isinstance(self.optimizer, _ArenaAdam):
             d["params"] = []
             return d
-        e.flush_pending()
         shared = getattr(self, "_ckpt_cpu", None) or {}        # CPU copies the trainer already made for checkpoint['model']
         cpu_params = []
         for p in self.params:
