@@ -51,6 +51,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define G2_HB(i) ((i) >> 1)
 #define G2_KK(i) ((i) & 1)
+constexpr int G2_COMBINE_GROUPS = 1;          // groups of 8 tokens per workgroup of the combine kernel
 constexpr float G2_L2E = 1.4426950408889634f;
 constexpr float G2_THR = 60.f;             // lazy-reference slack (natural-log units): exp(60) ~ 1e26 stays far inside bf16 / f32 range
 
@@ -139,7 +140,10 @@ __device__ __forceinline__ u32x4 g2_lds_read_b128(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
   return r;
 }
-__device__ __forceinline__ void g2_wait_lgkm0(u32x4& a, u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+template <int N>
+__device__ __forceinline__ void g2_wait_lgkm_seg(fs16x4& a, fs16x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
 
 template <int I, int N, class F>
 __device__ __forceinline__ void g2_static_for(F&& f) {
@@ -313,6 +317,7 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
     G2_STAMP(2);
     // ---- element-wise: S^T -> P^T (bf16 B-operand fragments of the second product: k-step kk = accumulator registers 8 kk .. 8 kk + 7)
     bf16x8 pf[2];
+    u32x4 seg[2];                                           // P output: two 16-byte row segments per lane (see below)
     if (c0 + C::BC > a.ncols) {                           // last tile of the vocabulary: rows >= V do not exist
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -380,18 +385,12 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
       g2_lds_write_b64<16>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[0]), __builtin_bit_cast(fs16x8, pf[0]), 4, 5, 6, 7));
       g2_lds_write_b64<32>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[1]), __builtin_bit_cast(fs16x8, pf[1]), 0, 1, 2, 3));
       g2_lds_write_b64<48>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[1]), __builtin_bit_cast(fs16x8, pf[1]), 4, 5, 6, 7));
-      u32x4 seg[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int q = lane + 64 * j;
         seg[j] = g2_lds_read_b128(patch + (q >> 2) * C::PPITCH + (q & 3) * 16);
       }
-      g2_wait_lgkm0(seg[0], seg[1]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int q = lane + 64 * j, prow = q >> 2, ch = q & 3;
-        if (R0 + prow < a.nrows) *reinterpret_cast<u32x4*>(a.p_out + (long)(R0 + prow) * a.ldp + c0 + ch * 8) = seg[j];
-      }
+      // (the segments are stored behind the first MFMA of the second product: its operand wait covers these older reads too)
     }
 
     G2_STAMP(3);
@@ -413,11 +412,22 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
       g2_static_for<0, NM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int inflight = 2 * ((PD - 1) < (NM - 1 - i) ? (PD - 1) : (NM - 1 - i));
-        g2_wait_lgkm<inflight>(fl[i % PD], fh[i % PD]);
+        if constexpr (i == 0) g2_wait_lgkm_seg<inflight>(fl[0], fh[0], seg[0], seg[1]);
+        else g2_wait_lgkm<inflight>(fl[i % PD], fh[i % PD]);
         const fs16x8 v = __builtin_shufflevector(fl[i % PD], fh[i % PD], 0, 1, 2, 3, 4, 5, 6, 7);
         __builtin_amdgcn_sched_barrier(0);
         acc[G2_HB(i)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), pf[G2_KK(i)], acc[G2_HB(i)], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i == 0) {
+          if (a.p_out) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int q = lane + 64 * j, prow = q >> 2, ch = q & 3;
+              if (R0 + prow < a.nrows) *reinterpret_cast<u32x4*>(a.p_out + (long)(R0 + prow) * a.ldp + c0 + ch * 8) = seg[j];
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (i + PD < NM) rd(std::integral_constant<int, i + PD>{});
       });
     }
@@ -469,7 +479,7 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
                                                            const float* __restrict__ tgt_logit, const long long* __restrict__ y, int M, int pad,
                                                            float inv_norm, const bf16_t* __restrict__ W, long ldw,
                                                            float* __restrict__ lse, float* __restrict__ tok_nll,
-                                                           int* __restrict__ y32, float* __restrict__ dO, long lddo, float* __restrict__ stats,
+                                                           int* __restrict__ y32, float* __restrict__ dO, long lddo, float* __restrict__ blk_part,
                                                            const bf16_t* __restrict__ O, long ldo, float* __restrict__ cs,
                                                            bf16_t* __restrict__ Os, long ldos, long os_stride) {
   constexpr int MAXS = 16;
@@ -477,64 +487,77 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
   __shared__ float s_c[8][MAXS];
   __shared__ float s_invl[8], s_sc[8];
   __shared__ int s_y[8];
-  const int tid = threadIdx.x, m0 = blockIdx.x * 8;
-  if (tid < 64) {                                           // wave 0: lanes 0..7 = the block's tokens
-    const int m = m0 + tid;
+  const int tid = threadIdx.x;
+  float nll_t = 0.f, nw_t = 0.f, nc_t = 0.f;              // statistics of this wave's tokens: three atomics per wave at the very end
+  for (int it = 0; it < G2_COMBINE_GROUPS; ++it) {
+  const int m0 = (blockIdx.x * G2_COMBINE_GROUPS + it) * 8;
+  if (it) __syncthreads();                                  // the previous group's readers are done with s_w / s_c / ...
+  if (tid < 128) {
+    // waves 0-1: lane group of 16 = one token, lane s of the group = vocabulary slice s (one round trip for all partials)
+    const int tk = tid >> 4, sl = tid & 15, m = m0 + tk;
+    const bool live = m < M && sl < nsplit;
+    const float r_s = live ? p_ref[(long)sl * mpad + m] : -INFINITY;
+    const float l_s = live ? p_l[(long)sl * mpad + m] : 0.f;
+    float mx = live ? p_max[(long)sl * mpad + m] : -INFINITY;
+    float rstar = r_s;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { rstar = fmaxf(rstar, __shfl_xor(rstar, o, 16)); mx = fmaxf(mx, __shfl_xor(mx, o, 16)); }
+    const float w = live ? __expf(r_s - rstar) : 0.f;
+    float l = w * l_s;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) l += __shfl_xor(l, o, 16);
     float nll = 0.f, nw = 0.f, nc = 0.f;
-    if (tid < 8) {
-      if (m < M) {
-        float rstar = -INFINITY, mx = -INFINITY;
-        for (int s = 0; s < nsplit; ++s) { rstar = fmaxf(rstar, p_ref[(long)s * mpad + m]); mx = fmaxf(mx, p_max[(long)s * mpad + m]); }
-        float l = 0.f;
-        for (int s = 0; s < nsplit; ++s) {
-          const float w = __expf(p_ref[(long)s * mpad + m] - rstar);
-          s_w[tid][s] = w;
-          l += w * p_l[(long)s * mpad + m];
-        }
-        const float ls = rstar + logf(l);
-        const long long ym = y[m];
-        const bool wv = ym != pad;
+    if (m < M) {
+      const float ls = rstar + logf(l);
+      const long long ym = y[m];
+      const bool wv = ym != pad;
+      const float sc = wv ? inv_norm : 0.f;
+      // slice s stored its softmax weights in units of exp(ref_s): dL/dlogit[m][v] = P[m][v] c_s[m] - [v == y_m] s_m
+      const float c = live ? sc * __expf(r_s - ls) : 0.f;
+      s_w[tk][sl] = w; s_c[tk][sl] = c;
+      if (cs && sl < nsplit) cs[(long)sl * mpad + m] = c;
+      if (sl == 0) {
+        const float tl = tgt_logit[m];
         lse[m] = ls;
-        nll = wv ? ls - tgt_logit[m] : 0.f;
+        nll = wv ? ls - tl : 0.f;
         tok_nll[m] = nll;
         nw = wv ? 1.f : 0.f;
-        nc = (wv && tgt_logit[m] >= mx) ? 1.f : 0.f;         // accuracy: the target's logit is the row maximum (Loss.py:150-160)
-        const float sc = wv ? inv_norm : 0.f;
+        nc = (wv && tl >= mx) ? 1.f : 0.f;                  // accuracy: the target's logit is the row maximum (Loss.py:150-160)
         y32[m] = wv ? (int)ym : -1;
-        s_invl[tid] = 1.f / l; s_sc[tid] = sc; s_y[tid] = (int)ym;
-        // slice s stored its softmax weights in units of exp(ref_s): dL/dlogit[m][v] = P[m][v] c_s[m] - [v == y_m] s_m
-        for (int s = 0; s < nsplit; ++s) {
-          const float c = sc * __expf(p_ref[(long)s * mpad + m] - ls);
-          s_c[tid][s] = c;
-          if (cs) cs[(long)s * mpad + m] = c;
-        }
-      } else {
+        s_invl[tk] = 1.f / l; s_sc[tk] = sc; s_y[tk] = (int)ym;
+      }
+    } else {
+      s_w[tk][sl] = 0.f; s_c[tk][sl] = 0.f;
+      if (sl == 0) {
         if (m < ((M + 31) / 32) * 32) y32[m] = -1;
-        s_sc[tid] = 0.f; s_invl[tid] = 0.f; s_y[tid] = 0;
-        for (int s = 0; s < nsplit; ++s) s_w[tid][s] = 0.f;
+        s_sc[tk] = 0.f; s_invl[tk] = 0.f; s_y[tk] = 0;
       }
     }
-    nll = wave_sum(nll); nw = wave_sum(nw); nc = wave_sum(nc);
-    if (tid == 0) {
-      atomicAdd(stats + VMMT_STAT_NLL, nll);
-      atomicAdd(stats + VMMT_STAT_NWORDS, nw);
-      atomicAdd(stats + VMMT_STAT_NCORRECT, nc);
-    }
+    nll_t += nll; nw_t += nw; nc_t += nc;
   }
   __syncthreads();
   const int tk = tid >> 5, j = tid & 31, m = m0 + tk;
-  if (m >= M) return;
+  if (m < M) {
   const float invl = s_invl[tk], sc = s_sc[tk];
   const bf16_t* wr = W + (long)s_y[tk] * ldw;
 #pragma unroll
   for (int c = 0; c < D / 128; ++c) {
     const int h = c * 128 + j * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nsplit; ++s) {
-      const f32x4 pa = *reinterpret_cast<const f32x4*>(p_acc + ((long)s * mpad + m) * D + h);
-      const float w = s_w[tk][s];
+    // the slices' partials eight at a time: independent loads in flight (the kernel is latency-bound: 2.5 workgroups per CU)
+    for (int s0 = 0; s0 < nsplit; s0 += 8) {
+      f32x4 pa[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(w, pa[e], v[e]);
+      for (int u = 0; u < 8; ++u) {
+        const int sc_ = s0 + u < nsplit ? s0 + u : nsplit - 1;
+        pa[u] = *reinterpret_cast<const f32x4*>(p_acc + ((long)sc_ * mpad + m) * D + h);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float w = s0 + u < nsplit ? s_w[tk][(s0 + u) & (MAXS - 1)] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(w, pa[u][e], v[e]);
+      }
     }
     const uint2 wb = *reinterpret_cast<const uint2*>(wr + h);
     const float w4[4] = {__uint_as_float(wb.x << 16), __uint_as_float(wb.x & 0xffff0000u), __uint_as_float(wb.y << 16),
@@ -554,6 +577,37 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
         *reinterpret_cast<uint2*>(Os + s * os_stride + (long)m * ldos + h) = r;
       }
     }
+  }
+  }
+  }
+  if (tid < 128) {
+    // statistics: per-wave partial sums into scratch, folded by gen2_stats_kernel (thousands of same-address atomics cost ~10-20 ns
+    // each: with them this kernel took 70 us instead of 35)
+    nll_t = wave_sum(nll_t); nw_t = wave_sum(nw_t); nc_t = wave_sum(nc_t);
+    if ((tid & 63) == 0) {
+      float* bp = blk_part + ((long)blockIdx.x * 2 + (tid >> 6)) * 3;
+      bp[0] = nll_t; bp[1] = nw_t; bp[2] = nc_t;
+    }
+  }
+}
+
+// stats[NLL, NWORDS, NCORRECT] += the combine kernel's per-wave partial sums (one workgroup; fixed order: reproducible)
+__global__ void __launch_bounds__(256) gen2_stats_kernel(const float* __restrict__ blk_part, int n, float* __restrict__ stats) {
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) a[e] += blk_part[(long)i * 3 + e];
+  __shared__ float red[4][3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) a[e] = wave_sum(a[e]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) red[threadIdx.x >> 6][e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int e = threadIdx.x;
+    const int slot = e == 0 ? VMMT_STAT_NLL : e == 1 ? VMMT_STAT_NWORDS : VMMT_STAT_NCORRECT;
+    stats[slot] += red[0][e] + red[1][e] + red[2][e] + red[3][e];
   }
 }
 
@@ -647,7 +701,8 @@ extern "C" int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M
 
 extern "C" int64_t vmmt_gen_fused_ws_floats(int M, int V, int K) {
   const int64_t mpad = (int64_t)((M + 127) / 128) * 128;
-  return (int64_t)vmmt::g2_nsplit(M, V) * mpad * (K + 3);
+  // partial accumulators + (ref, l, max) per slice, + the combine kernel's per-wave statistics (2 x 3 floats per 8 tokens)
+  return (int64_t)vmmt::g2_nsplit(M, V) * mpad * (K + 3) + (mpad / 8 + 4) * 6;
 }
 
 extern "C" int vmmt_gen_fused_geometry(int M, int V, int* nsplit, int* v_per_split, int64_t* mpad) {
@@ -685,14 +740,17 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const floa
   int rc = K == 512 ? g2_launch<512>(a, nmt * ns, st) : g2_launch<256>(a, nmt * ns, st);
   if (rc) return rc;
   const int mt = (M + 31) / 32 * 32;
+  float* blk_part = a.p_max + (long)ns * mpad;
+  const int ncb = (mt + 8 * G2_COMBINE_GROUPS - 1) / (8 * G2_COMBINE_GROUPS);
   if (K == 512)
-    hipLaunchKernelGGL((gen2_combine_kernel<512>), dim3((mt + 7) / 8), dim3(256), 0, st, a.p_acc, a.p_ref, a.p_l, a.p_max, mpad, ns, tgt_logit,
-                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, stats,
+    hipLaunchKernelGGL((gen2_combine_kernel<512>), dim3(ncb), dim3(256), 0, st, a.p_acc, a.p_ref, a.p_l, a.p_max, mpad, ns, tgt_logit,
+                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
                        (const bf16_t*)O, (long)ldo, Pw ? cs : nullptr, Pw ? (bf16_t*)Os : nullptr, (long)ldos, (long)os_stride);
   else
-    hipLaunchKernelGGL((gen2_combine_kernel<256>), dim3((mt + 7) / 8), dim3(256), 0, st, a.p_acc, a.p_ref, a.p_l, a.p_max, mpad, ns, tgt_logit,
-                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, stats,
+    hipLaunchKernelGGL((gen2_combine_kernel<256>), dim3(ncb), dim3(256), 0, st, a.p_acc, a.p_ref, a.p_l, a.p_max, mpad, ns, tgt_logit,
+                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
                        (const bf16_t*)O, (long)ldo, Pw ? cs : nullptr, Pw ? (bf16_t*)Os : nullptr, (long)ldos, (long)os_stride);
+  hipLaunchKernelGGL(gen2_stats_kernel, dim3(1), dim3(256), 0, st, blk_part, ncb * 2, stats);
   return check_launch();
 }
 
