@@ -620,14 +620,22 @@ __global__ void __launch_bounds__(256) gen2_db_kernel(const bf16_t* __restrict__
   float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (v0 < V) {
     const float* c = cs + (long)(v0 / v_per_split) * mpad;
-    for (int m = m0 + w; m < m1; m += 4) {
-      const u32x4 pw = *reinterpret_cast<const u32x4*>(P + (long)m * ldp + v0);
-      const float cm = c[m];
+    for (int mb = m0 + w; mb < m1; mb += 32) {             // eight rows in flight per lane
+      u32x4 pw[8];
+      float cm[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a8[2 * e] = __builtin_fmaf(__uint_as_float(pw[e] << 16), cm, a8[2 * e]);
-        a8[2 * e + 1] = __builtin_fmaf(__uint_as_float(pw[e] & 0xffff0000u), cm, a8[2 * e + 1]);
+      for (int u = 0; u < 8; ++u) {
+        const int m = mb + 4 * u < m1 ? mb + 4 * u : m1 - 1;
+        pw[u] = *reinterpret_cast<const u32x4*>(P + (long)m * ldp + v0);
+        cm[u] = mb + 4 * u < m1 ? c[m] : 0.f;
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a8[2 * e] = __builtin_fmaf(__uint_as_float(pw[u][e] << 16), cm[u], a8[2 * e]);
+          a8[2 * e + 1] = __builtin_fmaf(__uint_as_float(pw[u][e] & 0xffff0000u), cm[u], a8[2 * e + 1]);
+        }
     }
   }
   __shared__ float red[4][64][9];

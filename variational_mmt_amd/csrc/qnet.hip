@@ -88,12 +88,24 @@ __global__ void __launch_bounds__(512) qnet_fwd_kernel(QnetArgs a) {
       float acc[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-      for (int s = 0; s < len; ++s) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(a.ctx + ((long)s * B + b) * a.ldc + c0);
+      // eight positions per round trip (the sum itself stays in time order: same bits as vmmt_masked_mean); one load per trip
+      // made this phase ~40 us of back-to-back memory latencies
+      for (int s0 = 0; s0 < len; s0 += 8) {
+        u32x4 v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[2 * e] += __uint_as_float(v[e] << 16);
-          acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+        for (int u = 0; u < 8; ++u) {
+          const int sp = s0 + u < len ? s0 + u : len - 1;
+          v[u] = *reinterpret_cast<const u32x4*>(a.ctx + ((long)sp * B + b) * a.ldc + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (s0 + u < len) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[2 * e] += __uint_as_float(v[u][e] << 16);
+              acc[2 * e + 1] += __uint_as_float(v[u][e] & 0xffff0000u);
+            }
+          }
         }
       }
       u32x4 o;
