@@ -218,17 +218,17 @@ int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bia
                          int64_t ldgt, float* dbias, int v_off, void* stream);
 
 /* ---- the same loss with dL/dO in ONE sweep of Wg (csrc/generator_fused.hip; bf16, K = 512 or 256) --------------------
- * vmmt_gen_fwd_dO replaces vmmt_gen_loss_fwd + vmmt_gen_loss_bwd_db + the dO GEMM of the training step: per 128-token block and
- * vocabulary slice (vmmt-chosen: vmmt_gen_fused_geometry) a flash-attention-shaped sweep accumulates the softmax statistics and
- * the un-normalised dO; a combine kernel folds the slices.
- *   out: lse, tok_nll, tgt_logit f32 [M]; stats[NLL,NWORDS,NCORRECT] += sums; dO f32 [M][lddo] = s_m (softmax_m Wg - Wg[y_m]),
- *        s_m = [y_m != pad] inv_norm; y32 int32 [(M+31)/32*32]: targets, -1 at pads and beyond M.
- *   ws : vmmt_gen_fused_ws_floats(M, V, K) floats of scratch.
- * For dL/dWg it also stores (P != NULL; the training step always asks for them)
- *   P   T [M][ldp]  (ldp >= V rounded up to 32): un-normalised softmax weights exp(logit - ref_s[m]) of slice s = v / v_per_split;
- *   cs  f32 [nsplit][mpad]: c_s[m] = s_m exp(ref_s[m] - lse_m), so that dL/dlogit[m][v] = P[m][v] c_s[m] - [v == y_m] s_m;
- *   Os  T [nsplit][os_stride]: O'_s[m][:] = c_s[m] O[m][:] (rows ld ldos; rows >= M are never written: keep them zero),
- * so that dWg[v in slice s][:] = sum_m P[m][v] O'_s[m][:] is ONE vmmt_gemm (GEMM_TN, K = M, b_batch_rows = v_per_split,
+ * vmmt_gen_fwd_dO + vmmt_gen_fwd_combine replace vmmt_gen_loss_fwd + vmmt_gen_loss_bwd_db + the dO GEMM of the training step.
+ *   vmmt_gen_fwd_dO: per 128-token block and vocabulary slice (vmmt-chosen: vmmt_gen_fused_geometry) a flash-attention-shaped sweep
+ *     accumulates the softmax statistics and the un-normalised dO = sum_v P[m][v] Wg[v] into `ws`
+ *     (vmmt_gen_fused_ws_floats(M, V, K) floats) and writes tgt_logit f32 [M].  P != NULL (the training step): it also stores
+ *     P T [M][ldp] (ldp >= V rounded up to 32), the un-normalised softmax weights exp(logit - ref_s[m]) of slice s = v / v_per_split.
+ *   vmmt_gen_fwd_combine: folds the slices.  out: lse, tok_nll f32 [M]; stats[NLL,NWORDS,NCORRECT] += sums;
+ *     dO f32 [M][lddo] = s_m (softmax_m Wg - Wg[y_m]), s_m = [y_m != pad] inv_norm; y32 int32 [(M+31)/32*32]: targets, -1 at pads
+ *     and beyond M.  cs / Os != NULL (both or neither):
+ *       cs  f32 [nsplit][mpad]: c_s[m] = s_m exp(ref_s[m] - lse_m), so that dL/dlogit[m][v] = P[m][v] c_s[m] - [v == y_m] s_m;
+ *       Os  T [nsplit][os_stride]: O'_s[m][:] = c_s[m] O[m][:] (rows ld ldos; rows >= M are never written: keep them zero).
+ * Then dWg[v in slice s][:] = sum_m P[m][v] O'_s[m][:] is ONE vmmt_gemm (GEMM_TN, K = M, b_batch_rows = v_per_split,
  * b_batch_stride = os_stride, plain store) and vmmt_gen_dW_finish adds the bias gradient and the one-hot term.
  * vmmt_gen_fused_applies() tells whether the shape is served (otherwise VMMT_EINVAL: the caller uses the G^T path above).
  * Reference: the same lines as above (ModelConstructor.py:583-585, Loss.py:129,163-165). */
@@ -236,9 +236,10 @@ int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M, int V, in
 int64_t vmmt_gen_fused_ws_floats(int M, int V, int K);
 int vmmt_gen_fused_geometry(int M, int V, int* nsplit, int* v_per_split, int64_t* mpad);
 int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, const int64_t* y,
-                    int M, int V, int K, int pad, float inv_norm, float* ws, float* tgt_logit, float* lse, float* tok_nll,
-                    int* y32, float* dO, int64_t lddo, float* stats, void* P, int64_t ldp, float* cs, void* Os,
-                    int64_t ldos, int64_t os_stride, void* stream);
+                    int M, int V, int K, float* ws, float* tgt_logit, void* P, int64_t ldp, void* stream);
+int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
+                         int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
+                         float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride, void* stream);
 int vmmt_gen_dW_finish(int dtype, const void* P, int64_t ldp, const float* cs, const void* O, int64_t ldo, const int* y32, int M, int V,
                        int K, float inv_norm, float* dW, int64_t lddw, float* dbias, void* stream);
 

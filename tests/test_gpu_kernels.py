@@ -315,8 +315,9 @@ def test_generator_fused_pass_bf16(M, V, H, ramp):
     cs = torch.zeros(ns, mpad, device="cuda")
     Mk = (M + 63) // 64 * 64
     Os = torch.zeros(ns, Mk, H, device="cuda", dtype=T)
-    L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, P(bd), P(Od), H, P(yd), M, V, H, 1, inv_norm, P(ws), P(tl), P(lse), P(nll), P(y32),
-                                P(dO), H + 4, P(st), P(Pw), ldp, P(cs), P(Os), H, Mk * H, None), "gen fwd dO")
+    L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, P(bd), P(Od), H, P(yd), M, V, H, P(ws), P(tl), P(Pw), ldp, None), "gen fwd dO")
+    L.check(lib.vmmt_gen_fwd_combine(L.BF16, P(Wd), H, P(Od), H, P(yd), M, V, H, 1, inv_norm, P(ws), P(tl), P(lse), P(nll), P(y32),
+                                     P(dO), H + 4, P(st), P(cs), P(Os), H, Mk * H, None), "gen fwd combine")
     torch.cuda.synchronize()
     assert (lse.cpu().double() - lse_ref).abs().max().item() <= 2e-4 * max(1.0, lse_ref.abs().max().item())
     assert (nll.cpu().double() - nll_ref).abs().max().item() <= 5e-4 * max(1.0, nll_ref.abs().max().item())

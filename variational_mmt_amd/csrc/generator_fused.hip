@@ -721,20 +721,15 @@ extern "C" int vmmt_gen_fused_geometry(int M, int V, int* nsplit, int* v_per_spl
   return VMMT_OK;
 }
 
+// the sweep: partial softmax statistics + un-normalised dO per (128-token block, vocabulary slice) into `ws`, target logits, and
+// (Pw != NULL) the softmax weights P
 extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, const int64_t* y,
-                               int M, int V, int K, int pad, float inv_norm, float* ws, float* tgt_logit, float* lse, float* tok_nll,
-                               int* y32, float* dO, int64_t lddo, float* stats, void* Pw, int64_t ldp, float* cs, void* Os,
-                               int64_t ldos, int64_t os_stride, void* stream) {
+                               int M, int V, int K, float* ws, float* tgt_logit, void* Pw, int64_t ldp, void* stream) {
   using namespace vmmt;
-  if (!W || !bias || !O || !y || !ws || !tgt_logit || !lse || !tok_nll || !y32 || !dO || !stats || lddo < K || (lddo & 3) ||
-      (((uintptr_t)dO) & 15))
-    return VMMT_EINVAL;
-  if (Pw && (!cs || !Os || ldp < (V + 31) / 32 * 32 || (ldp & 7) || (((uintptr_t)Pw) & 15) || ldos < K || (ldos & 3) || (((uintptr_t)Os) & 7) ||
-             os_stride < (int64_t)M * ldos))
-    return VMMT_EINVAL;
+  if (!W || !bias || !O || !y || !ws || !tgt_logit) return VMMT_EINVAL;
+  if (Pw && (ldp < (V + 31) / 32 * 32 || (ldp & 7) || (((uintptr_t)Pw) & 15))) return VMMT_EINVAL;
   if (!g2_applies(dtype, W, ldw, O, ldo, M, V, K)) return VMMT_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int nmt = (M + 127) / 128, ntiles = (V + 31) / 32, ns = g2_nsplit(M, V);
+  const int nmt = (M + 127) / 128, ns = g2_nsplit(M, V);
   const long mpad = (long)nmt * 128;
   Gen2Args a{};
   a.X = (const bf16_t*)O; a.ldx = ldo; a.nrows = M;
@@ -745,19 +740,38 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const floa
   a.p_acc = ws; a.p_ref = ws + (long)ns * mpad * K; a.p_l = a.p_ref + (long)ns * mpad; a.p_max = a.p_l + (long)ns * mpad;
   a.tgt_logit = tgt_logit;
   a.p_out = (bf16_t*)Pw; a.ldp = ldp;
-  int rc = K == 512 ? g2_launch<512>(a, nmt * ns, st) : g2_launch<256>(a, nmt * ns, st);
-  if (rc) return rc;
+  return K == 512 ? g2_launch<512>(a, nmt * ns, (hipStream_t)stream) : g2_launch<256>(a, nmt * ns, (hipStream_t)stream);
+}
+
+// folds the slices of the sweep: lse, tok_nll, statistics, dO, y32 and (cs != NULL) c_s / O'_s for the dWg GEMM
+extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
+                                    int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
+                                    float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride,
+                                    void* stream) {
+  using namespace vmmt;
+  if (!W || !O || !y || !ws || !tgt_logit || !lse || !tok_nll || !y32 || !dO || !stats || lddo < K || (lddo & 3) || (((uintptr_t)dO) & 15))
+    return VMMT_EINVAL;
+  if ((cs != nullptr) != (Os != nullptr)) return VMMT_EINVAL;
+  if (cs && (ldos < K || (ldos & 3) || (((uintptr_t)Os) & 7) || os_stride < (int64_t)M * ldos)) return VMMT_EINVAL;
+  if (!g2_applies(dtype, W, ldw, O, ldo, M, V, K)) return VMMT_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nmt = (M + 127) / 128, ns = g2_nsplit(M, V);
+  const long mpad = (long)nmt * 128;
+  const float* p_acc = ws;
+  const float* p_ref = ws + (long)ns * mpad * K;
+  const float* p_l = p_ref + (long)ns * mpad;
+  const float* p_max = p_l + (long)ns * mpad;
+  float* blk_part = ws + (long)ns * mpad * (K + 3);
   const int mt = (M + 31) / 32 * 32;
-  float* blk_part = a.p_max + (long)ns * mpad;
   const int ncb = (mt + 8 * G2_COMBINE_GROUPS - 1) / (8 * G2_COMBINE_GROUPS);
   if (K == 512)
-    hipLaunchKernelGGL((gen2_combine_kernel<512>), dim3(ncb), dim3(256), 0, st, a.p_acc, a.p_ref, a.p_l, a.p_max, mpad, ns, tgt_logit,
+    hipLaunchKernelGGL((gen2_combine_kernel<512>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
                        (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
-                       (const bf16_t*)O, (long)ldo, Pw ? cs : nullptr, Pw ? (bf16_t*)Os : nullptr, (long)ldos, (long)os_stride);
+                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride);
   else
-    hipLaunchKernelGGL((gen2_combine_kernel<256>), dim3(ncb), dim3(256), 0, st, a.p_acc, a.p_ref, a.p_l, a.p_max, mpad, ns, tgt_logit,
+    hipLaunchKernelGGL((gen2_combine_kernel<256>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
                        (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
-                       (const bf16_t*)O, (long)ldo, Pw ? cs : nullptr, Pw ? (bf16_t*)Os : nullptr, (long)ldos, (long)os_stride);
+                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride);
   hipLaunchKernelGGL(gen2_stats_kernel, dim3(1), dim3(256), 0, st, blk_part, ncb * 2, stats);
   return check_launch();
 }

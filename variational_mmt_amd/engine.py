@@ -872,15 +872,18 @@ class Workspace(object):
         if training:
             self._loss_patch = None
         if training and self.gen_fused:
-            # statistics AND dO = dL/dO in one sweep of Wg (1 / normalization is patched in by loss_backward: argument 11); the softmax
-            # weights P and the per-slice scaled copies O'_s of O it leaves behind feed the dWg GEMM of the backward plan
+            # statistics AND dO = dL/dO in one sweep of Wg + the kernel that folds its vocabulary slices (1 / normalization is patched into
+            # the latter by loss_backward: argument 10); the softmax weights P and the per-slice scaled copies O'_s of O they leave
+            # behind feed the dWg GEMM of the backward plan
             assert O.ld == _ru(d.hid, KPAD)
-            self._loss_patch = (len(P), 11)
+            Kp = _ru(d.hid, KPAD)
             e._call(P, lib.vmmt_gen_fwd_dO, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(), self.M, d.vt,
-                    _ru(d.hid, KPAD), PAD, 0.0, self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.lse.data_ptr(),
-                    self.tok_nll.data_ptr(), self.gen_y32.data_ptr(), self.dO32.p(), self.dO32.ld, self.stats.data_ptr(),
-                    self.gen_P.data_ptr(), self.gen_ldp, self.gen_cs.data_ptr(), self.gen_Os.data_ptr(), self.gen_Os.shape[2],
-                    self.gen_Os.shape[1] * self.gen_Os.shape[2])
+                    Kp, self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.gen_P.data_ptr(), self.gen_ldp)
+            self._loss_patch = (len(P), 10)
+            e._call(P, lib.vmmt_gen_fwd_combine, e.dt, wg.p(), wg.ld, O.p(), O.ld, self.y.data_ptr(), self.M, d.vt, Kp, PAD, 0.0,
+                    self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.lse.data_ptr(), self.tok_nll.data_ptr(),
+                    self.gen_y32.data_ptr(), self.dO32.p(), self.dO32.ld, self.stats.data_ptr(), self.gen_cs.data_ptr(),
+                    self.gen_Os.data_ptr(), self.gen_Os.shape[2], self.gen_Os.shape[1] * self.gen_Os.shape[2])
             return P
         e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(),
                 self.M, d.vt, _ru(d.hid, KPAD), PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), None,
