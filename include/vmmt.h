@@ -250,6 +250,10 @@ int vmmt_gather_rows(int out_dtype, const float* table, int64_t ldt, const int64
                      int D, void* stream);
 /* out[c] += sum_r X[r][c], and out2[c] likewise when not NULL (bias gradients; b_ih and b_hh share one) */
 int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, float* out2, void* stream);
+/* out[ids[r]][0:D] += X[r][0:D] (f32; rows with ids[r] == pad_id are dropped): the embedding-gradient scatter-add with padding_idx
+ * (modules/Embeddings.py:118) behind the GEMM that produced X = dgates W_ih */
+int vmmt_scatter_add_rows(const float* X, int64_t ldx, const int64_t* ids, int64_t pad_id, float* out, int64_t ldo, int R, int D,
+                          void* stream);
 /* out[r] += sum_c X[r][c]  (generator bias gradient: row sums of G^T) */
 int vmmt_rowsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, void* stream);
 /* scaled dropout mask: 1/(1-p) with prob 1-p else 0 (counter-based RNG; VI_Model1.py:132, Models.py:124-129) */

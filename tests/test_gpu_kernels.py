@@ -370,3 +370,23 @@ def test_gemm_per_row_block_b_operand():
     bad = L.GemmArgs(L.BF16, L.GEMM_TN, At.data_ptr(), Mr + 4, Bs.data_ptr(), N, Cd.data_ptr(), N, Mr, N, K, 0, 0, None, 0, 0, 0, L.ACT_NONE,
                      1, 0, 1.0, None, 1, 0, 0, 100, K * N)
     assert lib.vmmt_gemm(C.byref(bad), None) != 0                   # blocks must be whole tiles (multiples of 256 rows)
+
+
+def test_scatter_add_rows_with_padding_row():
+    """vmmt_scatter_add_rows: out[ids[r]] += X[r] with the padding id dropped (modules/Embeddings.py:118) against index_add_"""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(11)
+    R, D, V = 777, 500, 300
+    X = torch.randn(R, 512, generator=g)
+    ids = torch.randint(0, V, (R,), generator=g)
+    ids[::7] = 1
+    out0 = torch.randn(V, D, generator=g)
+    Xd, idd, od = X.cuda(), ids.cuda(), out0.clone().cuda()
+    L.check(lib.vmmt_scatter_add_rows(C.c_void_p(Xd.data_ptr()), 512, C.c_void_p(idd.data_ptr()), 1, C.c_void_p(od.data_ptr()), D, R, D, None),
+            "scatter")
+    torch.cuda.synchronize()
+    keep = ids != 1
+    want = out0.double().index_add_(0, ids[keep], X[keep, :D].double())
+    assert (od.cpu().double() - want).abs().max().item() <= 1e-4
+    assert torch.equal(od[1].cpu(), out0[1])                          # the padding row receives nothing

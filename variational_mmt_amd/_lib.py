@@ -88,6 +88,7 @@ _SIGS = {
     "vmmt_gen_fused_geometry": (i32, [i32, i32, vp, vp, vp]),
     "vmmt_gen_dW_finish": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, f32, vp, i64, vp, vp]),
     "vmmt_gather_rows": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, vp]),
+    "vmmt_scatter_add_rows": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_colsum": (i32, [i32, vp, i64, i32, i32, vp, vp, vp]),
     "vmmt_rowsum": (i32, [i32, vp, i64, i32, i32, vp, vp]),
     "vmmt_dropout_mask": (i32, [i32, vp, i64, f32, u64, vp]),

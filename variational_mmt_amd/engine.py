@@ -620,6 +620,7 @@ class Workspace(object):
         # Fused generator passes (csrc/generator_fused.hip) where they apply: the statistics pass also produces dO, a second pass
         # dWg / db, and G^T is never formed.  Otherwise the G^T path of csrc/generator.hip.
         self.dO32 = nb(M, H, f32)
+        self.dXs, self.dXt = nb(MS, E, f32), nb(M, E, f32)          # d(embedding rows) before their scatter into the tables' gradients
         wg_ld = eng.sh["wg"].ld
         self.gen_fused = bool(eng.gen_fused and eng.lib.vmmt_gen_fused_applies(eng.dt, wg_ld, self.O.ld, M, V, _ru(H, KPAD)))
         if self.gen_fused:
@@ -1088,8 +1089,10 @@ class Workspace(object):
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * H, E, M, out_f32=1, split_k=-1)
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * H, Z, M, out_f32=1, split_k=-1, b_kmod=B)
                 we = e.sh["dec_wih_l0_e"]
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                        M, E, 4 * H, out_f32=1, scatter_ids=self.tgt_in.data_ptr())
+                # dX = dgates W_e, then its rows scattered into the embedding gradient (pad row dropped)
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, self.dXt.p(), self.dXt.ld, M, E, 4 * H, out_f32=1)
+                e._call(P, lib.vmmt_scatter_add_rows, self.dXt.p(), self.dXt.ld, self.tgt_in.data_ptr(), PAD,
+                        e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E, M, E)
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
@@ -1157,8 +1160,11 @@ class Workspace(object):
             if l == 0:                                # embedding gradient: one product over both directions, last on the main stream
                 assert all(r == (0, S) for r in ranges)
                 e._sid = MAIN
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                        MS, E, dirs * 4 * Hd, out_f32=1, scatter_ids=self.src.data_ptr())
+                # (as the GEMM's own atomic epilogue the scatter costs 47 us on top of a 28 us product in isolation; in the step the two
+                #  forms measure the same -- 2.07-2.08 ms, tools/ab.py -- the row kernel is kept for its simpler access pattern)
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.dXs.p(), self.dXs.ld, MS, E, dirs * 4 * Hd, out_f32=1)
+                e._call(P, lib.vmmt_scatter_add_rows, self.dXs.p(), self.dXs.ld, self.src.data_ptr(), PAD,
+                        e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E, MS, E)
 
         for l in reversed(range(Lyr)):
             e._sid = MAIN
