@@ -323,7 +323,8 @@ int vmmt_pack(int dtype, const float* src, const float* src2, int64_t ld_src, vo
               int transpose, void* stream);
 
 /* many vmmt_pack operations in ONE launch.  `descs` is a device array of n vmmt_pack_desc; `total_chunks` the sum of
- * their `chunks` (2048 elements each); chunk_start must be the exclusive prefix sum of `chunks`. */
+ * their `chunks` (2048 elements each: ceil(R*C / 2048), or for transpose != 0 ceil(R/64) * ceil(C/32) tiles of the source);
+ * chunk_start must be the exclusive prefix sum of `chunks`. */
 typedef struct vmmt_pack_desc {
   const float* src; const float* src2; void* dst;
   int64_t ld_src, ld_dst;

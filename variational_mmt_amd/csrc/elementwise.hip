@@ -376,6 +376,34 @@ __global__ void pack_multi_kernel(const vmmt_pack_desc* __restrict__ descs, int 
     }
     return;
   }
+  if (d.transpose) {
+    // transposed copies (W_hh^T): a chunk is a [64 rows][32 columns] tile of the source, read by rows and written by columns through
+    // LDS, so that both sides move whole 128-byte segments (element-wise, the strided side fetched one line per lane: the two
+    // transposes of a step cost more than the 15 M-element generator weight)
+    __shared__ float tile[64][33];
+    const int tpr = (d.C + 31) / 32, t = chunk - d.chunk_start;
+    const int r0 = (t / tpr) * 64, c0 = (t % tpr) * 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = (threadIdx.x >> 5) + 8 * i, cc = threadIdx.x & 31;
+      const int r = r0 + rr, c = c0 + cc;
+      float v = 0.f;
+      if (r < d.R && c < d.C) v = d.src[(long)r * d.ld_src + c] + (d.src2 ? d.src2[(long)r * d.ld_src + c] : 0.f);
+      tile[rr][cc] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int cc = (threadIdx.x >> 6) + 4 * i, rr = threadIdx.x & 63;
+      const int r = r0 + rr, c = c0 + cc;
+      if (r < d.R && c < d.C) {
+        const long o = (long)c * d.ld_dst + r;
+        if (d.dtype == VMMT_F32) reinterpret_cast<float*>(d.dst)[o] = tile[rr][cc];
+        else reinterpret_cast<bf16_t*>(d.dst)[o] = f2bf(tile[rr][cc]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     long i = base + k * 256 + threadIdx.x;

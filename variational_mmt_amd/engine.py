@@ -323,7 +323,7 @@ class Engine(object):
                 arr = (L.PackDesc * max(1, len(sel)))()
                 start = 0
                 for k, (code, sp, s2, lds, dst, ldd, R, Cc, tr) in enumerate(sel):
-                    ch = (R * Cc + 2047) // 2048
+                    ch = ((R + 63) // 64) * ((Cc + 31) // 32) if tr else (R * Cc + 2047) // 2048      # vmmt.h: vmmt_pack_multi
                     arr[k] = L.PackDesc(sp, s2, dst, lds, ldd, R, Cc, tr, code, start, ch)
                     start += ch
                 host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
