@@ -15,6 +15,8 @@ W = (torch.randn(Vp, H, generator=g) * 0.05).to(T).cuda(); W[V:] = 0
 O = torch.randn(M, H, generator=g).to(T).cuda()
 bias = (torch.randn(Vp, generator=g) * 0.1).cuda()
 y = torch.randint(2, V, (M,), generator=g).cuda()
+if "zeros" in sys.argv:          # power check: the same instruction stream on all-zero operands
+    W.zero_(); O.zero_()
 npart = lib.vmmt_gen_npart(V)
 pm = torch.zeros(npart * M, device="cuda"); ps = torch.zeros_like(pm)
 pi = torch.zeros(npart * M, device="cuda", dtype=torch.int32)
@@ -65,5 +67,6 @@ if lib.vmmt_gen_fused_applies(L.BF16, H, H, M, V, H):
         f1(); torch.cuda.synchronize()
         h.vmmt_g2_probe_read(buf)
         v = list(buf[:8]); n = max(1, v[6])
+        print("second product in quarters of 8 MFMAs: %.0f %.0f %.0f %.0f" % (buf[8] / n, buf[9] / n, buf[10] / n, (v[4] - 0) / n))
         print("tiles %d, in-kernel clock %d MHz; s_memtime ticks per tile: vmcnt-wait %.0f  barrier %.0f  S-phase %.0f  elementwise %.0f  PV-phase %.0f  loop-tail %.0f"
               % (n, v[7], v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5] / n))

@@ -179,7 +179,12 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   using C = G2<D>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, r31 = lane & 31;
-  const int rt = (int)blockIdx.x / a.nsplit, split = (int)blockIdx.x % a.nsplit;     // 128-token block, vocabulary slice
+  // (128-token block rt, vocabulary slice).  Workgroups go to the 8 XCDs round-robin by blockIdx, and every XCD has its own L2:
+  // consecutive job numbers j = split * nblocks + rt are dealt to ONE XCD, so that an XCD streams at most two slices of Wg instead
+  // of all of them (PMC: 155 MB of reads per launch against 36 MB algorithmic before this mapping).
+  const int nwg = (int)gridDim.x, nblk = nwg / a.nsplit;
+  const int j = (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int split = j / nblk, rt = j - split * nblk;
   const int R0 = rt * 128 + wave * 32;                      // this wave's 32 rows
   const int row = R0 + r31;
   const int rowc = row < a.nrows ? row : a.nrows - 1;
@@ -264,7 +269,7 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
 
 #if defined(VMMT_EXP_PROBE)
   const bool probe = blockIdx.x == 0 && threadIdx.x == 0;
-  unsigned long long ps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+  unsigned long long ps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
   const unsigned long long t_begin = last_, r_begin = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int t = t0; t < t1; ++t) {
@@ -429,6 +434,9 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (i + PD < NM) rd(std::integral_constant<int, i + PD>{});
+#if defined(VMMT_EXP_PROBE)
+        if constexpr (i == 7 || i == 15 || i == 23) { G2_STAMP(8 + i / 8); }
+#endif
       });
     }
     // (no instruction: pins the 256 accumulators to the accumulator half of the register file between tiles; without it the
@@ -447,6 +455,7 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
 #if defined(VMMT_EXP_PROBE)
   if (probe) {
     for (int i = 0; i < 6; ++i) g2_probe[i] = ps[i];
+    for (int i = 8; i < 11; ++i) g2_probe[i] = ps[i];
     g2_probe[6] = (unsigned long long)(t1 - t0);
     // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, reported in MHz
     g2_probe[7] = (__builtin_amdgcn_s_memtime() - t_begin) * 100ull / (__builtin_amdgcn_s_memrealtime() - r_begin);
