@@ -299,6 +299,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     st = eng.read_stats(ws, batch_global=B)
+    eng.check_async_errors()           # a persistent-kernel hand-off that timed out would have produced a fast, wrong step
 
     if rank == 0:
         fl = flops_per_triplet(d, S, Tp)

@@ -398,6 +398,15 @@ class Engine(object):
         words = self.lib.vmmt_lstm_seq_sync_words()
         return [int(s[2].item()) for s in self.seq_syncs]            # [launch epoch, finish count, error word]
 
+    def check_async_errors(self):
+        """raise if an in-launch wait of a persistent recurrence kernel ever ran into its 2-second bound (a workgroup of the row group
+        was not resident: another process on the GPU, a CU mask): the results of that step are then wrong.  Synchronises; the trainer
+        mirror calls it at the end of every epoch and before a checkpoint is written, bench.py after its timed region."""
+        bad = [i for i, x in enumerate(self.lstm_seq_errors()) if x != 0]
+        if bad:
+            raise RuntimeError("persistent LSTM launch(es) %s reported a hand-off timeout (error words %s): results invalid; "
+                               "rerun with VMMT_PERSISTENT_LSTM=0" % (bad, [self.lstm_seq_errors()[i] for i in bad]))
+
     def _zero(self, plan, tensors):
         """plan entry: clear all `tensors` (contiguous device tensors) with ONE vmmt_zero_multi launch"""
         arr = (L.ZeroDesc * len(tensors))()

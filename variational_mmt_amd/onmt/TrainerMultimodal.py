@@ -209,6 +209,7 @@ class TrainerMultimodal(object):
                     os.unlink(tmp_fname)
                 if self.early_stop.signal_early_stopping:
                     break
+        self.model.engine.check_async_errors()
         return total_stats
 
     def validate(self, valid_iter):
@@ -259,6 +260,7 @@ class TrainerMultimodal(object):
         """Same checkpoint dict as the reference (TrainerMultimodal.py:554-622): keys model / generator / vocab / opt /
         epoch / optim; parameter names per SURVEY.md Appendix B."""
         assert checkpoint_type in ("last", "best")
+        self.model.engine.check_async_errors()         # never write parameters that a timed-out device hand-off may have corrupted
         sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
         model_sd = {k: v for k, v in sd.items() if "generator" not in k}
         gen_sd = {k[len("generator."):]: v for k, v in sd.items() if k.startswith("generator.")}
