@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: bash tools/pmc_gen.sh [tag]   -- counters of gen_kernel_q (fwd = MODE 0, bwd = MODE 1), one counter set per pass
+# usage: bash tools/pmc_gen.sh [tag]   -- counters of the generator kernels of tools/gen_one.py (gen2 = fused sweep; fwd / bwd = gen_kernel_q<0/1>),
+# one counter set per pass
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 V=${1:-r2}
 cd /tmp && export TMPDIR=/tmp
@@ -15,7 +16,7 @@ else:
     for r in csv.DictReader(open(f[0])):
         k = r['Kernel_Name']
         if 'gen_kernel' in k or 'gen2_kernel' in k:
-            mode = ('F2 ' if ', 0>' in k else 'G2 ') if 'gen2_kernel' in k else ('bwd' if 'gen_kernel_q<1>' in k else 'fwd')
+            mode = 'gen2' if 'gen2_kernel' in k else ('bwd' if 'gen_kernel_q<1>' in k else 'fwd')
             agg[(mode, r['Counter_Name'])].append(float(r['Counter_Value']))
     for k, v in sorted(agg.items()): print("%-4s %-30s %16.0f" % (k[0], k[1], sum(v[2:]) / max(1, len(v[2:]))))
 PY
