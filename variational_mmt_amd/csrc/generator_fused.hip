@@ -174,7 +174,7 @@ __device__ unsigned long long g2_probe[16];
 #define G2_STAMP(i) do { } while (0)
 #endif
 
-template <int D>
+template <int D, bool HASP>          // HASP: the softmax weights P are stored (a.p_out != NULL)
 __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   using C = G2<D>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
     G2_STAMP(5);
     // tile t has landed.  vmcnt counts in issue order: the only operations younger than its DMA pieces are the two stores of P behind
     // the previous tile's element-wise phase, which may stay in flight (waiting for their acknowledgement costs ~0.5 us per tile)
-    if (a.p_out) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (HASP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2_STAMP(0);
     __syncthreads();                                        // ... for every wave; and every wave is done with tile t-1
@@ -318,6 +318,18 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
         if (ks == 3) issue_piece(tn, cur ^ 1, C::PER);
       }
     }
+
+    // The first PD operand pairs of the second product are requested HERE, in front of the element-wise phase (they depend on the tile
+    // only): their ~250 cycles of LDS latency pass underneath it instead of in front of the first MFMA.
+    constexpr int PD = 5, NM = C::HB * 2;                   // MFMA i: block hb = G2_HB(i), k-step kk = G2_KK(i)
+    fs16x4 fl[PD], fh[PD];
+    auto rd = [&](auto ic) {
+      constexpr int i = decltype(ic)::value, hb = G2_HB(i), kk = G2_KK(i);
+      constexpr int off = SB + (hb >> 2) * 256 + kk * 16 * C::ROWB;
+      fl[i % PD] = g2_tr_read<off>(lds0 + ul[hb & 3]);
+      fh[i % PD] = g2_tr_read<off>(lds0 + uh[hb & 3]);
+    };
+    g2_static_for<0, PD>([&](auto ic) { rd(ic); });
 
     G2_STAMP(2);
     // ---- element-wise: S^T -> P^T (bf16 B-operand fragments of the second product: k-step kk = accumulator registers 8 kk .. 8 kk + 7)
@@ -378,7 +390,7 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
       lsum += pv;
       pf[r >> 3][r & 7] = (__bf16)pv;
     }
-    if (a.p_out) {
+    if (HASP) {
       // P[m][c0 .. c0+31] for this wave's 32 tokens: through a [token][entry] patch in LDS (the lane holds 4 x 4 consecutive entries
       // of ONE token: registers 4 i .. 4 i + 3 = entries 8 i + 4 half + 0..3), written out as 16-byte row segments
       // (inline assembly: written as C++ the compiler puts an s_waitcnt vmcnt(0) in front of these LDS accesses -- it cannot tell
@@ -395,41 +407,34 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
         const int q = lane + 64 * j;
         seg[j] = g2_lds_read_b128(patch + (q >> 2) * C::PPITCH + (q & 3) * 16);
       }
-      // (the segments are stored behind the first MFMA of the second product: its operand wait covers these older reads too)
+      // (the segments are stored behind MFMA PD of the second product: that MFMA's operands were requested after these reads, so its wait covers them)
     }
 
     G2_STAMP(3);
     // ---- acc^T[h][r] += sum_c Y[c][h] P[r][c]   (A = Y^T by transposed reads, k order = the accumulator row order of S^T)
     // The transposed reads are written as inline assembly: as a builtin the compiler orders them behind the LDS-DMA of the NEXT tile
     // (s_waitcnt vmcnt(0) in front of the first one -- also with the loop unrolled by two and compile-time ring slots), which makes
-    // every wave wait out the DMA it has just issued.  The price is that their lgkmcnt bookkeeping is ours: LDS returns in order, and when MFMA i is due the
-    // reads of at most min(PD - 1, NM - 1 - i) younger MFMAs (two each) are in flight.
+    // every wave wait out the DMA it has just issued.  The price is that their lgkmcnt bookkeeping is ours (see `inflight` below).
     {
-      constexpr int PD = G2_PD, NM = C::HB * 2;             // MFMA i: block hb = G2_HB(i), k-step kk = G2_KK(i)
-      fs16x4 fl[PD], fh[PD];
-      auto rd = [&](auto ic) {
-        constexpr int i = decltype(ic)::value, hb = G2_HB(i), kk = G2_KK(i);
-        constexpr int off = SB + (hb >> 2) * 256 + kk * 16 * C::ROWB;
-        fl[i % PD] = g2_tr_read<off>(lds0 + ul[hb & 3]);
-        fh[i % PD] = g2_tr_read<off>(lds0 + uh[hb & 3]);
-      };
-      g2_static_for<0, PD>([&](auto ic) { rd(ic); });
       g2_static_for<0, NM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int inflight = 2 * ((PD - 1) < (NM - 1 - i) ? (PD - 1) : (NM - 1 - i));
-        if constexpr (i == 0) g2_wait_lgkm_seg<inflight>(fl[0], fh[0], seg[0], seg[1]);
+        // LDS operations younger than pair i when MFMA i is due (LDS returns in order; lgkmcnt has 4 bits: <= 15):
+        //   i <  PD: the other early pairs, the P patch's 4 writes + 2 reads (issued in the element-wise phase), the pairs issued behind
+        //            MFMAs 0 .. i-1                                  = 2 (PD - 1) + 6 HASP
+        //   i >= PD: the pairs behind it                              = 2 min(PD - 1, NM - 1 - i)
+        constexpr int inflight = i < PD ? 2 * (PD - 1) + (HASP ? 6 : 0) : 2 * ((PD - 1) < (NM - 1 - i) ? (PD - 1) : (NM - 1 - i));
+        static_assert(inflight <= 15, "lgkmcnt is a 4-bit counter");
+        if constexpr (i == PD) g2_wait_lgkm_seg<inflight>(fl[i % PD], fh[i % PD], seg[0], seg[1]);     // pair PD is younger than the patch reads
         else g2_wait_lgkm<inflight>(fl[i % PD], fh[i % PD]);
         const fs16x8 v = __builtin_shufflevector(fl[i % PD], fh[i % PD], 0, 1, 2, 3, 4, 5, 6, 7);
         __builtin_amdgcn_sched_barrier(0);
         acc[G2_HB(i)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), pf[G2_KK(i)], acc[G2_HB(i)], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (i == 0) {
-          if (a.p_out) {
+        if constexpr (i == PD && HASP) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int q = lane + 64 * j, prow = q >> 2, ch = q & 3;
-              if (R0 + prow < a.nrows) *reinterpret_cast<u32x4*>(a.p_out + (long)(R0 + prow) * a.ldp + c0 + ch * 8) = seg[j];
-            }
+          for (int j = 0; j < 2; ++j) {
+            const int q = lane + 64 * j, prow = q >> 2, ch = q & 3;
+            if (R0 + prow < a.nrows) *reinterpret_cast<u32x4*>(a.p_out + (long)(R0 + prow) * a.ldp + c0 + ch * 8) = seg[j];
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -692,15 +697,15 @@ static bool g2_applies(int dtype, const void* W, int64_t ldw, const void* O, int
          ((((uintptr_t)W) | ((uintptr_t)O)) & 15) == 0;
 }
 
-template <int D>
+template <int D, bool HASP>
 static int g2_launch(const Gen2Args& a, int grid, hipStream_t st) {
   static bool done = false;
   if (!done) {
-    if (hipFuncSetAttribute((const void*)gen2_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, G2<D>::LDSB) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gen2_kernel<D, HASP>, hipFuncAttributeMaxDynamicSharedMemorySize, G2<D>::LDSB) != hipSuccess)
       return VMMT_ELAUNCH;
     done = true;
   }
-  hipLaunchKernelGGL((gen2_kernel<D>), dim3(grid), dim3(256), G2<D>::LDSB, st, a);
+  hipLaunchKernelGGL((gen2_kernel<D, HASP>), dim3(grid), dim3(256), G2<D>::LDSB, st, a);
   return check_launch();
 }
 
@@ -749,7 +754,9 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const floa
   a.p_acc = ws; a.p_ref = ws + (long)ns * mpad * K; a.p_l = a.p_ref + (long)ns * mpad; a.p_max = a.p_l + (long)ns * mpad;
   a.tgt_logit = tgt_logit;
   a.p_out = (bf16_t*)Pw; a.ldp = ldp;
-  return K == 512 ? g2_launch<512>(a, nmt * ns, (hipStream_t)stream) : g2_launch<256>(a, nmt * ns, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (Pw) return K == 512 ? g2_launch<512, true>(a, nmt * ns, st) : g2_launch<256, true>(a, nmt * ns, st);
+  return K == 512 ? g2_launch<512, false>(a, nmt * ns, st) : g2_launch<256, false>(a, nmt * ns, st);
 }
 
 // folds the slices of the sweep: lse, tok_nll, statistics, dO, y32 and (cs != NULL) c_s / O'_s for the dWg GEMM
