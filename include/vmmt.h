@@ -221,7 +221,8 @@ int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bia
  * vmmt_gen_fwd_dO + vmmt_gen_fwd_combine replace vmmt_gen_loss_fwd + vmmt_gen_loss_bwd_db + the dO GEMM of the training step.
  *   vmmt_gen_fwd_dO: per 128-token block and vocabulary slice (vmmt-chosen: vmmt_gen_fused_geometry) a flash-attention-shaped sweep
  *     accumulates the softmax statistics and the un-normalised dO = sum_v P[m][v] Wg[v] into `ws`
- *     (vmmt_gen_fused_ws_floats(M, V, K) floats) and writes tgt_logit f32 [M].  P != NULL (the training step): it also stores
+ *     (vmmt_gen_fused_ws_floats(M, V, K) floats) and writes tgt_logit f32 [M].  W must be READABLE for w_rows >= (V rounded up to
+ *     32) + 32 rows (the sweep prefetches whole 32-row tiles, one beyond the last; contents beyond V are ignored).  P != NULL (the training step): it also stores
  *     P T [M][ldp] (ldp >= V rounded up to 32), the un-normalised softmax weights exp(logit - ref_s[m]) of slice s = v / v_per_split.
  *   vmmt_gen_fwd_combine: folds the slices.  out: lse, tok_nll f32 [M]; stats[NLL,NWORDS,NCORRECT] += sums;
  *     dO f32 [M][lddo] = s_m (softmax_m Wg - Wg[y_m]), s_m = [y_m != pad] inv_norm; y32 int32 [(M+31)/32*32]: targets, -1 at pads
@@ -235,7 +236,7 @@ int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bia
 int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M, int V, int K);
 int64_t vmmt_gen_fused_ws_floats(int M, int V, int K);
 int vmmt_gen_fused_geometry(int M, int V, int* nsplit, int* v_per_split, int64_t* mpad);
-int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, const int64_t* y,
+int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows, const float* bias, const void* O, int64_t ldo, const int64_t* y,
                     int M, int V, int K, float* ws, float* tgt_logit, void* P, int64_t ldp, void* stream);
 int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
                          int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,

@@ -315,7 +315,8 @@ def test_generator_fused_pass_bf16(M, V, H, ramp):
     cs = torch.zeros(ns, mpad, device="cuda")
     Mk = (M + 63) // 64 * 64
     Os = torch.zeros(ns, Mk, H, device="cuda", dtype=T)
-    L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, P(bd), P(Od), H, P(yd), M, V, H, P(ws), P(tl), P(Pw), ldp, None), "gen fwd dO")
+    L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, V + 256, P(bd), P(Od), H, P(yd), M, V, H, P(ws), P(tl), P(Pw), ldp, None), "gen fwd dO")
+    assert lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, V, P(bd), P(Od), H, P(yd), M, V, H, P(ws), P(tl), P(Pw), ldp, None) != 0     # W too short for the prefetch
     L.check(lib.vmmt_gen_fwd_combine(L.BF16, P(Wd), H, P(Od), H, P(yd), M, V, H, 1, inv_norm, P(ws), P(tl), P(lse), P(nll), P(y32),
                                      P(dO), H + 4, P(st), P(cs), P(Os), H, Mk * H, None), "gen fwd combine")
     torch.cuda.synchronize()

@@ -97,28 +97,6 @@ template <int D> struct G2 {
 //   four rows land 16 banks apart.
 __device__ __forceinline__ int g2_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-template <int D>
-__device__ __forceinline__ void g2_issue_one(const bf16_t* __restrict__ Y, long ldy, int c0, int limit, char* buf, int wave, int lane, int j) {
-  using C = G2<D>;
-  const int piece = wave * C::PER + j;
-  if constexpr (C::RPP == 1) {
-    // one row per piece: the row address is wave-uniform (scalar registers), the lane supplies a 32-bit byte offset only.
-    // Rows beyond the operand are clamped (and masked by the consumer).
-    const int rmax = limit - 1 - c0;
-    const int rr = __builtin_amdgcn_readfirstlane(piece < rmax ? piece : rmax);
-    const char* rowp = reinterpret_cast<const char*>(Y + (long)c0 * ldy) + (unsigned)rr * (unsigned)(ldy * 2);
-    const unsigned off = (unsigned)((lane ^ g2_swz(piece)) * 16);      // LDS slot `lane` of the row holds logical chunk lane ^ swz(row)
-    __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)(rowp + off), (f_lds_void_t*)(buf + piece * 1024), 16, 0, 0);
-  } else {
-    const int row = piece * C::RPP + lane / C::CPR;
-    const int lch = (lane % C::CPR) ^ g2_swz(row);
-    int g = c0 + row;
-    g = g < limit ? g : limit - 1;
-    const char* src = reinterpret_cast<const char*>(Y + (long)g * ldy) + lch * 16;
-    __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)src, (f_lds_void_t*)(buf + piece * 1024), 16, 0, 0);
-  }
-}
-
 template <int OFF>
 __device__ __forceinline__ fs16x4 g2_tr_read(unsigned addr) {
   fs16x4 r;
@@ -178,7 +156,8 @@ template <int D, bool HASP>          // HASP: the softmax weights P are stored (
 __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   using C = G2<D>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, r31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: everything derived from it stays in SGPRs
+  const int lane = threadIdx.x & 63, half = lane >> 5, r31 = lane & 31;
   // (128-token block rt, vocabulary slice).  Workgroups go to the 8 XCDs round-robin by blockIdx, and every XCD has its own L2:
   // consecutive job numbers j = split * nblocks + rt are dealt to ONE XCD, so that an XCD streams at most two slices of Wg instead
   // of all of them (PMC: 155 MB of reads per launch against 36 MB algorithmic before this mapping).
@@ -198,9 +177,22 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   // here is conditional: a branch around an issue splits the MFMA phase into basic blocks with full waits at their joins.  Inside
   // the tile loop the pieces are issued one per group of four MFMAs (an issue costs ~100 cycles of the wave's instruction stream:
   // it hides in the shadow of the matrix unit).
+  // Per-lane source pointers of this wave's PER pieces, advanced by one tile per issue (no per-piece address arithmetic in the tile
+  // loop: with it an issue cost ~87 cycles of the wave's instruction stream).  Rows are NOT clamped: the operand must be readable up
+  // to (V rounded up to 32) + 32 rows (vmmt_gen_fwd_dO checks the caller's w_rows); what lies beyond V is masked by the consumer.
+  const char* pp[C::PER];
+#pragma unroll
+  for (int j = 0; j < C::PER; ++j) {
+    const int piece = wave * C::PER + j;
+    const int prow = piece * C::RPP + (C::RPP > 1 ? lane / C::CPR : 0);
+    const int lch = (lane % C::CPR) ^ g2_swz(prow);         // LDS slot (lane % CPR) of the row holds logical chunk lch
+    pp[j] = reinterpret_cast<const char*>(a.Y + (long)(t0 * C::BC + prow) * a.ldy) + lch * 16;
+  }
+  const long tile_step = (long)C::BC * a.ldy * 2;
   auto issue_piece = [&](int t, int slot, int j) {
     if (j < C::PER) {
-      g2_issue_one<D>(a.Y, a.ldy, t * C::BC, a.ncols, smem + slot * C::TILEB, wave, lane, j);
+      __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)pp[j], (f_lds_void_t*)(smem + slot * C::TILEB + (wave * C::PER + j) * 1024), 16, 0, 0);
+      pp[j] += tile_step;
     } else {
       int c = t * C::BC + r31;
       c = c < a.ncols ? c : a.ncols - 1;
@@ -283,7 +275,7 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
     G2_STAMP(1);
     const int cur = (t - t0) & 1;                           // ring slot (its byte offset is folded into ua / ul / uh: see the loop tail)
     constexpr int SB = 0;
-    const int tn = t + 1 < t1 ? t + 1 : t;                  // (the last tile is fetched once more, into the slot nobody reads again)
+    const int tn = t + 1;                                   // (behind the slice's last tile: one tile further, into the slot nobody reads again)
     const char* sb = small + cur * C::SMALLB + wave * 256;
     const int c0 = t * C::BC;
 
@@ -321,7 +313,8 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
 
     // The first PD operand pairs of the second product are requested HERE, in front of the element-wise phase (they depend on the tile
     // only): their ~250 cycles of LDS latency pass underneath it instead of in front of the first MFMA.
-    constexpr int PD = 5, NM = C::HB * 2;                   // MFMA i: block hb = G2_HB(i), k-step kk = G2_KK(i)
+    constexpr int PD = 4, NM = C::HB * 2;                   // MFMA i: block hb = G2_HB(i), k-step kk = G2_KK(i).  (2 PD early reads + the 6 LDS
+                                                            // operations of the P patch must stay below the 15 the lgkmcnt counter can hold: a 16th stalls at issue)
     fs16x4 fl[PD], fh[PD];
     auto rd = [&](auto ic) {
       constexpr int i = decltype(ic)::value, hb = G2_HB(i), kk = G2_KK(i);
@@ -737,10 +730,11 @@ extern "C" int vmmt_gen_fused_geometry(int M, int V, int* nsplit, int* v_per_spl
 
 // the sweep: partial softmax statistics + un-normalised dO per (128-token block, vocabulary slice) into `ws`, target logits, and
 // (Pw != NULL) the softmax weights P
-extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, const float* bias, const void* O, int64_t ldo, const int64_t* y,
-                               int M, int V, int K, float* ws, float* tgt_logit, void* Pw, int64_t ldp, void* stream) {
+extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows, const float* bias, const void* O, int64_t ldo,
+                               const int64_t* y, int M, int V, int K, float* ws, float* tgt_logit, void* Pw, int64_t ldp, void* stream) {
   using namespace vmmt;
   if (!W || !bias || !O || !y || !ws || !tgt_logit) return VMMT_EINVAL;
+  if (w_rows < (V + 31) / 32 * 32 + 32) return VMMT_EINVAL;          // the sweep prefetches one 32-row tile beyond the last one (unclamped)
   if (Pw && (ldp < (V + 31) / 32 * 32 || (ldp & 7) || (((uintptr_t)Pw) & 15))) return VMMT_EINVAL;
   if (!g2_applies(dtype, W, ldw, O, ldo, M, V, K)) return VMMT_EINVAL;
   const int nmt = (M + 127) / 128, ns = g2_nsplit(M, V);

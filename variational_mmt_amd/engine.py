@@ -887,7 +887,7 @@ class Workspace(object):
             # behind feed the dWg GEMM of the backward plan
             assert O.ld == _ru(d.hid, KPAD)
             Kp = _ru(d.hid, KPAD)
-            e._call(P, lib.vmmt_gen_fwd_dO, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(), self.M, d.vt,
+            e._call(P, lib.vmmt_gen_fwd_dO, e.dt, wg.p(), wg.ld, wg.t.shape[0], e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(), self.M, d.vt,
                     Kp, self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.gen_P.data_ptr(), self.gen_ldp)
             self._loss_patch = (len(P), 10)
             e._call(P, lib.vmmt_gen_fwd_combine, e.dt, wg.p(), wg.ld, O.p(), O.ld, self.y.data_ptr(), self.M, d.vt, Kp, PAD, 0.0,
