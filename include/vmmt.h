@@ -382,9 +382,10 @@ int vmmt_standardise_rows(float* X, int64_t ld, const float* mean, const float* 
 #define VMMT_SUMSQ_MAXBLOCKS 768
 #define VMMT_SUMSQ_SCRATCH (2 * VMMT_SUMSQ_SLOTS + VMMT_SUMSQ_SLOTS * VMMT_SUMSQ_MAXBLOCKS)
 int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, void* stream);
-/* max_blocks > 0 caps the grid (grid-stride loop): used for the half of the update that runs in the background */
+/* max_blocks > 0 caps the grid (grid-stride loop).  shadow_bf16 (optional): the bf16 compute copy of THIS parameter range, same
+ * flat layout (a 2-D weight whose shadow rows are unpadded): written along with p, so the shadow refresh need not read p back */
 int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                   int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* stream);
+                   int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -115,8 +115,11 @@ def test_adam_and_sumsq():
         L.check(lib.vmmt_sumsq(gd.data_ptr(), n0, ss.data_ptr(), 0, None), "sumsq")
         L.check(lib.vmmt_sumsq(gd.data_ptr() + 4 * n0, n - n0, ss.data_ptr(), 3, None), "sumsq")
         assert torch.equal(ss[:L.SUMSQ_SLOTS], first)
+    sh = torch.full((n + 8,), 9.0, device="cuda", dtype=torch.bfloat16)        # the optional bf16 shadow of the updated parameters
     L.check(lib.vmmt_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 0.002, 0.9, 0.999, 1e-9, 3, 5.0,
-                               ss.data_ptr(), 1.0, 0, None), "adam")
+                               ss.data_ptr(), 1.0, 0, sh.data_ptr(), None), "adam")
+    torch.cuda.synchronize()
+    assert torch.equal(sh[:n], pd.to(torch.bfloat16)) and (sh[n:] == 9.0).all()
     coef = min(1.0, 5.0 / (tot ** 0.5 + 1e-6))
     gg = g.double() * coef
     m2 = 0.9 * m.double() + 0.1 * gg

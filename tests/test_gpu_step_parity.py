@@ -314,3 +314,27 @@ def test_reparameterised_gradient_switch(name, dtype):
     e.loss_backward(ws, normalization=B, kl_mult=0.7)
     torch.cuda.synchronize()
     _cmp("as executed again", e.grads[k0], g_det[k0], tol["grad"])
+
+
+def test_shadows_after_an_optimiser_step_equal_a_fresh_pack():
+    """bf16 mode: after optim_step every compute shadow -- those the Adam kernel writes itself (generator weight, image-network fc2:
+    Engine._fused_shadows) and those vmmt_pack_multi refreshes -- equals a full re-pack of the updated fp32 master, bit for bit"""
+    from variational_mmt_amd.engine import Dims, Engine
+    c = O.Cfg(vs=61, vt=4200, emb=64, hid=512, z=64, layers=1, brnn=True)
+    p = O.init_params(c, seed=2)
+    bt = O.synth_batch(c, B=8, S=5, T=6, n_img=10, seed=3, fixed_len=False)
+    e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="bf16", device="cuda:0")
+    e.load_state_dict(p)
+    e.set_image_table(bt["table"])
+    assert len(e._fused_shadows()) == 2                       # generator weight [4200 x 512], inf_net_image fc2 [2048 x 2048]
+    for _ in range(2):
+        ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+        e.loss_backward(ws, normalization=8)
+        e.optim_step()
+    torch.cuda.synchronize()
+    got = {k: b.t.clone() for k, b in e.sh.items()}
+    e.shadows_dirty = True
+    e.refresh_shadows(torch.cuda.current_stream().cuda_stream)          # parts 0 / 1: every shadow from the master
+    torch.cuda.synchronize()
+    for k, b in e.sh.items():
+        assert torch.equal(got[k], b.t), k

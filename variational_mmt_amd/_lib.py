@@ -110,7 +110,7 @@ _SIGS = {
     "vmmt_rows_select": (i32, [vp, i64, vp, vp, i64, i32, i32, vp]),
     "vmmt_standardise_rows": (i32, [vp, i64, vp, vp, i64, i32, vp]),
     "vmmt_sumsq": (i32, [vp, i64, vp, i32, vp]),
-    "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp]),
+    "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp, vp]),
 }
 
 EXPORTS = sorted(_SIGS)

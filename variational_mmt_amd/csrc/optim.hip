@@ -61,9 +61,11 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
   }
 }
 
+// `shadow` (optional): bf16 compute copy of this parameter range with the SAME flat layout (a 2-D weight whose shadow rows are not padded):
+// written here, so that the shadow refresh does not have to read the 15 M-element generator weight back
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2, float max_norm,
-                            const float* __restrict__ sumsq, float grad_scale) {
+                            const float* __restrict__ sumsq, float grad_scale, bf16_t* __restrict__ shadow) {
   float coef = grad_scale;
   if (max_norm > 0.f) {
     float ss = 0.f;
@@ -89,12 +91,19 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
       *reinterpret_cast<f32x4*>(p + i) = pp;
       *reinterpret_cast<f32x4*>(m + i) = mm;
       *reinterpret_cast<f32x4*>(v + i) = vv;
+      if (shadow) {
+        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+        const us4 h = {f2bf(pp[0]), f2bf(pp[1]), f2bf(pp[2]), f2bf(pp[3])};
+        *reinterpret_cast<us4*>(shadow + i) = h;
+      }
     } else {
       for (long k = i; k < n; ++k) {
         float ge = g[k] * coef;
         float mk = b1 * m[k] + (1.f - b1) * ge, vk = b2 * v[k] + (1.f - b2) * ge * ge;
         m[k] = mk; v[k] = vk;
-        p[k] -= step_size * mk / (sqrtf(vk) * inv_sqrt_bc2 + eps);
+        const float pk = p[k] - step_size * mk / (sqrtf(vk) * inv_sqrt_bc2 + eps);
+        p[k] = pk;
+        if (shadow) shadow[k] = f2bf(pk);
       }
     }
   }
@@ -118,10 +127,11 @@ extern "C" int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, v
 
 extern "C" int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                               float eps, int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks,
-                              void* stream) {
+                              void* shadow_bf16, void* stream) {
   using namespace vmmt;
   if (!p || !g || !m || !v || n < 0 || step < 1 || (max_norm > 0.f && !sumsq)) return VMMT_EINVAL;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return VMMT_EINVAL;
+  if (((uintptr_t)shadow_bf16) & 7) return VMMT_EINVAL;
   if (n == 0) return VMMT_OK;
   double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
@@ -130,7 +140,7 @@ extern "C" int vmmt_adam_step(float* p, const float* g, float* m, float* v, int6
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;   // throttle: a background update must not saturate HBM
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1,
-                     beta2, eps, inv_sqrt_bc2, max_norm, sumsq, grad_scale);
+                     beta2, eps, inv_sqrt_bc2, max_norm, sumsq, grad_scale, (bf16_t*)shadow_bf16);
   return check_launch();
 }
 

@@ -311,15 +311,32 @@ class Engine(object):
         shadow("iv_w2", d.img, d.img, "inf_net_image.location.fc2.weight")
         shadow("wg", d.vt, d.hid, "generator.0.weight")
 
+    def _fused_shadows(self):
+        """[(lo, hi, shadow pointer)] in arena order: optimised 2-D weights of at least 2 M elements whose bf16 shadow has unpadded rows
+        and no second source -- the shadow then has the parameter's flat layout and vmmt_adam_step writes it (optim_step)"""
+        if not hasattr(self, "_fused_sh"):
+            self._fused_sh = []
+            base = self.flat_p.data_ptr()
+            for code, sp, s2, lds, dst, ldd, R, Cc, tr in self.pack_calls:
+                o = (sp - base) // 4
+                whole = any(off == o and len(shp) == 2 and shp[0] * shp[1] == R * Cc for off, shp in self.offsets.values())
+                if code == L.BF16 and not tr and s2 is None and ldd == Cc and lds == Cc and whole and R * Cc >= (1 << 21) and \
+                        o + R * Cc <= self.n_opt and dst % 8 == 0:
+                    self._fused_sh.append((o, o + R * Cc, dst))
+            self._fused_sh.sort()
+        return self._fused_sh
+
     def _pack_tables(self):
-        """two descriptor tables for vmmt_pack_multi: part 0 = shadows the forward needs first (encoder + inference
-        networks), part 1 = decoder / attention / generator (refreshed on the side stream under the encoder phase)"""
+        """descriptor tables for vmmt_pack_multi.  Parts 0 / 1: every shadow of [encoder + inference networks] / [generator + attention +
+        decoder] (after load_state_dict / a replica broadcast); parts 2 / 3: the same without the shadows the optimiser step writes
+        itself (_fused_shadows): what optim_step refreshes"""
         if not hasattr(self, "_pack_tab"):
             self._pack_tab = []
             enc_lo = self.offsets[self.first_enc_name][0]
             base = self.flat_p.data_ptr()
-            for part in (0, 1):
-                sel = [c for c in self.pack_calls if ((c[1] - base) // 4 >= enc_lo) == (part == 0)]
+            fused = set(d for _, _, d in self._fused_shadows())
+            for part in (0, 1, 2, 3):
+                sel = [c for c in self.pack_calls if ((c[1] - base) // 4 >= enc_lo) == (part % 2 == 0) and (part < 2 or c[4] not in fused)]
                 arr = (L.PackDesc * max(1, len(sel)))()
                 start = 0
                 for k, (code, sp, s2, lds, dst, ldd, R, Cc, tr) in enumerate(sel):
@@ -1592,29 +1609,41 @@ def _engine_methods():
         self.step_count += 1
         split = self.offsets[self.first_enc_name][0]
 
-        def adam(lo, hi, stream, max_blocks=0):
-            L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
-                                            self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, lr, beta1, beta2,
-                                            eps, self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
-                                            max_blocks, stream), "vmmt_adam_step")
+        def adam_range(lo, hi, stream, shadow=None):
+            if hi > lo:
+                L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
+                                                self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, lr, beta1, beta2,
+                                                eps, self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
+                                                0, shadow, stream), "vmmt_adam_step")
+
+        def adam(lo, hi, stream):
+            # the big unpadded bf16 shadows (generator weight, image network fc2) are written by the update itself: their range is
+            # a launch of its own with the shadow attached, and the shadow refresh behind it skips them (_pack_tables)
+            cur = lo
+            for s_lo, s_hi, ptr in self._fused_shadows():
+                if lo <= s_lo and s_hi <= hi:
+                    adam_range(cur, s_lo, stream)
+                    adam_range(s_lo, s_hi, stream, ptr)
+                    cur = s_hi
+            adam_range(cur, hi, stream)
         if self.use_side_stream and self.split_optim:
             # both halves are HBM-bound: the critical half runs alone at full bandwidth, the other one starts behind it
             adam(split, self.n_opt, st)
             ev = self.global_events.setdefault("adam_main_done", torch.cuda.Event())
             ev.record(main)
-            self._pack_part(0, st)
+            self._pack_part(2, st)
             side = self.side_stream
 
             def background():
                 side.wait_event(ev)
                 adam(0, split, side.cuda_stream)
-                self._pack_part(1, side.cuda_stream)
+                self._pack_part(3, side.cuda_stream)
                 self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
             background()
         else:
             adam(0, self.n_opt, st)
-            self._pack_part(0, st)
-            self._pack_part(1, st)
+            self._pack_part(2, st)
+            self._pack_part(3, st)
         self.shadows_dirty = False
 
     for k, v in list(locals().items()):
