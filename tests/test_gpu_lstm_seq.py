@@ -160,3 +160,34 @@ def test_persistent_backward_recurrence_is_bit_identical(B, H, ndir, T, lens_on)
         if rep == 3:
             assert torch.equal(first[0], outs[1][0]) and torch.equal(first[1], outs[1][1])
     assert int(sync[0].item()) == 4                                  # four launches, four epochs
+
+
+@pytest.mark.parametrize("B,H,ndir,T,cuts", [(21, 256, 2, 24, (0, 6, 12, 24)), (256, 512, 1, 20, (0, 9, 20)), (70, 128, 2, 9, (0, 2, 4, 9))])
+def test_persistent_backward_recurrence_cut_into_pieces(B, H, ndir, T, cuts):
+    """a recurrence issued as several vmmt_lstm_seq_bwd calls (step 0 of a later piece carries dgates_next = the plain dgates
+    buffer of the piece before; dc_carry goes through memory) gives the bits of the single call -- the conditional model cuts
+    encoder_tgt's 2 x B-step backward this way to run the weight gradients of the finished part next to the rest"""
+    import ctypes as C
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    t_, build, M, ldg = _bwd_case(B, H, ndir, T, 21, False)
+    outs = []
+    for pieces in ((0, T), cuts):
+        dg = torch.full((M + 64, ldg), 3.0, dtype=torch.bfloat16, device="cuda")
+        dcc = t_["dcc0"].clone()
+        arr = build(dg, dcc, None)
+        keep = []
+        for s0, s1 in zip(pieces[:-1], pieces[1:]):
+            n = s1 - s0
+            part = (L.LstmDirBwd * (n * ndir)).from_buffer_copy(bytes(arr)[s0 * ndir * C.sizeof(L.LstmDirBwd):s1 * ndir * C.sizeof(L.LstmDirBwd)])
+            dev_arr = torch.frombuffer(bytearray(bytes(part)), dtype=torch.uint8).cuda()
+            sync = torch.zeros(lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device="cuda")
+            xchg = torch.zeros(max(16, lib.vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H)), dtype=torch.uint8, device="cuda")
+            L.check(lib.vmmt_lstm_seq_bwd(L.BF16, ndir, n, part, dev_arr.data_ptr(), None, B, H, 0, sync.data_ptr(), xchg.data_ptr(), None), "seq bwd")
+            keep.append((part, dev_arr, sync, xchg))
+        torch.cuda.synchronize()
+        assert all(int(k[2][2].item()) == 0 for k in keep)
+        assert all(int(k[2][0].item()) == 1 for k in keep)          # every piece ran as the persistent kernel (one epoch each)
+        outs.append((dg.clone(), dcc.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]), (outs[0][0].float() - outs[1][0].float()).abs().max().item()
+    assert torch.equal(outs[0][1], outs[1][1])

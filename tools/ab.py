@@ -11,12 +11,14 @@ for a in sys.argv[1:]:
     kv = {}
     for item in filter(None, rest.split(",")):
         k, _, v = item.partition("=")
-        kv[k] = (v == "1") if v in ("0", "1") else v
+        kv[k] = (v == "1") if v in ("0", "1") else v      # other values stay strings
     cfgs.append((name, kv))
-d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.5)
+COND = os.environ.get("AB_CONDITIONAL", "0") == "1"
+d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.5, conditional=COND)
 table = torch.rand(29000, d.img)
 bs = bench.make_batches(d, 256, 20, 21, 29000, 4, "cuda", 1)
 engs = []
+TLEN = torch.full((256,), 21, dtype=torch.int64, device="cuda")
 for name, kv in cfgs:
     e = Engine(d, dtype="bf16", device="cuda", seed=0)
     for k, v in kv.items():
@@ -24,14 +26,14 @@ for name, kv in cfgs:
         setattr(e, k, v)
     e.set_image_table(table)
     if engs:        # all arms on the SAME streams: a process has few hardware queues, and the streams of a second engine share them
-        for attr in ("side_stream", "_side_stream_plain", "aux_stream", "compute_stream"):
+        for attr in ("side_stream", "_side_stream_plain", "aux_stream", "tgt_stream", "compute_stream"):
             setattr(e, attr, getattr(engs[0], attr))
     engs.append(e)
 
 def run(e, n):
     for i in range(n):
         src, sl, tgt, idx = bs[i % 4]
-        ws = e.forward(src, sl, tgt, idx, training=True)
+        ws = e.forward(src, sl, tgt, idx, training=True, tgt_len=TLEN if COND else None)
         e.loss_backward(ws, normalization=256, batch_global=256)
         e.optim_step()
 

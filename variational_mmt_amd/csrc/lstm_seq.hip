@@ -480,7 +480,11 @@ template <int H> struct SeqCfgB {
 };
 
 template <int H>
+#ifdef VMMT_EXP_OLDLB
 __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
+#else
+__global__ void __launch_bounds__(256, (H <= 256 ? 2 : 1)) lstm_seq_bwd_kernel(SeqArgsB a) {
+#endif
   using Cf = SeqCfgB<H>;
   constexpr int ROWB = Cf::ROWB, KQ = Cf::KQ, NKS = Cf::NKS, CH = Cf::CH;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -522,6 +526,9 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
         __builtin_amdgcn_s_sleep(2);
       }
       *flag = f;
+#ifdef VMMT_EXP_XCCDBG
+      if (f == 0) __hip_atomic_fetch_add(a.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     }
   }
   bool alive = true, same_xcd = false;
@@ -594,6 +601,18 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) { acc[j][0] = f32x4_s{0.f, 0.f, 0.f, 0.f}; acc[j][1] = f32x4_s{0.f, 0.f, 0.f, 0.f}; }
     if (d.dgates_next) {
+      u32x4 af[2][KQ];
+      if (t == 0) {
+        // a chain CONTINUED from an earlier launch (the caller cut the recurrence into pieces): the previous step's dgates are in
+        // its plain [B][4H] buffer, complete since that launch ended.  Same fragments as the sweep below: row n of row half wm,
+        // columns ks * 32 + kg * 8 .. + 8
+        const long rr = (m0 + wm * 16 + n) < B ? (m0 + wm * 16 + n) : B - 1;
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(d.dgates_next) + rr * d.ld_dgn + kg * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) af[j][q] = *reinterpret_cast<const u32x4*>(src + ((2 * wk + j) * KQ + q) * 32);
+      } else {
       const unsigned want = tag0 + (unsigned)t;                 // tag of the step processed just before
       const unsigned sbase = (unsigned)((((t - 1) & 1) * 2 + wm) * (NKS * 2048));
       const unsigned long long t_start = wall_clock64();
@@ -613,7 +632,6 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
       }
       SEQ_TS(1);
       // the whole K half of this wave in flight at once (2 * KQ k-steps, a lo and a hi piece each), then tags, then MFMAs
-      u32x4 af[2][KQ];
       const unsigned gbase = sbase + (unsigned)((2 * wk * KQ) * 2048 + lane * 16);
       for (;;) {
         bool ok = true;
@@ -638,6 +656,7 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
           break;
         }
         __builtin_amdgcn_s_sleep(1);
+      }
       }
       if (t + 1 < a.nsteps) fetch_in(load_desc_b(a.steps, (long)(t + 1) * ndir + k));
 #pragma unroll
@@ -801,7 +820,9 @@ extern "C" int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lst
 // Whole BACKWARD recurrence (mode 0 steps of vmmt_lstm_step_bwd) in one launch; same contract as vmmt_lstm_seq_fwd.  `xchg`:
 // vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H) bytes.  Falls back to vmmt_lstm_chain_bwd when the persistent kernel does not apply
 // (fp32, H not in {64,128,256,512}, more workgroups than CUs, unaligned rows, dgates_next[t] != dgates_out[t-1], a dc_carry
-// buffer that changes between steps).
+// buffer that changes between steps).  A recurrence may be cut into several calls (the caller then runs the weight gradients of
+// the finished part next to the rest): step 0 of a later piece carries dgates_next = the last dgates_out of the piece before,
+// which is read from that plain buffer, and dc_carry is read at the first and written at the last step of every call.
 extern "C" int64_t vmmt_lstm_seq_xchg_bytes_bwd(int ndir, int B, int H) {
   if (ndir < 1 || B < 1 || H < 1) return 0;
   return (int64_t)ndir * ((B + 31) / 32) * 2 * 2 * (4 * H / 32) * 2048;
@@ -821,7 +842,7 @@ extern "C" int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lst
       ok = d.w_hh_t && d.gates && d.c_t && d.dc_carry && d.dgates_out && al16s(d.dgates_out, d.ld_dgo) && al16s(d.w_hh_t, d.ld_wt) &&
            d.w_hh_t == dirs[k].w_hh_t && d.ld_wt == dirs[k].ld_wt && d.dc_carry == dirs[k].dc_carry && d.ld_dcc == dirs[k].ld_dcc &&
            (!d.dh_n || d.dc_n);
-      if (ok && i == 0) ok = d.dgates_next == nullptr;
+      if (ok && i == 0) ok = d.dgates_next == nullptr || al16s(d.dgates_next, d.ld_dgn);   // non-null: a chain continued from an earlier launch
       if (ok && i > 0) {
         const vmmt_lstm_dir_bwd& p = dirs[(long)(i - 1) * ndir + k];
         ok = d.dgates_next == p.dgates_out && d.ld_dgn == p.ld_dgo;

@@ -164,6 +164,11 @@ class Engine(object):
         # measured (tools/sched_ab.py, fixed prior): 2.53 ms/step with that work on the side stream vs 2.59 ms on a stream of
         # its own; the conditional model keeps it (encoder_tgt's 2 x B-step recurrences would otherwise block the side stream)
         self.use_aux_stream = _os_env.get("VMMT_AUX_STREAM", "1") == "1"
+        # fourth stream (conditional model only): encoder_tgt's backward recurrence, 2 x B dependent steps that would otherwise hold
+        # up everything queued behind them on the aux stream
+        self.tgt_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        self.cond_dec_steps = _os_env.get("VMMT_COND_DEC_STEPS", "1") == "1"
+        self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1")      # issue order of the backward plan (see _plan_backward)
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
@@ -393,10 +398,11 @@ class Engine(object):
         else:
             plan.append((self.lib.vmmt_lstm_chain_fwd, (self.dt, ndir, nsteps, arr, lens_ptr, B, H), "vmmt_lstm_chain_fwd", arr, self._sid))
 
-    def _lstm_seq_bwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H, with_dh0=0):
+    def _lstm_seq_bwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H, with_dh0=0, persistent=True):
         """plan entry: a whole backward recurrence (the mode-0 steps; with_dh0: `arr` ends with one mode-1 step, the gradient of
-        the initial hidden state), see _lstm_seq_fwd"""
-        if self.persistent_lstm:
+        the initial hidden state), see _lstm_seq_fwd.  persistent=False: one launch per step even when the engine uses the
+        persistent kernels (a recurrence that has to run NEXT TO another persistent launch it cannot share a CU with)"""
+        if self.persistent_lstm and persistent:
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
             sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
             xchg = torch.zeros(max(16, self.lib.vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H)), dtype=torch.uint8, device=self.dev)
@@ -469,8 +475,9 @@ class Engine(object):
         main = torch.cuda.current_stream(self.dev)
         side = self.side_stream if self.use_side_stream else main
         aux = self.aux_stream if (self.use_side_stream and self.use_aux_stream) else side
-        ts = (main, side, aux)
-        hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream)
+        tgt = self.tgt_stream if aux is self.aux_stream else aux
+        ts = (main, side, aux, tgt)
+        hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream, tgt.cuda_stream)
         trace, last = self.trace, None
         for entry in plan:
             fn, args, name, _keep, sid = entry
@@ -957,33 +964,8 @@ class Workspace(object):
             e._gemm(P, L.GEMM_TN, self.GT.p(), self.GT.ld, wg.p(), wg.ld, self.dO32.p(), self.dO32.ld, M, H, V, out_f32=1,
                     split_k=max(1, min(8, (1024 * 128 * 128) // max(1, M * H))))
         # ================= aux: image term + its network (z is detached: independent of the text path) ==========
-        e._sid = AUX
-        e._wait(P, "bwd_begin")
-        self._patch["img"] = (len(P), 7)
-        e._call(P, lib.vmmt_image_loss, dt, self.mu_v.p(), self.mu_v.ld, self.img.p(), self.img.ld, B, D, inv_norm,
-                self.dmu_v.p(), self.dmu_v.ld, self.stats.data_ptr())
-        w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
-        e._gemm(P, L.GEMM_TN, self.dmu_v.p(), self.dmu_v.ld, self.h1v.p(), self.h1v.ld, e.gp("inf_net_image.location.fc2.weight"), D,
-                D, D, B, out_f32=1, split_k=-1)
-        e._call(P, lib.vmmt_colsum, dt, self.dmu_v.p(), self.dmu_v.ld, B, D, e.gp("inf_net_image.location.fc2.bias"), None)
-        # [B x D] x [D x D] with B = a few hundred rows: 32 tiles of 128 x 128 would leave 7/8 of the chip idle for 100 us, so the
-        # reduction is split over workgroups (f32 atomics into dh1v32, zeroed with the gradient arena) and the ReLU backward reads f32
-        e._gemm(P, L.GEMM_NN, self.dmu_v.p(), self.dmu_v.ld, w2.p(), w2.ld, self.dh1v32.p(), self.dh1v32.ld, B, D, D, out_f32=1,
-                split_k=max(1, min(D // 256, 512 // max(1, ((B + 127) // 128) * ((D + 127) // 128)))))
-        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.dh1v32.p(), self.dh1v32.ld, 1, self.h1v.p(), self.h1v.ld, None, 0,
-                self.dh1v.p(), self.dh1v.ld, B, D)
-        e._gemm(P, L.GEMM_TN, self.dh1v.p(), self.dh1v.ld, self.zt.p(), self.zt.ld, e.gp("inf_net_image.location.fc1.weight"), Z,
-                D, Z, B, out_f32=1, split_k=-1)
-        e._call(P, lib.vmmt_colsum, dt, self.dh1v.p(), self.dh1v.ld, B, D, e.gp("inf_net_image.location.fc1.bias"), None)
-        e._gemm(P, L.GEMM_NN, self.dh1v.p(), self.dh1v.ld, w1.p(), w1.ld, self.dzt.p(), self.dzt.ld, B, Z, D, out_f32=1,
-                split_k=max(1, min(D // 256, 256 // max(1, ((B + 63) // 64) * ((Z + 63) // 64)))))
-        e._call(P, lib.vmmt_gate_bwd, self.dzt.p(), self.dzt.ld, self.z32.p(), self.gate.data_ptr(),
-                e.gp("inf_net_image.gate_affine_transform.weight"), e.gp("inf_net_image.gate_affine_transform.bias"), B, Z)
         rp = bool(e.reparam_grad)
-        if rp and not hasattr(self, "dzrow"):
-            self.dzrow = Buf(M, Z, torch.float32, e.dev)       # dgates_t W_z per decoder row
-            self.dz = Buf(B, Z, torch.float32, e.dev, ld=Z)    # dL/dz of the reparameterised sample
-
+        TGT = 3
         def kl_and_q_backward():
             # --- KL term -> q(z|x) networks (mu, sigma receive gradient only through the KL: H2) ------------------
             # data parallelism: free bits compares the GLOBAL batch-mean KL with the margin (VILoss.py:463-476), so the KL sum is
@@ -992,35 +974,122 @@ class Workspace(object):
             self._latent_bwd_index = len(P)
             if d.conditional:
                 e._call(P, lib.vmmt_latent_cond_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
-                self._cond_backward(P, drop)
             else:
                 e._call(P, lib.vmmt_latent_bwd, *self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm))
             qx = self.hq if d.conditional else self.hbar        # input of the q network's first layer
-            for i, (br, dy) in enumerate((("location", self.q_dmu), ("scale", self.q_dpre))):
+            branches = (("location", self.q_dmu), ("scale", self.q_dpre))
+
+            def data_grads(i, br, dy):      # d h1 = relu'(.) (dy W2); conditional: d h_y = d h_q[:, H:2H] (h_x detached, v is data)
                 w2q = e.sh["q_%s_w2" % br]
-                pre = "inf_net_global.%s" % br
-                e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
-                e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"), None)
                 e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2q.p(), w2q.ld, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, Z)
                 e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.q_dh1[br].p(), self.q_dh1[br].ld, 0, self.q_h1[br].p(), self.q_h1[br].ld,
                         None, 0, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z)
-                e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, qx.p(), qx.ld, e.gp(pre + ".fc1.weight"), d.qin,
-                        Z, d.qin, B, out_f32=1, split_k=-1)
-                e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
-                if d.conditional:   # d h_y = d h_q[:, H:2H] (h_x is detached, v is data): columns [H, 2H) of W1
+                if d.conditional:           # columns [H, 2H) of W1
                     w1q = e.sh["q_%s_w1" % br]
                     e._gemm(P, L.GEMM_NN, self.q_dh1[br].p(), self.q_dh1[br].ld, w1q.p(0, H), w1q.ld, self.dhy.p(), self.dhy.ld, B, H, Z,
                             accumulate=1 if i else 0)
+
+            def weight_grads(part, br, dy):
+                pre = "inf_net_global.%s" % br
+                if part == 2:
+                    e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
+                    e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"), None)
+                else:
+                    e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, qx.p(), qx.ld, e.gp(pre + ".fc1.weight"), d.qin,
+                            Z, d.qin, B, out_f32=1, split_k=-1)
+                    e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
+
+            if cond_first:
+                # d h_y first (6 small kernels), then encoder_tgt's recurrence on its own stream; the weight gradients, p's backward
+                # and the image network follow on this stream, next to the recurrence.  encoder_tgt scatters into the shared
+                # target-embedding gradient, so the first arena half is finished behind it (finish_first_half at the end of the plan)
+                for i, (br, dy) in enumerate(branches):
+                    data_grads(i, br, dy)
+                e._record(P, "dhy")
+                e._sid = TGT
+                e._wait(P, "dhy")
+                self._cond_backward_tgt(P, drop)
+                e._record(P, "tgt_done")
+                e._sid = AUX
+                self._cond_backward(P, drop)        # d h_x for the encoder chain of the main stream (event dhbar_p)
+                for i, (br, dy) in enumerate(branches):
+                    weight_grads(2, br, dy)
+                    weight_grads(1, br, dy)
+                return                              # aux_chain() closes the stream (all-reduce, aux_done) behind the image network
+            if d.conditional:
+                self._cond_backward(P, drop)
+            for i, (br, dy) in enumerate(branches):
+                weight_grads(2, br, dy)
+                data_grads(i, br, dy)
+                weight_grads(1, br, dy)
             e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
             if d.conditional:
-                # encoder_tgt's backward: 2 x B dependent launches that only need d h_y, next to everything below.  They scatter
-                # into the shared target-embedding gradient, so the first arena half is finished behind them (finish_first_half
-                # at the end of the plan).  (Issuing them from a helper thread was measured: no gain, removed.)
                 self._cond_backward_tgt(P, drop)
             e._record(P, "aux_done")
 
-        if not rp:
-            kl_and_q_backward()
+        # conditional model: the critical path of the whole backward is d h_y -> encoder_tgt's 2 x B-step recurrence -> its parameter
+        # gradients, so the few kernels that produce d h_y go out first and the recurrence gets a stream of its own (TGT); everything
+        # else of this chain (image network, weight gradients of q / p, p's backward) runs next to it
+        cond_first = bool(d.conditional and not rp)
+        def aux_chain():
+            e._sid = AUX
+            e._wait(P, "bwd_begin")
+            if cond_first:
+                kl_and_q_backward()
+            self._patch["img"] = (len(P), 7)
+            e._call(P, lib.vmmt_image_loss, dt, self.mu_v.p(), self.mu_v.ld, self.img.p(), self.img.ld, B, D, inv_norm,
+                    self.dmu_v.p(), self.dmu_v.ld, self.stats.data_ptr())
+            w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
+            e._gemm(P, L.GEMM_TN, self.dmu_v.p(), self.dmu_v.ld, self.h1v.p(), self.h1v.ld, e.gp("inf_net_image.location.fc2.weight"), D,
+                    D, D, B, out_f32=1, split_k=-1)
+            e._call(P, lib.vmmt_colsum, dt, self.dmu_v.p(), self.dmu_v.ld, B, D, e.gp("inf_net_image.location.fc2.bias"), None)
+            # [B x D] x [D x D] with B = a few hundred rows: 32 tiles of 128 x 128 would leave 7/8 of the chip idle for 100 us, so the
+            # reduction is split over workgroups (f32 atomics into dh1v32, zeroed with the gradient arena) and the ReLU backward reads f32
+            e._gemm(P, L.GEMM_NN, self.dmu_v.p(), self.dmu_v.ld, w2.p(), w2.ld, self.dh1v32.p(), self.dh1v32.ld, B, D, D, out_f32=1,
+                    split_k=max(1, min(D // 256, 512 // max(1, ((B + 127) // 128) * ((D + 127) // 128)))))
+            e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.dh1v32.p(), self.dh1v32.ld, 1, self.h1v.p(), self.h1v.ld, None, 0,
+                    self.dh1v.p(), self.dh1v.ld, B, D)
+            e._gemm(P, L.GEMM_TN, self.dh1v.p(), self.dh1v.ld, self.zt.p(), self.zt.ld, e.gp("inf_net_image.location.fc1.weight"), Z,
+                    D, Z, B, out_f32=1, split_k=-1)
+            e._call(P, lib.vmmt_colsum, dt, self.dh1v.p(), self.dh1v.ld, B, D, e.gp("inf_net_image.location.fc1.bias"), None)
+            e._gemm(P, L.GEMM_NN, self.dh1v.p(), self.dh1v.ld, w1.p(), w1.ld, self.dzt.p(), self.dzt.ld, B, Z, D, out_f32=1,
+                    split_k=max(1, min(D // 256, 256 // max(1, ((B + 63) // 64) * ((Z + 63) // 64)))))
+            e._call(P, lib.vmmt_gate_bwd, self.dzt.p(), self.dzt.ld, self.z32.p(), self.gate.data_ptr(),
+                    e.gp("inf_net_image.gate_affine_transform.weight"), e.gp("inf_net_image.gate_affine_transform.bias"), B, Z)
+            if rp and not hasattr(self, "dzrow"):
+                self.dzrow = Buf(M, Z, torch.float32, e.dev)       # dgates_t W_z per decoder row
+                self.dz = Buf(B, Z, torch.float32, e.dev, ld=Z)    # dL/dz of the reparameterised sample
+
+            if cond_first:
+                e._wait(P, "tgt_done")
+                e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
+                e._record(P, "aux_done")
+            elif not rp:
+                kl_and_q_backward()
+
+        def main_head():
+            # main: dropout + tanh backward, linear_out, attention
+            e._sid = MAIN
+            e._call(P, lib.vmmt_act_bwd, dt, L.ACT_TANH, self.dO32.p(), self.dO32.ld, 1, self.AH.p(), self.AH.ld,
+                    self.out_mask.p() if drop else None, self.out_mask.ld if drop else 0, self.dPre.p(), self.dPre.ld, M, H)
+            e._record(P, "dPre")
+            wo, wa = e.sh["wo"], e.sh["wa"]
+            e._gemm(P, L.GEMM_NN, self.dPre.p(), self.dPre.ld, wo.p(), wo.ld, self.dcat.p(), self.dcat.ld, M, 2 * H, H)
+            ctx = self.enc_out[Lyr - 1]
+            e._call(P, lib.vmmt_attn_bwd, dt, self.dcat.p(), self.dcat.ld, self.probs.data_ptr(), self.Q.p(), self.Q.ld, ctx.p(), ctx.ld,
+                    self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, H)
+            e._record(P, "dQ")
+            e._gemm(P, L.GEMM_NN, self.dQ.p(), self.dQ.ld, wa.p(), wa.ld, self.dR.p(), self.dR.ld, M, H, H,
+                    addend=self.dcat.p(0, H), ld_add=self.dcat.ld, add_rows=-1, add_is_T=1)
+
+        # issue order = the order of this list.  With the fused generator dO exists when the plan starts, so the main stream's first
+        # kernels go out first instead of behind the ~20 small launches of the aux chain (tools/ab.py: 2.009 against 2.037 ms, equal
+        # in a second run); the conditional model keeps the aux chain first, it IS the critical path there (4.42 against 4.45 ms)
+        main_first = bool(self.gen_fused and not d.conditional and str(e.bwd_main_first) not in ('0', 'False'))
+        if main_first:
+            main_head()
+        else:
+            aux_chain()
         # side: dWg = G^T O as soon as G^T exists, underneath dO = G Wg of the main stream (measured, tools/ab.py: issuing it behind dR,
         # underneath the LSTM backward chains instead, is 3 % slower -- 2.333 vs 2.264 ms)
         e._sid = SIDE
@@ -1045,19 +1114,12 @@ class Workspace(object):
             if not fuse_db:
                 e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
         e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
-        # main: dropout + tanh backward, linear_out
-        e._sid = MAIN
-        e._call(P, lib.vmmt_act_bwd, dt, L.ACT_TANH, self.dO32.p(), self.dO32.ld, 1, self.AH.p(), self.AH.ld,
-                self.out_mask.p() if drop else None, self.out_mask.ld if drop else 0, self.dPre.p(), self.dPre.ld, M, H)
-        e._record(P, "dPre")
-        wo, wa = e.sh["wo"], e.sh["wa"]
-        e._gemm(P, L.GEMM_NN, self.dPre.p(), self.dPre.ld, wo.p(), wo.ld, self.dcat.p(), self.dcat.ld, M, 2 * H, H)
-        ctx = self.enc_out[Lyr - 1]
-        e._call(P, lib.vmmt_attn_bwd, dt, self.dcat.p(), self.dcat.ld, self.probs.data_ptr(), self.Q.p(), self.Q.ld, ctx.p(), ctx.ld,
-                self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, H)
-        e._record(P, "dQ")
-        e._gemm(P, L.GEMM_NN, self.dQ.p(), self.dQ.ld, wa.p(), wa.ld, self.dR.p(), self.dR.ld, M, H, H,
-                addend=self.dcat.p(0, H), ld_add=self.dcat.ld, add_rows=-1, add_is_T=1)
+        aux_late = main_first and str(e.bwd_main_first) == "2"
+        if main_first:
+            if not aux_late:
+                aux_chain()
+        else:
+            main_head()
         e._sid = SIDE
         e._wait(P, "dPre")
         e._gemm(P, L.GEMM_TN, self.dPre.p(), self.dPre.ld, self.cat.p(), self.cat.ld, e.gp("decoder.attn.linear_out.weight"), 2 * H,
@@ -1093,7 +1155,10 @@ class Workspace(object):
             a.dgates_next, a.ld_dgn = dg.p(0), dg.ld
             a.w_hh_t, a.ld_wt = whhT.p(), whhT.ld
             a.dh0_out, a.ld_dh0 = self.dec_dh0[l].p(), self.dec_dh0[l].ld
-            e._lstm_seq_bwd(P, seq, 1, Tp, None, B, H, with_dh0=1)
+            # conditional model: encoder_tgt's persistent backward (2 x B steps, 244 registers a lane) is running by now and the decoder's
+            # persistent kernel (373 registers, every CU) cannot share a SIMD with it -- it would wait for the whole chain; per-step
+            # launches fit next to it
+            e._lstm_seq_bwd(P, seq, 1, Tp, None, B, H, with_dh0=1, persistent=not (d.conditional and e.cond_dec_steps))
             e._record(P, "dec_dg%d" % l)
             if l > 0:       # gradient w.r.t. the layer input stays on the critical path
                 wi = e.sh["dec_wih_l%d" % l]
@@ -1122,6 +1187,8 @@ class Workspace(object):
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
+        if aux_late:
+            aux_chain()
         if rp:
             # reparameterised gradient (H2 switched off): dL/dz = sum_t dgates_t W_z (decoder input, VI_Model1.py:99-100) + the image
             # network's gate path; it joins the KL gradient at mu / sigma, so the q(z|x) networks' backward can only start here,
@@ -1374,7 +1441,10 @@ class Workspace(object):
         e._record(P, "dhbar_p")
 
     def _cond_backward_tgt(self, P, drop):
-        """aux stream: d h_y -> encoder_tgt (BPTT over the B recurrent steps) -> its parameters and the shared target embeddings"""
+        """stream TGT: d h_y -> encoder_tgt (BPTT over the B recurrent steps) -> its parameters and the shared target embeddings.
+        (Cutting the recurrence into 2 / 4 / 8 launches -- vmmt_lstm_seq_bwd continues a chain -- with the parameter gradients of a
+        finished piece issued next to the rest was measured: 4.36 / 4.38 / 4.59 ms per step against 4.27 ms in one piece; every
+        relaunch costs more than the shorter tail saves.)"""
         e, d, lib = self.e, self.e.d, self.e.lib
         B, H, ht, E, Lyr = self.B, d.hid, d.ht, d.emb, d.layers
         Tn, MT = self.Tn, self.MT
