@@ -167,8 +167,13 @@ class Engine(object):
         # fourth stream (conditional model only): encoder_tgt's backward recurrence, 2 x B dependent steps that would otherwise hold
         # up everything queued behind them on the aux stream
         self.tgt_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        # workgroups of the BACKGROUND half of Adam (side stream, underneath the next step's encoder recurrence).  Unthrottled it takes
+        # the memory system for ~200 us and the latency-bound persistent LSTM kernel next to it runs at half speed; one workgroup per
+        # CU still finishes before the decoder-side weights are needed.  tools/ab.py, ms per step: 4096 wgs 1.958-2.007 | 384: 1.957 |
+        # 288: 1.972 | 256: 1.921-1.951 | 224: 1.908 | 192: 1.987 | 128: 2.051 | 64: 2.324 (a faster two-chunk kernel at 256: 1.98)
+        self.bg_adam_blocks = int(_os_env.get("VMMT_BG_ADAM_BLOCKS", "256"))
         self.cond_dec_steps = _os_env.get("VMMT_COND_DEC_STEPS", "1") == "1"
-        self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1")      # issue order of the backward plan (see _plan_backward)
+        self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
@@ -1085,7 +1090,7 @@ class Workspace(object):
         # issue order = the order of this list.  With the fused generator dO exists when the plan starts, so the main stream's first
         # kernels go out first instead of behind the ~20 small launches of the aux chain (tools/ab.py: 2.009 against 2.037 ms, equal
         # in a second run); the conditional model keeps the aux chain first, it IS the critical path there (4.42 against 4.45 ms)
-        main_first = bool(self.gen_fused and not d.conditional and str(e.bwd_main_first) not in ('0', 'False'))
+        main_first = bool(self.gen_fused and not d.conditional and e.bwd_main_first)
         if main_first:
             main_head()
         else:
@@ -1102,6 +1107,7 @@ class Workspace(object):
                     V, H, M, out_f32=1, b_batch_rows=self.gen_vps, b_batch_stride=self.gen_Os.shape[1] * Kp)
             Og = self.O if (training_dropout and d.dropout > 0) else self.AH
             self._patch["gen"] = (len(P), 10)
+            # (bias gradient + one-hot term at the END of the side stream or of the aux stream instead: 1.988 / 1.967 against 1.931-1.934 ms)
             e._call(P, lib.vmmt_gen_dW_finish, dt, self.gen_P.data_ptr(), self.gen_ldp, self.gen_cs.data_ptr(), Og.p(), Og.ld,
                     self.gen_y32.data_ptr(), M, V, Kp, inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"))
         if self.gen_fused:
@@ -1114,10 +1120,8 @@ class Workspace(object):
             if not fuse_db:
                 e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
         e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
-        aux_late = main_first and str(e.bwd_main_first) == "2"
         if main_first:
-            if not aux_late:
-                aux_chain()
+            aux_chain()
         else:
             main_head()
         e._sid = SIDE
@@ -1187,8 +1191,6 @@ class Workspace(object):
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
-        if aux_late:
-            aux_chain()
         if rp:
             # reparameterised gradient (H2 switched off): dL/dz = sum_t dgates_t W_z (decoder input, VI_Model1.py:99-100) + the image
             # network's gate path; it joins the KL gradient at mu / sigma, so the q(z|x) networks' backward can only start here,
@@ -1680,11 +1682,12 @@ def _engine_methods():
         split = self.offsets[self.first_enc_name][0]
 
         def adam_range(lo, hi, stream, shadow=None):
+            blocks = int(self.bg_adam_blocks) if stream != st else 0
             if hi > lo:
                 L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
                                                 self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, lr, beta1, beta2,
                                                 eps, self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
-                                                0, shadow, stream), "vmmt_adam_step")
+                                                blocks, shadow, stream), "vmmt_adam_step")
 
         def adam(lo, hi, stream):
             # the big unpadded bf16 shadows (generator weight, image network fc2) are written by the update itself: their range is
