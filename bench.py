@@ -229,6 +229,10 @@ def main():
     eng = Engine(d, dtype=a.dtype, device=dev, seed=0)
     if a.no_side_stream:
         eng.use_side_stream = False
+    if os.environ.get("VMMT_BENCH_ONE_GPU") == "1" and world > 1:
+        # rehearsal only: the persistent recurrence kernels need every workgroup of a launch resident at once, which two processes
+        # sharing one GPU cannot both have (the launches then run into their 2-second hand-off bound and the run fails loudly)
+        eng.persistent_lstm = False
     n_img = cf["n_img"]
     gt = torch.Generator().manual_seed(11)
     eng.set_image_table(torch.rand(n_img, d.img, generator=gt))
