@@ -338,3 +338,50 @@ def test_shadows_after_an_optimiser_step_equal_a_fresh_pack():
     torch.cuda.synchronize()
     for k, b in e.sh.items():
         assert torch.equal(got[k], b.t), k
+
+
+def test_conditional_step_with_persistent_recurrences_bf16():
+    """the conditional model at a shape the persistent recurrence kernels serve (bf16, hid 128 -> encoder_tgt 2 x 64): encoder_tgt's
+    backward chain on its own stream, the decoder backward as per-step launches next to it, d h_y first -- every gradient against
+    the oracle, and against the same step issued on ONE stream with per-step launches (same kernels' arithmetic: the schedules
+    may only differ by the order of float atomics)"""
+    c = O.Cfg(vs=97, vt=101, emb=64, hid=128, z=32, img=2048, layers=1, brnn=True, conditional=True)
+    p = O.init_params(c, seed=4)
+    B, S, T = 40, 7, 9
+    bt = O.synth_batch(c, B=B, S=S, T=T, n_img=64, seed=9, fixed_len=False)
+    img = bt["table"][bt["indices"]]
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], img_semantic="B", tgt_len=bt["tgt_len"])
+    tol = TOL["bf16"]
+    grads = []
+    for plain in (False, True):
+        e = _engine(c, p, "bf16")
+        if plain:
+            e.persistent_lstm = False
+            e.use_side_stream = False
+        e.set_image_table(bt["table"])
+        for _ in range(2):          # twice through the same plans and exchange buffers
+            ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"], tgt_len=bt["tgt_len"])
+            e.loss_backward(ws, normalization=B)
+        torch.cuda.synchronize()
+        names = [n for _f, _a, n, _k, _s in ws.plan_bwd]
+        if not plain:
+            assert "vmmt_lstm_seq_bwd" in names and "vmmt_lstm_chain_bwd" in names      # encoder / encoder_tgt persistent, decoder per step
+            assert any(s == 3 for _f, _a, _n, _k, s in ws.plan_bwd)                      # encoder_tgt's chain on the fourth stream
+            assert not any(e.lstm_seq_errors())
+        else:
+            assert "vmmt_lstm_seq_bwd" not in names
+        grads.append({k: v.detach().cpu().double() for k, v in e.grads.items()})
+    bad = []
+    for k in g:
+        want = g[k].double()
+        scale = max(want.abs().max().item(), 1e-12)
+        for which, got in (("persistent", grads[0][k]), ("plain", grads[1][k])):
+            if "inf_net_image.location.fc1" in k or "gate_affine_transform" in k:
+                if (got - want).norm().item() > 0.15 * want.norm().item():
+                    bad.append((which, k, "relL2", (got - want).norm().item() / want.norm().item()))
+            elif (got - want).abs().max().item() > tol["grad"] * scale + 1e-9:
+                bad.append((which, k, (got - want).abs().max().item(), scale))
+        d = (grads[0][k] - grads[1][k]).abs().max().item()
+        if d > 2e-3 * scale + 1e-9:                     # schedules differ by float-atomic order only
+            bad.append(("schedules differ", k, d, scale))
+    assert not bad, bad
