@@ -204,6 +204,24 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
     alive = f >= 0;
   }
   __syncthreads();                                              // the flag word is part of the fold buffer
+  // ---- this wave's B fragments of W_hh (its two K quarters x four gates) -> REGISTERS, once: they are the same at every step, and
+  //      read from LDS per step (32 ds_read_b128 per wave at H = 512) the reads took as long as the MFMAs they feed -- 1.1 us of a
+  //      4 us step, 0.85 us with the fragments resident (tools/probe/lstm_seq_probe.hip).  2 * KQ * 4 fragments of 4 registers:
+  //      128 registers at H = 512.  (The backward kernel's sweep is bound by its 256 KiB of granules per workgroup and step, not
+  //      by its fragment reads: resident fragments and MFMAs pipelined under the sweep measured the same 6.9 us per step.)
+  bf16x8 wreg[2][KQ][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int ks = (2 * wk + j) * KQ + q;
+      const int c = (ks < Cf::NKS ? ks : 0) * 4 + kg;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = g * 16 + n;
+        wreg[j][q][g] = *reinterpret_cast<const bf16x8*>(lds + row * ROWB + ((c ^ Cf::key(row)) * 16));
+      }
+    }
 
   // epilogue operands that do not depend on the recurrence (x W_ih^T + b of the cell's four gates): those of step t+1 are
   // requested while step t computes, so that no step waits for them (they come from HBM: ~1 us when fetched at the step's top)
@@ -313,25 +331,13 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
       for (int g = 0; g < 4; ++g) acc[j][g] = f32x4_s{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      // all B fragments of a quarter first (KQ x 4 ds_read_b128 in flight), then its MFMAs: one LDS latency per quarter, not per MFMA
-      bf16x8 bv[KQ][4];
-#pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        const int ks = (2 * wk + j) * KQ + q;
-        const int c = (ks < Cf::NKS ? ks : 0) * 4 + kg;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = g * 16 + n;
-          bv[q][g] = *reinterpret_cast<const bf16x8*>(lds + row * ROWB + ((c ^ Cf::key(row)) * 16));
-        }
-      }
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         const int ks = (2 * wk + j) * KQ + q;
         if (ks < Cf::NKS) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            acc[j][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[j][q]), bv[q][g], acc[j][g], 0, 0, 0);
+            acc[j][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[j][q]), wreg[j][q][g], acc[j][g], 0, 0, 0);
         }
       }
     }
