@@ -149,7 +149,8 @@ int vmmt_lstm_seq_sync_words(void);
 int64_t vmmt_lstm_seq_xchg_bytes(int ndir, int B, int H);
 int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd* dirs, const vmmt_lstm_dir_fwd* dirs_dev,
                       const int64_t* lens, int B, int H, uint32_t* sync, void* xchg, void* stream);
-/* ... and the BACKWARD recurrence (the mode-0 steps of vmmt_lstm_step_bwd: step t consumes dgates_out of step t-1; dc_carry is
+/* ... and the BACKWARD recurrence (in-launch hand-off of dgates: dense pieces + one ready flag per producer wave, stored behind
+ * the acknowledged pieces).  The mode-0 steps of vmmt_lstm_step_bwd: step t consumes dgates_out of step t-1; dc_carry is
  * read at the first and written at the last step; step 0 has dgates_next == NULL, or -- a recurrence cut into several calls --
  * the plain dgates_out buffer of the last step of the call before, which is then read from memory).  What the row group exchanges is dgates
  * (4H values per sentence and step).  `xchg`: vmmt_lstm_seq_xchg_bytes_bwd() bytes; otherwise the contract of vmmt_lstm_seq_fwd;

@@ -342,7 +342,7 @@ def test_shadows_after_an_optimiser_step_equal_a_fresh_pack():
 
 def test_conditional_step_with_persistent_recurrences_bf16():
     """the conditional model at a shape the persistent recurrence kernels serve (bf16, hid 128 -> encoder_tgt 2 x 64): encoder_tgt's
-    backward chain on its own stream, the decoder backward as per-step launches next to it, d h_y first -- every gradient against
+    backward chain on its own stream next to the decoder's and the encoder's persistent launches, d h_y first -- every gradient against
     the oracle, and against the same step issued on ONE stream with per-step launches (same kernels' arithmetic: the schedules
     may only differ by the order of float atomics)"""
     c = O.Cfg(vs=97, vt=101, emb=64, hid=128, z=32, img=2048, layers=1, brnn=True, conditional=True)
@@ -365,7 +365,7 @@ def test_conditional_step_with_persistent_recurrences_bf16():
         torch.cuda.synchronize()
         names = [n for _f, _a, n, _k, _s in ws.plan_bwd]
         if not plain:
-            assert "vmmt_lstm_seq_bwd" in names and "vmmt_lstm_chain_bwd" in names      # encoder / encoder_tgt persistent, decoder per step
+            assert names.count("vmmt_lstm_seq_bwd") == 3 and "vmmt_lstm_chain_bwd" not in names      # decoder, encoder, encoder_tgt: persistent
             assert any(s == 3 for _f, _a, _n, _k, s in ws.plan_bwd)                      # encoder_tgt's chain on the fourth stream
             assert not any(e.lstm_seq_errors())
         else:

@@ -436,9 +436,14 @@ static int launch_seq_fwd(const SeqArgsF& a, hipStream_t st) {
 
 // ==============================================================================================================
 // Backward recurrence, same structure: dh_t[32 x 16] = dgates_{t+1}[32 x 4H] W_hh^T slice[16 x 4H]^T, then the cell backward.
-// What the workgroups of a row group exchange is dgates (4H values per sentence and step, 4x the forward's payload), again as
-// tagged granules in the consumers' fragment order; the W_hh^T slice (16 rows of 4H) stays in LDS; dL/dc stays in registers.
-// K quarters, accumulator pairs and fold order are those of lstm_step_bwd_fast (same bits).
+// What the workgroups of a row group exchange is dgates (4H values per sentence and step, 4x the forward's payload): every
+// workgroup reads the whole 32 x 4H tile of its group at every step, and that traffic is what bounds the step.  So the tile travels
+// DENSE (in the consumers' fragment order) and validity travels separately: a producer wave stores its pieces, waits until they
+// are acknowledged, and then stores a flag (the step's tag); consumers poll the 4 x S flags of the group and sweep without
+// checking anything.  Against the forward kernel's self-validating granules this costs one store acknowledgement (~0.7 us) per
+// hand-off and halves the bytes: 6.7 -> 5.1 us per step at H = 512 on an idle chip (tools/probe/lstm_seq_probe.hip), and 365 -> 272
+// registers.  The W_hh^T slice (16 rows of 4H) stays in LDS; dL/dc stays in registers.  K quarters, accumulator pairs and fold
+// order are those of lstm_step_bwd_fast (same bits).
 // ==============================================================================================================
 struct SeqDirB {      // == vmmt_lstm_dir_bwd
   const void* dgates_next; long ld_dgn;
@@ -486,11 +491,7 @@ template <int H> struct SeqCfgB {
 };
 
 template <int H>
-#ifdef VMMT_EXP_OLDLB
 __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
-#else
-__global__ void __launch_bounds__(256, (H <= 256 ? 2 : 1)) lstm_seq_bwd_kernel(SeqArgsB a) {
-#endif
   using Cf = SeqCfgB<H>;
   constexpr int ROWB = Cf::ROWB, KQ = Cf::KQ, NKS = Cf::NKS, CH = Cf::CH;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -510,8 +511,17 @@ __global__ void __launch_bounds__(256, (H <= 256 ? 2 : 1)) lstm_seq_bwd_kernel(S
   const int u = u0 + n;
   unsigned* err = a.sync + 2;
   const unsigned tag0 = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 4096u;
-  constexpr long SLOT_BYTES = 2L * NKS * 2048;                  // [2 row halves][NKS][lo / hi][64 lanes x 16 B]
-  char* xg = reinterpret_cast<char*>(a.xchg) + (long)grp * 2 * SLOT_BYTES;
+  // exchange area of my (direction, row group): two slots of DENSE dgates in the consumers' fragment order,
+  // [slot][row half][NKS k-steps][64 lanes x 16 B] (lane (row n of the half, k group kg) finds its 8 columns of k-step ks in ONE
+  // 16-byte load), then the ready flags [slot][4 producer waves x S producers] (a tag each).  The forward kernel's tagged granules
+  // carry their own validity but double the bytes, and this kernel is bound by them: every workgroup reads the whole 32 x 4H tile
+  // of its group at every step (tagged: 256 KiB per workgroup and step at H = 512, sweep + MFMAs 4.2 us of a 6.1 us step).
+  constexpr long DSLOT = 2L * NKS * 1024;
+  constexpr long GROUP_BYTES = 4L * NKS * 2048;                 // == vmmt_lstm_seq_xchg_bytes_bwd per (direction, row group)
+  constexpr int NFLAG = 4 * (H / 16);                           // per slot
+  static_assert(2 * DSLOT + 2 * NFLAG * 4 <= GROUP_BYTES, "flags must fit behind the data");
+  char* xg = reinterpret_cast<char*>(a.xchg) + (long)grp * GROUP_BYTES;
+  constexpr unsigned FLAG_OFF = (unsigned)(2 * DSLOT);
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(xg);
   {
     int* flag = reinterpret_cast<int*>(lds + Cf::W_BYTES);
@@ -619,50 +629,34 @@ __global__ void __launch_bounds__(256, (H <= 256 ? 2 : 1)) lstm_seq_bwd_kernel(S
 #pragma unroll
           for (int q = 0; q < KQ; ++q) af[j][q] = *reinterpret_cast<const u32x4*>(src + ((2 * wk + j) * KQ + q) * 32);
       } else {
-      const unsigned want = tag0 + (unsigned)t;                 // tag of the step processed just before
-      const unsigned sbase = (unsigned)((((t - 1) & 1) * 2 + wm) * (NKS * 2048));
-      const unsigned long long t_start = wall_clock64();
-      {   // cheap poll: one granule (hi piece of the odd k group, row 0) per 16-unit producer piece of this wave's K half
-        const int ks = wk * (NKS / 2) + (lane >> 1);
-        const unsigned pbase = sbase + (unsigned)((ks * 2 + 1) * 1024 + ((2 * (lane & 1) + 1) * 16) * 16);
-        while (alive) {
-          unsigned long long g = 0;
-          if (lane < NKS) g = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(xg + pbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__all(lane >= NKS || (unsigned)(g >> 32) == want)) break;
-          if (timed_out(t_start)) {
-            if (lane == 0) __hip_atomic_store(err, 0x500u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            alive = false;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      SEQ_TS(1);
-      // the whole K half of this wave in flight at once (2 * KQ k-steps, a lo and a hi piece each), then tags, then MFMAs
-      const unsigned gbase = sbase + (unsigned)((2 * wk * KQ) * 2048 + lane * 16);
-      for (;;) {
-        bool ok = true;
+        const unsigned want = tag0 + (unsigned)t;               // tag of the step processed just before
+        const unsigned long long t_start = wall_clock64();
+        {   // wait until every producer wave of the row group has flagged that step: NFLAG tags, 4 bytes each, contiguous
+          const unsigned fbase = FLAG_OFF + (unsigned)(((t - 1) & 1) * NFLAG * 4);
+          while (alive) {
+            bool ok = true;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          u32x4 lo[KQ], hi[KQ];
-#pragma unroll
-          for (int q = 0; q < KQ; ++q) {
-            lo[q] = load16_sc1(xr, gbase + (unsigned)((j * KQ + q) * 2048));
-            hi[q] = load16_sc1(xr, gbase + (unsigned)((j * KQ + q) * 2048 + 1024));
-          }
-#pragma unroll
-          for (int q = 0; q < KQ; ++q) {
-            ok = ok && lo[q][1] == want && lo[q][3] == want && hi[q][1] == want && hi[q][3] == want;
-            af[j][q] = u32x4{lo[q][0], lo[q][2], hi[q][0], hi[q][2]};
+            for (int i = 0; i < (NFLAG + 63) / 64; ++i) {
+              const int f = i * 64 + lane;
+              unsigned g = want;
+              if (f < NFLAG) g = __hip_atomic_load(reinterpret_cast<const unsigned*>(xg + fbase) + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = ok && g == want;
+            }
+            if (__all(ok)) break;
+            if (timed_out(t_start)) {
+              if (lane == 0) __hip_atomic_store(err, 0x500u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              alive = false;
+            }
+            __builtin_amdgcn_s_sleep(1);
           }
         }
-        if (__all(ok) || !alive) break;
-        if (timed_out(t_start)) {
-          if (lane == 0) __hip_atomic_store(err, 0x600u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          alive = false;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
+        SEQ_TS(1);
+        // the flags were stored behind the producers' data (acknowledged by the L2 / by memory): the tile is complete, no tags to check
+        const unsigned gbase = (unsigned)((((t - 1) & 1) * 2 + wm) * (NKS * 1024) + (2 * wk * KQ) * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) af[j][q] = load16_sc1(xr, gbase + (unsigned)((j * KQ + q) * 1024));
       }
       if (t + 1 < a.nsteps) fetch_in(load_desc_b(a.steps, (long)(t + 1) * ndir + k));
 #pragma unroll
@@ -726,20 +720,24 @@ __global__ void __launch_bounds__(256, (H <= 256 ? 2 : 1)) lstm_seq_bwd_kernel(S
     SEQ_TS(5);
     __syncthreads();
     SEQ_TS(6);
-    // ---- publish dgates_t: 512 pieces of two granules (gate, row, 4 units) for the row group, then the plain [B][4H] buffer
+    // ---- publish dgates_t: 256 dense 16-byte pieces (gate, half of the 16 units, row), each wave flags its own stores once they
+    //      are acknowledged; then the plain [B][4H] buffer for the kernels that follow
     {
       const unsigned tg = tag0 + (unsigned)t + 1u;
-#pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) {
-        // piece id -> (gate, piece-of-4-units, row) with the row fastest: 16 consecutive lanes store 256 contiguous bytes
-        const int id = i2 * 256 + threadIdx.x, g = id >> 7, piece = (id >> 5) & 3, r = id & 31;
-        const unsigned* hw = reinterpret_cast<const unsigned*>(dtile + r * 64 + g * 16 + piece * 4);
-        const int ks = (g * H + u0) >> 5;
-        const unsigned off = (unsigned)((((t & 1) * 2 + (r >> 4)) * (NKS * 2048)) + (ks * 2 + (piece & 1)) * 1024 +
-                                        (((u0 & 16) ? 2 : 0) + (piece >> 1)) * 256 + (r & 15) * 16);
-        const u32x4 v = u32x4{hw[0], tg, hw[1], tg};
-        if (same_xcd) *reinterpret_cast<u32x4*>(xg + off) = v;
-        else store16_sc1(xr, off, v);
+      {
+        // piece id -> (gate, 8-unit half, row) with the row fastest: 16 consecutive lanes store 256 contiguous bytes
+        const int id = threadIdx.x, g = id >> 6, half = (id >> 5) & 1, r = id & 31;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(dtile + r * 64 + g * 16 + half * 8);
+        const int ks = (g * H + u0) >> 5, kgp = ((u0 & 16) ? 2 : 0) + half;
+        const unsigned off = (unsigned)((((t & 1) * 2 + (r >> 4)) * (NKS * 1024)) + ks * 1024 + (kgp * 16 + (r & 15)) * 16);
+        if (same_xcd) *reinterpret_cast<u32x4*>(xg + off) = v;   // stays in the group's L2
+        else store16_sc1(xr, off, v);                             // write-through: visible to every XCD
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces have reached the L2 (or memory)
+      if (lane == 0) {
+        unsigned* fl = reinterpret_cast<unsigned*>(xg + FLAG_OFF) + (t & 1) * NFLAG + wave * S + slice;
+        if (same_xcd) *reinterpret_cast<volatile unsigned*>(fl) = tg;
+        else __hip_atomic_store(fl, tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       // plain copy for the kernels that follow (weight gradients, dx): 32 rows x 4 gates x 32 bytes = 256 x 16 bytes
       const int r = threadIdx.x >> 3, g = (threadIdx.x >> 1) & 3, half = threadIdx.x & 1;

@@ -172,7 +172,6 @@ class Engine(object):
         # CU still finishes before the decoder-side weights are needed.  tools/ab.py, ms per step: 4096 wgs 1.958-2.007 | 384: 1.957 |
         # 288: 1.972 | 256: 1.921-1.951 | 224: 1.908 | 192: 1.987 | 128: 2.051 | 64: 2.324 (a faster two-chunk kernel at 256: 1.98)
         self.bg_adam_blocks = int(_os_env.get("VMMT_BG_ADAM_BLOCKS", "256"))
-        self.cond_dec_steps = _os_env.get("VMMT_COND_DEC_STEPS", "1") == "1"
         self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
@@ -403,11 +402,10 @@ class Engine(object):
         else:
             plan.append((self.lib.vmmt_lstm_chain_fwd, (self.dt, ndir, nsteps, arr, lens_ptr, B, H), "vmmt_lstm_chain_fwd", arr, self._sid))
 
-    def _lstm_seq_bwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H, with_dh0=0, persistent=True):
+    def _lstm_seq_bwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H, with_dh0=0):
         """plan entry: a whole backward recurrence (the mode-0 steps; with_dh0: `arr` ends with one mode-1 step, the gradient of
-        the initial hidden state), see _lstm_seq_fwd.  persistent=False: one launch per step even when the engine uses the
-        persistent kernels (a recurrence that has to run NEXT TO another persistent launch it cannot share a CU with)"""
-        if self.persistent_lstm and persistent:
+        the initial hidden state), see _lstm_seq_fwd"""
+        if self.persistent_lstm:
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
             sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
             xchg = torch.zeros(max(16, self.lib.vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H)), dtype=torch.uint8, device=self.dev)
@@ -1159,10 +1157,9 @@ class Workspace(object):
             a.dgates_next, a.ld_dgn = dg.p(0), dg.ld
             a.w_hh_t, a.ld_wt = whhT.p(), whhT.ld
             a.dh0_out, a.ld_dh0 = self.dec_dh0[l].p(), self.dec_dh0[l].ld
-            # conditional model: encoder_tgt's persistent backward (2 x B steps, 244 registers a lane) is running by now and the decoder's
-            # persistent kernel (373 registers, every CU) cannot share a SIMD with it -- it would wait for the whole chain; per-step
-            # launches fit next to it
-            e._lstm_seq_bwd(P, seq, 1, Tp, None, B, H, with_dh0=1, persistent=not (d.conditional and e.cond_dec_steps))
+            # (conditional model: encoder_tgt's persistent backward is running by now; two persistent launches share a CU only if their
+            #  registers fit one SIMD file and their LDS one CU -- 272 + 166 registers, 72 + 40 KiB here)
+            e._lstm_seq_bwd(P, seq, 1, Tp, None, B, H, with_dh0=1)
             e._record(P, "dec_dg%d" % l)
             if l > 0:       # gradient w.r.t. the layer input stays on the critical path
                 wi = e.sh["dec_wih_l%d" % l]
