@@ -81,8 +81,14 @@ typedef struct vmmt_gemm_args {
   int b_batch_rows; int64_t b_batch_stride; /* b_batch_rows > 0 (a multiple of 256): output rows [i r, (i + 1) r) use the B operand
                   at B + i * b_batch_stride elements -- one launch for row blocks that share A's layout but not B (the generator's
                   weight gradient: one scaled copy of the decoder outputs per vocabulary slice) */
+  const float* colsum_w; int64_t colsum_w_stride; float* colsum_out; /* colsum_w != NULL (layout TN only): colsum_out[m] += sum_k
+                  A[k][m] * w[k] with w = colsum_w + (m / b_batch_rows) * colsum_w_stride (w = colsum_w without B blocks), f32, K
+                  entries readable -- the weighted column sums of the K-strided A operand out of the pass that multiplies it (the
+                  generator's bias gradient next to its weight gradient).  Only where vmmt_gemm_colsum_applies() returns 1;
+                  otherwise VMMT_EINVAL */
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
+int vmmt_gemm_colsum_applies(const vmmt_gemm_args* args);
 
 /* ---- LSTM time steps ------------------------------------------------------------------------------------------
  * One launch per time step (both directions of a bidirectional layer in the same launch).  The input projection
@@ -232,7 +238,9 @@ int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bia
  *       cs  f32 [nsplit][mpad]: c_s[m] = s_m exp(ref_s[m] - lse_m), so that dL/dlogit[m][v] = P[m][v] c_s[m] - [v == y_m] s_m;
  *       Os  T [nsplit][os_stride]: O'_s[m][:] = c_s[m] O[m][:] (rows ld ldos; rows >= M are never written: keep them zero).
  * Then dWg[v in slice s][:] = sum_m P[m][v] O'_s[m][:] is ONE vmmt_gemm (GEMM_TN, K = M, b_batch_rows = v_per_split,
- * b_batch_stride = os_stride, plain store) and vmmt_gen_dW_finish adds the bias gradient and the one-hot term.
+ * b_batch_stride = os_stride, plain store) and vmmt_gen_dW_finish adds the bias gradient and the one-hot term; where
+ * vmmt_gemm_colsum_applies() holds the bias gradient's weighted column sums of P come out of that GEMM (colsum_w = cs, stride mpad,
+ * colsum_out = dbias; entries of cs beyond M must be zero) and the finish call is told so (colsum_done = 1).
  * vmmt_gen_fused_applies() tells whether the shape is served (otherwise VMMT_EINVAL: the caller uses the G^T path above).
  * Reference: the same lines as above (ModelConstructor.py:583-585, Loss.py:129,163-165). */
 int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M, int V, int K);
@@ -244,7 +252,7 @@ int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, i
                          int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
                          float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride, void* stream);
 int vmmt_gen_dW_finish(int dtype, const void* P, int64_t ldp, const float* cs, const void* O, int64_t ldo, const int* y32, int M, int V,
-                       int K, float inv_norm, float* dW, int64_t lddw, float* dbias, void* stream);
+                       int K, float inv_norm, float* dW, int64_t lddw, float* dbias, int colsum_done, void* stream);
 
 /* ---- row gathers / small fused kernels -------------------------------------------------------------------------- */
 /* out[r][0:D] = table[ids[r]][0:D]; table f32 (embedding master weights: modules/Embeddings.py:181; or the HBM-resident

@@ -342,7 +342,7 @@ def test_generator_fused_pass_bf16(M, V, H, ramp):
         if v0 < v1:
             dW2[v0:v1] = Pw[:M, v0:v1].float().t() @ Os[s_, :M].float()
     db2 = torch.full((V,), 0.5, device="cuda")
-    L.check(lib.vmmt_gen_dW_finish(L.BF16, P(Pw), ldp, P(cs), P(Od), H, P(y32), M, V, H, inv_norm, P(dW2), H, P(db2), None), "dW finish")
+    L.check(lib.vmmt_gen_dW_finish(L.BF16, P(Pw), ldp, P(cs), P(Od), H, P(y32), M, V, H, inv_norm, P(dW2), H, P(db2), 0, None), "dW finish")
     torch.cuda.synchronize()
     e4 = (dW2.cpu().double() - dW_ref).norm().item() / max(1e-30, dW_ref.norm().item())
     assert e4 <= 6e-3, e4
@@ -374,6 +374,44 @@ def test_gemm_per_row_block_b_operand():
     bad = L.GemmArgs(L.BF16, L.GEMM_TN, At.data_ptr(), Mr + 4, Bs.data_ptr(), N, Cd.data_ptr(), N, Mr, N, K, 0, 0, None, 0, 0, 0, L.ACT_NONE,
                      1, 0, 1.0, None, 1, 0, 0, 100, K * N)
     assert lib.vmmt_gemm(C.byref(bad), None) != 0                   # blocks must be whole tiles (multiples of 256 rows)
+
+
+def test_gemm_weighted_column_sums_of_the_k_strided_operand():
+    """vmmt_gemm_args.colsum_w / colsum_out: colsum_out[m] += sum_k A[k][m] w_block(m)[k] out of the same pass as C = A^T B (the
+    generator's bias gradient next to its weight gradient), where vmmt_gemm_colsum_applies() says so; the product itself unchanged"""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5)
+    T = torch.bfloat16
+    Mr, N, K, r = 24980, 512, 704, 8192                            # ragged last tile (24980 = 97 * 256 + 148), 4 row blocks
+    nb = (Mr + r - 1) // r
+    lda = Mr + 4
+    At = (torch.randn(K, lda, generator=g) * 0.5).to(T).cuda()
+    Bs = (torch.randn(nb, K, N, generator=g) * 0.5).to(T).cuda()
+    w = torch.randn(nb, K + 64, generator=g).cuda()                # stride K + 64 between the blocks' weight vectors
+    out = torch.full((Mr + 8,), 0.25, device="cuda")
+    outs = []
+    for with_sums in (True, False):
+        Cd = torch.full((Mr, N), 9.0, device="cuda")
+        a = L.GemmArgs(L.BF16, L.GEMM_TN, At.data_ptr(), lda, Bs.data_ptr(), N, Cd.data_ptr(), N, Mr, N, K, 0, 0, None, 0, 0, 0, L.ACT_NONE,
+                       1, 0, 1.0, None, 1, 0, 0, r, K * N)
+        if with_sums:
+            a.colsum_w, a.colsum_w_stride, a.colsum_out = w.data_ptr(), K + 64, out.data_ptr()
+            assert lib.vmmt_gemm_colsum_applies(C.byref(a)) == 1
+        L.check(lib.vmmt_gemm(C.byref(a), None), "gemm")
+        torch.cuda.synchronize()
+        outs.append(Cd)
+    assert torch.equal(outs[0], outs[1])                           # the product does not notice
+    for i in range(nb):
+        r0, r1 = i * r, min(Mr, (i + 1) * r)
+        want = 0.25 + (At[:, r0:r1].double() * w[i, :K].double()[:, None]).sum(0)
+        got = out[r0:r1].double()
+        assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item()), (i, (got - want).abs().max().item())
+    assert (out[Mr:] == 0.25).all()
+    small = L.GemmArgs(L.BF16, L.GEMM_TN, At.data_ptr(), lda, Bs.data_ptr(), N, outs[0].data_ptr(), N, 1024, N, K, 0, 0, None, 0, 0, 0, L.ACT_NONE,
+                       1, 0, 1.0, None, 1, 0, 0, 0, 0)
+    small.colsum_w, small.colsum_out = w.data_ptr(), out.data_ptr()
+    assert lib.vmmt_gemm_colsum_applies(C.byref(small)) == 0 and lib.vmmt_gemm(C.byref(small), None) != 0     # small products: not offered
 
 
 def test_scatter_add_rows_with_padding_row():

@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
                 ("ldc", i64), ("M", i32), ("N", i32), ("K", i32), ("a_kmod", i32), ("b_kmod", i32),
                 ("addend", vp), ("ld_add", i64), ("add_rows", i32), ("add_is_T", i32), ("act", i32),
                 ("out_f32", i32), ("accumulate", i32), ("alpha", f32), ("scatter_ids", vp), ("pad_id", i32),
-                ("tile", i32), ("split_k", i32), ("b_batch_rows", i32), ("b_batch_stride", i64)]
+                ("tile", i32), ("split_k", i32), ("b_batch_rows", i32), ("b_batch_stride", i64),
+                ("colsum_w", vp), ("colsum_w_stride", i64), ("colsum_out", vp)]
 
 
 class LstmDirFwd(C.Structure):
@@ -86,7 +87,8 @@ _SIGS = {
     "vmmt_gen_fwd_dO": (i32, [i32, vp, i64, i32, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, i64, vp]),
     "vmmt_gen_fwd_combine": (i32, [i32, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp]),
     "vmmt_gen_fused_geometry": (i32, [i32, i32, vp, vp, vp]),
-    "vmmt_gen_dW_finish": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, f32, vp, i64, vp, vp]),
+    "vmmt_gen_dW_finish": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, f32, vp, i64, vp, i32, vp]),
+    "vmmt_gemm_colsum_applies": (i32, [C.POINTER(GemmArgs)]),
     "vmmt_gather_rows": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, vp]),
     "vmmt_scatter_add_rows": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_colsum": (i32, [i32, vp, i64, i32, i32, vp, vp, vp]),

@@ -17,6 +17,7 @@ struct GemmEpi {
   const long long* scatter_ids; int pad_id;                      // embedding-gradient scatter (atomic add, fp32 C)
   int atomic;                                                    // split-K: fp32 atomicAdd into a pre-zeroed / partial C
   int b_batch_rows; long b_batch_stride;                         // B of output rows [i r, (i + 1) r) starts at B + i * stride (elements)
+  const float* colsum_w; long colsum_w_stride; float* colsum_out; // K-strided A only: colsum_out[m] += sum_k A[k][m] w[k] (w per B block)
 };
 
 // The epilogue runs as a few small, fully unrolled passes over the accumulator registers (static indices only:
@@ -99,7 +100,9 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B_, long ld
   const int kbeg = blockIdx.y * kper;                 // split-K: this block reduces over [kbeg, kend)
   const int kend = min(K, kbeg + kper);
   if constexpr (GL == 3) {   // LDS-DMA main loops (glds_gemm.hpp); preconditions checked by launch_layout
-    gemm_mainloop_glds3<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
+    // the weighted column sums of A ride along in the workgroups of the first column tile (one pass over A per launch)
+    const float* cw = (epi.colsum_w && tn == 0) ? epi.colsum_w + (epi.b_batch_rows > 0 ? (long)(m0 / epi.b_batch_rows) * epi.colsum_w_stride : 0L) : nullptr;
+    gemm_mainloop_glds3<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, cw, epi.colsum_out);
   } else if constexpr (GL == 4) {   // half-depth slabs, both operands K-contiguous (glds_gemm.hpp)
     static_assert(GL != 4 || (A_KC && B_KC), "the half-depth loop stages K-contiguous operands");
     gemm_mainloop_hglds3<BM, BN, NT / 64, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
@@ -158,11 +161,13 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
       // the two-stage 128 x 128 loop on the [30000 x 512 x 5120]-class products, equal or worse on small ones (tools/gemm_ab.py)
       if (gl_ok && lds_min == 0 && a->tile == 0 && t128 >= 768 && a->K >= 512)
         return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
+      if (epi.colsum_w) return VMMT_EINVAL;        // vmmt_gemm_colsum_applies() says when the fused column sums are available
       // LDS-DMA main loop when its preconditions hold (+10..15 % over the register-staged loop, tools/gemm_ab.py)
       if (gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st, lds_min);
       return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st, lds_min);
     } else return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st, lds_min);
   }
+  if (epi.colsum_w) return VMMT_EINVAL;
   return launch_cfg<T, 64, 64, 32, 32, A_KC, B_KC>(a, epi, st);
 }
 
@@ -195,6 +200,16 @@ int gemm_launch_nn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) 
 }  // namespace vmmt
 
 #if VMMT_GEMM_PART == -1 || VMMT_GEMM_PART == 0
+// 1 when vmmt_gemm would compute colsum_w / colsum_out for these arguments: bf16, layout TN (A K-strided), the 256 x 128 three-stage
+// LDS-DMA configuration (>= 768 tiles of 128 x 128, K >= 512 and a multiple of 64, aligned operands, no k-modulus, no split-K)
+extern "C" int vmmt_gemm_colsum_applies(const vmmt_gemm_args* a) {
+  if (!a || a->dtype != VMMT_BF16 || a->layout != VMMT_GEMM_TN || a->tile != 0 || a->split_k > 1 || a->scatter_ids) return 0;
+  const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+  const bool gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
+                     ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
+  return gl_ok && t128 >= 768 && a->K >= 512 ? 1 : 0;
+}
+
 extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
   using namespace vmmt;
   if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N < 0 || a->K < 0) return VMMT_EINVAL;
@@ -207,6 +222,8 @@ extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
   e.alpha = a->alpha; e.scatter_ids = (const long long*)a->scatter_ids; e.pad_id = a->pad_id;
   e.atomic = a->split_k > 1 ? 1 : 0;
   e.b_batch_rows = a->b_batch_rows; e.b_batch_stride = (long)a->b_batch_stride;
+  e.colsum_w = a->colsum_w; e.colsum_w_stride = (long)a->colsum_w_stride; e.colsum_out = a->colsum_out;
+  if (a->colsum_w && (!a->colsum_out || !vmmt_gemm_colsum_applies(a))) return VMMT_EINVAL;
   if (a->b_batch_rows < 0 || (a->b_batch_rows > 0 && a->b_batch_rows % 256 != 0)) return VMMT_EINVAL;   // whole tiles (<= 256 rows) per block
   hipStream_t st = (hipStream_t)stream;
   switch (a->layout) {

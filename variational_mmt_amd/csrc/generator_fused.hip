@@ -788,16 +788,20 @@ extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const
 
 // what the dWg GEMMs (one per vocabulary slice: dWg[slice] = P[:, slice]^T O'_slice, plain vmmt_gemm calls) leave to do:
 //   dbias[v] += sum_m P[m][v] c_s(v)[m]   and the one-hot term   dWg[y_m] -= s_m O[m],  dbias[y_m] -= s_m
+// colsum_done != 0: the weighted column sums came out of the dWg GEMM itself (vmmt_gemm_args.colsum_w = cs, colsum_w_stride = mpad,
+// colsum_out = dbias: no second pass over P); only the one-hot term is left
 extern "C" int vmmt_gen_dW_finish(int dtype, const void* Pw, int64_t ldp, const float* cs, const void* O, int64_t ldo, const int* y32,
-                                  int M, int V, int K, float inv_norm, float* dW, int64_t lddw, float* dbias, void* stream) {
+                                  int M, int V, int K, float inv_norm, float* dW, int64_t lddw, float* dbias, int colsum_done,
+                                  void* stream) {
   using namespace vmmt;
   if (dtype != VMMT_BF16 || !Pw || !cs || !O || !y32 || !dW || !dbias || M <= 0 || V <= 0 || (K != 512 && K != 256) || (ldp & 7) ||
       (((uintptr_t)Pw) & 15) || lddw < K)
     return VMMT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long mpad = (long)((M + 127) / 128) * 128;
-  hipLaunchKernelGGL(gen2_db_kernel, dim3((V + 511) / 512, (M + 127) / 128), dim3(256), 0, st, (const bf16_t*)Pw, (long)ldp, cs, mpad,
-                     g2_tiles_per_split(M, V) * 32, M, V, dbias);
+  if (!colsum_done)
+    hipLaunchKernelGGL(gen2_db_kernel, dim3((V + 511) / 512, (M + 127) / 128), dim3(256), 0, st, (const bf16_t*)Pw, (long)ldp, cs, mpad,
+                       g2_tiles_per_split(M, V) * 32, M, V, dbias);
   if (K == 512)
     hipLaunchKernelGGL((gen2_onehot_kernel<512>), dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)O, (long)ldo, y32, inv_norm, M, dW,
                        (long)lddw, dbias);

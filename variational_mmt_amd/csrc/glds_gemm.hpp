@@ -208,11 +208,52 @@ __device__ __forceinline__ void glds_wait_vm() { asm volatile("s_waitcnt vmcnt(%
 template <int BM, int BN>
 constexpr int glds3_smem_bytes() { return 3 * (BM + BN) * GBK * 2; }
 
+// Weighted column sums of a K-strided A slab that sits in LDS anyway: csum[col] += sum_k A[k][col] * w[k] over the 64 k-rows of the
+// slab (the generator's bias gradient db[v] = sum_m P[m][v] c[m] next to dWg = P^T O': a second pass over the 307 MB of P
+// otherwise).  256 columns, 8 waves: wave w owns k-rows 8 w .. 8 w + 7, whose weights arrive by ONE scalar load (SMEM does not touch
+// the VM counter the LDS-DMA pipeline is counted on) and stay wave-uniform: lane l reads 8 bytes = columns 4 l .. 4 l + 3 of one k-row
+// per instruction (64 lanes = the whole 512-byte row).
+typedef const float __attribute__((address_space(4))) * GldsConstF;
+typedef unsigned gu32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void glds_colsum_slab(const char* As, const float* __restrict__ w, int wave, int lane, float (&cs)[4]) {
+  float wk[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+  GldsConstF wp = reinterpret_cast<GldsConstF>(reinterpret_cast<uintptr_t>(w + wave * 8));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wk[i] = wp[i];
+#else
+  for (int i = 0; i < 8; ++i) wk[i] = w[wave * 8 + i];
+#endif
+  // the reads are inline assembly: as plain loads the compiler orders them behind the LDS-DMA of the slab just requested (s_waitcnt
+  // vmcnt(0) in front of their first use), which would drain the three-stage pipeline in every workgroup that carries the sums
+  const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)As + (unsigned)((lane >> 5) * 16384 + (lane & 1) * 8);
+  const int ch = (lane >> 1) & 15;
+  gu32x2 vv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int kr = wave * 8 + i;                                  // (kr & 3) == (i & 3): the swizzle key is a compile-time constant
+    asm volatile("ds_read_b64 %0, %1" : "=v"(vv[i]) : "v"(base + (unsigned)(kr * 256) + (unsigned)((ch ^ ((i & 3) * 4)) * 16)) : "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      cs[2 * e] = __builtin_fmaf(__uint_as_float(vv[i][e] << 16), wk[i], cs[2 * e]);
+      cs[2 * e + 1] = __builtin_fmaf(__uint_as_float(vv[i][e] & 0xffff0000u), wk[i], cs[2 * e + 1]);
+    }
+  }
+}
+
 template <int BM, int BN, int NW, bool A_KC, bool B_KC, int TI, int TJ>
 __device__ __forceinline__ void gemm_mainloop_glds3(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
                                                     long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
-                                                    const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem) {
+                                                    const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem,
+                                                    const float* __restrict__ colsum_w = nullptr, float* __restrict__ colsum_out = nullptr) {
   constexpr int ABYTES = BM * GBK * 2, BBYTES = BN * GBK * 2, BUF = ABYTES + BBYTES;
+  constexpr bool CS_OK = !A_KC && BM == 256 && NW == 8;          // the only shape glds_colsum_slab is written for
+  const bool cs_on = CS_OK && colsum_w != nullptr;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
   using GA = GldsOperand<BM, A_KC, NW>;
   using GB = GldsOperand<BN, B_KC, NW>;
   constexpr int PW = GA::PER + GB::PER;           // LDS-DMA instructions per wave and slab
@@ -241,6 +282,7 @@ __device__ __forceinline__ void gemm_mainloop_glds3(const bf16_t* __restrict__ A
       ga.issue(smem + (NXT2) * BUF, wave);                                                             \
       gb.issue(smem + (NXT2) * BUF + ABYTES, wave);                                                    \
     }                                                                                                  \
+    if (cs_on) glds_colsum_slab(smem + (CUR) * BUF, colsum_w + kbeg + s * GBK, wave, lane, csum);       \
     glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem + (CUR) * BUF, smem + (CUR) * BUF + ABYTES, fa, fb, aoff, boff, acc); \
     ++s;                                                                                               \
   }
@@ -254,6 +296,13 @@ __device__ __forceinline__ void gemm_mainloop_glds3(const bf16_t* __restrict__ A
   }
 #undef VMMT_GLDS3_STEP
   __builtin_amdgcn_s_barrier();      // the staging buffers may be reused by the caller's epilogue
+  if (cs_on) {                       // every wave holds the sums of its eight k-rows per slab for all 256 columns: one atomic per wave and column
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = m0 + lane * 4 + e;
+      if (col < M) atomicAdd(colsum_out + col, csum[e]);
+    }
+  }
 }
 
 

@@ -172,6 +172,7 @@ class Engine(object):
         # CU still finishes before the decoder-side weights are needed.  tools/ab.py, ms per step: 4096 wgs 1.958-2.007 | 384: 1.957 |
         # 288: 1.972 | 256: 1.921-1.951 | 224: 1.908 | 192: 1.987 | 128: 2.051 | 64: 2.324 (a faster two-chunk kernel at 256: 1.98)
         self.bg_adam_blocks = int(_os_env.get("VMMT_BG_ADAM_BLOCKS", "256"))
+        self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
         self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
@@ -372,7 +373,9 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------ helpers
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
               act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
-              b_batch_rows=0, b_batch_stride=0):
+              b_batch_rows=0, b_batch_stride=0, colsum=None):
+        """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out): the weighted column sums of the K-strided A operand from the same
+        pass, where the library offers them; returns whether they were attached"""
         if split_k == -1:
             # weight-gradient heuristic: enough workgroups to fill 256 CUs a few times, >= 256 reduction steps each
             tiles = ((M + 63) // 64) * ((N + 63) // 64)
@@ -382,8 +385,16 @@ class Engine(object):
         if a_kmod == 0 and b_kmod == 0:
             K = _ru(K, KPAD)            # operands are Bufs: zero-padded to whole slabs (see Buf)
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
-                       add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k, b_batch_rows, b_batch_stride)
+                       add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k, b_batch_rows, b_batch_stride,
+                       None, 0, None)
+        attached = False
+        if colsum is not None:
+            a.colsum_w, a.colsum_w_stride, a.colsum_out = colsum
+            attached = bool(self.lib.vmmt_gemm_colsum_applies(C.byref(a)))
+            if not attached:
+                a.colsum_w, a.colsum_w_stride, a.colsum_out = None, 0, None
         plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
+        return attached
 
     def _call(self, plan, fn, *args):
         plan.append((fn, args, fn.__name__, None, self._sid))
@@ -1101,13 +1112,16 @@ class Workspace(object):
             # dWg[slice s] = P[:, slice s]^T O'_s: ONE plain GEMM (K = tokens; the B operand switches with the vocabulary slice), then the
             # bias gradient and the one-hot term
             Kp = _ru(H, KPAD)
-            e._gemm(P, L.GEMM_TN, self.gen_P.data_ptr(), self.gen_ldp, self.gen_Os.data_ptr(), Kp, e.gp("generator.0.weight"), H,
-                    V, H, M, out_f32=1, b_batch_rows=self.gen_vps, b_batch_stride=self.gen_Os.shape[1] * Kp)
+            # the bias gradient's weighted column sums of P ride in the GEMM's first column tile where its large-tile path runs
+            # (e.gen_db_in_gemm: switch for tools/ab.py); otherwise vmmt_gen_dW_finish makes its own pass over P
+            fused_db = e._gemm(P, L.GEMM_TN, self.gen_P.data_ptr(), self.gen_ldp, self.gen_Os.data_ptr(), Kp, e.gp("generator.0.weight"), H,
+                               V, H, M, out_f32=1, b_batch_rows=self.gen_vps, b_batch_stride=self.gen_Os.shape[1] * Kp,
+                               colsum=(self.gen_cs.data_ptr(), self.gen_mpad, e.gp("generator.0.bias")) if e.gen_db_in_gemm else None)
             Og = self.O if (training_dropout and d.dropout > 0) else self.AH
             self._patch["gen"] = (len(P), 10)
             # (bias gradient + one-hot term at the END of the side stream or of the aux stream instead: 1.988 / 1.967 against 1.931-1.934 ms)
             e._call(P, lib.vmmt_gen_dW_finish, dt, self.gen_P.data_ptr(), self.gen_ldp, self.gen_cs.data_ptr(), Og.p(), Og.ld,
-                    self.gen_y32.data_ptr(), M, V, Kp, inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"))
+                    self.gen_y32.data_ptr(), M, V, Kp, inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"), 1 if fused_db else 0)
         if self.gen_fused:
             # right away: issued later (on the aux stream behind the image / q(z|x) backward, i.e. underneath the LSTM backward chains) the
             # GEMM competes with the persistent LSTM kernels for CUs -- 2.20 against 2.11-2.13 ms per step (tools/ab.py, arms on shared streams)
