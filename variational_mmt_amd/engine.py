@@ -173,6 +173,7 @@ class Engine(object):
         # 288: 1.972 | 256: 1.921-1.951 | 224: 1.908 | 192: 1.987 | 128: 2.051 | 64: 2.324 (a faster two-chunk kernel at 256: 1.98)
         self.bg_adam_blocks = int(_os_env.get("VMMT_BG_ADAM_BLOCKS", "256"))
         self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
+        self.dec_grads_on_aux = _os_env.get("VMMT_DEC_GRADS_ON_AUX", "1") == "1"
         self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
@@ -1143,7 +1144,12 @@ class Workspace(object):
         e._wait(P, "dQ")
         e._gemm(P, L.GEMM_TN, self.dQ.p(), self.dQ.ld, self.cat.p(0, H), self.cat.ld, e.gp("decoder.attn.linear_in.weight"), H,
                 H, H, M, out_f32=1, split_k=-1)
-        # ================= decoder LSTM backward (main) + its parameter gradients (side) ==========================
+        # the decoder's parameter gradients and the first-half norm go to the AUX stream, which is idle once its own chain (image /
+        # q(z|x) networks) is through: behind the generator's products on the side stream they reached into the step's tail
+        dec_on_aux = bool(e.dec_grads_on_aux and not rp and not d.conditional and e.use_aux_stream)
+        if dec_on_aux:
+            e._record(P, "side_first")              # generator + attention products issued on the side stream
+        # ================= decoder LSTM backward (main) + its parameter gradients (side / aux) ====================
         dh_above = self.dR
         for l in reversed(range(Lyr)):
             e._sid = MAIN
@@ -1182,8 +1188,8 @@ class Workspace(object):
                     e._call(P, lib.vmmt_mul, dt, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, self.dec_mask[l - 1].p(),
                             self.dec_mask[l - 1].ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H)
                 dh_above = self.dec_dx[l - 1]
-            # ---- side: parameter gradients of this layer
-            e._sid = SIDE
+            # ---- side / aux: parameter gradients of this layer
+            e._sid = AUX if dec_on_aux else SIDE
             e._wait(P, "dec_dg%d" % l)
             gw = "decoder.rnn.weight_hh_l%d" % l
             if Tp > 1:
@@ -1222,7 +1228,13 @@ class Workspace(object):
             e._sumsq_entry(P, "generator.0.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1), 0)
             e._wait(P, "aux_done")
             e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None, 2)
-        if not d.conditional:
+        if dec_on_aux:
+            e._sid = AUX
+            e._wait(P, "side_first")
+            finish_first_half()
+            e._record(P, "aux_end")
+            e._sid = SIDE
+        elif not d.conditional:
             finish_first_half()
         # ================= encoder LSTM backward (main) + its parameter gradients (side) ==========================
         if d.conditional:   # p(z|x) reads the NON-detached memory (Models.py:889): d context[s,b] += d hbar_p[b] / len_b
@@ -1258,11 +1270,11 @@ class Workspace(object):
                     if t1 > lo:
                         e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, self.enc_out[l].p((lo + 1) * B, k * Hd), self.enc_out[l].ld,
                                 e.gp(gw), Hd, 4 * Hd, Hd, (t1 - lo) * B, out_f32=1, split_k=-1)
-                e._call(P, lib.vmmt_colsum, dt, dg.p(lo * B, k * 4 * Hd), dg.ld, (hi - lo) * B, 4 * Hd,
-                        e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)), e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
-                alt()
+                alt()           # (alternating: main = the two dW_hh and the embedding product behind them, side = dW_ih + bias sums)
                 e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, xin.p(lo * B), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)),
                         xcols, 4 * Hd, xcols, (hi - lo) * B, out_f32=1, split_k=-1)
+                e._call(P, lib.vmmt_colsum, dt, dg.p(lo * B, k * 4 * Hd), dg.ld, (hi - lo) * B, 4 * Hd,
+                        e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)), e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
             if l == 0:                                # embedding gradient: one product over both directions, last on the main stream
                 assert all(r == (0, S) for r in ranges)
                 e._sid = MAIN
@@ -1322,6 +1334,8 @@ class Workspace(object):
         e._record(P, "side_done")
         e._sid = MAIN
         e._wait(P, "side_done")
+        if dec_on_aux:
+            e._wait(P, "aux_end")
         e._allreduce(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
         e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight", 1)
         return P
