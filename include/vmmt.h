@@ -84,8 +84,10 @@ typedef struct vmmt_gemm_args {
   const float* colsum_w; int64_t colsum_w_stride; float* colsum_out; /* colsum_w != NULL (layout TN only): colsum_out[m] += sum_k
                   A[k][m] * w[k] with w = colsum_w + (m / b_batch_rows) * colsum_w_stride (w = colsum_w without B blocks), f32, K
                   entries readable -- the weighted column sums of the K-strided A operand out of the pass that multiplies it (the
-                  generator's bias gradient next to its weight gradient).  Only where vmmt_gemm_colsum_applies() returns 1;
-                  otherwise VMMT_EINVAL */
+                  generator's bias gradient next to its weight gradient).  colsum_w == NULL, colsum_out != NULL: plain sums
+                  colsum_out[m] += sum_k A[k][m] (an LSTM bias gradient next to dW_hh).  Only where vmmt_gemm_colsum_applies()
+                  returns 1; otherwise VMMT_EINVAL */
+  float* colsum_out2; /* plain sums only: a second destination of the same sums (nn.LSTM's bias_ih and bias_hh), or NULL */
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
 int vmmt_gemm_colsum_applies(const vmmt_gemm_args* args);

@@ -414,6 +414,33 @@ def test_gemm_weighted_column_sums_of_the_k_strided_operand():
     assert lib.vmmt_gemm_colsum_applies(C.byref(small)) == 0 and lib.vmmt_gemm(C.byref(small), None) != 0     # small products: not offered
 
 
+def test_gemm_plain_column_sums_with_split_k():
+    """colsum_w == NULL: colsum_out[m] (and colsum_out2[m]) += sum_k A[k][m] next to a split-K weight-gradient product (an LSTM bias
+    gradient, both nn.LSTM bias vectors, out of dW_ih = dgates^T x)"""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(6)
+    T = torch.bfloat16
+    Mr, N, K = 1000, 500, 5120                                     # ragged rows and columns
+    At = (torch.randn(K, 1024, generator=g) * 0.5).to(T).cuda()
+    Bm = (torch.randn(K, 512, generator=g) * 0.5).to(T).cuda()
+    for split in (1, 4):
+        Cd = torch.zeros(Mr, N, device="cuda")
+        o1, o2 = torch.full((Mr + 8,), 0.5, device="cuda"), torch.full((Mr + 8,), -1.0, device="cuda")
+        a = L.GemmArgs(L.BF16, L.GEMM_TN, At.data_ptr(), 1024, Bm.data_ptr(), 512, Cd.data_ptr(), N, Mr, N, K, 0, 0, None, 0, 0, 0, L.ACT_NONE,
+                       1, 1 if split == 1 else 0, 1.0, None, 1, 128 if split == 1 else 0, split, 0, 0)
+        a.colsum_out, a.colsum_out2 = o1.data_ptr(), o2.data_ptr()
+        assert lib.vmmt_gemm_colsum_applies(C.byref(a)) == 1
+        L.check(lib.vmmt_gemm(C.byref(a), None), "gemm")
+        torch.cuda.synchronize()
+        want_c = At[:, :Mr].float().t() @ Bm[:, :N].float()
+        assert (Cd - want_c).abs().max().item() <= 2e-2 * want_c.abs().max().item()
+        want = At[:, :Mr].double().sum(0)
+        assert (o1[:Mr].double() - 0.5 - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item()), split
+        assert (o2[:Mr].double() + 1.0 - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item()), split
+        assert (o1[Mr:] == 0.5).all() and (o2[Mr:] == -1.0).all()
+
+
 def test_scatter_add_rows_with_padding_row():
     """vmmt_scatter_add_rows: out[ids[r]] += X[r] with the padding id dropped (modules/Embeddings.py:118) against index_add_"""
     from variational_mmt_amd import _lib as L

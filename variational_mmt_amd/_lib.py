@@ -28,7 +28,7 @@ class GemmArgs(C.Structure):
                 ("addend", vp), ("ld_add", i64), ("add_rows", i32), ("add_is_T", i32), ("act", i32),
                 ("out_f32", i32), ("accumulate", i32), ("alpha", f32), ("scatter_ids", vp), ("pad_id", i32),
                 ("tile", i32), ("split_k", i32), ("b_batch_rows", i32), ("b_batch_stride", i64),
-                ("colsum_w", vp), ("colsum_w_stride", i64), ("colsum_out", vp)]
+                ("colsum_w", vp), ("colsum_w_stride", i64), ("colsum_out", vp), ("colsum_out2", vp)]
 
 
 class LstmDirFwd(C.Structure):

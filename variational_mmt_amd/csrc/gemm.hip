@@ -18,6 +18,7 @@ struct GemmEpi {
   int atomic;                                                    // split-K: fp32 atomicAdd into a pre-zeroed / partial C
   int b_batch_rows; long b_batch_stride;                         // B of output rows [i r, (i + 1) r) starts at B + i * stride (elements)
   const float* colsum_w; long colsum_w_stride; float* colsum_out; // K-strided A only: colsum_out[m] += sum_k A[k][m] w[k] (w per B block)
+  float* colsum_out2;                                            // unit weights (colsum_w == NULL): a second destination of the same sums
 };
 
 // The epilogue runs as a few small, fully unrolled passes over the accumulator registers (static indices only:
@@ -107,7 +108,9 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B_, long ld
     static_assert(GL != 4 || (A_KC && B_KC), "the half-depth loop stages K-contiguous operands");
     gemm_mainloop_hglds3<BM, BN, NT / 64, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
   } else if constexpr (GL == 1) {
-    gemm_mainloop_glds<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
+    // plain column sums of A (unit weights) in the workgroups of the first column tile, every K split adds its share
+    float* co = (epi.colsum_out && !epi.colsum_w && tn == 0) ? epi.colsum_out : nullptr;
+    gemm_mainloop_glds<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, co, epi.colsum_out2);
   } else {
     gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ, LinearMap, LinearMap, DB>(A, lda, amap, B, ldb, bmap, kend, a_kmod,
                                                                                     b_kmod, aoff, boff, acc, smem, kbeg);
@@ -159,15 +162,24 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
     if constexpr (sizeof(T) == 2) {
       // large problems: 256 x 128 tiles, 8 waves, three LDS stages with counted waits (two slabs in flight): +7..14 % over
       // the two-stage 128 x 128 loop on the [30000 x 512 x 5120]-class products, equal or worse on small ones (tools/gemm_ab.py)
-      if (gl_ok && lds_min == 0 && a->tile == 0 && t128 >= 768 && a->K >= 512)
+      // (column sums of A: weighted ones ride in the 256 x 128 loop, plain ones in the two-stage 128 x 128 loop; anything else is
+      //  refused -- vmmt_gemm_colsum_applies() says beforehand which it will be)
+      const bool cs_w = epi.colsum_w != nullptr, cs_1 = epi.colsum_out != nullptr && !cs_w;
+      if (gl_ok && lds_min == 0 && a->tile == 0 && t128 >= 768 && a->K >= 512) {
+        if (cs_1) return VMMT_EINVAL;
         return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
-      if (epi.colsum_w) return VMMT_EINVAL;        // vmmt_gemm_colsum_applies() says when the fused column sums are available
+      }
+      if (cs_w) return VMMT_EINVAL;
       // LDS-DMA main loop when its preconditions hold (+10..15 % over the register-staged loop, tools/gemm_ab.py)
       if (gl_ok) return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 1>(a, epi, st, lds_min);
+      if (cs_1) return VMMT_EINVAL;
       return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true>(a, epi, st, lds_min);
-    } else return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st, lds_min);
+    } else {
+      if (epi.colsum_out) return VMMT_EINVAL;
+      return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC>(a, epi, st, lds_min);
+    }
   }
-  if (epi.colsum_w) return VMMT_EINVAL;
+  if (epi.colsum_out) return VMMT_EINVAL;
   return launch_cfg<T, 64, 64, 32, 32, A_KC, B_KC>(a, epi, st);
 }
 
@@ -200,14 +212,21 @@ int gemm_launch_nn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) 
 }  // namespace vmmt
 
 #if VMMT_GEMM_PART == -1 || VMMT_GEMM_PART == 0
-// 1 when vmmt_gemm would compute colsum_w / colsum_out for these arguments: bf16, layout TN (A K-strided), the 256 x 128 three-stage
-// LDS-DMA configuration (>= 768 tiles of 128 x 128, K >= 512 and a multiple of 64, aligned operands, no k-modulus, no split-K)
+// 1 when vmmt_gemm would compute the column sums of A for these arguments (bf16, layout TN = A K-strided, K a multiple of 64, aligned
+// operands, no k-modulus): WEIGHTED sums (colsum_w) in the 256 x 128 three-stage configuration (>= 768 tiles of 128 x 128, K >= 512,
+// no split-K), PLAIN sums (colsum_w == NULL, colsum_out and optionally colsum_out2) in the two-stage 128 x 128 configuration, split-K
+// included
 extern "C" int vmmt_gemm_colsum_applies(const vmmt_gemm_args* a) {
-  if (!a || a->dtype != VMMT_BF16 || a->layout != VMMT_GEMM_TN || a->tile != 0 || a->split_k > 1 || a->scatter_ids) return 0;
-  const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+  if (!a || a->dtype != VMMT_BF16 || a->layout != VMMT_GEMM_TN || a->scatter_ids) return 0;
+  const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * (a->split_k > 1 ? a->split_k : 1);
   const bool gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
                      ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
-  return gl_ok && t128 >= 768 && a->K >= 512 ? 1 : 0;
+  if (!gl_ok) return 0;
+  const bool big = a->tile == 0 && t128 >= 768 && a->K >= 512;     // the 256 x 128 three-stage configuration (launch_layout)
+  if (a->colsum_w) return (big && a->split_k <= 1 && !a->colsum_out2) ? 1 : 0;
+  // plain sums: the two-stage 128 x 128 LDS-DMA configuration
+  const bool t128path = a->tile == 128 || (a->tile == 0 && (t128 >= 192 || (a->K >= 1024 && t128 >= 8)));
+  return (t128path && !big) ? 1 : 0;
 }
 
 extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
@@ -222,8 +241,8 @@ extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
   e.alpha = a->alpha; e.scatter_ids = (const long long*)a->scatter_ids; e.pad_id = a->pad_id;
   e.atomic = a->split_k > 1 ? 1 : 0;
   e.b_batch_rows = a->b_batch_rows; e.b_batch_stride = (long)a->b_batch_stride;
-  e.colsum_w = a->colsum_w; e.colsum_w_stride = (long)a->colsum_w_stride; e.colsum_out = a->colsum_out;
-  if (a->colsum_w && (!a->colsum_out || !vmmt_gemm_colsum_applies(a))) return VMMT_EINVAL;
+  e.colsum_w = a->colsum_w; e.colsum_w_stride = (long)a->colsum_w_stride; e.colsum_out = a->colsum_out; e.colsum_out2 = a->colsum_out2;
+  if ((a->colsum_w || a->colsum_out || a->colsum_out2) && (!a->colsum_out || !vmmt_gemm_colsum_applies(a))) return VMMT_EINVAL;
   if (a->b_batch_rows < 0 || (a->b_batch_rows > 0 && a->b_batch_rows % 256 != 0)) return VMMT_EINVAL;   // whole tiles (<= 256 rows) per block
   hipStream_t st = (hipStream_t)stream;
   switch (a->layout) {

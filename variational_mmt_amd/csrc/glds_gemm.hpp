@@ -147,13 +147,40 @@ __device__ __forceinline__ void glds_slab(const char* As, const char* Bs, const 
 template <int BM, int BN, bool DBUF = true>
 constexpr int glds_smem_bytes() { return (DBUF ? 2 : 1) * (BM + BN) * GBK * 2; }
 
+typedef unsigned gu32x2 __attribute__((ext_vector_type(2)));
+// Plain column sums of a K-strided 128-column A slab, 4 waves (the bias gradient db = sum over tokens of dgates next to dW_hh =
+// dgates^T h: the dgates would otherwise be read once more by a kernel of their own): wave w owns k-rows 16 w .. 16 w + 15, one
+// 8-byte read covers columns 4 (l & 31) .. + 3 of k-row 2 i + (l >> 5).  Inline assembly for the reason given at glds_colsum_slab.
+__device__ __forceinline__ void glds_colsum128_slab(const char* As, int wave, int lane, float (&cs)[4]) {
+  const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)As + (unsigned)((lane & 1) * 8);
+  const int ch = (lane >> 1) & 15, par = lane >> 5;
+  gu32x2 vv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int kr = wave * 16 + 2 * i + par;                       // (kr & 3) = (2 i + par) & 3
+    asm volatile("ds_read_b64 %0, %1" : "=v"(vv[i]) : "v"(base + (unsigned)(kr * 256 + ((ch ^ ((kr & 3) * 4)) * 16))) : "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      cs[2 * e] += __uint_as_float(vv[i][e] << 16);
+      cs[2 * e + 1] += __uint_as_float(vv[i][e] & 0xffff0000u);
+    }
+}
+
 // C_tile += A_tile * B_tile^T over k in [kbeg, kend), kend - kbeg a positive multiple of 64.
 template <int BM, int BN, int NW, bool A_KC, bool B_KC, int TI, int TJ, bool DBUF = true>
 __device__ __forceinline__ void gemm_mainloop_glds(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
                                                    long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
-                                                   const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem) {
+                                                   const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem,
+                                                   float* __restrict__ colsum_out = nullptr, float* __restrict__ colsum_out2 = nullptr) {
   constexpr int ABYTES = BM * GBK * 2, BBYTES = BN * GBK * 2, BUF = ABYTES + BBYTES;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  constexpr bool CS_OK = !A_KC && BM == 128 && NW == 4 && DBUF;   // the shape glds_colsum128_slab is written for
+  const bool cs_on = CS_OK && colsum_out != nullptr;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
   GldsOperand<BM, A_KC, NW> ga;
   GldsOperand<BN, B_KC, NW> gb;
   ga.init(A, lda, m0, M, kbeg, wave, lane);
@@ -182,18 +209,32 @@ __device__ __forceinline__ void gemm_mainloop_glds(const bf16_t* __restrict__ A,
     // slab s in buffer 0, slab s+1 into buffer 1
     ga.issue(smem + BUF, wave);
     gb.issue(smem + BUF + ABYTES, wave);
+    if (cs_on) glds_colsum128_slab(smem, wave, lane, csum);
     glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem, smem + ABYTES, fa, fb, aoff, boff, acc);
     __syncthreads();
     if (s + 2 < nslab) {
       ga.issue(smem, wave);
       gb.issue(smem + ABYTES, wave);
     }
+    if (cs_on) glds_colsum128_slab(smem + BUF, wave, lane, csum);
     glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem + BUF, smem + BUF + ABYTES, fa, fb, aoff, boff, acc);
     __syncthreads();
   }
   if (s < nslab) {   // odd count: the last slab sits in buffer 0
+    if (cs_on) glds_colsum128_slab(smem, wave, lane, csum);
     glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem, smem + ABYTES, fa, fb, aoff, boff, acc);
     __syncthreads();
+  }
+  if (cs_on) {       // lanes l and l + 32 hold the two k-row parities of the same four columns
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = csum[e] + __shfl_xor(csum[e], 32, 64);
+      const int col = m0 + (lane & 31) * 4 + e;
+      if (lane < 32 && col < M) {
+        atomicAdd(colsum_out + col, t);
+        if (colsum_out2) atomicAdd(colsum_out2 + col, t);
+      }
+    }
   }
 }
 
@@ -214,7 +255,6 @@ constexpr int glds3_smem_bytes() { return 3 * (BM + BN) * GBK * 2; }
 // the VM counter the LDS-DMA pipeline is counted on) and stay wave-uniform: lane l reads 8 bytes = columns 4 l .. 4 l + 3 of one k-row
 // per instruction (64 lanes = the whole 512-byte row).
 typedef const float __attribute__((address_space(4))) * GldsConstF;
-typedef unsigned gu32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void glds_colsum_slab(const char* As, const float* __restrict__ w, int wave, int lane, float (&cs)[4]) {
   float wk[8];
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -173,6 +173,7 @@ class Engine(object):
         # 288: 1.972 | 256: 1.921-1.951 | 224: 1.908 | 192: 1.987 | 128: 2.051 | 64: 2.324 (a faster two-chunk kernel at 256: 1.98)
         self.bg_adam_blocks = int(_os_env.get("VMMT_BG_ADAM_BLOCKS", "256"))
         self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
+        self.lstm_db_in_gemm = _os_env.get("VMMT_LSTM_DB_IN_GEMM", "1") == "1"
         self.dec_grads_on_aux = _os_env.get("VMMT_DEC_GRADS_ON_AUX", "1") == "1"
         self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
@@ -375,8 +376,8 @@ class Engine(object):
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
               act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
               b_batch_rows=0, b_batch_stride=0, colsum=None):
-        """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out): the weighted column sums of the K-strided A operand from the same
-        pass, where the library offers them; returns whether they were attached"""
+        """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out[, out2]): the column sums of the K-strided A operand from the same
+        pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached"""
         if split_k == -1:
             # weight-gradient heuristic: enough workgroups to fill 256 CUs a few times, >= 256 reduction steps each
             tiles = ((M + 63) // 64) * ((N + 63) // 64)
@@ -387,13 +388,14 @@ class Engine(object):
             K = _ru(K, KPAD)            # operands are Bufs: zero-padded to whole slabs (see Buf)
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
                        add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k, b_batch_rows, b_batch_stride,
-                       None, 0, None)
+                       None, 0, None, None)
         attached = False
         if colsum is not None:
-            a.colsum_w, a.colsum_w_stride, a.colsum_out = colsum
+            a.colsum_w, a.colsum_w_stride, a.colsum_out = colsum[:3]
+            a.colsum_out2 = colsum[3] if len(colsum) > 3 else None
             attached = bool(self.lib.vmmt_gemm_colsum_applies(C.byref(a)))
             if not attached:
-                a.colsum_w, a.colsum_w_stride, a.colsum_out = None, 0, None
+                a.colsum_w, a.colsum_w_stride, a.colsum_out, a.colsum_out2 = None, 0, None, None
         plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
         return attached
 
@@ -1195,10 +1197,12 @@ class Workspace(object):
             if Tp > 1:
                 e._gemm(P, L.GEMM_TN, dg.p(B), dg.ld, outb.p(0, ocol), outb.ld, e.gp(gw), H, 4 * H, H, (Tp - 1) * B, out_f32=1, split_k=-1)
             e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * H, H, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_ih_l%d" % l), e.gp("decoder.rnn.bias_hh_l%d" % l))
             gi = "decoder.rnn.weight_ih_l%d" % l
+            # the bias gradient (column sums of dgates) rides in the dW_ih product, which reads all M rows of dgates anyway
+            bsum = (None, 0, e.gp("decoder.rnn.bias_ih_l%d" % l), e.gp("decoder.rnn.bias_hh_l%d" % l)) if e.lstm_db_in_gemm else None
             if l == 0:
-                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * H, E, M, out_f32=1, split_k=-1)
+                fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * H, E, M, out_f32=1, split_k=-1,
+                                  colsum=bsum)
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * H, Z, M, out_f32=1, split_k=-1, b_kmod=B)
                 we = e.sh["dec_wih_l0_e"]
                 # dX = dgates W_e, then its rows scattered into the embedding gradient (pad row dropped)
@@ -1207,7 +1211,9 @@ class Workspace(object):
                         e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E, M, E)
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
-                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1)
+                fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1, colsum=bsum)
+            if not fused_b:
+                e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_ih_l%d" % l), e.gp("decoder.rnn.bias_hh_l%d" % l))
         if rp:
             # reparameterised gradient (H2 switched off): dL/dz = sum_t dgates_t W_z (decoder input, VI_Model1.py:99-100) + the image
             # network's gate path; it joins the KL gradient at mu / sigma, so the q(z|x) networks' backward can only start here,
@@ -1271,10 +1277,12 @@ class Workspace(object):
                         e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, self.enc_out[l].p((lo + 1) * B, k * Hd), self.enc_out[l].ld,
                                 e.gp(gw), Hd, 4 * Hd, Hd, (t1 - lo) * B, out_f32=1, split_k=-1)
                 alt()           # (alternating: main = the two dW_hh and the embedding product behind them, side = dW_ih + bias sums)
-                e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, xin.p(lo * B), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)),
-                        xcols, 4 * Hd, xcols, (hi - lo) * B, out_f32=1, split_k=-1)
-                e._call(P, lib.vmmt_colsum, dt, dg.p(lo * B, k * 4 * Hd), dg.ld, (hi - lo) * B, 4 * Hd,
-                        e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)), e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf)))
+                bih, bhh = e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)), e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf))
+                fused_b = e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, xin.p(lo * B), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)),
+                                  xcols, 4 * Hd, xcols, (hi - lo) * B, out_f32=1, split_k=-1,
+                                  colsum=(None, 0, bih, bhh) if e.lstm_db_in_gemm else None)      # bias gradient: see the decoder's
+                if not fused_b:
+                    e._call(P, lib.vmmt_colsum, dt, dg.p(lo * B, k * 4 * Hd), dg.ld, (hi - lo) * B, 4 * Hd, bih, bhh)
             if l == 0:                                # embedding gradient: one product over both directions, last on the main stream
                 assert all(r == (0, S) for r in ranges)
                 e._sid = MAIN
