@@ -172,6 +172,10 @@ class Engine(object):
         # CU still finishes before the decoder-side weights are needed.  tools/ab.py, ms per step: 4096 wgs 1.958-2.007 | 384: 1.957 |
         # 288: 1.972 | 256: 1.921-1.951 | 224: 1.908 | 192: 1.987 | 128: 2.051 | 64: 2.324 (a faster two-chunk kernel at 256: 1.98)
         self.bg_adam_blocks = int(_os_env.get("VMMT_BG_ADAM_BLOCKS", "256"))
+        # cap of the weight-gradient products' split-K.  On an idle chip 4, 8 and 16 splits cost the same (tools/gemm_split.py), in the step
+        # the extra workgroups and atomics get in the way of everything that runs next to them (tools/ab.py, ms per step by cap: 64:
+        # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)
+        self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
         self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
         self.lstm_db_in_gemm = _os_env.get("VMMT_LSTM_DB_IN_GEMM", "1") == "1"
         self.dec_grads_on_aux = _os_env.get("VMMT_DEC_GRADS_ON_AUX", "1") == "1"
@@ -379,9 +383,9 @@ class Engine(object):
         """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out[, out2]): the column sums of the K-strided A operand from the same
         pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached"""
         if split_k == -1:
-            # weight-gradient heuristic: enough workgroups to fill 256 CUs a few times, >= 256 reduction steps each
+            # weight-gradient heuristic: enough workgroups to fill 256 CUs, >= 256 reduction steps each, at most max_split_k splits
             tiles = ((M + 63) // 64) * ((N + 63) // 64)
-            split_k = max(1, min(K // 256, (1024 + tiles - 1) // tiles))
+            split_k = max(1, min(K // 256, (1024 + tiles - 1) // tiles, int(self.max_split_k)))
             if split_k == 1:
                 accumulate = 1          # gradients always ACCUMULATE into the arena (zeroed at the start of a step)
         if a_kmod == 0 and b_kmod == 0:
