@@ -4,7 +4,7 @@
 # gpurun_out/; the summaries worth keeping are copied into profiles/ by hand.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-timeout -k 10 300 bash tools/prof.sh r2final --steps 20 --warmup 5 > gpurun_out/r2_prof.txt 2>&1 &&
+timeout -k 10 300 bash tools/prof.sh r2final > gpurun_out/r2_prof.txt 2>&1 &&
 python tools/timeline.py gpurun_out/prof_r2final > gpurun_out/r2_timeline.txt 2>&1 &&
 cp $(find gpurun_out/prof_r2final -name "*kernel_stats.csv" | head -1) gpurun_out/r2_kernel_stats.csv &&
 timeout -k 10 400 bash tools/pmc.sh r2final > gpurun_out/r2_pmc.txt 2>&1 &&
