@@ -334,7 +334,7 @@ __global__ void zero_multi_kernel(const vmmt_zero_desc* __restrict__ descs, int 
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const long off = off0 + ((long)k * 256 + threadIdx.x) * 16;
-    if (off + 16 <= d.bytes) *reinterpret_cast<f32x4*>(base + off) = z;
+    if (off + 16 <= d.bytes) __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(base + off));     // streamed: keep the L2s for the kernels next door
     else
       for (long o = off; o + 4 <= d.bytes; o += 4) *reinterpret_cast<float*>(base + o) = 0.f;     // tail (bytes % 16 != 0)
   }

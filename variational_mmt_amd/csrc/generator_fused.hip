@@ -427,6 +427,7 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int q = lane + 64 * j, prow = q >> 2, ch = q & 3;
+            // (as non-temporal stores: the same step time and kernel time)
             if (R0 + prow < a.nrows) *reinterpret_cast<u32x4*>(a.p_out + (long)(R0 + prow) * a.ldp + c0 + ch * 8) = seg[j];
           }
           __builtin_amdgcn_sched_barrier(0);
