@@ -176,6 +176,7 @@ class Engine(object):
         # the extra workgroups and atomics get in the way of everything that runs next to them (tools/ab.py, ms per step by cap: 64:
         # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)
         self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
+        self.aux_early = _os_env.get("VMMT_AUX_EARLY", "1") == "1"
         self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
         self.lstm_db_in_gemm = _os_env.get("VMMT_LSTM_DB_IN_GEMM", "1") == "1"
         self.dec_grads_on_aux = _os_env.get("VMMT_DEC_GRADS_ON_AUX", "1") == "1"
@@ -1054,7 +1055,10 @@ class Workspace(object):
         cond_first = bool(d.conditional and not rp)
         def aux_chain():
             e._sid = AUX
-            e._wait(P, "bwd_begin")
+            # the image term and the KL / q(z|x) backward depend on the forward only (mu_v, mu / sigma, the KL sum), not on the generator
+            # loss: gated by the forward's image network (behind the step's gradient zeroing on the same stream) they start while the
+            # decoder's forward is still running -- the host is a step ahead of the GPU, so the launches are already queued
+            e._wait(P, "img_fwd" if (e.aux_early and not d.conditional and not rp) else "bwd_begin")
             if cond_first:
                 kl_and_q_backward()
             self._patch["img"] = (len(P), 7)
