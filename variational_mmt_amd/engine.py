@@ -177,6 +177,7 @@ class Engine(object):
         # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)
         self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
         self.aux_early = _os_env.get("VMMT_AUX_EARLY", "1") == "1"
+        self.aux_kl_first = _os_env.get("VMMT_AUX_KL_FIRST", "1") == "1"
         self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
         self.lstm_db_in_gemm = _os_env.get("VMMT_LSTM_DB_IN_GEMM", "1") == "1"
         self.dec_grads_on_aux = _os_env.get("VMMT_DEC_GRADS_ON_AUX", "1") == "1"
@@ -1044,6 +1045,8 @@ class Workspace(object):
                 weight_grads(2, br, dy)
                 data_grads(i, br, dy)
                 weight_grads(1, br, dy)
+            if kl_first:
+                return                              # aux_chain() closes the stream behind the image network
             e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
             if d.conditional:
                 self._cond_backward_tgt(P, drop)
@@ -1053,8 +1056,15 @@ class Workspace(object):
         # gradients, so the few kernels that produce d h_y go out first and the recurrence gets a stream of its own (TGT); everything
         # else of this chain (image network, weight gradients of q / p, p's backward) runs next to it
         cond_first = bool(d.conditional and not rp)
+        # fixed prior: the KL / q(z|x) backward needs mu, sigma and the KL sum only -- it goes first, gated by the sample (and by the side
+        # stream's gradient zeroing: dec_gx is recorded behind it), the image term follows when the forward's image network is through
+        kl_first = bool(e.aux_early and e.aux_kl_first and not d.conditional and not rp)
         def aux_chain():
             e._sid = AUX
+            if kl_first:
+                e._wait(P, "z_ready")
+                e._wait(P, "dec_gx")
+                kl_and_q_backward()
             # the image term and the KL / q(z|x) backward depend on the forward only (mu_v, mu / sigma, the KL sum), not on the generator
             # loss: gated by the forward's image network (behind the step's gradient zeroing on the same stream) they start while the
             # decoder's forward is still running -- the host is a step ahead of the GPU, so the launches are already queued
@@ -1087,6 +1097,9 @@ class Workspace(object):
 
             if cond_first:
                 e._wait(P, "tgt_done")
+                e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
+                e._record(P, "aux_done")
+            elif kl_first:
                 e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
                 e._record(P, "aux_done")
             elif not rp:
