@@ -176,6 +176,7 @@ class Engine(object):
         # the extra workgroups and atomics get in the way of everything that runs next to them (tools/ab.py, ms per step by cap: 64:
         # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)
         self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
+        self.cond_aux_early = _os_env.get("VMMT_COND_AUX_EARLY", "1") == "1"
         self.aux_early = _os_env.get("VMMT_AUX_EARLY", "1") == "1"
         self.aux_kl_first = _os_env.get("VMMT_AUX_KL_FIRST", "1") == "1"
         self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
@@ -1068,9 +1069,18 @@ class Workspace(object):
             # the image term and the KL / q(z|x) backward depend on the forward only (mu_v, mu / sigma, the KL sum), not on the generator
             # loss: gated by the forward's image network (behind the step's gradient zeroing on the same stream) they start while the
             # decoder's forward is still running -- the host is a step ahead of the GPU, so the launches are already queued
-            e._wait(P, "img_fwd" if (e.aux_early and not d.conditional and not rp) else "bwd_begin")
-            if cond_first:
+            early_cond = bool(cond_first and e.aux_early and e.cond_aux_early)
+            if early_cond:
+                # conditional model: the chain d h_y -> encoder_tgt's backward recurrence is the critical path of the whole backward and
+                # depends on the forward only (KL of q against p(z|x)): it starts behind the sample, 0.5 ms before the loss is through
+                e._wait(P, "z_ready")
+                e._wait(P, "dec_gx")
                 kl_and_q_backward()
+                e._wait(P, "img_fwd")
+            else:
+                e._wait(P, "img_fwd" if (e.aux_early and not d.conditional and not rp) else "bwd_begin")
+                if cond_first:
+                    kl_and_q_backward()
             self._patch["img"] = (len(P), 7)
             e._call(P, lib.vmmt_image_loss, dt, self.mu_v.p(), self.mu_v.ld, self.img.p(), self.img.ld, B, D, inv_norm,
                     self.dmu_v.p(), self.dmu_v.ld, self.stats.data_ptr())
