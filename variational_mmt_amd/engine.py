@@ -177,6 +177,7 @@ class Engine(object):
         # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)
         self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
         self.cond_aux_early = _os_env.get("VMMT_COND_AUX_EARLY", "1") == "1"
+        self.cond_emb_first = _os_env.get("VMMT_COND_EMB_FIRST", "1") == "1"
         self.aux_early = _os_env.get("VMMT_AUX_EARLY", "1") == "1"
         self.aux_kl_first = _os_env.get("VMMT_AUX_KL_FIRST", "1") == "1"
         self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
@@ -1425,7 +1426,9 @@ class Workspace(object):
         MAIN, AUX = 0, 2
         e._sid = AUX
         e._wait(P, "fwd_begin")
-        e._wait(P, "side_fwd")           # the shared target embedding table is updated by the side half of Adam
+        # the shared target embedding table is updated by the side half of Adam: its own event when that half runs it first
+        # (resolved by name at run time: before the first optimiser step there is nothing to wait for)
+        e._wait(P, "opt_emb_done" if e.cond_emb_first else "side_fwd")
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                 self.tgt_bt.data_ptr(), self.Yt.p(), self.Yt.ld, MT, E)
         x, xcols = self.Yt, E
@@ -1776,7 +1779,16 @@ def _engine_methods():
 
             def background():
                 side.wait_event(ev)
-                adam(0, split, side.cuda_stream)
+                g_hi = self.offsets["generator.0.bias"][0]
+                if self.d.conditional and self.cond_emb_first and 0 < g_hi < split:
+                    # conditional model: encoder_tgt's forward recurrence (the step's first long chain) gathers from the shared target
+                    # embedding table, which sits in this half: everything but the generator weight goes first
+                    adam(g_hi, split, side.cuda_stream)
+                    self.global_events.setdefault("opt_emb_done", torch.cuda.Event()).record(side)
+                    adam(0, g_hi, side.cuda_stream)
+                else:
+                    self.global_events.pop("opt_emb_done", None)
+                    adam(0, split, side.cuda_stream)
                 self._pack_part(3, side.cuda_stream)
                 self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
             background()
