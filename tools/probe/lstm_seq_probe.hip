@@ -10,7 +10,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-  const int B = 256, H = argc > 1 ? atoi(argv[1]) : 512, ndir = argc > 2 ? atoi(argv[2]) : 1, T = 20;
+  const int H = argc > 1 ? atoi(argv[1]) : 512, ndir = argc > 2 ? atoi(argv[2]) : 1, B = argc > 3 ? atoi(argv[3]) : 256, T = argc > 4 ? atoi(argv[4]) : 20;   // e.g. 256 2 21 256 = encoder_tgt of the conditional model
   const long M = (long)T * B;
   void *hout, *whh, *gs, *xchg; float *gx, *cc; unsigned* sync; vmmt_lstm_dir_fwd* ddev;
   CK(hipMalloc(&hout, (M + B) * H * 2 * ndir)); CK(hipMalloc(&whh, (long)4 * H * H * 2 * ndir)); CK(hipMalloc(&gs, M * 4 * H * 2 * ndir));
