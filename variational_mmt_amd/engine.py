@@ -178,6 +178,7 @@ class Engine(object):
         self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
         self.cond_aux_early = _os_env.get("VMMT_COND_AUX_EARLY", "1") == "1"
         self.cond_emb_first = _os_env.get("VMMT_COND_EMB_FIRST", "1") == "1"
+        self.cond_emb_fg = _os_env.get("VMMT_COND_EMB_FG", "1") == "1"
         self.aux_early = _os_env.get("VMMT_AUX_EARLY", "1") == "1"
         self.aux_kl_first = _os_env.get("VMMT_AUX_KL_FIRST", "1") == "1"
         self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
@@ -1427,8 +1428,10 @@ class Workspace(object):
         e._sid = AUX
         e._wait(P, "fwd_begin")
         # the shared target embedding table is updated by the side half of Adam: its own event when that half runs it first
-        # (resolved by name at run time: before the first optimiser step there is nothing to wait for)
-        e._wait(P, "opt_emb_done" if e.cond_emb_first else "side_fwd")
+        # (resolved by name at run time: before the first optimiser step there is nothing to wait for; cond_emb_fg: the table is updated
+        #  by the foreground half of the optimiser step, i.e. before this plan starts)
+        if not e.cond_emb_fg:
+            e._wait(P, "opt_emb_done" if e.cond_emb_first else "side_fwd")
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                 self.tgt_bt.data_ptr(), self.Yt.p(), self.Yt.ld, MT, E)
         x, xcols = self.Yt, E
@@ -1750,6 +1753,11 @@ def _engine_methods():
         self._sumsq_by_plan = False
         self.step_count += 1
         split = self.offsets[self.first_enc_name][0]
+        emb_fg = bool(self.d.conditional and self.cond_emb_fg)
+        if emb_fg:
+            # conditional model: the shared target embedding table (last item of the background half, no compute shadow) is updated in the
+            # FOREGROUND: encoder_tgt's forward recurrence, the step's first long chain, gathers from it right at the start of the step
+            split = self.offsets["decoder.embeddings.make_embedding.emb_luts.0.weight"][0]
 
         def adam_range(lo, hi, stream, shadow=None):
             blocks = int(self.bg_adam_blocks) if stream != st else 0
@@ -1780,7 +1788,7 @@ def _engine_methods():
             def background():
                 side.wait_event(ev)
                 g_hi = self.offsets["generator.0.bias"][0]
-                if self.d.conditional and self.cond_emb_first and 0 < g_hi < split:
+                if self.d.conditional and self.cond_emb_first and not emb_fg and 0 < g_hi < split:
                     # conditional model: encoder_tgt's forward recurrence (the step's first long chain) gathers from the shared target
                     # embedding table, which sits in this half: everything but the generator weight goes first
                     adam(g_hi, split, side.cuda_stream)
