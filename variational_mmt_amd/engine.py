@@ -1488,12 +1488,25 @@ class Workspace(object):
         e._wait(P, "enct_done")
         e._call(P, lib.vmmt_masked_mean_bm, dt, self.enct_out[Lyr - 1].p(), self.enct_out[Lyr - 1].ld, self.tgt_len.data_ptr(),
                 self.hq.p(0, H), self.hq.ld, B, Tn, H)
-        for br, outb, act in (("location", self.mu, L.ACT_NONE), ("scale", self.sigma, L.ACT_SOFTPLUS)):
+        # q(z|x,y,v) sits on the step's critical path (behind encoder_tgt's recurrence) and its two branches are 16-workgroup products over
+        # K = 2H + D: the scale branch runs on the side stream next to the location branch (as in the fixed-prior model's unfused path)
+        par = bool(e.q_parallel and e.use_side_stream)
+        if par:
+            e._record(P, "hq_ready")
+        for br, outb, act in (("scale", self.sigma, L.ACT_SOFTPLUS), ("location", self.mu, L.ACT_NONE)):
             w1, w2 = e.sh["q_%s_w1" % br], e.sh["q_%s_w2" % br]
+            if par and br == "scale":
+                e._sid = 1
+                e._wait(P, "hq_ready")
             e._gemm(P, L.GEMM_NT, self.hq.p(), self.hq.ld, w1.p(), w1.ld, self.q_h1[br].p(), self.q_h1[br].ld, B, Z, d.qin,
                     addend=e.pp("inf_net_global.%s.fc1.bias" % br), ld_add=Z, add_rows=1, act=L.ACT_RELU)
             e._gemm(P, L.GEMM_NT, self.q_h1[br].p(), self.q_h1[br].ld, w2.p(), w2.ld, outb.p(), outb.ld, B, Z, Z,
                     addend=e.pp("inf_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
+            if par and br == "scale":
+                e._record(P, "sigma_ready")
+                e._sid = MAIN
+        if par:
+            e._wait(P, "sigma_ready")
 
     def _cond_backward(self, P, drop):
         """aux stream, right behind vmmt_latent_cond_bwd: backward of p(z|x); d h_x goes to the main stream (event dhbar_p)"""
