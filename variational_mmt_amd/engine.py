@@ -177,7 +177,6 @@ class Engine(object):
         # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)
         self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
         self.cond_aux_early = _os_env.get("VMMT_COND_AUX_EARLY", "1") == "1"
-        self.cond_emb_first = _os_env.get("VMMT_COND_EMB_FIRST", "1") == "1"
         self.cond_emb_fg = _os_env.get("VMMT_COND_EMB_FG", "1") == "1"
         self.aux_early = _os_env.get("VMMT_AUX_EARLY", "1") == "1"
         self.aux_kl_first = _os_env.get("VMMT_AUX_KL_FIRST", "1") == "1"
@@ -1428,10 +1427,10 @@ class Workspace(object):
         e._sid = AUX
         e._wait(P, "fwd_begin")
         # the shared target embedding table is updated by the side half of Adam: its own event when that half runs it first
-        # (resolved by name at run time: before the first optimiser step there is nothing to wait for; cond_emb_fg: the table is updated
-        #  by the foreground half of the optimiser step, i.e. before this plan starts)
+        # (cond_emb_fg, the default: the table is updated by the FOREGROUND half of the optimiser step, i.e. before this plan starts; updating
+        #  it first in the background half and waiting for that alone was worth 3.524 -> 3.507 ms, this 3.518 -> 3.483)
         if not e.cond_emb_fg:
-            e._wait(P, "opt_emb_done" if e.cond_emb_first else "side_fwd")
+            e._wait(P, "side_fwd")
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                 self.tgt_bt.data_ptr(), self.Yt.p(), self.Yt.ld, MT, E)
         x, xcols = self.Yt, E
@@ -1800,16 +1799,7 @@ def _engine_methods():
 
             def background():
                 side.wait_event(ev)
-                g_hi = self.offsets["generator.0.bias"][0]
-                if self.d.conditional and self.cond_emb_first and not emb_fg and 0 < g_hi < split:
-                    # conditional model: encoder_tgt's forward recurrence (the step's first long chain) gathers from the shared target
-                    # embedding table, which sits in this half: everything but the generator weight goes first
-                    adam(g_hi, split, side.cuda_stream)
-                    self.global_events.setdefault("opt_emb_done", torch.cuda.Event()).record(side)
-                    adam(0, g_hi, side.cuda_stream)
-                else:
-                    self.global_events.pop("opt_emb_done", None)
-                    adam(0, split, side.cuda_stream)
+                adam(0, split, side.cuda_stream)
                 self._pack_part(3, side.cuda_stream)
                 self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
             background()
