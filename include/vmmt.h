@@ -88,6 +88,13 @@ typedef struct vmmt_gemm_args {
                   colsum_out[m] += sum_k A[k][m] (an LSTM bias gradient next to dW_hh).  Only where vmmt_gemm_colsum_applies()
                   returns 1; otherwise VMMT_EINVAL */
   float* colsum_out2; /* plain sums only: a second destination of the same sums (nn.LSTM's bias_ih and bias_hh), or NULL */
+  int c_row_blk, c_row_valid; /* c_row_blk > 0 (out_f32 = 1, no scatter): the M output rows are blocks of c_row_blk rows of which the first
+                  c_row_valid are stored, block after block without gaps: row m goes to C row (m / blk) * valid + m % blk, rows with
+                  m % blk >= valid are dropped.  The caller computes with hidden sizes padded to what the MFMA kernels tile
+                  (opts.py:54 -rnn_size 500 -> 4 gate blocks of 512) while C keeps nn.LSTM's [4H][I] gradient layout.  The plain
+                  column sums (colsum_out / colsum_out2) follow the same map */
+  int c_col_blk, c_col_valid; /* the same for the N output columns (e.g. dW_out [H][2H] of GlobalAttention.py:187 from a [c ; r]
+                  buffer whose halves are padded) */
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
 int vmmt_gemm_colsum_applies(const vmmt_gemm_args* args);
@@ -261,8 +268,10 @@ int vmmt_gen_dW_finish(int dtype, const void* P, int64_t ldp, const float* cs, c
  * image-feature table: TrainerMultimodal.py:632-639), out f32 or bf16 per out_dtype. */
 int vmmt_gather_rows(int out_dtype, const float* table, int64_t ldt, const int64_t* ids, void* out, int64_t ldo, int R,
                      int D, void* stream);
-/* out[c] += sum_r X[r][c], and out2[c] likewise when not NULL (bias gradients; b_ih and b_hh share one) */
-int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, float* out2, void* stream);
+/* out[c] += sum_r X[r][c], and out2[c] likewise when not NULL (bias gradients; b_ih and b_hh share one).
+ * blk > 0: the C columns are blocks of `blk` of which the first `valid` are summed into out[(c / blk) * valid + c % blk]
+ * (padded gate blocks -> nn.LSTM's [4H] bias layout, see vmmt_gemm_args.c_row_blk); blk = 0: out[c] */
+int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, int blk, int valid, float* out, float* out2, void* stream);
 /* out[ids[r]][0:D] += X[r][0:D] (f32; rows with ids[r] == pad_id are dropped): the embedding-gradient scatter-add with padding_idx
  * (modules/Embeddings.py:118) behind the GEMM that produced X = dgates W_ih */
 int vmmt_scatter_add_rows(const float* X, int64_t ldx, const int64_t* ids, int64_t pad_id, float* out, int64_t ldo, int R, int D,
@@ -284,14 +293,17 @@ int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float*
                     float* kl_b, float* stats, int B, int Z, int training, void* stream);
 /* q(z|x) forward in ONE launch: hbar = masked mean over time of the (detached) encoder memory (NormalVariationalEncoder.py:65-84),
  * h1 = relu(hbar W1^T + b1), out = h1 W2^T + b2 for the location and the scale network (:12-43; scale: Softplus), then
- * vmmt_latent_fwd's sample and KL.  bf16 only; H % 128 == 0, Z % 64 == 0, Z <= 256-ish (LDS); returns 1 (invalid argument)
+ * vmmt_latent_fwd's sample and KL.  bf16 only; H % 256 == 0, Z % 128 == 0, Z <= 512; returns 1 (invalid argument)
  * otherwise and the caller issues vmmt_masked_mean + 4 vmmt_gemm + vmmt_latent_fwd instead (same results up to f32 summation
- * order).  hbar / h1_* are written for the backward pass. */
+ * order).  hbar / h1_* are written for the backward pass.
+ * Z is the TILED latent size, Z_valid <= Z the model's (opts.py --z_latent_dim 500 -> Z 512, Z_valid 500): biases, eps, mu, sigma,
+ * z32 hold Z_valid entries per row (row stride Z_valid), the weights' rows / columns beyond Z_valid must read as zeros, and the
+ * sample / KL cover Z_valid lanes only. */
 int vmmt_qnet_fwd(int dtype, const void* ctx, int64_t ldc, const int64_t* lens, const void* w1_loc, const void* w1_scale, int64_t ldw1,
                   const float* b1_loc, const float* b1_scale, const void* w2_loc, const void* w2_scale, int64_t ldw2,
                   const float* b2_loc, const float* b2_scale, const float* eps, void* hbar, int64_t ldh, void* h1_loc, void* h1_scale,
                   int64_t ldh1, float* mu, float* sigma, float* z32, void* zT, int64_t ldz, float* kl_b, float* stats, int B, int S,
-                  int H, int Z, int training, void* stream);
+                  int H, int Z, int Z_valid, int training, void* stream);
 /* d/d(mu, pre-softplus scale) of max(mult * KL_mean, margin) * inv_norm  (VILoss.py:460-473, Loss.py:129).
  * dz / eps (f32 [B][Z], both or NULL): the reparameterised gradient z = mu + sigma * eps NOT detached -- d mu += dz,
  * d sigma += dz * eps.  As executed the reference detaches the sample (hazard H2: modules/Dists.py:21-26, Models.py:930-933),

@@ -35,6 +35,10 @@ CASES = {
     # z 256, emb 500): every tensor above 65 536 elements is formula-initialised / kept as a strided sample + sums, so the
     # fixture stays a few MB.  Reaches the bf16 *_fast kernels (H % 32 == 0, LDS-DMA GEMM loops) with reference-held values.
     "cfg1_shape":  (dict(vs=30000, vt=30000, emb=500, hid=512, z=256, layers=1, brnn=True), 40, 20, 21, False),
+    # the run scripts AS WRITTEN (run_translated_m30k_only.sh:46-57 + opts.py defaults: -rnn_size 500 --z_latent_dim 500, word vectors
+    # 500, 2-layer uni-directional LSTMs, batch 40): hidden sizes that are no multiple of anything the MFMA kernels tile -- the build
+    # computes them padded to 512 (engine.Dims.hp) and must reproduce the reference exactly in the 500 real lanes
+    "script_shape": (dict(vs=30000, vt=30000, emb=500, hid=500, z=500, layers=2, brnn=False), 40, 20, 21, False),
 }
 
 

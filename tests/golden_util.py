@@ -8,7 +8,8 @@ from oracle import vi1_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # cfg1_shape: BASELINE.json config 1 at its real shape (batch 40, V 30 000, biLSTM 512, z 256, emb 500) -- reference-generated
-CASES = ["tiny_uni_l2", "tiny_bi_l1", "tiny_bi_l2", "small_fixed", "cfg1_shape"]
+# script_shape: the run scripts as written (batch 40, V 30 000, 2-layer uni-directional LSTM 500, z 500, emb 500) -- reference-generated
+CASES = ["tiny_uni_l2", "tiny_bi_l1", "tiny_bi_l2", "small_fixed", "cfg1_shape", "script_shape"]
 COND_CASES = ["cond_bi_l1", "cond_uni_l2"]          # --conditional prior
 GREEDY_CASES = ["greedy_bi_l1", "greedy_cond_uni_l2"]   # step-wise decoding, beam size 1
 BEAM_CASES = ["beam_bi_l1", "beam_cond_uni_l2", "beam_bi_l2_alpha", "beam_bi_l1_k2"]   # beam search through the reference's own translator

@@ -67,10 +67,21 @@ def test_gradients_and_adam_step(name):
             _close(s2, z["bigsum_g_" + k][1], what="grad sumsq " + k, rtol=1e-3)
     new, norm = O.clip_and_adam(p, g, {}, lr=0.002, max_grad_norm=5.0)
     for k in new:
+        # the first Adam update is lr * g / (|g| + 1e-9): where a gradient element is itself within a few hundred times Adam's eps (1e-9) of zero, the
+        # summation-order difference between the restatement and the reference moves the update by a visible fraction of lr -- those
+        # elements (a handful, in the image network's 2048-term cancellation class) are compared at lr instead of 2e-6
         if "p1_" + k in z.files:
-            _close(new[k], z["p1_" + k], what="adam " + k, rtol=1e-5, atol=2e-6)
+            got, want, gk = new[k], torch.from_numpy(z["p1_" + k]), g[k]
         elif "big_p1_" + k in z.files:
-            _close(O.sample_big(new[k])[0], z["big_p1_" + k], what="adam(sample) " + k, rtol=1e-5, atol=2e-6)
+            got, want, gk = O.sample_big(new[k])[0], torch.from_numpy(z["big_p1_" + k]), O.sample_big(g[k])[0]
+        else:
+            continue
+        firm = (gk.abs() >= 1e-7) | (gk == 0)
+        _close(got[firm], want[firm], what="adam " + k, rtol=1e-5, atol=2e-6)
+        if (~firm).any():
+            _close(got[~firm], want[~firm], what="adam (|g| < 1e-7) " + k, rtol=0, atol=2.1e-3)
+            off = ((got.double() - want.double()).abs() > 2e-6 + 1e-5 * want.abs().max().item()).float().mean().item()
+            assert off <= 0.01, ("adam: share of elements beyond 2e-6", k, off)
 
 
 def test_fp64_matches_fp32():

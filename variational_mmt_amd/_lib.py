@@ -28,7 +28,8 @@ class GemmArgs(C.Structure):
                 ("addend", vp), ("ld_add", i64), ("add_rows", i32), ("add_is_T", i32), ("act", i32),
                 ("out_f32", i32), ("accumulate", i32), ("alpha", f32), ("scatter_ids", vp), ("pad_id", i32),
                 ("tile", i32), ("split_k", i32), ("b_batch_rows", i32), ("b_batch_stride", i64),
-                ("colsum_w", vp), ("colsum_w_stride", i64), ("colsum_out", vp), ("colsum_out2", vp)]
+                ("colsum_w", vp), ("colsum_w_stride", i64), ("colsum_out", vp), ("colsum_out2", vp),
+                ("c_row_blk", i32), ("c_row_valid", i32), ("c_col_blk", i32), ("c_col_valid", i32)]
 
 
 class LstmDirFwd(C.Structure):
@@ -91,14 +92,14 @@ _SIGS = {
     "vmmt_gemm_colsum_applies": (i32, [C.POINTER(GemmArgs)]),
     "vmmt_gather_rows": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, vp]),
     "vmmt_scatter_add_rows": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),
-    "vmmt_colsum": (i32, [i32, vp, i64, i32, i32, vp, vp, vp]),
+    "vmmt_colsum": (i32, [i32, vp, i64, i32, i32, i32, i32, vp, vp, vp]),
     "vmmt_rowsum": (i32, [i32, vp, i64, i32, i32, vp, vp]),
     "vmmt_dropout_mask": (i32, [i32, vp, i64, f32, u64, vp]),
     "vmmt_randn": (i32, [vp, i64, u64, vp]),
     "vmmt_mul": (i32, [i32, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_act_bwd": (i32, [i32, i32, vp, i64, i32, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_qnet_fwd": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp,
-                            i32, i32, i32, i32, i32, vp]),
+                            i32, i32, i32, i32, i32, i32, vp]),
     "vmmt_latent_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),
     "vmmt_latent_bwd": (i32, [i32, vp, vp, vp, f32, f32, i32, f32, f32, vp, vp, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_gate_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),

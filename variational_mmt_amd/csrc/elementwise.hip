@@ -33,7 +33,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, long ldt, co
 // one fp32 atomic per column and chunk.
 template <class T>
 __global__ void colsum_kernel(const T* __restrict__ X, long ld, int R, int C, float* __restrict__ out, float* __restrict__ out2,
-                              int rows_per_block) {
+                              int rows_per_block, int blk, int valid) {
   constexpr int VEC = 16 / sizeof(T);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c0 = (blockIdx.x * 64 + lane) * VEC;
@@ -75,8 +75,10 @@ __global__ void colsum_kernel(const T* __restrict__ X, long ld, int R, int C, fl
     for (int e = 0; e < VEC; ++e) {
       if (c0 + e < C) {
         float t = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
-        atomicAdd(out + c0 + e, t);
-        if (out2) atomicAdd(out2 + c0 + e, t);
+        int o = c0 + e;
+        if (blk) { const int q = o / blk, r = o - q * blk; if (r >= valid) continue; o = q * valid + r; }      // padded blocks -> dense layout
+        atomicAdd(out + o, t);
+        if (out2) atomicAdd(out2 + o, t);
       }
     }
   }
@@ -456,8 +458,8 @@ extern "C" int vmmt_gather_rows(int out_dtype, const float* table, int64_t ldt, 
   return check_launch();
 }
 
-extern "C" int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, float* out, float* out2, void* stream) {
-  if (!X || !out || R < 0 || C <= 0) return VMMT_EINVAL;
+extern "C" int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, int blk, int valid, float* out, float* out2, void* stream) {
+  if (!X || !out || R < 0 || C <= 0 || blk < 0 || (blk > 0 && (valid <= 0 || valid > blk))) return VMMT_EINVAL;
   if (R == 0) return VMMT_OK;
   int vec = dtype == VMMT_F32 ? 4 : 8;
   int gx = (C + 64 * vec - 1) / (64 * vec);
@@ -465,8 +467,8 @@ extern "C" int vmmt_colsum(int dtype, const void* X, int64_t ld, int R, int C, f
   int rpb = 32;
   while (rpb < R && ((R + rpb - 1) / rpb > 64 || (long)gx * ((R + rpb - 1) / rpb) > 2048)) rpb *= 2;
   dim3 grid(gx, (R + rpb - 1) / rpb);
-  if (dtype == VMMT_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST, (const float*)X, (long)ld, R, C, out, out2, rpb);
-  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)X, (long)ld, R, C, out, out2, rpb);
+  if (dtype == VMMT_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, ST, (const float*)X, (long)ld, R, C, out, out2, rpb, blk, valid);
+  else if (dtype == VMMT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, ST, (const bf16_t*)X, (long)ld, R, C, out, out2, rpb, blk, valid);
   else return VMMT_EINVAL;
   return check_launch();
 }

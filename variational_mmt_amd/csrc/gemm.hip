@@ -19,6 +19,7 @@ struct GemmEpi {
   int b_batch_rows; long b_batch_stride;                         // B of output rows [i r, (i + 1) r) starts at B + i * stride (elements)
   const float* colsum_w; long colsum_w_stride; float* colsum_out; // K-strided A only: colsum_out[m] += sum_k A[k][m] w[k] (w per B block)
   float* colsum_out2;                                            // unit weights (colsum_w == NULL): a second destination of the same sums
+  int rblk, rvalid, cblk, cvalid;                                // output row / column block map (vmmt_gemm_args.c_row_blk): 0 = identity
 };
 
 // The epilogue runs as a few small, fully unrolled passes over the accumulator registers (static indices only:
@@ -53,7 +54,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
   else if (e.act == VMMT_ACT_TANH) { VMMT_FOR_ACC(v = tanhf_(v);) }
   else if (e.act == VMMT_ACT_SOFTPLUS) { VMMT_FOR_ACC(v = v > 20.f ? v : log1pf(__expf(v));) }  // nn.Softplus(1, 20)
   else if (e.act == VMMT_ACT_SIGMOID) { VMMT_FOR_ACC(v = sigmoidf_(v);) }
-  if (e.scatter_ids) {
+  if (e.rblk | e.cblk) {
+    // padded blocks -> the reference's dense layout (out_f32, no scatter: checked by vmmt_gemm): rows / columns in a block's padding are dropped
+    float* C = reinterpret_cast<float*>(e.C);
+    const int rb = e.rblk ? e.rblk : 0x7fffffff, rv = e.rblk ? e.rvalid : 0x7fffffff;
+    const int cb = e.cblk ? e.cblk : 0x7fffffff, cv = e.cblk ? e.cvalid : 0x7fffffff;
+#define VMMT_MAPPED(STORE)                                                                  \
+    VMMT_FOR_ACC(const int rq = row / rb; const int rr = row - rq * rb; const int cq = col / cb; const int cr = col - cq * cb; \
+                 if (rr < rv && cr < cv) { float* p = C + (long)(rq * rv + rr) * e.ldc + (cq * cv + cr); STORE })
+    if (e.atomic) { VMMT_MAPPED(atomicAdd(p, v);) }
+    else if (e.accumulate) { VMMT_MAPPED(*p += v;) }
+    else { VMMT_MAPPED(*p = v;) }
+#undef VMMT_MAPPED
+  } else if (e.scatter_ids) {
     float* C = reinterpret_cast<float*>(e.C);
     VMMT_FOR_ACC(long long id = e.scatter_ids[row]; if (id != e.pad_id) atomicAdd(C + id * e.ldc + col, v);)
   } else if (e.atomic) {
@@ -110,7 +123,8 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B_, long ld
   } else if constexpr (GL == 1) {
     // plain column sums of A (unit weights) in the workgroups of the first column tile, every K split adds its share
     float* co = (epi.colsum_out && !epi.colsum_w && tn == 0) ? epi.colsum_out : nullptr;
-    gemm_mainloop_glds<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, co, epi.colsum_out2);
+    gemm_mainloop_glds<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, co, epi.colsum_out2,
+                                                            epi.rblk, epi.rvalid);
   } else {
     gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ, LinearMap, LinearMap, DB>(A, lda, amap, B, ldb, bmap, kend, a_kmod,
                                                                                     b_kmod, aoff, boff, acc, smem, kbeg);
@@ -242,6 +256,11 @@ extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
   e.atomic = a->split_k > 1 ? 1 : 0;
   e.b_batch_rows = a->b_batch_rows; e.b_batch_stride = (long)a->b_batch_stride;
   e.colsum_w = a->colsum_w; e.colsum_w_stride = (long)a->colsum_w_stride; e.colsum_out = a->colsum_out; e.colsum_out2 = a->colsum_out2;
+  e.rblk = a->c_row_blk; e.rvalid = a->c_row_valid; e.cblk = a->c_col_blk; e.cvalid = a->c_col_valid;
+  if (e.rblk < 0 || e.cblk < 0 || (e.rblk > 0 && (e.rvalid <= 0 || e.rvalid > e.rblk)) || (e.cblk > 0 && (e.cvalid <= 0 || e.cvalid > e.cblk)))
+    return VMMT_EINVAL;
+  if ((e.rblk | e.cblk) && (!a->out_f32 || a->scatter_ids || a->act != VMMT_ACT_NONE)) return VMMT_EINVAL;
+  if (e.rblk && a->colsum_w) return VMMT_EINVAL;                 // the weighted sums (generator bias) have no padded blocks
   if ((a->colsum_w || a->colsum_out || a->colsum_out2) && (!a->colsum_out || !vmmt_gemm_colsum_applies(a))) return VMMT_EINVAL;
   if (a->b_batch_rows < 0 || (a->b_batch_rows > 0 && a->b_batch_rows % 256 != 0)) return VMMT_EINVAL;   // whole tiles (<= 256 rows) per block
   hipStream_t st = (hipStream_t)stream;

@@ -668,7 +668,8 @@ __global__ void __launch_bounds__(256) gen2_onehot_kernel(const bf16_t* __restri
   const int ym = y32[m];
   if (ym < 0) return;
   float* dst = dW + (long)ym * lddw;
-  for (int h = lane; h < D; h += 64) atomicAdd(dst + h, -inv_norm * bf2f(O[(long)m * ldo + h]));
+  const int hend = lddw < D ? (int)lddw : D;      // rows of dW narrower than the tiled width (H = 500 in 512): O's padding is not part of the row
+  for (int h = lane; h < hend; h += 64) atomicAdd(dst + h, -inv_norm * bf2f(O[(long)m * ldo + h]));
   if (lane == 0) atomicAdd(db + ym, -inv_norm);
 }
 

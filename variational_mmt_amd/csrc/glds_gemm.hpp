@@ -175,7 +175,8 @@ template <int BM, int BN, int NW, bool A_KC, bool B_KC, int TI, int TJ, bool DBU
 __device__ __forceinline__ void gemm_mainloop_glds(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
                                                    long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
                                                    const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem,
-                                                   float* __restrict__ colsum_out = nullptr, float* __restrict__ colsum_out2 = nullptr) {
+                                                   float* __restrict__ colsum_out = nullptr, float* __restrict__ colsum_out2 = nullptr,
+                                                   int cs_blk = 0, int cs_valid = 0) {
   constexpr int ABYTES = BM * GBK * 2, BBYTES = BN * GBK * 2, BUF = ABYTES + BBYTES;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   constexpr bool CS_OK = !A_KC && BM == 128 && NW == 4 && DBUF;   // the shape glds_colsum128_slab is written for
@@ -229,8 +230,10 @@ __device__ __forceinline__ void gemm_mainloop_glds(const bf16_t* __restrict__ A,
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float t = csum[e] + __shfl_xor(csum[e], 32, 64);
-      const int col = m0 + (lane & 31) * 4 + e;
-      if (lane < 32 && col < M) {
+      int col = m0 + (lane & 31) * 4 + e;
+      bool ok = lane < 32 && col < M;
+      if (cs_blk) { const int q = col / cs_blk, r = col - q * cs_blk; ok = ok && r < cs_valid; col = q * cs_valid + r; }   // padded gate blocks
+      if (ok) {
         atomicAdd(colsum_out + col, t);
         if (colsum_out2) atomicAdd(colsum_out2 + col, t);
       }

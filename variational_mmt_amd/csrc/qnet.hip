@@ -26,7 +26,7 @@ struct QnetArgs {
   bf16_t* h1[2]; long ldh1;                                // out [B][ldh1]  (hidden activations: saved for backward)
   float* mu; float* sigma; float* z32; bf16_t* zT; long ldz;
   float* kl_b; float* stats;
-  int B, S, H, Z, training;
+  int B, S, H, Z, Zv, training;                            // Z: tiled latent size; Zv <= Z: the model's (row stride of eps / mu / sigma / z32)
 };
 
 typedef float f32x4_q __attribute__((ext_vector_type(4)));
@@ -71,7 +71,7 @@ __device__ __forceinline__ void mm16(const bf16_t* a_lds, int pitch, const bf16_
 template <int NT>        // NT = Z / 128: 16-column tiles per wave (8 waves)
 __global__ void __launch_bounds__(512) qnet_fwd_kernel(QnetArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int H = a.H, Z = a.Z, B = a.B;
+  const int H = a.H, Z = a.Z, Zv = a.Zv, B = a.B;
   const int PH = H + 8, PZ = Z + 8;
   bf16_t* hb = reinterpret_cast<bf16_t*>(smem);                       // [16][PH]
   bf16_t* h1s = hb + 16 * PH;                                         // [16][PZ]
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(512) qnet_fwd_kernel(QnetArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + j * 16 + n;
-      const float bias = a.b1[br][col];
+      const float bias = col < Zv ? a.b1[br][col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = kg * 4 + r;
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(512) qnet_fwd_kernel(QnetArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + j * 16 + n;
-      const float bias = a.b2[br][col];
+      const float bias = col < Zv ? a.b2[br][col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = kg * 4 + r;
@@ -157,12 +157,12 @@ __global__ void __launch_bounds__(512) qnet_fwd_kernel(QnetArgs a) {
     const int row = wave * 2 + rr, b = r0 + row;
     if (b >= B) continue;
     float kl = 0.f;
-    for (int k = lane; k < Z; k += 64) {
+    for (int k = lane; k < Zv; k += 64) {
       const float m = outs[row * Z + k], s = outs[(16 + row) * Z + k];
-      const float z = a.training ? m + s * a.eps[(long)b * Z + k] : m;
-      a.mu[(long)b * Z + k] = m;
-      a.sigma[(long)b * Z + k] = s;
-      a.z32[(long)b * Z + k] = z;
+      const float z = a.training ? m + s * a.eps[(long)b * Zv + k] : m;
+      a.mu[(long)b * Zv + k] = m;
+      a.sigma[(long)b * Zv + k] = s;
+      a.z32[(long)b * Zv + k] = z;
       a.zT[(long)b * a.ldz + k] = f2bf(z);
       kl += 0.5f * (m * m + s * s - 1.f) - logf(s);
     }
@@ -182,12 +182,12 @@ extern "C" int vmmt_qnet_fwd(int dtype, const void* ctx, int64_t ldc, const int6
                              int64_t ldw1, const float* b1_loc, const float* b1_scale, const void* w2_loc, const void* w2_scale,
                              int64_t ldw2, const float* b2_loc, const float* b2_scale, const float* eps, void* hbar, int64_t ldh,
                              void* h1_loc, void* h1_scale, int64_t ldh1, float* mu, float* sigma, float* z32, void* zT, int64_t ldz,
-                             float* kl_b, float* stats, int B, int S, int H, int Z, int training, void* stream) {
+                             float* kl_b, float* stats, int B, int S, int H, int Z, int Z_valid, int training, void* stream) {
   using namespace vmmt;
   if (dtype != VMMT_BF16 || !ctx || !lens || !w1_loc || !w1_scale || !b1_loc || !b1_scale || !w2_loc || !w2_scale || !b2_loc || !b2_scale ||
       !hbar || !h1_loc || !h1_scale || !mu || !sigma || !z32 || !zT || !kl_b || !stats || (training && !eps) || B <= 0 || S <= 0)
     return VMMT_EINVAL;
-  if (H % 256 != 0 || Z % 128 != 0 || Z > 512) return VMMT_EINVAL;
+  if (H % 256 != 0 || Z % 128 != 0 || Z > 512 || Z_valid <= 0 || Z_valid > Z) return VMMT_EINVAL;
   const uintptr_t al = (uintptr_t)ctx | (uintptr_t)w1_loc | (uintptr_t)w1_scale | (uintptr_t)w2_loc | (uintptr_t)w2_scale | (uintptr_t)hbar;
   if ((al & 15) || ldc % 8 || ldw1 % 8 || ldw2 % 8 || ldh % 8) return VMMT_EINVAL;
   QnetArgs a;
@@ -196,16 +196,28 @@ extern "C" int vmmt_qnet_fwd(int dtype, const void* ctx, int64_t ldc, const int6
   a.w2[0] = (const bf16_t*)w2_loc; a.w2[1] = (const bf16_t*)w2_scale; a.ldw2 = ldw2; a.b2[0] = b2_loc; a.b2[1] = b2_scale;
   a.eps = eps; a.hbar = (bf16_t*)hbar; a.ldh = ldh; a.h1[0] = (bf16_t*)h1_loc; a.h1[1] = (bf16_t*)h1_scale; a.ldh1 = ldh1;
   a.mu = mu; a.sigma = sigma; a.z32 = z32; a.zT = (bf16_t*)zT; a.ldz = ldz; a.kl_b = kl_b; a.stats = stats;
-  a.B = B; a.S = S; a.H = H; a.Z = Z; a.training = training;
+  a.B = B; a.S = S; a.H = H; a.Z = Z; a.Zv = Z_valid; a.training = training;
   const size_t sm = (size_t)16 * (H + 8) * 2 + (size_t)16 * (Z + 8) * 2 + (size_t)2 * 16 * Z * 4;
-  if (sm > 64 * 1024) return VMMT_EINVAL;
+  if (sm > 128 * 1024) return VMMT_EINVAL;
   const dim3 grid((B + 15) / 16);
+  // (Z = 512 needs 100 KiB of LDS: above the 64-KiB default the limit is raised once per instantiation)
+#define VMMT_QNET_LAUNCH(NT)                                                                                                    \
+  {                                                                                                                             \
+    static size_t allowed = 64 * 1024;                                                                                          \
+    if (sm > allowed) {                                                                                                         \
+      if (hipFuncSetAttribute((const void*)qnet_fwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) \
+        return VMMT_ELAUNCH;                                                                                                    \
+      allowed = sm;                                                                                                             \
+    }                                                                                                                           \
+    hipLaunchKernelGGL(qnet_fwd_kernel<NT>, grid, dim3(512), sm, (hipStream_t)stream, a);                                       \
+  }
   switch (Z / 128) {
-    case 1: hipLaunchKernelGGL(qnet_fwd_kernel<1>, grid, dim3(512), sm, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL(qnet_fwd_kernel<2>, grid, dim3(512), sm, (hipStream_t)stream, a); break;
-    case 3: hipLaunchKernelGGL(qnet_fwd_kernel<3>, grid, dim3(512), sm, (hipStream_t)stream, a); break;
-    case 4: hipLaunchKernelGGL(qnet_fwd_kernel<4>, grid, dim3(512), sm, (hipStream_t)stream, a); break;
+    case 1: VMMT_QNET_LAUNCH(1) break;
+    case 2: VMMT_QNET_LAUNCH(2) break;
+    case 3: VMMT_QNET_LAUNCH(3) break;
+    case 4: VMMT_QNET_LAUNCH(4) break;
     default: return VMMT_EINVAL;
   }
+#undef VMMT_QNET_LAUNCH
   return check_launch();
 }

@@ -22,13 +22,14 @@ class _Stepper(object):
         self.eng, self.R, self.S = eng, R, S
         d, dev, T, f32 = eng.d, eng.dev, eng.T, torch.float32
         H, E, Lyr = d.hid, d.emb, d.layers
+        Hp = d.hp                       # hidden size as computed (engine.Dims.hp): gate g at column g * Hp, [c ; h] halves at 0 / Hp
         nb = lambda r, c, t=T: Buf(r, c, t, dev)
         self.X = nb(R, E)
-        self.gx = [nb(R, 4 * H, f32) for _ in range(Lyr)]
-        self.gates = nb(R, 4 * H)
+        self.gx = [nb(R, 4 * Hp, f32) for _ in range(Lyr)]
+        self.gates = nb(R, 4 * Hp)
         self.c = [[nb(R, H, f32), nb(R, H, f32)] for _ in range(Lyr)]
         self.h = [[nb(R, H), nb(R, H)] for _ in range(Lyr - 1)]
-        self.cat = [nb(R, 2 * H), nb(R, 2 * H)]
+        self.cat = [nb(R, 2 * Hp), nb(R, 2 * Hp)]
         self.Q, self.AH = nb(R, H), nb(R, H)
         self.probs = torch.zeros(R * S, dtype=f32, device=dev)
         self.ctx, self.ctx_ld, self.src_len, self.zx, self.zx_ld = ctx, ctx_ld, src_len, zx, zx_ld
@@ -41,14 +42,13 @@ class _Stepper(object):
 
     def h_buf(self, l, which):
         """(buffer, column offset) of layer l's hidden state in set `which`"""
-        H = self.eng.d.hid
-        return (self.cat[which], H) if l == self.eng.d.layers - 1 else (self.h[l][which], 0)
+        return (self.cat[which], self.eng.d.hp) if l == self.eng.d.layers - 1 else (self.h[l][which], 0)
 
     def step(self, tok_ptr, t):
         """tokens at `tok_ptr` (int64 [R]) -> AH = tanh(W_o [c ; h]) of this position, attention in self.probs; state 0 -> 1"""
         e = self.eng
         d, lib, dt, st, R = e.d, e.lib, e.dt, e.stream(), self.R
-        H, E, Lyr = d.hid, d.emb, d.layers
+        H, E, Lyr, Hp = d.hid, d.emb, d.layers, d.hp
         L.check(lib.vmmt_gather_rows(dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E, tok_ptr,
                                      self.X.p(), self.X.ld, R, E, st), "vmmt_gather_rows")
         x, xoff, xcols = self.X, 0, E
@@ -56,10 +56,10 @@ class _Stepper(object):
             gx = self.gx[l]
             if l == 0:
                 we = e.sh["dec_wih_l0_e"]
-                self.gemm(L.GEMM_NT, x.p(0, xoff), x.ld, we.p(), we.ld, gx.p(), gx.ld, R, 4 * H, xcols, out_f32=1)
+                self.gemm(L.GEMM_NT, x.p(0, xoff), x.ld, we.p(), we.ld, gx.p(), gx.ld, R, 4 * Hp, xcols, out_f32=1)
             else:
                 wi, bs = e.sh["dec_wih_l%d" % l], e.sh["dec_b_l%d" % l]
-                self.gemm(L.GEMM_NT, x.p(0, xoff), x.ld, wi.p(), wi.ld, gx.p(), gx.ld, R, 4 * H, xcols, addend=bs.p(), ld_add=bs.ld,
+                self.gemm(L.GEMM_NT, x.p(0, xoff), x.ld, wi.p(), wi.ld, gx.p(), gx.ld, R, 4 * Hp, xcols, addend=bs.p(), ld_add=bs.ld,
                           add_rows=1, out_f32=1)
             arr = (L.LstmDirFwd * 2)()
             a = arr[0]
@@ -75,14 +75,14 @@ class _Stepper(object):
             a.c_out, a.ld_c = self.c[l][1].p(), self.c[l][1].ld
             a.h_out, a.ld_h = ho[0].p(0, ho[1]), ho[0].ld
             a.t, a.capture = t, 0
-            L.check(lib.vmmt_lstm_step_fwd(dt, 1, arr, None, R, H, st), "vmmt_lstm_step_fwd")
+            L.check(lib.vmmt_lstm_step_fwd(dt, 1, arr, None, R, Hp, st), "vmmt_lstm_step_fwd")
             x, xoff, xcols = ho[0], ho[1], H
         cat = self.cat[1]
         wa, wo = e.sh["wa"], e.sh["wo"]
-        self.gemm(L.GEMM_NT, cat.p(0, H), cat.ld, wa.p(), wa.ld, self.Q.p(), self.Q.ld, R, H, H)
+        self.gemm(L.GEMM_NT, cat.p(0, Hp), cat.ld, wa.p(), wa.ld, self.Q.p(), self.Q.ld, R, H, H)
         L.check(lib.vmmt_attn_fwd(dt, self.Q.p(), self.Q.ld, self.ctx, self.ctx_ld, self.src_len.data_ptr(), cat.p(), cat.ld,
-                                  self.probs.data_ptr(), 1, R, self.S, H, st), "vmmt_attn_fwd")
-        self.gemm(L.GEMM_NT, cat.p(), cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, R, H, 2 * H, act=L.ACT_TANH)
+                                  self.probs.data_ptr(), 1, R, self.S, Hp, st), "vmmt_attn_fwd")
+        self.gemm(L.GEMM_NT, cat.p(), cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, R, H, 2 * Hp, act=L.ACT_TANH)
 
     def carry(self, rows_ptr=None):
         """state set 1 -> set 0 for the next position; `rows_ptr` (int64 [R]) selects each row's parent (beam re-ordering,
@@ -174,7 +174,7 @@ def beam_decode(eng, src, src_len, beam_size, max_len=100, min_length=0, bos=2, 
     b = eng.ws.get(key)
     if b is None:
         b = dict(stepper=_Stepper(eng, R, S, None, 0, None, None, 0),
-                 ctx=Buf(S * R, H, eng.T, dev), zx=Buf(R, 4 * H, f32, dev), src_len=torch.zeros(R, dtype=i64, device=dev),
+                 ctx=Buf(S * R, H, eng.T, dev), zx=Buf(R, 4 * d.hp, f32, dev), src_len=torch.zeros(R, dtype=i64, device=dev),
                  logits=Buf(R, V, f32, dev), tok=torch.zeros(2, R, dtype=i64, device=dev), sel=torch.zeros(R, dtype=i64, device=dev),
                  scores=torch.zeros(B, K, dtype=f32, device=dev), h_score=torch.zeros(max_len, B, K, dtype=f32, device=dev),
                  h_prev=torch.zeros(max_len, B, K, dtype=torch.int32, device=dev),

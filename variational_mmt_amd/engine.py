@@ -29,6 +29,10 @@ from . import _lib as L
 PAD = 1  # '<blank>' (onmt/io/DatasetBase.py:7-11)
 
 
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
 class Dims(object):
     def __init__(self, vs, vt, emb=500, hid=500, z=500, img=2048, layers=2, brnn=False, dropout=0.0, conditional=False):
         self.vs, self.vt, self.emb, self.hid, self.z, self.img = vs, vt, emb, hid, z, img
@@ -41,6 +45,17 @@ class Dims(object):
         assert hid % self.dirs == 0
         self.hd = hid // self.dirs
         assert hid <= 1024, "attention kernel limit (H <= 1024)"
+        # COMPUTE layout of the hidden size.  The run scripts train -rnn_size 500 --z_latent_dim 500, 2-layer uni-directional
+        # (run_translated_m30k_only.sh:46-57, opts.py:14-16,54,67-69); the MFMA LSTM / attention kernels tile H in 32s and the persistent
+        # recurrences serve H in {64, 128, 256, 512}.  So hidden vectors are computed `hp` wide (500 -> 512, gate g of a 4H vector at
+        # g * hp) with zeros in the padding: shadows are packed gate block by gate block, pre-activations / h / c / every gradient
+        # are exactly zero in padded lanes (sigmoid(0) * tanh(0)), and gradients are stored back through the block map of
+        # vmmt_gemm_args.c_row_blk.  The arena, the state dict, checkpoints, Adam and the all-reduce keep the reference shapes.
+        # (bidirectional / conditional models with an odd per-direction size keep the general kernels.)
+        self.pad = (not self.brnn) and (not self.conditional) and hid % 32 != 0 and _os_env.get("VMMT_PAD_HIDDEN", "1") == "1"
+        self.hp = _ru(hid, 32) if self.pad else hid
+        self.hdp = self.hp // self.dirs
+        self.zp = _ru(z, 128)                       # tiled latent size of the fused q(z|x) kernel (Z_valid = z)
 
     def param_shapes(self):
         """name -> shape, in ARENA order (reverse of backward completion is not needed: order == completion)."""
@@ -81,10 +96,6 @@ class Dims(object):
         nograd = [("inf_net_image.scale.fc1.weight", (d.img, d.z)), ("inf_net_image.scale.fc1.bias", (d.img,)),
                   ("inf_net_image.scale.fc2.weight", (d.img, d.img)), ("inf_net_image.scale.fc2.bias", (d.img,))]
         return s, nograd
-
-
-def _ru(x, m):
-    return (x + m - 1) // m * m
 
 
 KPAD = 64          # GEMM reduction slab (elements)
@@ -272,44 +283,64 @@ class Engine(object):
         self.sh = {}
         self.pack_calls = []
 
-        def shadow(key, rows, cols, src, c0=0, ncols=None, transpose=False, dtype=None, src2=None, row_off=0):
+        def shadow(key, rows, cols, src, c0=0, ncols=None, transpose=False, dtype=None, src2=None, row_off=0, col_off=0, gate=None):
+            """one compute copy (or one piece of it).  (row_off, col_off): position of the piece in the shadow as stored, i.e. AFTER the
+            transpose.  gate = (h, hp), h != hp: the source's 4h rows (a bias: its 4h entries) are nn.LSTM's gate blocks i, f, g, o; block
+            g lands at g * hp of the shadow (Dims.hp): one pack descriptor per block"""
             dt = dtype if dtype is not None else T
             code = L.F32 if dt == torch.float32 else L.BF16
             _, shp = self.offsets[src]
-            ld_src = shp[1] if len(shp) > 1 else shp[0]
-            R = shp[0] if len(shp) > 1 else 1
-            Cc = ncols if ncols is not None else (shp[1] if len(shp) > 1 else shp[0])
+            two_d = len(shp) > 1
+            ld_src = shp[1] if two_d else shp[0]
+            R = shp[0] if two_d else 1
+            Cc = ncols if ncols is not None else (shp[1] if two_d else shp[0])
             if key not in self.sh:
                 self.sh[key] = Buf(rows, cols, dt, dev)
             b = self.sh[key]
-            dst = b.p(row_off, 0) if not transpose else b.p(0, row_off)
-            s2 = self.pp(src2) if src2 else None
-            self.pack_calls.append((code, self.pp(src, 0, c0), s2, ld_src, dst, b.ld, R, Cc, 1 if transpose else 0))
+            blocks = [(0, 0)] if (gate is None or gate[0] == gate[1]) else [(g * gate[0], g * gate[1]) for g in range(4)]
+            for s0, d0 in blocks:
+                if len(blocks) > 1:
+                    if two_d:
+                        R = gate[0]
+                    else:
+                        Cc = gate[0]
+                if two_d:       # gate blocks are row blocks of the source: row blocks of the shadow, column blocks of a transposed one
+                    sp = self.pp(src, s0, c0)
+                    s2 = self.pp(src2, s0, c0) if src2 else None
+                    dst = b.p(row_off + d0, col_off) if not transpose else b.p(row_off, col_off + d0)
+                else:           # a bias vector [4h] packed as one row
+                    sp = self.pp(src, 0, s0)
+                    s2 = self.pp(src2, 0, s0) if src2 else None
+                    dst = b.p(row_off, col_off + d0)
+                self.pack_calls.append((code, sp, s2, ld_src, dst, b.ld, R, Cc, 1 if transpose else 0))
 
+        ge, gd = (d.hd, d.hdp), (d.hid, d.hp)       # gate blocks of the encoder's directions / of the decoder as stored -> as computed
         for l in range(d.layers):
             i = d.emb if l == 0 else d.hid
             for k, suf in enumerate([""] + (["_reverse"] if d.brnn else [])):
                 # concatenated over directions: rows k*4Hd ..
-                shadow("enc_wih_l%d" % l, d.dirs * 4 * d.hd, i, "encoder.rnn.weight_ih_l%d%s" % (l, suf), row_off=k * 4 * d.hd)
-                shadow("enc_b_l%d" % l, 1, d.dirs * 4 * d.hd, "encoder.rnn.bias_ih_l%d%s" % (l, suf), dtype=torch.float32,
-                       src2="encoder.rnn.bias_hh_l%d%s" % (l, suf), transpose=False, row_off=0, c0=0)
-                # bias: place at column offset k*4Hd -> patch destination pointer
-                code, sp, s2, lds, dst, ldd, R, Cc, tr = self.pack_calls[-1]
-                self.pack_calls[-1] = (code, sp, s2, lds, self.sh["enc_b_l%d" % l].p(0, k * 4 * d.hd), ldd, R, Cc, tr)
-                shadow("enc_whh_l%d_d%d" % (l, k), 4 * d.hd, d.hd, "encoder.rnn.weight_hh_l%d%s" % (l, suf))
-                shadow("enc_whhT_l%d_d%d" % (l, k), d.hd, 4 * d.hd, "encoder.rnn.weight_hh_l%d%s" % (l, suf), transpose=True)
+                shadow("enc_wih_l%d" % l, d.dirs * 4 * d.hdp, i, "encoder.rnn.weight_ih_l%d%s" % (l, suf), row_off=k * 4 * d.hdp, gate=ge)
+                shadow("enc_b_l%d" % l, 1, d.dirs * 4 * d.hdp, "encoder.rnn.bias_ih_l%d%s" % (l, suf), dtype=torch.float32,
+                       src2="encoder.rnn.bias_hh_l%d%s" % (l, suf), col_off=k * 4 * d.hdp, gate=ge)
+                shadow("enc_whh_l%d_d%d" % (l, k), 4 * d.hdp, d.hd, "encoder.rnn.weight_hh_l%d%s" % (l, suf), gate=ge)
+                shadow("enc_whhT_l%d_d%d" % (l, k), d.hd, 4 * d.hdp, "encoder.rnn.weight_hh_l%d%s" % (l, suf), transpose=True, gate=ge)
         for l in range(d.layers):
             if l == 0:
-                shadow("dec_wih_l0_e", 4 * d.hid, d.emb, "decoder.rnn.weight_ih_l0", c0=0, ncols=d.emb)
-                shadow("dec_wih_l0_z", 4 * d.hid, d.z, "decoder.rnn.weight_ih_l0", c0=d.emb, ncols=d.z)
+                shadow("dec_wih_l0_e", 4 * d.hp, d.emb, "decoder.rnn.weight_ih_l0", c0=0, ncols=d.emb, gate=gd)
+                shadow("dec_wih_l0_z", 4 * d.hp, d.z, "decoder.rnn.weight_ih_l0", c0=d.emb, ncols=d.z, gate=gd)
             else:
-                shadow("dec_wih_l%d" % l, 4 * d.hid, d.hid, "decoder.rnn.weight_ih_l%d" % l)
-            shadow("dec_b_l%d" % l, 1, 4 * d.hid, "decoder.rnn.bias_ih_l%d" % l, dtype=torch.float32,
-                   src2="decoder.rnn.bias_hh_l%d" % l)
-            shadow("dec_whh_l%d" % l, 4 * d.hid, d.hid, "decoder.rnn.weight_hh_l%d" % l)
-            shadow("dec_whhT_l%d" % l, d.hid, 4 * d.hid, "decoder.rnn.weight_hh_l%d" % l, transpose=True)
+                shadow("dec_wih_l%d" % l, 4 * d.hp, d.hid, "decoder.rnn.weight_ih_l%d" % l, gate=gd)
+            shadow("dec_b_l%d" % l, 1, 4 * d.hp, "decoder.rnn.bias_ih_l%d" % l, dtype=torch.float32,
+                   src2="decoder.rnn.bias_hh_l%d" % l, gate=gd)
+            shadow("dec_whh_l%d" % l, 4 * d.hp, d.hid, "decoder.rnn.weight_hh_l%d" % l, gate=gd)
+            shadow("dec_whhT_l%d" % l, d.hid, 4 * d.hp, "decoder.rnn.weight_hh_l%d" % l, transpose=True, gate=gd)
         shadow("wa", d.hid, d.hid, "decoder.attn.linear_in.weight")
-        shadow("wo", d.hid, 2 * d.hid, "decoder.attn.linear_out.weight")
+        # W_out [H][2H] multiplies [c ; r] (GlobalAttention.py:187); the two halves of that buffer start at 0 and hp
+        if d.hp == d.hid:
+            shadow("wo", d.hid, 2 * d.hid, "decoder.attn.linear_out.weight")
+        else:
+            shadow("wo", d.hid, 2 * d.hp, "decoder.attn.linear_out.weight", c0=0, ncols=d.hid)
+            shadow("wo", d.hid, 2 * d.hp, "decoder.attn.linear_out.weight", c0=d.hid, ncols=d.hid, col_off=d.hp)
         for br in ("location", "scale"):
             shadow("q_%s_w1" % br, d.z, d.qin, "inf_net_global.%s.fc1.weight" % br)
             shadow("q_%s_w2" % br, d.z, d.z, "inf_net_global.%s.fc2.weight" % br)
@@ -383,7 +414,7 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------------ helpers
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
               act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
-              b_batch_rows=0, b_batch_stride=0, colsum=None):
+              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None):
         """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out[, out2]): the column sums of the K-strided A operand from the same
         pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached"""
         if split_k == -1:
@@ -397,6 +428,11 @@ class Engine(object):
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
                        add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k, b_batch_rows, b_batch_stride,
                        None, 0, None, None)
+        # rmap / cmap = (blk, valid): output rows / columns computed in padded blocks, stored densely (vmmt_gemm_args.c_row_blk)
+        if rmap is not None and rmap[0] != rmap[1]:
+            a.c_row_blk, a.c_row_valid = rmap
+        if cmap is not None and cmap[0] != cmap[1]:
+            a.c_col_blk, a.c_col_valid = cmap
         attached = False
         if colsum is not None:
             a.colsum_w, a.colsum_w_stride, a.colsum_out = colsum[:3]
@@ -613,6 +649,7 @@ class Workspace(object):
         d, T, dev = eng.d, eng.T, eng.dev
         f32, i64 = torch.float32, torch.int64
         H, Hd, E, Z, D, V, Lyr, dirs = d.hid, d.hd, d.emb, d.z, d.img, d.vt, d.layers, d.dirs
+        Hp, Hdp = d.hp, d.hdp         # hidden sizes as computed (Dims.hp): gate g of a 4H vector at column g * Hp; [c ; r] halves at 0 / Hp
         M, MS = Tp * B, S * B
         self.M, self.MS = M, MS
         nb = lambda r, c, dt=T, **kw: Buf(r, c, dt, dev, **kw)
@@ -628,8 +665,8 @@ class Workspace(object):
         self.kl_global = torch.zeros(1, dtype=f32, device=dev)
         # encoder
         self.Xs = nb(MS, E)
-        self.enc_gx = [nb(MS, dirs * 4 * Hd, f32) for _ in range(Lyr)]
-        self.enc_gates = [nb(MS, dirs * 4 * Hd) for _ in range(Lyr)]
+        self.enc_gx = [nb(MS, dirs * 4 * Hdp, f32) for _ in range(Lyr)]
+        self.enc_gates = [nb(MS, dirs * 4 * Hdp) for _ in range(Lyr)]
         self.enc_c = [nb(MS, H, f32) for _ in range(Lyr)]
         self.enc_out = [nb(MS, H) for _ in range(Lyr)]
         self.enc_mask = [nb(MS, H) if (d.dropout > 0 and l < Lyr - 1) else None for l in range(Lyr)]
@@ -646,14 +683,14 @@ class Workspace(object):
         self.kl_b = torch.zeros(B, dtype=f32, device=dev)
         # decoder
         self.Xt = nb(M, E)
-        self.zx = nb(B, 4 * H, f32)
-        self.dec_gx = [nb(M, 4 * H, f32) for _ in range(Lyr)]
-        self.dec_gates = [nb(M, 4 * H) for _ in range(Lyr)]
+        self.zx = nb(B, 4 * Hp, f32)
+        self.dec_gx = [nb(M, 4 * Hp, f32) for _ in range(Lyr)]
+        self.dec_gates = [nb(M, 4 * Hp) for _ in range(Lyr)]
         self.dec_c = [nb(M, H, f32) for _ in range(Lyr)]
         self.dec_out = [nb(M, H) for _ in range(Lyr - 1)]
         self.dec_mask = [nb(M, H) if d.dropout > 0 else None for _ in range(Lyr - 1)]
         self.dec_xdrop = [nb(M, H) if d.dropout > 0 else None for _ in range(Lyr - 1)]
-        self.cat = nb(M, 2 * H)
+        self.cat = nb(M, 2 * Hp)
         self.Q = nb(M, H)
         self.probs = torch.zeros(M * S, dtype=f32, device=dev)
         self.AH = nb(M, H)
@@ -699,15 +736,15 @@ class Workspace(object):
         else:
             self.GT = Buf(V, M, T, dev, storage=eng.shared_storage("GT", Buf.elems(V, M), T))
         self.dPre = nb(M, H)
-        self.dcat = nb(M, 2 * H)
+        self.dcat = nb(M, 2 * Hp)
         self.dQ = nb(M, H)
         self.dctx = nb(MS, H)
         self.dR = nb(M, H)
-        self.dec_dgates = [nb(M, 4 * H) for _ in range(Lyr)]
+        self.dec_dgates = [nb(M, 4 * Hp) for _ in range(Lyr)]
         self.dec_dcc = [nb(B, H, f32) for _ in range(Lyr)]
         self.dec_dh0 = [nb(B, H, f32) for _ in range(Lyr)]
         self.dec_dx = [nb(M, H) for _ in range(Lyr - 1)]
-        self.enc_dgates = [nb(MS, dirs * 4 * Hd) for _ in range(Lyr)]
+        self.enc_dgates = [nb(MS, dirs * 4 * Hdp) for _ in range(Lyr)]
         self.enc_dcc = [nb(B, H, f32) for _ in range(Lyr)]
         self.enc_dx = [nb(MS, H) for _ in range(Lyr - 1)]
         self.q_dmu = nb(B, Z)
@@ -733,6 +770,7 @@ class Workspace(object):
         e, d, lib = self.e, self.e.d, self.e.lib
         B, S, Tp, M, MS = self.B, self.S, self.Tp, self.M, self.MS
         H, Hd, E, Z, D, V, Lyr, dirs = d.hid, d.hd, d.emb, d.z, d.img, d.vt, d.layers, d.dirs
+        Hp, Hdp = d.hp, d.hdp
         dt = e.dt
         P = []
         drop = training and d.dropout > 0
@@ -760,7 +798,7 @@ class Workspace(object):
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                 self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
         we = e.sh["dec_wih_l0_e"]
-        e._gemm(P, L.GEMM_NT, self.Xt.p(), self.Xt.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * H, E, out_f32=1)
+        e._gemm(P, L.GEMM_NT, self.Xt.p(), self.Xt.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * Hp, E, out_f32=1)
         e._record(P, "dec_gx")
         if d.conditional:
             self._cond_forward_aux(P, training)
@@ -781,7 +819,7 @@ class Workspace(object):
         x, xcols = self.Xs, E
         for l in range(Lyr):
             wih, bsum = e.sh["enc_wih_l%d" % l], e.sh["enc_b_l%d" % l]
-            e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hd,
+            e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hdp,
                     xcols, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
             seq = (L.LstmDirFwd * (S * dirs))()                 # the whole recurrence: step-major, then direction
             if not hasattr(self, "hzero"):
@@ -793,22 +831,22 @@ class Workspace(object):
                     first = step == 0
                     whh = e.sh["enc_whh_l%d_d%d" % (l, k)]
                     a = seq[step * dirs + k]
-                    a.h_prev = self.enc_out[l].p(tp * B, k * Hd) if not first else self.enc_out[l].p(t * B, k * Hd)
+                    a.h_prev = self.enc_out[l].p(tp * B, k * Hdp) if not first else self.enc_out[l].p(t * B, k * Hdp)
                     a.ld_hprev = self.enc_out[l].ld
-                    a.c_prev = None if first else self.enc_c[l].p(tp * B, k * Hd)
+                    a.c_prev = None if first else self.enc_c[l].p(tp * B, k * Hdp)
                     a.ld_cprev = self.enc_c[l].ld
                     a.w_hh, a.ld_w = whh.p(), whh.ld
-                    a.gx, a.ld_gx = self.enc_gx[l].p(t * B, k * 4 * Hd), self.enc_gx[l].ld
-                    a.gates, a.ld_gates = self.enc_gates[l].p(t * B, k * 4 * Hd), self.enc_gates[l].ld
-                    a.c_out, a.ld_c = self.enc_c[l].p(t * B, k * Hd), self.enc_c[l].ld
-                    a.h_out, a.ld_h = self.enc_out[l].p(t * B, k * Hd), self.enc_out[l].ld
-                    a.h_n, a.ld_hn = self.hn[l].p(0, k * Hd), self.hn[l].ld
-                    a.c_n, a.ld_cn = self.cn[l].p(0, k * Hd), self.cn[l].ld
+                    a.gx, a.ld_gx = self.enc_gx[l].p(t * B, k * 4 * Hdp), self.enc_gx[l].ld
+                    a.gates, a.ld_gates = self.enc_gates[l].p(t * B, k * 4 * Hdp), self.enc_gates[l].ld
+                    a.c_out, a.ld_c = self.enc_c[l].p(t * B, k * Hdp), self.enc_c[l].ld
+                    a.h_out, a.ld_h = self.enc_out[l].p(t * B, k * Hdp), self.enc_out[l].ld
+                    a.h_n, a.ld_hn = self.hn[l].p(0, k * Hdp), self.hn[l].ld
+                    a.c_n, a.ld_cn = self.cn[l].p(0, k * Hdp), self.cn[l].ld
                     a.t = t
                     a.capture = 1 if k == 0 else 2
                     if first:
-                        a.h_prev, a.ld_hprev = self.hzero.p(0, k * Hd), self.hzero.ld
-            e._lstm_seq_fwd(P, seq, dirs, S, self.src_len.data_ptr(), B, Hd)
+                        a.h_prev, a.ld_hprev = self.hzero.p(0, k * Hdp), self.hzero.ld
+            e._lstm_seq_fwd(P, seq, dirs, S, self.src_len.data_ptr(), B, Hdp)
             x, xcols = self.enc_out[l], H
             if l < Lyr - 1 and drop:
                 e._call(P, lib.vmmt_mul, dt, self.enc_out[l].p(), self.enc_out[l].ld, self.enc_mask[l].p(), self.enc_mask[l].ld,
@@ -819,15 +857,17 @@ class Workspace(object):
             self._cond_forward(P, training, ctx)
         # a4 + a5 fused: masked mean -> both MLPs -> sample -> KL in ONE launch (csrc/qnet.hip); the separate kernels below remain for
         # fp32 parity mode, the conditional model and sizes the fused kernel does not take
-        fused_q = (e.fused_qnet and not d.conditional and dt == L.BF16 and H % 256 == 0 and Z % 128 == 0 and
-                   16 * (H + 8) * 2 + 16 * (Z + 8) * 2 + 2 * 16 * Z * 4 <= 64 * 1024)
+        Zp = d.zp
+        fused_q = (e.fused_qnet and not d.conditional and dt == L.BF16 and Hp % 256 == 0 and Zp <= 512 and
+                   16 * (Hp + 8) * 2 + 16 * (Zp + 8) * 2 + 2 * 16 * Zp * 4 <= 128 * 1024)
+        self.fused_q = bool(fused_q)
         if fused_q:
             wl1, ws1, wl2, ws2 = e.sh["q_location_w1"], e.sh["q_scale_w1"], e.sh["q_location_w2"], e.sh["q_scale_w2"]
             e._call(P, lib.vmmt_qnet_fwd, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), wl1.p(), ws1.p(), wl1.ld,
                     e.pp("inf_net_global.location.fc1.bias"), e.pp("inf_net_global.scale.fc1.bias"), wl2.p(), ws2.p(), wl2.ld,
                     e.pp("inf_net_global.location.fc2.bias"), e.pp("inf_net_global.scale.fc2.bias"), self.eps.p(), self.hbar.p(),
                     self.hbar.ld, self.q_h1["location"].p(), self.q_h1["scale"].p(), self.q_h1["location"].ld, self.mu.p(),
-                    self.sigma.p(), self.z32.p(), self.zT.p(), self.zT.ld, self.kl_b.data_ptr(), self.stats.data_ptr(), B, S, H, Z,
+                    self.sigma.p(), self.z32.p(), self.zT.p(), self.zT.ld, self.kl_b.data_ptr(), self.stats.data_ptr(), B, S, Hp, Zp, Z,
                     1 if training else 0)
         else:
             # a4 q(z|x): masked mean of the detached memory, two 2-layer MLPs
@@ -873,7 +913,7 @@ class Workspace(object):
         # a6 decoder: gx[t] = emb(y_t) W_e^T (side stream, above) ; zx = z W_z^T + b is added inside the step kernel
         e._wait(P, "opt_side_done")      # decoder / attention / generator parameters + shadows of the previous update
         wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
-        e._gemm(P, L.GEMM_NT, self.zT.p(), self.zT.ld, wz.p(), wz.ld, self.zx.p(), self.zx.ld, B, 4 * H, Z,
+        e._gemm(P, L.GEMM_NT, self.zT.p(), self.zT.ld, wz.p(), wz.ld, self.zx.p(), self.zx.ld, B, 4 * Hp, Z,
                 addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
         x, xcols = self.Xt, E
         for l in range(Lyr):
@@ -881,10 +921,10 @@ class Workspace(object):
                 e._wait(P, "dec_gx")
             else:
                 wi, bs = e.sh["dec_wih_l%d" % l], e.sh["dec_b_l%d" % l]
-                e._gemm(P, L.GEMM_NT, x.p(), x.ld, wi.p(), wi.ld, self.dec_gx[l].p(), self.dec_gx[l].ld, M, 4 * H, H,
+                e._gemm(P, L.GEMM_NT, x.p(), x.ld, wi.p(), wi.ld, self.dec_gx[l].p(), self.dec_gx[l].ld, M, 4 * Hp, H,
                         addend=bs.p(), ld_add=bs.ld, add_rows=1, out_f32=1)
             last = l == Lyr - 1
-            outb, ocol = (self.cat, H) if last else (self.dec_out[l], 0)
+            outb, ocol = (self.cat, Hp) if last else (self.dec_out[l], 0)
             whh = e.sh["dec_whh_l%d" % l]
             seq = (L.LstmDirFwd * Tp)()
             for t in range(Tp):
@@ -903,7 +943,7 @@ class Workspace(object):
                 a.c_out, a.ld_c = self.dec_c[l].p(t * B), self.dec_c[l].ld
                 a.h_out, a.ld_h = outb.p(t * B, ocol), outb.ld
                 a.h_n, a.c_n, a.t, a.capture = None, None, t, 0
-            e._lstm_seq_fwd(P, seq, 1, Tp, None, B, H)
+            e._lstm_seq_fwd(P, seq, 1, Tp, None, B, Hp)
             if not last:
                 x, xcols = self.dec_out[l], H
                 if drop:
@@ -912,10 +952,10 @@ class Workspace(object):
                     x = self.dec_xdrop[l]
         # a7 attention
         wa, wo = e.sh["wa"], e.sh["wo"]
-        e._gemm(P, L.GEMM_NT, self.cat.p(0, H), self.cat.ld, wa.p(), wa.ld, self.Q.p(), self.Q.ld, M, H, H)
+        e._gemm(P, L.GEMM_NT, self.cat.p(0, Hp), self.cat.ld, wa.p(), wa.ld, self.Q.p(), self.Q.ld, M, H, H)
         e._call(P, lib.vmmt_attn_fwd, dt, self.Q.p(), self.Q.ld, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.cat.p(), self.cat.ld,
-                self.probs.data_ptr(), Tp, B, S, H)
-        e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * H, act=L.ACT_TANH)
+                self.probs.data_ptr(), Tp, B, S, Hp)
+        e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * Hp, act=L.ACT_TANH)
         if drop:
             e._wait(P, "out_mask")
             e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
@@ -957,6 +997,8 @@ class Workspace(object):
         e, d, lib = self.e, self.e.d, self.e.lib
         B, S, Tp, M, MS = self.B, self.S, self.Tp, self.M, self.MS
         H, Hd, E, Z, D, V, Lyr, dirs = d.hid, d.hd, d.emb, d.z, d.img, d.vt, d.layers, d.dirs
+        Hp, Hdp = d.hp, d.hdp
+        gmap_d, gmap_e = (Hp, H), (Hdp, Hd)       # padded gate blocks -> nn.LSTM's [4H] rows (vmmt_gemm_args.c_row_blk)
         dt = e.dt
         P = []
         drop = training_dropout and d.dropout > 0
@@ -1018,11 +1060,11 @@ class Workspace(object):
                 pre = "inf_net_global.%s" % br
                 if part == 2:
                     e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
-                    e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"), None)
+                    e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, 0, 0, e.gp(pre + ".fc2.bias"), None)
                 else:
                     e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, qx.p(), qx.ld, e.gp(pre + ".fc1.weight"), d.qin,
                             Z, d.qin, B, out_f32=1, split_k=-1)
-                    e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
+                    e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, 0, 0, e.gp(pre + ".fc1.bias"), None)
 
             if cond_first:
                 # d h_y first (6 small kernels), then encoder_tgt's recurrence on its own stream; the weight gradients, p's backward
@@ -1088,7 +1130,7 @@ class Workspace(object):
             w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
             e._gemm(P, L.GEMM_TN, self.dmu_v.p(), self.dmu_v.ld, self.h1v.p(), self.h1v.ld, e.gp("inf_net_image.location.fc2.weight"), D,
                     D, D, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, self.dmu_v.p(), self.dmu_v.ld, B, D, e.gp("inf_net_image.location.fc2.bias"), None)
+            e._call(P, lib.vmmt_colsum, dt, self.dmu_v.p(), self.dmu_v.ld, B, D, 0, 0, e.gp("inf_net_image.location.fc2.bias"), None)
             # [B x D] x [D x D] with B = a few hundred rows: 32 tiles of 128 x 128 would leave 7/8 of the chip idle for 100 us, so the
             # reduction is split over workgroups (f32 atomics into dh1v32, zeroed with the gradient arena) and the ReLU backward reads f32
             e._gemm(P, L.GEMM_NN, self.dmu_v.p(), self.dmu_v.ld, w2.p(), w2.ld, self.dh1v32.p(), self.dh1v32.ld, B, D, D, out_f32=1,
@@ -1097,7 +1139,7 @@ class Workspace(object):
                     self.dh1v.p(), self.dh1v.ld, B, D)
             e._gemm(P, L.GEMM_TN, self.dh1v.p(), self.dh1v.ld, self.zt.p(), self.zt.ld, e.gp("inf_net_image.location.fc1.weight"), Z,
                     D, Z, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, self.dh1v.p(), self.dh1v.ld, B, D, e.gp("inf_net_image.location.fc1.bias"), None)
+            e._call(P, lib.vmmt_colsum, dt, self.dh1v.p(), self.dh1v.ld, B, D, 0, 0, e.gp("inf_net_image.location.fc1.bias"), None)
             e._gemm(P, L.GEMM_NN, self.dh1v.p(), self.dh1v.ld, w1.p(), w1.ld, self.dzt.p(), self.dzt.ld, B, Z, D, out_f32=1,
                     split_k=max(1, min(D // 256, 256 // max(1, ((B + 63) // 64) * ((Z + 63) // 64)))))
             e._call(P, lib.vmmt_gate_bwd, self.dzt.p(), self.dzt.ld, self.z32.p(), self.gate.data_ptr(),
@@ -1123,13 +1165,13 @@ class Workspace(object):
                     self.out_mask.p() if drop else None, self.out_mask.ld if drop else 0, self.dPre.p(), self.dPre.ld, M, H)
             e._record(P, "dPre")
             wo, wa = e.sh["wo"], e.sh["wa"]
-            e._gemm(P, L.GEMM_NN, self.dPre.p(), self.dPre.ld, wo.p(), wo.ld, self.dcat.p(), self.dcat.ld, M, 2 * H, H)
+            e._gemm(P, L.GEMM_NN, self.dPre.p(), self.dPre.ld, wo.p(), wo.ld, self.dcat.p(), self.dcat.ld, M, 2 * Hp, H)
             ctx = self.enc_out[Lyr - 1]
             e._call(P, lib.vmmt_attn_bwd, dt, self.dcat.p(), self.dcat.ld, self.probs.data_ptr(), self.Q.p(), self.Q.ld, ctx.p(), ctx.ld,
-                    self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, H)
+                    self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, Hp)
             e._record(P, "dQ")
             e._gemm(P, L.GEMM_NN, self.dQ.p(), self.dQ.ld, wa.p(), wa.ld, self.dR.p(), self.dR.ld, M, H, H,
-                    addend=self.dcat.p(0, H), ld_add=self.dcat.ld, add_rows=-1, add_is_T=1)
+                    addend=self.dcat.p(0, Hp), ld_add=self.dcat.ld, add_rows=-1, add_is_T=1)
 
         # issue order = the order of this list.  With the fused generator dO exists when the plan starts, so the main stream's first
         # kernels go out first instead of behind the ~20 small launches of the aux chain (tools/ab.py: 2.009 against 2.037 ms, equal
@@ -1174,9 +1216,9 @@ class Workspace(object):
         e._sid = SIDE
         e._wait(P, "dPre")
         e._gemm(P, L.GEMM_TN, self.dPre.p(), self.dPre.ld, self.cat.p(), self.cat.ld, e.gp("decoder.attn.linear_out.weight"), 2 * H,
-                H, 2 * H, M, out_f32=1, split_k=-1)
+                H, 2 * Hp, M, out_f32=1, split_k=-1, cmap=(Hp, H))
         e._wait(P, "dQ")
-        e._gemm(P, L.GEMM_TN, self.dQ.p(), self.dQ.ld, self.cat.p(0, H), self.cat.ld, e.gp("decoder.attn.linear_in.weight"), H,
+        e._gemm(P, L.GEMM_TN, self.dQ.p(), self.dQ.ld, self.cat.p(0, Hp), self.cat.ld, e.gp("decoder.attn.linear_in.weight"), H,
                 H, H, M, out_f32=1, split_k=-1)
         # the decoder's parameter gradients and the first-half norm go to the AUX stream, which is idle once its own chain (image /
         # q(z|x) networks) is through: behind the generator's products on the side stream they reached into the step's tail
@@ -1188,7 +1230,7 @@ class Workspace(object):
         for l in reversed(range(Lyr)):
             e._sid = MAIN
             last = l == Lyr - 1
-            outb, ocol = (self.cat, H) if last else (self.dec_out[l], 0)
+            outb, ocol = (self.cat, Hp) if last else (self.dec_out[l], 0)
             whhT = e.sh["dec_whhT_l%d" % l]
             dg = self.dec_dgates[l]
             seq = (L.LstmDirBwd * (Tp + 1))()                   # Tp cell-backward steps + the dh0 step
@@ -1213,11 +1255,11 @@ class Workspace(object):
             a.dh0_out, a.ld_dh0 = self.dec_dh0[l].p(), self.dec_dh0[l].ld
             # (conditional model: encoder_tgt's persistent backward is running by now; two persistent launches share a CU only if their
             #  registers fit one SIMD file and their LDS one CU -- 272 + 166 registers, 72 + 40 KiB here)
-            e._lstm_seq_bwd(P, seq, 1, Tp, None, B, H, with_dh0=1)
+            e._lstm_seq_bwd(P, seq, 1, Tp, None, B, Hp, with_dh0=1)
             e._record(P, "dec_dg%d" % l)
             if l > 0:       # gradient w.r.t. the layer input stays on the critical path
                 wi = e.sh["dec_wih_l%d" % l]
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wi.p(), wi.ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H, 4 * H)
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wi.p(), wi.ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H, 4 * Hp)
                 if drop:
                     e._call(P, lib.vmmt_mul, dt, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, self.dec_mask[l - 1].p(),
                             self.dec_mask[l - 1].ld, self.dec_dx[l - 1].p(), self.dec_dx[l - 1].ld, M, H)
@@ -1227,25 +1269,29 @@ class Workspace(object):
             e._wait(P, "dec_dg%d" % l)
             gw = "decoder.rnn.weight_hh_l%d" % l
             if Tp > 1:
-                e._gemm(P, L.GEMM_TN, dg.p(B), dg.ld, outb.p(0, ocol), outb.ld, e.gp(gw), H, 4 * H, H, (Tp - 1) * B, out_f32=1, split_k=-1)
-            e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * H, H, B, out_f32=1, split_k=-1)
+                e._gemm(P, L.GEMM_TN, dg.p(B), dg.ld, outb.p(0, ocol), outb.ld, e.gp(gw), H, 4 * Hp, H, (Tp - 1) * B, out_f32=1, split_k=-1,
+                        rmap=gmap_d)
+            e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * Hp, H, B, out_f32=1, split_k=-1, rmap=gmap_d)
             gi = "decoder.rnn.weight_ih_l%d" % l
             # the bias gradient (column sums of dgates) rides in the dW_ih product, which reads all M rows of dgates anyway
             bsum = (None, 0, e.gp("decoder.rnn.bias_ih_l%d" % l), e.gp("decoder.rnn.bias_hh_l%d" % l)) if e.lstm_db_in_gemm else None
             if l == 0:
-                fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * H, E, M, out_f32=1, split_k=-1,
-                                  colsum=bsum)
-                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * H, Z, M, out_f32=1, split_k=-1, b_kmod=B)
+                fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * Hp, E, M, out_f32=1, split_k=-1,
+                                  colsum=bsum, rmap=gmap_d)
+                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * Hp, Z, M, out_f32=1, split_k=-1, b_kmod=B,
+                        rmap=gmap_d)
                 we = e.sh["dec_wih_l0_e"]
                 # dX = dgates W_e, then its rows scattered into the embedding gradient (pad row dropped)
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, self.dXt.p(), self.dXt.ld, M, E, 4 * H, out_f32=1)
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, self.dXt.p(), self.dXt.ld, M, E, 4 * Hp, out_f32=1)
                 e._call(P, lib.vmmt_scatter_add_rows, self.dXt.p(), self.dXt.ld, self.tgt_in.data_ptr(), PAD,
                         e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E, M, E)
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
-                fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * H, H, M, out_f32=1, split_k=-1, colsum=bsum)
+                fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * Hp, H, M, out_f32=1, split_k=-1, colsum=bsum,
+                                  rmap=gmap_d)
             if not fused_b:
-                e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * H, e.gp("decoder.rnn.bias_ih_l%d" % l), e.gp("decoder.rnn.bias_hh_l%d" % l))
+                e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * Hp, Hp if Hp != H else 0, H, e.gp("decoder.rnn.bias_ih_l%d" % l),
+                        e.gp("decoder.rnn.bias_hh_l%d" % l))
         if rp:
             # reparameterised gradient (H2 switched off): dL/dz = sum_t dgates_t W_z (decoder input, VI_Model1.py:99-100) + the image
             # network's gate path; it joins the KL gradient at mu / sigma, so the q(z|x) networks' backward can only start here,
@@ -1253,7 +1299,7 @@ class Workspace(object):
             e._sid = AUX
             e._wait(P, "dec_dg0")
             dg0, wz = self.dec_dgates[0], e.sh["dec_wih_l0_z"]
-            e._gemm(P, L.GEMM_NN, dg0.p(), dg0.ld, wz.p(), wz.ld, self.dzrow.p(), self.dzrow.ld, M, Z, 4 * H, out_f32=1)
+            e._gemm(P, L.GEMM_NN, dg0.p(), dg0.ld, wz.p(), wz.ld, self.dzrow.p(), self.dzrow.ld, M, Z, 4 * Hp, out_f32=1)
             e._call(P, lib.vmmt_reparam_dz, self.dzrow.p(), self.dzrow.ld, Tp, self.dzt.p(), self.dzt.ld, self.z32.p(),
                     self.gate.data_ptr(), e.pp("inf_net_image.gate_affine_transform.weight"), self.dz.p(), B, Z)
             kl_and_q_backward()
@@ -1301,26 +1347,26 @@ class Workspace(object):
                 if k == 0:      # h_prev[t] = out[t-1]: t in [max(lo, 1), hi)
                     t0 = max(lo, 1)
                     if hi > t0:
-                        e._gemm(P, L.GEMM_TN, dg.p(t0 * B, k * 4 * Hd), dg.ld, self.enc_out[l].p((t0 - 1) * B, k * Hd), self.enc_out[l].ld,
-                                e.gp(gw), Hd, 4 * Hd, Hd, (hi - t0) * B, out_f32=1, split_k=-1)
+                        e._gemm(P, L.GEMM_TN, dg.p(t0 * B, k * 4 * Hdp), dg.ld, self.enc_out[l].p((t0 - 1) * B, k * Hdp), self.enc_out[l].ld,
+                                e.gp(gw), Hd, 4 * Hdp, Hd, (hi - t0) * B, out_f32=1, split_k=-1, rmap=gmap_e)
                 else:           # h_prev[t] = out[t+1]: t in [lo, min(hi, S-1))
                     t1 = min(hi, S - 1)
                     if t1 > lo:
-                        e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, self.enc_out[l].p((lo + 1) * B, k * Hd), self.enc_out[l].ld,
-                                e.gp(gw), Hd, 4 * Hd, Hd, (t1 - lo) * B, out_f32=1, split_k=-1)
+                        e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hdp), dg.ld, self.enc_out[l].p((lo + 1) * B, k * Hdp), self.enc_out[l].ld,
+                                e.gp(gw), Hd, 4 * Hdp, Hd, (t1 - lo) * B, out_f32=1, split_k=-1, rmap=gmap_e)
                 alt()           # (alternating: main = the two dW_hh and the embedding product behind them, side = dW_ih + bias sums)
                 bih, bhh = e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)), e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf))
-                fused_b = e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hd), dg.ld, xin.p(lo * B), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)),
-                                  xcols, 4 * Hd, xcols, (hi - lo) * B, out_f32=1, split_k=-1,
+                fused_b = e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hdp), dg.ld, xin.p(lo * B), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)),
+                                  xcols, 4 * Hdp, xcols, (hi - lo) * B, out_f32=1, split_k=-1, rmap=gmap_e,
                                   colsum=(None, 0, bih, bhh) if e.lstm_db_in_gemm else None)      # bias gradient: see the decoder's
                 if not fused_b:
-                    e._call(P, lib.vmmt_colsum, dt, dg.p(lo * B, k * 4 * Hd), dg.ld, (hi - lo) * B, 4 * Hd, bih, bhh)
+                    e._call(P, lib.vmmt_colsum, dt, dg.p(lo * B, k * 4 * Hdp), dg.ld, (hi - lo) * B, 4 * Hdp, Hdp if Hdp != Hd else 0, Hd, bih, bhh)
             if l == 0:                                # embedding gradient: one product over both directions, last on the main stream
                 assert all(r == (0, S) for r in ranges)
                 e._sid = MAIN
                 # (as the GEMM's own atomic epilogue the scatter costs 47 us on top of a 28 us product in isolation; in the step the two
                 #  forms measure the same -- 2.07-2.08 ms, tools/ab.py -- the row kernel is kept for its simpler access pattern)
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.dXs.p(), self.dXs.ld, MS, E, dirs * 4 * Hd, out_f32=1)
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.dXs.p(), self.dXs.ld, MS, E, dirs * 4 * Hdp, out_f32=1)
                 e._call(P, lib.vmmt_scatter_add_rows, self.dXs.p(), self.dXs.ld, self.src.data_ptr(), PAD,
                         e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E, MS, E)
 
@@ -1337,27 +1383,27 @@ class Workspace(object):
                     a = seq[step * dirs + k]
                     whhT = e.sh["enc_whhT_l%d_d%d" % (l, k)]
                     if step > 0:
-                        a.dgates_next, a.ld_dgn = dg.p(tn * B, k * 4 * Hd), dg.ld
+                        a.dgates_next, a.ld_dgn = dg.p(tn * B, k * 4 * Hdp), dg.ld
                     a.w_hh_t, a.ld_wt = whhT.p(), whhT.ld
-                    a.dh_above, a.ld_dha = dh_above.p(t * B, k * Hd), dh_above.ld
-                    a.gates, a.ld_gates = self.enc_gates[l].p(t * B, k * 4 * Hd), self.enc_gates[l].ld
-                    a.c_t, a.ld_ct = self.enc_c[l].p(t * B, k * Hd), self.enc_c[l].ld
+                    a.dh_above, a.ld_dha = dh_above.p(t * B, k * Hdp), dh_above.ld
+                    a.gates, a.ld_gates = self.enc_gates[l].p(t * B, k * 4 * Hdp), self.enc_gates[l].ld
+                    a.c_t, a.ld_ct = self.enc_c[l].p(t * B, k * Hdp), self.enc_c[l].ld
                     if 0 <= tp < S:
-                        a.c_prev, a.ld_cp = self.enc_c[l].p(tp * B, k * Hd), self.enc_c[l].ld
-                    a.dc_carry, a.ld_dcc = self.enc_dcc[l].p(0, k * Hd), self.enc_dcc[l].ld
-                    a.dgates_out, a.ld_dgo = dg.p(t * B, k * 4 * Hd), dg.ld
-                    a.dh_n, a.ld_dhn = self.dec_dh0[l].p(0, k * Hd), self.dec_dh0[l].ld
-                    a.dc_n, a.ld_dcn = self.dec_dcc[l].p(0, k * Hd), self.dec_dcc[l].ld
+                        a.c_prev, a.ld_cp = self.enc_c[l].p(tp * B, k * Hdp), self.enc_c[l].ld
+                    a.dc_carry, a.ld_dcc = self.enc_dcc[l].p(0, k * Hdp), self.enc_dcc[l].ld
+                    a.dgates_out, a.ld_dgo = dg.p(t * B, k * 4 * Hdp), dg.ld
+                    a.dh_n, a.ld_dhn = self.dec_dh0[l].p(0, k * Hdp), self.dec_dh0[l].ld
+                    a.dc_n, a.ld_dcn = self.dec_dcc[l].p(0, k * Hdp), self.dec_dcc[l].ld
                     a.t = t
                     a.inject = 1 if k == 0 else 2
             # (the encoder's parameter gradients are the step's tail; cutting this recurrence into two launches so that the products of
             #  the first half of its steps run next to the second half was measured: 2.000 against 1.881 ms -- the relaunch has to wait
             #  for the product's workgroups to leave before all of its own are resident)
-            e._lstm_seq_bwd(P, seq, dirs, S, self.src_len.data_ptr(), B, Hd)
+            e._lstm_seq_bwd(P, seq, dirs, S, self.src_len.data_ptr(), B, Hdp)
             e._record(P, "enc_dg%d" % l)
             wih = e.sh["enc_wih_l%d" % l]
             if l > 0:
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H, dirs * 4 * Hd)
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H, dirs * 4 * Hdp)
                 if drop:
                     e._call(P, lib.vmmt_mul, dt, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, self.enc_mask[l - 1].p(),
                             self.enc_mask[l - 1].ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H)
@@ -1516,13 +1562,13 @@ class Workspace(object):
             w1, w2 = e.sh["p_%s_w1" % br], e.sh["p_%s_w2" % br]
             pre = "gen_net_global.%s" % br
             e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.p_h1[br].p(), self.p_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, e.gp(pre + ".fc2.bias"), None)
+            e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, 0, 0, e.gp(pre + ".fc2.bias"), None)
             e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2.p(), w2.ld, self.p_dh1[br].p(), self.p_dh1[br].ld, B, Z, Z)
             e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.p_dh1[br].p(), self.p_dh1[br].ld, 0, self.p_h1[br].p(), self.p_h1[br].ld,
                     None, 0, self.p_dh1[br].p(), self.p_dh1[br].ld, B, Z)
             e._gemm(P, L.GEMM_TN, self.p_dh1[br].p(), self.p_dh1[br].ld, self.hq.p(), self.hq.ld, e.gp(pre + ".fc1.weight"), H,
                     Z, H, B, out_f32=1, split_k=-1)
-            e._call(P, lib.vmmt_colsum, dt, self.p_dh1[br].p(), self.p_dh1[br].ld, B, Z, e.gp(pre + ".fc1.bias"), None)
+            e._call(P, lib.vmmt_colsum, dt, self.p_dh1[br].p(), self.p_dh1[br].ld, B, Z, 0, 0, e.gp(pre + ".fc1.bias"), None)
             e._gemm(P, L.GEMM_NN, self.p_dh1[br].p(), self.p_dh1[br].ld, w1.p(), w1.ld, self.dhbar_p.p(), self.dhbar_p.ld, B, H, Z,
                     accumulate=1 if i else 0)
         e._record(P, "dhbar_p")
@@ -1580,7 +1626,7 @@ class Workspace(object):
                     else:        # h_prev[t] = out[t+1]
                         e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * ht), dg.ld, self.enct_out[l].p(Tn, k * ht), self.enct_out[l].ld, e.gp(gw), ht,
                                 4 * ht, ht, (B - 1) * Tn, out_f32=1, split_k=-1)
-                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * ht), dg.ld, MT, 4 * ht, e.gp("encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf)),
+                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * ht), dg.ld, MT, 4 * ht, 0, 0, e.gp("encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf)),
                         e.gp("encoder_tgt.rnn.bias_hh_l%d%s" % (l, suf)))
                 e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * ht), dg.ld, xin.p(), xin.ld, e.gp("encoder_tgt.rnn.weight_ih_l%d%s" % (l, suf)), xcols,
                         4 * ht, xcols, MT, out_f32=1, split_k=-1)
