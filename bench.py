@@ -2,11 +2,13 @@
 """Benchmark of the hot path: one VI_Model1 training step (image-row gather -> forward -> ELBO -> backward ->
 [gradient all-reduce] -> clip + Adam) on synthetic batches.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|5]
+    python bench.py --gpus N --steps K --warmup W [--config 2|5|script]
 
 --config 2 (default; the configuration BASELINE.json's metric is quoted on): batch 256 per GPU, src/tgt length 20, 30k
 vocabularies, 1-layer biLSTM 512, z 256, emb 500 (reference default), 2048-d image features, bf16 compute / fp32
 accumulate, dropout 0.5.  --config 5 (roofline stress): src/tgt length 64, 50k vocabularies, 2-layer 1024, z 512.
+--config script: the run scripts as written (run_translated_m30k_only.sh:46-57, opts.py defaults): 2-layer uni-directional LSTM
+500, z 500, emb 500 -- sizes the engine computes padded to 512 (engine.Dims.hp).
 
 N > 1: one rank per GPU over RCCL.  Either the driver launches the ranks itself (`python -m torch.distributed.run ...
 bench.py --gpus N ...`: RANK / WORLD_SIZE are in the environment) or a plain `python bench.py --gpus N` starts them: the
@@ -33,12 +35,15 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 CONFIGS = {
-    2: dict(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, S=20, T=21, n_img=29000,
+    "2": dict(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, S=20, T=21, n_img=29000,
             name="BASELINE config 2: VI_Model1 training step, batch %d/GPU, src/tgt len 20, V=30000, 1-layer biLSTM 512, z 256, "
                  "emb 500, 2048-d image feats"),
-    5: dict(vs=50000, vt=50000, emb=1024, hid=1024, z=512, img=2048, layers=2, brnn=True, S=64, T=65, n_img=100000,
+    "5": dict(vs=50000, vt=50000, emb=1024, hid=1024, z=512, img=2048, layers=2, brnn=True, S=64, T=65, n_img=100000,
             name="BASELINE config 5 (roofline stress): VI_Model1 training step, batch %d/GPU, src/tgt len 64, V=50000, 2-layer "
                  "biLSTM 1024, z 512, emb 1024, 2048-d image feats"),
+    "script": dict(vs=30000, vt=30000, emb=500, hid=500, z=500, img=2048, layers=2, brnn=False, S=20, T=21, n_img=29000,
+                   name="run scripts as written (run_translated_m30k_only.sh): VI_Model1 training step, batch %d/GPU, src/tgt len 20, V=30000, "
+                        "2-layer uni-directional LSTM 500, z 500, emb 500, 2048-d image feats"),
 }
 
 
@@ -174,7 +179,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # 50 x 1.8 ms: still a 0.1-second timed region; 20 steps read ~1 % slow
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = headline, 5 = stress)")
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS), help="BASELINE.json configuration (2 = headline, 5 = stress) or "
+                    "'script' (the run scripts' own sizes: 2-layer uni-directional 500)")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--dropout", type=float, default=0.5)
@@ -322,7 +328,7 @@ def main():
         ach = gen_flop / (t_dom * 1e-3) / 1e12 if t_dom > 0 else 0.0
         traffic = None      # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["config%d" % a.config]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["config%s" % a.config]
             if B == 256 and a.dtype == "bf16" and not a.conditional:
                 traffic = tj["read_bytes"] + tj["write_bytes"]
         except Exception:

@@ -797,8 +797,8 @@ extern "C" int vmmt_gen_dW_finish(int dtype, const void* Pw, int64_t ldp, const 
                                   void* stream) {
   using namespace vmmt;
   if (dtype != VMMT_BF16 || !Pw || !cs || !O || !y32 || !dW || !dbias || M <= 0 || V <= 0 || (K != 512 && K != 256) || (ldp & 7) ||
-      (((uintptr_t)Pw) & 15) || lddw < K)
-    return VMMT_EINVAL;
+      (((uintptr_t)Pw) & 15) || lddw <= 0)
+    return VMMT_EINVAL;          // (lddw < K: rows of dW narrower than the tiled width, e.g. H = 500 in K = 512 -- the one-hot kernel stops at lddw)
   hipStream_t st = (hipStream_t)stream;
   const long mpad = (long)((M + 127) / 128) * 128;
   if (!colsum_done)

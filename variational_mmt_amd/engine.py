@@ -343,7 +343,7 @@ class Engine(object):
             shadow("wo", d.hid, 2 * d.hp, "decoder.attn.linear_out.weight", c0=d.hid, ncols=d.hid, col_off=d.hp)
         for br in ("location", "scale"):
             shadow("q_%s_w1" % br, d.z, d.qin, "inf_net_global.%s.fc1.weight" % br)
-            shadow("q_%s_w2" % br, d.z, d.z, "inf_net_global.%s.fc2.weight" % br)
+            shadow("q_%s_w2" % br, d.z, d.zp, "inf_net_global.%s.fc2.weight" % br)     # (read d.zp columns wide by the fused q(z|x) kernel)
         if d.conditional:
             for br in ("location", "scale"):
                 shadow("p_%s_w1" % br, d.z, d.hid, "gen_net_global.%s.fc1.weight" % br)
@@ -675,7 +675,7 @@ class Workspace(object):
         self.cn = [nb(B, H, f32) for _ in range(Lyr)]
         # q(z|x)
         self.hbar = nb(B, H)
-        self.q_h1 = {br: nb(B, Z) for br in ("location", "scale")}
+        self.q_h1 = {br: nb(B, d.zp) for br in ("location", "scale")}     # (the fused q(z|x) kernel stores whole 128-column tiles: zeros beyond Z)
         self.mu = nb(B, Z, f32, ld=Z)
         self.sigma = nb(B, Z, f32, ld=Z)
         self.z32 = nb(B, Z, f32, ld=Z)
