@@ -3,7 +3,7 @@ import torch
 
 from ..engine import Dims
 from .Models import NMTVIModel
-from .Utils import MODEL_TYPES
+from .Utils import MODEL_TYPES, use_gpu
 
 
 def make_vi_model_mmt(model_opt, fields, gpu, checkpoint=None):
@@ -53,3 +53,21 @@ def make_vi_model_mmt(model_opt, fields, gpu, checkpoint=None):
             del sd[alias]
         model.load_state_dict(sd, strict=True)
     return model
+
+
+def load_test_model(opt, dummy_opt):
+    """onmt/ModelConstructor.py:148-174: checkpoint -> (fields, model in evaluation mode, model options); options the checkpoint's
+    `opt` predates are filled from `dummy_opt` (a dict of defaults, translate_mm_vi.py:55-57)."""
+    from . import io
+    checkpoint = torch.load(opt.model, map_location="cpu", weights_only=False)
+    fields = io.load_fields_from_vocab(checkpoint["vocab"], data_type=getattr(opt, "data_type", "text"))
+    model_opt = checkpoint["opt"]
+    for k, v in dict(dummy_opt).items():
+        if k not in model_opt.__dict__:
+            model_opt.__dict__[k] = v
+    if getattr(opt, "multimodal_model_type", "vi-model1") not in MODEL_TYPES:
+        raise NotImplementedError("only the variational multi-modal models (%s) are on the MI355X path" % ", ".join(MODEL_TYPES))
+    print("Building variational multi-modal model...")
+    model = make_vi_model_mmt(model_opt, fields, use_gpu(opt), checkpoint)
+    model.eval()
+    return fields, model, model_opt

@@ -110,6 +110,16 @@ class VIStatistics(object):
         self.n_updates = 0
         sys.stdout.flush()
 
+    def log(self, prefix, experiment, lr):
+        """scalars to a crayon experiment (`-exp_host`; TrainerMultimodal.py:186-201): anything with add_scalar_value(name, value)"""
+        vals = [("ppl", self.ppl()), ("accuracy", self.accuracy()), ("img-feats-loss", self.image_feats_loss),
+                ("img-feats-cos", self.image_feats_cos), ("img-pixels-loss", self.image_pixels_loss), ("img-pixels-acc", self.img_pixels_acc),
+                ("td-kl-before", self.td_kl_before), ("td-kl-after", self.td_kl_after), ("td-kl", self.td_kl),
+                ("td-kl-multiplier", self.td_kl_multiplier), ("elbo", self.elbo_loss),
+                ("tgtper", self.n_words / (self.elapsed_time() + 1e-5)), ("lr", lr)]
+        for name, v in vals:
+            experiment.add_scalar_value(prefix + "_" + name, float(v))
+
     def save_progress(self, lr, model_updates, epoch, split):
         """The reference appends a dict per update (unbounded, with a device sync each time); here one entry per call
         without forcing a read-back of pending device statistics."""
