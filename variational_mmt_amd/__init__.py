@@ -23,7 +23,7 @@ def install_as_onmt(tables=True, legacy_torch_load=True):
     import sys
     pkg = importlib.import_module("variational_mmt_amd.onmt")
     sys.modules["onmt"] = pkg
-    for sub in ("io", "io.TextDataset", "io.DatasetBase", "Utils", "Loss", "Models", "ModelConstructor", "Optim", "Trainer", "TrainerMultimodal",
+    for sub in ("io", "Utils", "Loss", "Models", "ModelConstructor", "Optim", "Trainer", "TrainerMultimodal",
                 "VILoss", "modules", "modules.Dists", "modules.SRU", "translate", "translate.Beam", "translate.TranslatorMultimodalVI",
                 "h5tables", "bleu", "EarlyStop", "translate.translate_file"):
         sys.modules["onmt." + sub] = importlib.import_module("variational_mmt_amd.onmt." + sub)
@@ -32,7 +32,16 @@ def install_as_onmt(tables=True, legacy_torch_load=True):
         m = sys.modules["onmt." + mod]
         for n in names:
             getattr(m, n).__module__ = "onmt." + mod
+    # module paths that pickles name: the `.train.N.pt` / `.valid.N.pt` files hold an `onmt.io.TextDataset.TextDataset`
+    # (onmt/io/TextDataset.py:16, preprocess.py:97-110) and the driver reads them with a plain torch.load
+    # (train_mm_vi_model1.py:372-376).  Synthetic modules, registered in sys.modules only: as attributes of the package the
+    # names `TextDataset` / `DatasetBase` must stay what `onmt.io` exports (the class)
+    import types
     from .onmt.io import textdata as td
+    m_td, m_base = types.ModuleType("onmt.io.TextDataset"), types.ModuleType("onmt.io.DatasetBase")
+    m_td.TextDataset = m_base.ONMTDatasetBase = td.TextDataset
+    m_base.PAD_WORD, m_base.BOS_WORD, m_base.EOS_WORD, m_base.UNK = td.PAD_WORD, td.BOS_WORD, td.EOS_WORD, 0
+    sys.modules["onmt.io.TextDataset"], sys.modules["onmt.io.DatasetBase"] = m_td, m_base
     td.TextDataset.__module__ = "onmt.io.TextDataset"          # datasets written here unpickle in the reference too
     _torchtext_standin()
     if tables:
