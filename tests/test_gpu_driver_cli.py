@@ -48,6 +48,8 @@ def test_train_resume_finetune_translate(tmp_path):
     cks = sorted(glob.glob(os.path.join(tmp, "m_acc_*_e*.pt")))
     assert [c[-6:] for c in cks] == ["_e1.pt", "_e2.pt"] or len(cks) == 2
     e1 = [c for c in cks if c.endswith("_e1.pt")][0]
+    import variational_mmt_amd
+    variational_mmt_amd.install_as_onmt()          # the checkpoint pickles `onmt.Optim.Optim` and torchtext's Vocab
     ck = torch.load(e1, map_location="cpu", weights_only=False)
     assert sorted(ck) == ["epoch", "generator", "model", "opt", "optim", "vocab"] and ck["epoch"] == 1 and ck["opt"].rnn_size == 32
     # ---- continue the run: options + optimiser (its learning rate, its decay state) come from the checkpoint

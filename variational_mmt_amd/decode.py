@@ -103,12 +103,12 @@ def _encode(eng, src, src_len, bos):
     """encoder + latent mean + z W_z^T: the evaluation-mode forward plan on a dummy 2-token target (its decoder step is ignored)"""
     d, dev = eng.d, eng.dev
     B = int(src.shape[1])
-    dummy = torch.tensor([[bos] * B, [3] * B], dtype=torch.int64)
+    dummy = torch.tensor([[bos] * B, [3] * B], dtype=torch.int64, device="cpu")
     tab = getattr(eng, "img_table", None)
     if tab is None:
         tab = torch.zeros(1, d.img, dtype=torch.float32, device=dev)        # the image row only feeds the training loss
-    return eng.forward(src, src_len, dummy, torch.zeros(B, dtype=torch.int64), training=False, table=tab,
-                       tgt_len=torch.full((B,), 2, dtype=torch.int64) if d.conditional else None)
+    return eng.forward(src, src_len, dummy, torch.zeros(B, dtype=torch.int64, device="cpu"), training=False, table=tab,
+                       tgt_len=torch.full((B,), 2, dtype=torch.int64, device="cpu") if d.conditional else None)
 
 
 def greedy_decode(eng, src, src_len, max_len=50, bos=2):

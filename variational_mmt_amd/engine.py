@@ -246,14 +246,14 @@ class Engine(object):
         self.flat_m = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
         self.params, self.grads = {}, {}
-        g = torch.Generator().manual_seed(seed)
+        g = torch.Generator(device="cpu").manual_seed(seed)       # (explicit devices: a driver may have made CUDA the default tensor type)
         for n, (o, shp) in self.offsets.items():
             k = int(math.prod(shp))
             self.params[n] = self.flat_p[o:o + k].view(*shp)
             if o < self.n_opt:
                 self.grads[n] = self.flat_g[o:o + k].view(*shp)
             if param_init:                             # ModelConstructor.py:598-603 (H7: every parameter)
-                self.params[n].copy_(((torch.rand(*shp, generator=g) * 2 - 1) * param_init))
+                self.params[n].copy_(((torch.rand(*shp, generator=g, device="cpu") * 2 - 1) * param_init))
 
     def pp(self, name, r=0, c=0):
         o, shp = self.offsets[name]

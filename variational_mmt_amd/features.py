@@ -44,7 +44,7 @@ def load_image_table(path, node="global_feats", device="cuda", mean_path=None, s
         rows = max(1, min(N, slab_bytes // max(1, D * 4)))
         native = arr.dtype.newbyteorder("=")
         direct = native == np.dtype(np.float32)
-        stage = [torch.empty((rows, D), dtype=torch.float32).pin_memory() for _ in range(2 if N > rows else 1)]
+        stage = [torch.empty((rows, D), dtype=torch.float32, device="cpu").pin_memory() for _ in range(2 if N > rows else 1)]
         done = [None] * len(stage)
         copy_stream = torch.cuda.Stream(device=dev)
         for i, r0 in enumerate(range(0, N, rows)):

@@ -38,7 +38,7 @@ class _ArenaAdam(object):
                 continue                      # parameters that never received a gradient have no Adam state (H6)
             off, shp = e.offsets[name]
             n = p.numel()
-            state[i] = {"step": torch.tensor(float(e.step_count)),
+            state[i] = {"step": torch.tensor(float(e.step_count), device="cpu"),
                         "exp_avg": e.flat_m[off:off + n].view(*shp).detach().cpu().clone(),
                         "exp_avg_sq": e.flat_v[off:off + n].view(*shp).detach().cpu().clone()}
         groups = [dict(self.param_groups[0], params=list(range(len(o.params))))]
@@ -189,7 +189,7 @@ class Optim(object):
                     continue                  # never received a gradient: torch.optim.Adam holds no state for it (H6)
                 off, shp = e.offsets[name]
                 n = p.numel()
-                adam.state[q] = {"step": torch.tensor(float(e.step_count)),
+                adam.state[q] = {"step": torch.tensor(float(e.step_count), device="cpu"),
                                  "exp_avg": e.flat_m[off:off + n].view(*shp).detach().cpu().clone(),
                                  "exp_avg_sq": e.flat_v[off:off + n].view(*shp).detach().cpu().clone()}
         d["params"] = cpu_params

@@ -82,10 +82,10 @@ class Field(object):
         lengths = None
         if self.include_lengths:
             arr, lengths = arr
-            lengths = torch.tensor(lengths, dtype=torch.int64)
+            lengths = torch.tensor(lengths, dtype=torch.int64, device="cpu")
         if self.use_vocab:
             arr = [[self.vocab.stoi[w] for w in ex] for ex in arr] if self.sequential else [self.vocab.stoi[x] for x in arr]
-        t = torch.tensor(arr, dtype=torch.int64)
+        t = torch.tensor(arr, dtype=torch.int64, device="cpu")
         if self.sequential:
             t = t.t().contiguous()                      # [len, batch]
         if device is not None and device != -1:

@@ -29,10 +29,10 @@ class GNMTGlobalScorer(object):
 class Beam(object):
     def __init__(self, size, pad, bos, eos, n_best=1, cuda=False, global_scorer=None, min_length=0):
         self.size = size
-        self.scores = torch.zeros(size)
+        self.scores = torch.zeros(size, device="cpu")
         self.all_scores = []
         self.prev_ks = []
-        self.next_ys = [torch.full((size,), pad, dtype=torch.int64)]
+        self.next_ys = [torch.full((size,), pad, dtype=torch.int64, device="cpu")]
         self.next_ys[0][0] = bos
         self._eos = eos
         self.eos_top = False

@@ -32,10 +32,10 @@ def translate_file(model, fields, src_path, out_path, batch_size=64, beam_size=1
         for i in range(0, len(order), batch_size):
             grp = order[i:i + batch_size]
             S = len(ids[grp[0]])
-            src = torch.full((S, len(grp)), 1, dtype=torch.int64)
+            src = torch.full((S, len(grp)), 1, dtype=torch.int64, device="cpu")
             for j, k in enumerate(grp):
-                src[:len(ids[k]), j] = torch.tensor(ids[k], dtype=torch.int64)
-            lens = torch.tensor([len(ids[k]) for k in grp], dtype=torch.int64)
+                src[:len(ids[k]), j] = torch.tensor(ids[k], dtype=torch.int64, device="cpu")
+            lens = torch.tensor([len(ids[k]) for k in grp], dtype=torch.int64, device="cpu")
             ret = tr.translate_batch(types.SimpleNamespace(src=(src, lens), batch_size=len(grp)))
             for j, k in enumerate(grp):
                 toks = ret["predictions"][j][0]
