@@ -59,17 +59,27 @@ def flops_per_triplet(d, S, Tp):
     return dict(enc=enc, dec=dec, att=att, gen=gen, qnet=qn, img=im, total=enc + dec + att + gen + qn + im)
 
 
-def make_batches(d, B, S, T, n_img, n_batches, device, seed):
+def make_batches(d, B, S, T, n_img, n_batches, device, seed, ragged=False):
+    """seeded synthetic batches: src ids U[2, V), tgt ids U[4, V) with <s> first and </s> last, <blank> = 1
+    beyond a sentence's length; lengths all S / T ("Multi30k-shaped, fixed"), or with `ragged` U[S/2, S] sorted by decreasing source
+    length as the reference's iterator delivers them (tensor shapes = the longest sentence of the batch)"""
     g = torch.Generator().manual_seed(seed)
     out = []
     for _ in range(n_batches):
-        src = torch.randint(2, d.vs, (S, B), generator=g)
-        tgt = torch.randint(4, d.vt, (T, B), generator=g)
+        if ragged:
+            sl = torch.sort(torch.randint(S // 2, S + 1, (B,), generator=g), descending=True).values
+            tl = torch.randint((T - 1) // 2, T, (B,), generator=g) + 1              # incl. <s> and </s>
+            S_, T_ = int(sl.max()), int(tl.max())
+        else:
+            sl, tl, S_, T_ = torch.full((B,), S, dtype=torch.int64), torch.full((B,), T, dtype=torch.int64), S, T
+        src = torch.randint(2, d.vs, (S_, B), generator=g)
+        tgt = torch.randint(4, d.vt, (T_, B), generator=g)
+        src[torch.arange(S_).unsqueeze(1) >= sl.unsqueeze(0)] = 1
         tgt[0] = 2
-        tgt[T - 1] = 3
-        sl = torch.full((B,), S, dtype=torch.int64)
+        tgt[tl - 1, torch.arange(B)] = 3
+        tgt[torch.arange(T_).unsqueeze(1) >= tl.unsqueeze(0)] = 1
         idx = torch.randint(0, n_img, (B,), generator=g)
-        out.append(tuple(x.to(device) for x in (src, sl, tgt, idx)))
+        out.append(tuple(x.to(device) for x in (src, sl, tgt, idx, tl)))
     return out
 
 
@@ -101,7 +111,8 @@ def host_cpu():
 
 def _cpu_run(threads, seconds_budget, max_steps):
     """full training steps (forward + loss + backward + clip + Adam, dropout masks included) of the CPU oracle with torch's
-    fused LSTM (oracle/fast_cpu.py = the reference's own CPU kernel choice) at BASELINE config 1: batch 40"""
+    fused LSTM (oracle/fast_cpu.py = the reference's own CPU kernel choice) at BASELINE config 1: batch 40.
+    -> (triplets/s, timed steps, seconds, [fwd, loss+bwd, optim] seconds per step)"""
     from oracle import fast_cpu as F
     from oracle import vi1_oracle as O
     c = O.Cfg(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.5)
@@ -112,36 +123,128 @@ def _cpu_run(threads, seconds_budget, max_steps):
     img = bt["table"][bt["indices"]]
     g = torch.Generator().manual_seed(3)
     state, steps, t0 = {}, 0, None
+    phase = [0.0, 0.0, 0.0]
+    first = None
     while True:
         masks = {"dec_out": (torch.rand(T - 1, B, c.hid, generator=g) >= 0.5).float() * 2.0}
         if steps == 1:
             t0 = time.perf_counter()          # first step = warm-up
-        r, Lo, gr = F.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], masks=masks)
-        p, _ = O.clip_and_adam(p, gr, state)
+            phase = [0.0, 0.0, 0.0]
+        ta = time.perf_counter()
+        pp = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+        r = O.forward(pp, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], True, masks, False, lstm_layer=F.lstm_layer)
+        tb = time.perf_counter()
+        Lo = O.loss(pp, c, r, bt["tgt"], img)
+        (Lo["loss"] / float(B)).backward()
+        gr = {k: v.grad.detach() for k, v in pp.items() if v.grad is not None}
+        tc = time.perf_counter()
+        p, _ = F.clip_and_adam(p, gr, state)          # in place, torch.optim.Adam's operation order (the reference's optimiser)
+        td = time.perf_counter()
+        phase[0] += tb - ta
+        phase[1] += tc - tb
+        phase[2] += td - tc
         steps += 1
+        if steps == 1:
+            first = td - ta
+            if first > seconds_budget:        # a thread count at which ONE step already exceeds the budget: report that step
+                return B / first, 1, first, [tb - ta, tc - tb, td - tc]
         if t0 is not None and (time.perf_counter() - t0 > seconds_budget or steps > max_steps):
             break
     dt = time.perf_counter() - t0
-    return B * (steps - 1) / dt, steps - 1, dt
+    n = steps - 1
+    return B * n / dt, n, dt, [x / n for x in phase]
 
 
-def cpu_baseline(seconds_budget=12.0):
+def cpu_baseline(seconds_budget=10.0):
     """The CPU oracle (oracle/vi1_oracle.py, validated against the real reference; LSTM through torch's fused CPU kernel like
-    the reference) timed on this host at two thread counts: 8 (the core count the reference itself was timed on at survey time,
-    BASELINE.md) and 32 (near the best this small-matrix workload reaches: torch's intra-op pool does not scale beyond that --
-    256 threads took 150 s/step on the MI355X host).  `value` / `cores` = the faster of the two."""
+    the reference) timed on this host at 8 threads (the core count the reference itself was timed on at survey time),
+    32 threads, and ALL physical cores (torch's intra-op pool does not scale on these small matrices: the run
+    is bounded to one step when a step takes longer than the budget).  `value` = the fastest run, `cores` = the threads it used;
+    every run with its forward / loss+backward / optimiser split is listed in `runs`."""
     model, phys, logical = host_cpu()
     runs = {}
-    for th in sorted({min(8, logical), min(32, logical)}):
-        v, n, dt = _cpu_run(th, seconds_budget, 40)
-        runs[th] = (v, n, dt)
-    best = max(runs, key=lambda k: runs[k][0])
-    v, n, dt = runs[best]
-    return dict(value=round(v, 2), unit="triplets/sec", cores=best, kind="port",
+    counts = sorted({min(8, logical), min(32, logical), min(phys or logical, logical)})
+    for th in counts:
+        v, n, dt, ph = _cpu_run(th, seconds_budget if th <= 32 else 6.0, 40)
+        runs[th] = dict(triplets_per_sec=round(v, 2), steps=n, seconds=round(dt, 2), fwd_s=round(ph[0], 4), loss_bwd_s=round(ph[1], 4),
+                        optim_s=round(ph[2], 4))
+    best = max(runs, key=lambda k: runs[k]["triplets_per_sec"])
+    b = runs[best]
+    return dict(value=b["triplets_per_sec"], unit="triplets/sec", cores=best, kind="port",
                 host_cpu=model, host_physical_cores=phys, host_logical_cpus=logical,
-                by_threads={str(k): round(runs[k][0], 2) for k in sorted(runs)},
+                by_threads={str(k): runs[k]["triplets_per_sec"] for k in sorted(runs)}, runs={str(k): runs[k] for k in sorted(runs)},
                 sample="%d full training steps of the CPU oracle (torch CPU fp32, fused ATen LSTM, %d threads) at batch 40, src/tgt "
-                       "len 20, V=30000, 1-layer biLSTM 512, z 256 (BASELINE config 1), %.1f s" % (n, best, dt))
+                       "len 20, V=30000, 1-layer biLSTM 512, z 256 (BASELINE config 1), %.1f s; per step: forward %.3f s, loss + backward "
+                       "%.3f s, clip + Adam %.3f s" % (b["steps"], best, b["seconds"], b["fwd_s"], b["loss_bwd_s"], b["optim_s"]))
+
+
+def through_trainer(a, dev, rank, world):
+    """`--through-trainer`: the drop-in surface end to end.  A synthetic dataset of 29 000 triplets (Multi30k's size; source /
+    target lengths U[10, 20], word ids Zipf-distributed over 30 k-word vocabularies) is walked by onmt.io.OrderedIterator (pools of 100
+    batches sorted by length, shuffled batches: host numericalisation + H2D of the ids every step) and trained by
+    onmt.TrainerMultimodal.train (ModelConstructor / VILoss / Optim mirrors) for two epochs; the SECOND epoch is timed (the first one
+    builds the launch plans of every shape bucket).  Reports triplets/s over the epoch, the share of the wall clock the host needed to
+    enqueue it, and the number of workspace shape buckets."""
+    import random
+    import types
+    import variational_mmt_amd
+    onmt = variational_mmt_amd.install_as_onmt()
+    from variational_mmt_amd.onmt.io import textdata as td
+    cf = CONFIGS[a.config]
+    V, N, B = cf["vs"], 29000, a.batch
+    rng = random.Random(1234)
+    itos_s = ["<unk>", "<blank>"] + ["s%d" % i for i in range(V - 2)]
+    itos_t = ["<unk>", "<blank>", "<s>", "</s>"] + ["t%d" % i for i in range(V - 4)]
+    fields = td.get_fields()
+    fields["src"].vocab, fields["tgt"].vocab = td.Vocab(itos_s), td.Vocab(itos_t)
+    # Zipf-ish ranks: id = floor(V ** u), u ~ U[0, 1): log-uniform over the vocabulary
+    def words(itos, lo, n):
+        return tuple(itos[min(len(itos) - 1, lo + int((len(itos) - lo) ** rng.random()) - 1)] for _ in range(n))
+    examples = []
+    for i in range(N):
+        ex = td.Example()
+        ex.src, ex.tgt, ex.indices = words(itos_s, 2, rng.randint(10, 20)), words(itos_t, 4, rng.randint(10, 20)), i
+        examples.append(ex)
+    ds = td.TextDataset(examples, fields)
+    opt = types.SimpleNamespace(model_type="text", multimodal_model_type="vi-model1", path_to_train_img_feats="resnet50.hdf5",
+                                src_word_vec_size=cf["emb"], tgt_word_vec_size=cf["emb"], rnn_size=cf["hid"], z_latent_dim=cf["z"],
+                                enc_layers=cf["layers"], dec_layers=cf["layers"], encoder_type="brnn" if cf["brnn"] else "rnn",
+                                brnn=cf["brnn"], dropout=a.dropout, param_init=0.1, gpuid=[dev.index], seed=1, compute_dtype=a.dtype,
+                                conditional=a.conditional, rnn_type="LSTM", global_attention="general")
+    model = onmt.ModelConstructor.make_vi_model_mmt(opt, fields, True, None)
+    loss = onmt.VILoss.NMTVIModel1LossCompute(model.generator, fields["tgt"].vocab)
+    optim = onmt.Optim("adam", 0.002, 5.0, lr_decay=0.5, start_decay_at=8)
+    optim.set_parameters(model.parameters())
+    gt = torch.Generator().manual_seed(11)
+    feats = torch.rand(N, cf["img"], generator=gt).to(dev)
+    trainer = onmt.TrainerMultimodal(model, loss, loss, optim, 0, 32, "text", "sents", 1, train_img_feats=feats, valid_img_feats=feats[:64],
+                                     multimodal_model_type="vi-model1")
+    def epoch(n):
+        it = onmt.io.OrderedIterator(dataset=ds, batch_size=B, device=dev, sort=False, train=True, sort_within_batch=True, repeat=False,
+                                     dp_rank=rank, dp_world=world) if world > 1 else \
+            onmt.io.OrderedIterator(dataset=ds, batch_size=B, device=dev, sort=False, train=True, sort_within_batch=True, repeat=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = trainer.train(it, n, None)
+        t_host = time.perf_counter() - t0          # everything enqueued (trainer.train ends with one check of the async error words)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, t_host, st
+    epoch(1)
+    eng = model.engine
+    buckets = sum(1 for k in eng.ws if isinstance(k, tuple) and len(k) == 3)
+    dt, t_host, st = epoch(2)
+    steps = (N + B * world - 1) // (B * world)
+    if rank == 0:
+        out = {"metric": "triplets/sec", "value": round(N / dt, 1), "unit": "triplets/sec", "n_gpus": world, "steps": steps, "warmup": steps,
+               "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": a.dtype,
+               "data": "synthetic",
+               "config": {"workload": "through onmt.TrainerMultimodal.train + onmt.io.OrderedIterator: one epoch over 29000 synthetic triplets, "
+                                      "lengths U[10,20], Zipf word ids, " + (cf["name"] % B) + ", dropout %.1f, Adam" % a.dropout,
+                          "global_batch": B * world, "parallelism": "dp%d" % world},
+               "host_enqueue_share": round(t_host / dt, 3), "shape_buckets": buckets, "workspace_evictions": eng.ws_evictions,
+               "workspace_gb": round(eng.workspace_bytes() / 2 ** 30, 2),
+               "train_ppl": round(st.ppl(), 2), "elbo_per_sentence": round(st.elbo_loss / N, 3)}
+        print(json.dumps(out), flush=True)
 
 
 def _free_port():
@@ -187,6 +290,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-stream", action="store_true", help="profiling aid: issue the whole step on one stream")
     ap.add_argument("--conditional", action="store_true", help="the --conditional prior variant (SURVEY.md 8f-1) instead of the fixed prior")
+    ap.add_argument("--lengths", default="fixed", choices=["fixed", "ragged"], help="sentence lengths: all 20 (the headline shape) or U[10, 20] "
+                    "sorted by source length (BASELINE.md section 3)")
+    ap.add_argument("--through-trainer", action="store_true", help="time onmt.TrainerMultimodal.train over an OrderedIterator on a synthetic "
+                    "29 K-triplet dataset (the drop-in surface: host numericalisation, H2D of ids, ragged lengths, shape buckets) instead of "
+                    "the engine-level step")
     ap.add_argument("--selftest-launch", action="store_true", help="CPU check of the N-rank launch path: gloo ranks, one all-reduce, no GPU")
     a = ap.parse_args()
 
@@ -226,6 +334,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if a.through_trainer:
+        return through_trainer(a, dev, rank, world)
     from variational_mmt_amd.engine import Dims, Engine
     cf = CONFIGS[a.config]
     d = Dims(vs=cf["vs"], vt=cf["vt"], emb=cf["emb"], hid=cf["hid"], z=cf["z"], img=cf["img"], layers=cf["layers"], brnn=cf["brnn"],
@@ -242,14 +352,13 @@ def main():
     n_img = cf["n_img"]
     gt = torch.Generator().manual_seed(11)
     eng.set_image_table(torch.rand(n_img, d.img, generator=gt))
-    batches = make_batches(d, B, S, T, n_img, 8, dev, 1234 + rank)
+    batches = make_batches(d, B, S, T, n_img, 8, dev, 1234 + rank, ragged=a.lengths == "ragged")
     Bg = B * world
-    tlen = torch.full((B,), T, dtype=torch.int64, device=dev)
     from variational_mmt_amd.dp import GradSync
     sync = GradSync(eng)          # attaches itself to the engine when torch.distributed runs with > 1 rank
 
     def step(i):
-        src, sl, tgt, idx = batches[i % len(batches)]
+        src, sl, tgt, idx, tlen = batches[i % len(batches)]
         ws = eng.forward(src, sl, tgt, idx, training=True, tgt_len=tlen if a.conditional else None)
         eng.loss_backward(ws, normalization=Bg, batch_global=Bg)
         sync.all_reduce()          # waits for the segment all-reduces the backward plan issued behind each segment
@@ -257,7 +366,7 @@ def main():
         return ws
 
     # ---- dominant-kernel timing hooks: events on the launch stream around the generator kernels -----------------
-    ws0 = eng.workspace(B, S, Tp)
+    ws0 = eng.workspace(B, S, Tp)        # (ragged lengths: the hooks sit on the full-length bucket only; other buckets run unhooked)
     dom = {"gen_fwd": [], "gen_bwd": []}
 
     def wrap(plan, index, key):
@@ -326,23 +435,32 @@ def main():
         t_b = sum(s.elapsed_time(e_) for s, e_ in dom["gen_bwd"]) / max(1, a.steps)
         t_dom = max(t_f, t_b)
         ach = gen_flop / (t_dom * 1e-3) / 1e12 if t_dom > 0 else 0.0
-        traffic = None      # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json).  The entry names the
+        # kernel source it was measured on (sha256 of the .hip file); if that file has changed since, the figure is withheld
+        traffic, traffic_note = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["config%s" % a.config]
-            if B == 256 and a.dtype == "bf16" and not a.conditional:
-                traffic = tj["read_bytes"] + tj["write_bytes"]
-        except Exception:
-            traffic = None
+            if B == 256 and a.dtype == "bf16" and not a.conditional and a.lengths == "fixed":
+                import hashlib
+                src_file = os.path.join(ROOT, tj["kernel_source"])
+                sha = hashlib.sha256(open(src_file, "rb").read()).hexdigest()[:16]
+                if sha == tj["kernel_source_sha16"]:
+                    traffic = tj["read_bytes"] + tj["write_bytes"]
+                else:
+                    traffic_note = "profiles/traffic.json is stale: %s changed since the PMC pass (%s != %s)" % (tj["kernel_source"], sha, tj["kernel_source_sha16"])
+        except Exception as ex:
+            traffic_note = "no PMC figure for this configuration (%s)" % type(ex).__name__
         out = {
             "metric": "triplets/sec", "value": round(value, 1), "unit": "triplets/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": (cf["name"] % B) + ", dropout %.1f, Adam%s" % (a.dropout, ", --conditional prior" if a.conditional else ""),
+            "config": {"workload": (cf["name"] % B) + ", dropout %.1f, Adam%s%s" % (a.dropout, ", --conditional prior" if a.conditional else "",
+                                                                                    ", lengths U[10,20]" if a.lengths == "ragged" else ""),
                        "global_batch": Bg, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": ("gen2_kernel (fused vocabulary sweep: logits + softmax statistics + dO, softmax weights stored for the dWg GEMM)" if fused else
                                     "gen_kernel (vocab projection + log-softmax/NLL pass, slower of fwd/bwd)"),
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "ms_fwd": round(t_f, 4), "ms_bwd": round(t_b, 4),
                          "step_tflops": round(3 * fl["total"] * Bg / (dt / a.steps) / 1e12, 2)},
             "elbo_per_sentence": round(st["elbo"] / B, 4),

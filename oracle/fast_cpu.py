@@ -28,3 +28,28 @@ def lstm_layer(x, mask, lengths, dirs, h0s, c0s):
 
 def step_grads(*a, **k):
     return O.step_grads(*a, lstm_layer=lstm_layer, **k)
+
+
+def clip_and_adam(p, grads, state, lr=0.002, max_grad_norm=5.0, b1=0.9, b2=0.999, eps=1e-9):
+    """onmt/Optim.py:94-96 the way the reference's torch executes it: `clip_grad_norm` (one fp32 norm per tensor, scaled in place) then
+    torch.optim.Adam's in-place update (exp_avg.mul_().add_(), exp_avg_sq.mul_().addcmul_(), p.addcdiv_()).  Same arithmetic as
+    vi1_oracle.clip_and_adam (checked in tests/test_oracle_fast_cpu.py), without its out-of-place 60 M-element temporaries and fp64 norm:
+    this is the optimiser leg of the timed CPU baseline.  Updates `p` IN PLACE and returns (p, total norm)."""
+    import math
+    tot = math.sqrt(sum(float(torch.linalg.vector_norm(g)) ** 2 for g in grads.values()))
+    coef = max_grad_norm / (tot + 1e-6)
+    state["step"] = state.get("step", 0) + 1
+    t = state["step"]
+    m, v = state.setdefault("m", {}), state.setdefault("v", {})
+    bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+    with torch.no_grad():
+        for k, g in grads.items():
+            if coef < 1:
+                g = g.mul_(coef)
+            if k not in m:
+                m[k], v[k] = torch.zeros_like(p[k]), torch.zeros_like(p[k])
+            m[k].mul_(b1).add_(g, alpha=1 - b1)
+            v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+            p[k].addcdiv_(m[k], denom, value=-lr / bc1)
+    return p, tot

@@ -39,7 +39,7 @@ def run(e, n):
 
 def run_(e, n):
     for i in range(n):
-        src, sl, tgt, idx = bs[i % 4]
+        src, sl, tgt, idx, _tl = bs[i % 4]
         ws = e.forward(src, sl, tgt, idx, training=True, tgt_len=TLEN if COND else None)
         e.loss_backward(ws, normalization=256, batch_global=256)
         e.optim_step()
