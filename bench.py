@@ -184,7 +184,8 @@ def through_trainer(a, dev, rank, world):
     batches sorted by length, shuffled batches: host numericalisation + H2D of the ids every step) and trained by
     onmt.TrainerMultimodal.train (ModelConstructor / VILoss / Optim mirrors) for two epochs; the SECOND epoch is timed (the first one
     builds the launch plans of every shape bucket).  Reports triplets/s over the epoch, the share of the wall clock the host needed to
-    enqueue it, and the number of workspace shape buckets."""
+    prepare and enqueue it (loop time minus the time the loader spent waiting for the device to catch up: < 1 means the GPU is the
+    bottleneck), and the number of workspace shape buckets."""
     import random
     import types
     import variational_mmt_amd
@@ -203,7 +204,8 @@ def through_trainer(a, dev, rank, world):
     examples = []
     for i in range(N):
         ex = td.Example()
-        ex.src, ex.tgt, ex.indices = words(itos_s, 2, rng.randint(10, 20)), words(itos_t, 4, rng.randint(10, 20)), i
+        # source 10..20 words; target 8..18 words + <s> + </s> = 10..20 positions: the lengths of `--lengths ragged` (make_batches)
+        ex.src, ex.tgt, ex.indices = words(itos_s, 2, rng.randint(10, 20)), words(itos_t, 4, rng.randint(8, 18)), i
         examples.append(ex)
     ds = td.TextDataset(examples, fields)
     opt = types.SimpleNamespace(model_type="text", multimodal_model_type="vi-model1", path_to_train_img_feats="resnet50.hdf5",
@@ -224,13 +226,21 @@ def through_trainer(a, dev, rank, world):
                                      dp_rank=rank, dp_world=world) if world > 1 else \
             onmt.io.OrderedIterator(dataset=ds, batch_size=B, device=dev, sort=False, train=True, sort_within_batch=True, repeat=False)
         torch.cuda.synchronize()
+        mark = {}
+        real_check = eng.check_async_errors
+        eng.check_async_errors = lambda: (mark.setdefault("t", time.perf_counter()), real_check())[1]    # (it synchronises: note when the loop got there)
+        stg = td._staging.get(str(dev))
+        w0 = stg.waited if stg is not None else 0.0
         t0 = time.perf_counter()
         st = trainer.train(it, n, None)
-        t_host = time.perf_counter() - t0          # everything enqueued (trainer.train ends with one check of the async error words)
+        eng.check_async_errors = real_check
+        t_host = mark.get("t", time.perf_counter()) - t0          # every step enqueued ...
+        stg = td._staging.get(str(dev))
+        t_host -= (stg.waited - w0) if stg is not None else 0.0   # ... minus the time the loader waited for the device to catch up
         torch.cuda.synchronize()
         return time.perf_counter() - t0, t_host, st
-    epoch(1)
     eng = model.engine
+    epoch(1)
     buckets = sum(1 for k in eng.ws if isinstance(k, tuple) and len(k) == 3)
     dt, t_host, st = epoch(2)
     steps = (N + B * world - 1) // (B * world)
@@ -241,7 +251,7 @@ def through_trainer(a, dev, rank, world):
                "config": {"workload": "through onmt.TrainerMultimodal.train + onmt.io.OrderedIterator: one epoch over 29000 synthetic triplets, "
                                       "lengths U[10,20], Zipf word ids, " + (cf["name"] % B) + ", dropout %.1f, Adam" % a.dropout,
                           "global_batch": B * world, "parallelism": "dp%d" % world},
-               "host_enqueue_share": round(t_host / dt, 3), "shape_buckets": buckets, "workspace_evictions": eng.ws_evictions,
+               "host_busy_share": round(t_host / dt, 3), "shape_buckets": buckets, "workspace_evictions": eng.ws_evictions,
                "workspace_gb": round(eng.workspace_bytes() / 2 ** 30, 2),
                "train_ppl": round(st.ppl(), 2), "elbo_per_sentence": round(st.elbo_loss / N, 3)}
         print(json.dumps(out), flush=True)

@@ -89,3 +89,32 @@ def test_model_takes_a_feature_file_path():
     assert abs(stats[0]["img_feats_loss"] - stats[1]["img_feats_loss"]) <= 1e-6 * abs(stats[0]["img_feats_loss"])
     r, Lo, _g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], torch.from_numpy(table)[bt["indices"]], bt["eps"])
     assert abs(stats[1]["elbo"] - float(Lo["elbo"])) / abs(float(Lo["elbo"])) < 2e-5
+
+
+def test_prefetching_iterator_delivers_the_same_batches():
+    """onmt.io.OrderedIterator with its background prefetch thread (host-to-device copies on a stream of their own) against the same
+    iterator building every batch in the consumer's thread: same order, same tensors, on the device"""
+    import random
+
+    from variational_mmt_amd.onmt import io as oio
+    D = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textdata")
+    ds = oio.load_dataset(os.path.join(D, "demo.train.1.pt"))
+    fields = oio.load_fields_from_vocab(oio.load_vocab(os.path.join(D, "demo.vocab.pt")))
+    ds.fields = dict((k, f) for k, f in fields.items() if k in ds.examples[0].__dict__)
+    got = {}
+    for pf in (0, 3):
+        random.seed(11)
+        it = oio.OrderedIterator(dataset=ds, batch_size=5, device="cuda", sort=False, train=True, sort_within_batch=True, repeat=False,
+                                 prefetch=pf)
+        assert it.prefetch == pf
+        got[pf] = [(b.src[0].clone(), b.src[1].clone(), b.tgt[0].clone(), b.tgt[1].clone(), b.indices.clone()) for b in it]
+        torch.cuda.synchronize()
+    assert len(got[0]) == len(got[3]) == (len(ds) + 4) // 5
+    for a, b in zip(got[0], got[3]):
+        for x, y in zip(a, b):
+            assert x.is_cuda and torch.equal(x, y)
+    # an abandoned epoch does not leave the producer thread blocked
+    it = oio.OrderedIterator(dataset=ds, batch_size=5, device="cuda", sort=False, train=True, sort_within_batch=True, repeat=False, prefetch=2)
+    g = iter(it)
+    next(g)
+    g.close()

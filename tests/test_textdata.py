@@ -180,3 +180,27 @@ def test_evaluation_iterator_replays_the_reference_contract():
         s.sort(key=ds.sort_key, reverse=True)
         want.append([e.indices for e in s])
     assert got == want
+
+
+def test_fast_batch_equals_field_by_field():
+    """Batch builds its tensors from cached word ids with vectorised padding (one staging buffer, one copy); the result must be what
+    Field.pad + Field.numericalize give field by field, for every batch of a training and of a validation epoch"""
+    from variational_mmt_amd.onmt.io import textdata as td
+    for split, train in (("train", True), ("valid", False)):
+        ds, _ = _load(split)
+        random.seed(5)
+        it = oio.OrderedIterator(dataset=ds, batch_size=7, device=None, sort=False, train=train, sort_within_batch=True, repeat=False)
+        it.create_batches()
+        n = 0
+        for mb in it.batches:
+            mb = sorted(mb, key=ds.sort_key, reverse=True)
+            fast = td.Batch(mb, ds, None, train)
+            slow = td.Batch()
+            slow.dataset, slow.train = ds, train
+            slow.slow(mb, None)
+            for name in ("src", "tgt"):
+                assert torch.equal(getattr(fast, name)[0], getattr(slow, name)[0]) and torch.equal(getattr(fast, name)[1], getattr(slow, name)[1])
+                assert getattr(fast, name)[0].is_contiguous() and getattr(fast, name)[0].dtype == torch.int64
+            assert torch.equal(fast.indices, slow.indices)
+            n += 1
+        assert n == (len(ds) + 6) // 7

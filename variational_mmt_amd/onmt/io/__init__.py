@@ -19,6 +19,8 @@ def make_features(batch, side, data_type="text"):
     keys = sorted(k for k in batch.__dict__ if (side + "_feat_") in k)
     levels = [data] + [batch.__dict__[k] for k in keys]
     if data_type == "text":
+        if len(levels) == 1:                     # no word features: a view, not a device copy
+            return levels[0].unsqueeze(2)
         return torch.cat([lv.unsqueeze(2) for lv in levels], 2)
     return levels[0]
 
