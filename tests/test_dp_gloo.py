@@ -135,3 +135,61 @@ def test_sharded_iterator_partitions_every_global_minibatch():
             seen += b.indices.tolist()
     assert len(seen) == len(set(seen))                           # disjoint
     assert len(ds) - len(seen) < world                           # at most world-1 examples (a tail minibatch) are skipped
+
+
+def _worker_shards(rank, world, port, out):
+    """dp.GradSync's sharded-optimiser collectives on plain tensors: ownership arithmetic, reduce-scatter (own shard = the sum),
+    all-gather (every shard back on every rank), for segments that split evenly and for one with an uneven tail"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from variational_mmt_amd.dp import GradSync
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sync = GradSync(flat=torch.zeros(1), sharded=True)
+    assert sync.world == world and sync.sharded
+    segs = [(0, 512 * 3), (512 * 3, 512 * 3 + 512 * 40), (512 * 43, 512 * 43 + 64 * 13)]      # the last one: 13 units over `world` ranks
+    n = segs[-1][1]
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.rand(n, generator=g)
+    everyone = [torch.rand(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    want = torch.stack(everyone).sum(0)
+    flat = mine.clone()
+    ok = True
+    covered = torch.zeros(n, dtype=torch.int64)
+    for lo, hi in segs:
+        # ownership: the ranks' shards tile the segment exactly once, whole 64-element units
+        for r in range(world):
+            a, b = GradSync.shard(type("R", (), dict(world=world, rank=r))(), lo, hi)
+            assert lo <= a <= b <= hi and (a - lo) % 64 == 0 and ((b - lo) % 64 == 0 or b == hi)
+            if rank == 0:
+                covered[a:b] += 1
+        sync.reduce_scatter(flat, lo, hi).wait()
+        a, b = sync.shard(lo, hi)
+        ok = ok and bool(torch.allclose(flat[a:b], want[a:b], rtol=1e-6, atol=0))
+    if rank == 0:
+        assert (covered == 1).all()
+    # "Adam" on the own shards: an element-wise function of the reduced gradient, then the parameters travel back
+    p = torch.zeros(n)
+    for lo, hi in segs:
+        a, b = sync.shard(lo, hi)
+        p[a:b] = flat[a:b] * 0.5 + 1.0
+    for lo, hi in segs:
+        sync.all_gather(p, lo, hi).wait()
+    ok = ok and bool(torch.allclose(p, want * 0.5 + 1.0, rtol=1e-6, atol=0))
+    rows = sync.all_gather_rows(torch.tensor([float(rank), 2.0 * rank]))
+    ok = ok and rows.shape == (world, 2) and rows[:, 0].tolist() == [float(r) for r in range(world)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (ok, p.double().sum().item()))
+    if rank == 0:
+        torch.save({"ok": all(x[0] for x in gathered), "same": len({x[1] for x in gathered}) == 1}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimiser_collectives(tmp_path, world):
+    out = str(tmp_path / "res.pt")
+    port = 27000 + (os.getpid() % 2000) + world
+    mp.spawn(_worker_shards, args=(world, port, out), nprocs=world, join=True)
+    r = torch.load(out)
+    assert r["ok"] and r["same"], r

@@ -121,3 +121,58 @@ def test_two_ranks_freebits_clip_and_replica_identity(tmp_path):
         assert x["q_grad_zero"] == x["q_want_zero"], (tag, x)
         assert x["same"], (tag, x)
     assert r["kl_below_margin"]["q_grad_zero"] and not r["kl_above_margin"]["q_grad_zero"]
+
+
+def _worker_sharded(rank, world, port, out):
+    """the sharded optimiser (reduce-scatter -> clip + Adam on the own 1 / world of every arena segment -> all-gather of the
+    parameters) against the replicated one (all-reduce -> Adam everywhere): three updates each, with clipping active; parameters must
+    agree BIT FOR BIT (the reduced gradient of an element is the same sum either way, the update is element-wise, and both norms are
+    deterministic reductions that every rank evaluates identically ... up to the norm's own summation order, hence a second run with
+    clipping off for the bitwise claim), replicas identical, moments complete after gather_moments()"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import vi1_oracle as O
+    from variational_mmt_amd.dp import GradSync
+    from variational_mmt_amd.engine import Dims, Engine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = O.Cfg(vs=41, vt=43, emb=16, hid=32, z=8, img=2048, layers=2, brnn=False)
+    p = O.init_params(c, seed=6)
+    Bg = 10
+    bt = O.synth_batch(c, Bg, 6, 7, n_img=16, seed=8, fixed_len=False)
+    sl = slice(rank * Bg // world, (rank + 1) * Bg // world)
+    res = {}
+    for clip in (0.0, 0.05):
+        runs = {}
+        for sharded in (False, True):
+            e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda:0")
+            e.load_state_dict(p)
+            e.set_image_table(bt["table"])
+            sync = GradSync(e, sharded=sharded)
+            assert e.dp is sync and sync.sharded == sharded
+            assert all((hi - lo) % 512 == 0 for lo, hi in e.segments[:-1]) and e.segments[-1][1] == e.n_opt
+            for _ in range(3):
+                ws = e.forward(bt["src"][:, sl], bt["src_len"][sl], bt["tgt"][:, sl], bt["indices"][sl], training=True, eps=bt["eps"][sl])
+                e.loss_backward(ws, normalization=Bg, batch_global=Bg)
+                sync.all_reduce()
+                e.optim_step(lr=0.01, max_grad_norm=clip)
+            torch.cuda.synchronize()
+            same = sync.replicas_identical()
+            sync.gather_moments()
+            torch.cuda.synchronize()
+            runs[sharded] = (e.flat_p.cpu().clone(), e.flat_m[:e.n_opt].cpu().clone(), e.flat_v[:e.n_opt].cpu().clone(), same)
+        (p0, m0, v0, s0), (p1, m1, v1, s1) = runs[False], runs[True]
+        res[clip] = dict(replicas=bool(s0 and s1), p_equal=bool(torch.equal(p0, p1)), m_equal=bool(torch.equal(m0, m1)),
+                         v_equal=bool(torch.equal(v0, v1)), p_err=float((p0 - p1).abs().max()), m_err=float((m0 - m1).abs().max()))
+    if rank == 0:
+        torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_sharded_optimiser_equals_replicated(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 21000 + (os.getpid() % 2000)
+    mp.spawn(_worker_sharded, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r[0.0]["replicas"] and r[0.0]["p_equal"] and r[0.0]["m_equal"] and r[0.0]["v_equal"], r       # no clipping: bit for bit
+    assert r[0.05]["replicas"] and r[0.05]["p_err"] <= 1e-6 and r[0.05]["m_err"] <= 1e-6, r                 # clipping: the norm's summation order differs

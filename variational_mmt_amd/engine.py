@@ -99,6 +99,7 @@ class Dims(object):
 
 
 KPAD = 64          # GEMM reduction slab (elements)
+SEG_ALIGN = 512    # arena segments start on multiples of this many elements (8 ranks x 64-element units)
 
 
 class Buf(object):
@@ -233,13 +234,24 @@ class Engine(object):
         self.names_nograd = [n for n, _ in ng]
         off = 0
         self.offsets = {}
+        self.first_enc_name = "encoder.rnn.weight_ih_l%d" % (self.d.layers - 1)     # arena: [generator|attn|decoder|dec emb][encoder|enc emb|inference nets]
+        # the four data-parallel SEGMENTS of the arena, in the order backward completes them (_plan_backward issues one collective per
+        # segment): [generator][attention + decoder + target embeddings][encoder + source embeddings (+ conditional networks)]
+        # [inference networks].  A segment starts on a multiple of SEG_ALIGN elements, so that it splits into 1 / 2 / 4 / 8 equal
+        # rank shards of whole 64-element units (reduce-scatter + sharded Adam + all-gather: optim_step); the padding holds zeros
+        seg_starts = ("generator.0.weight", "decoder.attn.linear_out.weight", self.first_enc_name, "inf_net_image.location.fc2.weight")
+        self.seg_bounds = []
         for n, shp in wg + ng:
+            if n in seg_starts or n == ng[0][0]:
+                off = _ru(off, SEG_ALIGN)
+                self.seg_bounds.append(off)
             if n == ng[0][0]:
                 self.n_opt = off                       # optimiser / all-reduce range = [0, n_opt)
             self.offsets[n] = (off, shp)
             off += _ru(int(math.prod(shp)), 64)
         self.n_total = off
-        self.first_enc_name = "encoder.rnn.weight_ih_l%d" % (self.d.layers - 1)     # arena: [generator|attn|decoder|dec emb][encoder|enc emb|inference nets]
+        assert len(self.seg_bounds) == 5 and self.seg_bounds[-1] == self.n_opt
+        self.segments = list(zip(self.seg_bounds[:-1], self.seg_bounds[1:]))
         dev = self.dev
         self.flat_p = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
@@ -553,6 +565,8 @@ class Engine(object):
         fn, args, name, _keep, sid = entry
         if fn is None:
             if name == "SUMSQ":
+                if self.dp is not None and self.dp.world > 1 and self.dp.sharded:
+                    return          # sharded optimiser: every rank takes the norm of ITS shards in optim_step
                 lo, hi, slot = args
                 if self._works:
                     with torch.cuda.stream(ts[sid]):
@@ -573,7 +587,10 @@ class Engine(object):
                 if self.dp is not None and self.dp.world > 1:
                     lo, hi = args
                     with torch.cuda.stream(ts[sid]):
-                        self._works.append(self.dp.dist.all_reduce(self.flat_g[lo:hi], async_op=True))
+                        if self.dp.sharded:     # each rank receives the sum of ITS 1/world of the segment (in place)
+                            self._works.append(self.dp.reduce_scatter(self.flat_g, lo, hi))
+                        else:
+                            self._works.append(self.dp.dist.all_reduce(self.flat_g[lo:hi], async_op=True))
                 return
             if single_stream:
                 return
@@ -1805,6 +1822,8 @@ def _engine_methods():
         phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights."""
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
+        if self.dp is not None and self.dp.world > 1 and self.dp.sharded:
+            return self._optim_step_sharded(lr, max_grad_norm, beta1, beta2, eps, grad_scale)
         if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
             self._sumsq[:L.SUMSQ_SLOTS].zero_()
             L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), 0, st), "vmmt_sumsq")
@@ -1853,6 +1872,60 @@ def _engine_methods():
             adam(0, self.n_opt, st)
             self._pack_part(2, st)
             self._pack_part(3, st)
+        self.shadows_dirty = False
+
+    def _optim_step_sharded(self, lr, max_grad_norm, beta1, beta2, eps, grad_scale):
+        """Data-parallel optimiser step with the state sharded over the ranks (dp.GradSync.sharded).  The backward plan has
+        reduce-scattered every arena segment, so this rank holds the SUM of the gradients for its 1 / world of each segment
+        (dp.shard).  Here: squared norm of the own shards (the deterministic reduction of vmmt_sumsq, one slot per segment) ->
+        all-gather of the ranks' slot totals, added in rank order: every rank computes the same clip coefficient bit for bit ->
+        clip + Adam on the own shards only (28 B/param of HBM traffic over 1 / world of the arena) -> all-gather of the updated
+        parameters, segment by segment: [encoder | inference networks] in the foreground (the next forward starts with them),
+        [generator | attention + decoder] on the side stream underneath the next step's encoder -> shadow refresh.
+        The Adam moments of the other ranks' shards are not maintained here (dp.GradSync.gather_moments collects them for a
+        checkpoint).  Same parameters, bit for bit, as the replicated path: the reduced gradient of an element is the same sum
+        wherever it is formed, and the update is element-wise."""
+        dp = self.dp
+        main = torch.cuda.current_stream(self.dev)
+        st = main.cuda_stream
+        self.finish_allreduce()                           # the reduce-scatters of the backward plan
+        self._sumsq_by_plan = False
+        self.step_count += 1
+        segs = self.segments
+        own = [dp.shard(lo, hi) for lo, hi in segs]
+        if max_grad_norm:
+            self._sumsq[:L.SUMSQ_SLOTS].zero_()
+            for i, (a, b) in enumerate(own):
+                if b > a:
+                    L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * a, b - a, self._sumsq.data_ptr(), i, st), "vmmt_sumsq")
+            tot = dp.all_gather_rows(self._sumsq[:L.SUMSQ_SLOTS])           # [world][SLOTS]
+            self._sumsq[:L.SUMSQ_SLOTS].zero_()
+            self._sumsq[0:1].copy_(tot.sum(dim=1).sum(dim=0, keepdim=True))  # fixed order: slots of a rank, then the ranks
+
+        def adam(a, b, stream):
+            if b > a:
+                L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * a, self.flat_g.data_ptr() + 4 * a, self.flat_m.data_ptr() + 4 * a,
+                                                self.flat_v.data_ptr() + 4 * a, b - a, lr, beta1, beta2, eps, self.step_count,
+                                                float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, 0, None, stream),
+                        "vmmt_adam_step")
+        fg, bg = (2, 3), (0, 1)                           # foreground: encoder + inference networks; background: generator, decoder
+        for i in fg:
+            adam(own[i][0], own[i][1], st)
+        for i in fg:
+            dp.all_gather(self.flat_p, *segs[i]).wait()
+        self._pack_part(0, st)
+        ev = self.global_events.setdefault("adam_main_done", torch.cuda.Event())
+        ev.record(main)
+        side = self.side_stream if (self.use_side_stream and self.split_optim) else main
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            for i in bg:
+                adam(own[i][0], own[i][1], side.cuda_stream)
+            for i in bg:
+                dp.all_gather(self.flat_p, *segs[i]).wait()
+            self._pack_part(1, side.cuda_stream)
+        if side is not main:
+            self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
         self.shadows_dirty = False
 
     for k, v in list(locals().items()):

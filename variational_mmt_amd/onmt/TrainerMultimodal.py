@@ -271,6 +271,7 @@ class TrainerMultimodal(object):
         epoch / optim; parameter names per SURVEY.md Appendix B."""
         assert checkpoint_type in ("last", "best")
         self.model.engine.check_async_errors()         # never write parameters that a timed-out device hand-off may have corrupted
+        self.dp.gather_moments()                       # sharded data-parallel optimiser: collect Adam's moments from their owners
         sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
         model_sd = {k: v for k, v in sd.items() if "generator" not in k}
         gen_sd = {k[len("generator."):]: v for k, v in sd.items() if k.startswith("generator.")}
