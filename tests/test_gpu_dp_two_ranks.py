@@ -28,7 +28,7 @@ def _worker(rank, world, port, out):
     e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda:0")
     e.load_state_dict(p)
     e.set_image_table(bt["table"])
-    sync = GradSync(e)
+    sync = GradSync(e, sharded=False)          # the replicated path: every rank ends with the whole reduced gradient (compared below)
     assert sync.world == world and e.dp is sync
     ws = e.forward(bt["src"][:, sl], bt["src_len"][sl], bt["tgt"][:, sl], bt["indices"][sl], training=True, eps=bt["eps"][sl])
     e.loss_backward(ws, normalization=Bg, batch_global=Bg)
@@ -81,7 +81,7 @@ def _worker_freebits(rank, world, port, out):
         rng0 = e.rng_counter
         e.load_state_dict(p)
         e.set_image_table(bt["table"])
-        sync = GradSync(e)
+        sync = GradSync(e, sharded=False)
         assert e.rng_counter - rng0 == rank * (1 << 40)          # every replica draws its own eps / dropout stream
         ws = e.forward(bt["src"][:, sl], bt["src_len"][sl], bt["tgt"][:, sl], bt["indices"][sl], training=True, eps=bt["eps"][sl])
         e.loss_backward(ws, normalization=Bg, batch_global=Bg, use_freebits=True, margin=margin)
@@ -126,9 +126,8 @@ def test_two_ranks_freebits_clip_and_replica_identity(tmp_path):
 def _worker_sharded(rank, world, port, out):
     """the sharded optimiser (reduce-scatter -> clip + Adam on the own 1 / world of every arena segment -> all-gather of the
     parameters) against the replicated one (all-reduce -> Adam everywhere): three updates each, with clipping active; parameters must
-    agree BIT FOR BIT (the reduced gradient of an element is the same sum either way, the update is element-wise, and both norms are
-    deterministic reductions that every rank evaluates identically ... up to the norm's own summation order, hence a second run with
-    clipping off for the bitwise claim), replicas identical, moments complete after gather_moments()"""
+    agree (the reduced gradient of an element is the same sum either way and the update is element-wise; the norm is summed in another
+    order), the replicas of a run stay bit-identical, and the moments are complete after gather_moments()"""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -174,5 +173,7 @@ def test_sharded_optimiser_equals_replicated(tmp_path):
     port = 21000 + (os.getpid() % 2000)
     mp.spawn(_worker_sharded, args=(2, port, out), nprocs=2, join=True)
     r = torch.load(out)
-    assert r[0.0]["replicas"] and r[0.0]["p_equal"] and r[0.0]["m_equal"] and r[0.0]["v_equal"], r       # no clipping: bit for bit
-    assert r[0.05]["replicas"] and r[0.05]["p_err"] <= 1e-6 and r[0.05]["m_err"] <= 1e-6, r                 # clipping: the norm's summation order differs
+    # two separate runs of the step differ in the last bits on their own (split-K weight-gradient products add with float atomics), so
+    # the two optimiser paths are compared at fp32 rounding level; WITHIN a run the replicas are bit-identical
+    for clip in (0.0, 0.05):
+        assert r[clip]["replicas"] and r[clip]["p_err"] <= 2e-6 and r[clip]["m_err"] <= 1e-7, (clip, r)

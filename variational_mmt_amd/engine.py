@@ -1883,8 +1883,9 @@ def _engine_methods():
         parameters, segment by segment: [encoder | inference networks] in the foreground (the next forward starts with them),
         [generator | attention + decoder] on the side stream underneath the next step's encoder -> shadow refresh.
         The Adam moments of the other ranks' shards are not maintained here (dp.GradSync.gather_moments collects them for a
-        checkpoint).  Same parameters, bit for bit, as the replicated path: the reduced gradient of an element is the same sum
-        wherever it is formed, and the update is element-wise."""
+        checkpoint).  Same update as the replicated path: the reduced gradient of an element is the same sum wherever it is
+        formed and the update is element-wise (only the norm is added up in another order); the replicas stay bit-identical
+        (tests/test_gpu_dp_two_ranks.py)."""
         dp = self.dp
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
