@@ -61,6 +61,18 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
   }
 }
 
+// ONE Adam element update, shared by the dense kernel and the row-wise (lazy) kernels below.  Floating-point contraction is switched
+// off: the row-wise kernels replay steps whose gradient is zero, and their results must be the bits the dense kernel would have
+// produced for g = 0 whatever the compiler would like to fuse in either place.
+#pragma clang fp contract(off)
+__device__ __forceinline__ void adam_elem(float& p, float ge, float& m, float& v, float step_size, float b1, float b2, float eps,
+                                          float inv_sqrt_bc2) {
+  m = b1 * m + (1.f - b1) * ge;
+  v = b2 * v + (1.f - b2) * ge * ge;
+  p -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+}
+#pragma clang fp contract(fast)
+
 // `shadow` (optional): bf16 compute copy of this parameter range with the SAME flat layout (a 2-D weight whose shadow rows are not padded):
 // written here, so that the shadow refresh does not have to read the 15 M-element generator weight back
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -90,10 +102,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 #endif
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float ge = gg[e] * coef;
-        mm[e] = b1 * mm[e] + (1.f - b1) * ge;
-        vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
-        pp[e] -= step_size * mm[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps);
+        float pe = pp[e], me = mm[e], ve = vv[e];
+        adam_elem(pe, gg[e] * coef, me, ve, step_size, b1, b2, eps, inv_sqrt_bc2);
+        pp[e] = pe; mm[e] = me; vv[e] = ve;
       }
 #ifndef VMMT_EXP_ADAMT
       __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(p + i));
@@ -111,10 +122,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
       }
     } else {
       for (long k = i; k < n; ++k) {
-        float ge = g[k] * coef;
-        float mk = b1 * m[k] + (1.f - b1) * ge, vk = b2 * v[k] + (1.f - b2) * ge * ge;
+        float mk = m[k], vk = v[k], pk = p[k];
+        adam_elem(pk, g[k] * coef, mk, vk, step_size, b1, b2, eps, inv_sqrt_bc2);
         m[k] = mk; v[k] = vk;
-        const float pk = p[k] - step_size * mk / (sqrtf(vk) * inv_sqrt_bc2 + eps);
         p[k] = pk;
         if (shadow) shadow[k] = f2bf(pk);
       }
@@ -122,7 +132,160 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Row-wise (lazy) Adam for embedding tables.  An embedding table [R][C] receives gradient in the rows of the current batch only
+// (<= 5120 of 30 000 at the benchmark shape); for every other row dense Adam still runs m *= b1, v *= b2, p -= step(m, v) -- 28 B per
+// element of pure streaming.  Here a row's state is brought up to date only when the row is USED: `last[r]` = the optimiser step
+// row r is current for, `hist[2 s], hist[2 s + 1]` = (lr / (1 - b1^s), 1 / sqrt(1 - b2^s)) of step s.  Before a batch gathers rows,
+// vmmt_adam_rows_catchup replays the zero-gradient steps last[r] + 1 .. t for its (flagged) rows; the optimiser step then updates
+// the flagged rows with their gradient.  Every replayed step is the dense kernel's arithmetic with g = 0 (adam_elem), in the same
+// order, so parameters and moments are bit-identical to the dense path.  One wave per row.
+__global__ void rows_mark_kernel(const long long* __restrict__ ids, long n, int* __restrict__ flags, int R) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long id = ids[i];
+  if (id >= 0 && id < R) flags[id] = 1;
+}
+
+template <bool STEP>
+__global__ void __launch_bounds__(256) adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                        int R, int C, int* __restrict__ flags, int* __restrict__ last, float* __restrict__ hist,
+                                                        float b1, float b2, float eps, int upto, int zero_g, float step_size, float inv_sqrt_bc2,
+                                                        float max_norm, const float* __restrict__ sumsq, float grad_scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (STEP && blockIdx.x == 0 && threadIdx.x == 0) { hist[2 * upto] = step_size; hist[2 * upto + 1] = inv_sqrt_bc2; }
+  if (row >= R) return;
+  if (flags && !flags[row]) return;
+  const int l = last[row];
+  // STEP: zero-gradient steps l + 1 .. upto - 1, then step `upto` with the gradient; otherwise zero-gradient steps l + 1 .. upto
+  const int zend = STEP ? upto - 1 : upto;
+  float coef = grad_scale;
+  if (STEP && max_norm > 0.f) {
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < VMMT_SUMSQ_SLOTS; ++k) ss += sumsq[k];
+    const float c = max_norm / (sqrtf(ss) * grad_scale + 1e-6f);
+    if (c < 1.f) coef *= c;
+  }
+  const long base = (long)row * C;
+  const bool work = STEP || l < upto;
+  for (int c0 = lane * 4; c0 < C; c0 += 256) {
+    const int n = C - c0 < 4 ? C - c0 : 4;
+    float pp[4], mm[4], vv[4], gg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (work) {
+      if (n == 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + base + c0), b = *reinterpret_cast<const f32x4*>(m + base + c0),
+                    c = *reinterpret_cast<const f32x4*>(v + base + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pp[e] = a[e]; mm[e] = b[e]; vv[e] = c[e]; }
+        if (STEP) { const f32x4 d = *reinterpret_cast<const f32x4*>(g + base + c0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gg[e] = d[e]; }
+      } else {
+        for (int e = 0; e < n; ++e) { pp[e] = p[base + c0 + e]; mm[e] = m[base + c0 + e]; vv[e] = v[base + c0 + e]; if (STEP) gg[e] = g[base + c0 + e]; }
+      }
+      for (int s = l + 1; s <= zend; ++s) {
+        const float ss = hist[2 * s], ib = hist[2 * s + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) adam_elem(pp[e], 0.f, mm[e], vv[e], ss, b1, b2, eps, ib);
+      }
+      if (STEP) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) adam_elem(pp[e], gg[e] * coef, mm[e], vv[e], step_size, b1, b2, eps, inv_sqrt_bc2);
+      }
+      if (n == 4) {
+        *reinterpret_cast<f32x4*>(p + base + c0) = f32x4{pp[0], pp[1], pp[2], pp[3]};
+        *reinterpret_cast<f32x4*>(m + base + c0) = f32x4{mm[0], mm[1], mm[2], mm[3]};
+        *reinterpret_cast<f32x4*>(v + base + c0) = f32x4{vv[0], vv[1], vv[2], vv[3]};
+      } else {
+        for (int e = 0; e < n; ++e) { p[base + c0 + e] = pp[e]; m[base + c0 + e] = mm[e]; v[base + c0 + e] = vv[e]; }
+      }
+    }
+    if (!STEP && zero_g) {
+      if (n == 4) *reinterpret_cast<f32x4*>(g + base + c0) = f32x4{0.f, 0.f, 0.f, 0.f};
+      else for (int e = 0; e < n; ++e) g[base + c0 + e] = 0.f;
+    }
+  }
+  if (lane == 0) {
+    if (work) last[row] = upto;
+    if (STEP && flags) flags[row] = 0;
+  }
+}
+
+// ||g||^2 over the flagged rows (the other rows hold zeros): per-row sums by one wave each, then ONE workgroup adds the R row sums in a
+// fixed order into the slot total: deterministic, like sumsq_kernel
+__global__ void __launch_bounds__(256) rows_sumsq_kernel(const float* __restrict__ g, int R, int C, const int* __restrict__ flags,
+                                                         float* __restrict__ rowsq) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float a = 0.f;
+  if (flags[row]) {
+    const float* x = g + (long)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+      if (c + 4 <= C) { const f32x4 q = *reinterpret_cast<const f32x4*>(x + c); a += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]; }
+      else for (int e = c; e < C; ++e) a += x[e] * x[e];
+    }
+    a = wave_sum(a);
+  }
+  if (lane == 0) rowsq[row] = a;
+}
+__global__ void __launch_bounds__(1024) rows_sumsq_total_kernel(const float* __restrict__ rowsq, int R, float* __restrict__ total) {
+  float a = 0.f;
+  for (int r = threadIdx.x; r < R; r += 1024) a += rowsq[r];
+  a = wave_sum(a);
+  __shared__ float red[16];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += red[k];
+    *total = t;
+  }
+}
+
 }  // namespace vmmt
+
+extern "C" int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, void* stream) {
+  using namespace vmmt;
+  if (!ids || !flags || n < 0 || R <= 0) return VMMT_EINVAL;
+  if (n == 0) return VMMT_OK;
+  hipLaunchKernelGGL(rows_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, (long)n, flags, R);
+  return check_launch();
+}
+
+static bool rows_ok(const void* p, const void* g, const void* m, const void* v, int R, int C) {
+  return p && m && v && R > 0 && C > 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0 && (C % 4 == 0 || C < 4 || true);
+}
+
+extern "C" int vmmt_adam_rows_catchup(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last,
+                                      const float* hist, float beta1, float beta2, float eps, int upto, int zero_g, void* stream) {
+  using namespace vmmt;
+  if (!rows_ok(p, g, m, v, R, C) || !last || !hist || upto < 0 || (zero_g && !g) || (C % 4 != 0)) return VMMT_EINVAL;
+  hipLaunchKernelGGL(adam_rows_kernel<false>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, R, C,
+                     const_cast<int*>(flags), last, const_cast<float*>(hist), beta1, beta2, eps, upto, zero_g, 0.f, 0.f, 0.f, (const float*)nullptr, 1.f);
+  return check_launch();
+}
+
+extern "C" int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, int32_t* last, float* hist,
+                                   float lr, float beta1, float beta2, float eps, int step, float max_norm, const float* sumsq,
+                                   float grad_scale, void* stream) {
+  using namespace vmmt;
+  if (!rows_ok(p, g, m, v, R, C) || !g || !flags || !last || !hist || step < 1 || (max_norm > 0.f && !sumsq) || (C % 4 != 0)) return VMMT_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));        // as vmmt_adam_step
+  hipLaunchKernelGGL(adam_rows_kernel<true>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), m, v, R, C,
+                     flags, last, hist, beta1, beta2, eps, step, 0, step_size, inv_sqrt_bc2, max_norm, sumsq, grad_scale);
+  return check_launch();
+}
+
+extern "C" int vmmt_sumsq_rows(const float* g, int R, int C, const int32_t* flags, float* rowsq, float* scratch, int slot, void* stream) {
+  using namespace vmmt;
+  if (!g || !flags || !rowsq || !scratch || R <= 0 || C <= 0 || slot < 0 || slot >= VMMT_SUMSQ_SLOTS || (((uintptr_t)g) & 15) || C % 4 != 0)
+    return VMMT_EINVAL;
+  hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, R, C, flags, rowsq);
+  hipLaunchKernelGGL(rows_sumsq_total_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rowsq, R, scratch + slot);
+  return check_launch();
+}
 
 extern "C" int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, void* stream) {
   using namespace vmmt;

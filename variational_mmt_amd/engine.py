@@ -133,6 +133,30 @@ class Buf(object):
         return self.t[:self.rows, :self.cols]
 
 
+class _ParamDict(dict):
+    """name -> view of the parameter arena.  Reading an embedding table through it first brings the rows the lazy optimiser has not
+    touched lately up to date (Engine.flush_lazy_rows); views obtained EARLIER (e.g. the nn.Parameters of the onmt mirror) see such rows
+    only after a flush -- state_dict(), checkpoints and decoding flush by themselves."""
+
+    def __init__(self, engine):
+        super(_ParamDict, self).__init__()
+        self._engine = engine
+
+    def __getitem__(self, k):
+        e = self._engine
+        if e._lazy_dirty and k in e._lazy_names:
+            e.flush_lazy_rows()
+        return dict.__getitem__(self, k)
+
+    def items(self):
+        self._engine.flush_lazy_rows()
+        return dict.items(self)
+
+    def values(self):
+        self._engine.flush_lazy_rows()
+        return dict.values(self)
+
+
 class Engine(object):
     def __init__(self, dims, dtype="bf16", device="cuda", seed=0, param_init=0.1, batch_global=None):
         self.d = dims
@@ -140,10 +164,12 @@ class Engine(object):
         if self.dev.type != "cuda":
             raise RuntimeError("variational_mmt_amd needs a GPU (MI355X); there is no CPU path")
         self.lib = L.lib()
+        self._lazy_dirty, self._lazy_names, self.lazy_tables = False, (), []
         self.dt = L.BF16 if dtype in ("bf16", torch.bfloat16) else L.F32
         self.T = torch.bfloat16 if self.dt == L.BF16 else torch.float32
         self.tsz = 2 if self.dt == L.BF16 else 4
         self._build_arena(seed, param_init)
+        self._build_lazy()
         self._build_shadows()
         # per-shape workspaces: a bounded LRU (real data has hundreds of (S, T') pairs per epoch).  Shapes are rounded up to
         # `shape_bucket` positions (pad positions are masked everywhere), the largest buffer (G^T) is shared between all
@@ -257,7 +283,7 @@ class Engine(object):
         self.flat_g = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
-        self.params, self.grads = {}, {}
+        self.params, self.grads = _ParamDict(self), {}
         g = torch.Generator(device="cpu").manual_seed(seed)       # (explicit devices: a driver may have made CUDA the default tensor type)
         for n, (o, shp) in self.offsets.items():
             k = int(math.prod(shp))
@@ -266,6 +292,72 @@ class Engine(object):
                 self.grads[n] = self.flat_g[o:o + k].view(*shp)
             if param_init:                             # ModelConstructor.py:598-603 (H7: every parameter)
                 self.params[n].copy_(((torch.rand(*shp, generator=g, device="cpu") * 2 - 1) * param_init))
+
+    # ------------------------------------------------------------------------------------------------ lazy embedding rows
+    def _build_lazy(self):
+        """Row-wise (lazy) Adam for the two embedding tables (csrc/optim.hip: vmmt_adam_rows_*).  The tables are 54 % of the optimised
+        parameters and a step's gradient lives in the <= S B + T' B rows the batch looked up (17 % of 30 000 at the benchmark shape):
+        dense Adam streams 28 B for every element of the other 83 % just to decay their moments.  Lazily, a row's (p, m, v) are
+        brought up to date when a batch is about to gather it (forward plan: mark + catch-up in front of the gather) and updated with
+        its gradient by the optimiser step; gradient zeroing and the norm walk the flagged rows only.  Bit-identical to the dense
+        update (tests/test_gpu_lazy_adam.py).  Off under data parallelism (the flagged set would have to be the union over the
+        ranks) and for the conditional model (two streams gather from the shared target table)."""
+        names = ("encoder.embeddings.make_embedding.emb_luts.0.weight", "decoder.embeddings.make_embedding.emb_luts.0.weight")
+        self.lazy_rows = _os_env.get("VMMT_LAZY_EMB_ADAM", "1") == "1" and not self.d.conditional
+        self.lazy_tables = []
+        if not self.lazy_rows:
+            return
+        for n in names:
+            off, (R, Cc) = self.offsets[n]
+            if Cc % 4 or off % 4:
+                self.lazy_rows, self.lazy_tables = False, []
+                return
+            self.lazy_tables.append(dict(name=n, off=off, R=R, C=Cc, end=off + R * Cc,
+                                         flags=torch.zeros(R, dtype=torch.int32, device=self.dev),
+                                         last=torch.zeros(R, dtype=torch.int32, device=self.dev),
+                                         rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev)))
+        self._lazy_names = names
+        self.lazy_hist = torch.zeros(2 * (1 << 16), dtype=torch.float32, device=self.dev)      # (lr / bc1, 1 / sqrt(bc2)) per step; grows
+        self.adam_betas_eps = (0.9, 0.999, 1e-9)                                               # of the last optim_step (replays use them)
+
+    def lazy_active(self):
+        return bool(self.lazy_tables) and self.lazy_rows and not (self.dp is not None and self.dp.world > 1)
+
+    def _lazy_table_ptrs(self, t):
+        o = 4 * t["off"]
+        return (self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o, self.flat_v.data_ptr() + o)
+
+    def flush_lazy_rows(self, stream=None):
+        """bring EVERY row of the embedding tables up to the current optimiser step (before parameters or moments are read as a
+        whole: state_dict, checkpoints, decoding, a switch to the dense / data-parallel optimiser)"""
+        if not self._lazy_dirty:
+            return
+        st = stream if stream is not None else self.stream()
+        b1, b2, eps = self.adam_betas_eps
+        for t in self.lazy_tables:
+            pp_, gg_, mm_, vv_ = self._lazy_table_ptrs(t)
+            L.check(self.lib.vmmt_adam_rows_catchup(pp_, gg_, mm_, vv_, t["R"], t["C"], None, t["last"].data_ptr(), self.lazy_hist.data_ptr(),
+                                                    b1, b2, eps, self.step_count, 0, st), "vmmt_adam_rows_catchup")
+        self._lazy_dirty = False
+
+    def reset_lazy_rows(self):
+        """every row is current for step `step_count` (after parameters / moments were loaded or the optimiser was re-created)"""
+        for t in self.lazy_tables:
+            t["last"].fill_(int(self.step_count))
+            t["flags"].zero_()
+        self._lazy_dirty = False
+
+    def _lazy_forward_entries(self, plan, table_index, ids_ptr, n_ids, zero_g):
+        """plan entries in front of a gather from an embedding table: flag the batch's rows, replay their missed zero-gradient steps
+        (and clear their gradient rows when a backward pass will follow).  The step to catch up to is patched in per run."""
+        if not self.lazy_active():
+            return
+        t = self.lazy_tables[table_index]
+        self._call(plan, self.lib.vmmt_rows_mark, ids_ptr, n_ids, t["flags"].data_ptr(), t["R"])
+        pp_, gg_, mm_, vv_ = self._lazy_table_ptrs(t)
+        plan.append((self.lib.vmmt_adam_rows_catchup, (pp_, gg_, mm_, vv_, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(),
+                                                        self.lazy_hist.data_ptr(), 0.9, 0.999, 1e-9, 0, 1 if zero_g else 0),
+                     "vmmt_adam_rows_catchup", None, self._sid))
 
     def pp(self, name, r=0, c=0):
         o, shp = self.offsets[name]
@@ -278,13 +370,14 @@ class Engine(object):
         return self.flat_g.data_ptr() + (o + r * ld + c) * 4
 
     def load_state_dict(self, sd):
+        self.flush_lazy_rows()
         for n, t in sd.items():
             if n in self.params:
-                self.params[n].copy_(t.to(torch.float32))
+                dict.__getitem__(self.params, n).copy_(t.to(torch.float32))
         self.shadows_dirty = True
 
     def state_dict(self):
-        sd = {n: v.detach().clone() for n, v in self.params.items()}
+        sd = {n: v.detach().clone() for n, v in self.params.items()}          # (items() flushes the lazily updated rows)
         if self.d.conditional:      # encoder_tgt shares the decoder's table; the reference's state dict lists it under both names
             sd["encoder_tgt.embeddings.make_embedding.emb_luts.0.weight"] = sd["decoder.embeddings.make_embedding.emb_luts.0.weight"]
         return sd
@@ -536,7 +629,19 @@ class Engine(object):
         every range has a slot of its own and Adam adds the slots in index order: the norm is bit-reproducible"""
         lo = self.offsets[first_name][0]
         hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
-        plan.append((None, (lo, min(hi, self.n_opt), slot), "SUMSQ", None, self._sid))
+        hi = min(hi, self.n_opt)
+        if self.lazy_active():
+            # an embedding table inside the range: its flagged rows go to a slot of their own (3 + table index), the dense kernel
+            # takes what lies in front of it (slot) and behind it (slot + 5: only the conditional model has parameters there)
+            for k, t in enumerate(self.lazy_tables):
+                if lo <= t["off"] and t["end"] <= hi:
+                    plan.append((None, (k, 3 + k), "SUMSQ_ROWS", None, self._sid))
+                    if t["off"] > lo:
+                        plan.append((None, (lo, t["off"], slot), "SUMSQ", None, self._sid))
+                    if hi - t["end"] >= SEG_ALIGN:      # (less: only the segment's alignment padding follows)
+                        plan.append((None, (t["end"], hi, slot + 5), "SUMSQ", None, self._sid))
+                    return
+        plan.append((None, (lo, hi, slot), "SUMSQ", None, self._sid))
 
     def finish_allreduce(self):
         """make the current stream wait for every outstanding gradient all-reduce (call before optim_step)"""
@@ -552,8 +657,14 @@ class Engine(object):
         ts = (main, side, aux, tgt)
         hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream, tgt.cuda_stream)
         trace, last = self.trace, None
+        lazy_fn = self.lib.vmmt_adam_rows_catchup if self.lazy_tables else None
         for entry in plan:
             fn, args, name, _keep, sid = entry
+            if fn is lazy_fn and fn is not None:
+                # the optimiser step to catch up to and the optimiser's constants are those of NOW, not of the time the plan was built
+                b1, b2, eps = self.adam_betas_eps
+                entry = (fn, args[:9] + (b1, b2, eps, int(self.step_count)) + args[13:], name, _keep, sid)
+                self._lazy_dirty = True
             if trace is not None and sid == 0 and name != last:     # tools/phase_times.py: timing events at phase changes
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(main)
@@ -575,6 +686,12 @@ class Engine(object):
                     self._works = []
                 L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq")
                 self._sumsq_by_plan = True
+                return
+            if name == "SUMSQ_ROWS":
+                k, slot = args
+                t = self.lazy_tables[k]
+                L.check(self.lib.vmmt_sumsq_rows(self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr(), t["rowsq"].data_ptr(),
+                                                 self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq_rows")
                 return
             if name == "KL_ALLREDUCE":
                 if self.dp is not None and self.dp.world > 1:
@@ -803,7 +920,16 @@ class Workspace(object):
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             # ... together with the small accumulators of the backward plan (off the critical path instead of in front of
             # their users): one launch
-            e._zero(P, [e.flat_g[e.offsets["generator.0.bias"][0]:], e._sumsq[:L.SUMSQ_SLOTS], self.dh1v32.t, self.dzt.t] +
+            if e.lazy_active():        # the tables' gradient rows are cleared row by row (vmmt_adam_rows_catchup, zero_g)
+                g_ranges, lo = [], e.offsets["generator.0.bias"][0]
+                for t in sorted(e.lazy_tables, key=lambda t: t["off"]):
+                    g_ranges.append(e.flat_g[lo:t["off"]])
+                    lo = t["end"]
+                g_ranges.append(e.flat_g[lo:])
+                g_ranges = [r for r in g_ranges if r.numel()]
+            else:
+                g_ranges = [e.flat_g[e.offsets["generator.0.bias"][0]:]]
+            e._zero(P, g_ranges + [e._sumsq[:L.SUMSQ_SLOTS], self.dh1v32.t, self.dzt.t] +
                     ([] if self.gen_fused else [self.dO32.t]) +       # (fused generator: dO is stored, not accumulated)
                     [b.t for l in range(Lyr) for b in (self.dec_dcc[l], self.enc_dcc[l])])
         self._mask_entries = getattr(self, "_mask_entries", {})
@@ -812,6 +938,7 @@ class Workspace(object):
             self._mask_entries["dec_out"] = (len(P), self.out_mask)
             e._call(P, lib.vmmt_dropout_mask, dt, self.out_mask.p(), self.out_mask.rows * self.out_mask.ld, d.dropout, 0)
             e._record(P, "out_mask")
+        e._lazy_forward_entries(P, 1, self.tgt_in.data_ptr(), M, training)
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                 self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
         we = e.sh["dec_wih_l0_e"]
@@ -830,6 +957,7 @@ class Workspace(object):
         e._call(P, lib.vmmt_gather_rows, L.F32, None, D, self.img_idx.data_ptr(), self.img.p(), self.img.ld, B, D)
         e._sid = MAIN
         # a2 source embeddings
+        e._lazy_forward_entries(P, 0, self.src.data_ptr(), MS, training)
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                 self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
         # a3 encoder
@@ -1825,6 +1953,7 @@ def _engine_methods():
         if self.dp is not None and self.dp.world > 1 and self.dp.sharded:
             return self._optim_step_sharded(lr, max_grad_norm, beta1, beta2, eps, grad_scale)
         if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
+            # (a dense pass is right with the lazy optimiser too: the rows it has not flagged hold zeros)
             self._sumsq[:L.SUMSQ_SLOTS].zero_()
             L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), 0, st), "vmmt_sumsq")
         self._sumsq_by_plan = False
@@ -1844,15 +1973,38 @@ def _engine_methods():
                                                 eps, self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
                                                 blocks, shadow, stream), "vmmt_adam_step")
 
+        lazy = self.lazy_active()
+        self.adam_betas_eps = (float(beta1), float(beta2), float(eps))
+        if self.lazy_tables and not lazy:
+            self.flush_lazy_rows(st)              # (the dense update below needs every row current)
+        if lazy and 2 * (self.step_count + 2) > self.lazy_hist.numel():
+            grown = torch.zeros(2 * self.lazy_hist.numel(), dtype=torch.float32, device=self.dev)
+            grown[:self.lazy_hist.numel()].copy_(self.lazy_hist)
+            torch.cuda.synchronize(self.dev)      # plans hold the old pointer: drop them with the workspaces (rare: every 32 K steps)
+            self.drop_workspaces()
+            self.lazy_hist = grown
+
+        def rows_step(t, stream):
+            pp_, gg_, mm_, vv_ = self._lazy_table_ptrs(t)
+            L.check(self.lib.vmmt_adam_rows_step(pp_, gg_, mm_, vv_, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(),
+                                                 self.lazy_hist.data_ptr(), lr, beta1, beta2, eps, self.step_count,
+                                                 float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, stream), "vmmt_adam_rows_step")
+
         def adam(lo, hi, stream):
             # the big unpadded bf16 shadows (generator weight, image network fc2) are written by the update itself: their range is
-            # a launch of its own with the shadow attached, and the shadow refresh behind it skips them (_pack_tables)
+            # a launch of its own with the shadow attached, and the shadow refresh behind it skips them (_pack_tables); the embedding
+            # tables are updated row by row (their flagged rows only) when the lazy optimiser is on
+            pieces = [(s_lo, s_hi, ("shadow", ptr)) for s_lo, s_hi, ptr in self._fused_shadows() if lo <= s_lo and s_hi <= hi]
+            if lazy:
+                pieces += [(t["off"], t["end"], ("rows", t)) for t in self.lazy_tables if lo <= t["off"] and t["end"] <= hi]
             cur = lo
-            for s_lo, s_hi, ptr in self._fused_shadows():
-                if lo <= s_lo and s_hi <= hi:
-                    adam_range(cur, s_lo, stream)
-                    adam_range(s_lo, s_hi, stream, ptr)
-                    cur = s_hi
+            for p_lo, p_hi, (kind, what) in sorted(pieces, key=lambda x: x[0]):
+                adam_range(cur, p_lo, stream)
+                if kind == "shadow":
+                    adam_range(p_lo, p_hi, stream, what)
+                else:
+                    rows_step(what, stream)
+                cur = p_hi
             adam_range(cur, hi, stream)
         if self.use_side_stream and self.split_optim:
             # both halves are HBM-bound: the critical half runs alone at full bandwidth, the other one starts behind it
