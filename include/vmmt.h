@@ -424,6 +424,10 @@ int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
  *     vmmt_adam_step), last[r] = step, flags[r] = 0; records hist[step].
  *   vmmt_sumsq_rows: ||g||^2 over the flagged rows into slot `slot` of the norm scratch (deterministic); rowsq f32 [R] scratch. */
 int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, void* stream);
+/* the embedding lookup of a lazily updated table: out[i] = row ids[i] advanced, in registers only, by the zero-gradient steps it has not
+ * seen (last[r] + 1 .. upto); out T per out_dtype, row stride ldo.  Read-only on p / m / v. */
+int vmmt_gather_rows_lazy(int out_dtype, const float* p, const float* m, const float* v, int C, const int64_t* ids, void* out, int64_t ldo,
+                          int n, const int32_t* last, const float* hist, float beta1, float beta2, float eps, int upto, void* stream);
 int vmmt_adam_rows_catchup(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last, const float* hist,
                            float beta1, float beta2, float eps, int upto, int zero_g, void* stream);
 int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, int32_t* last, float* hist, float lr,

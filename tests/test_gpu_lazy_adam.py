@@ -1,5 +1,5 @@
 """GPU: the row-wise (lazy) Adam of the embedding tables (csrc/optim.hip: vmmt_rows_mark / vmmt_adam_rows_catchup / vmmt_adam_rows_step /
-vmmt_sumsq_rows; engine._build_lazy) against dense Adam.
+vmmt_gather_rows_lazy / vmmt_sumsq_rows; engine._build_lazy) against dense Adam.
 
 Reference: torch.optim.Adam over every element at every step (onmt/Optim.py:68-70,94-96).  A row without gradient still moves under
 dense Adam (its moments decay, the parameter follows them); the lazy path replays exactly those zero-gradient steps when the row is next
@@ -54,6 +54,14 @@ def test_rows_kernels_bit_identical_to_dense_adam():
         assert (grad_l[flags.bool()] == 0).all()
         # rows about to be gathered are current: equal to the dense parameters right now
         assert torch.equal(lazy["p"][rows.to(dev)], dense["p"][rows.to(dev)]), step
+        # ... and the lazy lookup of ANY rows (stale ones included) returns the dense parameters without touching the table
+        probe = torch.randint(0, R, (37,), generator=g).to(dev)
+        outp = torch.zeros(37, Cc, dtype=torch.float32, device=dev)
+        before = lazy["p"].clone()
+        L.check(lib.vmmt_gather_rows_lazy(L.F32, lazy["p"].data_ptr(), lazy["m"].data_ptr(), lazy["v"].data_ptr(), Cc, probe.data_ptr(),
+                                          outp.data_ptr(), Cc, 37, last.data_ptr(), hist.data_ptr(), b1, b2, eps, step - 1, st), "gather_lazy")
+        torch.cuda.synchronize()
+        assert torch.equal(outp, dense["p"][probe]) and torch.equal(before, lazy["p"]), step
         gr = (torch.rand(rows.numel(), Cc, generator=g) - 0.5).to(dev) * (10.0 if step % 5 == 0 else 0.1)
         grad_d.zero_()
         grad_d[rows.to(dev)] = gr
@@ -136,4 +144,4 @@ def test_engine_lazy_rows_equal_dense_over_many_steps(dtype):
     # the lazy engine zeroes / norms / updates only the flagged rows: its plans carry the row-wise entries
     ws = a.workspace(6, 5, 5)
     names = [en[2] for en in ws.plan_fwd_train]
-    assert names.count("vmmt_rows_mark") == 2 and names.count("vmmt_adam_rows_catchup") == 2
+    assert names.count("vmmt_rows_mark") == 2 and names.count("vmmt_gather_rows_lazy") == 2 and names.count("vmmt_gather_rows") == 1

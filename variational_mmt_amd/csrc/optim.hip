@@ -212,6 +212,36 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(float* __restrict__ p, f
   }
 }
 
+// Embedding lookup from a lazily updated table (modules/Embeddings.py:181): out[i][:] = CURRENT value of row ids[i], i.e. the stored
+// row advanced by the zero-gradient steps last[r] + 1 .. upto it has not seen yet -- computed in registers, nothing is written back
+// (read-only: positions that share a row need no coordination; vmmt_adam_rows_step replays the same steps for good at the end of
+// the step).  One wave per position; C <= 1024, C % 4 == 0.
+template <class TO>
+__global__ void __launch_bounds__(256) gather_rows_lazy_kernel(const float* __restrict__ p, const float* __restrict__ m, const float* __restrict__ v,
+                                                               int C, const long long* __restrict__ ids, TO* __restrict__ out, long ldo, int n,
+                                                               const int* __restrict__ last, const float* __restrict__ hist, float b1, float b2,
+                                                               float eps, int upto) {
+  const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pos >= n) return;
+  const long long r = ids[pos];
+  const long base = (long)r * C;
+  const int l = __builtin_amdgcn_readfirstlane(last[r]);
+  TO* dst = out + (long)pos * ldo;
+  for (int c0 = lane * 4; c0 < C; c0 += 256) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p + base + c0);
+    if (l < upto) {
+      f32x4 mm = *reinterpret_cast<const f32x4*>(m + base + c0), vv = *reinterpret_cast<const f32x4*>(v + base + c0);
+      for (int s = l + 1; s <= upto; ++s) {
+        const float ss = hist[2 * s], ib = hist[2 * s + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float pe = a[e], me = mm[e], ve = vv[e]; adam_elem(pe, 0.f, me, ve, ss, b1, b2, eps, ib); a[e] = pe; mm[e] = me; vv[e] = ve; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[c0 + e] = from_f<TO>(a[e]);
+  }
+}
+
 // ||g||^2 over the flagged rows (the other rows hold zeros): per-row sums by one wave each, then ONE workgroup adds the R row sums in a
 // fixed order into the slot total: deterministic, like sumsq_kernel
 __global__ void __launch_bounds__(256) rows_sumsq_kernel(const float* __restrict__ g, int R, int C, const int* __restrict__ flags,
@@ -230,8 +260,12 @@ __global__ void __launch_bounds__(256) rows_sumsq_kernel(const float* __restrict
   if (lane == 0) rowsq[row] = a;
 }
 __global__ void __launch_bounds__(1024) rows_sumsq_total_kernel(const float* __restrict__ rowsq, int R, float* __restrict__ total) {
-  float a = 0.f;
-  for (int r = threadIdx.x; r < R; r += 1024) a += rowsq[r];
+  // a fixed order with independent loads in flight (a chain of 30 dependent loads per thread cost 17 us)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = threadIdx.x;
+  for (; r + 3 * 1024 < R; r += 4 * 1024) { a0 += rowsq[r]; a1 += rowsq[r + 1024]; a2 += rowsq[r + 2048]; a3 += rowsq[r + 3072]; }
+  for (; r < R; r += 1024) a0 += rowsq[r];
+  float a = (a0 + a1) + (a2 + a3);
   a = wave_sum(a);
   __shared__ float red[16];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
@@ -275,6 +309,25 @@ extern "C" int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v,
   const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));        // as vmmt_adam_step
   hipLaunchKernelGGL(adam_rows_kernel<true>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), m, v, R, C,
                      flags, last, hist, beta1, beta2, eps, step, 0, step_size, inv_sqrt_bc2, max_norm, sumsq, grad_scale);
+  return check_launch();
+}
+
+extern "C" int vmmt_gather_rows_lazy(int out_dtype, const float* p, const float* m, const float* v, int C, const int64_t* ids, void* out,
+                                     int64_t ldo, int n, const int32_t* last, const float* hist, float beta1, float beta2, float eps, int upto,
+                                     void* stream) {
+  using namespace vmmt;
+  if (!p || !m || !v || !ids || !out || !last || !hist || n < 0 || C <= 0 || C % 4 != 0 || upto < 0 ||
+      ((((uintptr_t)p) | ((uintptr_t)m) | ((uintptr_t)v)) & 15))
+    return VMMT_EINVAL;
+  if (n == 0) return VMMT_OK;
+  const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+  if (out_dtype == VMMT_F32)
+    hipLaunchKernelGGL(gather_rows_lazy_kernel<float>, grid, block, 0, (hipStream_t)stream, p, m, v, C, (const long long*)ids, (float*)out,
+                       (long)ldo, n, last, hist, beta1, beta2, eps, upto);
+  else if (out_dtype == VMMT_BF16)
+    hipLaunchKernelGGL(gather_rows_lazy_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p, m, v, C, (const long long*)ids, (bf16_t*)out,
+                       (long)ldo, n, last, hist, beta1, beta2, eps, upto);
+  else return VMMT_EINVAL;
   return check_launch();
 }
 

@@ -347,17 +347,28 @@ class Engine(object):
             t["flags"].zero_()
         self._lazy_dirty = False
 
-    def _lazy_forward_entries(self, plan, table_index, ids_ptr, n_ids, zero_g):
-        """plan entries in front of a gather from an embedding table: flag the batch's rows, replay their missed zero-gradient steps
-        (and clear their gradient rows when a backward pass will follow).  The step to catch up to is patched in per run."""
+    def _lazy_mark_entries(self, plan, table_index, ids_ptr, n_ids, zero_g):
+        """plan entries (off the critical path): flag the batch's rows of an embedding table and, when a backward pass will follow,
+        clear their gradient rows (the catch-up kernel with nothing to catch up: upto = 0)"""
         if not self.lazy_active():
             return
         t = self.lazy_tables[table_index]
         self._call(plan, self.lib.vmmt_rows_mark, ids_ptr, n_ids, t["flags"].data_ptr(), t["R"])
-        pp_, gg_, mm_, vv_ = self._lazy_table_ptrs(t)
-        plan.append((self.lib.vmmt_adam_rows_catchup, (pp_, gg_, mm_, vv_, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(),
-                                                        self.lazy_hist.data_ptr(), 0.9, 0.999, 1e-9, 0, 1 if zero_g else 0),
-                     "vmmt_adam_rows_catchup", None, self._sid))
+        if zero_g:
+            pp_, gg_, mm_, vv_ = self._lazy_table_ptrs(t)
+            self._call(plan, self.lib.vmmt_adam_rows_catchup, pp_, gg_, mm_, vv_, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(),
+                       self.lazy_hist.data_ptr(), 0.9, 0.999, 1e-9, 0, 1)
+
+    def _gather_embedding(self, plan, table_index, name, ids_ptr, out, n, E):
+        """plan entry: the embedding lookup (modules/Embeddings.py:181).  Lazy optimiser: rows the optimiser has not touched lately are
+        advanced to the current step on the fly, in registers (vmmt_gather_rows_lazy); the step to advance to is patched in per run"""
+        if not self.lazy_active():
+            self._call(plan, self.lib.vmmt_gather_rows, self.dt, self.pp(name), E, ids_ptr, out.p(), out.ld, n, E)
+            return
+        t = self.lazy_tables[table_index]
+        pp_, _gg, mm_, vv_ = self._lazy_table_ptrs(t)
+        plan.append((self.lib.vmmt_gather_rows_lazy, (self.dt, pp_, mm_, vv_, t["C"], ids_ptr, out.p(), out.ld, n, t["last"].data_ptr(),
+                                                       self.lazy_hist.data_ptr(), 0.9, 0.999, 1e-9, 0), "vmmt_gather_rows_lazy", None, self._sid))
 
     def pp(self, name, r=0, c=0):
         o, shp = self.offsets[name]
@@ -657,14 +668,13 @@ class Engine(object):
         ts = (main, side, aux, tgt)
         hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream, tgt.cuda_stream)
         trace, last = self.trace, None
-        lazy_fn = self.lib.vmmt_adam_rows_catchup if self.lazy_tables else None
+        lazy_fn = self.lib.vmmt_gather_rows_lazy if self.lazy_tables else None
         for entry in plan:
             fn, args, name, _keep, sid = entry
             if fn is lazy_fn and fn is not None:
-                # the optimiser step to catch up to and the optimiser's constants are those of NOW, not of the time the plan was built
+                # the optimiser step to advance to and the optimiser's constants are those of NOW, not of the time the plan was built
                 b1, b2, eps = self.adam_betas_eps
-                entry = (fn, args[:9] + (b1, b2, eps, int(self.step_count)) + args[13:], name, _keep, sid)
-                self._lazy_dirty = True
+                entry = (fn, args[:11] + (b1, b2, eps, int(self.step_count)), name, _keep, sid)
             if trace is not None and sid == 0 and name != last:     # tools/phase_times.py: timing events at phase changes
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(main)
@@ -938,11 +948,14 @@ class Workspace(object):
             self._mask_entries["dec_out"] = (len(P), self.out_mask)
             e._call(P, lib.vmmt_dropout_mask, dt, self.out_mask.p(), self.out_mask.rows * self.out_mask.ld, d.dropout, 0)
             e._record(P, "out_mask")
-        e._lazy_forward_entries(P, 1, self.tgt_in.data_ptr(), M, training)
-        e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
+        e._gather_embedding(P, 1, "decoder.embeddings.make_embedding.emb_luts.0.weight", self.tgt_in.data_ptr(), self.Xt, M, E)
         we = e.sh["dec_wih_l0_e"]
         e._gemm(P, L.GEMM_NT, self.Xt.p(), self.Xt.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * Hp, E, out_f32=1)
+        if training:
+            # lazy optimiser: flag this batch's rows of both tables and clear their gradient rows -- for the backward plan's scatter-adds
+            # and the optimiser step; in front of `dec_gx`, which every later stream waits for
+            e._lazy_mark_entries(P, 1, self.tgt_in.data_ptr(), M, True)
+            e._lazy_mark_entries(P, 0, self.src.data_ptr(), MS, True)
         e._record(P, "dec_gx")
         if d.conditional:
             self._cond_forward_aux(P, training)
@@ -957,9 +970,7 @@ class Workspace(object):
         e._call(P, lib.vmmt_gather_rows, L.F32, None, D, self.img_idx.data_ptr(), self.img.p(), self.img.ld, B, D)
         e._sid = MAIN
         # a2 source embeddings
-        e._lazy_forward_entries(P, 0, self.src.data_ptr(), MS, training)
-        e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
+        e._gather_embedding(P, 0, "encoder.embeddings.make_embedding.emb_luts.0.weight", self.src.data_ptr(), self.Xs, MS, E)
         # a3 encoder
         x, xcols = self.Xs, E
         for l in range(Lyr):
@@ -1975,6 +1986,8 @@ def _engine_methods():
 
         lazy = self.lazy_active()
         self.adam_betas_eps = (float(beta1), float(beta2), float(eps))
+        if lazy:
+            self._lazy_dirty = True               # rows outside this step's batch fall behind from here on
         if self.lazy_tables and not lazy:
             self.flush_lazy_rows(st)              # (the dense update below needs every row current)
         if lazy and 2 * (self.step_count + 2) > self.lazy_hist.numel():
