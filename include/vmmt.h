@@ -298,12 +298,14 @@ int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float*
  * order).  hbar / h1_* are written for the backward pass.
  * Z is the TILED latent size, Z_valid <= Z the model's (opts.py --z_latent_dim 500 -> Z 512, Z_valid 500): biases, eps, mu, sigma,
  * z32 hold Z_valid entries per row (row stride Z_valid), the weights' rows / columns beyond Z_valid must read as zeros, and the
- * sample / KL cover Z_valid lanes only. */
+ * sample / KL cover Z_valid lanes only.
+ * split != 0: two workgroups per 16 sentences (location / scale network): mu and sigma are written, the sample and the KL are NOT
+ * (z32 / zT / kl_b / stats untouched): follow with vmmt_latent_fwd. */
 int vmmt_qnet_fwd(int dtype, const void* ctx, int64_t ldc, const int64_t* lens, const void* w1_loc, const void* w1_scale, int64_t ldw1,
                   const float* b1_loc, const float* b1_scale, const void* w2_loc, const void* w2_scale, int64_t ldw2,
                   const float* b2_loc, const float* b2_scale, const float* eps, void* hbar, int64_t ldh, void* h1_loc, void* h1_scale,
                   int64_t ldh1, float* mu, float* sigma, float* z32, void* zT, int64_t ldz, float* kl_b, float* stats, int B, int S,
-                  int H, int Z, int Z_valid, int training, void* stream);
+                  int H, int Z, int Z_valid, int training, int split, void* stream);
 /* d/d(mu, pre-softplus scale) of max(mult * KL_mean, margin) * inv_norm  (VILoss.py:460-473, Loss.py:129).
  * dz / eps (f32 [B][Z], both or NULL): the reparameterised gradient z = mu + sigma * eps NOT detached -- d mu += dz,
  * d sigma += dz * eps.  As executed the reference detaches the sample (hazard H2: modules/Dists.py:21-26, Models.py:930-933),

@@ -26,7 +26,7 @@ struct QnetArgs {
   bf16_t* h1[2]; long ldh1;                                // out [B][ldh1]  (hidden activations: saved for backward)
   float* mu; float* sigma; float* z32; bf16_t* zT; long ldz;
   float* kl_b; float* stats;
-  int B, S, H, Z, Zv, training;                            // Z: tiled latent size; Zv <= Z: the model's (row stride of eps / mu / sigma / z32)
+  int B, S, H, Z, Zv, training, split;                            // Z: tiled latent size; Zv <= Z: the model's (row stride of eps / mu / sigma / z32)
 };
 
 typedef float f32x4_q __attribute__((ext_vector_type(4)));
@@ -113,12 +113,16 @@ __global__ void __launch_bounds__(512) qnet_fwd_kernel(QnetArgs a) {
       for (int e = 0; e < 4; ++e)
         o[e] = (unsigned)f2bf(acc[2 * e] / (float)len) | ((unsigned)f2bf(acc[2 * e + 1] / (float)len) << 16);
       *reinterpret_cast<u32x4*>(hb + r * PH + c0) = o;
-      if (r0 + r < B) *reinterpret_cast<u32x4*>(a.hbar + (long)(r0 + r) * a.ldh + c0) = o;
+      if (r0 + r < B && (!a.split || blockIdx.y == 0)) *reinterpret_cast<u32x4*>(a.hbar + (long)(r0 + r) * a.ldh + c0) = o;
     }
   }
   __syncthreads();
   const int n0 = wave * (NT * 16);
-  for (int br = 0; br < 2; ++br) {
+  // split: the location and the scale network of a sentence group run in two workgroups (blockIdx.y) on two CUs -- the chain is
+  // latency-bound (each network streams its ~1 MB of weights through one workgroup), so the two halves take half the time; mu / sigma
+  // then go to memory and vmmt_latent_fwd draws the sample (one more small launch).  Same bits in mu / sigma either way.
+  const int br_lo = a.split ? (int)blockIdx.y : 0, br_hi = a.split ? (int)blockIdx.y + 1 : 2;
+  for (int br = br_lo; br < br_hi; ++br) {
     // ---- 2. h1 = relu(hbar W1^T + b1)
     f32x4_q acc[NT];
     mm16<NT>(hb, PH, a.w1[br], a.ldw1, n0, H, acc);
@@ -147,11 +151,16 @@ __global__ void __launch_bounds__(512) qnet_fwd_kernel(QnetArgs a) {
         const int row = kg * 4 + r;
         float v = acc[j][r] + bias;
         if (br == 1) v = v > 20.f ? v : log1pf(__expf(v));
-        outs[(br * 16 + row) * Z + col] = v;
+        if (a.split) {
+          if (r0 + row < B && col < Zv) (br == 0 ? a.mu : a.sigma)[(long)(r0 + row) * Zv + col] = v;
+        } else {
+          outs[(br * 16 + row) * Z + col] = v;
+        }
       }
     }
     __syncthreads();            // h1s is rewritten by the next branch; outs is read below
   }
+  if (a.split) return;
   // ---- 4. z = mu + sigma * eps (training) | mu ; KL_b = sum_k 0.5 (mu^2 + sigma^2 - 1) - log sigma : wave w -> rows 2w, 2w+1
   for (int rr = 0; rr < 2; ++rr) {
     const int row = wave * 2 + rr, b = r0 + row;
@@ -182,7 +191,7 @@ extern "C" int vmmt_qnet_fwd(int dtype, const void* ctx, int64_t ldc, const int6
                              int64_t ldw1, const float* b1_loc, const float* b1_scale, const void* w2_loc, const void* w2_scale,
                              int64_t ldw2, const float* b2_loc, const float* b2_scale, const float* eps, void* hbar, int64_t ldh,
                              void* h1_loc, void* h1_scale, int64_t ldh1, float* mu, float* sigma, float* z32, void* zT, int64_t ldz,
-                             float* kl_b, float* stats, int B, int S, int H, int Z, int Z_valid, int training, void* stream) {
+                             float* kl_b, float* stats, int B, int S, int H, int Z, int Z_valid, int training, int split, void* stream) {
   using namespace vmmt;
   if (dtype != VMMT_BF16 || !ctx || !lens || !w1_loc || !w1_scale || !b1_loc || !b1_scale || !w2_loc || !w2_scale || !b2_loc || !b2_scale ||
       !hbar || !h1_loc || !h1_scale || !mu || !sigma || !z32 || !zT || !kl_b || !stats || (training && !eps) || B <= 0 || S <= 0)
@@ -196,10 +205,10 @@ extern "C" int vmmt_qnet_fwd(int dtype, const void* ctx, int64_t ldc, const int6
   a.w2[0] = (const bf16_t*)w2_loc; a.w2[1] = (const bf16_t*)w2_scale; a.ldw2 = ldw2; a.b2[0] = b2_loc; a.b2[1] = b2_scale;
   a.eps = eps; a.hbar = (bf16_t*)hbar; a.ldh = ldh; a.h1[0] = (bf16_t*)h1_loc; a.h1[1] = (bf16_t*)h1_scale; a.ldh1 = ldh1;
   a.mu = mu; a.sigma = sigma; a.z32 = z32; a.zT = (bf16_t*)zT; a.ldz = ldz; a.kl_b = kl_b; a.stats = stats;
-  a.B = B; a.S = S; a.H = H; a.Z = Z; a.Zv = Z_valid; a.training = training;
+  a.B = B; a.S = S; a.H = H; a.Z = Z; a.Zv = Z_valid; a.training = training; a.split = split ? 1 : 0;
   const size_t sm = (size_t)16 * (H + 8) * 2 + (size_t)16 * (Z + 8) * 2 + (size_t)2 * 16 * Z * 4;
   if (sm > 128 * 1024) return VMMT_EINVAL;
-  const dim3 grid((B + 15) / 16);
+  const dim3 grid((B + 15) / 16, split ? 2 : 1);
   // (Z = 512 needs 100 KiB of LDS: above the 64-KiB default the limit is raised once per instantiation)
 #define VMMT_QNET_LAUNCH(NT)                                                                                                    \
   {                                                                                                                             \

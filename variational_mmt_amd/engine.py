@@ -235,6 +235,7 @@ class Engine(object):
         self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
         self._sumsq_by_plan = False
         self.fused_qnet = _os_env.get("VMMT_FUSED_QNET", "1") == "1"
+        self.qnet_split = _os_env.get("VMMT_QNET_SPLIT", "1") == "1"     # location / scale networks in separate workgroups (csrc/qnet.hip)
         self.gen_fused = _os_env.get("VMMT_GEN_FUSED", "1") == "1"       # csrc/generator_fused.hip where it applies (bf16, H = 512 / 256)
         self.persistent_lstm = _os_env.get("VMMT_PERSISTENT_LSTM", "1") == "1"     # plans are built per workspace: set before the first forward
         self.seq_syncs = []
@@ -1024,7 +1025,10 @@ class Workspace(object):
                     e.pp("inf_net_global.location.fc2.bias"), e.pp("inf_net_global.scale.fc2.bias"), self.eps.p(), self.hbar.p(),
                     self.hbar.ld, self.q_h1["location"].p(), self.q_h1["scale"].p(), self.q_h1["location"].ld, self.mu.p(),
                     self.sigma.p(), self.z32.p(), self.zT.p(), self.zT.ld, self.kl_b.data_ptr(), self.stats.data_ptr(), B, S, Hp, Zp, Z,
-                    1 if training else 0)
+                    1 if training else 0, 1 if e.qnet_split else 0)
+            if e.qnet_split:        # the two networks ran in separate workgroups: the sample and the KL in a small launch of their own
+                e._call(P, lib.vmmt_latent_fwd, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
+                        self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
         else:
             # a4 q(z|x): masked mean of the detached memory, two 2-layer MLPs
             if not d.conditional:
