@@ -199,13 +199,19 @@ def through_trainer(a, dev, rank, world):
     fields = td.get_fields()
     fields["src"].vocab, fields["tgt"].vocab = td.Vocab(itos_s), td.Vocab(itos_t)
     # Zipf-ish ranks: id = floor(V ** u), u ~ U[0, 1): log-uniform over the vocabulary
+    uniform_ids = os.environ.get("VMMT_TT_UNIFORM") == "1"          # diagnostic knobs: uniform word ids / all sentences full length
+    fixed_len = os.environ.get("VMMT_TT_FIXED") == "1"
+
     def words(itos, lo, n):
+        if uniform_ids:
+            return tuple(itos[rng.randrange(lo, len(itos))] for _ in range(n))
         return tuple(itos[min(len(itos) - 1, lo + int((len(itos) - lo) ** rng.random()) - 1)] for _ in range(n))
     examples = []
     for i in range(N):
         ex = td.Example()
         # source 10..20 words; target 8..18 words + <s> + </s> = 10..20 positions: the lengths of `--lengths ragged` (make_batches)
-        ex.src, ex.tgt, ex.indices = words(itos_s, 2, rng.randint(10, 20)), words(itos_t, 4, rng.randint(8, 18)), i
+        ls, lt = (20, 18) if fixed_len else (rng.randint(10, 20), rng.randint(8, 18))
+        ex.src, ex.tgt, ex.indices = words(itos_s, 2, ls), words(itos_t, 4, lt), i
         examples.append(ex)
     ds = td.TextDataset(examples, fields)
     opt = types.SimpleNamespace(model_type="text", multimodal_model_type="vi-model1", path_to_train_img_feats="resnet50.hdf5",

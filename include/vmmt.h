@@ -413,27 +413,20 @@ int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, void* stream
 int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16, void* stream);
 
-/* ---- row-wise (lazy) Adam for embedding tables -------------------------------------------------------------------------------
- * nn.Embedding tables (modules/Embeddings.py:118,181) receive gradient only in the rows a batch looks up, yet torch.optim.Adam
- * (Optim.py:68-70) streams all of m, v, p for every row at every step.  These entry points produce the SAME bits while touching the
- * used rows only: `last` int32 [R] = the optimiser step each row is current for; `hist` f32 [2 (steps + 1)] = per step
- * (lr / (1 - beta1^s), 1 / sqrt(1 - beta2^s)), written by vmmt_adam_rows_step; `flags` int32 [R] = rows of the batch(es) since the
- * last step (vmmt_rows_mark sets, vmmt_adam_rows_step clears).  C % 4 == 0, rows 16-byte aligned.
- *   vmmt_adam_rows_catchup: rows with flags[r] != 0 (flags == NULL: every row): apply the zero-gradient steps last[r] + 1 .. upto
- *     (m *= beta1, v *= beta2, p -= step(m, v): exactly dense Adam with g = 0), last[r] = upto; zero_g != 0: also clear the rows'
- *     gradient (they are about to receive this batch's scatter-add).  Call before a batch gathers its rows.
- *   vmmt_adam_rows_step: flagged rows: [catch up to step - 1,] apply step `step` with gradient g (clip coefficient from `sumsq` as
- *     vmmt_adam_step), last[r] = step, flags[r] = 0; records hist[step].
- *   vmmt_sumsq_rows: ||g||^2 over the flagged rows into slot `slot` of the norm scratch (deterministic); rowsq f32 [R] scratch. */
+/* ---- embedding tables: gradient bookkeeping by row -----------------------------------------------------------------------------
+ * nn.Embedding tables (modules/Embeddings.py:118,181) receive gradient only in the rows a batch looks up, yet the dense path clears,
+ * norms and reads the whole gradient of each table at every step (loss.backward()'s zero-filled .grad, clip_grad_norm, Adam:
+ * TrainerMultimodal.py:628-629, Optim.py:94-96).  `flags` int32 [R]: rows of the batch(es) since the last optimiser step.
+ *   vmmt_rows_mark      flags[ids[i]] = 1
+ *   vmmt_rows_zero      g[r][:] = 0 for flagged rows (before the batch's scatter-add)
+ *   vmmt_sumsq_rows     ||g||^2 over the flagged rows into slot `slot` of the norm scratch (deterministic); rowsq f32 [R] scratch
+ *   vmmt_adam_rows_step vmmt_adam_step over the WHOLE table (every row moves under Adam, with or without gradient), reading g for
+ *                       flagged rows only (zero elsewhere); clears the flags.  Bit-identical to vmmt_adam_step on a gradient that
+ *                       is zero outside the flagged rows.  C % 4 == 0, rows 16-byte aligned. */
 int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, void* stream);
-/* the embedding lookup of a lazily updated table: out[i] = row ids[i] advanced, in registers only, by the zero-gradient steps it has not
- * seen (last[r] + 1 .. upto); out T per out_dtype, row stride ldo.  Read-only on p / m / v. */
-int vmmt_gather_rows_lazy(int out_dtype, const float* p, const float* m, const float* v, int C, const int64_t* ids, void* out, int64_t ldo,
-                          int n, const int32_t* last, const float* hist, float beta1, float beta2, float eps, int upto, void* stream);
-int vmmt_adam_rows_catchup(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last, const float* hist,
-                           float beta1, float beta2, float eps, int upto, int zero_g, void* stream);
-int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, int32_t* last, float* hist, float lr,
-                        float beta1, float beta2, float eps, int step, float max_norm, const float* sumsq, float grad_scale, void* stream);
+int vmmt_rows_zero(float* g, int R, int C, const int32_t* flags, void* stream);
+int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, float lr, float beta1, float beta2,
+                        float eps, int step, float max_norm, const float* sumsq, float grad_scale, void* stream);
 int vmmt_sumsq_rows(const float* g, int R, int C, const int32_t* flags, float* rowsq, float* scratch, int slot, void* stream);
 
 #ifdef __cplusplus

@@ -322,3 +322,45 @@ def test_script_as_written_bf16_on_the_fast_kernels(B):
         stats2[dt] = e.read_stats(ws)
     assert stats2["f32"]["elbo"] < s32["elbo"]                         # the step went downhill
     assert abs(stats2["bf16"]["elbo"] - stats2["f32"]["elbo"]) <= 3e-3 * abs(stats2["f32"]["elbo"])
+
+
+def test_cfg5_full_batch_properties():
+    """BASELINE config 5 at its FULL per-GPU batch (256 sentences x 64 positions = 16 384 target rows, V 50 000, 2 x 1024, z 512) --
+    what `bench.py --config 5` runs.  The oracle stays at batch 16 (above); here the bf16 step against the fp32 step on the same
+    inputs, plus the size-independent properties: softmax-gradient columns sum to zero (exactly zero at <blank> targets), attention
+    rows sum to one and vanish beyond the source length, the KL statistic equals its closed form, per-token NLL >= 0 and additive."""
+    from variational_mmt_amd.engine import Dims, Engine
+    c, p, bt = _setup5(B=256)
+    B, S, Tp = 256, 64, 64
+    out = {}
+    for dt in ("f32", "bf16"):
+        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype=dt, device="cuda:0")
+        e.load_state_dict(p)
+        e.set_image_table(bt["table"])
+        ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+        e.loss_backward(ws, normalization=B)
+        torch.cuda.synchronize()
+        st = e.read_stats(ws)
+        M = Tp * B
+        y = bt["tgt"][1:].reshape(-1)
+        tok = ws.tok_nll.cpu()
+        assert (tok >= -1e-4).all() and (tok[y == 1] == 0).all()
+        assert abs(float(tok.double().sum()) - st["nmt"]) <= (1e-5 if dt == "f32" else 1e-4) * st["nmt"]
+        mu, sg = ws.mu.view().cpu().double(), ws.sigma.view().cpu().double()
+        kl = (0.5 * (mu ** 2 + sg ** 2 - 1.0) - torch.log(sg)).sum(1).mean().item()
+        assert abs(kl - st["td_kl_before"]) <= 1e-4 * abs(kl)
+        pr = ws.probs.view(Tp, B, S)
+        assert (pr.sum(2) - 1).abs().max().item() <= 1e-5
+        beyond = torch.arange(S).view(1, 1, S) >= bt["src_len"].view(1, B, 1)
+        assert (pr.cpu()[beyond.expand(Tp, B, S)] == 0).all()
+        G = ws.GT.view()[:, :M]
+        assert G.float().sum(0).abs().max().item() <= (2e-6 if dt == "f32" else 3e-4)
+        assert (G[:, (y == 1).cuda()] == 0).all()
+        assert st["n_words"] == int((y != 1).sum())
+        out[dt] = (st, e.flat_g[:e.n_opt].double().clone())
+        del e, ws
+        torch.cuda.empty_cache()
+    (s32, g32), (s16, g16) = out["f32"], out["bf16"]
+    for k in ("nmt", "td_kl_before", "elbo"):
+        assert abs(s16[k] - s32[k]) <= 3e-3 * abs(s32[k]), (k, s16[k], s32[k])
+    assert ((g16 - g32).norm() / g32.norm()).item() <= 5e-2

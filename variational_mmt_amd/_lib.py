@@ -115,9 +115,8 @@ _SIGS = {
     "vmmt_sumsq": (i32, [vp, i64, vp, i32, vp]),
     "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp, vp]),
     "vmmt_rows_mark": (i32, [vp, i64, vp, i32, vp]),
-    "vmmt_gather_rows_lazy": (i32, [i32, vp, vp, vp, i32, vp, vp, i64, i32, vp, vp, f32, f32, f32, i32, vp]),
-    "vmmt_adam_rows_catchup": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, i32, i32, vp]),
-    "vmmt_adam_rows_step": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, f32, i32, f32, vp, f32, vp]),
+    "vmmt_rows_zero": (i32, [vp, i32, i32, vp, vp]),
+    "vmmt_adam_rows_step": (i32, [vp, vp, vp, vp, i32, i32, vp, f32, f32, f32, f32, i32, f32, vp, f32, vp]),
     "vmmt_sumsq_rows": (i32, [vp, i32, i32, vp, vp, vp, i32, vp]),
 }
 

@@ -61,9 +61,9 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
   }
 }
 
-// ONE Adam element update, shared by the dense kernel and the row-wise (lazy) kernels below.  Floating-point contraction is switched
-// off: the row-wise kernels replay steps whose gradient is zero, and their results must be the bits the dense kernel would have
-// produced for g = 0 whatever the compiler would like to fuse in either place.
+// ONE Adam element update, shared by the dense kernel and the row-wise kernel below.  Floating-point contraction is switched off: the
+// row-wise kernel passes g = 0 for rows without gradient, and its results must be the bits the dense kernel produces for a zero
+// gradient whatever the compiler would like to fuse in either place.
 #pragma clang fp contract(off)
 __device__ __forceinline__ void adam_elem(float& p, float ge, float& m, float& v, float step_size, float b1, float b2, float eps,
                                           float inv_sqrt_bc2) {
@@ -133,13 +133,16 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Row-wise (lazy) Adam for embedding tables.  An embedding table [R][C] receives gradient in the rows of the current batch only
-// (<= 5120 of 30 000 at the benchmark shape); for every other row dense Adam still runs m *= b1, v *= b2, p -= step(m, v) -- 28 B per
-// element of pure streaming.  Here a row's state is brought up to date only when the row is USED: `last[r]` = the optimiser step
-// row r is current for, `hist[2 s], hist[2 s + 1]` = (lr / (1 - b1^s), 1 / sqrt(1 - b2^s)) of step s.  Before a batch gathers rows,
-// vmmt_adam_rows_catchup replays the zero-gradient steps last[r] + 1 .. t for its (flagged) rows; the optimiser step then updates
-// the flagged rows with their gradient.  Every replayed step is the dense kernel's arithmetic with g = 0 (adam_elem), in the same
-// order, so parameters and moments are bit-identical to the dense path.  One wave per row.
+// Embedding tables: gradient bookkeeping by ROW.  An embedding table [R][C] receives gradient in the rows of the current batch only
+// (<= 5120 of 30 000 at the benchmark shape), but the dense path clears, norms and reads the whole 60 MB gradient of each table every
+// step.  With one flag per row (set for the batch's rows by rows_mark_kernel) only the flagged rows' gradient is cleared
+// (rows_zero_kernel), summed into the norm (rows_sumsq_kernel) and read by the update (adam_rows_kernel: g = 0 for the other rows
+// without touching memory).  EVERY row is still updated at every step with the dense kernel's arithmetic (adam_elem): a row without
+// gradient moves under Adam too (its moments decay, the parameter follows them), so results are bit-identical to the dense kernels.
+// (A lazy variant -- rows brought up to date only when a batch uses them, replaying the missed zero-gradient steps -- was built and
+//  measured: bit-identical as well and 1.5 % faster on the benchmark's eight recurring batches, but on Zipf-distributed word ids most
+//  rows come back after hundreds of steps and the replays -- a sqrt and a division per element and missed step, on the critical path in
+//  front of the embedding lookup -- cost more than the 28 B/element they save: 2.11 against 1.92 ms per step through the trainer.)
 __global__ void rows_mark_kernel(const long long* __restrict__ ids, long n, int* __restrict__ flags, int R) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -147,20 +150,24 @@ __global__ void rows_mark_kernel(const long long* __restrict__ ids, long n, int*
   if (id >= 0 && id < R) flags[id] = 1;
 }
 
-template <bool STEP>
-__global__ void __launch_bounds__(256) adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                        int R, int C, int* __restrict__ flags, int* __restrict__ last, float* __restrict__ hist,
-                                                        float b1, float b2, float eps, int upto, int zero_g, float step_size, float inv_sqrt_bc2,
-                                                        float max_norm, const float* __restrict__ sumsq, float grad_scale) {
+// g[r][:] = 0 for the flagged rows (one wave per row; the rows are about to receive this batch's scatter-add)
+__global__ void __launch_bounds__(256) rows_zero_kernel(float* __restrict__ g, int R, int C, const int* __restrict__ flags) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (STEP && blockIdx.x == 0 && threadIdx.x == 0) { hist[2 * upto] = step_size; hist[2 * upto + 1] = inv_sqrt_bc2; }
+  if (row >= R || !flags[row]) return;
+  float* x = g + (long)row * C;
+  for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(x + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Adam over a whole table, one wave per row; the gradient is read for flagged rows only (zero elsewhere); flags are cleared
+__global__ void __launch_bounds__(256) adam_rows_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int R, int C, int* __restrict__ flags, float b1, float b2,
+                                                        float eps, float step_size, float inv_sqrt_bc2, float max_norm,
+                                                        const float* __restrict__ sumsq, float grad_scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
-  if (flags && !flags[row]) return;
-  const int l = last[row];
-  // STEP: zero-gradient steps l + 1 .. upto - 1, then step `upto` with the gradient; otherwise zero-gradient steps l + 1 .. upto
-  const int zend = STEP ? upto - 1 : upto;
+  const bool has_g = flags[row] != 0;
   float coef = grad_scale;
-  if (STEP && max_norm > 0.f) {
+  if (max_norm > 0.f) {
     float ss = 0.f;
 #pragma unroll
     for (int k = 0; k < VMMT_SUMSQ_SLOTS; ++k) ss += sumsq[k];
@@ -168,78 +175,23 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(float* __restrict__ p, f
     if (c < 1.f) coef *= c;
   }
   const long base = (long)row * C;
-  const bool work = STEP || l < upto;
   for (int c0 = lane * 4; c0 < C; c0 += 256) {
-    const int n = C - c0 < 4 ? C - c0 : 4;
-    float pp[4], mm[4], vv[4], gg[4] = {0.f, 0.f, 0.f, 0.f};
-    if (work) {
-      if (n == 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p + base + c0), b = *reinterpret_cast<const f32x4*>(m + base + c0),
-                    c = *reinterpret_cast<const f32x4*>(v + base + c0);
+    f32x4 pp = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + base + c0));
+    f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + base + c0));
+    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + base + c0));
+    f32x4 gg = {0.f, 0.f, 0.f, 0.f};
+    if (has_g) gg = *reinterpret_cast<const f32x4*>(g + base + c0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { pp[e] = a[e]; mm[e] = b[e]; vv[e] = c[e]; }
-        if (STEP) { const f32x4 d = *reinterpret_cast<const f32x4*>(g + base + c0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) gg[e] = d[e]; }
-      } else {
-        for (int e = 0; e < n; ++e) { pp[e] = p[base + c0 + e]; mm[e] = m[base + c0 + e]; vv[e] = v[base + c0 + e]; if (STEP) gg[e] = g[base + c0 + e]; }
-      }
-      for (int s = l + 1; s <= zend; ++s) {
-        const float ss = hist[2 * s], ib = hist[2 * s + 1];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) adam_elem(pp[e], 0.f, mm[e], vv[e], ss, b1, b2, eps, ib);
-      }
-      if (STEP) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) adam_elem(pp[e], gg[e] * coef, mm[e], vv[e], step_size, b1, b2, eps, inv_sqrt_bc2);
-      }
-      if (n == 4) {
-        *reinterpret_cast<f32x4*>(p + base + c0) = f32x4{pp[0], pp[1], pp[2], pp[3]};
-        *reinterpret_cast<f32x4*>(m + base + c0) = f32x4{mm[0], mm[1], mm[2], mm[3]};
-        *reinterpret_cast<f32x4*>(v + base + c0) = f32x4{vv[0], vv[1], vv[2], vv[3]};
-      } else {
-        for (int e = 0; e < n; ++e) { p[base + c0 + e] = pp[e]; m[base + c0 + e] = mm[e]; v[base + c0 + e] = vv[e]; }
-      }
+    for (int e = 0; e < 4; ++e) {
+      float pe = pp[e], me = mm[e], ve = vv[e];
+      adam_elem(pe, gg[e] * coef, me, ve, step_size, b1, b2, eps, inv_sqrt_bc2);
+      pp[e] = pe; mm[e] = me; vv[e] = ve;
     }
-    if (!STEP && zero_g) {
-      if (n == 4) *reinterpret_cast<f32x4*>(g + base + c0) = f32x4{0.f, 0.f, 0.f, 0.f};
-      else for (int e = 0; e < n; ++e) g[base + c0 + e] = 0.f;
-    }
+    __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(p + base + c0));
+    __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m + base + c0));
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + base + c0));
   }
-  if (lane == 0) {
-    if (work) last[row] = upto;
-    if (STEP && flags) flags[row] = 0;
-  }
-}
-
-// Embedding lookup from a lazily updated table (modules/Embeddings.py:181): out[i][:] = CURRENT value of row ids[i], i.e. the stored
-// row advanced by the zero-gradient steps last[r] + 1 .. upto it has not seen yet -- computed in registers, nothing is written back
-// (read-only: positions that share a row need no coordination; vmmt_adam_rows_step replays the same steps for good at the end of
-// the step).  One wave per position; C <= 1024, C % 4 == 0.
-template <class TO>
-__global__ void __launch_bounds__(256) gather_rows_lazy_kernel(const float* __restrict__ p, const float* __restrict__ m, const float* __restrict__ v,
-                                                               int C, const long long* __restrict__ ids, TO* __restrict__ out, long ldo, int n,
-                                                               const int* __restrict__ last, const float* __restrict__ hist, float b1, float b2,
-                                                               float eps, int upto) {
-  const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (pos >= n) return;
-  const long long r = ids[pos];
-  const long base = (long)r * C;
-  const int l = __builtin_amdgcn_readfirstlane(last[r]);
-  TO* dst = out + (long)pos * ldo;
-  for (int c0 = lane * 4; c0 < C; c0 += 256) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(p + base + c0);
-    if (l < upto) {
-      f32x4 mm = *reinterpret_cast<const f32x4*>(m + base + c0), vv = *reinterpret_cast<const f32x4*>(v + base + c0);
-      for (int s = l + 1; s <= upto; ++s) {
-        const float ss = hist[2 * s], ib = hist[2 * s + 1];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { float pe = a[e], me = mm[e], ve = vv[e]; adam_elem(pe, 0.f, me, ve, ss, b1, b2, eps, ib); a[e] = pe; mm[e] = me; vv[e] = ve; }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dst[c0 + e] = from_f<TO>(a[e]);
-  }
+  if (lane == 0 && has_g) flags[row] = 0;
 }
 
 // ||g||^2 over the flagged rows (the other rows hold zeros): per-row sums by one wave each, then ONE workgroup adds the R row sums in a
@@ -251,10 +203,7 @@ __global__ void __launch_bounds__(256) rows_sumsq_kernel(const float* __restrict
   float a = 0.f;
   if (flags[row]) {
     const float* x = g + (long)row * C;
-    for (int c = lane * 4; c < C; c += 256) {
-      if (c + 4 <= C) { const f32x4 q = *reinterpret_cast<const f32x4*>(x + c); a += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]; }
-      else for (int e = c; e < C; ++e) a += x[e] * x[e];
-    }
+    for (int c = lane * 4; c < C; c += 256) { const f32x4 q = *reinterpret_cast<const f32x4*>(x + c); a += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]; }
     a = wave_sum(a);
   }
   if (lane == 0) rowsq[row] = a;
@@ -287,47 +236,23 @@ extern "C" int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int
   return check_launch();
 }
 
-static bool rows_ok(const void* p, const void* g, const void* m, const void* v, int R, int C) {
-  return p && m && v && R > 0 && C > 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0 && (C % 4 == 0 || C < 4 || true);
-}
-
-extern "C" int vmmt_adam_rows_catchup(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last,
-                                      const float* hist, float beta1, float beta2, float eps, int upto, int zero_g, void* stream) {
+extern "C" int vmmt_rows_zero(float* g, int R, int C, const int32_t* flags, void* stream) {
   using namespace vmmt;
-  if (!rows_ok(p, g, m, v, R, C) || !last || !hist || upto < 0 || (zero_g && !g) || (C % 4 != 0)) return VMMT_EINVAL;
-  hipLaunchKernelGGL(adam_rows_kernel<false>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, R, C,
-                     const_cast<int*>(flags), last, const_cast<float*>(hist), beta1, beta2, eps, upto, zero_g, 0.f, 0.f, 0.f, (const float*)nullptr, 1.f);
+  if (!g || !flags || R <= 0 || C <= 0 || C % 4 != 0 || (((uintptr_t)g) & 15)) return VMMT_EINVAL;
+  hipLaunchKernelGGL(rows_zero_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, R, C, flags);
   return check_launch();
 }
 
-extern "C" int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, int32_t* last, float* hist,
-                                   float lr, float beta1, float beta2, float eps, int step, float max_norm, const float* sumsq,
-                                   float grad_scale, void* stream) {
+extern "C" int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, float lr, float beta1,
+                                   float beta2, float eps, int step, float max_norm, const float* sumsq, float grad_scale, void* stream) {
   using namespace vmmt;
-  if (!rows_ok(p, g, m, v, R, C) || !g || !flags || !last || !hist || step < 1 || (max_norm > 0.f && !sumsq) || (C % 4 != 0)) return VMMT_EINVAL;
+  if (!p || !g || !m || !v || !flags || R <= 0 || C <= 0 || C % 4 != 0 || step < 1 || (max_norm > 0.f && !sumsq) ||
+      ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15))
+    return VMMT_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));        // as vmmt_adam_step
-  hipLaunchKernelGGL(adam_rows_kernel<true>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), m, v, R, C,
-                     flags, last, hist, beta1, beta2, eps, step, 0, step_size, inv_sqrt_bc2, max_norm, sumsq, grad_scale);
-  return check_launch();
-}
-
-extern "C" int vmmt_gather_rows_lazy(int out_dtype, const float* p, const float* m, const float* v, int C, const int64_t* ids, void* out,
-                                     int64_t ldo, int n, const int32_t* last, const float* hist, float beta1, float beta2, float eps, int upto,
-                                     void* stream) {
-  using namespace vmmt;
-  if (!p || !m || !v || !ids || !out || !last || !hist || n < 0 || C <= 0 || C % 4 != 0 || upto < 0 ||
-      ((((uintptr_t)p) | ((uintptr_t)m) | ((uintptr_t)v)) & 15))
-    return VMMT_EINVAL;
-  if (n == 0) return VMMT_OK;
-  const dim3 grid((unsigned)((n + 3) / 4)), block(256);
-  if (out_dtype == VMMT_F32)
-    hipLaunchKernelGGL(gather_rows_lazy_kernel<float>, grid, block, 0, (hipStream_t)stream, p, m, v, C, (const long long*)ids, (float*)out,
-                       (long)ldo, n, last, hist, beta1, beta2, eps, upto);
-  else if (out_dtype == VMMT_BF16)
-    hipLaunchKernelGGL(gather_rows_lazy_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p, m, v, C, (const long long*)ids, (bf16_t*)out,
-                       (long)ldo, n, last, hist, beta1, beta2, eps, upto);
-  else return VMMT_EINVAL;
+  hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, R, C, flags, beta1, beta2,
+                     eps, step_size, inv_sqrt_bc2, max_norm, sumsq, grad_scale);
   return check_launch();
 }
 

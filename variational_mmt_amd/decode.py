@@ -102,7 +102,6 @@ class _Stepper(object):
 def _encode(eng, src, src_len, bos):
     """encoder + latent mean + z W_z^T: the evaluation-mode forward plan on a dummy 2-token target (its decoder step is ignored)"""
     d, dev = eng.d, eng.dev
-    eng.flush_lazy_rows()       # decoding looks up target rows chosen on the device: every row of the tables has to be current
     B = int(src.shape[1])
     dummy = torch.tensor([[bos] * B, [3] * B], dtype=torch.int64, device="cpu")
     tab = getattr(eng, "img_table", None)

@@ -40,8 +40,7 @@ class GradSync(object):
                 self.world = dist.get_world_size()
                 self.rank = dist.get_rank()
                 if engine is not None and engine.dp is None:
-                    engine.flush_lazy_rows()           # the row-wise lazy optimiser is single-process only (engine._build_lazy)
-                    engine.drop_workspaces()           # ... and its plan entries go with the cached plans
+                    engine.drop_workspaces()           # (plans built for one process carry the row-wise gradient bookkeeping of the embedding tables: engine._build_row_tables)
                     engine.dp = self
                     # the seed is shared (identical initial parameters); the noise streams must not be: each replica draws
                     # its own eps ~ N(0, I) and dropout masks (counter-based RNG: disjoint counter ranges per rank)

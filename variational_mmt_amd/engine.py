@@ -133,30 +133,6 @@ class Buf(object):
         return self.t[:self.rows, :self.cols]
 
 
-class _ParamDict(dict):
-    """name -> view of the parameter arena.  Reading an embedding table through it first brings the rows the lazy optimiser has not
-    touched lately up to date (Engine.flush_lazy_rows); views obtained EARLIER (e.g. the nn.Parameters of the onmt mirror) see such rows
-    only after a flush -- state_dict(), checkpoints and decoding flush by themselves."""
-
-    def __init__(self, engine):
-        super(_ParamDict, self).__init__()
-        self._engine = engine
-
-    def __getitem__(self, k):
-        e = self._engine
-        if e._lazy_dirty and k in e._lazy_names:
-            e.flush_lazy_rows()
-        return dict.__getitem__(self, k)
-
-    def items(self):
-        self._engine.flush_lazy_rows()
-        return dict.items(self)
-
-    def values(self):
-        self._engine.flush_lazy_rows()
-        return dict.values(self)
-
-
 class Engine(object):
     def __init__(self, dims, dtype="bf16", device="cuda", seed=0, param_init=0.1, batch_global=None):
         self.d = dims
@@ -164,12 +140,12 @@ class Engine(object):
         if self.dev.type != "cuda":
             raise RuntimeError("variational_mmt_amd needs a GPU (MI355X); there is no CPU path")
         self.lib = L.lib()
-        self._lazy_dirty, self._lazy_names, self.lazy_tables = False, (), []
+        self.row_tables = []
         self.dt = L.BF16 if dtype in ("bf16", torch.bfloat16) else L.F32
         self.T = torch.bfloat16 if self.dt == L.BF16 else torch.float32
         self.tsz = 2 if self.dt == L.BF16 else 4
         self._build_arena(seed, param_init)
-        self._build_lazy()
+        self._build_row_tables()
         self._build_shadows()
         # per-shape workspaces: a bounded LRU (real data has hundreds of (S, T') pairs per epoch).  Shapes are rounded up to
         # `shape_bucket` positions (pad positions are masked everywhere), the largest buffer (G^T) is shared between all
@@ -284,7 +260,7 @@ class Engine(object):
         self.flat_g = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
-        self.params, self.grads = _ParamDict(self), {}
+        self.params, self.grads = {}, {}
         g = torch.Generator(device="cpu").manual_seed(seed)       # (explicit devices: a driver may have made CUDA the default tensor type)
         for n, (o, shp) in self.offsets.items():
             k = int(math.prod(shp))
@@ -294,82 +270,48 @@ class Engine(object):
             if param_init:                             # ModelConstructor.py:598-603 (H7: every parameter)
                 self.params[n].copy_(((torch.rand(*shp, generator=g, device="cpu") * 2 - 1) * param_init))
 
-    # ------------------------------------------------------------------------------------------------ lazy embedding rows
-    def _build_lazy(self):
-        """Row-wise (lazy) Adam for the two embedding tables (csrc/optim.hip: vmmt_adam_rows_*).  The tables are 54 % of the optimised
-        parameters and a step's gradient lives in the <= S B + T' B rows the batch looked up (17 % of 30 000 at the benchmark shape):
-        dense Adam streams 28 B for every element of the other 83 % just to decay their moments.  Lazily, a row's (p, m, v) are
-        brought up to date when a batch is about to gather it (forward plan: mark + catch-up in front of the gather) and updated with
-        its gradient by the optimiser step; gradient zeroing and the norm walk the flagged rows only.  Bit-identical to the dense
-        update (tests/test_gpu_lazy_adam.py).  Off under data parallelism (the flagged set would have to be the union over the
-        ranks) and for the conditional model (two streams gather from the shared target table)."""
+    # ------------------------------------------------------------------------------------------------ embedding tables by row
+    def _build_row_tables(self):
+        """Row-wise gradient bookkeeping for the two embedding tables (csrc/optim.hip: vmmt_rows_mark / _zero / vmmt_sumsq_rows /
+        vmmt_adam_rows_step).  The tables are 54 % of the optimised parameters and a step's gradient lives in the <= S B + T' B rows
+        the batch looked up (17 % of 30 000 at the benchmark shape): with one flag per row, the gradient is cleared, normed and read
+        for those rows only -- 12 of the 36 B per element and step the dense path moves (4 zeroing + 4 norm + 28 Adam), and the
+        zero-fill and the norm stop touching 200 MB each.  Every row is still UPDATED at every step (the moments of a row without
+        gradient decay, its parameter follows them): bit-identical to dense Adam (tests/test_gpu_row_adam.py).  Off under data
+        parallelism (the flagged set would have to be the union over the ranks) and for the conditional model (two streams flag
+        rows of the shared target table).
+        OPT-IN (VMMT_ROW_ADAM=1): measured on MI355X it does not pay at these sizes -- 1.787 against 1.746 ms per step at BASELINE
+        config 2, 2.704 against 2.728 at the run scripts' shape, 1.867 against 1.863 through the trainer: the dense streams run at
+        6.7 TB/s, half of them underneath the next step's encoder, while the row kernels add six small launches to the step's head
+        and tail.  (The LAZY variant -- rows updated only when used, missed zero-gradient steps replayed -- saves 0.7 GB per step and
+        was 1.5 % faster on the benchmark's recurring batches, but with Zipf-distributed ids the replays (sqrt + division per element
+        and missed step, in front of the embedding lookup) cost more than the traffic: 2.11 against 1.92 ms through the trainer.  Not
+        kept: DESIGN.md section 6.)"""
         names = ("encoder.embeddings.make_embedding.emb_luts.0.weight", "decoder.embeddings.make_embedding.emb_luts.0.weight")
-        self.lazy_rows = _os_env.get("VMMT_LAZY_EMB_ADAM", "1") == "1" and not self.d.conditional
-        self.lazy_tables = []
-        if not self.lazy_rows:
+        self.row_adam = _os_env.get("VMMT_ROW_ADAM", "0") == "1" and not self.d.conditional
+        self.row_tables = []
+        if self.d.conditional:
             return
-        for n in names:
+        for n in names:          # (the flag arrays are always there -- 240 KB -- so that the switch can be set after construction)
             off, (R, Cc) = self.offsets[n]
             if Cc % 4 or off % 4:
-                self.lazy_rows, self.lazy_tables = False, []
+                self.row_adam, self.row_tables = False, []
                 return
-            self.lazy_tables.append(dict(name=n, off=off, R=R, C=Cc, end=off + R * Cc,
-                                         flags=torch.zeros(R, dtype=torch.int32, device=self.dev),
-                                         last=torch.zeros(R, dtype=torch.int32, device=self.dev),
-                                         rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev)))
-        self._lazy_names = names
-        self.lazy_hist = torch.zeros(2 * (1 << 16), dtype=torch.float32, device=self.dev)      # (lr / bc1, 1 / sqrt(bc2)) per step; grows
-        self.adam_betas_eps = (0.9, 0.999, 1e-9)                                               # of the last optim_step (replays use them)
+            self.row_tables.append(dict(name=n, off=off, R=R, C=Cc, end=off + R * Cc,
+                                        flags=torch.zeros(R, dtype=torch.int32, device=self.dev),
+                                        rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev)))
 
-    def lazy_active(self):
-        return bool(self.lazy_tables) and self.lazy_rows and not (self.dp is not None and self.dp.world > 1)
+    def rows_active(self):
+        return bool(self.row_tables) and self.row_adam and not (self.dp is not None and self.dp.world > 1)
 
-    def _lazy_table_ptrs(self, t):
-        o = 4 * t["off"]
-        return (self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o, self.flat_v.data_ptr() + o)
-
-    def flush_lazy_rows(self, stream=None):
-        """bring EVERY row of the embedding tables up to the current optimiser step (before parameters or moments are read as a
-        whole: state_dict, checkpoints, decoding, a switch to the dense / data-parallel optimiser)"""
-        if not self._lazy_dirty:
+    def _row_mark_entries(self, plan, table_index, ids_ptr, n_ids):
+        """plan entries (training forward, off the critical path): flag the batch's rows of an embedding table and clear their
+        gradient rows, which the backward plan's scatter-add accumulates into"""
+        if not self.rows_active():
             return
-        st = stream if stream is not None else self.stream()
-        b1, b2, eps = self.adam_betas_eps
-        for t in self.lazy_tables:
-            pp_, gg_, mm_, vv_ = self._lazy_table_ptrs(t)
-            L.check(self.lib.vmmt_adam_rows_catchup(pp_, gg_, mm_, vv_, t["R"], t["C"], None, t["last"].data_ptr(), self.lazy_hist.data_ptr(),
-                                                    b1, b2, eps, self.step_count, 0, st), "vmmt_adam_rows_catchup")
-        self._lazy_dirty = False
-
-    def reset_lazy_rows(self):
-        """every row is current for step `step_count` (after parameters / moments were loaded or the optimiser was re-created)"""
-        for t in self.lazy_tables:
-            t["last"].fill_(int(self.step_count))
-            t["flags"].zero_()
-        self._lazy_dirty = False
-
-    def _lazy_mark_entries(self, plan, table_index, ids_ptr, n_ids, zero_g):
-        """plan entries (off the critical path): flag the batch's rows of an embedding table and, when a backward pass will follow,
-        clear their gradient rows (the catch-up kernel with nothing to catch up: upto = 0)"""
-        if not self.lazy_active():
-            return
-        t = self.lazy_tables[table_index]
+        t = self.row_tables[table_index]
         self._call(plan, self.lib.vmmt_rows_mark, ids_ptr, n_ids, t["flags"].data_ptr(), t["R"])
-        if zero_g:
-            pp_, gg_, mm_, vv_ = self._lazy_table_ptrs(t)
-            self._call(plan, self.lib.vmmt_adam_rows_catchup, pp_, gg_, mm_, vv_, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(),
-                       self.lazy_hist.data_ptr(), 0.9, 0.999, 1e-9, 0, 1)
-
-    def _gather_embedding(self, plan, table_index, name, ids_ptr, out, n, E):
-        """plan entry: the embedding lookup (modules/Embeddings.py:181).  Lazy optimiser: rows the optimiser has not touched lately are
-        advanced to the current step on the fly, in registers (vmmt_gather_rows_lazy); the step to advance to is patched in per run"""
-        if not self.lazy_active():
-            self._call(plan, self.lib.vmmt_gather_rows, self.dt, self.pp(name), E, ids_ptr, out.p(), out.ld, n, E)
-            return
-        t = self.lazy_tables[table_index]
-        pp_, _gg, mm_, vv_ = self._lazy_table_ptrs(t)
-        plan.append((self.lib.vmmt_gather_rows_lazy, (self.dt, pp_, mm_, vv_, t["C"], ids_ptr, out.p(), out.ld, n, t["last"].data_ptr(),
-                                                       self.lazy_hist.data_ptr(), 0.9, 0.999, 1e-9, 0), "vmmt_gather_rows_lazy", None, self._sid))
+        self._call(plan, self.lib.vmmt_rows_zero, self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr())
 
     def pp(self, name, r=0, c=0):
         o, shp = self.offsets[name]
@@ -382,14 +324,13 @@ class Engine(object):
         return self.flat_g.data_ptr() + (o + r * ld + c) * 4
 
     def load_state_dict(self, sd):
-        self.flush_lazy_rows()
         for n, t in sd.items():
             if n in self.params:
-                dict.__getitem__(self.params, n).copy_(t.to(torch.float32))
+                self.params[n].copy_(t.to(torch.float32))
         self.shadows_dirty = True
 
     def state_dict(self):
-        sd = {n: v.detach().clone() for n, v in self.params.items()}          # (items() flushes the lazily updated rows)
+        sd = {n: v.detach().clone() for n, v in self.params.items()}
         if self.d.conditional:      # encoder_tgt shares the decoder's table; the reference's state dict lists it under both names
             sd["encoder_tgt.embeddings.make_embedding.emb_luts.0.weight"] = sd["decoder.embeddings.make_embedding.emb_luts.0.weight"]
         return sd
@@ -642,10 +583,10 @@ class Engine(object):
         lo = self.offsets[first_name][0]
         hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
         hi = min(hi, self.n_opt)
-        if self.lazy_active():
+        if self.rows_active():
             # an embedding table inside the range: its flagged rows go to a slot of their own (3 + table index), the dense kernel
             # takes what lies in front of it (slot) and behind it (slot + 5: only the conditional model has parameters there)
-            for k, t in enumerate(self.lazy_tables):
+            for k, t in enumerate(self.row_tables):
                 if lo <= t["off"] and t["end"] <= hi:
                     plan.append((None, (k, 3 + k), "SUMSQ_ROWS", None, self._sid))
                     if t["off"] > lo:
@@ -669,13 +610,8 @@ class Engine(object):
         ts = (main, side, aux, tgt)
         hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream, tgt.cuda_stream)
         trace, last = self.trace, None
-        lazy_fn = self.lib.vmmt_gather_rows_lazy if self.lazy_tables else None
         for entry in plan:
             fn, args, name, _keep, sid = entry
-            if fn is lazy_fn and fn is not None:
-                # the optimiser step to advance to and the optimiser's constants are those of NOW, not of the time the plan was built
-                b1, b2, eps = self.adam_betas_eps
-                entry = (fn, args[:11] + (b1, b2, eps, int(self.step_count)), name, _keep, sid)
             if trace is not None and sid == 0 and name != last:     # tools/phase_times.py: timing events at phase changes
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(main)
@@ -700,7 +636,7 @@ class Engine(object):
                 return
             if name == "SUMSQ_ROWS":
                 k, slot = args
-                t = self.lazy_tables[k]
+                t = self.row_tables[k]
                 L.check(self.lib.vmmt_sumsq_rows(self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr(), t["rowsq"].data_ptr(),
                                                  self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq_rows")
                 return
@@ -931,9 +867,9 @@ class Workspace(object):
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             # ... together with the small accumulators of the backward plan (off the critical path instead of in front of
             # their users): one launch
-            if e.lazy_active():        # the tables' gradient rows are cleared row by row (vmmt_adam_rows_catchup, zero_g)
+            if e.rows_active():        # the tables' gradient rows are cleared row by row (vmmt_rows_zero)
                 g_ranges, lo = [], e.offsets["generator.0.bias"][0]
-                for t in sorted(e.lazy_tables, key=lambda t: t["off"]):
+                for t in sorted(e.row_tables, key=lambda t: t["off"]):
                     g_ranges.append(e.flat_g[lo:t["off"]])
                     lo = t["end"]
                 g_ranges.append(e.flat_g[lo:])
@@ -949,14 +885,15 @@ class Workspace(object):
             self._mask_entries["dec_out"] = (len(P), self.out_mask)
             e._call(P, lib.vmmt_dropout_mask, dt, self.out_mask.p(), self.out_mask.rows * self.out_mask.ld, d.dropout, 0)
             e._record(P, "out_mask")
-        e._gather_embedding(P, 1, "decoder.embeddings.make_embedding.emb_luts.0.weight", self.tgt_in.data_ptr(), self.Xt, M, E)
+        e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
         we = e.sh["dec_wih_l0_e"]
         e._gemm(P, L.GEMM_NT, self.Xt.p(), self.Xt.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * Hp, E, out_f32=1)
         if training:
-            # lazy optimiser: flag this batch's rows of both tables and clear their gradient rows -- for the backward plan's scatter-adds
-            # and the optimiser step; in front of `dec_gx`, which every later stream waits for
-            e._lazy_mark_entries(P, 1, self.tgt_in.data_ptr(), M, True)
-            e._lazy_mark_entries(P, 0, self.src.data_ptr(), MS, True)
+            # row-wise gradient bookkeeping of the embedding tables: flag this batch's rows and clear their gradient rows -- for the
+            # backward plan's scatter-adds and the optimiser step; in front of `dec_gx`, which every later stream waits for
+            e._row_mark_entries(P, 1, self.tgt_in.data_ptr(), M)
+            e._row_mark_entries(P, 0, self.src.data_ptr(), MS)
         e._record(P, "dec_gx")
         if d.conditional:
             self._cond_forward_aux(P, training)
@@ -971,7 +908,8 @@ class Workspace(object):
         e._call(P, lib.vmmt_gather_rows, L.F32, None, D, self.img_idx.data_ptr(), self.img.p(), self.img.ld, B, D)
         e._sid = MAIN
         # a2 source embeddings
-        e._gather_embedding(P, 0, "encoder.embeddings.make_embedding.emb_luts.0.weight", self.src.data_ptr(), self.Xs, MS, E)
+        e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
         # a3 encoder
         x, xcols = self.Xs, E
         for l in range(Lyr):
@@ -1968,7 +1906,7 @@ def _engine_methods():
         if self.dp is not None and self.dp.world > 1 and self.dp.sharded:
             return self._optim_step_sharded(lr, max_grad_norm, beta1, beta2, eps, grad_scale)
         if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
-            # (a dense pass is right with the lazy optimiser too: the rows it has not flagged hold zeros)
+            # (a dense pass is right with the row bookkeeping too: the rows it has not flagged hold zeros)
             self._sumsq[:L.SUMSQ_SLOTS].zero_()
             L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), 0, st), "vmmt_sumsq")
         self._sumsq_by_plan = False
@@ -1988,32 +1926,22 @@ def _engine_methods():
                                                 eps, self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
                                                 blocks, shadow, stream), "vmmt_adam_step")
 
-        lazy = self.lazy_active()
-        self.adam_betas_eps = (float(beta1), float(beta2), float(eps))
-        if lazy:
-            self._lazy_dirty = True               # rows outside this step's batch fall behind from here on
-        if self.lazy_tables and not lazy:
-            self.flush_lazy_rows(st)              # (the dense update below needs every row current)
-        if lazy and 2 * (self.step_count + 2) > self.lazy_hist.numel():
-            grown = torch.zeros(2 * self.lazy_hist.numel(), dtype=torch.float32, device=self.dev)
-            grown[:self.lazy_hist.numel()].copy_(self.lazy_hist)
-            torch.cuda.synchronize(self.dev)      # plans hold the old pointer: drop them with the workspaces (rare: every 32 K steps)
-            self.drop_workspaces()
-            self.lazy_hist = grown
+        rows = self.rows_active()
 
         def rows_step(t, stream):
-            pp_, gg_, mm_, vv_ = self._lazy_table_ptrs(t)
-            L.check(self.lib.vmmt_adam_rows_step(pp_, gg_, mm_, vv_, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(),
-                                                 self.lazy_hist.data_ptr(), lr, beta1, beta2, eps, self.step_count,
-                                                 float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, stream), "vmmt_adam_rows_step")
+            o = 4 * t["off"]
+            L.check(self.lib.vmmt_adam_rows_step(self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o,
+                                                 self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), lr, beta1, beta2, eps,
+                                                 self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, stream),
+                    "vmmt_adam_rows_step")
 
         def adam(lo, hi, stream):
             # the big unpadded bf16 shadows (generator weight, image network fc2) are written by the update itself: their range is
             # a launch of its own with the shadow attached, and the shadow refresh behind it skips them (_pack_tables); the embedding
-            # tables are updated row by row (their flagged rows only) when the lazy optimiser is on
+            # tables are updated by the row-wise kernel (gradient read for the batch's rows only) when the row bookkeeping is on
             pieces = [(s_lo, s_hi, ("shadow", ptr)) for s_lo, s_hi, ptr in self._fused_shadows() if lo <= s_lo and s_hi <= hi]
-            if lazy:
-                pieces += [(t["off"], t["end"], ("rows", t)) for t in self.lazy_tables if lo <= t["off"] and t["end"] <= hi]
+            if rows:
+                pieces += [(t["off"], t["end"], ("rows", t)) for t in self.row_tables if lo <= t["off"] and t["end"] <= hi]
             cur = lo
             for p_lo, p_hi, (kind, what) in sorted(pieces, key=lambda x: x[0]):
                 adam_range(cur, p_lo, stream)

@@ -43,7 +43,7 @@ class NMTVIModel(nn.Module):
         self.dims = dims
         self.engine = Engine(dims, dtype=dtype, device=device, seed=seed, param_init=param_init)
         for name in self.engine.names_grad + self.engine.names_nograd:
-            p = nn.Parameter(dict.__getitem__(self.engine.params, name), requires_grad=True)
+            p = nn.Parameter(self.engine.params[name], requires_grad=True)
             p._vmmt_engine = self.engine
             p._vmmt_name = name
             if name in self.engine.grads:
@@ -64,11 +64,9 @@ class NMTVIModel(nn.Module):
         pass          # the gradient arena is zeroed by the training forward plan (side stream)
 
     def state_dict(self, *args, **kwargs):
-        self.engine.flush_lazy_rows()           # embedding rows the lazy optimiser has not touched lately (engine._build_lazy)
         return super(NMTVIModel, self).state_dict(*args, **kwargs)
 
     def load_state_dict(self, state_dict, strict=True):
-        self.engine.flush_lazy_rows()           # every row current before its values are replaced (the row bookkeeping stays valid)
         out = super(NMTVIModel, self).load_state_dict(state_dict, strict=strict)
         self.engine.shadows_dirty = True
         return out

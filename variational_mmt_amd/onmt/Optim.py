@@ -31,7 +31,6 @@ class _ArenaAdam(object):
         if o is None or o.engine is None:
             return self._saved or {"state": {}, "param_groups": self.param_groups}
         e = o.engine
-        e.flush_lazy_rows()           # the moments of rows the lazy optimiser has not touched lately
         state = {}
         for i, p in enumerate(o.params):
             name = getattr(p, "_vmmt_name", None)
@@ -95,13 +94,12 @@ class Optim(object):
             e.flat_m.zero_()          # a NEW Adam, as in the reference (Optim.py:68-70)
             e.flat_v.zero_()
             e.step_count = 0
-            e.reset_lazy_rows()
             if saved is not None:
                 self._push_state(saved)
         elif self.method in ("sgd", "adagrad", "adadelta"):
             # not on the hot path (every reference recipe uses adam): thin delegation to torch on the arena views
-            self.engine.flush_lazy_rows()
-            self.engine.lazy_rows = False          # torch's dense optimisers on the arena views: no row-wise bookkeeping
+            self.engine.row_adam = False           # torch's dense optimisers on the arena views read / clear the whole gradient
+            self.engine.drop_workspaces()
             cls = {"sgd": torch.optim.SGD, "adagrad": torch.optim.Adagrad, "adadelta": torch.optim.Adadelta}[self.method]
             self.optimizer = cls(self.params, lr=self.lr)
         else:
@@ -139,7 +137,6 @@ class Optim(object):
             e.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
             step = max(step, int(float(st["step"])))
         e.step_count = step
-        e.reset_lazy_rows()
 
     def _set_rate(self, lr):
         self.lr = lr
@@ -179,7 +176,6 @@ class Optim(object):
         if e is None or not isinstance(self.optimizer, _ArenaAdam):
             d["params"] = []
             return d
-        e.flush_lazy_rows()
         shared = getattr(self, "_ckpt_cpu", None) or {}        # CPU copies the trainer already made for checkpoint['model']
         cpu_params = []
         for p in self.params:
