@@ -364,3 +364,42 @@ def test_cfg5_full_batch_properties():
     for k in ("nmt", "td_kl_before", "elbo"):
         assert abs(s16[k] - s32[k]) <= 3e-3 * abs(s32[k]), (k, s16[k], s32[k])
     assert ((g16 - g32).norm() / g32.norm()).item() <= 5e-2
+
+
+@pytest.mark.parametrize("B", [40])
+def test_script_as_written_conditional(B):
+    """the `--conditional` half of the run scripts (run_translated_m30k_only.sh:59-71) at its real shape: hidden 500 (encoder_tgt: 2 x 250,
+    computed as 2 x 256), z 500, 2 uni-directional layers, V 30 000.  fp32 parity mode against the oracle (statistics + every gradient),
+    bf16 on the persistent recurrences (encoder_tgt's included) against fp32."""
+    c = O.Cfg(vs=30000, vt=30000, emb=500, hid=500, z=500, img=2048, layers=2, brnn=False, conditional=True)
+    p = O.init_params(c, seed=0)
+    bt = O.synth_batch(c, B=B, S=20, T=21, n_img=300, seed=9, fixed_len=False)
+    img = bt["table"][bt["indices"]]
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], tgt_len=bt["tgt_len"])
+    from variational_mmt_amd.engine import Dims, Engine
+    out = {}
+    for dt in ("f32", "bf16"):
+        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0, conditional=True), dtype=dt, device="cuda:0")
+        assert e.d.pad and e.d.hp == 512 and e.d.htp == 256 and e.d.qin_p == 512 + 512 + 2048
+        e.load_state_dict(p)
+        e.set_image_table(bt["table"])
+        ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"], tgt_len=bt["tgt_len"])
+        e.loss_backward(ws, normalization=B)
+        torch.cuda.synchronize()
+        out[dt] = (e, ws, e.read_stats(ws))
+    e32, ws32, s32 = out["f32"]
+    for k, ok in (("nmt", "nll"), ("td_kl_before", "kl_before"), ("elbo", "elbo"), ("img_feats_loss", "img_logprob")):
+        ref = float(Lo[ok])
+        assert abs(s32[k] - ref) <= 5e-5 * abs(ref), (k, s32[k], ref)
+    assert set(g) == set(e32.grads)
+    for k in g:
+        err = (e32.grads[k].cpu().double() - g[k].double()).abs().max().item() / max(g[k].abs().max().item(), 1e-30)
+        tol = 5e-3 if (k.startswith("inf_net_image.location.fc1") or k.startswith("inf_net_image.gate_affine_transform")) else 3e-4
+        assert err <= tol, (k, err)
+    e16, ws16, s16 = out["bf16"]
+    assert not any(e16.lstm_seq_errors()) and sum(int(s[0].item()) >= 1 for s in e16.seq_syncs) == 12      # 4 + 2 forward, 4 + 2 backward
+    for k in ("nmt", "td_kl_before", "elbo"):
+        assert abs(s16[k] - s32[k]) <= 5e-3 * abs(s32[k]), (k, s16[k], s32[k])
+    g32, g16 = e32.flat_g[:e32.n_opt].double(), e16.flat_g[:e16.n_opt].double()
+    assert ((g16 - g32).norm() / g32.norm()).item() <= 3e-2

@@ -135,9 +135,15 @@ def test_conditional_step_matches_oracle_and_reference(name, dtype):
     img = bt["table"][bt["indices"]]
     r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], img_semantic="B", tgt_len=bt["tgt_len"])
     H, Tp = c.hid, T - 1
-    tctx = ws.enct_out[-1].view().float().view(B, T, H).transpose(0, 1)          # rows b*T+t -> [T,B,H]
+    # encoder_tgt's output and h_y as computed: [fwd : htp | bwd : htp] (engine.Dims.htp; htp == hid / 2 unless the hidden size is padded)
+    ht, htp, hp = c.hid // 2, e.d.htp, e.d.hp
+    halves = lambda x: torch.cat([x[..., :ht], x[..., htp:htp + ht]], -1)
+    tctx = halves(ws.enct_out[-1].view().float().view(B, T, 2 * htp)).transpose(0, 1)          # rows b*T+t -> [T,B,H]
     _cmp("tgt_context", tctx, r["tgt_context"], tol["act"], False)
-    _cmp("hy", ws.hq.view()[:, H:2 * H], r["hy"], tol["act"], False)
+    _cmp("hy", halves(ws.hq.view()[:, hp:hp + 2 * htp]), r["hy"], tol["act"], False)
+    if e.d.pad:          # the padding of every range of the q-network input holds zeros
+        hqv = ws.hq.view()
+        assert (hqv[:, H:hp] == 0).all() and (hqv[:, hp + ht:hp + htp] == 0).all() and (hqv[:, hp + htp + ht:hp + 2 * htp] == 0).all()
     _cmp("mu_p", ws.mu_p.view(), r["mu_p"], tol["act"], False)
     _cmp("sigma_p", ws.sigma_p.view(), r["sigma_p"], tol["act"], False)
     _cmp("mu", ws.mu.view(), r["mu"], tol["act"] * 2, False)

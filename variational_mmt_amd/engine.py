@@ -51,10 +51,14 @@ class Dims(object):
         # g * hp) with zeros in the padding: shadows are packed gate block by gate block, pre-activations / h / c / every gradient
         # are exactly zero in padded lanes (sigmoid(0) * tanh(0)), and gradients are stored back through the block map of
         # vmmt_gemm_args.c_row_blk.  The arena, the state dict, checkpoints, Adam and the all-reduce keep the reference shapes.
-        # (bidirectional / conditional models with an odd per-direction size keep the general kernels.)
-        self.pad = (not self.brnn) and (not self.conditional) and hid % 32 != 0 and _os_env.get("VMMT_PAD_HIDDEN", "1") == "1"
+        # (a bidirectional ENCODER with an odd per-direction size keeps the general kernels.)  The conditional model's encoder_tgt is
+        # always bidirectional with hid / 2 units per direction (250 -> 256): its output is laid out [fwd | pad | bwd | pad], 2 * htp
+        # wide, and feeds the posterior network's input [h_x : hp | h_y : 2 htp | v : img] (qin_p columns).
+        self.pad = (not self.brnn) and hid % 32 != 0 and _os_env.get("VMMT_PAD_HIDDEN", "1") == "1"
         self.hp = _ru(hid, 32) if self.pad else hid
         self.hdp = self.hp // self.dirs
+        self.htp = _ru(self.ht, 32) if self.pad else self.ht
+        self.qin_p = (self.hp + 2 * self.htp + img) if self.conditional else self.hp
         self.zp = _ru(z, 128)                       # tiled latent size of the fused q(z|x) kernel (Z_valid = z)
 
     def param_shapes(self):
@@ -400,22 +404,30 @@ class Engine(object):
             shadow("wo", d.hid, 2 * d.hp, "decoder.attn.linear_out.weight", c0=0, ncols=d.hid)
             shadow("wo", d.hid, 2 * d.hp, "decoder.attn.linear_out.weight", c0=d.hid, ncols=d.hid, col_off=d.hp)
         for br in ("location", "scale"):
-            shadow("q_%s_w1" % br, d.z, d.qin, "inf_net_global.%s.fc1.weight" % br)
+            if d.conditional and d.pad:
+                # W1 [Z][h_x (H) | h_y (2 ht) | v] against the padded input [h_x : hp | h_y fwd : htp | h_y bwd : htp | v]
+                for c0, nc, co in ((0, d.hid, 0), (d.hid, d.ht, d.hp), (d.hid + d.ht, d.ht, d.hp + d.htp), (2 * d.hid, d.img, d.hp + 2 * d.htp)):
+                    shadow("q_%s_w1" % br, d.z, d.qin_p, "inf_net_global.%s.fc1.weight" % br, c0=c0, ncols=nc, col_off=co)
+            else:
+                shadow("q_%s_w1" % br, d.z, d.qin, "inf_net_global.%s.fc1.weight" % br)
             shadow("q_%s_w2" % br, d.z, d.zp, "inf_net_global.%s.fc2.weight" % br)     # (read d.zp columns wide by the fused q(z|x) kernel)
         if d.conditional:
             for br in ("location", "scale"):
                 shadow("p_%s_w1" % br, d.z, d.hid, "gen_net_global.%s.fc1.weight" % br)
                 shadow("p_%s_w2" % br, d.z, d.z, "gen_net_global.%s.fc2.weight" % br)
+            gt = (d.ht, d.htp)
             for l in range(d.layers):
-                i = d.emb if l == 0 else d.hid
                 for k, suf in enumerate(("", "_reverse")):
-                    shadow("enct_wih_l%d" % l, 2 * 4 * d.ht, i, "encoder_tgt.rnn.weight_ih_l%d%s" % (l, suf), row_off=k * 4 * d.ht)
-                    shadow("enct_b_l%d" % l, 1, 2 * 4 * d.ht, "encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf), dtype=torch.float32,
-                           src2="encoder_tgt.rnn.bias_hh_l%d%s" % (l, suf))
-                    code, sp, s2, lds, dst, ldd, R, Cc, tr = self.pack_calls[-1]
-                    self.pack_calls[-1] = (code, sp, s2, lds, self.sh["enct_b_l%d" % l].p(0, k * 4 * d.ht), ldd, R, Cc, tr)
-                    shadow("enct_whh_l%d_d%d" % (l, k), 4 * d.ht, d.ht, "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf))
-                    shadow("enct_whhT_l%d_d%d" % (l, k), d.ht, 4 * d.ht, "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf), transpose=True)
+                    nm = "encoder_tgt.rnn.weight_ih_l%d%s" % (l, suf)
+                    if l == 0 or d.htp == d.ht:
+                        shadow("enct_wih_l%d" % l, 2 * 4 * d.htp, d.emb if l == 0 else d.hid, nm, row_off=k * 4 * d.htp, gate=gt)
+                    else:       # the layer below delivers [fwd : htp | bwd : htp]
+                        shadow("enct_wih_l%d" % l, 2 * 4 * d.htp, 2 * d.htp, nm, row_off=k * 4 * d.htp, gate=gt, c0=0, ncols=d.ht)
+                        shadow("enct_wih_l%d" % l, 2 * 4 * d.htp, 2 * d.htp, nm, row_off=k * 4 * d.htp, gate=gt, c0=d.ht, ncols=d.ht, col_off=d.htp)
+                    shadow("enct_b_l%d" % l, 1, 2 * 4 * d.htp, "encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf), dtype=torch.float32,
+                           src2="encoder_tgt.rnn.bias_hh_l%d%s" % (l, suf), col_off=k * 4 * d.htp, gate=gt)
+                    shadow("enct_whh_l%d_d%d" % (l, k), 4 * d.htp, d.ht, "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf), gate=gt)
+                    shadow("enct_whhT_l%d_d%d" % (l, k), d.ht, 4 * d.htp, "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf), transpose=True, gate=gt)
         shadow("iv_w1", d.img, d.z, "inf_net_image.location.fc1.weight")
         shadow("iv_w2", d.img, d.img, "inf_net_image.location.fc2.weight")
         shadow("wg", d.vt, d.hid, "generator.0.weight")
@@ -1149,9 +1161,9 @@ class Workspace(object):
                 e._gemm(P, L.GEMM_NN, dy.p(), dy.ld, w2q.p(), w2q.ld, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, Z)
                 e._call(P, lib.vmmt_act_bwd, dt, L.ACT_RELU, self.q_dh1[br].p(), self.q_dh1[br].ld, 0, self.q_h1[br].p(), self.q_h1[br].ld,
                         None, 0, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z)
-                if d.conditional:           # columns [H, 2H) of W1
+                if d.conditional:           # the h_y columns of W1: [H, 2H) as stored, [Hp, Hp + 2 htp) as computed
                     w1q = e.sh["q_%s_w1" % br]
-                    e._gemm(P, L.GEMM_NN, self.q_dh1[br].p(), self.q_dh1[br].ld, w1q.p(0, H), w1q.ld, self.dhy.p(), self.dhy.ld, B, H, Z,
+                    e._gemm(P, L.GEMM_NN, self.q_dh1[br].p(), self.q_dh1[br].ld, w1q.p(0, Hp), w1q.ld, self.dhy.p(), self.dhy.ld, B, 2 * d.htp, Z,
                             accumulate=1 if i else 0)
 
             def weight_grads(part, br, dy):
@@ -1160,8 +1172,14 @@ class Workspace(object):
                     e._gemm(P, L.GEMM_TN, dy.p(), dy.ld, self.q_h1[br].p(), self.q_h1[br].ld, e.gp(pre + ".fc2.weight"), Z, Z, Z, B, out_f32=1, split_k=-1)
                     e._call(P, lib.vmmt_colsum, dt, dy.p(), dy.ld, B, Z, 0, 0, e.gp(pre + ".fc2.bias"), None)
                 else:
-                    e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, qx.p(), qx.ld, e.gp(pre + ".fc1.weight"), d.qin,
-                            Z, d.qin, B, out_f32=1, split_k=-1)
+                    if d.conditional and d.pad:
+                        # dW1 piece by piece: the input's column ranges are padded each to its own width (h_x : Hp, h_y : 2 x htp, v)
+                        for c0, nc, co, cm in ((0, H, 0, None), (H, 2 * d.htp, Hp, (d.htp, d.ht)), (2 * H, D, Hp + 2 * d.htp, None)):
+                            e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, qx.p(0, co), qx.ld, e.gp(pre + ".fc1.weight", 0, c0), d.qin,
+                                    Z, nc, B, out_f32=1, split_k=-1, cmap=cm)
+                    else:
+                        e._gemm(P, L.GEMM_TN, self.q_dh1[br].p(), self.q_dh1[br].ld, qx.p(), qx.ld, e.gp(pre + ".fc1.weight"), d.qin,
+                                Z, d.qin, B, out_f32=1, split_k=-1)
                     e._call(P, lib.vmmt_colsum, dt, self.q_dh1[br].p(), self.q_dh1[br].ld, B, Z, 0, 0, e.gp(pre + ".fc1.bias"), None)
 
             if cond_first:
@@ -1532,6 +1550,8 @@ class Workspace(object):
         T, dev = e.T, e.dev
         f32, i64 = torch.float32, torch.int64
         B, H, ht, E, Z, Lyr = self.B, d.hid, d.ht, d.emb, d.z, d.layers
+        htp = d.htp
+        Ht = 2 * htp                       # encoder_tgt's output as computed: [fwd : htp | bwd : htp] (Dims.htp)
         Tn = self.Tp + 1
         MT = B * Tn
         self.Tn, self.MT = Tn, MT
@@ -1539,14 +1559,14 @@ class Workspace(object):
         self.tgt_bt = torch.zeros(MT, dtype=i64, device=dev)
         self.tgt_len = torch.zeros(B, dtype=i64, device=dev)
         self.Yt = nb(MT, E)
-        self.enct_gx = [nb(MT, 8 * ht, f32) for _ in range(Lyr)]
-        self.enct_gates = [nb(MT, 8 * ht) for _ in range(Lyr)]
-        self.enct_c = [nb(MT, H, f32) for _ in range(Lyr)]
-        self.enct_out = [nb(MT, H) for _ in range(Lyr)]
-        self.enct_mask = [nb(MT, H) if (d.dropout > 0 and l < Lyr - 1) else None for l in range(Lyr)]
-        self.enct_xdrop = [nb(MT, H) if (d.dropout > 0 and l < Lyr - 1) else None for l in range(Lyr)]
-        self.enct_hzero = nb(Tn, H)
-        self.hq = nb(B, d.qin)
+        self.enct_gx = [nb(MT, 8 * htp, f32) for _ in range(Lyr)]
+        self.enct_gates = [nb(MT, 8 * htp) for _ in range(Lyr)]
+        self.enct_c = [nb(MT, Ht, f32) for _ in range(Lyr)]
+        self.enct_out = [nb(MT, Ht) for _ in range(Lyr)]
+        self.enct_mask = [nb(MT, Ht) if (d.dropout > 0 and l < Lyr - 1) else None for l in range(Lyr)]
+        self.enct_xdrop = [nb(MT, Ht) if (d.dropout > 0 and l < Lyr - 1) else None for l in range(Lyr)]
+        self.enct_hzero = nb(Tn, Ht)
+        self.hq = nb(B, d.qin_p)
         self.mu_p = nb(B, Z, f32, ld=Z)
         self.sigma_p = nb(B, Z, f32, ld=Z)
         self.p_h1 = {br: nb(B, Z) for br in ("location", "scale")}
@@ -1554,16 +1574,17 @@ class Workspace(object):
         self.p_dpre = nb(B, Z)
         self.p_dh1 = {br: nb(B, Z) for br in ("location", "scale")}
         self.dhbar_p = nb(B, H)
-        self.dhy = nb(B, H)
-        self.enct_dout = nb(MT, H)
-        self.enct_dgates = [nb(MT, 8 * ht) for _ in range(Lyr)]
-        self.enct_dcc = [nb(Tn, H, f32) for _ in range(Lyr)]
-        self.enct_dx = [nb(MT, H) for _ in range(Lyr - 1)]
+        self.dhy = nb(B, Ht)
+        self.enct_dout = nb(MT, Ht)
+        self.enct_dgates = [nb(MT, 8 * htp) for _ in range(Lyr)]
+        self.enct_dcc = [nb(Tn, Ht, f32) for _ in range(Lyr)]
+        self.enct_dx = [nb(MT, Ht) for _ in range(Lyr - 1)]
 
     def _cond_forward_aux(self, P, training):
         """aux stream: encoder_tgt over the transposed target (B recurrent steps with T rows each; Models.py:892-894)"""
         e, d, lib = self.e, self.e.d, self.e.lib
-        B, S, H, ht, E, Z, D, Lyr = self.B, self.S, d.hid, d.ht, d.emb, d.z, d.img, d.layers
+        B, S, H, E, Z, D, Lyr = self.B, self.S, d.hid, d.emb, d.z, d.img, d.layers
+        ht = d.htp                         # (per-direction size AS COMPUTED: every offset / kernel size below is in the padded layout)
         Tn, MT = self.Tn, self.MT
         dt = e.dt
         drop = training and d.dropout > 0
@@ -1603,24 +1624,25 @@ class Workspace(object):
                     a.h_out, a.ld_h = self.enct_out[l].p(t * Tn, k * ht), self.enct_out[l].ld
                     a.t, a.capture = t, 0
             e._lstm_seq_fwd(P, arr, 2, B, None, Tn, ht)
-            x, xcols = self.enct_out[l], H
+            x, xcols = self.enct_out[l], 2 * ht
             if l < Lyr - 1 and drop:
                 e._call(P, lib.vmmt_mul, dt, self.enct_out[l].p(), self.enct_out[l].ld, self.enct_mask[l].p(), self.enct_mask[l].ld,
-                        self.enct_xdrop[l].p(), self.enct_xdrop[l].ld, MT, H)
+                        self.enct_xdrop[l].p(), self.enct_xdrop[l].ld, MT, 2 * ht)
                 x = self.enct_xdrop[l]
         e._record(P, "enct_done")
 
     def _cond_forward(self, P, training, ctx):
         """main stream: h_x, h_y, v -> p(z|x) and q(z|x,y,v)  (Models.py:883-914)"""
         e, d, lib = self.e, self.e.d, self.e.lib
-        B, S, H, ht, E, Z, D, Lyr = self.B, self.S, d.hid, d.ht, d.emb, d.z, d.img, d.layers
+        B, S, H, E, Z, D, Lyr = self.B, self.S, d.hid, d.emb, d.z, d.img, d.layers
+        Hp, Ht = d.hp, 2 * d.htp            # column ranges of the q-network input as computed: [h_x : Hp | h_y : Ht | v : D]
         Tn, MT = self.Tn, self.MT
         dt = e.dt
         MAIN = 0
         e._sid = MAIN
         # [h_x ; h_y ; v]: the two means are written straight into their column ranges of the q-network input
         e._call(P, lib.vmmt_masked_mean, dt, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.hq.p(0, 0), self.hq.ld, B, S, H)
-        e._call(P, lib.vmmt_pack, dt, self.img.p(), None, self.img.ld, self.hq.p(0, 2 * H), self.hq.ld, B, D, 0)
+        e._call(P, lib.vmmt_pack, dt, self.img.p(), None, self.img.ld, self.hq.p(0, Hp + Ht), self.hq.ld, B, D, 0)
         # p(z|x) = gen_net_global(h_x) (the values of h_x are those of the detached copy)
         for br, outb, act in (("location", self.mu_p, L.ACT_NONE), ("scale", self.sigma_p, L.ACT_SOFTPLUS)):
             w1, w2 = e.sh["p_%s_w1" % br], e.sh["p_%s_w2" % br]
@@ -1630,7 +1652,7 @@ class Workspace(object):
                     addend=e.pp("gen_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
         e._wait(P, "enct_done")
         e._call(P, lib.vmmt_masked_mean_bm, dt, self.enct_out[Lyr - 1].p(), self.enct_out[Lyr - 1].ld, self.tgt_len.data_ptr(),
-                self.hq.p(0, H), self.hq.ld, B, Tn, H)
+                self.hq.p(0, Hp), self.hq.ld, B, Tn, Ht)
         # q(z|x,y,v) sits on the step's critical path (behind encoder_tgt's recurrence) and its two branches are 16-workgroup products over
         # K = 2H + D: the scale branch runs on the side stream next to the location branch (as in the fixed-prior model's unfused path)
         par = bool(e.q_parallel and e.use_side_stream)
@@ -1641,7 +1663,7 @@ class Workspace(object):
             if par and br == "scale":
                 e._sid = 1
                 e._wait(P, "hq_ready")
-            e._gemm(P, L.GEMM_NT, self.hq.p(), self.hq.ld, w1.p(), w1.ld, self.q_h1[br].p(), self.q_h1[br].ld, B, Z, d.qin,
+            e._gemm(P, L.GEMM_NT, self.hq.p(), self.hq.ld, w1.p(), w1.ld, self.q_h1[br].p(), self.q_h1[br].ld, B, Z, d.qin_p,
                     addend=e.pp("inf_net_global.%s.fc1.bias" % br), ld_add=Z, add_rows=1, act=L.ACT_RELU)
             e._gemm(P, L.GEMM_NT, self.q_h1[br].p(), self.q_h1[br].ld, w2.p(), w2.ld, outb.p(), outb.ld, B, Z, Z,
                     addend=e.pp("inf_net_global.%s.fc2.bias" % br), ld_add=Z, add_rows=1, act=act, out_f32=1)
@@ -1677,11 +1699,13 @@ class Workspace(object):
         finished piece issued next to the rest was measured: 4.36 / 4.38 / 4.59 ms per step against 4.27 ms in one piece; every
         relaunch costs more than the shorter tail saves.)"""
         e, d, lib = self.e, self.e.d, self.e.lib
-        B, H, ht, E, Lyr = self.B, d.hid, d.ht, d.emb, d.layers
+        B, H, E, Lyr = self.B, d.hid, d.emb, d.layers
+        ht, ht_t = d.htp, d.ht              # per-direction size as computed / as stored in the arena
+        tmap = (ht, ht_t)                   # padded gate blocks -> nn.LSTM's rows; padded direction blocks -> the layer input's columns
         Tn, MT = self.Tn, self.MT
         dt = e.dt
         e._call(P, lib.vmmt_masked_mean_bwd, dt, self.dhy.p(), self.dhy.ld, self.tgt_len.data_ptr(), self.enct_dout.p(),
-                self.enct_dout.ld, B, Tn, H, 1, 0)
+                self.enct_dout.ld, B, Tn, 2 * ht, 1, 0)
         dh_above = self.enct_dout
         for l in reversed(range(Lyr)):
             dg = self.enct_dgates[l]
@@ -1708,26 +1732,27 @@ class Workspace(object):
             e._lstm_seq_bwd(P, arr, 2, B, None, Tn, ht)
             wih = e.sh["enct_wih_l%d" % l]
             if l > 0:
-                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, MT, H, 8 * ht)
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, MT, 2 * ht, 8 * ht)
                 if drop:
                     e._call(P, lib.vmmt_mul, dt, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, self.enct_mask[l - 1].p(),
-                            self.enct_mask[l - 1].ld, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, MT, H)
+                            self.enct_mask[l - 1].ld, self.enct_dx[l - 1].p(), self.enct_dx[l - 1].ld, MT, 2 * ht)
                 dh_above = self.enct_dx[l - 1]
             xin = (self.Yt if l == 0 else (self.enct_xdrop[l - 1] if drop else self.enct_out[l - 1]))
-            xcols = E if l == 0 else H
+            xcols_t = E if l == 0 else H                               # columns of weight_ih as stored ...
+            xcols, xmap = (E, None) if l == 0 else (2 * ht, tmap)      # ... and of the layer input as computed
             for k, suf in enumerate(("", "_reverse")):
                 gw = "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf)
                 if B > 1:
                     if k == 0:   # h_prev[t] = out[t-1]
-                        e._gemm(P, L.GEMM_TN, dg.p(Tn, k * 4 * ht), dg.ld, self.enct_out[l].p(0, k * ht), self.enct_out[l].ld, e.gp(gw), ht,
-                                4 * ht, ht, (B - 1) * Tn, out_f32=1, split_k=-1)
+                        e._gemm(P, L.GEMM_TN, dg.p(Tn, k * 4 * ht), dg.ld, self.enct_out[l].p(0, k * ht), self.enct_out[l].ld, e.gp(gw), ht_t,
+                                4 * ht, ht_t, (B - 1) * Tn, out_f32=1, split_k=-1, rmap=tmap)
                     else:        # h_prev[t] = out[t+1]
-                        e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * ht), dg.ld, self.enct_out[l].p(Tn, k * ht), self.enct_out[l].ld, e.gp(gw), ht,
-                                4 * ht, ht, (B - 1) * Tn, out_f32=1, split_k=-1)
-                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * ht), dg.ld, MT, 4 * ht, 0, 0, e.gp("encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf)),
-                        e.gp("encoder_tgt.rnn.bias_hh_l%d%s" % (l, suf)))
-                e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * ht), dg.ld, xin.p(), xin.ld, e.gp("encoder_tgt.rnn.weight_ih_l%d%s" % (l, suf)), xcols,
-                        4 * ht, xcols, MT, out_f32=1, split_k=-1)
+                        e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * ht), dg.ld, self.enct_out[l].p(Tn, k * ht), self.enct_out[l].ld, e.gp(gw), ht_t,
+                                4 * ht, ht_t, (B - 1) * Tn, out_f32=1, split_k=-1, rmap=tmap)
+                e._call(P, lib.vmmt_colsum, dt, dg.p(0, k * 4 * ht), dg.ld, MT, 4 * ht, ht if ht != ht_t else 0, ht_t,
+                        e.gp("encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf)), e.gp("encoder_tgt.rnn.bias_hh_l%d%s" % (l, suf)))
+                e._gemm(P, L.GEMM_TN, dg.p(0, k * 4 * ht), dg.ld, xin.p(), xin.ld, e.gp("encoder_tgt.rnn.weight_ih_l%d%s" % (l, suf)), xcols_t,
+                        4 * ht, xcols, MT, out_f32=1, split_k=-1, rmap=tmap, cmap=xmap)
             if l == 0:   # shared table (ModelConstructor.py:456-457): scatter-add next to the decoder's contribution; pad row skipped
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                         MT, E, 8 * ht, out_f32=1, scatter_ids=self.tgt_bt.data_ptr())
