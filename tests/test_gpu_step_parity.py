@@ -391,3 +391,40 @@ def test_conditional_step_with_persistent_recurrences_bf16():
         if d > 2e-3 * scale + 1e-9:                     # schedules differ by float-atomic order only
             bad.append(("schedules differ", k, d, scale))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,S,T,brnn,layers,hid", [
+    (1, 1, 2, True, 1, 32),        # one sentence, one source position, one decoder step (<s> -> </s>)
+    (1, 9, 7, False, 2, 20),       # a single sentence through the padded layout (hid 20 -> 32)
+    (3, 1, 5, True, 2, 32),        # source length 1 for every sentence: the attention distribution is a point mass
+    (4, 64, 3, False, 1, 64),      # the longest source the attention kernels take, next to a two-step target
+    (33, 5, 4, True, 1, 32),       # one sentence more than a 32-row group of the recurrence kernels
+])
+def test_minimal_and_extreme_shapes(dtype, B, S, T, brnn, layers, hid):
+    """edge shapes of a batch: a single sentence, a single position, the maximum source length, a batch just past a
+    row-group boundary -- forward, statistics and every gradient against the oracle"""
+    c = O.Cfg(vs=40, vt=45, emb=16, hid=hid, z=8, layers=layers, brnn=brnn)
+    p = O.init_params(c, seed=9)
+    bt = O.synth_batch(c, B, S, T, n_img=max(B, 4), seed=31 + B + S, fixed_len=(S == 1))
+    if S == 1:
+        bt["tgt_len"][:] = T
+    e = _engine(c, p, dtype)
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+    e.loss_backward(ws, normalization=B)
+    torch.cuda.synchronize()
+    img = bt["table"][bt["indices"]]
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"])
+    st = e.read_stats(ws)
+    tl, ta, tg = (3e-5, 3e-5, 4e-4) if dtype == "f32" else (5e-3, 3e-2, 6e-2)
+    assert abs(st["elbo"] - float(Lo["elbo"])) <= tl * abs(float(Lo["elbo"]))
+    assert st["n_words"] == Lo["n_words"]
+    _cmp("attn", ws.probs.view(ws.Tp, B, ws.S)[:T - 1, :, :S], r["attn"], ta, False)
+    if S == 1:
+        assert (ws.probs.view(ws.Tp, B, ws.S)[:T - 1, :, 0] == 1).all()
+    for k in g:
+        if "inf_net_image.location.fc1" in k or "gate_affine" in k:
+            continue
+        got, want = e.grads[k].cpu().double(), g[k].double()
+        assert (got - want).norm().item() <= tg * max(want.norm().item(), 1e-12), (k, (got - want).norm().item(), want.norm().item())

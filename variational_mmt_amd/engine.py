@@ -514,6 +514,9 @@ class Engine(object):
         return attached
 
     def _call(self, plan, fn, *args):
+        # plan entries are positional ctypes calls: at least the COUNT is checked against the declared signature when the plan is built
+        # (the stream is appended at run time), so that a kernel that gained an argument fails here and not as a shifted pointer
+        assert fn.argtypes is not None and len(args) + 1 == len(fn.argtypes), (fn.__name__, len(args) + 1, len(fn.argtypes))
         plan.append((fn, args, fn.__name__, None, self._sid))
 
     def _lstm_seq_fwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H):
