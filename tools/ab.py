@@ -14,11 +14,16 @@ for a in sys.argv[1:]:
         kv[k] = (v == "1") if v in ("0", "1") else v      # other values stay strings
     cfgs.append((name, kv))
 COND = os.environ.get("AB_CONDITIONAL", "0") == "1"
-d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.5, conditional=COND)
+SCRIPT = os.environ.get("AB_SCRIPT", "0") == "1"            # the run scripts' shape instead of BASELINE config 2
+BATCH = int(os.environ.get("AB_BATCH", "256"))
+if SCRIPT:
+    d = Dims(vs=30000, vt=30000, emb=500, hid=500, z=500, img=2048, layers=2, brnn=False, dropout=0.5, conditional=COND)
+else:
+    d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.5, conditional=COND)
 table = torch.rand(29000, d.img)
-bs = bench.make_batches(d, 256, 20, 21, 29000, 4, "cuda", 1)
+bs = bench.make_batches(d, BATCH, 20, 21, 29000, 4, "cuda", 1)
 engs = []
-TLEN = torch.full((256,), 21, dtype=torch.int64, device="cuda")
+TLEN = torch.full((BATCH,), 21, dtype=torch.int64, device="cuda")
 for name, kv in cfgs:
     e = Engine(d, dtype="bf16", device="cuda", seed=0)
     for k, v in kv.items():
@@ -41,7 +46,7 @@ def run_(e, n):
     for i in range(n):
         src, sl, tgt, idx, _tl = bs[i % 4]
         ws = e.forward(src, sl, tgt, idx, training=True, tgt_len=TLEN if COND else None)
-        e.loss_backward(ws, normalization=256, batch_global=256)
+        e.loss_backward(ws, normalization=BATCH, batch_global=BATCH)
         e.optim_step()
 
 for e in engs:

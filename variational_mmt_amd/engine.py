@@ -202,6 +202,7 @@ class Engine(object):
         self.lstm_db_in_gemm = _os_env.get("VMMT_LSTM_DB_IN_GEMM", "1") == "1"
         self.dec_grads_on_aux = _os_env.get("VMMT_DEC_GRADS_ON_AUX", "1") == "1"
         self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
+        self.bwd_layers_parallel = _os_env.get("VMMT_BWD_LAYERS_PARALLEL", "1") == "1"   # >= 2 layers: top encoder layer next to the lower decoder layers
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
@@ -1489,8 +1490,19 @@ class Workspace(object):
                 e._call(P, lib.vmmt_scatter_add_rows, self.dXs.p(), self.dXs.ld, self.src.data_ptr(), PAD,
                         e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E, MS, E)
 
+        # two or more layers: the TOP encoder layer's backward recurrence needs the top decoder layer's state gradients and d context
+        # only, not the lower decoder layers -- it runs on a stream of its own next to them (dec_l1 -> {dec_l0 || enc_l1} -> enc_l0
+        # instead of four recurrences in a row).  Two persistent launches share the chip only when their workgroups fit side by side
+        # (the scripts' batch of 40: 2 x 64 workgroups; at 256 sentences each launch fills the chip and they run one after the other
+        # as before)
+        par_top = bool(e.bwd_layers_parallel and Lyr >= 2 and not d.conditional and not rp and e.use_side_stream and e.use_aux_stream)
         for l in reversed(range(Lyr)):
-            e._sid = MAIN
+            on_tgt = par_top and l == Lyr - 1
+            e._sid = TGT if on_tgt else MAIN
+            if on_tgt:
+                e._wait(P, "dec_dg%d" % l)
+            elif par_top and l == Lyr - 2:
+                e._wait(P, "enc_top_dx")
             dg = self.enc_dgates[l]
             seq = (L.LstmDirBwd * (S * dirs))()
             for step in range(S):
@@ -1527,6 +1539,8 @@ class Workspace(object):
                     e._call(P, lib.vmmt_mul, dt, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, self.enc_mask[l - 1].p(),
                             self.enc_mask[l - 1].ld, self.enc_dx[l - 1].p(), self.enc_dx[l - 1].ld, MS, H)
                 dh_above = self.enc_dx[l - 1]
+            if on_tgt:
+                e._record(P, "enc_top_dx")
             e._sid = SIDE
             e._wait(P, "enc_dg%d" % l)
             enc_param_grads(l, [(0, S)] * dirs, l == 0)
