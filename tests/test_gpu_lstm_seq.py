@@ -20,7 +20,10 @@ def _engine(c, p, persistent, dropout=0.0):
 
 @pytest.mark.parametrize("hid,layers,brnn,B,S,T,cond", [(512, 1, True, 256, 20, 21, False), (256, 2, True, 70, 9, 12, False),
                                                         (128, 1, False, 33, 7, 8, False), (512, 2, False, 40, 6, 7, False),
-                                                        (128, 1, True, 24, 6, 9, True)])
+                                                        (128, 1, True, 24, 6, 9, True),
+                                                        # H = 1024 (BASELINE config 5's decoder; its encoder: 2 x 512): 64 unit slices per row
+                                                        # group, so 200 sentences run as two persistent launches of <= 128 rows
+                                                        (1024, 2, True, 200, 7, 6, False), (1024, 1, False, 40, 5, 6, False)])
 def test_persistent_recurrence_is_bit_identical_to_the_step_kernels(hid, layers, brnn, B, S, T, cond):
     c = O.Cfg(vs=97, vt=101, emb=64, hid=hid, z=32, layers=layers, brnn=brnn, conditional=cond)
     p = O.init_params(c, seed=3)
@@ -50,7 +53,11 @@ def test_persistent_recurrence_is_bit_identical_to_the_step_kernels(hid, layers,
     for i, (a, b) in enumerate(zip(*outs)):
         for k in a:
             for x, y in zip(a[k] if isinstance(a[k], list) else [a[k]], b[k] if isinstance(b[k], list) else [b[k]]):
-                assert torch.equal(x, y), ("persistent differs from per-step", i, k, (x.float() - y.float()).abs().max().item())
+                if hid <= 512:
+                    assert torch.equal(x, y), ("persistent differs from per-step", i, k, (x.float() - y.float()).abs().max().item())
+                else:       # H = 1024: another (equally valid) order of the f32 additions, see test_persistent_backward_recurrence_is_bit_identical
+                    d_ = (x.float() - y.float()).abs()
+                    assert d_.max().item() <= 2e-2 and d_.mean().item() <= 2e-4, ("persistent differs from per-step", i, k, d_.max().item(), d_.mean().item())
     assert not torch.equal(outs[1][0]["AH"], outs[1][1]["AH"])                              # the batches do differ
     for k in outs[1][0]:                                                                    # batch 0 again: same bits as the first time
         for x, y in zip(*(v[k] if isinstance(v[k], list) else [v[k]] for v in (outs[1][0], outs[1][3]))):
@@ -117,7 +124,7 @@ def _bwd_case(B, H, ndir, T, seed, lens_on):
 
 
 @pytest.mark.parametrize("B,H,ndir,T,lens_on", [(256, 512, 1, 20, False), (256, 256, 2, 20, True), (70, 128, 2, 9, True), (33, 64, 1, 7, False),
-                                                (40, 512, 1, 6, False)])
+                                                (40, 512, 1, 6, False), (128, 1024, 1, 8, False), (100, 1024, 1, 5, True)])
 def test_persistent_backward_recurrence_is_bit_identical(B, H, ndir, T, lens_on):
     """vmmt_lstm_seq_bwd against vmmt_lstm_chain_bwd on the same inputs (the training step's own backward inputs carry
     float-atomic noise, so the comparison is made at the kernel level): dgates of every step and the final dL/dc, bit for bit,
@@ -150,9 +157,18 @@ def test_persistent_backward_recurrence_is_bit_identical(B, H, ndir, T, lens_on)
             torch.cuda.synchronize()
             outs.append((dg.clone(), dcc.clone(), dh0.clone() if with_dh0 else torch.zeros(1)))
         assert int(sync[2].item()) == 0                              # every in-launch wait completed
-        assert torch.equal(outs[0][0], outs[1][0]), ("dgates differ", rep, (outs[0][0].float() - outs[1][0].float()).abs().max().item())
-        assert torch.equal(outs[0][1], outs[1][1]), ("dc carry differs", rep)
-        assert torch.equal(outs[0][2], outs[1][2]), ("dh0 differs", rep)
+        if H <= 512:
+            assert torch.equal(outs[0][0], outs[1][0]), ("dgates differ", rep, (outs[0][0].float() - outs[1][0].float()).abs().max().item())
+            assert torch.equal(outs[0][1], outs[1][1]), ("dc carry differs", rep)
+            assert torch.equal(outs[0][2], outs[1][2]), ("dh0 differs", rep)
+        else:
+            # H = 1024: the step kernels walk the reduction in chunks of 512 / 2048 with four partial sums each, the persistent kernel
+            # in four quarters of the whole length: the same numbers up to the order of the f32 additions (bf16 results within an ulp
+            # or two, a few steps deep)
+            for i, what in enumerate(("dgates", "dc carry", "dh0")):
+                a_, b_ = outs[0][i].float(), outs[1][i].float()
+                assert (a_ - b_).abs().max().item() <= 2e-2 * max(1.0, b_.abs().max().item()), (what, rep, (a_ - b_).abs().max().item())
+                assert (a_ - b_).abs().mean().item() <= 2e-4 * max(1.0, b_.abs().mean().item()) + 1e-5, (what, rep, (a_ - b_).abs().mean().item())
         assert not (outs[1][2] == -7.0).any()
         assert (outs[1][0][M:] == 3.0).all()                         # nothing written beyond the rows of the sequence
         if rep == 0:

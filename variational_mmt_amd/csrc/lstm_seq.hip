@@ -179,8 +179,10 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
       for (int j = 0; j < 16; ++j) {
         const int r = wave + 4 * j;
         const long row = (long)(r >> 4) * H + u0 + (r & 15);
-        __builtin_amdgcn_global_load_lds((glb_cvoid_seq*)(wp + row * d0.ld_w * 2 + ((lane ^ Cf::key(r)) * 16)),
-                                         (lds_void_seq*)(lds + r * ROWB), 16, 0, 0);
+#pragma unroll
+        for (int pc = 0; pc < Cf::PIECES; ++pc)        // rows longer than 1 KiB (H = 1024): one LDS-DMA instruction per 1-KiB piece
+          __builtin_amdgcn_global_load_lds((glb_cvoid_seq*)(wp + row * d0.ld_w * 2 + (((pc * 64 + lane) ^ Cf::key(r)) * 16)),
+                                           (lds_void_seq*)(lds + r * ROWB + pc * 1024), 16, 0, 0);
       }
     }
   }
@@ -796,7 +798,7 @@ extern "C" int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lst
   if (nsteps < 0 || !dirs || ndir < 1 || ndir > 2 || B <= 0 || H <= 0) return VMMT_EINVAL;
   if (nsteps == 0) return VMMT_OK;
   const int ngroups = (B + 31) / 32;
-  bool ok = dtype == VMMT_BF16 && dirs_dev && sync && xchg && (((uintptr_t)xchg) & 15) == 0 && (H == 64 || H == 128 || H == 256 || H == 512) &&
+  bool ok = dtype == VMMT_BF16 && dirs_dev && sync && xchg && (((uintptr_t)xchg) & 15) == 0 && (H == 64 || H == 128 || H == 256 || H == 512 || H == 1024) &&
             (long)ngroups * (H / 16) * ndir <= 256 && nsteps >= 2 && nsteps < 4095;
   for (int i = 0; ok && i < nsteps; ++i)
     for (int k = 0; ok && k < ndir; ++k) {
@@ -814,6 +816,7 @@ extern "C" int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lst
   a.xchg = reinterpret_cast<unsigned long long*>(xchg);
   a.B = B; a.nsteps = nsteps; a.ndir = ndir; a.ngroups = ngroups;
   switch (H) {
+    case 1024: return launch_seq_fwd<1024>(a, (hipStream_t)stream);
     case 512: return launch_seq_fwd<512>(a, (hipStream_t)stream);
     case 256: return launch_seq_fwd<256>(a, (hipStream_t)stream);
     case 128: return launch_seq_fwd<128>(a, (hipStream_t)stream);
@@ -838,7 +841,7 @@ extern "C" int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lst
   if (nsteps < 0 || !dirs || ndir < 1 || ndir > 2 || B <= 0 || H <= 0) return VMMT_EINVAL;
   if (nsteps == 0) return with_dh0 ? VMMT_EINVAL : VMMT_OK;
   const int ngroups = (B + 31) / 32;
-  bool ok = dtype == VMMT_BF16 && dirs_dev && sync && xchg && (((uintptr_t)xchg) & 15) == 0 && (H == 64 || H == 128 || H == 256 || H == 512) &&
+  bool ok = dtype == VMMT_BF16 && dirs_dev && sync && xchg && (((uintptr_t)xchg) & 15) == 0 && (H == 64 || H == 128 || H == 256 || H == 512 || H == 1024) &&
             (long)ngroups * (H / 16) * ndir <= 256 && nsteps >= 2 && nsteps < 4094;
   for (int i = 0; ok && i < nsteps; ++i)
     for (int k = 0; ok && k < ndir; ++k) {
@@ -868,6 +871,7 @@ extern "C" int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lst
   a.xchg = reinterpret_cast<unsigned long long*>(xchg);
   a.B = B; a.nsteps = nsteps; a.ndir = ndir; a.ngroups = ngroups;
   switch (H) {
+    case 1024: return launch_seq_bwd<1024>(a, (hipStream_t)stream);
     case 512: return launch_seq_bwd<512>(a, (hipStream_t)stream);
     case 256: return launch_seq_bwd<256>(a, (hipStream_t)stream);
     case 128: return launch_seq_bwd<128>(a, (hipStream_t)stream);

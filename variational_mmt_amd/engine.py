@@ -520,10 +520,48 @@ class Engine(object):
         assert fn.argtypes is not None and len(args) + 1 == len(fn.argtypes), (fn.__name__, len(args) + 1, len(fn.argtypes))
         plan.append((fn, args, fn.__name__, None, self._sid))
 
+    # pointer fields of the step descriptors that walk the batch: (pointer, leading dimension, element size; None = the storage type T)
+    _SEQ_F = (("h_prev", "ld_hprev", None), ("c_prev", "ld_cprev", 4), ("gx", "ld_gx", 4), ("gx2", "ld_gx2", 4), ("gates", "ld_gates", None),
+              ("c_out", "ld_c", 4), ("h_out", "ld_h", None), ("h_n", "ld_hn", None), ("c_n", "ld_cn", 4))
+    _SEQ_B = (("dgates_next", "ld_dgn", None), ("dh_above", "ld_dha", None), ("gates", "ld_gates", None), ("c_t", "ld_ct", 4), ("c_prev", "ld_cp", 4),
+              ("dc_carry", "ld_dcc", 4), ("dgates_out", "ld_dgo", None), ("dh_n", "ld_dhn", 4), ("dc_n", "ld_dcn", 4), ("dh0_out", "ld_dh0", 4))
+
+    def _seq_row_chunks(self, arr, fields, ndir, B, H):
+        """A persistent recurrence needs all of its workgroups resident at once: (B / 32 row groups) x (H / 16 unit slices) x directions
+        <= 256.  Sentences are independent in a recurrence, so a batch that does not fit is cut into ROW chunks, one persistent launch
+        each, one after the other (BASELINE config 5: H = 1024 -> 64 slices -> 128 sentences per launch; the per-step kernels it
+        replaces re-read their W_hh slice from L2 at every step: 35 us per backward step against 8).  -> [(descriptors, row offset,
+        rows)], or None when the persistent kernel does not serve this size at all."""
+        if H not in (64, 128, 256, 512, 1024):
+            return None
+        groups = 256 // ((H // 16) * ndir)
+        if groups < 1:
+            return None
+        rows = 32 * groups
+        if B <= rows:
+            return [(arr, 0, B)]
+        out = []
+        n = len(arr)
+        for r0 in range(0, B, rows):
+            chunk = (type(arr[0]) * n)()
+            C.memmove(chunk, arr, C.sizeof(arr))
+            for a in chunk:
+                for ptr, ld, esz in fields:
+                    p0 = getattr(a, ptr)
+                    if p0:
+                        setattr(a, ptr, p0 + r0 * getattr(a, ld) * (esz if esz is not None else self.tsz))
+            out.append((chunk, r0, min(rows, B - r0)))
+        return out
+
     def _lstm_seq_fwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H):
         """plan entry: a whole forward recurrence (nsteps x ndir step descriptors in `arr`).  persistent_lstm: ONE launch of the
         persistent kernel (W_hh resident in LDS, in-launch hand-off of h_t: csrc/lstm_seq.hip), which falls back by itself to the
         per-step kernels where it does not apply; otherwise the per-step kernels issued from one host call."""
+        chunks = self._seq_row_chunks(arr, self._SEQ_F, ndir, B, H) if (self.persistent_lstm and self.dt == L.BF16) else None
+        if chunks is not None and len(chunks) > 1:
+            for sub, r0, rows in chunks:
+                self._lstm_seq_fwd(plan, sub, ndir, nsteps, (lens_ptr + 8 * r0) if lens_ptr else None, rows, H)
+            return
         if self.persistent_lstm:
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
             sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
@@ -537,6 +575,11 @@ class Engine(object):
     def _lstm_seq_bwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H, with_dh0=0):
         """plan entry: a whole backward recurrence (the mode-0 steps; with_dh0: `arr` ends with one mode-1 step, the gradient of
         the initial hidden state), see _lstm_seq_fwd"""
+        chunks = self._seq_row_chunks(arr, self._SEQ_B, ndir, B, H) if (self.persistent_lstm and self.dt == L.BF16) else None
+        if chunks is not None and len(chunks) > 1:
+            for sub, r0, rows in chunks:
+                self._lstm_seq_bwd(plan, sub, ndir, nsteps, (lens_ptr + 8 * r0) if lens_ptr else None, rows, H, with_dh0=with_dh0)
+            return
         if self.persistent_lstm:
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
             sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
