@@ -157,8 +157,9 @@ int vmmt_lstm_chain_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd
  * `dirs` = the nsteps x ndir step descriptors in HOST memory (validated here), `dirs_dev` = the same array in DEVICE memory
  * (read by the kernel); `sync` (vmmt_lstm_seq_sync_words() uint32: launch epoch, finish count, error code -- 0 = every wait
  * completed) and `xchg` (vmmt_lstm_seq_xchg_bytes() bytes, 16-byte aligned): device scratch private to the call site, zeroed
- * ONCE when allocated and then left alone.  Same semantics and BITS as vmmt_lstm_chain_fwd, which this call falls back to when
- * the persistent kernel does not apply (fp32, H not in {64,128,256,512}, more workgroups than CUs, unaligned rows, steps not
+ * ONCE when allocated and then left alone.  Same semantics and BITS as vmmt_lstm_chain_fwd (H = 1024: the same numbers up to the
+ * order of the f32 partial sums, <= 1 bf16 ulp), which this call falls back to when the persistent kernel does not apply (fp32, H not
+ * in {64,128,256,512,1024}, more workgroups than CUs -- (B / 32) (H / 16) ndir > 256: cut the batch into row chunks --, unaligned rows, steps not
  * chained h_prev[t] == h_out[t-1] / c_prev[t] == c_out[t-1]). */
 int vmmt_lstm_seq_sync_words(void);
 int64_t vmmt_lstm_seq_xchg_bytes(int ndir, int B, int H);
@@ -234,9 +235,9 @@ int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bia
                          const int64_t* y, int M, int V, int K, int pad, const float* lse, float inv_norm, void* GT,
                          int64_t ldgt, float* dbias, int v_off, void* stream);
 
-/* ---- the same loss with dL/dO in ONE sweep of Wg (csrc/generator_fused.hip; bf16, K = 512 or 256) --------------------
+/* ---- the same loss with dL/dO in ONE sweep of Wg (csrc/generator_fused.hip; bf16, K = 1024, 512 or 256) --------------
  * vmmt_gen_fwd_dO + vmmt_gen_fwd_combine replace vmmt_gen_loss_fwd + vmmt_gen_loss_bwd_db + the dO GEMM of the training step.
- *   vmmt_gen_fwd_dO: per 128-token block and vocabulary slice (vmmt-chosen: vmmt_gen_fused_geometry) a flash-attention-shaped sweep
+ *   vmmt_gen_fwd_dO: per 128-token block (64 at K = 1024) and vocabulary slice (vmmt-chosen: vmmt_gen_fused_geometry) a flash-attention-shaped sweep
  *     accumulates the softmax statistics and the un-normalised dO = sum_v P[m][v] Wg[v] into `ws`
  *     (vmmt_gen_fused_ws_floats(M, V, K) floats) and writes tgt_logit f32 [M].  W must be READABLE for w_rows >= (V rounded up to
  *     32) + 32 rows (the sweep prefetches whole 32-row tiles, one beyond the last; contents beyond V are ignored).  P != NULL (the training step): it also stores
@@ -254,7 +255,7 @@ int vmmt_gen_loss_bwd_db(int dtype, const void* W, int64_t ldw, const float* bia
  * Reference: the same lines as above (ModelConstructor.py:583-585, Loss.py:129,163-165). */
 int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M, int V, int K);
 int64_t vmmt_gen_fused_ws_floats(int M, int V, int K);
-int vmmt_gen_fused_geometry(int M, int V, int* nsplit, int* v_per_split, int64_t* mpad);
+int vmmt_gen_fused_geometry(int M, int V, int K, int* nsplit, int* v_per_split, int64_t* mpad);
 int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows, const float* bias, const void* O, int64_t ldo, const int64_t* y,
                     int M, int V, int K, float* ws, float* tgt_logit, void* P, int64_t ldp, void* stream);
 int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,

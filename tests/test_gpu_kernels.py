@@ -274,7 +274,9 @@ def test_generator_kernel_bf16(M, V, H):
 
 
 @pytest.mark.parametrize("M,V,H,ramp", [(5120, 3000, 512, 0.0), (200, 1000, 256, 0.0), (37, 515, 512, 0.0), (264, 130, 256, 0.0),
-                                        (300, 2100, 512, 0.09), (8, 67, 256, 0.0)])
+                                        (300, 2100, 512, 0.09), (8, 67, 256, 0.0),
+                                        # H = 1024: gen2w_kernel (two waves per 32 tokens, 64-token blocks)
+                                        (5200, 3000, 1024, 0.0), (37, 515, 1024, 0.0), (300, 2100, 1024, 0.09), (81, 67, 1024, 0.0)])
 def test_generator_fused_pass_bf16(M, V, H, ramp):
     """csrc/generator_fused.hip: vmmt_gen_fwd_dO (softmax statistics + dL/dO in one sweep of Wg, softmax weights P stored on the way),
     dL/dWg as the per-slice product of P with the scaled decoder outputs O'_s, and vmmt_gen_dW_finish (dL/db, one-hot term) against fp64
@@ -311,7 +313,7 @@ def test_generator_fused_pass_bf16(M, V, H, ramp):
     dO = torch.full((M, H + 4), 7.0, device="cuda"); st = torch.zeros(8, device="cuda")
     sc = inv_norm
     ns, vps, mpad = C.c_int(), C.c_int(), C.c_int64()
-    L.check(lib.vmmt_gen_fused_geometry(M, V, C.byref(ns), C.byref(vps), C.byref(mpad)), "geometry")
+    L.check(lib.vmmt_gen_fused_geometry(M, V, H, C.byref(ns), C.byref(vps), C.byref(mpad)), "geometry")
     ns, vps, mpad = ns.value, vps.value, mpad.value
     ldp = (V + 31) // 32 * 32 + 32
     Pw = torch.full((M + 2, ldp), 3.0, device="cuda", dtype=T)

@@ -49,6 +49,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef G2_PD
 #define G2_PD 6
 #endif
+#ifndef G2W_PD
+#define G2W_PD 4
+#endif
 #define G2_HB(i) ((i) >> 1)
 #define G2_KK(i) ((i) & 1)
 constexpr int G2_COMBINE_GROUPS = 1;          // groups of 8 tokens per workgroup of the combine kernel
@@ -478,6 +481,292 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   }
 }
 
+// ---- the same sweep at H = 1024 ------------------------------------------------------------------------------------------------
+// acc^T for 32 tokens x 1024 columns would be 512 accumulator registers per lane.  Here TWO waves share a group of 32 tokens: wave
+// (tg, dh) owns the columns [512 dh, 512 dh + 512) of acc^T (256 accumulator registers, as at H = 512) and -- the k range of S^T being
+// those same columns -- computes HALF of the reduction of S^T, from its half of the rows of the streamed tile and its half of O (32
+// k-steps, all in registers: 128).  The two partial S^T meet through 4 KiB of LDS per wave (a + b and b + a are the same number, so
+// both waves go on with bit-identical logits, statistics and softmax weights) and each wave runs the second product for its columns.
+// A workgroup is 2 token groups x 2 column halves = 64 tokens; a tile of Wg is 32 rows x 2 KiB = 64 KiB, the ring two of them.
+// Per wave and tile that is the H = 512 kernel's 32 + 32 MFMAs plus the exchange (one more barrier), for twice the L2 -> LDS bytes.
+struct G2W {
+  static constexpr int D = 1024, BC = 32, NSLOT = 2;
+  static constexpr int ROWB = 2048, TILEB = BC * ROWB;      // 64 KiB
+  static constexpr int PER = TILEB / 1024 / 4;              // 1-KiB LDS-DMA pieces per wave and tile: 16
+  static constexpr int KS = 32, HB = 16;                    // per wave: k-steps of its half of S^T, 32-column blocks of its half of acc^T
+  static constexpr int SMALLB = 4 * 256;
+  static constexpr int SOFF = NSLOT * TILEB;
+  static constexpr int EOFF = SOFF + NSLOT * SMALLB;        // exchange of the partial S^T: 4 KiB per wave
+  static constexpr int POFF = EOFF + 4 * 4096;
+  static constexpr int PPITCH = 80, PATCHB = 32 * PPITCH;
+  static constexpr int LDSB = POFF + 4 * PATCHB;
+  static_assert(LDSB <= 160 * 1024, "LDS of one CU");
+};
+
+__device__ __forceinline__ void g2_lds_write_b128(unsigned addr, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 g2_lds_read_f128(unsigned addr) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void g2_wait_lgkm_seg1(fs16x4& a, fs16x4& b, u32x4& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+}
+
+template <bool HASP>
+__global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
+  using C = G2W;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tg = wave >> 1, dh = wave & 1;                  // token group, column half
+  const int lane = threadIdx.x & 63, half = lane >> 5, r31 = lane & 31;
+  const int nwg = (int)gridDim.x, nblk = nwg / a.nsplit;
+  const int j = (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;     // see gen2_kernel
+  const int split = j / nblk, rt = j - split * nblk;
+  const int R0 = rt * 64 + tg * 32;                         // this wave pair's 32 rows
+  const int row = R0 + r31;
+  const int rowc = row < a.nrows ? row : a.nrows - 1;
+  const int ntall = (a.ncols + C::BC - 1) / C::BC;
+  const int t0 = split * a.tiles_per_split, t1 = min(ntall, t0 + a.tiles_per_split);
+
+  // LDS-DMA: piece jj (0..15) of this wave = the 1-KiB half (jj & 1) of row 4 (jj >> 1) + wave of the tile.  The row's swizzle is
+  // swz(row) = (wave << 2) | ((jj >> 1) & 3): four per-lane offsets serve all pieces; the rest of the address is uniform.
+  char* const small = smem + C::SOFF;
+  const unsigned voff0 = (unsigned)(((lane ^ (wave << 2)) & 63) * 16);        // (r & 3 enters as an XOR of bits 4-5)
+  const long row4 = 4 * a.ldy * 2, tile_step = (long)C::BC * a.ldy * 2;
+  const char* yt = reinterpret_cast<const char*>(a.Y + (long)(t0 * C::BC + wave) * a.ldy);       // row `wave` of the tile being fetched
+  auto issue_piece = [&](const char* yb, int t, int slot, int jj) {
+    if (jj < C::PER) {
+      const int r = jj >> 1, hp = jj & 1;
+      const char* src = yb + r * row4 + hp * 1024 + (voff0 ^ (unsigned)((r & 3) << 4));
+      __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)src, (f_lds_void_t*)(smem + slot * C::TILEB + (4 * r + wave) * C::ROWB + hp * 1024), 16, 0, 0);
+    } else {
+      int c = t * C::BC + r31;
+      c = c < a.ncols ? c : a.ncols - 1;
+      const void* src = (const void*)(a.cvec + c);
+      __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)src, (f_lds_void_t*)(small + slot * C::SMALLB + wave * 256), 4, 0, 0);
+    }
+  };
+  if (t0 < t1) {
+#pragma unroll
+    for (int jj = 0; jj <= C::PER; ++jj) issue_piece(yt, t0, 0, jj);
+  }
+
+  // resident operand: this wave's half of the k range, B-operand fragments (lane = row r31, k = 512 dh + 16 ks + 8 half + 0..7)
+  bf16x8 xf[C::KS];
+  {
+    const bf16_t* xr = a.X + (long)rowc * a.ldx + dh * 512 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 16);
+  }
+  f32x16 acc[C::HB];
+#pragma unroll
+  for (int hb = 0; hb < C::HB; ++hb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[hb][r] = 0.f;
+
+  // fragment addressing as in gen2_kernel, inside this wave's 1-KiB half of every row.  The register file is full (256 accumulators
+  // + 128 for X), so instead of eight + four + four per-lane offsets that flip with the ring slot there are three constants, and the
+  // fragment index e and the slot enter as ONE uniform XOR per read: ((2 e + half) ^ sw) * 16 = ((half ^ sw) * 16) ^ (e << 5),
+  // ((4 e + tw) ^ x) * 16 = ((tw ^ x) * 16) ^ (e << 6), slot = bit 16.
+  int ua0, ul0, uh0;
+  {
+    const int sw = g2_swz(r31);
+    ua0 = r31 * C::ROWB + dh * 1024 + ((half ^ sw) * 16);
+    const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, g1 = (lane >> 4) & 1;
+    const int tw = 2 * g1 + (p4 >> 1);
+    const int x_lo = (q << 2) | half, x_hi = (q << 2) | (half + 2);
+    ul0 = (4 * half + q) * C::ROWB + dh * 1024 + (p4 & 1) * 8 + ((tw ^ x_lo) * 16);
+    uh0 = (4 * half + q + 8) * C::ROWB + dh * 1024 + (p4 & 1) * 8 + ((tw ^ x_hi) * 16);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned ex_mine = lds0 + C::EOFF + wave * 4096 + lane * 16, ex_other = lds0 + C::EOFF + (wave ^ 1) * 4096 + lane * 16;
+  const float bsel = dh == 0 ? 1.f : 0.f;                   // the column constants enter through ONE of the two partial sums
+
+  float ref = -INFINITY, nrl = 0.f, lsum = 0.f, rmax = -INFINITY;
+  int ym = row < a.nrows ? (int)a.y[row] : -1;
+  asm volatile("" : "+v"(ym));
+
+  // (a wave none of whose 16 stored rows exists issues no store: it must not leave a DMA piece in flight instead)
+  const bool stores = HASP && R0 + 16 * dh < a.nrows;
+  for (int t = t0; t < t1; ++t) {
+    // tile t has landed (the only younger operation is the store of P behind the previous tile's last DMA piece)
+    if (stores) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int cur = (t - t0) & 1, sx = cur << 16;
+    const int tn = t + 1;
+    const char* yn = yt + tile_step;
+    const char* sb = small + cur * C::SMALLB + wave * 256;
+    const int c0 = t * C::BC;
+
+    // ---- this wave's half of S^T[c][r] = sum_h Y[c][h] X[r][h]
+    f32x16 sT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sb + (8 * i + 4 * half) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sT[4 * i + e] = v[e] * bsel;
+    }
+    {
+      constexpr int PD = G2W_PD;
+      bf16x8 fa[PD];
+      auto rd = [&](int ks) { fa[ks % PD] = *reinterpret_cast<const bf16x8*>(smem + (ua0 ^ (((ks & 7) << 5) | sx)) + (ks >> 3) * 256); };
+#pragma unroll
+      for (int ks = 0; ks < PD; ++ks) rd(ks);
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+        sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks % PD], xf[ks], sT, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + PD < C::KS) rd(ks + PD);
+        if ((ks & 3) == 1) issue_piece(yn, tn, cur ^ 1, ks >> 2);          // pieces 0..7; 8..15 ride in the second product
+        if (ks == 3) issue_piece(yn, tn, cur ^ 1, C::PER);
+      }
+    }
+    // ---- the partner's half
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g2_lds_write_b128(ex_mine + i * 1024, f32x4{sT[4 * i], sT[4 * i + 1], sT[4 * i + 2], sT[4 * i + 3]});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+      f32x4 o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = g2_lds_read_f128(ex_other + i * 1024);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sT[4 * i + e] += o[i][e];
+    }
+
+    constexpr int PD = 4, NM = C::HB * 2;
+    fs16x4 fl[PD], fh[PD];
+    auto rd = [&](auto ic) {
+      constexpr int i = decltype(ic)::value, hb = G2_HB(i), kk = G2_KK(i);
+      constexpr int off = (hb >> 2) * 256 + kk * 16 * C::ROWB;
+      fl[i % PD] = g2_tr_read<off>(lds0 + (ul0 ^ (((hb & 3) << 6) | sx)));
+      fh[i % PD] = g2_tr_read<off>(lds0 + (uh0 ^ (((hb & 3) << 6) | sx)));
+    };
+    g2_static_for<0, PD>([&](auto ic) { rd(ic); });
+
+    // ---- element-wise (both waves of the pair, on identical numbers)
+    bf16x8 pf[2];
+    u32x4 seg;
+    if (c0 + C::BC > a.ncols) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (c0 + (r & 3) + 8 * (r >> 2) + 4 * half >= a.ncols) sT[r] = -INFINITY;
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sT[r]), sT[r + 1]);
+    rmax = fmaxf(rmax, tmax);
+    if (__any(tmax > ref + G2_THR)) {
+      const float nm = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const bool mv = nm > ref + G2_THR;
+      const float f = mv ? __expf(ref - nm) : 1.f;
+      if (mv) { ref = nm; nrl = -nm * G2_L2E; }
+      lsum *= f;
+#pragma unroll
+      for (int hb = 0; hb < C::HB; ++hb) g2_scale_acc(acc[hb], f);
+      if (a.p_out && t > t0) {
+        // (practically never, see gen2_kernel)  Each wave rewrites the rows IT stored: tokens 16 dh .. 16 dh + 15 of the group
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (mv && row < a.nrows && (r31 >> 4) == dh) {
+          bf16_t* pr = a.p_out + (long)row * a.ldp;
+          for (int v = t0 * C::BC + half * 8; v < c0; v += 16) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = __hip_atomic_load(reinterpret_cast<uint32_t*>(pr + v) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = __uint_as_float(w[e] << 16) * f, hi = __uint_as_float(w[e] & 0xffff0000u) * f;
+              w[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+            }
+            *reinterpret_cast<u32x4*>(pr + v) = u32x4{w[0], w[1], w[2], w[3]};
+          }
+        }
+      }
+    }
+    if (__any(ym >= c0 && ym < c0 + C::BC)) {
+      float tl = 0.f;
+      bool hit = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool h = c0 + (r & 3) + 8 * (r >> 2) + 4 * half == ym;
+        tl = h ? sT[r] : tl;
+        hit = hit || h;
+      }
+      if (hit && dh == 0) a.tgt_logit[row] = tl;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[r], G2_L2E, nrl));
+      lsum += pv;
+      pf[r >> 3][r & 7] = (__bf16)pv;
+    }
+    if (HASP) {
+      // P[m][c0 .. c0+31] through the wave's [token][entry] patch (see gen2_kernel); wave dh stores the tokens 16 dh .. 16 dh + 15
+      const unsigned patch = lds0 + C::POFF + wave * C::PATCHB;
+      const unsigned wr = patch + r31 * C::PPITCH + 8 * half;
+      g2_lds_write_b64<0>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[0]), __builtin_bit_cast(fs16x8, pf[0]), 0, 1, 2, 3));
+      g2_lds_write_b64<16>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[0]), __builtin_bit_cast(fs16x8, pf[0]), 4, 5, 6, 7));
+      g2_lds_write_b64<32>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[1]), __builtin_bit_cast(fs16x8, pf[1]), 0, 1, 2, 3));
+      g2_lds_write_b64<48>(wr, __builtin_shufflevector(__builtin_bit_cast(fs16x8, pf[1]), __builtin_bit_cast(fs16x8, pf[1]), 4, 5, 6, 7));
+      const int q = lane + 64 * dh;
+      seg = g2_lds_read_b128(patch + (q >> 2) * C::PPITCH + (q & 3) * 16);
+    }
+
+    // ---- this wave's columns of acc^T[h][r] += sum_c Y[c][h] P[r][c]
+    {
+      g2_static_for<0, NM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        // younger LDS operations when MFMA i is due: see gen2_kernel (the patch: 4 writes + 1 read)
+        constexpr int inflight = i < PD ? 2 * (PD - 1) + (HASP ? 5 : 0) : 2 * ((PD - 1) < (NM - 1 - i) ? (PD - 1) : (NM - 1 - i));
+        static_assert(inflight <= 15, "lgkmcnt is a 4-bit counter");
+        if constexpr (i == PD && HASP) g2_wait_lgkm_seg1<inflight>(fl[i % PD], fh[i % PD], seg);
+        else g2_wait_lgkm<inflight>(fl[i % PD], fh[i % PD]);
+        const fs16x8 v = __builtin_shufflevector(fl[i % PD], fh[i % PD], 0, 1, 2, 3, 4, 5, 6, 7);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[G2_HB(i)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), pf[G2_KK(i)], acc[G2_HB(i)], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i + PD < NM) rd(std::integral_constant<int, i + PD>{});
+        if constexpr ((i & 3) == 1) issue_piece(yn, tn, cur ^ 1, 8 + (i >> 2));
+        if constexpr (i == NM - 2 && HASP) {
+          // behind the tile's last DMA piece: the wait at the top of the next tile may leave exactly this store in flight
+          const int q = lane + 64 * dh, prow = q >> 2, ch = q & 3;
+          if (R0 + prow < a.nrows) *reinterpret_cast<u32x4*>(a.p_out + (long)(R0 + prow) * a.ldp + c0 + ch * 8) = seg;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    }
+#pragma unroll
+    for (int hb = 0; hb < C::HB; ++hb) asm volatile("" : "+a"(acc[hb]));
+    yt = yn;
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (row < a.nrows) {
+    const long pr = (long)split * a.mpad + row;
+    float* dst = a.p_acc + pr * C::D + dh * 512;
+    const float lt = lsum + __shfl_xor(lsum, 32, 64), mt = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    if (half == 0 && dh == 0) { a.p_ref[pr] = ref; a.p_l[pr] = lt; a.p_max[pr] = mt; }
+#pragma unroll
+    for (int hb = 0; hb < C::HB; ++hb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[hb][4 * i + e];
+        *reinterpret_cast<f32x4*>(dst + 32 * hb + 8 * i + 4 * half) = v;
+      }
+  }
+}
+
 // combine of pass F: 8 tokens per workgroup (32 threads per token).  Folds the vocabulary slices' (ref, l, max, acc) and writes
 //   lse, tok_nll, the statistics (NLL, words, correct), y32 (targets as int32, -1 at pads; whole 32-token tiles),
 //   dO[m][h] = s_m (sum_s w_s acc_s[m][h] / l* - Wg[y_m][h]),  w_s = exp(ref_s - ref*).
@@ -675,20 +964,31 @@ __global__ void __launch_bounds__(256) gen2_onehot_kernel(const bf16_t* __restri
 
 // vocabulary slices of the forward sweep: about 256 workgroups in all, whole groups of 8 tiles (256 rows) per slice so that
 // a slice boundary is also a tile boundary of the dWg GEMM (vmmt_gemm_args.b_batch_rows)
-static int g2_tiles_per_split(int M, int V) {
+static int g2_tiles_per_split(int M, int V, int K) {
   const int nmt = (M + 127) / 128, ntiles = (V + 31) / 32;
   int ns = 256 / nmt;
+  if (K > 512) {
+    // 64-token blocks (gen2w_kernel): BASELINE config 5 has 260 of them, which no slice count turns into whole rounds of 256
+    // workgroups.  Cost of c slices in sweeps of the vocabulary: ceil(blocks c / 256) / c rounds + ~1 % per slice for its partials
+    // (measured there, ms per launch: 4 slices 4.13, 8: 4.05, 12: 4.51, 16: 4.45 -- with 8 every XCD streams exactly one slice)
+    const int nb = (M + 63) / 64;
+    double best = 1e30;
+    for (int c = 1; c <= 16; ++c) {
+      const double cost = (double)((nb * c + 255) / 256) / c + 0.012 * c;
+      if (cost < best - 1e-9) { best = cost; ns = c; }
+    }
+  }
   ns = ns < 1 ? 1 : ns > 16 ? 16 : ns;
   ns = ns > ntiles ? ntiles : ns;
   return ((ntiles + ns - 1) / ns + 7) / 8 * 8;
 }
-static int g2_nsplit(int M, int V) {
-  const int ntiles = (V + 31) / 32, tps = g2_tiles_per_split(M, V);
+static int g2_nsplit(int M, int V, int K) {
+  const int ntiles = (V + 31) / 32, tps = g2_tiles_per_split(M, V, K);
   return (ntiles + tps - 1) / tps;
 }
 
 static bool g2_applies(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, int M, int V, int K) {
-  return dtype == VMMT_BF16 && (K == 512 || K == 256) && M > 0 && V > 0 && ldw % 8 == 0 && ldo % 8 == 0 && ldw >= K && ldo >= K &&
+  return dtype == VMMT_BF16 && (K == 1024 || K == 512 || K == 256) && M > 0 && V > 0 && ldw % 8 == 0 && ldo % 8 == 0 && ldw >= K && ldo >= K &&
          ((((uintptr_t)W) | ((uintptr_t)O)) & 15) == 0;
 }
 
@@ -701,6 +1001,17 @@ static int g2_launch(const Gen2Args& a, int grid, hipStream_t st) {
     done = true;
   }
   hipLaunchKernelGGL((gen2_kernel<D, HASP>), dim3(grid), dim3(256), G2<D>::LDSB, st, a);
+  return check_launch();
+}
+
+template <bool HASP>
+static int g2w_launch(const Gen2Args& a, int grid, hipStream_t st) {
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)gen2w_kernel<HASP>, hipFuncAttributeMaxDynamicSharedMemorySize, G2W::LDSB) != hipSuccess) return VMMT_ELAUNCH;
+    done = true;
+  }
+  hipLaunchKernelGGL((gen2w_kernel<HASP>), dim3(grid), dim3(256), G2W::LDSB, st, a);
   return check_launch();
 }
 
@@ -719,13 +1030,13 @@ extern "C" int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M
 extern "C" int64_t vmmt_gen_fused_ws_floats(int M, int V, int K) {
   const int64_t mpad = (int64_t)((M + 127) / 128) * 128;
   // partial accumulators + (ref, l, max) per slice, + the combine kernel's per-wave statistics (2 x 3 floats per 8 tokens)
-  return (int64_t)vmmt::g2_nsplit(M, V) * mpad * (K + 3) + (mpad / 8 + 4) * 6;
+  return (int64_t)vmmt::g2_nsplit(M, V, K) * mpad * (K + 3) + (mpad / 8 + 4) * 6;
 }
 
-extern "C" int vmmt_gen_fused_geometry(int M, int V, int* nsplit, int* v_per_split, int64_t* mpad) {
-  if (M <= 0 || V <= 0 || !nsplit || !v_per_split || !mpad) return VMMT_EINVAL;
-  *nsplit = vmmt::g2_nsplit(M, V);
-  *v_per_split = vmmt::g2_tiles_per_split(M, V) * 32;
+extern "C" int vmmt_gen_fused_geometry(int M, int V, int K, int* nsplit, int* v_per_split, int64_t* mpad) {
+  if (M <= 0 || V <= 0 || K <= 0 || !nsplit || !v_per_split || !mpad) return VMMT_EINVAL;
+  *nsplit = vmmt::g2_nsplit(M, V, K);
+  *v_per_split = vmmt::g2_tiles_per_split(M, V, K) * 32;
   *mpad = (int64_t)((M + 127) / 128) * 128;
   return VMMT_OK;
 }
@@ -739,18 +1050,19 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows
   if (w_rows < (V + 31) / 32 * 32 + 32) return VMMT_EINVAL;          // the sweep prefetches one 32-row tile beyond the last one (unclamped)
   if (Pw && (ldp < (V + 31) / 32 * 32 || (ldp & 7) || (((uintptr_t)Pw) & 15))) return VMMT_EINVAL;
   if (!g2_applies(dtype, W, ldw, O, ldo, M, V, K)) return VMMT_EINVAL;
-  const int nmt = (M + 127) / 128, ns = g2_nsplit(M, V);
+  const int nmt = (M + 127) / 128, ns = g2_nsplit(M, V, K);
   const long mpad = (long)nmt * 128;
   Gen2Args a{};
   a.X = (const bf16_t*)O; a.ldx = ldo; a.nrows = M;
   a.Y = (const bf16_t*)W; a.ldy = ldw; a.ncols = V;
   a.cvec = bias; a.y = (const long long*)y;
-  a.nsplit = ns; a.tiles_per_split = g2_tiles_per_split(M, V);
+  a.nsplit = ns; a.tiles_per_split = g2_tiles_per_split(M, V, K);
   a.mpad = mpad;
   a.p_acc = ws; a.p_ref = ws + (long)ns * mpad * K; a.p_l = a.p_ref + (long)ns * mpad; a.p_max = a.p_l + (long)ns * mpad;
   a.tgt_logit = tgt_logit;
   a.p_out = (bf16_t*)Pw; a.ldp = ldp;
   hipStream_t st = (hipStream_t)stream;
+  if (K == 1024) return Pw ? g2w_launch<true>(a, (M + 63) / 64 * ns, st) : g2w_launch<false>(a, (M + 63) / 64 * ns, st);
   if (Pw) return K == 512 ? g2_launch<512, true>(a, nmt * ns, st) : g2_launch<256, true>(a, nmt * ns, st);
   return K == 512 ? g2_launch<512, false>(a, nmt * ns, st) : g2_launch<256, false>(a, nmt * ns, st);
 }
@@ -767,7 +1079,7 @@ extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const
   if (cs && (ldos < K || (ldos & 3) || (((uintptr_t)Os) & 7) || os_stride < (int64_t)M * ldos)) return VMMT_EINVAL;
   if (!g2_applies(dtype, W, ldw, O, ldo, M, V, K)) return VMMT_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int nmt = (M + 127) / 128, ns = g2_nsplit(M, V);
+  const int nmt = (M + 127) / 128, ns = g2_nsplit(M, V, K);
   const long mpad = (long)nmt * 128;
   const float* p_acc = ws;
   const float* p_ref = ws + (long)ns * mpad * K;
@@ -776,7 +1088,11 @@ extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const
   float* blk_part = ws + (long)ns * mpad * (K + 3);
   const int mt = (M + 31) / 32 * 32;
   const int ncb = (mt + 8 * G2_COMBINE_GROUPS - 1) / (8 * G2_COMBINE_GROUPS);
-  if (K == 512)
+  if (K == 1024)
+    hipLaunchKernelGGL((gen2_combine_kernel<1024>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
+                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
+                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride);
+  else if (K == 512)
     hipLaunchKernelGGL((gen2_combine_kernel<512>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
                        (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
                        (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride);
@@ -796,15 +1112,18 @@ extern "C" int vmmt_gen_dW_finish(int dtype, const void* Pw, int64_t ldp, const 
                                   int M, int V, int K, float inv_norm, float* dW, int64_t lddw, float* dbias, int colsum_done,
                                   void* stream) {
   using namespace vmmt;
-  if (dtype != VMMT_BF16 || !Pw || !cs || !O || !y32 || !dW || !dbias || M <= 0 || V <= 0 || (K != 512 && K != 256) || (ldp & 7) ||
+  if (dtype != VMMT_BF16 || !Pw || !cs || !O || !y32 || !dW || !dbias || M <= 0 || V <= 0 || (K != 1024 && K != 512 && K != 256) || (ldp & 7) ||
       (((uintptr_t)Pw) & 15) || lddw <= 0)
     return VMMT_EINVAL;          // (lddw < K: rows of dW narrower than the tiled width, e.g. H = 500 in K = 512 -- the one-hot kernel stops at lddw)
   hipStream_t st = (hipStream_t)stream;
   const long mpad = (long)((M + 127) / 128) * 128;
   if (!colsum_done)
     hipLaunchKernelGGL(gen2_db_kernel, dim3((V + 511) / 512, (M + 127) / 128), dim3(256), 0, st, (const bf16_t*)Pw, (long)ldp, cs, mpad,
-                       g2_tiles_per_split(M, V) * 32, M, V, dbias);
-  if (K == 512)
+                       g2_tiles_per_split(M, V, K) * 32, M, V, dbias);
+  if (K == 1024)
+    hipLaunchKernelGGL((gen2_onehot_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)O, (long)ldo, y32, inv_norm, M, dW,
+                       (long)lddw, dbias);
+  else if (K == 512)
     hipLaunchKernelGGL((gen2_onehot_kernel<512>), dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)O, (long)ldo, y32, inv_norm, M, dW,
                        (long)lddw, dbias);
   else

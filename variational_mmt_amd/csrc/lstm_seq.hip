@@ -784,7 +784,7 @@ static bool al16s(const void* p, long ld_elems) { return (((uintptr_t)p) & 15) =
 // descriptors in host and in device memory (step i = [i*ndir, (i+1)*ndir)); `sync` (vmmt_lstm_seq_sync_words() uint32) and `xchg`
 // (vmmt_lstm_seq_xchg_bytes(ndir, B, H) bytes): device scratch private to this call site, zeroed ONCE by the caller when it
 // allocates them and never touched by it again.  Same results as nsteps vmmt_lstm_step_fwd calls -- which is what this function
-// issues when the persistent kernel does not apply (fp32, H not in {64,128,256,512}, more workgroups than CUs, unaligned rows,
+// issues when the persistent kernel does not apply (fp32, H not in {64,128,256,512,1024}, more workgroups than CUs, unaligned rows,
 // or steps that are not chained h_prev[t] == h_out[t-1]).
 extern "C" int vmmt_lstm_seq_sync_words(void) { return 4 + 2 * 256; }   // epoch, finish count, error, pad; per group: arrivals, XCC mask
 extern "C" int64_t vmmt_lstm_seq_xchg_bytes(int ndir, int B, int H) {
@@ -826,7 +826,7 @@ extern "C" int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lst
 
 // Whole BACKWARD recurrence (mode 0 steps of vmmt_lstm_step_bwd) in one launch; same contract as vmmt_lstm_seq_fwd.  `xchg`:
 // vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H) bytes.  Falls back to vmmt_lstm_chain_bwd when the persistent kernel does not apply
-// (fp32, H not in {64,128,256,512}, more workgroups than CUs, unaligned rows, dgates_next[t] != dgates_out[t-1], a dc_carry
+// (fp32, H not in {64,128,256,512,1024}, more workgroups than CUs, unaligned rows, dgates_next[t] != dgates_out[t-1], a dc_carry
 // buffer that changes between steps).  A recurrence may be cut into several calls (the caller then runs the weight gradients of
 // the finished part next to the rest): step 0 of a later piece carries dgates_next = the last dgates_out of the piece before,
 // which is read from that plain buffer, and dc_carry is read at the first and written at the last step of every call.

@@ -864,7 +864,7 @@ class Workspace(object):
             self.gen_y32 = torch.zeros(_ru(M, 32), dtype=torch.int32, device=dev)
             self.GT = None
             ns, vps, mpad = C.c_int(), C.c_int(), C.c_int64()
-            L.check(eng.lib.vmmt_gen_fused_geometry(M, V, C.byref(ns), C.byref(vps), C.byref(mpad)), "vmmt_gen_fused_geometry")
+            L.check(eng.lib.vmmt_gen_fused_geometry(M, V, _ru(H, KPAD), C.byref(ns), C.byref(vps), C.byref(mpad)), "vmmt_gen_fused_geometry")
             self.gen_ns, self.gen_vps, self.gen_mpad = ns.value, vps.value, mpad.value
             Mk = _ru(M, KPAD) + KPAD
             self.gen_ldp = _ru(V, 32)
