@@ -1538,7 +1538,11 @@ class Workspace(object):
         # instead of four recurrences in a row).  Two persistent launches share the chip only when their workgroups fit side by side
         # (the scripts' batch of 40: 2 x 64 workgroups; at 256 sentences each launch fills the chip and they run one after the other
         # as before)
-        par_top = bool(e.bwd_layers_parallel and Lyr >= 2 and not d.conditional and not rp and e.use_side_stream and e.use_aux_stream)
+        # ... and ONLY then are they put on two streams: two persistent launches that start at the same moment without room for both
+        # could each get a part of their workgroups resident and wait for the rest until the in-launch waits time out.
+        seq_wgs = lambda hh, nd: min(256, -(-B // 32) * (hh // 16) * nd)
+        par_top = bool(e.bwd_layers_parallel and Lyr >= 2 and not d.conditional and not rp and e.use_side_stream and e.use_aux_stream
+                       and seq_wgs(Hdp, dirs) + seq_wgs(Hp, 1) <= 256)
         for l in reversed(range(Lyr)):
             on_tgt = par_top and l == Lyr - 1
             e._sid = TGT if on_tgt else MAIN
