@@ -383,14 +383,25 @@ int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const int64_t* sr
  * kernel applies it).  `scores` [B][K] in/out (Beam.scores), `cur_tok` [K*B] the tokens just fed (Beam.next_ys[-1]);
  * first != 0: only beam 0 is scored (Beam.py:91-92); mask_eos != 0: word_probs[:, eos] = -1e20 (min_length, Beam.py:77-80).
  * Outputs: next_tok [K*B] (next input rows), sel_rows [K*B] = parent row index prev_k*B + b (for vmmt_rows_select),
- * and this position's history slots hist_score / hist_prev / hist_next [B][K].  Ties: lowest flat index.  K <= 16. */
+ * and this position's history slots hist_score / hist_prev / hist_next [B][K].  Ties: lowest flat index.  K <= 16.
+ * `ws`: vmmt_beam_advance_ws_bytes(B, K, V) bytes of device scratch (per-chunk softmax statistics and candidates). */
+int64_t vmmt_beam_advance_ws_bytes(int B, int K, int V);
 int vmmt_beam_advance(const float* logits, int64_t ld, int B, int K, int V, const int64_t* cur_tok, float* scores, int first,
                       int mask_eos, int eos, int64_t* next_tok, int64_t* sel_rows, float* hist_score, int* hist_prev,
-                      int64_t* hist_next, void* stream);
+                      int64_t* hist_next, void* ws, int64_t ws_bytes, void* stream);
 /* dst[r][0:row_bytes] = src[rows[r]][0:row_bytes] (byte strides; row_bytes even): re-orders decoder state rows by parent
  * beam (RNNDecoderState.beam_update, onmt/Models.py:589-594).  src and dst must not overlap. */
 int vmmt_rows_select(const void* src, int64_t ld_src_bytes, const int64_t* rows, void* dst, int64_t ld_dst_bytes, int R,
                      int row_bytes, void* stream);
+
+/* One decoded position's results -> their slot of the per-position history, indexed by a DEVICE counter:
+ *   dst_i + counter * stride_bytes_i  <-  src_i[0 : bytes_i]   for the n <= VMMT_HIST_MAX_SEGS segments (4-byte granularity),
+ * nothing when counter is outside [0, limit); then counter += bump.  With the position index on the device every position of a
+ * decoding loop (variational_mmt_amd/decode.py; reference loop: TranslatorMultimodalVI.py:170-216) is the same launch sequence
+ * with the same arguments, captured once as a hipGraph and replayed. */
+#define VMMT_HIST_MAX_SEGS 6
+typedef struct { const void* src; void* dst; int64_t bytes; int64_t stride_bytes; } vmmt_hist_seg;
+int vmmt_history_append(const vmmt_hist_seg* segs, int n, int* counter, int limit, int bump, void* stream);
 
 /* ---- image-feature table ------------------------------------------------------------------------------------------
  * In-place X[r][c] = (X[r][c] - mean[c]) / std[c] over the HBM-resident fp32 table [R][D] (row stride ld): the

@@ -41,3 +41,39 @@ def test_sort_finished_pads_with_beam_zero_as_executed():
     assert ks == [(2, 0), (2, 1)] and [float(s) for s in scores] == [-1.5, -2.5]
     hyp, _ = bm.get_hyp(2, 1)
     assert [int(x) for x in hyp] == [8, 3]
+
+
+@pytest.mark.parametrize("name", BEAM_CASES[:2])
+@pytest.mark.parametrize("with_attn", [True, False])
+def test_load_records_equals_position_by_position(name, with_attn):
+    """Beam.load_records (whole-array bookkeeping, what TranslatorMultimodalVI._replay uses without a global scorer) leaves the beam in
+    the state T calls of advance_from_device leave it in: same finished list in the same order, same back-pointers, tokens,
+    attention, and therefore the same n-best extraction"""
+    c, p, bt, z, (B, S, max_len) = load(name)
+    K, n_best, min_length = [int(x) for x in z["beam"]]
+    for b in range(B):
+        n = int(bt["src_len"][b])
+        r = O.beam_search(p, c, bt["src"][:n, b], K, n_best=n_best, max_len=max_len, alpha=0.0, beta=0.0, min_length=min_length)
+        T = r["steps"]
+        sc = torch.stack([r["hist_score"][t] for t in range(T)])
+        pv = torch.stack([r["hist_prev"][t].to(torch.int32) for t in range(T)])
+        nx = torch.stack([r["hist_next"][t + 1] for t in range(T)])
+        at = torch.stack([r["attn_rows"][t] for t in range(T)]) if with_attn else None
+        one, two = Beam(K, 1, 2, 3, n_best=n_best, min_length=min_length), Beam(K, 1, 2, 3, n_best=n_best, min_length=min_length)
+        for t in range(T):
+            one.advance_from_device(sc[t], pv[t], nx[t], None if at is None else at[t])
+        two.load_records(sc, pv, nx, at)
+        assert one.eos_top == two.eos_top and one.done() == two.done() and len(one.finished) == len(two.finished)
+        for (s1, t1, k1), (s2, t2, k2) in zip(one.finished, two.finished):
+            assert (t1, k1) == (t2, k2) and float(s1) == float(s2)
+        assert torch.equal(one.scores, two.scores) and len(one.all_scores) == len(two.all_scores)
+        for x, y in zip(one.prev_ks + one.next_ys + one.all_scores + one.attn, two.prev_ks + two.next_ys + two.all_scores + two.attn):
+            assert torch.equal(x, y)
+        assert len(one.attn) == len(two.attn) == (T if with_attn else 0)
+        s1, k1 = one.sort_finished(minimum=n_best)
+        s2, k2 = two.sort_finished(minimum=n_best)
+        assert k1 == k2 and [float(v) for v in s1] == [float(v) for v in s2]
+        for times, k in k1[:n_best]:
+            h1, a1 = one.get_hyp(times, k)
+            h2, a2 = two.get_hyp(times, k)
+            assert [int(v) for v in h1] == [int(v) for v in h2] and ((a1 is None and a2 is None) or torch.equal(a1, a2))

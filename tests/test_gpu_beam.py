@@ -91,7 +91,7 @@ def _advance_ref(logits, scores, cur, first, mask_eos, eos, K):
     return best, pk, ids - pk * V
 
 
-@pytest.mark.parametrize("B,K,V", [(1, 5, 30000), (7, 3, 1000), (3, 12, 501), (2, 1, 64), (4, 16, 257)])
+@pytest.mark.parametrize("B,K,V", [(1, 5, 30000), (7, 3, 1000), (3, 12, 501), (2, 1, 64), (4, 16, 257), (30, 5, 4100), (2, 16, 2048)])
 def test_beam_advance_kernel(B, K, V):
     from variational_mmt_amd import _lib as L
     lib = L.lib()
@@ -114,8 +114,9 @@ def test_beam_advance_kernel(B, K, V):
         hn = torch.zeros(B, K, dtype=torch.int64, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         P = lambda t: C.c_void_p(t.data_ptr())
+        wsb = torch.zeros(lib.vmmt_beam_advance_ws_bytes(B, K, V) // 4, device="cuda")
         L.check(lib.vmmt_beam_advance(P(lg), ld, B, K, V, P(curd), P(scd), first, mask_eos, eos, P(nxt), P(sel), P(hs), P(hp), P(hn),
-                                      C.c_void_p(st)), "vmmt_beam_advance")
+                                      P(wsb), wsb.numel() * 4, C.c_void_p(st)), "vmmt_beam_advance")
         torch.cuda.synchronize()
         for b in range(B):
             rows = torch.arange(K) * B + b
@@ -126,9 +127,13 @@ def test_beam_advance_kernel(B, K, V):
             assert torch.equal(scd[b].cpu(), hs[b].cpu())
             assert torch.equal(nxt.cpu()[rows], hn[b].cpu()) and torch.equal(sel.cpu()[rows], hp[b].cpu().long() * B + b)
     with pytest.raises(RuntimeError):
-        L.check(lib.vmmt_beam_advance(None, ld, B, K, V, None, None, 0, 0, eos, None, None, None, None, None, None), "beam")
+        L.check(lib.vmmt_beam_advance(None, ld, B, K, V, None, None, 0, 0, eos, None, None, None, None, None, None, 0, None), "beam")
     with pytest.raises(RuntimeError):     # K > 16
-        L.check(lib.vmmt_beam_advance(P(lg), ld, B, 17, V, P(curd), P(scd), 0, 0, eos, P(nxt), P(sel), P(hs), P(hp), P(hn), None), "beam")
+        L.check(lib.vmmt_beam_advance(P(lg), ld, B, 17, V, P(curd), P(scd), 0, 0, eos, P(nxt), P(sel), P(hs), P(hp), P(hn), P(wsb),
+                                      wsb.numel() * 4, None), "beam")
+    with pytest.raises(RuntimeError):     # scratch too small
+        L.check(lib.vmmt_beam_advance(P(lg), ld, B, K, V, P(curd), P(scd), 0, 0, eos, P(nxt), P(sel), P(hs), P(hp), P(hn), P(wsb),
+                                      wsb.numel() * 4 - 4, None), "beam")
 
 
 def test_rows_select_kernel():

@@ -56,3 +56,63 @@ def test_translator_mirror_beam1():
         assert abs(ret["scores"][b][0] - float(z["scores"][:n, b].sum())) <= 1e-3
     with pytest.raises(NotImplementedError):
         TranslatorMultimodalVI(model, fields, beam_size=5, copy_attn=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graph_replay_equals_launch_by_launch(dtype):
+    """decode.py: a position is one hipGraph, replayed (Engine.decode_graphs) -- same launches, same arguments, same bits as issuing
+    them one by one; arg-max decoding and beam search, twice through the same workspace (the second call replays the captured graph
+    on re-initialised state)"""
+    from variational_mmt_amd.engine import Dims, Engine
+    from variational_mmt_amd.decode import beam_decode, greedy_decode
+    c, p, bt, z, (B, S, max_len) = load("greedy_bi_l1")
+    out = {}
+    for graphs in (True, False):
+        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0, conditional=c.conditional), dtype=dtype,
+                   device="cuda", seed=1)
+        e.load_state_dict(p)
+        e.decode_graphs = graphs
+        res = []
+        for rep in range(2):
+            src = bt["src"] if rep == 0 else bt["src"].flip(1)[:, :B]
+            sl = bt["src_len"] if rep == 0 else bt["src_len"]
+            toks, scores = greedy_decode(e, src, sl, max_len=max_len)
+            res += [toks.cpu().clone(), scores.cpu().clone()]
+            rec = beam_decode(e, src, sl, 4, max_len=max_len, min_length=2)
+            res += [rec["scores"], rec["prev"], rec["next"], rec["attn"]]
+        torch.cuda.synchronize()
+        assert any("graph" in v for k, v in e.ws.items() if isinstance(k, tuple) and k[0] in ("decode", "beam")) == graphs
+        out[graphs] = res
+    for a, b_ in zip(out[True], out[False]):
+        assert torch.equal(a, b_)
+
+
+def test_history_append_kernel():
+    """vmmt_history_append: history[counter] <- staging buffers for up to six segments, then counter += bump; nothing is written once
+    the counter has reached the limit"""
+    import ctypes as C
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5)
+    shapes = [((7, 3), torch.float32), ((5,), torch.int64), ((2, 33, 20), torch.float32), ((1,), torch.int32)]
+    limit = 4
+    src = [(torch.randn(sh, generator=g) * 100).to(dt).cuda() for sh, dt in shapes]
+    hist = [torch.full((limit + 1,) + sh, 7, dtype=dt, device="cuda") for sh, dt in shapes]
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    want = [h.clone() for h in hist]
+    for t in range(limit + 2):
+        for s_ in src:
+            s_.add_(1)
+        arr = (L.HistSeg * len(src))()
+        for a, s_, h in zip(arr, src, hist):
+            nb = s_.numel() * s_.element_size()
+            a.src, a.dst, a.bytes, a.stride_bytes = s_.data_ptr(), h.data_ptr(), nb, nb
+        L.check(lib.vmmt_history_append(arr, len(src), C.c_void_p(counter.data_ptr()), limit, 1, None), "vmmt_history_append")
+        if t < limit:
+            for w, s_ in zip(want, src):
+                w[t] = s_
+    torch.cuda.synchronize()
+    assert int(counter.item()) == limit + 2
+    for h, w in zip(hist, want):
+        assert torch.equal(h, w)                      # slots [0, limit) hold the positions in order, slot `limit` is untouched
+    assert lib.vmmt_history_append(arr, 7, C.c_void_p(counter.data_ptr()), limit, 1, None) != 0

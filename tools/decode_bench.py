@@ -8,13 +8,38 @@ d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=T
 e = Engine(d, dtype="bf16", device="cuda", seed=0)
 g = torch.Generator().manual_seed(0)
 S, L = 20, 24
-for B, K in ((1, 1), (64, 1), (256, 1), (1, 5), (16, 5), (64, 5)):
+for graphs in (False, True):
+    e.decode_graphs = graphs
+    e.drop_workspaces()
+    print("position = %s" % ("one hipGraph, replayed (Engine.decode_graphs)" if graphs else "plain launches (default)"))
+    for B, K in ((1, 1), (64, 1), (256, 1), (1, 5), (16, 5), (30, 5), (64, 5)):
+        src = torch.randint(2, d.vs, (S, B), generator=g)
+        sl = torch.full((B,), S, dtype=torch.int64)
+        fn = (lambda: greedy_decode(e, src, sl, max_len=L)) if K == 1 else (lambda: beam_decode(e, src, sl, K, max_len=L))
+        fn(); torch.cuda.synchronize()
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); n = 5
+        for _ in range(n): fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print("  batch %4d beam %d: %7.2f ms per batch of %d positions = %8.0f sentences/s, %9.0f target positions/s" % (B, K, dt * 1e3, L, B / dt, B * L / dt))
+e.decode_graphs = False
+e.drop_workspaces()
+
+# the translator mirror on top (host Beam replay + stopping rule every 8 positions): what onmt.translate.TranslatorMultimodalVI.translate_batch costs
+import types
+from variational_mmt_amd.onmt.Models import NMTVIModel
+from variational_mmt_amd.onmt.translate import TranslatorMultimodalVI
+model = types.SimpleNamespace(engine=e)
+fields = {"tgt": types.SimpleNamespace(vocab=types.SimpleNamespace(stoi={"<blank>": 1, "<s>": 2, "</s>": 3}))}
+for B, K in ((30, 5), (64, 5), (30, 1)):
+    tr = TranslatorMultimodalVI(model, fields, beam_size=K, n_best=1, max_length=L)
     src = torch.randint(2, d.vs, (S, B), generator=g)
     sl = torch.full((B,), S, dtype=torch.int64)
-    fn = (lambda: greedy_decode(e, src, sl, max_len=L)) if K == 1 else (lambda: beam_decode(e, src, sl, K, max_len=L))
-    fn(); torch.cuda.synchronize()
-    t0 = time.perf_counter(); n = 3
-    for _ in range(n): fn()
+    batch = types.SimpleNamespace(src=(src, sl))
+    tr.translate_batch(batch); torch.cuda.synchronize()
+    t0 = time.perf_counter(); n = 5
+    for _ in range(n): tr.translate_batch(batch)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print("batch %4d beam %d: %7.2f ms per batch of %d positions = %8.0f sentences/s, %9.0f target positions/s" % (B, K, dt * 1e3, L, B / dt, B * L / dt))
+    print("translate_batch: batch %4d beam %d: %7.2f ms per batch = %8.0f sentences/s" % (B, K, dt * 1e3, B / dt))

@@ -51,6 +51,10 @@ class ZeroDesc(C.Structure):
     _fields_ = [("ptr", vp), ("bytes", i64), ("chunk_start", i64)]
 
 
+class HistSeg(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("bytes", i64), ("stride_bytes", i64)]
+
+
 class PackDesc(C.Structure):
     _fields_ = [("src", vp), ("src2", vp), ("dst", vp), ("ld_src", i64), ("ld_dst", i64), ("R", i32), ("C", i32),
                 ("transpose", i32), ("dtype", i32), ("chunk_start", i32), ("chunks", i32)]
@@ -109,8 +113,10 @@ _SIGS = {
     "vmmt_pack_multi": (i32, [vp, i32, i32, vp]),
     "vmmt_prepare_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, u64, vp]),
     "vmmt_zero_multi": (i32, [vp, i32, i32, vp]),
-    "vmmt_beam_advance": (i32, [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "vmmt_beam_advance_ws_bytes": (i64, [i32, i32, i32]),
+    "vmmt_beam_advance": (i32, [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp]),
     "vmmt_rows_select": (i32, [vp, i64, vp, vp, i64, i32, i32, vp]),
+    "vmmt_history_append": (i32, [vp, i32, vp, i32, i32, vp]),
     "vmmt_standardise_rows": (i32, [vp, i64, vp, vp, i64, i32, vp]),
     "vmmt_sumsq": (i32, [vp, i64, vp, i32, vp]),
     "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp, vp]),

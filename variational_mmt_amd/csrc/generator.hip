@@ -509,19 +509,29 @@ static int launch_gen_v(const GenArgs& a, hipStream_t st) {
 }
 
 // arg-max over the vocabulary from the partial statistics of pass 0 (step-wise decoding: the next input token)
-__global__ void gen_argmax_kernel(const float* __restrict__ part_max, const int* __restrict__ part_idx, int M, int npart,
-                                  long long* __restrict__ out_idx, float* __restrict__ out_max) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+// (one wave per token: the ~2 V / 128 partials of a token are scanned by its 64 lanes -- as one lane per token this kernel took
+//  74 us per decoded position at V = 30 000, 38 % of it)
+__global__ void __launch_bounds__(256) gen_argmax_kernel(const float* __restrict__ part_max, const int* __restrict__ part_idx, int M,
+                                                         int npart, long long* __restrict__ out_idx, float* __restrict__ out_max) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (m >= M) return;
   float mx = -INFINITY;
   int mi = 0x7fffffff;
-  for (int p = 0; p < npart; ++p) {
+  for (int p = lane; p < npart; p += 64) {
     const float x = part_max[(long)p * M + m];
     const int xi = part_idx[(long)p * M + m];
     if (x > mx || (x == mx && xi < mi)) { mx = x; mi = xi; }      // ties: lowest vocabulary index
   }
-  out_idx[m] = mi;
-  if (out_max) out_max[m] = mx;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ox = __shfl_xor(mx, off, 64);
+    const int oi = __shfl_xor(mi, off, 64);
+    if (ox > mx || (ox == mx && oi < mi)) { mx = ox; mi = oi; }
+  }
+  if (lane == 0) {
+    out_idx[m] = mi == 0x7fffffff ? 0 : mi;                       // (a row of NaNs has no maximum: a valid id all the same -- it is fed to a table lookup)
+    if (out_max) out_max[m] = mx;
+  }
 }
 
 // preconditions of the bf16 throughput kernel (gen_kernel_q): LDS-DMA operands (16-byte aligned rows, K in whole 32-slabs) and,
@@ -550,7 +560,7 @@ extern "C" int vmmt_gen_argmax(const float* part_max, const int* part_idx, int M
                                void* stream) {
   using namespace vmmt;
   if (!part_max || !part_idx || !out_idx || M <= 0 || npart <= 0) return VMMT_EINVAL;
-  hipLaunchKernelGGL(gen_argmax_kernel, dim3((M + 127) / 128), dim3(128), 0, (hipStream_t)stream, part_max, part_idx, M, npart,
+  hipLaunchKernelGGL(gen_argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, part_max, part_idx, M, npart,
                      (long long*)out_idx, out_max);
   return check_launch();
 }

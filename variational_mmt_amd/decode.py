@@ -5,7 +5,16 @@ same C-ABI as the training step.  `greedy_decode`: beam size 1, arg-max fed back
 device runs Beam.advance (vmmt_beam_advance) and the beam re-ordering of the decoder state (vmmt_rows_select) for all
 sentences of a batch with no host synchronisation inside a block of positions, and records every position's beam
 (scores, parents, tokens, attention); `onmt/translate/Beam.py` (host mirror) replays the records into the reference's
-bookkeeping (finished list, stopping rule, n-best extraction)."""
+bookkeeping (finished list, stopping rule, n-best extraction).
+
+A position is written as ONE launch sequence with FIXED arguments -- tokens ping through a pair of fixed buffers, the per-position
+records go through staging buffers into history[counter] with the counter on the device (vmmt_history_append) -- so that it can be
+captured once per decoding workspace as a hipGraph and replayed (`Engine.decode_graphs`, VMMT_DECODE_GRAPHS=1; torch.cuda.CUDAGraph is
+the capture plumbing).  Bit-identical to the plain launches (tests/test_gpu_decode.py) and, measured, SLOWER than them on this stack
+(tools/decode_bench.py: beam 5 x 30 sentences 3.87 against 3.62 ms per 24 positions, arg-max x 256 sentences 3.68 against 2.92), so the
+default issues the launches one by one: a position is bound by the dependent-kernel turnaround on the GPU, not by the host.  What did
+pay was the two kernels the profile showed (tools/decode_profile.py): Beam.advance as (row x vocabulary chunk) workgroups instead of one
+per sentence (216 -> 39 us per position) and the arg-max fold as a wave per token (74 -> 5 us)."""
 import ctypes as C
 
 import torch
@@ -111,6 +120,38 @@ def _encode(eng, src, src_len, bos):
                        tgt_len=torch.full((B,), 2, dtype=torch.int64, device="cpu") if d.conditional else None)
 
 
+def _hist(eng, segs, counter, limit):
+    """vmmt_history_append: [(src tensor, history tensor [limit][...])] -> history[counter] <- src; counter += 1"""
+    arr = (L.HistSeg * len(segs))()
+    for a, (src, hist) in zip(arr, segs):
+        nbytes = src.numel() * src.element_size()
+        assert hist[0].numel() * hist.element_size() == nbytes and hist.shape[0] >= limit and src.is_contiguous() and hist.is_contiguous()
+        a.src, a.dst, a.bytes, a.stride_bytes = src.data_ptr(), hist.data_ptr(), nbytes, nbytes
+    L.check(eng.lib.vmmt_history_append(arr, len(segs), counter.data_ptr(), limit, 1, eng.stream()), "vmmt_history_append")
+
+
+def _position_graph(eng, b, position, init):
+    """the launch sequence `position()` of decoding workspace `b` as a replayable graph (None: graphs are switched off).  Captured
+    once per workspace; the warm-up position runs on the state `init()` prepares (valid lengths and tokens: garbage would put NaNs
+    into the padding lanes of the state buffers, which no later `init()` rewrites), and the caller runs `init()` again afterwards."""
+    if not getattr(eng, "decode_graphs", True):
+        return None
+    if "graph" not in b:
+        init()
+        cur = torch.cuda.current_stream(eng.dev)
+        side = torch.cuda.Stream(device=eng.dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            position()                           # first calls of a kernel set its attributes (LDS size): not capturable
+        cur.wait_stream(side)
+        torch.cuda.synchronize(eng.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            position()
+        b["graph"] = g
+    return b["graph"]
+
+
 def greedy_decode(eng, src, src_len, max_len=50, bos=2):
     """src [S,B] int64, src_len [B] (sorted descending).  Returns (tokens [max_len,B] int64, log-probs [max_len,B] f32) on the
     device; every sentence runs max_len steps (cut at the first </s> on the host).  No host synchronisation inside."""
@@ -118,41 +159,59 @@ def greedy_decode(eng, src, src_len, max_len=50, bos=2):
     S, B = int(src.shape[0]), int(src.shape[1])
     H, V, Lyr = d.hid, d.vt, d.layers
     ws = _encode(eng, src, src_len, bos)
-    st = eng.stream()
     f32 = torch.float32
     key = ("decode", B, S, max_len)
     b = eng.ws.get(key)
-    ctx = ws.enc_out[Lyr - 1]
+    enc = ws.enc_out[Lyr - 1]
     if b is None:
-        b = dict(tokens=torch.zeros(max_len + 1, B, dtype=torch.int64, device=dev),
+        b = dict(tokens=torch.zeros(max_len, B, dtype=torch.int64, device=dev), tok=torch.zeros(2, B, dtype=torch.int64, device=dev),
                  vmax=torch.zeros(max_len, B, dtype=f32, device=dev), lse=torch.zeros(max_len, B, dtype=f32, device=dev),
-                 npart=lib.vmmt_gen_npart(V))
+                 st_vmax=torch.zeros(B, dtype=f32, device=dev), st_lse=torch.zeros(B, dtype=f32, device=dev),
+                 counter=torch.zeros(1, dtype=torch.int32, device=dev), npart=lib.vmmt_gen_npart(V),
+                 # the source-side operands in buffers of this workspace: the graph holds their addresses
+                 ctx=Buf(S * B, enc.t.shape[1], eng.T, dev, ld=enc.ld), zx=Buf(B, ws.zx.t.shape[1], f32, dev, ld=ws.zx.ld),
+                 src_len=torch.zeros(B, dtype=torch.int64, device=dev))
         n = b["npart"] * B
         b.update(pm=torch.zeros(n, dtype=f32, device=dev), ps=torch.zeros(n, dtype=f32, device=dev),
                  pi=torch.zeros(n, dtype=torch.int32, device=dev), tl=torch.zeros(B, dtype=f32, device=dev),
                  nll=torch.zeros(B, dtype=f32, device=dev), stats=torch.zeros(L.STAT_COUNT, dtype=f32, device=dev))
-        b["stepper"] = _Stepper(eng, B, S, None, 0, None, None, 0)
+        b["stepper"] = _Stepper(eng, B, S, b["ctx"].p(), b["ctx"].ld, b["src_len"], b["zx"].p(), b["zx"].ld)
         eng.ws[key] = b
-    sp = b["stepper"]
-    sp.ctx, sp.ctx_ld, sp.src_len, sp.zx, sp.zx_ld = ctx.p(), ctx.ld, ws.src_len, ws.zx.p(), ws.zx.ld
-    tokens = b["tokens"]
-    tokens[0].fill_(bos)
-    # decoder state: h0 / c0 = encoder final states (Models.py:1158-1165)
-    for l in range(Lyr):
-        sp.c[l][0].view().copy_(ws.cn[l].view())
-        hb, ho = sp.h_buf(l, 0)
-        hb.t[:B, ho:ho + H].copy_(ws.hn[l].view())
+    sp, tok = b["stepper"], b["tok"]
     wg = eng.sh["wg"]
-    for t in range(max_len):
-        sp.step(tokens.data_ptr() + 8 * t * B, t)
-        L.check(lib.vmmt_gen_loss_fwd(dt, wg.p(), wg.ld, eng.pp("generator.0.bias"), sp.AH.p(), sp.AH.ld,
-                                      tokens.data_ptr() + 8 * t * B, B, V, _ru(H, KPAD), PAD, b["pm"].data_ptr(), b["ps"].data_ptr(),
-                                      b["pi"].data_ptr(), b["tl"].data_ptr(), b["lse"].data_ptr() + 4 * t * B, b["nll"].data_ptr(),
-                                      b["stats"].data_ptr(), st), "vmmt_gen_loss_fwd")
-        L.check(lib.vmmt_gen_argmax(b["pm"].data_ptr(), b["pi"].data_ptr(), B, b["npart"], tokens.data_ptr() + 8 * (t + 1) * B,
-                                    b["vmax"].data_ptr() + 4 * t * B, st), "vmmt_gen_argmax")
+
+    def position():
+        st = eng.stream()
+        sp.step(tok[0].data_ptr(), 0)
+        L.check(lib.vmmt_gen_loss_fwd(dt, wg.p(), wg.ld, eng.pp("generator.0.bias"), sp.AH.p(), sp.AH.ld, tok[0].data_ptr(), B, V,
+                                      _ru(H, KPAD), PAD, b["pm"].data_ptr(), b["ps"].data_ptr(), b["pi"].data_ptr(), b["tl"].data_ptr(),
+                                      b["st_lse"].data_ptr(), b["nll"].data_ptr(), b["stats"].data_ptr(), st), "vmmt_gen_loss_fwd")
+        L.check(lib.vmmt_gen_argmax(b["pm"].data_ptr(), b["pi"].data_ptr(), B, b["npart"], tok[1].data_ptr(), b["st_vmax"].data_ptr(), st),
+                "vmmt_gen_argmax")
+        _hist(eng, [(tok[1], b["tokens"]), (b["st_lse"], b["lse"]), (b["st_vmax"], b["vmax"])], b["counter"], max_len)
         sp.carry()
-    return tokens[1:], b["vmax"] - b["lse"]
+        tok[0].copy_(tok[1])
+
+    def init():
+        b["ctx"].t.copy_(enc.t[:b["ctx"].t.shape[0]])
+        b["zx"].t[:B].copy_(ws.zx.t[:B])
+        b["src_len"].copy_(ws.src_len)
+        tok[0].fill_(bos)
+        b["counter"].zero_()
+        # decoder state: h0 / c0 = encoder final states (Models.py:1158-1165)
+        for l in range(Lyr):
+            sp.c[l][0].view().copy_(ws.cn[l].view())
+            hb, ho = sp.h_buf(l, 0)
+            hb.t[:B, ho:ho + H].copy_(ws.hn[l].view())
+
+    graph = _position_graph(eng, b, position, init)
+    init()
+    for t in range(max_len):
+        if graph is not None:
+            graph.replay()
+        else:
+            position()
+    return b["tokens"], b["vmax"] - b["lse"]
 
 
 def beam_decode(eng, src, src_len, beam_size, max_len=100, min_length=0, bos=2, eos=3, pad=PAD, stop=None, check_every=8):
@@ -168,46 +227,60 @@ def beam_decode(eng, src, src_len, beam_size, max_len=100, min_length=0, bos=2, 
     H, V, Lyr = d.hid, d.vt, d.layers
     R = K * B
     ws = _encode(eng, src, src_len, bos)
-    st = eng.stream()
     f32, i64 = torch.float32, torch.int64
-    key = ("beam", B, S, K, max_len)
+    key = ("beam", B, S, K, max_len, int(eos))
     b = eng.ws.get(key)
     if b is None:
-        b = dict(stepper=_Stepper(eng, R, S, None, 0, None, None, 0),
-                 ctx=Buf(S * R, H, eng.T, dev), zx=Buf(R, 4 * d.hp, f32, dev), src_len=torch.zeros(R, dtype=i64, device=dev),
+        b = dict(ctx=Buf(S * R, H, eng.T, dev), zx=Buf(R, 4 * d.hp, f32, dev), src_len=torch.zeros(R, dtype=i64, device=dev),
                  logits=Buf(R, V, f32, dev), tok=torch.zeros(2, R, dtype=i64, device=dev), sel=torch.zeros(R, dtype=i64, device=dev),
                  scores=torch.zeros(B, K, dtype=f32, device=dev), h_score=torch.zeros(max_len, B, K, dtype=f32, device=dev),
                  h_prev=torch.zeros(max_len, B, K, dtype=torch.int32, device=dev),
-                 h_next=torch.zeros(max_len, B, K, dtype=i64, device=dev), h_attn=torch.zeros(max_len, R, S, dtype=f32, device=dev))
+                 h_next=torch.zeros(max_len, B, K, dtype=i64, device=dev), h_attn=torch.zeros(max_len, R, S, dtype=f32, device=dev),
+                 st_score=torch.zeros(B, K, dtype=f32, device=dev), st_prev=torch.zeros(B, K, dtype=torch.int32, device=dev),
+                 st_next=torch.zeros(B, K, dtype=i64, device=dev), counter=torch.zeros(1, dtype=torch.int32, device=dev),
+                 adv_ws=torch.zeros(int(lib.vmmt_beam_advance_ws_bytes(B, K, V)) // 4, dtype=f32, device=dev))
+        b["stepper"] = _Stepper(eng, R, S, b["ctx"].p(), b["ctx"].ld, b["src_len"], b["zx"].p(), b["zx"].ld)
         eng.ws[key] = b
-    sp = b["stepper"]
-    # (2) repeat the source-side objects beam_size times (TranslatorMultimodalVI.py:141-157): row k*B + b <- sentence b
-    enc = ws.enc_out[Lyr - 1]
-    b["ctx"].t[:S * R].view(S, K, B, -1).copy_(enc.t[:S * B].view(S, 1, B, -1).expand(S, K, B, enc.ld))
-    b["zx"].t[:R].view(K, B, -1).copy_(ws.zx.t[:B].unsqueeze(0).expand(K, B, ws.zx.ld))
-    b["src_len"].view(K, B).copy_(ws.src_len.view(1, B).expand(K, B))
-    sp.ctx, sp.ctx_ld, sp.src_len, sp.zx, sp.zx_ld = b["ctx"].p(), b["ctx"].ld, b["src_len"], b["zx"].p(), b["zx"].ld
-    for l in range(Lyr):
-        sp.c[l][0].t[:R].view(K, B, -1).copy_(ws.cn[l].t[:B].unsqueeze(0).expand(K, B, ws.cn[l].ld))
-        hb, ho = sp.h_buf(l, 0)
-        hb.t[:R, ho:ho + H].view(K, B, H).copy_(ws.hn[l].view().unsqueeze(0).expand(K, B, H))
-    tok = b["tok"]
-    tok[0].fill_(pad)                         # Beam.__init__: next_ys[0] = [bos, pad, pad, ...] (Beam.py:34-36)
-    tok[0, :B].fill_(bos)
-    b["scores"].zero_()
+    sp, tok = b["stepper"], b["tok"]
     wg, lg = eng.sh["wg"], b["logits"]
     bias = eng.pp("generator.0.bias")
+
+    def position(first=0, mask_eos=0):
+        sp.step(tok[0].data_ptr(), 0)
+        sp.gemm(L.GEMM_NT, sp.AH.p(), sp.AH.ld, wg.p(), wg.ld, lg.p(), lg.ld, R, V, H, addend=bias, ld_add=0, add_rows=1, out_f32=1)
+        L.check(lib.vmmt_beam_advance(lg.p(), lg.ld, B, K, V, tok[0].data_ptr(), b["scores"].data_ptr(), first, mask_eos, eos,
+                                      tok[1].data_ptr(), b["sel"].data_ptr(), b["st_score"].data_ptr(), b["st_prev"].data_ptr(),
+                                      b["st_next"].data_ptr(), b["adv_ws"].data_ptr(), b["adv_ws"].numel() * 4, eng.stream()),
+                "vmmt_beam_advance")
+        _hist(eng, [(b["st_score"], b["h_score"]), (b["st_prev"], b["h_prev"]), (b["st_next"], b["h_next"]), (sp.probs, b["h_attn"])],
+              b["counter"], max_len)
+        sp.carry(b["sel"].data_ptr())
+        tok[0].copy_(tok[1])
+
+    def init():
+        # (2) repeat the source-side objects beam_size times (TranslatorMultimodalVI.py:141-157): row k*B + b <- sentence b
+        enc = ws.enc_out[Lyr - 1]
+        b["ctx"].t[:S * R].view(S, K, B, -1).copy_(enc.t[:S * B].view(S, 1, B, -1).expand(S, K, B, enc.ld))
+        b["zx"].t[:R].view(K, B, -1).copy_(ws.zx.t[:B].unsqueeze(0).expand(K, B, ws.zx.ld))
+        b["src_len"].view(K, B).copy_(ws.src_len.view(1, B).expand(K, B))
+        for l in range(Lyr):
+            sp.c[l][0].t[:R].view(K, B, -1).copy_(ws.cn[l].t[:B].unsqueeze(0).expand(K, B, ws.cn[l].ld))
+            hb, ho = sp.h_buf(l, 0)
+            hb.t[:R, ho:ho + H].view(K, B, H).copy_(ws.hn[l].view().unsqueeze(0).expand(K, B, H))
+        tok[0].fill_(pad)                         # Beam.__init__: next_ys[0] = [bos, pad, pad, ...] (Beam.py:34-36)
+        tok[0, :B].fill_(bos)
+        b["scores"].zero_()
+        b["counter"].zero_()
+
+    graph = _position_graph(eng, b, position, init)
+    init()
     n = 0
     for t in range(max_len):
-        cur, nxt = tok[t & 1], tok[(t + 1) & 1]
-        sp.step(cur.data_ptr(), t)
-        sp.gemm(L.GEMM_NT, sp.AH.p(), sp.AH.ld, wg.p(), wg.ld, lg.p(), lg.ld, R, V, H, addend=bias, ld_add=0, add_rows=1, out_f32=1)
-        L.check(lib.vmmt_beam_advance(lg.p(), lg.ld, B, K, V, cur.data_ptr(), b["scores"].data_ptr(), int(t == 0),
-                                      int(t + 1 < min_length), eos, nxt.data_ptr(), b["sel"].data_ptr(),
-                                      b["h_score"][t].data_ptr(), b["h_prev"][t].data_ptr(), b["h_next"][t].data_ptr(), st),
-                "vmmt_beam_advance")
-        b["h_attn"][t].view(-1).copy_(sp.probs)
-        sp.carry(b["sel"].data_ptr())
+        first, mask_eos = int(t == 0), int(t + 1 < min_length)
+        if graph is not None and not first and not mask_eos:
+            graph.replay()
+        else:
+            position(first, mask_eos)         # the first position scores beam 0 only; positions below min_length mask </s>
         n = t + 1
         if stop is not None and (n % check_every == 0 or n == max_len):
             rec = dict(scores=b["h_score"][:n].cpu(), prev=b["h_prev"][:n].cpu(), next=b["h_next"][:n].cpu(), attn=None)

@@ -218,6 +218,10 @@ class Engine(object):
         self.fused_qnet = _os_env.get("VMMT_FUSED_QNET", "1") == "1"
         self.qnet_split = _os_env.get("VMMT_QNET_SPLIT", "1") == "1"     # location / scale networks in separate workgroups (csrc/qnet.hip)
         self.gen_fused = _os_env.get("VMMT_GEN_FUSED", "1") == "1"       # csrc/generator_fused.hip where it applies (bf16, H = 512 / 256)
+        # decode.py: a decoded position as ONE hipGraph, replayed -- built, bit-identical, and measured SLOWER than issuing its ~15 launches
+        # one by one (tools/decode_bench.py, ms per 24 positions, graph / plain: beam 5 x 30 sentences 3.87 / 3.62, arg-max x 256 3.68 / 2.92:
+        # a position is bound by the GPU's dependent-kernel turnaround, not by the host, and a replay does not overlap the next one's launch)
+        self.decode_graphs = _os_env.get("VMMT_DECODE_GRAPHS", "0") == "1"
         self.persistent_lstm = _os_env.get("VMMT_PERSISTENT_LSTM", "1") == "1"     # plans are built per workspace: set before the first forward
         self.seq_syncs = []
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank

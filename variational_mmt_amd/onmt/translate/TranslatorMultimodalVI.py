@@ -59,6 +59,18 @@ class TranslatorMultimodalVI(object):
         beams = [Beam(self.beam_size, pad, bos, eos, n_best=self.n_best, global_scorer=self.global_scorer,
                       min_length=self.min_length) for _ in range(B)]
         n = rec["scores"].shape[0]
+        if self.global_scorer is None:
+            # a beam advances until it is done (Beam.py:117-124): the number of positions each one takes, for the whole batch at once
+            # (see `stop` in _beam), then every beam's bookkeeping in whole-array operations
+            fin = rec["next"] == eos
+            done = (fin[:, :, 0].cumsum(0) > 0) & (fin.sum(2).cumsum(0) >= self.n_best)           # [n, B]
+            steps = torch.where(done.any(0), done.int().argmax(0) + 1, torch.full((B,), n, dtype=torch.int64)).tolist()
+            lens = rec["src_len"].tolist()
+            for b, bm in enumerate(beams):
+                T = steps[b]
+                bm.load_records(rec["scores"][:T, b], rec["prev"][:T, b], rec["next"][:T, b],
+                                rec["attn"][:T, :, b, :int(lens[b])] if with_attn else None)
+            return beams
         for b, bm in enumerate(beams):
             for t in range(n):
                 if bm.done():
@@ -70,7 +82,16 @@ class TranslatorMultimodalVI(object):
     def _beam(self, batch, src, src_lengths):
         pad, bos, eos = self._specials()
         B = int(src.shape[1])
-        stop = lambda rec: all(bm.done() for bm in self._replay(rec, B, False))
+        n_best = self.n_best
+
+        def stop(rec):
+            # Beam.done for every sentence, from the records alone: eos_top = </s> has headed the beam at some position; finished counts
+            # one entry per </s> on the beam (Beam.py:108-124).  Both only grow, and a beam that is done stops advancing, so "done at
+            # some position <= n" is what the replay below will find.  (Replaying the Beam mirror here cost 10x the device time.)
+            fin = rec["next"] == eos                                  # [n, B, K]
+            top = fin[:, :, 0].cumsum(0) > 0
+            cnt = fin.sum(2).cumsum(0)
+            return bool(((top & (cnt >= n_best)).any(0)).all())
         rec = beam_decode(self.model.engine, src, src_lengths, self.beam_size, max_len=self.max_length, min_length=self.min_length,
                           bos=bos, eos=eos, pad=pad, stop=stop)
         beams = self._replay(rec, B, True)
