@@ -1,5 +1,5 @@
 """where the host time of a step through onmt.TrainerMultimodal goes (GPU box): cProfile over one epoch of `bench.py --through-trainer`'s
-second epoch.  usage: python tools/trainer_host_profile.py [n_lines]"""
+second epoch.  usage: python tools/trainer_host_profile.py [n_lines] [config] [batch]"""
 import cProfile
 import os
 import pstats
@@ -10,7 +10,8 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 
-a = type("A", (), dict(config="2", batch=256, dtype="bf16", dropout=0.5, conditional=False))()
+a = type("A", (), dict(config=sys.argv[2] if len(sys.argv) > 2 else "2", batch=int(sys.argv[3]) if len(sys.argv) > 3 else 256, dtype="bf16",
+                       dropout=0.5, conditional=False))()
 pr = cProfile.Profile()
 real = bench.time.perf_counter
 state = {"n": 0}
