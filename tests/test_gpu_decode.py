@@ -116,3 +116,30 @@ def test_history_append_kernel():
     for h, w in zip(hist, want):
         assert torch.equal(h, w)                      # slots [0, limit) hold the positions in order, slot `limit` is untouched
     assert lib.vmmt_history_append(arr, 7, C.c_void_p(counter.data_ptr()), limit, 1, None) != 0
+
+
+def test_argmax_decoding_stops_when_every_sentence_has_ended():
+    """greedy_decode(eos=...): the loop ends at the first check behind the position where the last sentence produced </s>; up to
+    there tokens and scores are those of the full-length run, and the translator's hypotheses (cut at the first </s>) are unchanged"""
+    from variational_mmt_amd.engine import Dims, Engine
+    from variational_mmt_amd.decode import greedy_decode
+    c, p, bt, z, (B, S, max_len) = load("greedy_bi_l1")
+    e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda", seed=1)
+    e.load_state_dict(p)
+    long_len = 40
+    full_t, full_s = [x.cpu().clone() for x in greedy_decode(e, bt["src"], bt["src_len"], max_len=long_len)]
+    assert full_t.shape[0] == long_len
+    # pick as "</s>" a token every sentence produces early (the fixture's model is random: its own </s> may never come)
+    first = {}
+    for b in range(B):
+        for t, tok in enumerate(full_t[:, b].tolist()):
+            first.setdefault((b, tok), t)
+    cands = [tok for tok in set(full_t.view(-1).tolist()) if all((b, tok) in first for b in range(B))]
+    if not cands:
+        pytest.skip("no token is produced by every sentence of the fixture")
+    eos = min(cands, key=lambda tok: max(first[(b, tok)] for b in range(B)))
+    last = max(first[(b, eos)] for b in range(B))
+    toks, sc = [x.cpu().clone() for x in greedy_decode(e, bt["src"], bt["src_len"], max_len=long_len, eos=eos, check_every=4)]
+    n = toks.shape[0]
+    assert n == min(long_len, -(-(last + 1) // 4) * 4) and n < long_len
+    assert torch.equal(toks, full_t[:n]) and torch.equal(sc, full_s[:n])

@@ -42,7 +42,7 @@ class TranslatorMultimodalVI(object):
 
     def _greedy(self, batch, src, src_lengths):
         _pad, bos, eos = self._specials()
-        toks, logp = greedy_decode(self.model.engine, src, src_lengths, max_len=self.max_length, bos=bos)
+        toks, logp = greedy_decode(self.model.engine, src, src_lengths, max_len=self.max_length, bos=bos, eos=eos)
         toks, logp = toks.cpu(), logp.cpu()            # ONE device-to-host copy per batch
         B = toks.shape[1]
         ret = {"predictions": [], "scores": [], "attention": [], "gold_score": [0] * B, "batch": batch}
