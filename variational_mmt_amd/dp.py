@@ -8,7 +8,7 @@ the CONCATENATED global batch B_g = sum_r B_r:
 so every rank back-propagates with normalization = B_g and KL batch size = B_g and the gradients are SUMMED (not
 averaged) -- see SURVEY.md section 8e.  What crosses ranks per step:
 
-  * the gradient arena, reduced segment by segment from inside the backward plan (engine.py: ALLREDUCE entries) so that the
+  * the gradient arena, reduced segment by segment from inside the backward plan (engine/backward.py: ALLREDUCE entries) so that the
     collectives overlap the rest of backward (xGMI is per-link bound: few, large collectives);
   * ONE float, the KL sum, before the latent backward (free bits compares the GLOBAL batch-mean KL with the margin);
   * nothing else: the global batch size / token count come from the loader (`onmt.io.OrderedIterator(dp_rank=, dp_world=)`

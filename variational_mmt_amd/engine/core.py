@@ -1,0 +1,661 @@
+"""The engine object: parameter arena, compute shadows, plan execution, workspace cache.  The step API (forward / loss /
+backward / optimiser) lives in step.py, the per-shape buffers and launch plans in workspace.py / backward.py / conditional.py."""
+import collections
+import ctypes as C
+import math
+from os import environ as _os_env
+
+import torch
+
+from .. import _lib as L
+from .layout import Buf, KPAD, PAD, SEG_ALIGN, Dims, _ru  # noqa: F401
+from .step import StepAPI
+from .workspace import Workspace
+
+
+class Engine(StepAPI):
+    def __init__(self, dims, dtype="bf16", device="cuda", seed=0, param_init=0.1, batch_global=None):
+        self.d = dims
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("variational_mmt_amd needs a GPU (MI355X); there is no CPU path")
+        self.lib = L.lib()
+        self.row_tables = []
+        self.dt = L.BF16 if dtype in ("bf16", torch.bfloat16) else L.F32
+        self.T = torch.bfloat16 if self.dt == L.BF16 else torch.float32
+        self.tsz = 2 if self.dt == L.BF16 else 4
+        self._build_arena(seed, param_init)
+        self._build_row_tables()
+        self._build_shadows()
+        # per-shape workspaces: a bounded LRU (real data has hundreds of (S, T') pairs per epoch).  Shapes are rounded up to
+        # `shape_bucket` positions (pad positions are masked everywhere), the largest buffer (G^T) is shared between all
+        # workspaces, and the least recently used workspaces are dropped once `ws_budget_bytes` is exceeded.
+        self.ws = collections.OrderedDict()
+        self.shape_bucket = max(1, int(_os_env.get("VMMT_SHAPE_BUCKET", "2")))
+        self.ws_budget_bytes = int(float(_os_env.get("VMMT_WS_BUDGET_GB", "48")) * (1 << 30))
+        self.ws_evictions = 0
+        self._shared = {}
+        self.shadows_dirty = True
+        self.step_count = 0          # Adam step counter
+        self.seed = seed
+        self.rng_counter = 1234567 + seed      # dp.GradSync offsets it by the rank: eps / dropout masks differ between replicas
+        # H2: as executed the reference detaches the latent sample (Dists.py:21-26, Models.py:930-933): mu / sigma get gradient only
+        # through the KL.  True = the reparameterised estimator the paper describes (d z flows from the decoder input and the
+        # image network into q(z|x)); tested against the oracle's reparam_grad=True (tests/test_gpu_step_parity.py)
+        self.reparam_grad = False
+        self.stats_host = None
+        self._sid = 0
+        # the side stream carries bulk work that is off the critical path: lowest hardware priority, so that small
+        # critical-path kernels on the main stream are dispatched ahead of its queued workgroups
+        try:
+            pr = torch.cuda.Stream.priority_range()
+            lo_pri, hi_pri = max(pr), min(pr)
+        except Exception:
+            lo_pri, hi_pri = 0, 0
+        self.side_stream = self._side_stream_plain = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        # third stream: the small, latency-bound backward of the image / q(z|x) networks, independent of the text path
+        self.aux_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        # measured (tools/sched_ab.py, fixed prior): 2.53 ms/step with that work on the side stream vs 2.59 ms on a stream of
+        # its own; the conditional model keeps it (encoder_tgt's 2 x B-step recurrences would otherwise block the side stream)
+        self.use_aux_stream = _os_env.get("VMMT_AUX_STREAM", "1") == "1"
+        # fourth stream (conditional model only): encoder_tgt's backward recurrence, 2 x B dependent steps that would otherwise hold
+        # up everything queued behind them on the aux stream
+        self.tgt_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        # workgroups of the BACKGROUND half of Adam (side stream, underneath the next step's encoder recurrence).  Unthrottled it takes
+        # the memory system for ~200 us and the latency-bound persistent LSTM kernel next to it runs at half speed; one workgroup per
+        # CU still finishes before the decoder-side weights are needed.  tools/ab.py, ms per step: 4096 wgs 1.958-2.007 | 384: 1.957 |
+        # 288: 1.972 | 256: 1.921-1.951 | 224: 1.908 | 192: 1.987 | 128: 2.051 | 64: 2.324 (a faster two-chunk kernel at 256: 1.98)
+        self.bg_adam_blocks = int(_os_env.get("VMMT_BG_ADAM_BLOCKS", "256"))
+        # cap of the weight-gradient products' split-K.  On an idle chip 4, 8 and 16 splits cost the same (tools/gemm_split.py), in the step
+        # the extra workgroups and atomics get in the way of everything that runs next to them (tools/ab.py, ms per step by cap: 64:
+        # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)
+        self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
+        self.cond_aux_early = _os_env.get("VMMT_COND_AUX_EARLY", "1") == "1"
+        self.cond_emb_fg = _os_env.get("VMMT_COND_EMB_FG", "1") == "1"
+        self.aux_early = _os_env.get("VMMT_AUX_EARLY", "1") == "1"
+        self.aux_kl_first = _os_env.get("VMMT_AUX_KL_FIRST", "1") == "1"
+        self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
+        self.lstm_db_in_gemm = _os_env.get("VMMT_LSTM_DB_IN_GEMM", "1") == "1"
+        self.dec_grads_on_aux = _os_env.get("VMMT_DEC_GRADS_ON_AUX", "1") == "1"
+        self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
+        self.bwd_layers_parallel = _os_env.get("VMMT_BWD_LAYERS_PARALLEL", "1") == "1"   # >= 2 layers: top encoder layer next to the lower decoder layers
+        # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
+        #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
+        self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
+        self.use_side_stream = True
+        self._masked_streams = []
+        import os as _os
+        self.q_parallel = _os.environ.get("VMMT_QPAR", "1") == "1"    # q(z|x): scale branch on the side stream next to the location branch
+        self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
+        self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
+        self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
+        self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
+        self._sumsq_by_plan = False
+        self.fused_qnet = _os_env.get("VMMT_FUSED_QNET", "1") == "1"
+        self.qnet_split = _os_env.get("VMMT_QNET_SPLIT", "1") == "1"     # location / scale networks in separate workgroups (csrc/qnet.hip)
+        self.gen_fused = _os_env.get("VMMT_GEN_FUSED", "1") == "1"       # csrc/generator_fused.hip where it applies (bf16, H = 512 / 256)
+        # decode.py: a decoded position as ONE hipGraph, replayed -- built, bit-identical, and measured SLOWER than issuing its ~15 launches
+        # one by one (tools/decode_bench.py, ms per 24 positions, graph / plain: beam 5 x 30 sentences 3.87 / 3.62, arg-max x 256 3.68 / 2.92:
+        # a position is bound by the GPU's dependent-kernel turnaround, not by the host, and a replay does not overlap the next one's launch)
+        self.decode_graphs = _os_env.get("VMMT_DECODE_GRAPHS", "0") == "1"
+        self.persistent_lstm = _os_env.get("VMMT_PERSISTENT_LSTM", "1") == "1"     # plans are built per workspace: set before the first forward
+        self.seq_syncs = []
+        self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
+        self._works = []
+
+    def set_side_cu_mask(self, mask_words):
+        """restrict the side stream to the CUs set in `mask_words` (list of 32-bit words, bit i = CU i); None restores the
+        unrestricted low-priority stream.  Keeps CUs free for the main stream's latency-critical kernels."""
+        if mask_words is None:
+            self.side_stream = self._side_stream_plain
+            return
+        arr = (C.c_uint32 * len(mask_words))(*[int(w) & 0xFFFFFFFF for w in mask_words])
+        out = C.c_void_p()
+        L.check(self.lib.vmmt_stream_create_masked(arr, len(mask_words), 0, C.byref(out)), "vmmt_stream_create_masked")
+        self._masked_streams.append(out.value)
+        self.side_stream = torch.cuda.ExternalStream(out.value, device=self.dev)
+
+    # ------------------------------------------------------------------------------------------------ arena
+    def _build_arena(self, seed, param_init):
+        wg, ng = self.d.param_shapes()
+        self.names_grad = [n for n, _ in wg]
+        self.names_nograd = [n for n, _ in ng]
+        off = 0
+        self.offsets = {}
+        self.first_enc_name = "encoder.rnn.weight_ih_l%d" % (self.d.layers - 1)     # arena: [generator|attn|decoder|dec emb][encoder|enc emb|inference nets]
+        # the four data-parallel SEGMENTS of the arena, in the order backward completes them (_plan_backward issues one collective per
+        # segment): [generator][attention + decoder + target embeddings][encoder + source embeddings (+ conditional networks)]
+        # [inference networks].  A segment starts on a multiple of SEG_ALIGN elements, so that it splits into 1 / 2 / 4 / 8 equal
+        # rank shards of whole 64-element units (reduce-scatter + sharded Adam + all-gather: optim_step); the padding holds zeros
+        seg_starts = ("generator.0.weight", "decoder.attn.linear_out.weight", self.first_enc_name, "inf_net_image.location.fc2.weight")
+        self.seg_bounds = []
+        for n, shp in wg + ng:
+            if n in seg_starts or n == ng[0][0]:
+                off = _ru(off, SEG_ALIGN)
+                self.seg_bounds.append(off)
+            if n == ng[0][0]:
+                self.n_opt = off                       # optimiser / all-reduce range = [0, n_opt)
+            self.offsets[n] = (off, shp)
+            off += _ru(int(math.prod(shp)), 64)
+        self.n_total = off
+        assert len(self.seg_bounds) == 5 and self.seg_bounds[-1] == self.n_opt
+        self.segments = list(zip(self.seg_bounds[:-1], self.seg_bounds[1:]))
+        dev = self.dev
+        self.flat_p = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(self.n_opt, dtype=torch.float32, device=dev)
+        self.params, self.grads = {}, {}
+        g = torch.Generator(device="cpu").manual_seed(seed)       # (explicit devices: a driver may have made CUDA the default tensor type)
+        for n, (o, shp) in self.offsets.items():
+            k = int(math.prod(shp))
+            self.params[n] = self.flat_p[o:o + k].view(*shp)
+            if o < self.n_opt:
+                self.grads[n] = self.flat_g[o:o + k].view(*shp)
+            if param_init:                             # ModelConstructor.py:598-603 (H7: every parameter)
+                self.params[n].copy_(((torch.rand(*shp, generator=g, device="cpu") * 2 - 1) * param_init))
+
+    # ------------------------------------------------------------------------------------------------ embedding tables by row
+    def _build_row_tables(self):
+        """Row-wise gradient bookkeeping for the two embedding tables (csrc/optim.hip: vmmt_rows_mark / _zero / vmmt_sumsq_rows /
+        vmmt_adam_rows_step).  The tables are 54 % of the optimised parameters and a step's gradient lives in the <= S B + T' B rows
+        the batch looked up (17 % of 30 000 at the benchmark shape): with one flag per row, the gradient is cleared, normed and read
+        for those rows only -- 12 of the 36 B per element and step the dense path moves (4 zeroing + 4 norm + 28 Adam), and the
+        zero-fill and the norm stop touching 200 MB each.  Every row is still UPDATED at every step (the moments of a row without
+        gradient decay, its parameter follows them): bit-identical to dense Adam (tests/test_gpu_row_adam.py).  Off under data
+        parallelism (the flagged set would have to be the union over the ranks) and for the conditional model (two streams flag
+        rows of the shared target table).
+        OPT-IN (VMMT_ROW_ADAM=1): measured on MI355X it does not pay at these sizes -- 1.787 against 1.746 ms per step at BASELINE
+        config 2, 2.704 against 2.728 at the run scripts' shape, 1.867 against 1.863 through the trainer: the dense streams run at
+        6.7 TB/s, half of them underneath the next step's encoder, while the row kernels add six small launches to the step's head
+        and tail.  (The LAZY variant -- rows updated only when used, missed zero-gradient steps replayed -- saves 0.7 GB per step and
+        was 1.5 % faster on the benchmark's recurring batches, but with Zipf-distributed ids the replays (sqrt + division per element
+        and missed step, in front of the embedding lookup) cost more than the traffic: 2.11 against 1.92 ms through the trainer.  Not
+        kept: DESIGN.md section 6.)"""
+        names = ("encoder.embeddings.make_embedding.emb_luts.0.weight", "decoder.embeddings.make_embedding.emb_luts.0.weight")
+        self.row_adam = _os_env.get("VMMT_ROW_ADAM", "0") == "1" and not self.d.conditional
+        self.row_tables = []
+        if self.d.conditional:
+            return
+        for n in names:          # (the flag arrays are always there -- 240 KB -- so that the switch can be set after construction)
+            off, (R, Cc) = self.offsets[n]
+            if Cc % 4 or off % 4:
+                self.row_adam, self.row_tables = False, []
+                return
+            self.row_tables.append(dict(name=n, off=off, R=R, C=Cc, end=off + R * Cc,
+                                        flags=torch.zeros(R, dtype=torch.int32, device=self.dev),
+                                        rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev)))
+
+    def rows_active(self):
+        return bool(self.row_tables) and self.row_adam and not (self.dp is not None and self.dp.world > 1)
+
+    def _row_mark_entries(self, plan, table_index, ids_ptr, n_ids):
+        """plan entries (training forward, off the critical path): flag the batch's rows of an embedding table and clear their
+        gradient rows, which the backward plan's scatter-add accumulates into"""
+        if not self.rows_active():
+            return
+        t = self.row_tables[table_index]
+        self._call(plan, self.lib.vmmt_rows_mark, ids_ptr, n_ids, t["flags"].data_ptr(), t["R"])
+        self._call(plan, self.lib.vmmt_rows_zero, self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr())
+
+    def pp(self, name, r=0, c=0):
+        o, shp = self.offsets[name]
+        ld = shp[1] if len(shp) > 1 else 0
+        return self.flat_p.data_ptr() + (o + r * ld + c) * 4
+
+    def gp(self, name, r=0, c=0):
+        o, shp = self.offsets[name]
+        ld = shp[1] if len(shp) > 1 else 0
+        return self.flat_g.data_ptr() + (o + r * ld + c) * 4
+
+    def load_state_dict(self, sd):
+        for n, t in sd.items():
+            if n in self.params:
+                self.params[n].copy_(t.to(torch.float32))
+        self.shadows_dirty = True
+
+    def state_dict(self):
+        sd = {n: v.detach().clone() for n, v in self.params.items()}
+        if self.d.conditional:      # encoder_tgt shares the decoder's table; the reference's state dict lists it under both names
+            sd["encoder_tgt.embeddings.make_embedding.emb_luts.0.weight"] = sd["decoder.embeddings.make_embedding.emb_luts.0.weight"]
+        return sd
+
+    # ------------------------------------------------------------------------------------------------ shadows
+    def _build_shadows(self):
+        d, T, dev = self.d, self.T, self.dev
+        self.sh = {}
+        self.pack_calls = []
+
+        def shadow(key, rows, cols, src, c0=0, ncols=None, transpose=False, dtype=None, src2=None, row_off=0, col_off=0, gate=None):
+            """one compute copy (or one piece of it).  (row_off, col_off): position of the piece in the shadow as stored, i.e. AFTER the
+            transpose.  gate = (h, hp), h != hp: the source's 4h rows (a bias: its 4h entries) are nn.LSTM's gate blocks i, f, g, o; block
+            g lands at g * hp of the shadow (Dims.hp): one pack descriptor per block"""
+            dt = dtype if dtype is not None else T
+            code = L.F32 if dt == torch.float32 else L.BF16
+            _, shp = self.offsets[src]
+            two_d = len(shp) > 1
+            ld_src = shp[1] if two_d else shp[0]
+            R = shp[0] if two_d else 1
+            Cc = ncols if ncols is not None else (shp[1] if two_d else shp[0])
+            if key not in self.sh:
+                self.sh[key] = Buf(rows, cols, dt, dev)
+            b = self.sh[key]
+            blocks = [(0, 0)] if (gate is None or gate[0] == gate[1]) else [(g * gate[0], g * gate[1]) for g in range(4)]
+            for s0, d0 in blocks:
+                if len(blocks) > 1:
+                    if two_d:
+                        R = gate[0]
+                    else:
+                        Cc = gate[0]
+                if two_d:       # gate blocks are row blocks of the source: row blocks of the shadow, column blocks of a transposed one
+                    sp = self.pp(src, s0, c0)
+                    s2 = self.pp(src2, s0, c0) if src2 else None
+                    dst = b.p(row_off + d0, col_off) if not transpose else b.p(row_off, col_off + d0)
+                else:           # a bias vector [4h] packed as one row
+                    sp = self.pp(src, 0, s0)
+                    s2 = self.pp(src2, 0, s0) if src2 else None
+                    dst = b.p(row_off, col_off + d0)
+                self.pack_calls.append((code, sp, s2, ld_src, dst, b.ld, R, Cc, 1 if transpose else 0))
+
+        ge, gd = (d.hd, d.hdp), (d.hid, d.hp)       # gate blocks of the encoder's directions / of the decoder as stored -> as computed
+        for l in range(d.layers):
+            i = d.emb if l == 0 else d.hid
+            for k, suf in enumerate([""] + (["_reverse"] if d.brnn else [])):
+                # concatenated over directions: rows k*4Hd ..
+                shadow("enc_wih_l%d" % l, d.dirs * 4 * d.hdp, i, "encoder.rnn.weight_ih_l%d%s" % (l, suf), row_off=k * 4 * d.hdp, gate=ge)
+                shadow("enc_b_l%d" % l, 1, d.dirs * 4 * d.hdp, "encoder.rnn.bias_ih_l%d%s" % (l, suf), dtype=torch.float32,
+                       src2="encoder.rnn.bias_hh_l%d%s" % (l, suf), col_off=k * 4 * d.hdp, gate=ge)
+                shadow("enc_whh_l%d_d%d" % (l, k), 4 * d.hdp, d.hd, "encoder.rnn.weight_hh_l%d%s" % (l, suf), gate=ge)
+                shadow("enc_whhT_l%d_d%d" % (l, k), d.hd, 4 * d.hdp, "encoder.rnn.weight_hh_l%d%s" % (l, suf), transpose=True, gate=ge)
+        for l in range(d.layers):
+            if l == 0:
+                shadow("dec_wih_l0_e", 4 * d.hp, d.emb, "decoder.rnn.weight_ih_l0", c0=0, ncols=d.emb, gate=gd)
+                shadow("dec_wih_l0_z", 4 * d.hp, d.z, "decoder.rnn.weight_ih_l0", c0=d.emb, ncols=d.z, gate=gd)
+            else:
+                shadow("dec_wih_l%d" % l, 4 * d.hp, d.hid, "decoder.rnn.weight_ih_l%d" % l, gate=gd)
+            shadow("dec_b_l%d" % l, 1, 4 * d.hp, "decoder.rnn.bias_ih_l%d" % l, dtype=torch.float32,
+                   src2="decoder.rnn.bias_hh_l%d" % l, gate=gd)
+            shadow("dec_whh_l%d" % l, 4 * d.hp, d.hid, "decoder.rnn.weight_hh_l%d" % l, gate=gd)
+            shadow("dec_whhT_l%d" % l, d.hid, 4 * d.hp, "decoder.rnn.weight_hh_l%d" % l, transpose=True, gate=gd)
+        shadow("wa", d.hid, d.hid, "decoder.attn.linear_in.weight")
+        # W_out [H][2H] multiplies [c ; r] (GlobalAttention.py:187); the two halves of that buffer start at 0 and hp
+        if d.hp == d.hid:
+            shadow("wo", d.hid, 2 * d.hid, "decoder.attn.linear_out.weight")
+        else:
+            shadow("wo", d.hid, 2 * d.hp, "decoder.attn.linear_out.weight", c0=0, ncols=d.hid)
+            shadow("wo", d.hid, 2 * d.hp, "decoder.attn.linear_out.weight", c0=d.hid, ncols=d.hid, col_off=d.hp)
+        for br in ("location", "scale"):
+            if d.conditional and d.pad:
+                # W1 [Z][h_x (H) | h_y (2 ht) | v] against the padded input [h_x : hp | h_y fwd : htp | h_y bwd : htp | v]
+                for c0, nc, co in ((0, d.hid, 0), (d.hid, d.ht, d.hp), (d.hid + d.ht, d.ht, d.hp + d.htp), (2 * d.hid, d.img, d.hp + 2 * d.htp)):
+                    shadow("q_%s_w1" % br, d.z, d.qin_p, "inf_net_global.%s.fc1.weight" % br, c0=c0, ncols=nc, col_off=co)
+            else:
+                shadow("q_%s_w1" % br, d.z, d.qin, "inf_net_global.%s.fc1.weight" % br)
+            shadow("q_%s_w2" % br, d.z, d.zp, "inf_net_global.%s.fc2.weight" % br)     # (read d.zp columns wide by the fused q(z|x) kernel)
+        if d.conditional:
+            for br in ("location", "scale"):
+                shadow("p_%s_w1" % br, d.z, d.hid, "gen_net_global.%s.fc1.weight" % br)
+                shadow("p_%s_w2" % br, d.z, d.z, "gen_net_global.%s.fc2.weight" % br)
+            gt = (d.ht, d.htp)
+            for l in range(d.layers):
+                for k, suf in enumerate(("", "_reverse")):
+                    nm = "encoder_tgt.rnn.weight_ih_l%d%s" % (l, suf)
+                    if l == 0 or d.htp == d.ht:
+                        shadow("enct_wih_l%d" % l, 2 * 4 * d.htp, d.emb if l == 0 else d.hid, nm, row_off=k * 4 * d.htp, gate=gt)
+                    else:       # the layer below delivers [fwd : htp | bwd : htp]
+                        shadow("enct_wih_l%d" % l, 2 * 4 * d.htp, 2 * d.htp, nm, row_off=k * 4 * d.htp, gate=gt, c0=0, ncols=d.ht)
+                        shadow("enct_wih_l%d" % l, 2 * 4 * d.htp, 2 * d.htp, nm, row_off=k * 4 * d.htp, gate=gt, c0=d.ht, ncols=d.ht, col_off=d.htp)
+                    shadow("enct_b_l%d" % l, 1, 2 * 4 * d.htp, "encoder_tgt.rnn.bias_ih_l%d%s" % (l, suf), dtype=torch.float32,
+                           src2="encoder_tgt.rnn.bias_hh_l%d%s" % (l, suf), col_off=k * 4 * d.htp, gate=gt)
+                    shadow("enct_whh_l%d_d%d" % (l, k), 4 * d.htp, d.ht, "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf), gate=gt)
+                    shadow("enct_whhT_l%d_d%d" % (l, k), d.ht, 4 * d.htp, "encoder_tgt.rnn.weight_hh_l%d%s" % (l, suf), transpose=True, gate=gt)
+        shadow("iv_w1", d.img, d.z, "inf_net_image.location.fc1.weight")
+        shadow("iv_w2", d.img, d.img, "inf_net_image.location.fc2.weight")
+        shadow("wg", d.vt, d.hid, "generator.0.weight")
+
+    def _fused_shadows(self):
+        """[(lo, hi, shadow pointer)] in arena order: optimised 2-D weights of at least 2 M elements whose bf16 shadow has unpadded rows
+        and no second source -- the shadow then has the parameter's flat layout and vmmt_adam_step writes it (optim_step)"""
+        if not hasattr(self, "_fused_sh"):
+            self._fused_sh = []
+            base = self.flat_p.data_ptr()
+            for code, sp, s2, lds, dst, ldd, R, Cc, tr in self.pack_calls:
+                o = (sp - base) // 4
+                whole = any(off == o and len(shp) == 2 and shp[0] * shp[1] == R * Cc for off, shp in self.offsets.values())
+                if code == L.BF16 and not tr and s2 is None and ldd == Cc and lds == Cc and whole and R * Cc >= (1 << 21) and \
+                        o + R * Cc <= self.n_opt and dst % 8 == 0:
+                    self._fused_sh.append((o, o + R * Cc, dst))
+            self._fused_sh.sort()
+        return self._fused_sh
+
+    def _pack_tables(self):
+        """descriptor tables for vmmt_pack_multi.  Parts 0 / 1: every shadow of [encoder + inference networks] / [generator + attention +
+        decoder] (after load_state_dict / a replica broadcast); parts 2 / 3: the same without the shadows the optimiser step writes
+        itself (_fused_shadows): what optim_step refreshes"""
+        if not hasattr(self, "_pack_tab"):
+            self._pack_tab = []
+            enc_lo = self.offsets[self.first_enc_name][0]
+            base = self.flat_p.data_ptr()
+            fused = set(d for _, _, d in self._fused_shadows())
+            for part in (0, 1, 2, 3):
+                sel = [c for c in self.pack_calls if ((c[1] - base) // 4 >= enc_lo) == (part % 2 == 0) and (part < 2 or c[4] not in fused)]
+                arr = (L.PackDesc * max(1, len(sel)))()
+                start = 0
+                for k, (code, sp, s2, lds, dst, ldd, R, Cc, tr) in enumerate(sel):
+                    ch = ((R + 63) // 64) * ((Cc + 31) // 32) if tr else (R * Cc + 2047) // 2048      # vmmt.h: vmmt_pack_multi
+                    arr[k] = L.PackDesc(sp, s2, dst, lds, ldd, R, Cc, tr, code, start, ch)
+                    start += ch
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                self._pack_tab.append((host.to(self.dev), len(sel), start))
+        return self._pack_tab
+
+    def _pack_part(self, part, stream):
+        tab, n, chunks = self._pack_tables()[part]
+        if n:
+            L.check(self.lib.vmmt_pack_multi(tab.data_ptr(), n, chunks, stream), "vmmt_pack_multi")
+
+    def refresh_shadows(self, stream):
+        """fp32 master -> compute shadows (after load_state_dict / first use; optim_step refreshes them itself)."""
+        if not self.shadows_dirty:
+            return
+        self._pack_part(0, stream)
+        self._pack_part(1, stream)
+        self.shadows_dirty = False
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
+              act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
+              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None):
+        """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out[, out2]): the column sums of the K-strided A operand from the same
+        pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached"""
+        if split_k == -1:
+            # weight-gradient heuristic: enough workgroups to fill 256 CUs, >= 256 reduction steps each, at most max_split_k splits
+            tiles = ((M + 63) // 64) * ((N + 63) // 64)
+            split_k = max(1, min(K // 256, (1024 + tiles - 1) // tiles, int(self.max_split_k)))
+            if split_k == 1:
+                accumulate = 1          # gradients always ACCUMULATE into the arena (zeroed at the start of a step)
+        if a_kmod == 0 and b_kmod == 0:
+            K = _ru(K, KPAD)            # operands are Bufs: zero-padded to whole slabs (see Buf)
+        a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
+                       add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k, b_batch_rows, b_batch_stride,
+                       None, 0, None, None)
+        # rmap / cmap = (blk, valid): output rows / columns computed in padded blocks, stored densely (vmmt_gemm_args.c_row_blk)
+        if rmap is not None and rmap[0] != rmap[1]:
+            a.c_row_blk, a.c_row_valid = rmap
+        if cmap is not None and cmap[0] != cmap[1]:
+            a.c_col_blk, a.c_col_valid = cmap
+        attached = False
+        if colsum is not None:
+            a.colsum_w, a.colsum_w_stride, a.colsum_out = colsum[:3]
+            a.colsum_out2 = colsum[3] if len(colsum) > 3 else None
+            attached = bool(self.lib.vmmt_gemm_colsum_applies(C.byref(a)))
+            if not attached:
+                a.colsum_w, a.colsum_w_stride, a.colsum_out, a.colsum_out2 = None, 0, None, None
+        plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
+        return attached
+
+    def _call(self, plan, fn, *args):
+        # plan entries are positional ctypes calls: at least the COUNT is checked against the declared signature when the plan is built
+        # (the stream is appended at run time), so that a kernel that gained an argument fails here and not as a shifted pointer
+        assert fn.argtypes is not None and len(args) + 1 == len(fn.argtypes), (fn.__name__, len(args) + 1, len(fn.argtypes))
+        plan.append((fn, args, fn.__name__, None, self._sid))
+
+    # pointer fields of the step descriptors that walk the batch: (pointer, leading dimension, element size; None = the storage type T)
+    _SEQ_F = (("h_prev", "ld_hprev", None), ("c_prev", "ld_cprev", 4), ("gx", "ld_gx", 4), ("gx2", "ld_gx2", 4), ("gates", "ld_gates", None),
+              ("c_out", "ld_c", 4), ("h_out", "ld_h", None), ("h_n", "ld_hn", None), ("c_n", "ld_cn", 4))
+    _SEQ_B = (("dgates_next", "ld_dgn", None), ("dh_above", "ld_dha", None), ("gates", "ld_gates", None), ("c_t", "ld_ct", 4), ("c_prev", "ld_cp", 4),
+              ("dc_carry", "ld_dcc", 4), ("dgates_out", "ld_dgo", None), ("dh_n", "ld_dhn", 4), ("dc_n", "ld_dcn", 4), ("dh0_out", "ld_dh0", 4))
+
+    def _seq_row_chunks(self, arr, fields, ndir, B, H):
+        """A persistent recurrence needs all of its workgroups resident at once: (B / 32 row groups) x (H / 16 unit slices) x directions
+        <= 256.  Sentences are independent in a recurrence, so a batch that does not fit is cut into ROW chunks, one persistent launch
+        each, one after the other (BASELINE config 5: H = 1024 -> 64 slices -> 128 sentences per launch; the per-step kernels it
+        replaces re-read their W_hh slice from L2 at every step: 35 us per backward step against 8).  -> [(descriptors, row offset,
+        rows)], or None when the persistent kernel does not serve this size at all."""
+        if H not in (64, 128, 256, 512, 1024):
+            return None
+        groups = 256 // ((H // 16) * ndir)
+        if groups < 1:
+            return None
+        rows = 32 * groups
+        if B <= rows:
+            return [(arr, 0, B)]
+        out = []
+        n = len(arr)
+        for r0 in range(0, B, rows):
+            chunk = (type(arr[0]) * n)()
+            C.memmove(chunk, arr, C.sizeof(arr))
+            for a in chunk:
+                for ptr, ld, esz in fields:
+                    p0 = getattr(a, ptr)
+                    if p0:
+                        setattr(a, ptr, p0 + r0 * getattr(a, ld) * (esz if esz is not None else self.tsz))
+            out.append((chunk, r0, min(rows, B - r0)))
+        return out
+
+    def _lstm_seq_fwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H):
+        """plan entry: a whole forward recurrence (nsteps x ndir step descriptors in `arr`).  persistent_lstm: ONE launch of the
+        persistent kernel (W_hh resident in LDS, in-launch hand-off of h_t: csrc/lstm_seq.hip), which falls back by itself to the
+        per-step kernels where it does not apply; otherwise the per-step kernels issued from one host call."""
+        chunks = self._seq_row_chunks(arr, self._SEQ_F, ndir, B, H) if (self.persistent_lstm and self.dt == L.BF16) else None
+        if chunks is not None and len(chunks) > 1:
+            for sub, r0, rows in chunks:
+                self._lstm_seq_fwd(plan, sub, ndir, nsteps, (lens_ptr + 8 * r0) if lens_ptr else None, rows, H)
+            return
+        if self.persistent_lstm:
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+            sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
+            xchg = torch.zeros(max(16, self.lib.vmmt_lstm_seq_xchg_bytes(ndir, B, H)), dtype=torch.uint8, device=self.dev)
+            plan.append((self.lib.vmmt_lstm_seq_fwd, (self.dt, ndir, nsteps, arr, dev.data_ptr(), lens_ptr, B, H, sync.data_ptr(), xchg.data_ptr()),
+                         "vmmt_lstm_seq_fwd", (arr, dev, sync, xchg), self._sid))
+            self.seq_syncs.append(sync)
+        else:
+            plan.append((self.lib.vmmt_lstm_chain_fwd, (self.dt, ndir, nsteps, arr, lens_ptr, B, H), "vmmt_lstm_chain_fwd", arr, self._sid))
+
+    def _lstm_seq_bwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H, with_dh0=0):
+        """plan entry: a whole backward recurrence (the mode-0 steps; with_dh0: `arr` ends with one mode-1 step, the gradient of
+        the initial hidden state), see _lstm_seq_fwd"""
+        chunks = self._seq_row_chunks(arr, self._SEQ_B, ndir, B, H) if (self.persistent_lstm and self.dt == L.BF16) else None
+        if chunks is not None and len(chunks) > 1:
+            for sub, r0, rows in chunks:
+                self._lstm_seq_bwd(plan, sub, ndir, nsteps, (lens_ptr + 8 * r0) if lens_ptr else None, rows, H, with_dh0=with_dh0)
+            return
+        if self.persistent_lstm:
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+            sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
+            xchg = torch.zeros(max(16, self.lib.vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H)), dtype=torch.uint8, device=self.dev)
+            plan.append((self.lib.vmmt_lstm_seq_bwd, (self.dt, ndir, nsteps, arr, dev.data_ptr(), lens_ptr, B, H, with_dh0, sync.data_ptr(),
+                                                      xchg.data_ptr()), "vmmt_lstm_seq_bwd", (arr, dev, sync, xchg), self._sid))
+            self.seq_syncs.append(sync)
+        else:
+            plan.append((self.lib.vmmt_lstm_chain_bwd, (self.dt, ndir, nsteps, arr, lens_ptr, B, H, 0), "vmmt_lstm_chain_bwd", arr, self._sid))
+            if with_dh0:
+                last = C.cast(C.byref(arr, nsteps * ndir * C.sizeof(L.LstmDirBwd)), C.POINTER(L.LstmDirBwd))
+                plan.append((self.lib.vmmt_lstm_step_bwd, (self.dt, ndir, last, lens_ptr, B, H, 1), "vmmt_lstm_step_bwd", arr, self._sid))
+
+    def lstm_seq_errors(self):
+        """error words of the persistent recurrence launches so far (0 = every in-launch wait completed); synchronises"""
+        torch.cuda.synchronize(self.dev)
+        words = self.lib.vmmt_lstm_seq_sync_words()
+        return [int(s[2].item()) for s in self.seq_syncs]            # [launch epoch, finish count, error word]
+
+    def check_async_errors(self):
+        """raise if an in-launch wait of a persistent recurrence kernel ever ran into its 2-second bound (a workgroup of the row group
+        was not resident: another process on the GPU, a CU mask): the results of that step are then wrong.  Synchronises; the trainer
+        mirror calls it at the end of every epoch and before a checkpoint is written, bench.py after its timed region."""
+        bad = [i for i, x in enumerate(self.lstm_seq_errors()) if x != 0]
+        if bad:
+            raise RuntimeError("persistent LSTM launch(es) %s reported a hand-off timeout (error words %s): results invalid; "
+                               "rerun with VMMT_PERSISTENT_LSTM=0" % (bad, [self.lstm_seq_errors()[i] for i in bad]))
+
+    def _zero(self, plan, tensors):
+        """plan entry: clear all `tensors` (contiguous device tensors) with ONE vmmt_zero_multi launch"""
+        arr = (L.ZeroDesc * len(tensors))()
+        start = 0
+        for k, t in enumerate(tensors):
+            nbytes = t.numel() * t.element_size()
+            assert t.is_contiguous() and t.data_ptr() % 16 == 0 and nbytes % 4 == 0
+            arr[k] = L.ZeroDesc(t.data_ptr(), nbytes, start)
+            start += (nbytes + 16383) // 16384
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+        plan.append((self.lib.vmmt_zero_multi, (tab.data_ptr(), len(tensors), start), "vmmt_zero_multi", (tab, tensors), self._sid))
+
+    # -- two-stream plans: entries carry a stream id (0 = main = torch's current stream, 1 = side stream); EV_RECORD /
+    #    EV_WAIT entries fork and join them.  Work that is off the critical path of the step (weight-gradient GEMMs, bias
+    #    sums, the image / q(z|x) networks' backward) runs on the side stream underneath the latency-bound LSTM steps.
+    def _record(self, plan, ev):
+        plan.append((None, ev, "EV_RECORD", None, self._sid))
+
+    def _wait(self, plan, ev):
+        plan.append((None, ev, "EV_WAIT", None, self._sid))
+
+    def _allreduce(self, plan, first_name, end_name):
+        """plan entry: sum the arena range [offset(first_name), offset(end_name)) over the data-parallel ranks, issued on
+        the entry's stream right behind the kernels that produced it (no-op for a single process)."""
+        lo = self.offsets[first_name][0]
+        hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
+        plan.append((None, (lo, min(hi, self.n_opt)), "ALLREDUCE", None, self._sid))
+
+    def _sumsq_entry(self, plan, first_name, end_name, slot):
+        """plan entry: ||g||^2 of an arena range into slot `slot` of the step's norm scratch (behind that range's all-reduce);
+        every range has a slot of its own and Adam adds the slots in index order: the norm is bit-reproducible"""
+        lo = self.offsets[first_name][0]
+        hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
+        hi = min(hi, self.n_opt)
+        if self.rows_active():
+            # an embedding table inside the range: its flagged rows go to a slot of their own (3 + table index), the dense kernel
+            # takes what lies in front of it (slot) and behind it (slot + 5: only the conditional model has parameters there)
+            for k, t in enumerate(self.row_tables):
+                if lo <= t["off"] and t["end"] <= hi:
+                    plan.append((None, (k, 3 + k), "SUMSQ_ROWS", None, self._sid))
+                    if t["off"] > lo:
+                        plan.append((None, (lo, t["off"], slot), "SUMSQ", None, self._sid))
+                    if hi - t["end"] >= SEG_ALIGN:      # (less: only the segment's alignment padding follows)
+                        plan.append((None, (t["end"], hi, slot + 5), "SUMSQ", None, self._sid))
+                    return
+        plan.append((None, (lo, hi, slot), "SUMSQ", None, self._sid))
+
+    def finish_allreduce(self):
+        """make the current stream wait for every outstanding gradient all-reduce (call before optim_step)"""
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def _run(self, plan, events=None):
+        main = torch.cuda.current_stream(self.dev)
+        side = self.side_stream if self.use_side_stream else main
+        aux = self.aux_stream if (self.use_side_stream and self.use_aux_stream) else side
+        tgt = self.tgt_stream if aux is self.aux_stream else aux
+        ts = (main, side, aux, tgt)
+        hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream, tgt.cuda_stream)
+        trace, last = self.trace, None
+        for entry in plan:
+            fn, args, name, _keep, sid = entry
+            if trace is not None and sid == 0 and name != last:     # tools/phase_times.py: timing events at phase changes
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(main)
+                trace.append((name, ev))
+                last = name
+            self._exec(entry, ts, hs, events, side is main)
+
+    def _exec(self, entry, ts, hs, events, single_stream):
+        fn, args, name, _keep, sid = entry
+        if fn is None:
+            if name == "SUMSQ":
+                if self.dp is not None and self.dp.world > 1 and self.dp.sharded:
+                    return          # sharded optimiser: every rank takes the norm of ITS shards in optim_step
+                lo, hi, slot = args
+                if self._works:
+                    with torch.cuda.stream(ts[sid]):
+                        for w in self._works:
+                            w.wait()
+                    self._works = []
+                L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq")
+                self._sumsq_by_plan = True
+                return
+            if name == "SUMSQ_ROWS":
+                k, slot = args
+                t = self.row_tables[k]
+                L.check(self.lib.vmmt_sumsq_rows(self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr(), t["rowsq"].data_ptr(),
+                                                 self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq_rows")
+                return
+            if name == "KL_ALLREDUCE":
+                if self.dp is not None and self.dp.world > 1:
+                    ws = self._cur_ws
+                    with torch.cuda.stream(ts[sid]):
+                        ws.kl_global.copy_(ws.stats[L.STAT_KL_SUM:L.STAT_KL_SUM + 1])
+                        self.dp.dist.all_reduce(ws.kl_global, async_op=True).wait()
+                return
+            if name == "ALLREDUCE":
+                if self.dp is not None and self.dp.world > 1:
+                    lo, hi = args
+                    with torch.cuda.stream(ts[sid]):
+                        if self.dp.sharded:     # each rank receives the sum of ITS 1/world of the segment (in place)
+                            self._works.append(self.dp.reduce_scatter(self.flat_g, lo, hi))
+                        else:
+                            self._works.append(self.dp.dist.all_reduce(self.flat_g[lo:hi], async_op=True))
+                return
+            if single_stream:
+                return
+            if name == "EV_RECORD":
+                ev = events.get(args)
+                if ev is None:
+                    ev = events[args] = torch.cuda.Event()
+                ev.record(ts[sid])
+            else:
+                ev = events.get(args) if args in events else self.global_events.get(args)
+                if ev is not None:
+                    ts[sid].wait_event(ev)
+        else:
+            rc = fn(*args, hs[sid])
+            if rc != 0:
+                L.check(rc, name)
+
+    # ------------------------------------------------------------------------------------------------ workspace
+    def bucket_shape(self, S, Tp):
+        g = self.shape_bucket
+        return min(_ru(S, g), max(S, 64)), _ru(Tp, g)
+
+    def shared_storage(self, name, elems, dtype):
+        """one device allocation per name, shared by every workspace and grown to the largest request.  Growing it invalidates
+        the pointers baked into the cached launch plans, so every cached workspace is dropped then (rare: a new largest shape)."""
+        cur = self._shared.get(name)
+        if cur is None or cur.numel() < elems or cur.dtype != dtype:
+            if cur is not None:
+                self.drop_workspaces()
+                self._shared[name] = cur = None
+            self._shared[name] = cur = torch.zeros(elems, dtype=dtype, device=self.dev)
+        return cur
+
+    def drop_workspaces(self, keep_last=0):
+        """evict cached training workspaces (oldest first), keeping the `keep_last` most recently used"""
+        keys = [k for k, v in self.ws.items() if isinstance(v, Workspace)]
+        victims = keys[:max(0, len(keys) - keep_last)]
+        if victims:
+            torch.cuda.synchronize(self.dev)      # their buffers may still be in use on the side streams
+            for k in victims:
+                del self.ws[k]
+                self.ws_evictions += 1
+
+    def workspace_bytes(self):
+        return sum(v.nbytes for v in self.ws.values() if isinstance(v, Workspace))
+
+    def workspace(self, B, S, Tp):
+        """the workspace (buffers + launch plans) serving B sentences, S source positions, T' decoder steps: shape
+        (B, bucket(S), bucket(T'))"""
+        Sb, Tb = self.bucket_shape(S, Tp)
+        key = (B, Sb, Tb)
+        ws = self.ws.get(key)
+        if ws is not None:
+            self.ws.move_to_end(key)
+            return ws
+        before = torch.cuda.memory_allocated(self.dev)
+        ws = Workspace(self, B, Sb, Tb)
+        ws.nbytes = max(0, torch.cuda.memory_allocated(self.dev) - before)
+        self.ws[key] = ws
+        while self.workspace_bytes() > self.ws_budget_bytes and sum(isinstance(v, Workspace) for v in self.ws.values()) > 1:
+            oldest = next(k for k, v in self.ws.items() if isinstance(v, Workspace))
+            torch.cuda.synchronize(self.dev)
+            del self.ws[oldest]
+            self.ws_evictions += 1
+        return ws

@@ -1,0 +1,264 @@
+"""The step API of the engine: forward, loss, backward, statistics, optimiser (mixin of core.Engine)."""
+import ctypes as C
+import math
+from os import environ as _os_env
+
+import torch
+
+from .. import _lib as L
+from .layout import Buf, KPAD, PAD, SEG_ALIGN, _ru  # noqa: F401
+
+
+class StepAPI(object):
+    def set_image_table(self, table):
+        """`table`: fp32 [N, D] image-feature array (numpy or tensor); kept resident in HBM
+        (reference: host numpy + per-step fancy-index + H2D copy, TrainerMultimodal.py:632-639)."""
+        t = torch.as_tensor(table)
+        self.img_table = t.to(device=self.dev, dtype=torch.float32).contiguous()
+        assert self.img_table.shape[1] == self.d.img
+
+    def stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def forward(self, src, src_len, tgt, img_indices, training=True, eps=None, masks=None, table=None, tgt_len=None):
+        """NMTVIModel.forward (Models.py:850-1011).  src [S,B] int64, src_len [B], tgt [T,B] (incl. <s>, </s>),
+        img_indices [B] rows of the resident image table.  Returns the Workspace holding every activation."""
+        S, B = int(src.shape[0]), int(src.shape[1])
+        Tp = int(tgt.shape[0]) - 1
+        if S > 64:
+            raise RuntimeError("source length %d > 64 not supported by the attention kernel" % S)
+        ws = self.workspace(B, S, Tp)
+        st = self.stream()
+        self.refresh_shadows(st)
+        dev = self.dev
+        tab = table if table is not None else getattr(self, "img_table", None)
+        if tab is None:
+            raise RuntimeError("no image-feature table: call set_image_table() first")
+        d = self.d
+
+        def dev64(t):
+            t = torch.as_tensor(t)
+            return t.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous()
+        src_d, tgt_d, len_d, idx_d = dev64(src), dev64(tgt), dev64(src_len).reshape(-1), dev64(img_indices).reshape(-1)
+        gen_eps = training and eps is None
+        self.rng_counter += 1
+        L.check(self.lib.vmmt_prepare_batch(src_d.data_ptr(), tgt_d.data_ptr(), len_d.data_ptr(), idx_d.data_ptr(), S, Tp + 1, B,
+                                            ws.S, ws.Tp + 1, PAD,
+                                            ws.src.data_ptr(), ws.tgt_in.data_ptr(), ws.y.data_ptr(), ws.src_len.data_ptr(),
+                                            ws.img_idx.data_ptr(), ws.stats.data_ptr(), ws.eps.p() if gen_eps else None,
+                                            B * d.z if gen_eps else 0, self.rng_counter, st), "vmmt_prepare_batch")
+        ws._inputs_keepalive = (src_d, tgt_d, len_d, idx_d)
+        if d.conditional:
+            if tgt_len is None:
+                raise RuntimeError("the conditional model needs tgt_lengths (q(z|x,y,v) averages the target encodings)")
+            ws.tgt_len.copy_(dev64(tgt_len).reshape(-1))
+            # rows b*T + t (encoder_tgt sees the transposed target); positions beyond the batch's T hold the pad id
+            ws.tgt_bt.fill_(PAD)
+            ws.tgt_bt.view(B, ws.Tn)[:, :Tp + 1].copy_(tgt_d.reshape(Tp + 1, B).t())
+        if training:
+            if eps is not None:
+                ws.eps.view().copy_(eps.to(device=dev, dtype=torch.float32))
+            if d.dropout > 0:
+                mk = [("enc_l%d" % l, ws.enc_mask[l]) for l in range(d.layers - 1)] + \
+                     [("dec_l%d" % l, ws.dec_mask[l]) for l in range(d.layers - 1)]
+                if d.conditional:
+                    mk += [("enct_l%d" % l, ws.enct_mask[l]) for l in range(d.layers - 1)]
+                for name, buf in mk:
+                    if masks is not None and name in masks:
+                        buf.view().copy_(masks[name].reshape(buf.rows, buf.cols).to(device=dev, dtype=self.T))
+                    else:
+                        self.rng_counter += 1
+                        # the mask is generated over the padded buffer (pad columns are never read)
+                        L.check(self.lib.vmmt_dropout_mask(self.dt, buf.p(), buf.rows * buf.ld, d.dropout, self.rng_counter, st),
+                                "vmmt_dropout_mask")
+                # the output mask is a plan entry on the side stream: give it this step's seed, or turn it into a no-op
+                # when the caller injects the mask (tests)
+                ii, buf = ws._mask_entries["dec_out"]
+                fn, args, name, keep, sid = ws.plan_fwd_train[ii]
+                self.rng_counter += 1
+                if masks is not None and "dec_out" in masks:
+                    buf.view().copy_(masks["dec_out"].reshape(buf.rows, buf.cols).to(device=dev, dtype=self.T))
+                    ws.plan_fwd_train[ii] = (fn, (args[0], args[1], 0, args[3], self.rng_counter), name, keep, sid)
+                else:
+                    ws.plan_fwd_train[ii] = (fn, (args[0], args[1], buf.rows * buf.ld, args[3], self.rng_counter), name, keep, sid)
+        plan = ws.plan_fwd_train if training else ws.plan_fwd_eval
+        ii = ws._img_idx[bool(training)]
+        fn, args, name, keep, sid = plan[ii]
+        plan[ii] = (fn, (L.F32, tab.data_ptr(), tab.shape[1]) + tuple(args[3:]), name, keep, sid)
+        self._run(plan, ws.events)
+        ws.training = training
+        return ws
+
+    def loss(self, ws):
+        """statistics of _compute_loss without backward (monolithic_compute_loss, Loss.py:68-86)."""
+        st = self.stream()
+        self._run(ws.plan_loss_train if ws.training else ws.plan_loss_eval, ws.events)
+        L.check(self.lib.vmmt_image_loss(self.dt, ws.mu_v.p(), ws.mu_v.ld, ws.img.p(), ws.img.ld, ws.B, self.d.img, 0.0, None, 0,
+                                         ws.stats.data_ptr(), st), "vmmt_image_loss")
+        return ws
+
+    def loss_backward(self, ws, normalization=None, batch_global=None, kl_mult=1.0, use_freebits=False, margin=0.0,
+                      zero_grad=True):
+        """sharded_compute_loss (Loss.py:88-132): loss statistics + `loss.div(normalization).backward()`
+        through the whole model into the gradient arena.  H3: all T' rows are used (monolithic semantics)."""
+        st = self.stream()
+        B = ws.B
+        norm = float(normalization if normalization is not None else B)
+        bg = float(batch_global if batch_global is not None else B)
+        # the gradient arena was zeroed by the training forward plan (side stream); zero_grad=False is meaningless here
+        if not ws.training:
+            raise RuntimeError("loss_backward() after an eval-mode forward")
+        if ws._loss_patch is not None:          # fused generator: the statistics pass writes dO = dL/dO scaled by 1 / normalization
+            ii, pos = ws._loss_patch
+            fn, args, name, keep, sid = ws.plan_loss_train[ii]
+            ws.plan_loss_train[ii] = (fn, args[:pos] + (float(1.0 / norm),) + args[pos + 1:], name, keep, sid)
+        self._run(ws.plan_loss_train, ws.events)
+        plan = ws.backward_plan(1.0 / norm, bg, kl_mult, use_freebits, margin, bool(ws.training))
+        self._cur_ws = ws
+        self._run(plan, ws.events)
+        return ws
+
+    def read_stats(self, ws, batch_global=None, kl_mult=1.0, use_freebits=False, margin=0.0):
+        """One D2H copy of the statistics vector -> the reference's loss_data dict (VILoss.py:483-497)."""
+        s = ws.stats.tolist()
+        B = float(batch_global if batch_global is not None else ws.B)
+        kl_before = s[L.STAT_KL_SUM] / B
+        kl_after = kl_before * kl_mult
+        if use_freebits:
+            kl_after = max(kl_after, margin)
+        img_logprob = s[L.STAT_IMG_LOGPROB]
+        nmt = s[L.STAT_NLL]
+        return dict(nmt=nmt, td_kl_before=kl_before, td_kl_after=kl_after, td_kl_multiplier=kl_mult,
+                    img_feats_loss=img_logprob, img_feats_cos=s[L.STAT_IMG_COS] / float(ws.B),
+                    elbo=nmt - img_logprob + kl_after, n_words=int(round(s[L.STAT_NWORDS])),
+                    n_correct=int(round(s[L.STAT_NCORRECT])))
+
+    def optim_step(self, lr=0.002, max_grad_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-9, grad_scale=1.0):
+        """Optim.step (Optim.py:78-96): global-norm clip + Adam over the arena, then the compute shadows are refreshed.
+        The arena is updated in two halves: [encoder | inference networks] on the current stream (the next forward needs
+        them first), [generator | attention | decoder] on the side stream, where it overlaps the next step's encoder
+        phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights."""
+        main = torch.cuda.current_stream(self.dev)
+        st = main.cuda_stream
+        if self.dp is not None and self.dp.world > 1 and self.dp.sharded:
+            return self._optim_step_sharded(lr, max_grad_norm, beta1, beta2, eps, grad_scale)
+        if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
+            # (a dense pass is right with the row bookkeeping too: the rows it has not flagged hold zeros)
+            self._sumsq[:L.SUMSQ_SLOTS].zero_()
+            L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), 0, st), "vmmt_sumsq")
+        self._sumsq_by_plan = False
+        self.step_count += 1
+        split = self.offsets[self.first_enc_name][0]
+        emb_fg = bool(self.d.conditional and self.cond_emb_fg)
+        if emb_fg:
+            # conditional model: the shared target embedding table (last item of the background half, no compute shadow) is updated in the
+            # FOREGROUND: encoder_tgt's forward recurrence, the step's first long chain, gathers from it right at the start of the step
+            split = self.offsets["decoder.embeddings.make_embedding.emb_luts.0.weight"][0]
+
+        def adam_range(lo, hi, stream, shadow=None):
+            blocks = int(self.bg_adam_blocks) if stream != st else 0
+            if hi > lo:
+                L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
+                                                self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, lr, beta1, beta2,
+                                                eps, self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
+                                                blocks, shadow, stream), "vmmt_adam_step")
+
+        rows = self.rows_active()
+
+        def rows_step(t, stream):
+            o = 4 * t["off"]
+            L.check(self.lib.vmmt_adam_rows_step(self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o,
+                                                 self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), lr, beta1, beta2, eps,
+                                                 self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, stream),
+                    "vmmt_adam_rows_step")
+
+        def adam(lo, hi, stream):
+            # the big unpadded bf16 shadows (generator weight, image network fc2) are written by the update itself: their range is
+            # a launch of its own with the shadow attached, and the shadow refresh behind it skips them (_pack_tables); the embedding
+            # tables are updated by the row-wise kernel (gradient read for the batch's rows only) when the row bookkeeping is on
+            pieces = [(s_lo, s_hi, ("shadow", ptr)) for s_lo, s_hi, ptr in self._fused_shadows() if lo <= s_lo and s_hi <= hi]
+            if rows:
+                pieces += [(t["off"], t["end"], ("rows", t)) for t in self.row_tables if lo <= t["off"] and t["end"] <= hi]
+            cur = lo
+            for p_lo, p_hi, (kind, what) in sorted(pieces, key=lambda x: x[0]):
+                adam_range(cur, p_lo, stream)
+                if kind == "shadow":
+                    adam_range(p_lo, p_hi, stream, what)
+                else:
+                    rows_step(what, stream)
+                cur = p_hi
+            adam_range(cur, hi, stream)
+        if self.use_side_stream and self.split_optim:
+            # both halves are HBM-bound: the critical half runs alone at full bandwidth, the other one starts behind it
+            adam(split, self.n_opt, st)
+            ev = self.global_events.setdefault("adam_main_done", torch.cuda.Event())
+            ev.record(main)
+            self._pack_part(2, st)
+            side = self.side_stream
+
+            def background():
+                side.wait_event(ev)
+                adam(0, split, side.cuda_stream)
+                self._pack_part(3, side.cuda_stream)
+                self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
+            background()
+        else:
+            adam(0, self.n_opt, st)
+            self._pack_part(2, st)
+            self._pack_part(3, st)
+        self.shadows_dirty = False
+
+    def _optim_step_sharded(self, lr, max_grad_norm, beta1, beta2, eps, grad_scale):
+        """Data-parallel optimiser step with the state sharded over the ranks (dp.GradSync.sharded).  The backward plan has
+        reduce-scattered every arena segment, so this rank holds the SUM of the gradients for its 1 / world of each segment
+        (dp.shard).  Here: squared norm of the own shards (the deterministic reduction of vmmt_sumsq, one slot per segment) ->
+        all-gather of the ranks' slot totals, added in rank order: every rank computes the same clip coefficient bit for bit ->
+        clip + Adam on the own shards only (28 B/param of HBM traffic over 1 / world of the arena) -> all-gather of the updated
+        parameters, segment by segment: [encoder | inference networks] in the foreground (the next forward starts with them),
+        [generator | attention + decoder] on the side stream underneath the next step's encoder -> shadow refresh.
+        The Adam moments of the other ranks' shards are not maintained here (dp.GradSync.gather_moments collects them for a
+        checkpoint).  Same update as the replicated path: the reduced gradient of an element is the same sum wherever it is
+        formed and the update is element-wise (only the norm is added up in another order); the replicas stay bit-identical
+        (tests/test_gpu_dp_two_ranks.py)."""
+        dp = self.dp
+        main = torch.cuda.current_stream(self.dev)
+        st = main.cuda_stream
+        self.finish_allreduce()                           # the reduce-scatters of the backward plan
+        self._sumsq_by_plan = False
+        self.step_count += 1
+        segs = self.segments
+        own = [dp.shard(lo, hi) for lo, hi in segs]
+        if max_grad_norm:
+            self._sumsq[:L.SUMSQ_SLOTS].zero_()
+            for i, (a, b) in enumerate(own):
+                if b > a:
+                    L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * a, b - a, self._sumsq.data_ptr(), i, st), "vmmt_sumsq")
+            tot = dp.all_gather_rows(self._sumsq[:L.SUMSQ_SLOTS])           # [world][SLOTS]
+            self._sumsq[:L.SUMSQ_SLOTS].zero_()
+            self._sumsq[0:1].copy_(tot.sum(dim=1).sum(dim=0, keepdim=True))  # fixed order: slots of a rank, then the ranks
+
+        def adam(a, b, stream):
+            if b > a:
+                L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * a, self.flat_g.data_ptr() + 4 * a, self.flat_m.data_ptr() + 4 * a,
+                                                self.flat_v.data_ptr() + 4 * a, b - a, lr, beta1, beta2, eps, self.step_count,
+                                                float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, 0, None, stream),
+                        "vmmt_adam_step")
+        fg, bg = (2, 3), (0, 1)                           # foreground: encoder + inference networks; background: generator, decoder
+        for i in fg:
+            adam(own[i][0], own[i][1], st)
+        for i in fg:
+            dp.all_gather(self.flat_p, *segs[i]).wait()
+        self._pack_part(0, st)
+        ev = self.global_events.setdefault("adam_main_done", torch.cuda.Event())
+        ev.record(main)
+        side = self.side_stream if (self.use_side_stream and self.split_optim) else main
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            for i in bg:
+                adam(own[i][0], own[i][1], side.cuda_stream)
+            for i in bg:
+                dp.all_gather(self.flat_p, *segs[i]).wait()
+            self._pack_part(1, side.cuda_stream)
+        if side is not main:
+            self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
+        self.shadows_dirty = False
