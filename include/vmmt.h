@@ -194,13 +194,19 @@ int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* 
  *   ctx  T [S*B][ldc]    rows s*B+b: encoder memory ; lens int64 [B]
  *   cat  T [Tp*B][ldcat] out: context vectors, columns [0,H) of the [c ; r] concat buffer (GlobalAttention.py:187)
  *   probs f32 [Tp][B][S] out: attention distributions (attns["std"])
- * limits: S <= 64, H <= 1024. */
+ * limits: S <= 256, H <= 1024 (S <= 64: a lane / an MFMA tile row per source position; longer sources -- a sentence handed to
+ * translate_mm_vi.py can be any length -- take a one-wave-per-query kernel). */
 int vmmt_attn_fwd(int dtype, const void* q, int64_t ldq, const void* ctx, int64_t ldc, const int64_t* lens, void* cat,
                   int64_t ldcat, float* probs, int Tp, int B, int S, int H, void* stream);
-/* backward: dcat columns [0,H) hold dL/dc; writes dq (T [Tp*B][lddq]) and dctx (T [S*B][lddx], zero at pads). */
+/* backward: dcat columns [0,H) hold dL/dc; writes dq (T [Tp*B][lddq]) and dctx (T [S*B][lddx], zero at pads).
+ * vmmt_attn_bwd: S <= 64 and T' <= 64 (VMMT_EINVAL beyond).  vmmt_attn_bwd_long: any T', S <= 256 -- two launches (per query:
+ * dS and dQ; per source position: dHs) with `dots` f32 [Tp*B] as scratch between them. */
 int vmmt_attn_bwd(int dtype, const void* dcat, int64_t lddc, const float* probs, const void* q, int64_t ldq,
                   const void* ctx, int64_t ldc, const int64_t* lens, void* dq, int64_t lddq, void* dctx, int64_t lddx,
                   int Tp, int B, int S, int H, void* stream);
+int vmmt_attn_bwd_long(int dtype, const void* dcat, int64_t lddc, const float* probs, const void* q, int64_t ldq,
+                       const void* ctx, int64_t ldc, const int64_t* lens, void* dq, int64_t lddq, void* dctx, int64_t lddx,
+                       int Tp, int B, int S, int H, float* dots, void* stream);
 /* hbar[b] = mean_{s<len_b} ctx[s][b]  (GlobalInferenceNetwork.encode_seq, modules/NormalVariationalEncoder.py:65-84) */
 int vmmt_masked_mean(int dtype, const void* ctx, int64_t ldc, const int64_t* lens, void* out, int64_t ldo, int B, int S,
                      int H, void* stream);

@@ -3,6 +3,7 @@
    * T', S <= 64, H <= 1024: attn_{fwd,bwd}_big -- 2 x 2 score tiles, the source memory staged in LDS (129 KB at H = 1024), queries /
      gradients straight from global memory into MFMA fragments (BASELINE config 5: S = T' = 64, H = 1024)
    * fp32 parity mode: the generic kernels.
+   * S > 64 (up to 256) or T' > 64: the one-wave-per-query kernels (long sources at translation time).
 Reference arithmetic: onmt/modules/GlobalAttention.py:113 (bmm), :171-176 (mask), :179-180 (softmax), :184 (bmm)."""
 import ctypes as C
 
@@ -25,7 +26,9 @@ def _buf(rows, cols, dtype, fill=None):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("Tp,S,H,B", [(20, 20, 512, 9), (64, 64, 1024, 5), (33, 17, 1024, 4), (7, 64, 96, 6), (64, 9, 512, 3),
-                                     (50, 41, 256, 7), (1, 64, 1024, 8), (24, 30, 1024, 3)])
+                                     (50, 41, 256, 7), (1, 64, 1024, 8), (24, 30, 1024, 3),
+                                     # beyond the per-sentence kernels (S > 64 or T' > 64): attn_fwd_long / vmmt_attn_bwd_long
+                                     (5, 65, 96, 4), (70, 100, 512, 3), (1, 256, 1024, 2), (130, 20, 128, 5), (66, 200, 500, 2)])
 def test_attention_forward_backward(Tp, S, H, B, dtype):
     from variational_mmt_amd import _lib as L
     lib = L.lib()
@@ -76,8 +79,15 @@ def test_attention_forward_backward(Tp, S, H, B, dtype):
     assert (got_c - cvec).abs().max().item() <= tol_c * max(1.0, cvec.abs().max().item())
     assert (CAT[:M, H:] == 0).all() and (CAT[M:] == 0).all()              # only the left half of [c ; r], only valid rows
     # backward consumes the probabilities the forward stored
-    L.check(lib.vmmt_attn_bwd(code, P(DCAT), DCAT.shape[1], P(probs), P(Q), Q.shape[1], P(CTX), CTX.shape[1], P(ld), P(DQ), DQ.shape[1],
-                              P(DCTX), DCTX.shape[1], Tp, B, S, H, None), "attn bwd")
+    if S > 64 or Tp > 64:
+        assert lib.vmmt_attn_bwd(code, P(DCAT), DCAT.shape[1], P(probs), P(Q), Q.shape[1], P(CTX), CTX.shape[1], P(ld), P(DQ), DQ.shape[1],
+                                 P(DCTX), DCTX.shape[1], Tp, B, S, H, None) != 0 or (S <= 64 and dtype == "f32")
+        dots = torch.zeros(M, device="cuda")
+        L.check(lib.vmmt_attn_bwd_long(code, P(DCAT), DCAT.shape[1], P(probs), P(Q), Q.shape[1], P(CTX), CTX.shape[1], P(ld), P(DQ),
+                                       DQ.shape[1], P(DCTX), DCTX.shape[1], Tp, B, S, H, P(dots), None), "attn bwd long")
+    else:
+        L.check(lib.vmmt_attn_bwd(code, P(DCAT), DCAT.shape[1], P(probs), P(Q), Q.shape[1], P(CTX), CTX.shape[1], P(ld), P(DQ), DQ.shape[1],
+                                  P(DCTX), DCTX.shape[1], Tp, B, S, H, None), "attn bwd")
     torch.cuda.synchronize()
     got_dq = DQ[:M, :H].float().cpu().double().view(Tp, B, H)
     got_dc = DCTX[:MS, :H].float().cpu().double().view(S, B, H)

@@ -273,10 +273,11 @@ def test_long_sequences_and_odd_dims(dtype, S, T, hid, emb, zd, brnn, layers):
         assert (got - want).norm().item() <= tg * want.norm().item(), (k, (got - want).norm().item() / want.norm().item())
 
 
-def test_source_longer_than_64_is_rejected():
+def test_source_longer_than_256_is_rejected():
+    """(up to 64 source positions the attention kernels work per sentence, up to 256 per query: test_minimal_and_extreme_shapes)"""
     c = O.Cfg(vs=30, vt=30, emb=16, hid=32, z=8, layers=1, brnn=True)
     e = _engine(c, O.init_params(c, seed=1), "f32")
-    bt = O.synth_batch(c, 3, 65, 5, n_img=4, seed=2)
+    bt = O.synth_batch(c, 3, 257, 5, n_img=4, seed=2)
     e.set_image_table(bt["table"])
     with pytest.raises(RuntimeError):
         e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
@@ -400,6 +401,8 @@ def test_conditional_step_with_persistent_recurrences_bf16():
     (3, 1, 5, True, 2, 32),        # source length 1 for every sentence: the attention distribution is a point mass
     (4, 64, 3, False, 1, 64),      # the longest source the attention kernels take, next to a two-step target
     (33, 5, 4, True, 1, 32),       # one sentence more than a 32-row group of the recurrence kernels
+    (3, 70, 6, True, 1, 32),       # a source longer than the per-sentence attention kernels take (one wave per query instead)
+    (2, 9, 70, False, 2, 64),      # a target longer than they take (T' = 69)
 ])
 def test_minimal_and_extreme_shapes(dtype, B, S, T, brnn, layers, hid):
     """edge shapes of a batch: a single sentence, a single position, the maximum source length, a batch just past a

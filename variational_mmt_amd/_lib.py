@@ -76,6 +76,7 @@ _SIGS = {
     "vmmt_lstm_chain_bwd": (i32, [i32, i32, i32, C.POINTER(LstmDirBwd), vp, i32, i32, i32, vp]),
     "vmmt_attn_fwd": (i32, [i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp]),
     "vmmt_attn_bwd": (i32, [i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    "vmmt_attn_bwd_long": (i32, [i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp]),
     "vmmt_masked_mean": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "vmmt_gen_npart": (i32, [i32]),
     "vmmt_gen_argmax": (i32, [vp, vp, i32, i32, vp, vp, vp]),

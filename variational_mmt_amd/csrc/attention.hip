@@ -135,6 +135,174 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dca
   }
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// Long sequences (64 < S <= 256, any T'): the kernels above give every source position a lane (or a 32 / 64-row MFMA tile).  Training
+// data is cut at 50 tokens by the reference's preprocess defaults, but a sentence handed to translate_mm_vi.py can be any length: these
+// kernels are the fallback -- one WAVE per (sentence, query), lanes hold the positions s = lane + 64 k (k < 4) and the hidden units
+// h = lane + 64 j (j < 16); operands straight from global memory / L2.  Same arithmetic as attn_fwd_kernel / attn_bwd_kernel.
+constexpr int ATT_LK = 4;     // S <= 64 * ATT_LK
+
+template <class T>
+__global__ void __launch_bounds__(256) attn_fwd_long(const T* __restrict__ q, long ldq, const T* __restrict__ ctx, long ldc,
+                                                     const long long* __restrict__ lens, T* __restrict__ cat, long ldcat,
+                                                     float* __restrict__ probs, int Tp, int B, int S, int H) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + wave;             // (t, b) pair: row = t * B + b
+  if (row >= (long)Tp * B) return;
+  const int b = (int)(row % B);
+  int len = (int)lens[b];
+  len = len < S ? len : S;
+  const T* qr = q + row * ldq;
+  float qv[ATT_MAXJ];
+#pragma unroll
+  for (int j = 0; j < ATT_MAXJ; ++j) qv[j] = lane + 64 * j < H ? to_f<T>(qr[lane + 64 * j]) : 0.f;
+  float my[ATT_LK];
+#pragma unroll
+  for (int k = 0; k < ATT_LK; ++k) my[k] = -INFINITY;
+  for (int s = 0; s < len; ++s) {
+    const T* hr = ctx + ((long)s * B + b) * ldc;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < ATT_MAXJ; ++j)
+      if (lane + 64 * j < H) part += qv[j] * to_f<T>(hr[lane + 64 * j]);
+    part = wave_sum(part);
+#pragma unroll
+    for (int k = 0; k < ATT_LK; ++k)
+      if ((s >> 6) == k && lane == (s & 63)) my[k] = part;
+  }
+  float m = my[0];
+#pragma unroll
+  for (int k = 1; k < ATT_LK; ++k) m = fmaxf(m, my[k]);
+  m = wave_max(m);
+  float pk[ATT_LK], sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < ATT_LK; ++k) { pk[k] = lane + 64 * k < len ? __expf(my[k] - m) : 0.f; sum += pk[k]; }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int k = 0; k < ATT_LK; ++k) {
+    pk[k] = pk[k] / sum;
+    if (lane + 64 * k < S) probs[row * S + lane + 64 * k] = pk[k];
+  }
+  float acc[ATT_MAXJ];
+#pragma unroll
+  for (int j = 0; j < ATT_MAXJ; ++j) acc[j] = 0.f;
+  for (int s = 0; s < len; ++s) {
+    float ps = 0.f;
+#pragma unroll
+    for (int k = 0; k < ATT_LK; ++k) { const float v = __shfl(pk[k], s & 63, 64); ps = (s >> 6) == k ? v : ps; }
+    const T* hr = ctx + ((long)s * B + b) * ldc;
+#pragma unroll
+    for (int j = 0; j < ATT_MAXJ; ++j)
+      if (lane + 64 * j < H) acc[j] += ps * to_f<T>(hr[lane + 64 * j]);
+  }
+  T* cr = cat + row * ldcat;
+#pragma unroll
+  for (int j = 0; j < ATT_MAXJ; ++j)
+    if (lane + 64 * j < H) cr[lane + 64 * j] = from_f<T>(acc[j]);
+}
+
+// backward, first half: per (sentence, query) dP = dC Hs^T, dot = sum_s P dP (kept in `dots` for the second half), dS = P (dP - dot),
+// dQ = dS Hs
+template <class T>
+__global__ void __launch_bounds__(256) attn_bwd_long_q(const T* __restrict__ dcat, long lddc, const float* __restrict__ probs,
+                                                       const T* __restrict__ ctx, long ldc, const long long* __restrict__ lens,
+                                                       T* __restrict__ dq, long lddq, float* __restrict__ dots, int Tp, int B, int S,
+                                                       int H) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= (long)Tp * B) return;
+  const int b = (int)(row % B);
+  int len = (int)lens[b];
+  len = len < S ? len : S;
+  const T* dcr = dcat + row * lddc;
+  float dv[ATT_MAXJ];
+#pragma unroll
+  for (int j = 0; j < ATT_MAXJ; ++j) dv[j] = lane + 64 * j < H ? to_f<T>(dcr[lane + 64 * j]) : 0.f;
+  float da[ATT_LK];
+#pragma unroll
+  for (int k = 0; k < ATT_LK; ++k) da[k] = 0.f;
+  for (int s = 0; s < len; ++s) {
+    const T* hr = ctx + ((long)s * B + b) * ldc;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < ATT_MAXJ; ++j)
+      if (lane + 64 * j < H) part += dv[j] * to_f<T>(hr[lane + 64 * j]);
+    part = wave_sum(part);
+#pragma unroll
+    for (int k = 0; k < ATT_LK; ++k)
+      if ((s >> 6) == k && lane == (s & 63)) da[k] = part;
+  }
+  float pk[ATT_LK], dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < ATT_LK; ++k) { pk[k] = lane + 64 * k < len ? probs[row * S + lane + 64 * k] : 0.f; dot += pk[k] * da[k]; }
+  dot = wave_sum(dot);
+  if (lane == 0) dots[row] = dot;
+  float ds[ATT_LK];
+#pragma unroll
+  for (int k = 0; k < ATT_LK; ++k) ds[k] = pk[k] * (da[k] - dot);
+  float acc[ATT_MAXJ];
+#pragma unroll
+  for (int j = 0; j < ATT_MAXJ; ++j) acc[j] = 0.f;
+  for (int s = 0; s < len; ++s) {
+    float dss = 0.f;
+#pragma unroll
+    for (int k = 0; k < ATT_LK; ++k) { const float v = __shfl(ds[k], s & 63, 64); dss = (s >> 6) == k ? v : dss; }
+    const T* hr = ctx + ((long)s * B + b) * ldc;
+#pragma unroll
+    for (int j = 0; j < ATT_MAXJ; ++j)
+      if (lane + 64 * j < H) acc[j] += dss * to_f<T>(hr[lane + 64 * j]);
+  }
+  T* dqr = dq + row * lddq;
+#pragma unroll
+  for (int j = 0; j < ATT_MAXJ; ++j)
+    if (lane + 64 * j < H) dqr[lane + 64 * j] = from_f<T>(acc[j]);
+}
+
+// backward, second half: per (source position, sentence)  dHs[s] = sum_t P[t][s] dC[t] + dS[t][s] Q[t],  dS[t][s] = P[t][s] (dC[t] . Hs[s] - dot[t])
+template <class T>
+__global__ void __launch_bounds__(256) attn_bwd_long_ctx(const T* __restrict__ dcat, long lddc, const float* __restrict__ probs,
+                                                         const T* __restrict__ q, long ldq, const T* __restrict__ ctx, long ldc,
+                                                         const long long* __restrict__ lens, const float* __restrict__ dots,
+                                                         T* __restrict__ dctx, long lddx, int Tp, int B, int S, int H) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long srow = (long)blockIdx.x * 4 + wave;            // row = s * B + b
+  if (srow >= (long)S * B) return;
+  const int b = (int)(srow % B), s = (int)(srow / B);
+  int len = (int)lens[b];
+  len = len < S ? len : S;
+  T* out = dctx + srow * lddx;
+  if (s >= len) {
+#pragma unroll
+    for (int j = 0; j < ATT_MAXJ; ++j)
+      if (lane + 64 * j < H) out[lane + 64 * j] = from_f<T>(0.f);
+    return;
+  }
+  const T* hr = ctx + srow * ldc;
+  float hv[ATT_MAXJ], acc[ATT_MAXJ];
+#pragma unroll
+  for (int j = 0; j < ATT_MAXJ; ++j) { hv[j] = lane + 64 * j < H ? to_f<T>(hr[lane + 64 * j]) : 0.f; acc[j] = 0.f; }
+  for (int t = 0; t < Tp; ++t) {
+    const long row = (long)t * B + b;
+    const T* dcr = dcat + row * lddc;
+    const T* qr = q + row * ldq;
+    float dv[ATT_MAXJ], part = 0.f;
+#pragma unroll
+    for (int j = 0; j < ATT_MAXJ; ++j) {
+      dv[j] = lane + 64 * j < H ? to_f<T>(dcr[lane + 64 * j]) : 0.f;
+      part += dv[j] * hv[j];
+    }
+    part = wave_sum(part);
+    const float p = probs[row * S + s];
+    const float ds = p * (part - dots[row]);
+#pragma unroll
+    for (int j = 0; j < ATT_MAXJ; ++j)
+      if (lane + 64 * j < H) acc[j] += p * dv[j] + ds * to_f<T>(qr[lane + 64 * j]);
+  }
+#pragma unroll
+  for (int j = 0; j < ATT_MAXJ; ++j)
+    if (lane + 64 * j < H) out[lane + 64 * j] = from_f<T>(acc[j]);
+}
+
 // ==============================================================================================================
 // MFMA attention for bf16 (T' <= 32, S <= 32, H % 32 == 0): one workgroup per sentence.  Q_b [T' x H] and the
 // sentence's source memory Hs_b [S x H] are staged once in LDS (zero-padded to 32 rows);
@@ -552,8 +720,19 @@ static bool big_ok(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 &
 extern "C" int vmmt_attn_fwd(int dtype, const void* q, int64_t ldq, const void* ctx, int64_t ldc, const int64_t* lens,
                              void* cat, int64_t ldcat, float* probs, int Tp, int B, int S, int H, void* stream) {
   using namespace vmmt;
-  if (!q || !ctx || !lens || !cat || !probs || S > ATT_MAXS || H > 64 * ATT_MAXJ || Tp <= 0 || B <= 0)
+  if (!q || !ctx || !lens || !cat || !probs || S <= 0 || S > 64 * ATT_LK || H > 64 * ATT_MAXJ || Tp <= 0 || B <= 0)
     return VMMT_EINVAL;
+  if (S > ATT_MAXS) {          // longer than the per-lane / per-tile kernels take: one wave per (sentence, query)
+    const unsigned grid = (unsigned)(((long)Tp * B + 3) / 4);
+    if (dtype == VMMT_F32)
+      hipLaunchKernelGGL(attn_fwd_long<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)q, (long)ldq, (const float*)ctx,
+                         (long)ldc, (const long long*)lens, (float*)cat, (long)ldcat, probs, Tp, B, S, H);
+    else if (dtype == VMMT_BF16)
+      hipLaunchKernelGGL(attn_fwd_long<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (long)ldq,
+                         (const bf16_t*)ctx, (long)ldc, (const long long*)lens, (bf16_t*)cat, (long)ldcat, probs, Tp, B, S, H);
+    else return VMMT_EINVAL;
+    return check_launch();
+  }
   if (dtype == VMMT_BF16 && Tp <= 32 && S <= 32 && H % 32 == 0 && attn_fast_lds(H, 2) <= 150 * 1024) {
     size_t sm = attn_fast_lds(H, 2);
     static size_t attr = 0;
@@ -627,6 +806,30 @@ extern "C" int vmmt_attn_bwd(int dtype, const void* dcat, int64_t lddc, const fl
                        (const long long*)lens, (bf16_t*)dq, (long)lddq, (bf16_t*)dctx, (long)lddx, Tp, B, S, H,
                        use_lds);
   else return VMMT_EINVAL;
+  return check_launch();
+}
+
+extern "C" int vmmt_attn_bwd_long(int dtype, const void* dcat, int64_t lddc, const float* probs, const void* q, int64_t ldq,
+                                  const void* ctx, int64_t ldc, const int64_t* lens, void* dq, int64_t lddq, void* dctx, int64_t lddx,
+                                  int Tp, int B, int S, int H, float* dots, void* stream) {
+  using namespace vmmt;
+  if (!dcat || !probs || !q || !ctx || !lens || !dq || !dctx || !dots || S <= 0 || S > 64 * ATT_LK || H > 64 * ATT_MAXJ || Tp <= 0 || B <= 0)
+    return VMMT_EINVAL;
+  const unsigned gq = (unsigned)(((long)Tp * B + 3) / 4), gc = (unsigned)(((long)S * B + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VMMT_F32) {
+    hipLaunchKernelGGL(attn_bwd_long_q<float>, dim3(gq), dim3(256), 0, st, (const float*)dcat, (long)lddc, probs, (const float*)ctx,
+                       (long)ldc, (const long long*)lens, (float*)dq, (long)lddq, dots, Tp, B, S, H);
+    hipLaunchKernelGGL(attn_bwd_long_ctx<float>, dim3(gc), dim3(256), 0, st, (const float*)dcat, (long)lddc, probs, (const float*)q,
+                       (long)ldq, (const float*)ctx, (long)ldc, (const long long*)lens, (const float*)dots, (float*)dctx, (long)lddx, Tp,
+                       B, S, H);
+  } else if (dtype == VMMT_BF16) {
+    hipLaunchKernelGGL(attn_bwd_long_q<bf16_t>, dim3(gq), dim3(256), 0, st, (const bf16_t*)dcat, (long)lddc, probs, (const bf16_t*)ctx,
+                       (long)ldc, (const long long*)lens, (bf16_t*)dq, (long)lddq, dots, Tp, B, S, H);
+    hipLaunchKernelGGL(attn_bwd_long_ctx<bf16_t>, dim3(gc), dim3(256), 0, st, (const bf16_t*)dcat, (long)lddc, probs, (const bf16_t*)q,
+                       (long)ldq, (const bf16_t*)ctx, (long)ldc, (const long long*)lens, (const float*)dots, (bf16_t*)dctx, (long)lddx,
+                       Tp, B, S, H);
+  } else return VMMT_EINVAL;
   return check_launch();
 }
 

@@ -193,8 +193,16 @@ class BackwardPlan(object):
             wo, wa = e.sh["wo"], e.sh["wa"]
             e._gemm(P, L.GEMM_NN, self.dPre.p(), self.dPre.ld, wo.p(), wo.ld, self.dcat.p(), self.dcat.ld, M, 2 * Hp, H)
             ctx = self.enc_out[Lyr - 1]
-            e._call(P, lib.vmmt_attn_bwd, dt, self.dcat.p(), self.dcat.ld, self.probs.data_ptr(), self.Q.p(), self.Q.ld, ctx.p(), ctx.ld,
-                    self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, Hp)
+            if S > 64 or Tp > 64:
+                # longer than the per-sentence kernels take (S <= 64, T' <= 64): one wave per query / per source position
+                if not hasattr(self, "attn_dots"):
+                    self.attn_dots = torch.zeros(M, dtype=torch.float32, device=e.dev)
+                e._call(P, lib.vmmt_attn_bwd_long, dt, self.dcat.p(), self.dcat.ld, self.probs.data_ptr(), self.Q.p(), self.Q.ld, ctx.p(),
+                        ctx.ld, self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, Hp,
+                        self.attn_dots.data_ptr())
+            else:
+                e._call(P, lib.vmmt_attn_bwd, dt, self.dcat.p(), self.dcat.ld, self.probs.data_ptr(), self.Q.p(), self.Q.ld, ctx.p(), ctx.ld,
+                        self.src_len.data_ptr(), self.dQ.p(), self.dQ.ld, self.dctx.p(), self.dctx.ld, Tp, B, S, Hp)
             e._record(P, "dQ")
             e._gemm(P, L.GEMM_NN, self.dQ.p(), self.dQ.ld, wa.p(), wa.ld, self.dR.p(), self.dR.ld, M, H, H,
                     addend=self.dcat.p(0, Hp), ld_add=self.dcat.ld, add_rows=-1, add_is_T=1)

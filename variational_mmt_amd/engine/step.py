@@ -25,8 +25,8 @@ class StepAPI(object):
         img_indices [B] rows of the resident image table.  Returns the Workspace holding every activation."""
         S, B = int(src.shape[0]), int(src.shape[1])
         Tp = int(tgt.shape[0]) - 1
-        if S > 64:
-            raise RuntimeError("source length %d > 64 not supported by the attention kernel" % S)
+        if S > 256:
+            raise RuntimeError("source length %d > 256 not supported by the attention kernels" % S)
         ws = self.workspace(B, S, Tp)
         st = self.stream()
         self.refresh_shadows(st)
