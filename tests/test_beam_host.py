@@ -43,9 +43,9 @@ def test_sort_finished_pads_with_beam_zero_as_executed():
     assert [int(x) for x in hyp] == [8, 3]
 
 
-@pytest.mark.parametrize("name", BEAM_CASES[:2])
-@pytest.mark.parametrize("with_attn", [True, False])
-def test_load_records_equals_position_by_position(name, with_attn):
+@pytest.mark.parametrize("name", BEAM_CASES)
+@pytest.mark.parametrize("with_attn,scorer", [(True, False), (False, False), (True, True)])
+def test_load_records_equals_position_by_position(name, with_attn, scorer):
     """Beam.load_records (whole-array bookkeeping, what TranslatorMultimodalVI._replay uses without a global scorer) leaves the beam in
     the state T calls of advance_from_device leave it in: same finished list in the same order, same back-pointers, tokens,
     attention, and therefore the same n-best extraction"""
@@ -53,13 +53,17 @@ def test_load_records_equals_position_by_position(name, with_attn):
     K, n_best, min_length = [int(x) for x in z["beam"]]
     for b in range(B):
         n = int(bt["src_len"][b])
-        r = O.beam_search(p, c, bt["src"][:n, b], K, n_best=n_best, max_len=max_len, alpha=0.0, beta=0.0, min_length=min_length)
+        alpha, beta = ([float(x) for x in z["scorer"]] if scorer else (0.0, 0.0))
+        if scorer and alpha == 0.0 and beta == 0.0:
+            alpha, beta = 0.6, 0.2                           # the fixture ran without re-scoring: exercise it all the same
+        r = O.beam_search(p, c, bt["src"][:n, b], K, n_best=n_best, max_len=max_len, alpha=alpha, beta=beta, min_length=min_length)
         T = r["steps"]
         sc = torch.stack([r["hist_score"][t] for t in range(T)])
         pv = torch.stack([r["hist_prev"][t].to(torch.int32) for t in range(T)])
         nx = torch.stack([r["hist_next"][t + 1] for t in range(T)])
         at = torch.stack([r["attn_rows"][t] for t in range(T)]) if with_attn else None
-        one, two = Beam(K, 1, 2, 3, n_best=n_best, min_length=min_length), Beam(K, 1, 2, 3, n_best=n_best, min_length=min_length)
+        mk = lambda: Beam(K, 1, 2, 3, n_best=n_best, min_length=min_length, global_scorer=GNMTGlobalScorer(alpha, beta) if scorer else None)
+        one, two = mk(), mk()
         for t in range(T):
             one.advance_from_device(sc[t], pv[t], nx[t], None if at is None else at[t])
         two.load_records(sc, pv, nx, at)
@@ -70,6 +74,8 @@ def test_load_records_equals_position_by_position(name, with_attn):
         for x, y in zip(one.prev_ks + one.next_ys + one.all_scores + one.attn, two.prev_ks + two.next_ys + two.all_scores + two.attn):
             assert torch.equal(x, y)
         assert len(one.attn) == len(two.attn) == (T if with_attn else 0)
+        if scorer:
+            assert torch.equal(one.global_state["coverage"], two.global_state["coverage"])
         s1, k1 = one.sort_finished(minimum=n_best)
         s2, k2 = two.sort_finished(minimum=n_best)
         assert k1 == k2 and [float(v) for v in s1] == [float(v) for v in s2]

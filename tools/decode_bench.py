@@ -33,7 +33,8 @@ from variational_mmt_amd.onmt.translate import TranslatorMultimodalVI
 model = types.SimpleNamespace(engine=e)
 fields = {"tgt": types.SimpleNamespace(vocab=types.SimpleNamespace(stoi={"<blank>": 1, "<s>": 2, "</s>": 3}))}
 for B, K in ((30, 5), (64, 5), (30, 1)):
-    tr = TranslatorMultimodalVI(model, fields, beam_size=K, n_best=1, max_length=L)
+    from variational_mmt_amd.onmt.translate import GNMTGlobalScorer        # translate_mm_vi.py always builds one (alpha = beta = 0 by default)
+    tr = TranslatorMultimodalVI(model, fields, beam_size=K, n_best=1, max_length=L, global_scorer=GNMTGlobalScorer(0.0, 0.0) if K > 1 else None)
     src = torch.randint(2, d.vs, (S, B), generator=g)
     sl = torch.full((B,), S, dtype=torch.int64)
     batch = types.SimpleNamespace(src=(src, sl))

@@ -74,7 +74,9 @@ class Beam(object):
         scorer nothing here depends on the position before it, so the bookkeeping is a handful of whole-array operations instead of
         ~10 small ones per position (which made the host replay 4x the cost of the device search)."""
         T = int(scores.shape[0])
-        if self.global_scorer is not None or self.prev_ks or T == 0:
+        gs = self.global_scorer
+        gnmt = type(gs) is GNMTGlobalScorer and attn is not None        # the reference's re-scoring (translate_mm_vi.py always builds one)
+        if (gs is not None and not gnmt) or self.prev_ks or T == 0:
             for t in range(T):
                 self.advance_from_device(scores[t], prev[t], nxt[t], None if attn is None else attn[t])
             return
@@ -84,12 +86,26 @@ class Beam(object):
         self.scores = scores[T - 1]
         self.prev_ks = list(prev.unbind(0))
         self.next_ys = self.next_ys + list(nxt.unbind(0))
+        cov = None
         if attn is not None:
             sel = attn.gather(1, prev.unsqueeze(2).expand(T, self.size, attn.shape[2]))       # attn[t].index_select(0, prev[t]) for every t
             self.attn = list(sel.unbind(0))
+            if gnmt:                                        # update_global_state position by position: T small operations
+                cov = [self.attn[0]]
+                for t in range(1, T):
+                    cov.append(cov[-1].index_select(0, self.prev_ks[t]).add(self.attn[t]))
+                self.global_state["coverage"] = cov[-1]
         fin = (nxt == self._eos)
+        final = {}
         for t, i in fin.nonzero().tolist():                 # row-major: position by position, beam by beam, as the loop appends them
-            self.finished.append((scores[t, i], t + 1, i))
+            if gnmt:
+                if t not in final:                          # GNMTGlobalScorer.score on the state the beam had at that position
+                    pen = gs.beta * torch.min(cov[t], torch.ones_like(cov[t])).log().sum(1)
+                    l_term = ((5 + (t + 2)) ** gs.alpha) / ((5 + 1) ** gs.alpha)
+                    final[t] = scores[t] / l_term + pen
+                self.finished.append((final[t][i], t + 1, i))
+            else:
+                self.finished.append((scores[t, i], t + 1, i))
         self.eos_top = bool(fin[:, 0].any())
 
     def _final_score(self, i):

@@ -59,7 +59,7 @@ class TranslatorMultimodalVI(object):
         beams = [Beam(self.beam_size, pad, bos, eos, n_best=self.n_best, global_scorer=self.global_scorer,
                       min_length=self.min_length) for _ in range(B)]
         n = rec["scores"].shape[0]
-        if self.global_scorer is None:
+        if self.global_scorer is None or (type(self.global_scorer) is GNMTGlobalScorer and with_attn):
             # a beam advances until it is done (Beam.py:117-124): the number of positions each one takes, for the whole batch at once
             # (see `stop` in _beam), then every beam's bookkeeping in whole-array operations
             fin = rec["next"] == eos
