@@ -17,9 +17,18 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc,
   for (int j = 0; j < 16; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   bf16x8 a, b;
   for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(lane + e); b[e] = (__bf16)(float)(lane - e); }
+  if (MODE == 7) {       // high-entropy operands (what a GEMM on real activations feeds the matrix unit): does the sustained rate depend on the data?
+    unsigned x = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    for (int e = 0; e < 8; ++e) {
+      x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+      a[e] = (__bf16)(((int)(x & 0xffff) - 32768) * (1.0f / 32768.0f));
+      x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+      b[e] = (__bf16)(((int)(x & 0xffff) - 32768) * (1.0f / 32768.0f));
+    }
+  }
   const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds + (lane & 15) * 1024 + (lane >> 4) * 8;
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  for (int it = 0; it < (MODE < 3 ? iters : 0); ++it) {
+  for (int it = 0; it < ((MODE < 3 || MODE == 7) ? iters : 0); ++it) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
 #pragma unroll
@@ -60,7 +69,7 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc,
         }
       }
     }
-  } else if (MODE >= 3) {       // LDS read throughput, four waves of the CU streaming: 3 = ds_read_b64_tr_b16, 4 = ds_read_b128, 5 = ds_read_b64
+  } else if (MODE >= 3 && MODE != 7) {       // LDS read throughput, four waves of the CU streaming: 3 = ds_read_b64_tr_b16, 4 = ds_read_b128, 5 = ds_read_b64
     const unsigned a8 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds + lane * 8 + (threadIdx.x >> 6) * 4096;
     const unsigned a16 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds + lane * 16 + (threadIdx.x >> 6) * 4096;
     s16x4 r[8];
@@ -107,5 +116,21 @@ int main() {
   const double nr = 64.0 * iters;
   printf("gen2_kernel's second-product pattern (MFMA + 2 tr reads 6 ahead): %.1f cycles per MFMA\n", h[6] / n);
   printf("cycles per LDS read wave-instruction (4 waves per CU streaming): tr_b64 %.2f   b128 %.2f   b64 %.2f\n", h[3] / nr, h[4] / nr, h[5] / nr);
+  // sustained matrix-unit rate, every SIMD of the chip issuing back-to-back MFMAs for ~10 ms: small-integer operands against high-entropy ones
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int long_iters = 20000;
+  for (int mode = 0; mode < 2; ++mode) {
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0, 0);
+      if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, out, cyc, long_iters);
+      else hipLaunchKernelGGL(k<7>, dim3(256), dim3(256), 0, 0, out, cyc, long_iters);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    }
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
+    const double nm = 32.0 * long_iters, flop = 256.0 * 4 * nm * 32768.0;
+    printf("%s operands: %.1f cycles per MFMA (s_memtime), %.2f ms for %.0f MFMAs per SIMD = %.0f TFLOP/s, clock %.2f GHz\n",
+           mode == 0 ? "small-integer" : "high-entropy ", h[mode == 0 ? 0 : 7] / nm, ms, nm, flop / (ms * 1e-3) / 1e12, h[mode == 0 ? 0 : 7] / (ms * 1e-3) / 1e9);
+  }
   return 0;
 }
