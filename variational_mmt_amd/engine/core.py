@@ -208,13 +208,21 @@ class Engine(StepAPI):
         ld = shp[1] if len(shp) > 1 else 0
         return self.flat_g.data_ptr() + (o + r * ld + c) * 4
 
+    def wait_background(self, stream=None):
+        """`stream` (default: the current one) waits for the half of the last optimiser step that runs on the side stream"""
+        ev = self.global_events.get("opt_side_done")
+        if ev is not None:
+            (stream if stream is not None else torch.cuda.current_stream(self.dev)).wait_event(ev)
+
     def load_state_dict(self, sd):
+        self.wait_background()
         for n, t in sd.items():
             if n in self.params:
                 self.params[n].copy_(t.to(torch.float32))
         self.shadows_dirty = True
 
     def state_dict(self):
+        self.wait_background()      # (decoder-side parameters are updated on the side stream: optim_step)
         sd = {n: v.detach().clone() for n, v in self.params.items()}
         if self.d.conditional:      # encoder_tgt shares the decoder's table; the reference's state dict lists it under both names
             sd["encoder_tgt.embeddings.make_embedding.emb_luts.0.weight"] = sd["decoder.embeddings.make_embedding.emb_luts.0.weight"]
