@@ -306,6 +306,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-stream", action="store_true", help="profiling aid: issue the whole step on one stream")
     ap.add_argument("--conditional", action="store_true", help="the --conditional prior variant (SURVEY.md 8f-1) instead of the fixed prior")
+    ap.add_argument("--n-img", type=int, default=0, help="rows of the resident image-feature table (default: the configuration's; 290000 = "
+                    "BASELINE config 4's 290 K-triplet set, 1000000 = config 5's synthetic 1 M triplets: 8.2 GB of HBM)")
     ap.add_argument("--lengths", default="fixed", choices=["fixed", "ragged"], help="sentence lengths: all 20 (the headline shape) or U[10, 20] "
                     "sorted by source length (BASELINE.md section 3)")
     ap.add_argument("--through-trainer", action="store_true", help="time onmt.TrainerMultimodal.train over an OrderedIterator on a synthetic "
@@ -365,9 +367,17 @@ def main():
         # rehearsal only: the persistent recurrence kernels need every workgroup of a launch resident at once, which two processes
         # sharing one GPU cannot both have (the launches then run into their 2-second hand-off bound and the run fails loudly)
         eng.persistent_lstm = False
-    n_img = cf["n_img"]
-    gt = torch.Generator().manual_seed(11)
-    eng.set_image_table(torch.rand(n_img, d.img, generator=gt))
+    n_img = a.n_img or cf["n_img"]
+    if n_img <= 100000:
+        gt = torch.Generator().manual_seed(11)
+        eng.set_image_table(torch.rand(n_img, d.img, generator=gt))
+    else:           # a table of GBs is drawn on the device (no host copy of it): the reference's array is the HDF5 file's, read once
+        gd = torch.Generator(device=dev).manual_seed(11)
+        tab = torch.empty(n_img, d.img, dtype=torch.float32, device=dev)
+        for lo in range(0, n_img, 65536):
+            tab[lo:lo + 65536].uniform_(0.0, 1.0, generator=gd)
+        eng.set_image_table(tab)
+        del tab
     batches = make_batches(d, B, S, T, n_img, 8, dev, 1234 + rank, ragged=a.lengths == "ragged")
     Bg = B * world
     from variational_mmt_amd.dp import GradSync
@@ -472,7 +482,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (cf["name"] % B) + ", dropout %.1f, Adam%s%s" % (a.dropout, ", --conditional prior" if a.conditional else "",
                                                                                     ", lengths U[10,20]" if a.lengths == "ragged" else ""),
-                       "global_batch": Bg, "parallelism": "dp%d" % world},
+                       "global_batch": Bg, "parallelism": "dp%d" % world, "image_rows": n_img},
             "roofline": {"bound": "mfma", "kernel": (("gen2w_kernel" if d.hid > 512 else "gen2_kernel") + " (fused vocabulary sweep: logits + softmax statistics + dO, softmax weights stored for the dWg GEMM)" if fused else
                                     "gen_kernel (vocab projection + log-softmax/NLL pass, slower of fwd/bwd)"),
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
