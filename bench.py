@@ -38,7 +38,7 @@ CONFIGS = {
     "2": dict(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, S=20, T=21, n_img=29000,
             name="BASELINE config 2: VI_Model1 training step, batch %d/GPU, src/tgt len 20, V=30000, 1-layer biLSTM 512, z 256, "
                  "emb 500, 2048-d image feats"),
-    "5": dict(vs=50000, vt=50000, emb=1024, hid=1024, z=512, img=2048, layers=2, brnn=True, S=64, T=65, n_img=100000,
+    "5": dict(vs=50000, vt=50000, emb=1024, hid=1024, z=512, img=2048, layers=2, brnn=True, S=64, T=65, n_img=1000000,
             name="BASELINE config 5 (roofline stress): VI_Model1 training step, batch %d/GPU, src/tgt len 64, V=50000, 2-layer "
                  "biLSTM 1024, z 512, emb 1024, 2048-d image feats"),
     "script": dict(vs=30000, vt=30000, emb=500, hid=500, z=500, img=2048, layers=2, brnn=False, S=20, T=21, n_img=29000,

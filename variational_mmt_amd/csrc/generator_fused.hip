@@ -968,9 +968,10 @@ static int g2_tiles_per_split(int M, int V, int K) {
   const int nmt = (M + 127) / 128, ntiles = (V + 31) / 32;
   int ns = 256 / nmt;
   if (K > 512) {
-    // 64-token blocks (gen2w_kernel): BASELINE config 5 has 260 of them, which no slice count turns into whole rounds of 256
-    // workgroups.  Cost of c slices in sweeps of the vocabulary: ceil(blocks c / 256) / c rounds + ~1 % per slice for its partials
-    // (measured there, ms per launch: 4 slices 4.13, 8: 4.05, 12: 4.51, 16: 4.45 -- with 8 every XCD streams exactly one slice)
+    // 64-token blocks (gen2w_kernel).  Cost of c slices in sweeps of the vocabulary: ceil(blocks c / 256) / c rounds + ~1 % per slice
+    // for its partials.  BASELINE config 5 (T' = 64, B = 256) has exactly 256 blocks: ONE slice, every workgroup sweeps the whole
+    // vocabulary and all of them stream the same tile at the same time (measured there, ms per launch: 1 slice 3.96, 2: 4.02, 4: 4.08,
+    // 8: 4.31); with 260 blocks (T' = 65): 4 slices 4.13, 8: 4.05, 12: 4.51, 16: 4.45
     const int nb = (M + 63) / 64;
     double best = 1e30;
     for (int c = 1; c <= 16; ++c) {
