@@ -1,0 +1,54 @@
+"""Register budgets the step's schedule depends on (CPU: read from variational_mmt_amd/kernel_resources.json, which the build writes from
+the compiler's own -Rpass-analysis=kernel-resource-usage remarks).  A gfx950 SIMD has 512 registers per lane for all of its waves
+(arch + accumulation registers, allocated in blocks of 8).  The persistent recurrences hold one wave per SIMD for a whole sequence, and the
+plan runs GEMMs of other streams on the same CUs next to them: that only happens while the two kernels' registers add up to <= 512.
+Measured when an epilogue change took the 128 x 128 NT product from 220 to 236 registers: the step went from 1.775 to 1.88 ms (same box)
+-- the products no longer fitted beside lstm_seq_fwd_kernel<512> and waited for it."""
+import json
+import os
+
+import pytest
+
+from variational_mmt_amd import build as B
+
+
+@pytest.fixture(scope="module")
+def res():
+    if not os.path.exists(B.RESOURCES):
+        B.build(verbose=False)
+    with open(B.RESOURCES) as f:
+        return json.load(f)
+
+
+def _total(v):
+    return ((v["vgprs"] + 3) // 4 * 4 + v["agprs"] + 7) // 8 * 8          # unified file: accumulation registers start at a multiple of 4
+
+
+def _find(res, *parts):
+    hits = [k for k in res if all(p in k for p in parts)]
+    assert len(hits) == 1, (parts, hits)
+    return _total(res[hits[0]])
+
+
+def test_no_kernel_spills(res):
+    assert len(res) > 100
+    bad = {k: v for k, v in res.items() if v.get("vgpr_spill", 0) or v.get("scratch", 0)}
+    assert not bad, bad
+
+
+def test_gemms_fit_beside_the_persistent_recurrences(res):
+    g = "gemm_kernelItLi128ELi128ELi64ELi64E"        # bf16, 128 x 128 tiles, LDS-DMA loop (the trailing ...Li1E)
+    nt, tn, nn = (_find(res, g + lay + "ELi64ELb1ELi1E") for lay in ("Lb1ELb1", "Lb0ELb0", "Lb1ELb0"))
+    fwd512, bwd512 = _find(res, "lstm_seq_fwd_kernelILi512E"), _find(res, "lstm_seq_bwd_kernelILi512E")
+    fwd256, bwd256 = _find(res, "lstm_seq_fwd_kernelILi256E"), _find(res, "lstm_seq_bwd_kernelILi256E")
+    # forward: the decoder's recurrence (H = 512) runs beside NT products (image network, target-side input projection)
+    assert fwd512 + nt <= 512, (fwd512, nt)
+    # backward: weight gradients (TN) and input gradients (NN) beside both backward recurrences
+    assert bwd512 + max(tn, nn, nt) <= 512, (bwd512, tn, nn, nt)
+    # the encoder's directions (H = 256) leave room for every product
+    assert max(fwd256, bwd256) + max(tn, nn, nt) <= 512, (fwd256, bwd256, tn, nn, nt)
+
+
+def test_one_wave_per_simd_kernels_stay_within_the_file(res):
+    for name in ("gen2_kernelILi512ELb1E", "gen2w_kernelILb1E", "lstm_seq_fwd_kernelILi1024E", "lstm_seq_bwd_kernelILi1024E"):
+        assert _find(res, name) <= 512, name
