@@ -94,3 +94,55 @@ def test_attention_forward_backward(Tp, S, H, B, dtype):
     assert (got_dq - dq_ref).abs().max().item() <= tol_g * max(1e-3, dq_ref.abs().max().item())
     assert (got_dc - dctx_ref).abs().max().item() <= tol_g * max(1e-3, dctx_ref.abs().max().item())
     assert (DQ[M:] == 0).all()
+
+
+@pytest.mark.parametrize("Tp,S,H,B", [(20, 20, 512, 256), (32, 32, 96, 5), (7, 31, 160, 6), (1, 1, 64, 3), (20, 17, 1024, 4)])
+def test_attention_backward_small_sentences_low_lds_kernel(Tp, S, H, B):
+    """T', S <= 32 in bf16 (BASELINE configs 1-4): `attn_bwd_lite` -- MFMA fragments of dC / Hs straight from global memory, the K-strided
+    tiles through one 2.5 KiB buffer per wave, 15 KiB of LDS in all so that it shares a CU with the dWg product's workgroups -- against fp64
+    math, and against `attn_bwd_fast` (three staged images), which serves the same call when the rows are not 16-byte aligned."""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    T = torch.bfloat16
+    g = torch.Generator().manual_seed(Tp * 100 + S + H)
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    lens[0] = S
+    lens, _ = torch.sort(lens, descending=True)
+    q = (torch.randn(Tp, B, H, generator=g) * 0.3).to(T)
+    ctx = (torch.randn(S, B, H, generator=g) * 0.3).to(T)
+    for b in range(B):
+        ctx[lens[b]:, b] = 0
+    dcat_l = (torch.randn(Tp, B, H, generator=g) * 0.1).to(T)
+    qd, cd, dd = q.double(), ctx.double(), dcat_l.double()
+    sc = torch.einsum("tbh,sbh->tbs", qd, cd).masked_fill(torch.arange(S).view(1, 1, S) >= lens.view(1, B, 1), float("-inf"))
+    pr = torch.softmax(sc, dim=2)
+    dp = torch.einsum("tbh,sbh->tbs", dd, cd)
+    ds = pr * (dp - (pr * dp).sum(2, keepdim=True))
+    dq_ref = torch.einsum("tbs,sbh->tbh", ds, cd)
+    dctx_ref = (torch.einsum("tbs,tbh->sbh", pr, dd) + torch.einsum("tbs,tbh->sbh", ds, qd)).masked_fill(
+        torch.arange(S).view(S, 1, 1) >= lens.view(1, B, 1), 0.0)
+    M, MS = Tp * B, S * B
+    probs = pr.float().reshape(M * S).cuda()
+    ld = lens.cuda()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    outs = []
+    for pad in (0, 4):                                  # leading dimensions H + 64 (aligned rows) / H + 68 (8-byte rows: the staged kernel)
+        def buf(rows, fill=None, val=0.0):
+            t = torch.full((rows + 8, H + 64 + pad), val, dtype=T, device="cuda")
+            if fill is not None:
+                t[:rows, :H] = fill.cuda()
+            return t
+        Q, CTX, DCAT = buf(M, q.reshape(M, H)), buf(MS, ctx.reshape(MS, H)), buf(M, dcat_l.reshape(M, H))
+        DQ, DCTX = buf(M, val=7.0), buf(MS, val=7.0)
+        L.check(lib.vmmt_attn_bwd(L.BF16, P(DCAT), DCAT.shape[1], P(probs), P(Q), Q.shape[1], P(CTX), CTX.shape[1], P(ld), P(DQ), DQ.shape[1],
+                                  P(DCTX), DCTX.shape[1], Tp, B, S, H, None), "attn bwd")
+        torch.cuda.synchronize()
+        assert (DQ[:, H:] == 7.0).all() and (DQ[M:] == 7.0).all() and (DCTX[:, H:] == 7.0).all() and (DCTX[MS:] == 7.0).all()
+        got_dq = DQ[:M, :H].float().cpu().double().view(Tp, B, H)
+        got_dc = DCTX[:MS, :H].float().cpu().double().view(S, B, H)
+        assert (got_dq - dq_ref).abs().max().item() <= 3e-2 * max(1e-3, dq_ref.abs().max().item())
+        assert (got_dc - dctx_ref).abs().max().item() <= 3e-2 * max(1e-3, dctx_ref.abs().max().item())
+        outs.append((got_dq, got_dc))
+    # the two kernels differ in the order of the f32 partial sums only
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 8e-3 * max(1e-3, dq_ref.abs().max().item())
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 8e-3 * max(1e-3, dctx_ref.abs().max().item())

@@ -33,7 +33,7 @@ def _resources(remarks):
     """{mangled kernel name: {vgprs, agprs, sgprs, scratch, vgpr_spill, occupancy}} from -Rpass-analysis=kernel-resource-usage"""
     out, cur = {}, None
     keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "TotalSGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch", "VGPRs Spill": "vgpr_spill",
-            "Occupancy [waves/SIMD]": "occupancy"}
+            "Occupancy [waves/SIMD]": "occupancy", "LDS Size [bytes/block]": "lds_static"}
     for line in remarks.splitlines():
         m = re.search(r"remark:\s+Function Name: (\S+)", line)
         if m:

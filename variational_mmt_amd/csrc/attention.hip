@@ -687,6 +687,118 @@ __global__ void __launch_bounds__(256) attn_bwd_big(const bf16_t* __restrict__ d
   }
 }
 
+// The same backward with 15 KiB of LDS instead of 122 (three staged operand images): in the training step this kernel runs while the
+// generator's dWg product holds every CU with 144 KiB workgroups, and a workgroup that needs a free CU's worth of LDS waits for one of
+// those to retire (137 us in the step against 25 alone).  Here nothing is staged whole:
+//   dP = dC Hs^T      both operands are K-contiguous in memory: the MFMA fragments are 16-byte global loads; EVERY wave runs the whole
+//                     reduction (H / 16 MFMAs, 1 us) instead of a quarter plus a fold through LDS
+//   dS                in the accumulator registers; wave w finishes rows 8w .. 8w+7 and writes P, dS (bf16 [32][40]) for the others
+//   dQ, dHs           per 32-column tile (tiles round-robin over the waves): the [32 x 32] tiles of Hs, dC and Q pass one after the other
+//                     through ONE wave-private 2.5 KiB buffer (they are read K-strided: ds_read_b64_tr_b16), and the two output tiles
+//                     leave through the same buffer as 16-byte rows instead of 2-byte column stores.
+// Preconditions (vmmt_attn_bwd falls back to attn_bwd_fast otherwise): T', S <= 32, H % 32 == 0, rows 16-byte aligned.
+__global__ void __launch_bounds__(256) attn_bwd_lite(const bf16_t* __restrict__ dcat, long lddc, const float* __restrict__ probs,
+                                                     const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ ctx,
+                                                     long ldc, const long long* __restrict__ lens, bf16_t* __restrict__ dq,
+                                                     long lddq, bf16_t* __restrict__ dctx, long lddx, int Tp, int B, int S, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  bf16_t* Pb = reinterpret_cast<bf16_t*>(smem_raw);          // [32][40]
+  bf16_t* dSb = Pb + 32 * 40;                                // [32][40]
+  bf16_t* tb = dSb + 32 * 40 + wave * (32 * 40);             // this wave's tile buffer [32][40]
+  int len = (int)lens[b];
+  len = len < S ? len : S;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int row = lane & 31, kq = 8 * (lane >> 5), nks = H / 16;
+    const bf16_t* ar = dcat + ((long)row * B + b) * lddc + kq;
+    const bf16_t* br = ctx + ((long)row * B + b) * ldc + kq;
+    const bool av = row < Tp, bv = row < S;
+    for (int k0 = 0; k0 < nks; k0 += 8) {
+      u32x4 fa[8], fb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool in = k0 + j < nks;
+        fa[j] = (av && in) ? *reinterpret_cast<const u32x4*>(ar + (k0 + j) * 16) : zero;
+        fb[j] = (bv && in) ? *reinterpret_cast<const u32x4*>(br + (k0 + j) * 16) : zero;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < nks)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[j]), __builtin_bit_cast(bf16x8, fb[j]), acc, 0, 0, 0);
+    }
+    // softmax backward on accumulator rows 8 wave .. 8 wave + 7 (registers 4 wave .. 4 wave + 3: static indices per branch)
+    const int s_ = lane & 31;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (wave == w) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int t = acc_row(4 * w + rr, lane);
+          const float dp = acc[4 * w + rr];
+          const float p = (t < Tp && s_ < len) ? probs[((long)t * B + b) * S + s_] : 0.f;
+          float dot = p * dp;
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+          Pb[t * 40 + s_] = f2bf(p);
+          dSb[t * 40 + s_] = f2bf(p * (dp - dot));
+        }
+      }
+  }
+  __syncthreads();
+  const int r0 = lane >> 2, c8 = 8 * (lane & 3);             // tile staging / output rows r0, r0 + 16; 8 columns from c8
+  for (int tile = wave; tile < H / 32; tile += 4) {
+    const int h0 = 32 * tile;
+    u32x4 vh[2], vc[2], vq[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = r0 + 16 * j;
+      vh[j] = r < S ? *reinterpret_cast<const u32x4*>(ctx + ((long)r * B + b) * ldc + h0 + c8) : zero;
+      vc[j] = r < Tp ? *reinterpret_cast<const u32x4*>(dcat + ((long)r * B + b) * lddc + h0 + c8) : zero;
+      vq[j] = r < Tp ? *reinterpret_cast<const u32x4*>(q + ((long)r * B + b) * ldq + h0 + c8) : zero;
+    }
+    f32x16 aq, ah;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ah[r] = 0.f; }
+    // (the buffer is private to this wave and the LDS executes a wave's operations in order: no barrier between a fill and its reads)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(tb + (r0 + 16 * j) * 40 + c8) = vh[j];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)          // dQ[t][h] += dS[t][s] Hs[s][h]        (k = s)
+      aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKC(dSb, 40, 0, ks * 16, lane), afragKS(tb, 40, 0, ks * 16, lane), aq, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(tb + (r0 + 16 * j) * 40 + c8) = vc[j];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)          // dHs[s][h] += P[t][s] dC[t][h]        (k = t: both operands K-strided)
+      ah = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKS(Pb, 40, 0, ks * 16, lane), afragKS(tb, 40, 0, ks * 16, lane), ah, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(tb + (r0 + 16 * j) * 40 + c8) = vq[j];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)          // dHs[s][h] += dS[t][s] Q[t][h]
+      ah = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afragKS(dSb, 40, 0, ks * 16, lane), afragKS(tb, 40, 0, ks * 16, lane), ah, 0, 0, 0);
+    // the two output tiles leave as rows of 16 bytes through the same buffer
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tb[acc_row(r, lane) * 40 + (lane & 31)] = f2bf(aq[r]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = r0 + 16 * j;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(tb + r * 40 + c8);
+      if (r < Tp) *reinterpret_cast<u32x4*>(dq + ((long)r * B + b) * lddq + h0 + c8) = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tb[acc_row(r, lane) * 40 + (lane & 31)] = f2bf(acc_row(r, lane) < len ? ah[r] : 0.f);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = r0 + 16 * j;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(tb + r * 40 + c8);
+      if (r < S) *reinterpret_cast<u32x4*>(dctx + ((long)r * B + b) * lddx + h0 + c8) = v;
+    }
+  }
+}
+
 // LDS request of the big kernels; bwd: the large region holds max(memory image, two column-chunk images)
 static int attn_big_chunk(int H) { return (H % 64 == 0 && H > 256) ? H / 2 : H; }
 static size_t attn_big_lds_fwd(int H) { return (size_t)64 * (H + 8) * 2 + 64 * ATT_PB * 2 + 64 * 2 * 4; }
@@ -771,6 +883,14 @@ extern "C" int vmmt_attn_bwd(int dtype, const void* dcat, int64_t lddc, const fl
   using namespace vmmt;
   if (!dcat || !probs || !q || !ctx || !lens || !dq || !dctx || S > ATT_MAXS || H > 64 * ATT_MAXJ || Tp <= 0 || B <= 0)
     return VMMT_EINVAL;
+  if (dtype == VMMT_BF16 && Tp <= 32 && S <= 32 && H % 32 == 0 && ((lddc | ldq | ldc | lddq | lddx) & 7) == 0 &&
+      ((((uintptr_t)dcat) | ((uintptr_t)q) | ((uintptr_t)ctx) | ((uintptr_t)dq) | ((uintptr_t)dctx)) & 15) == 0) {
+    const size_t sm = 6 * 32 * 40 * 2;          // P, dS and one tile buffer per wave: 15 KiB
+    hipLaunchKernelGGL(attn_bwd_lite, dim3(B), dim3(256), sm, (hipStream_t)stream, (const bf16_t*)dcat, (long)lddc, probs,
+                       (const bf16_t*)q, (long)ldq, (const bf16_t*)ctx, (long)ldc, (const long long*)lens, (bf16_t*)dq, (long)lddq,
+                       (bf16_t*)dctx, (long)lddx, Tp, B, S, H);
+    return check_launch();
+  }
   if (dtype == VMMT_BF16 && Tp <= 32 && S <= 32 && H % 32 == 0 && attn_fast_lds(H, 3) <= 150 * 1024) {
     size_t sm = attn_fast_lds(H, 3);
     static size_t attr = 0;
