@@ -52,3 +52,12 @@ def test_gemms_fit_beside_the_persistent_recurrences(res):
 def test_one_wave_per_simd_kernels_stay_within_the_file(res):
     for name in ("gen2_kernelILi512ELb1E", "gen2w_kernelILb1E", "lstm_seq_fwd_kernelILi1024E", "lstm_seq_bwd_kernelILi1024E"):
         assert _find(res, name) <= 512, name
+
+
+def test_attention_backward_fits_beside_the_dwg_product(res):
+    """attn_bwd_lite exists to run WHILE the generator's dWg product (256 x 128 tiles, 8 waves = 2 per SIMD, 144 KiB of LDS) holds every
+    CU: one of its waves per SIMD next to two of the product's, and its 15 KiB of LDS in what the product leaves of a CU's 160"""
+    dwg = _find(res, "gemm_kernelItLi256ELi128ELi64ELi64ELb0ELb0ELi64ELb1ELi3E")
+    lite = _find(res, "attn_bwd_lite")
+    assert 2 * dwg + lite <= 512, (dwg, lite)
+    assert 3 * (256 + 128) * 64 * 2 + 6 * 32 * 40 * 2 <= 160 * 1024          # the product's three operand stages + P, dS and four tile buffers
