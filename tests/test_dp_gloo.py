@@ -186,7 +186,7 @@ def _worker_shards(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_optimiser_collectives(tmp_path, world):
     out = str(tmp_path / "res.pt")
     port = 27000 + (os.getpid() % 2000) + world
