@@ -79,7 +79,8 @@ def make_batches(d, B, S, T, n_img, n_batches, device, seed, ragged=False):
         tgt[tl - 1, torch.arange(B)] = 3
         tgt[torch.arange(T_).unsqueeze(1) >= tl.unsqueeze(0)] = 1
         idx = torch.randint(0, n_img, (B,), generator=g)
-        out.append(tuple(x.to(device) for x in (src, sl, tgt, idx, tl)))
+        # (the last item: decoder rows that carry a target -- what a loader knows on the host; Engine.forward(n_tgt_tokens=))
+        out.append(tuple(x.to(device) for x in (src, sl, tgt, idx, tl)) + (int((tl - 1).sum()),))
     return out
 
 
@@ -384,8 +385,8 @@ def main():
     sync = GradSync(eng)          # attaches itself to the engine when torch.distributed runs with > 1 rank
 
     def step(i):
-        src, sl, tgt, idx, tlen = batches[i % len(batches)]
-        ws = eng.forward(src, sl, tgt, idx, training=True, tgt_len=tlen if a.conditional else None)
+        src, sl, tgt, idx, tlen, n_tok = batches[i % len(batches)]
+        ws = eng.forward(src, sl, tgt, idx, training=True, tgt_len=tlen if a.conditional else None, n_tgt_tokens=n_tok)
         eng.loss_backward(ws, normalization=Bg, batch_global=Bg)
         sync.all_reduce()          # waits for the segment all-reduces the backward plan issued behind each segment
         eng.optim_step(lr=0.002, max_grad_norm=5.0)
@@ -409,6 +410,8 @@ def main():
             rc = fn(*x)
             e_.record(st_)
             dom[key].append((s, e_))
+            if key == "gen_fwd" and name == "vmmt_gen_fwd_dO":
+                dom.setdefault("gen_fwd_tokens", []).append(int(x[8]))     # (ragged batches: the sweep runs over the rows that carry a target)
             return rc
         timed_fn.__name__ = name
         plan[index] = (timed_fn, args, name, keep, sid)
@@ -461,6 +464,9 @@ def main():
         t_b = sum(s.elapsed_time(e_) for s, e_ in dom["gen_bwd"]) / max(1, a.steps)
         t_dom = max(t_f, t_b)
         ach = gen_flop / (t_dom * 1e-3) / 1e12 if t_dom > 0 else 0.0
+        if fused and dom.get("gen_fwd_tokens"):      # per launch as issued: 4 H V x the launch's own token count over its own time
+            tsum = sum(s.elapsed_time(e_) for s, e_ in dom["gen_fwd"])
+            ach = 4.0 * sum(dom["gen_fwd_tokens"]) * d.vt * d.hid / (tsum * 1e-3) / 1e12 if tsum > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json).  The entry names the
         # kernel source it was measured on (sha256 of the .hip file); if that file has changed since, the figure is withheld
         traffic, traffic_note = None, None

@@ -263,12 +263,20 @@ int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M, int V, in
 int64_t vmmt_gen_fused_ws_floats(int M, int V, int K);
 int vmmt_gen_fused_geometry(int M, int V, int K, int* nsplit, int* v_per_split, int64_t* mpad);
 int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows, const float* bias, const void* O, int64_t ldo, const int64_t* y,
-                    int M, int V, int K, float* ws, float* tgt_logit, void* P, int64_t ldp, void* stream);
+                    int M, int V, int K, float* ws, float* tgt_logit, void* P, int64_t ldp, const int32_t* rows, void* stream);
 int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
                          int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
-                         float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride, void* stream);
+                         float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride, const int32_t* rows,
+                         void* stream);
 int vmmt_gen_dW_finish(int dtype, const void* P, int64_t ldp, const float* cs, const void* O, int64_t ldo, const int* y32, int M, int V,
-                       int K, float inv_norm, float* dW, int64_t lddw, float* dbias, int colsum_done, void* stream);
+                       int K, float inv_norm, float* dW, int64_t lddw, float* dbias, int colsum_done, const int32_t* rows, void* stream);
+/* COMPACTED tokens (rows != NULL in the three calls above): pads carry loss weight zero (Loss.py:163-165) but a dense sweep spends FLOPs on
+ * them -- 26 % of the decoder rows at target lengths U[10, 20].  vmmt_compact_nonpad lists the rows with y != pad in order (rows[j], j < n;
+ * -1 for n <= j < Mc; count, optional, receives n; one workgroup, deterministic).  The generator calls then take M = Mc (n rounded up, e.g.
+ * to 128) and `rows`: token m of the launch is row rows[m] of O, y, lse, tok_nll and dO (rows not listed are NOT written: clear them
+ * beforehand), while P, y32, cs, Os, tgt_logit and the workspace are indexed by m; the dWg product runs over K = Mc tokens.  Same sums as the
+ * dense calls up to the order of the f32 additions over tokens. */
+int vmmt_compact_nonpad(const int64_t* y, int M, int pad, int Mc, int32_t* rows, int32_t* count, void* stream);
 
 /* ---- row gathers / small fused kernels -------------------------------------------------------------------------- */
 /* out[r][0:D] = table[ids[r]][0:D]; table f32 (embedding master weights: modules/Embeddings.py:181; or the HBM-resident

@@ -30,15 +30,27 @@ def _dlogit_properties(ws, M, V, y, B, tol):
         return
     assert ws.gen_fused
     P = ws.gen_P[:(ws.gen_P.numel() // ws.gen_ldp) * ws.gen_ldp].view(-1, ws.gen_ldp)
-    cs = ws.gen_cs.view(ws.gen_ns, ws.gen_mpad)
-    tot = torch.zeros(M, device="cuda", dtype=torch.float64)
-    for s_ in range(ws.gen_ns):
-        v0, v1 = s_ * ws.gen_vps, min(V, (s_ + 1) * ws.gen_vps)
+    # (ragged batches: the generator ran over the Mc compacted token rows -- row j of P / cs is decoder row rows[j], -1 = no token)
+    (ns, vps, mpad), rows_ptr, _ = ws.gen_cur
+    Mc = ws.gen_Mc
+    cs = ws.gen_cs[:ns * mpad].view(ns, mpad)
+    tot = torch.zeros(Mc, device="cuda", dtype=torch.float64)
+    for s_ in range(ns):
+        v0, v1 = s_ * vps, min(V, (s_ + 1) * vps)
         if v0 < v1:
-            tot += P[:M, v0:v1].float().sum(1).double() * cs[s_, :M].double()
-    s_m = (~pad).double() / B
+            tot += P[:Mc, v0:v1].float().sum(1).double() * cs[s_, :Mc].double()
+    if rows_ptr is None:
+        assert Mc == M
+        s_m = (~pad).double() / B
+        assert (cs[:, :M][:, pad] == 0).all()
+    else:
+        assert Mc < M
+        rows = ws.gen_rows[:Mc].long()
+        n = int((~pad).sum())
+        assert torch.equal(rows[:n], torch.nonzero(~pad).flatten()) and (rows[n:] == -1).all()
+        s_m = (rows >= 0).double() / B
+        assert (cs[:, :Mc][:, rows < 0] == 0).all()
     assert (tot - s_m).abs().max().item() <= tol, (tot - s_m).abs().max().item()
-    assert (cs[:, :M][:, pad] == 0).all()
 
 
 def _run(c, p, bt, dtype, gen_fused=True):

@@ -320,10 +320,10 @@ def test_generator_fused_pass_bf16(M, V, H, ramp):
     cs = torch.zeros(ns, mpad, device="cuda")
     Mk = (M + 63) // 64 * 64
     Os = torch.zeros(ns, Mk, H, device="cuda", dtype=T)
-    L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, V + 256, P(bd), P(Od), H, P(yd), M, V, H, P(ws), P(tl), P(Pw), ldp, None), "gen fwd dO")
-    assert lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, V, P(bd), P(Od), H, P(yd), M, V, H, P(ws), P(tl), P(Pw), ldp, None) != 0     # W too short for the prefetch
+    L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, V + 256, P(bd), P(Od), H, P(yd), M, V, H, P(ws), P(tl), P(Pw), ldp, None, None), "gen fwd dO")
+    assert lib.vmmt_gen_fwd_dO(L.BF16, P(Wd), H, V, P(bd), P(Od), H, P(yd), M, V, H, P(ws), P(tl), P(Pw), ldp, None, None) != 0     # W too short for the prefetch
     L.check(lib.vmmt_gen_fwd_combine(L.BF16, P(Wd), H, P(Od), H, P(yd), M, V, H, 1, inv_norm, P(ws), P(tl), P(lse), P(nll), P(y32),
-                                     P(dO), H + 4, P(st), P(cs), P(Os), H, Mk * H, None), "gen fwd combine")
+                                     P(dO), H + 4, P(st), P(cs), P(Os), H, Mk * H, None, None), "gen fwd combine")
     torch.cuda.synchronize()
     assert (lse.cpu().double() - lse_ref).abs().max().item() <= 2e-4 * max(1.0, lse_ref.abs().max().item())
     assert (nll.cpu().double() - nll_ref).abs().max().item() <= 5e-4 * max(1.0, nll_ref.abs().max().item())
@@ -344,7 +344,7 @@ def test_generator_fused_pass_bf16(M, V, H, ramp):
         if v0 < v1:
             dW2[v0:v1] = Pw[:M, v0:v1].float().t() @ Os[s_, :M].float()
     db2 = torch.full((V,), 0.5, device="cuda")
-    L.check(lib.vmmt_gen_dW_finish(L.BF16, P(Pw), ldp, P(cs), P(Od), H, P(y32), M, V, H, inv_norm, P(dW2), H, P(db2), 0, None), "dW finish")
+    L.check(lib.vmmt_gen_dW_finish(L.BF16, P(Pw), ldp, P(cs), P(Od), H, P(y32), M, V, H, inv_norm, P(dW2), H, P(db2), 0, None, None), "dW finish")
     torch.cuda.synchronize()
     e4 = (dW2.cpu().double() - dW_ref).norm().item() / max(1e-30, dW_ref.norm().item())
     assert e4 <= 6e-3, e4
@@ -461,3 +461,88 @@ def test_scatter_add_rows_with_padding_row():
     want = out0.double().index_add_(0, ids[keep], X[keep, :D].double())
     assert (od.cpu().double() - want).abs().max().item() <= 1e-4
     assert torch.equal(od[1].cpu(), out0[1])                          # the padding row receives nothing
+
+
+def test_compact_nonpad_lists_the_target_rows_in_order():
+    import ctypes as C
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(9)
+    for M, frac in ((5120, 0.26), (1, 0.0), (1000, 1.0), (16640, 0.5), (777, 0.03)):
+        y = torch.randint(2, 50, (M,), generator=g)
+        y[torch.rand(M, generator=g) < frac] = 1
+        want = torch.nonzero(y != 1).flatten().int()
+        n = want.numel()
+        Mc = max(128, (n + 127) // 128 * 128)
+        rows = torch.full((Mc + 5,), 77, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        yd = y.cuda()
+        L.check(lib.vmmt_compact_nonpad(C.c_void_p(yd.data_ptr()), M, 1, Mc, C.c_void_p(rows.data_ptr()), C.c_void_p(cnt.data_ptr()), None), "compact")
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == n
+        assert torch.equal(rows[:n].cpu(), want) and (rows[n:Mc] == -1).all() and (rows[Mc:] == 77).all()
+
+
+@pytest.mark.parametrize("M,V,H", [(1500, 3000, 512), (2600, 4100, 256), (1300, 2500, 1024)])
+def test_generator_over_compacted_tokens_equals_the_dense_calls(M, V, H):
+    """the fused generator calls over the rows that carry a target only (vmmt_compact_nonpad + `rows`) against the same calls over all
+    rows: statistics, per-token lse / NLL (zero where no token stands), dO (zero rows at pads), dWg and db -- the same sums up to the order
+    of the f32 additions (the vocabulary slices follow the token count)"""
+    import ctypes as C
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    T = torch.bfloat16
+    g = torch.Generator().manual_seed(M + V)
+    Vp = (V + 31) // 32 * 32 + 256
+    W = (torch.randn(Vp, H, generator=g) * 0.05).to(T).cuda(); W[V:] = 0
+    O = (torch.randn(M, H, generator=g) * 0.5).to(T).cuda()
+    bias = (torch.randn(Vp, generator=g) * 0.1).cuda()
+    y = torch.randint(2, V, (M,), generator=g)
+    y[torch.rand(M, generator=g) < 0.3] = 1                     # 30 % pads
+    yd = y.cuda()
+    n = int((y != 1).sum())
+    Mc = (n + 127) // 128 * 128
+    assert Mc < M
+    inv_norm = 1.0 / 40.0
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def run(Mx, rows):
+        ns, vps, mpad = C.c_int(), C.c_int(), C.c_int64()
+        L.check(lib.vmmt_gen_fused_geometry(Mx, V, H, C.byref(ns), C.byref(vps), C.byref(mpad)), "geometry")
+        ns, vps, mpad = ns.value, vps.value, mpad.value
+        ws = torch.zeros(lib.vmmt_gen_fused_ws_floats(Mx, V, H), device="cuda")
+        ldp = (V + 31) // 32 * 32
+        Mk = Mx + 64
+        Pw = torch.zeros(Mk, ldp, device="cuda", dtype=T)
+        tl = torch.zeros(M, device="cuda"); lse = torch.zeros(M, device="cuda"); nll = torch.zeros(M, device="cuda")
+        y32 = torch.zeros((Mx + 31) // 32 * 32, device="cuda", dtype=torch.int32)
+        dO = torch.zeros(M, H, device="cuda"); st = torch.zeros(8, device="cuda")
+        cs = torch.zeros(ns, mpad, device="cuda"); Os = torch.zeros(ns, Mk, H, device="cuda", dtype=T)
+        L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(W), H, Vp, P(bias), P(O), H, P(yd), Mx, V, H, P(ws), P(tl), P(Pw), ldp, P(rows), None), "sweep")
+        L.check(lib.vmmt_gen_fwd_combine(L.BF16, P(W), H, P(O), H, P(yd), Mx, V, H, 1, inv_norm, P(ws), P(tl), P(lse), P(nll), P(y32),
+                                         P(dO), H, P(st), P(cs), P(Os), H, Mk * H, P(rows), None), "combine")
+        dW = torch.empty(V, H, device="cuda")
+        for s_ in range(ns):
+            v0, v1 = s_ * vps, min(V, (s_ + 1) * vps)
+            if v0 < v1:
+                dW[v0:v1] = Pw[:Mx, v0:v1].float().t() @ Os[s_, :Mx].float()
+        db = torch.zeros(V, device="cuda")
+        L.check(lib.vmmt_gen_dW_finish(L.BF16, P(Pw), ldp, P(cs), P(O), H, P(y32), Mx, V, H, inv_norm, P(dW), H, P(db), 0, P(rows), None), "finish")
+        torch.cuda.synchronize()
+        return dict(lse=lse.cpu(), nll=nll.cpu(), dO=dO.cpu(), st=st.cpu(), dW=dW.cpu(), db=db.cpu())
+
+    dense = run(M, None)
+    rows = torch.full((Mc,), -1, dtype=torch.int32, device="cuda")
+    L.check(lib.vmmt_compact_nonpad(P(yd), M, 1, Mc, P(rows), None, None), "compact")
+    comp = run(Mc, rows)
+    tok = y != 1
+    assert (comp["lse"][~tok] == 0).all() and (comp["nll"][~tok] == 0).all() and (comp["dO"][~tok] == 0).all()
+    assert (dense["dO"][~tok] == 0).all()
+    assert (comp["lse"][tok] - dense["lse"][tok]).abs().max().item() <= 1e-4 * dense["lse"].abs().max().item()
+    assert (comp["nll"][tok] - dense["nll"][tok]).abs().max().item() <= 2e-4 * dense["nll"].abs().max().item()
+    assert abs(comp["st"][L.STAT_NLL].item() - dense["st"][L.STAT_NLL].item()) <= 1e-5 * abs(dense["st"][L.STAT_NLL].item())
+    assert comp["st"][L.STAT_NWORDS].item() == dense["st"][L.STAT_NWORDS].item() == n
+    assert abs(comp["st"][L.STAT_NCORRECT].item() - dense["st"][L.STAT_NCORRECT].item()) <= 1
+    assert (comp["dO"] - dense["dO"]).abs().max().item() <= 2e-3 * dense["dO"].abs().max().item()
+    assert (comp["dW"] - dense["dW"]).norm().item() <= 2e-3 * dense["dW"].norm().item()
+    assert (comp["db"] - dense["db"]).abs().max().item() <= 2e-3 * max(1e-6, dense["db"].abs().max().item())

@@ -44,7 +44,7 @@ def run(e, n):
 
 def run_(e, n):
     for i in range(n):
-        src, sl, tgt, idx, _tl = bs[i % 4]
+        src, sl, tgt, idx, _tl, _ntok = bs[i % 4]
         ws = e.forward(src, sl, tgt, idx, training=True, tgt_len=TLEN if COND else None)
         e.loss_backward(ws, normalization=BATCH, batch_global=BATCH)
         e.optim_step()

@@ -49,10 +49,10 @@ if lib.vmmt_gen_fused_applies(L.BF16, H, H, M, V, H):
     Pw = torch.zeros(M, ldp, device="cuda", dtype=T); cs_ = torch.zeros(16, (M + 127) // 128 * 128, device="cuda")
     Os_ = torch.zeros(16, Mk, H, device="cuda", dtype=T)
     def f1():
-        L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(W), H, Vp, P(bias), P(O), H, P(y), M, V, H, P(ws), P(tl), P(Pw) if with_p else None, ldp, None), "fwd dO")
+        L.check(lib.vmmt_gen_fwd_dO(L.BF16, P(W), H, Vp, P(bias), P(O), H, P(y), M, V, H, P(ws), P(tl), P(Pw) if with_p else None, ldp, None, None), "fwd dO")
         if "nocombine" not in sys.argv:
             L.check(lib.vmmt_gen_fwd_combine(L.BF16, P(W), H, P(O), H, P(y), M, V, H, 1, 1.0 / 256, P(ws), P(tl), P(lse), P(nll), P(y32),
-                                             P(dO), H, P(st), P(cs_), P(Os_), H, Mk * H, None), "combine")
+                                             P(dO), H, P(st), P(cs_), P(Os_), H, Mk * H, None, None), "combine")
     for _ in range(3): f1()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()

@@ -20,7 +20,7 @@ bs = bench.make_batches(d, B, cf["S"], cf["T"], cf["n_img"], 4, "cuda", 1)
 
 
 def step(i):
-    src, sl, tgt, idx, _tl = bs[i % 4]
+    src, sl, tgt, idx, _tl, _ntok = bs[i % 4]
     ws = eng.forward(src, sl, tgt, idx, training=True)
     eng.loss_backward(ws, normalization=B, batch_global=B)
     eng.optim_step()

@@ -10,7 +10,7 @@ eng.set_image_table(torch.rand(29000, d.img))
 eng.use_side_stream = os.environ.get("SIDE", "1") == "1"
 bs = bench.make_batches(d, 256, 20, 21, 29000, 4, "cuda", 1)
 def step(i):
-    src, sl, tgt, idx, _tl = bs[i % 4]
+    src, sl, tgt, idx, _tl, _ntok = bs[i % 4]
     ws = eng.forward(src, sl, tgt, idx, training=True)
     eng.loss_backward(ws, normalization=256, batch_global=256)
     eng.optim_step()

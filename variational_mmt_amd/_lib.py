@@ -90,10 +90,11 @@ _SIGS = {
     "vmmt_gen_loss_bwd_db": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, f32, vp, i64, vp, i32, vp]),
     "vmmt_gen_fused_applies": (i32, [i32, i64, i64, i32, i32, i32]),
     "vmmt_gen_fused_ws_floats": (i64, [i32, i32, i32]),
-    "vmmt_gen_fwd_dO": (i32, [i32, vp, i64, i32, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, i64, vp]),
-    "vmmt_gen_fwd_combine": (i32, [i32, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp]),
+    "vmmt_gen_fwd_dO": (i32, [i32, vp, i64, i32, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, i64, vp, vp]),
+    "vmmt_gen_fwd_combine": (i32, [i32, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp]),
+    "vmmt_compact_nonpad": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "vmmt_gen_fused_geometry": (i32, [i32, i32, i32, vp, vp, vp]),
-    "vmmt_gen_dW_finish": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, f32, vp, i64, vp, i32, vp]),
+    "vmmt_gen_dW_finish": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, f32, vp, i64, vp, i32, vp, vp]),
     "vmmt_gemm_colsum_applies": (i32, [C.POINTER(GemmArgs)]),
     "vmmt_gather_rows": (i32, [i32, vp, i64, vp, vp, i64, i32, i32, vp]),
     "vmmt_scatter_add_rows": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),

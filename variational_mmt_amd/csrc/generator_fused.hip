@@ -67,6 +67,7 @@ struct Gen2Args {
   float* p_acc; float* p_ref; float* p_l; float* p_max; long mpad;      // partials [nsplit][mpad]([D])
   float* tgt_logit;                        // logit of the target [M]
   bf16_t* p_out; long ldp;                 // optional: the un-normalised softmax weights P[m][v] = exp(logit - ref), bf16 [M][ldp]
+  const int* rows;                         // optional row map: token m of this launch is row rows[m] of X and y (< 0: no token, a pad)
 };
 
 template <int D> struct G2 {
@@ -169,7 +170,9 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   const int split = j / nblk, rt = j - split * nblk;
   const int R0 = rt * 128 + wave * 32;                      // this wave's 32 rows
   const int row = R0 + r31;
-  const int rowc = row < a.nrows ? row : a.nrows - 1;
+  const int rowi = row < a.nrows ? row : a.nrows - 1;
+  const int rmap = a.rows ? a.rows[rowi] : rowi;            // (compacted tokens: the row of O / y this launch's token comes from)
+  const int rowc = rmap < 0 ? 0 : rmap;
   const int ntall = (a.ncols + C::BC - 1) / C::BC;
   const int t0 = split * a.tiles_per_split, t1 = min(ntall, t0 + a.tiles_per_split);
 
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   // role state
   float ref = -INFINITY, nrl = 0.f, lsum = 0.f, rmax = -INFINITY;       // F
   int ym = -1;
-  ym = row < a.nrows ? (int)a.y[row] : -1;
+  ym = (row < a.nrows && rmap >= 0) ? (int)a.y[rowc] : -1;
   // (no instruction: makes the compiler wait for these two loads HERE.  First used inside the tile loop, they get their
   //  s_waitcnt vmcnt(0) there -- in every iteration, in front of the element-wise phase, where it waits out the DMA of the next tile)
   asm volatile("" : "+v"(ym));
@@ -528,7 +531,9 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
   const int split = j / nblk, rt = j - split * nblk;
   const int R0 = rt * 64 + tg * 32;                         // this wave pair's 32 rows
   const int row = R0 + r31;
-  const int rowc = row < a.nrows ? row : a.nrows - 1;
+  const int rowi = row < a.nrows ? row : a.nrows - 1;
+  const int rmap = a.rows ? a.rows[rowi] : rowi;            // (compacted tokens: the row of O / y this launch's token comes from)
+  const int rowc = rmap < 0 ? 0 : rmap;
   const int ntall = (a.ncols + C::BC - 1) / C::BC;
   const int t0 = split * a.tiles_per_split, t1 = min(ntall, t0 + a.tiles_per_split);
 
@@ -587,7 +592,7 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
   const float bsel = dh == 0 ? 1.f : 0.f;                   // the column constants enter through ONE of the two partial sums
 
   float ref = -INFINITY, nrl = 0.f, lsum = 0.f, rmax = -INFINITY;
-  int ym = row < a.nrows ? (int)a.y[row] : -1;
+  int ym = (row < a.nrows && rmap >= 0) ? (int)a.y[rowc] : -1;
   asm volatile("" : "+v"(ym));
 
   // (a wave none of whose 16 stored rows exists issues no store: it must not leave a DMA piece in flight instead)
@@ -778,8 +783,12 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
                                                            float* __restrict__ lse, float* __restrict__ tok_nll,
                                                            int* __restrict__ y32, float* __restrict__ dO, long lddo, float* __restrict__ blk_part,
                                                            const bf16_t* __restrict__ O, long ldo, float* __restrict__ cs,
-                                                           bf16_t* __restrict__ Os, long ldos, long os_stride) {
+                                                           bf16_t* __restrict__ Os, long ldos, long os_stride,
+                                                           const int* __restrict__ rows) {
+  // rows != NULL: the launch's tokens are a compacted list -- token m is row rows[m] of O, y, lse, tok_nll and dO (< 0: no token: treated
+  // as a pad); P, y32, c_s, O'_s, the partials and tgt_logit are indexed by m
   constexpr int MAXS = 16;
+  __shared__ int s_row[8];
   __shared__ float s_w[8][MAXS];
   __shared__ float s_c[8][MAXS];
   __shared__ float s_invl[8], s_sc[8];
@@ -806,7 +815,8 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
     float nll = 0.f, nw = 0.f, nc = 0.f;
     if (m < M) {
       const float ls = rstar + logf(l);
-      const long long ym = y[m];
+      const int rmap = rows ? rows[m] : m;
+      const long long ym = rmap >= 0 ? y[rmap] : (long long)pad;
       const bool wv = ym != pad;
       const float sc = wv ? inv_norm : 0.f;
       // slice s stored its softmax weights in units of exp(ref_s): dL/dlogit[m][v] = P[m][v] c_s[m] - [v == y_m] s_m
@@ -815,19 +825,18 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
       if (cs && sl < nsplit) cs[(long)sl * mpad + m] = c;
       if (sl == 0) {
         const float tl = tgt_logit[m];
-        lse[m] = ls;
         nll = wv ? ls - tl : 0.f;
-        tok_nll[m] = nll;
+        if (rmap >= 0) { lse[rmap] = ls; tok_nll[rmap] = nll; }
         nw = wv ? 1.f : 0.f;
         nc = (wv && tl >= mx) ? 1.f : 0.f;                  // accuracy: the target's logit is the row maximum (Loss.py:150-160)
         y32[m] = wv ? (int)ym : -1;
-        s_invl[tk] = 1.f / l; s_sc[tk] = sc; s_y[tk] = (int)ym;
+        s_invl[tk] = 1.f / l; s_sc[tk] = sc; s_y[tk] = (int)ym; s_row[tk] = rmap;
       }
     } else {
       s_w[tk][sl] = 0.f; s_c[tk][sl] = 0.f;
       if (sl == 0) {
         if (m < ((M + 31) / 32) * 32) y32[m] = -1;
-        s_sc[tk] = 0.f; s_invl[tk] = 0.f; s_y[tk] = 0;
+        s_sc[tk] = 0.f; s_invl[tk] = 0.f; s_y[tk] = 0; s_row[tk] = -1;
       }
     }
     nll_t += nll; nw_t += nw; nc_t += nc;
@@ -836,6 +845,7 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
   const int tk = tid >> 5, j = tid & 31, m = m0 + tk;
   if (m < M) {
   const float invl = s_invl[tk], sc = s_sc[tk];
+  const int srow = s_row[tk];                              // (< 0: no token behind this slot -- nothing to store, O'_s = 0)
   const bf16_t* wr = W + (long)s_y[tk] * ldw;
 #pragma unroll
   for (int c = 0; c < D / 128; ++c) {
@@ -861,9 +871,9 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
                          __uint_as_float(wb.y & 0xffff0000u)};
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = sc * (v[e] * invl - w4[e]);
-    *reinterpret_cast<f32x4*>(dO + (long)m * lddo + h) = v;
+    if (srow >= 0) *reinterpret_cast<f32x4*>(dO + (long)srow * lddo + h) = v;
     if (Os) {                                               // O'_s[m] = c_s[m] O[m] (bf16): the B operand of dWg = P_s^T O'_s
-      const uint2 ob = *reinterpret_cast<const uint2*>(O + (long)m * ldo + h);
+      const uint2 ob = *reinterpret_cast<const uint2*>(O + (long)(srow < 0 ? 0 : srow) * ldo + h);
       const float o4[4] = {__uint_as_float(ob.x << 16), __uint_as_float(ob.x & 0xffff0000u), __uint_as_float(ob.y << 16),
                            __uint_as_float(ob.y & 0xffff0000u)};
       for (int s = 0; s < nsplit; ++s) {
@@ -951,15 +961,44 @@ __global__ void __launch_bounds__(256) gen2_db_kernel(const bf16_t* __restrict__
 // the one-hot term of dL/dlogit: dWg[y_m] -= s_m O[m], db[y_m] -= s_m  (one wave per token; after the dWg GEMMs have stored)
 template <int D>
 __global__ void __launch_bounds__(256) gen2_onehot_kernel(const bf16_t* __restrict__ O, long ldo, const int* __restrict__ y32, float inv_norm,
-                                                          int M, float* __restrict__ dW, long lddw, float* __restrict__ db) {
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (m >= M) return;
-  const int ym = y32[m];
+                                                          int M, float* __restrict__ dW, long lddw, float* __restrict__ db,
+                                                          const int* __restrict__ rows) {
+  const int mc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (mc >= M) return;
+  const int ym = y32[mc];
   if (ym < 0) return;
+  const int m = rows ? rows[mc] : mc;                      // (y32 >= 0 only where a token stands behind the slot)
   float* dst = dW + (long)ym * lddw;
   const int hend = lddw < D ? (int)lddw : D;      // rows of dW narrower than the tiled width (H = 500 in 512): O's padding is not part of the row
   for (int h = lane; h < hend; h += 64) atomicAdd(dst + h, -inv_norm * bf2f(O[(long)m * ldo + h]));
   if (lane == 0) atomicAdd(db + ym, -inv_norm);
+}
+
+// Order-preserving list of the decoder rows that carry a target (y != pad): rows[j] = the j-th such row for j < n, -1 for n <= j < Mc
+// (Mc = n rounded up by the caller; ONE workgroup: a deterministic scan, so that the token order -- and with it the order of the f32 sums
+// over tokens in the dWg product -- is the same in every run).  The generator's kernels then run over Mc compacted tokens instead of all
+// T' B rows: pads cost loss weight zero in the reference and FLOPs in a dense sweep (26 % of the rows at lengths U[10, 20]).
+__global__ void __launch_bounds__(1024) compact_nonpad_kernel(const long long* __restrict__ y, int M, int pad, int Mc, int* __restrict__ rows,
+                                                              int* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (M + 1023) / 1024, lo = tid * per, hi = min(M, lo + per);
+  int n = 0;
+  for (int i = lo; i < hi; ++i) n += y[i] != pad ? 1 : 0;
+  int incl = n;                                             // inclusive scan inside the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  if (tid == 0) { int a = 0; for (int w = 0; w < 16; ++w) { const int t = wsum[w]; wsum[w] = a; a += t; } total = a; }
+  __syncthreads();
+  int pos = wsum[wave] + incl - n;
+  for (int i = lo; i < hi; ++i)
+    if (y[i] != pad) { if (pos < Mc) rows[pos] = i; ++pos; }
+  const int nt = total;
+  for (int j = nt + tid; j < Mc; j += 1024) rows[j] = -1;
+  if (tid == 0 && count) *count = nt;
 }
 
 // vocabulary slices of the forward sweep: about 256 workgroups in all, whole groups of 8 tiles (256 rows) per slice so that
@@ -1024,6 +1063,12 @@ extern "C" int vmmt_g2_probe_read(unsigned long long* out) {
 }
 #endif
 
+extern "C" int vmmt_compact_nonpad(const int64_t* y, int M, int pad, int Mc, int32_t* rows, int32_t* count, void* stream) {
+  if (!y || !rows || M <= 0 || Mc <= 0) return VMMT_EINVAL;
+  hipLaunchKernelGGL(vmmt::compact_nonpad_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long long*)y, M, pad, Mc, rows, count);
+  return vmmt::check_launch();
+}
+
 extern "C" int vmmt_gen_fused_applies(int dtype, int64_t ldw, int64_t ldo, int M, int V, int K) {
   return vmmt::g2_applies(dtype, nullptr, ldw, nullptr, ldo, M, V, K) ? 1 : 0;
 }
@@ -1045,7 +1090,8 @@ extern "C" int vmmt_gen_fused_geometry(int M, int V, int K, int* nsplit, int* v_
 // the sweep: partial softmax statistics + un-normalised dO per (128-token block, vocabulary slice) into `ws`, target logits, and
 // (Pw != NULL) the softmax weights P
 extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows, const float* bias, const void* O, int64_t ldo,
-                               const int64_t* y, int M, int V, int K, float* ws, float* tgt_logit, void* Pw, int64_t ldp, void* stream) {
+                               const int64_t* y, int M, int V, int K, float* ws, float* tgt_logit, void* Pw, int64_t ldp,
+                               const int32_t* rows, void* stream) {
   using namespace vmmt;
   if (!W || !bias || !O || !y || !ws || !tgt_logit) return VMMT_EINVAL;
   if (w_rows < (V + 31) / 32 * 32 + 32) return VMMT_EINVAL;          // the sweep prefetches one 32-row tile beyond the last one (unclamped)
@@ -1062,6 +1108,7 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows
   a.p_acc = ws; a.p_ref = ws + (long)ns * mpad * K; a.p_l = a.p_ref + (long)ns * mpad; a.p_max = a.p_l + (long)ns * mpad;
   a.tgt_logit = tgt_logit;
   a.p_out = (bf16_t*)Pw; a.ldp = ldp;
+  a.rows = rows;
   hipStream_t st = (hipStream_t)stream;
   if (K == 1024) return Pw ? g2w_launch<true>(a, (M + 63) / 64 * ns, st) : g2w_launch<false>(a, (M + 63) / 64 * ns, st);
   if (Pw) return K == 512 ? g2_launch<512, true>(a, nmt * ns, st) : g2_launch<256, true>(a, nmt * ns, st);
@@ -1072,7 +1119,7 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows
 extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
                                     int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
                                     float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride,
-                                    void* stream) {
+                                    const int32_t* rows, void* stream) {
   using namespace vmmt;
   if (!W || !O || !y || !ws || !tgt_logit || !lse || !tok_nll || !y32 || !dO || !stats || lddo < K || (lddo & 3) || (((uintptr_t)dO) & 15))
     return VMMT_EINVAL;
@@ -1092,15 +1139,15 @@ extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const
   if (K == 1024)
     hipLaunchKernelGGL((gen2_combine_kernel<1024>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
                        (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
-                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride);
+                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride, rows);
   else if (K == 512)
     hipLaunchKernelGGL((gen2_combine_kernel<512>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
                        (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
-                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride);
+                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride, rows);
   else
     hipLaunchKernelGGL((gen2_combine_kernel<256>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
                        (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
-                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride);
+                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride, rows);
   hipLaunchKernelGGL(gen2_stats_kernel, dim3(1), dim3(256), 0, st, blk_part, ncb * 2, stats);
   return check_launch();
 }
@@ -1111,7 +1158,7 @@ extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const
 // colsum_out = dbias: no second pass over P); only the one-hot term is left
 extern "C" int vmmt_gen_dW_finish(int dtype, const void* Pw, int64_t ldp, const float* cs, const void* O, int64_t ldo, const int* y32,
                                   int M, int V, int K, float inv_norm, float* dW, int64_t lddw, float* dbias, int colsum_done,
-                                  void* stream) {
+                                  const int32_t* rows, void* stream) {
   using namespace vmmt;
   if (dtype != VMMT_BF16 || !Pw || !cs || !O || !y32 || !dW || !dbias || M <= 0 || V <= 0 || (K != 1024 && K != 512 && K != 256) || (ldp & 7) ||
       (((uintptr_t)Pw) & 15) || lddw <= 0)
@@ -1123,13 +1170,13 @@ extern "C" int vmmt_gen_dW_finish(int dtype, const void* Pw, int64_t ldp, const 
                        g2_tiles_per_split(M, V, K) * 32, M, V, dbias);
   if (K == 1024)
     hipLaunchKernelGGL((gen2_onehot_kernel<1024>), dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)O, (long)ldo, y32, inv_norm, M, dW,
-                       (long)lddw, dbias);
+                       (long)lddw, dbias, rows);
   else if (K == 512)
     hipLaunchKernelGGL((gen2_onehot_kernel<512>), dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)O, (long)ldo, y32, inv_norm, M, dW,
-                       (long)lddw, dbias);
+                       (long)lddw, dbias, rows);
   else
     hipLaunchKernelGGL((gen2_onehot_kernel<256>), dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)O, (long)ldo, y32, inv_norm, M, dW,
-                       (long)lddw, dbias);
+                       (long)lddw, dbias, rows);
   return check_launch();
 }
 

@@ -228,11 +228,16 @@ class BackwardPlan(object):
             fused_db = e._gemm(P, L.GEMM_TN, self.gen_P.data_ptr(), self.gen_ldp, self.gen_Os.data_ptr(), Kp, e.gp("generator.0.weight"), H,
                                V, H, M, out_f32=1, b_batch_rows=self.gen_vps, b_batch_stride=self.gen_Os.shape[1] * Kp,
                                colsum=(self.gen_cs.data_ptr(), self.gen_mpad, e.gp("generator.0.bias")) if e.gen_db_in_gemm else None)
+            self._dwg_gemm = P[-1][3]           # its GemmArgs: reduction length / slice geometry follow the step's token count (set_token_count)
+            self._dwg_K0 = self._dwg_gemm.K
+            self._bwd_tokens = M
             Og = self.O if (training_dropout and d.dropout > 0) else self.AH
             self._patch["gen"] = (len(P), 10)
             # (bias gradient + one-hot term at the END of the side stream or of the aux stream instead: 1.988 / 1.967 against 1.931-1.934 ms)
+            self._finish_entry = len(P)
             e._call(P, lib.vmmt_gen_dW_finish, dt, self.gen_P.data_ptr(), self.gen_ldp, self.gen_cs.data_ptr(), Og.p(), Og.ld,
-                    self.gen_y32.data_ptr(), M, V, Kp, inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"), 1 if fused_db else 0)
+                    self.gen_y32.data_ptr(), M, V, Kp, inv_norm, e.gp("generator.0.weight"), H, e.gp("generator.0.bias"), 1 if fused_db else 0,
+                    None)
         if self.gen_fused:
             # right away: issued later (on the aux stream behind the image / q(z|x) backward, i.e. underneath the LSTM backward chains) the
             # GEMM competes with the persistent LSTM kernels for CUs -- 2.20 against 2.11-2.13 ms per step (tools/ab.py, arms on shared streams)

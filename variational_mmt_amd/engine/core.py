@@ -83,6 +83,8 @@ class Engine(StepAPI):
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
         self.use_side_stream = True
+        # the generator's calls over the decoder rows that carry a target only (pads compacted away) when forward() knows their number
+        self.gen_compact = _os_env.get("VMMT_GEN_COMPACT", "1") == "1"
         self._masked_streams = []
         import os as _os
         self.q_parallel = _os.environ.get("VMMT_QPAR", "1") == "1"    # q(z|x): scale branch on the side stream next to the location branch

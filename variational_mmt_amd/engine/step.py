@@ -20,7 +20,7 @@ class StepAPI(object):
     def stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
-    def forward(self, src, src_len, tgt, img_indices, training=True, eps=None, masks=None, table=None, tgt_len=None):
+    def forward(self, src, src_len, tgt, img_indices, training=True, eps=None, masks=None, table=None, tgt_len=None, n_tgt_tokens=None):
         """NMTVIModel.forward (Models.py:850-1011).  src [S,B] int64, src_len [B], tgt [T,B] (incl. <s>, </s>),
         img_indices [B] rows of the resident image table.  Returns the Workspace holding every activation."""
         S, B = int(src.shape[0]), int(src.shape[1])
@@ -81,6 +81,12 @@ class StepAPI(object):
                     ws.plan_fwd_train[ii] = (fn, (args[0], args[1], 0, args[3], self.rng_counter), name, keep, sid)
                 else:
                     ws.plan_fwd_train[ii] = (fn, (args[0], args[1], buf.rows * buf.ld, args[3], self.rng_counter), name, keep, sid)
+        if training and ws.gen_fused:
+            # decoder rows that carry a target: told by the caller (a loader knows it) or counted here when the ids are still on the host
+            n_tok = n_tgt_tokens
+            if n_tok is None and self.gen_compact and torch.is_tensor(tgt) and not tgt.is_cuda:
+                n_tok = int((tgt[1:] != PAD).sum())
+            ws.set_token_count(n_tok)
         plan = ws.plan_fwd_train if training else ws.plan_fwd_eval
         ii = ws._img_idx[bool(training)]
         fn, args, name, keep, sid = plan[ii]

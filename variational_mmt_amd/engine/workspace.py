@@ -104,8 +104,32 @@ class Workspace(BackwardPlan, ConditionalPlans):
             self.gen_P = eng.shared_storage("gen_P", Mk * self.gen_ldp, T)
             self.gen_cs = torch.zeros(self.gen_ns * self.gen_mpad, dtype=f32, device=dev)
             self.gen_Os = torch.zeros(self.gen_ns, Mk, _ru(H, KPAD), dtype=T, device=dev)
+            # COMPACTED tokens (Engine.gen_compact; vmmt_compact_nonpad): when the forward is told how many decoder rows carry a target, the
+            # generator's calls run over that many tokens (rounded up to 128) instead of all T' B rows.  The vocabulary slices follow the
+            # token count (fewer token blocks -> more slices), so the per-slice buffers are sized for the worst count
+            self.gen_rows = torch.full((M + 256,), -1, dtype=torch.int32, device=dev)
+            self.gen_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.gen_geo = {}
+            Kp = _ru(H, KPAD)
+            need_cs, need_os, need_ws = self.gen_ns * self.gen_mpad, self.gen_ns * Mk * Kp, nws
+            if eng.gen_compact:
+                for Mc in range(1024, M, 128):
+                    L.check(eng.lib.vmmt_gen_fused_geometry(Mc, V, Kp, C.byref(ns), C.byref(vps), C.byref(mpad)), "vmmt_gen_fused_geometry")
+                    self.gen_geo[Mc] = (ns.value, vps.value, mpad.value)
+                    need_cs = max(need_cs, ns.value * mpad.value)
+                    need_os = max(need_os, ns.value * (Mc + KPAD) * Kp)
+                    need_ws = max(need_ws, int(eng.lib.vmmt_gen_fused_ws_floats(Mc, V, Kp)))
+                if need_ws > nws:
+                    self.gen_ws = eng.shared_storage("gen_ws", need_ws, f32)
+                if need_cs > self.gen_cs.numel():
+                    self.gen_cs = torch.zeros(need_cs, dtype=f32, device=dev)
+                if need_os > self.gen_Os.numel():
+                    self.gen_Os_flat = torch.zeros(need_os, dtype=T, device=dev)
+                    self.gen_Os = self.gen_Os_flat[:self.gen_ns * Mk * Kp].view(self.gen_ns, Mk, Kp)
+            self.gen_Mc = M                   # token count of the current step's generator calls (M: not compacted)
         else:
             self.GT = Buf(V, M, T, dev, storage=eng.shared_storage("GT", Buf.elems(V, M), T))
+        self.gen_Mc = getattr(self, "gen_Mc", M)
         self.dPre = nb(M, H)
         self.dcat = nb(M, 2 * Hp)
         self.dQ = nb(M, H)
@@ -166,9 +190,13 @@ class Workspace(BackwardPlan, ConditionalPlans):
                 g_ranges = [r for r in g_ranges if r.numel()]
             else:
                 g_ranges = [e.flat_g[e.offsets["generator.0.bias"][0]:]]
+            compact = bool(self.gen_fused and e.gen_compact)       # (rows of dO / lse / tok_nll without a token are not written then)
             e._zero(P, g_ranges + [e._sumsq[:L.SUMSQ_SLOTS], self.dh1v32.t, self.dzt.t] +
-                    ([] if self.gen_fused else [self.dO32.t]) +       # (fused generator: dO is stored, not accumulated)
+                    ([self.dO32.t, self.lse, self.tok_nll] if compact else [] if self.gen_fused else [self.dO32.t]) +       # (fused generator: dO is stored, not accumulated)
                     [b.t for l in range(Lyr) for b in (self.dec_dcc[l], self.enc_dcc[l])])
+            if compact:
+                self._compact_entry = len(P)
+                e._call(P, lib.vmmt_compact_nonpad, self.y.data_ptr(), M, PAD, M, self.gen_rows.data_ptr(), self.gen_cnt.data_ptr())
         self._mask_entries = getattr(self, "_mask_entries", {})
         if drop:
             # output dropout mask (VI_Model1.py:132): only needed after the decoder -> generated in the background
@@ -364,13 +392,14 @@ class Workspace(BackwardPlan, ConditionalPlans):
             # behind feed the dWg GEMM of the backward plan
             assert O.ld == _ru(d.hid, KPAD)
             Kp = _ru(d.hid, KPAD)
+            self._sweep_entry = len(P)           # (Workspace.set_token_count patches M / rows / strides of these two per step)
             e._call(P, lib.vmmt_gen_fwd_dO, e.dt, wg.p(), wg.ld, wg.t.shape[0], e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(), self.M, d.vt,
-                    Kp, self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.gen_P.data_ptr(), self.gen_ldp)
+                    Kp, self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.gen_P.data_ptr(), self.gen_ldp, None)
             self._loss_patch = (len(P), 10)
             e._call(P, lib.vmmt_gen_fwd_combine, e.dt, wg.p(), wg.ld, O.p(), O.ld, self.y.data_ptr(), self.M, d.vt, Kp, PAD, 0.0,
                     self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.lse.data_ptr(), self.tok_nll.data_ptr(),
                     self.gen_y32.data_ptr(), self.dO32.p(), self.dO32.ld, self.stats.data_ptr(), self.gen_cs.data_ptr(),
-                    self.gen_Os.data_ptr(), self.gen_Os.shape[2], self.gen_Os.shape[1] * self.gen_Os.shape[2])
+                    self.gen_Os.data_ptr(), self.gen_Os.shape[2], self.gen_Os.shape[1] * self.gen_Os.shape[2], None)
             return P
         e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(),
                 self.M, d.vt, _ru(d.hid, KPAD), PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), None,
@@ -397,6 +426,43 @@ class Workspace(BackwardPlan, ConditionalPlans):
                 float(kl_mult), 1 if use_freebits else 0, float(margin), float(inv_norm), dzp, epp, self.q_dmu.p(), self.q_dmu.ld,
                 self.q_dpre.p(), self.q_dpre.ld, self.B, self.e.d.z)
 
+    def set_token_count(self, n):
+        """the generator's calls of THIS step run over the n decoder rows that carry a target (rounded up to 128; n = None or too close to
+        T' B: all rows, as the reference does).  Patches the launch plans: token count, row map, the vocabulary-slice geometry that
+        follows the count"""
+        e, M = self.e, self.M
+        Mc = M if n is None else min(M, _ru(max(int(n), 1), 128))
+        if not (self.gen_fused and e.gen_compact) or Mc not in self.gen_geo:
+            Mc = M
+        if Mc == M:
+            geo, rows, os_stride = (self.gen_ns, self.gen_vps, self.gen_mpad), None, self.gen_Os.shape[1] * self.gen_Os.shape[2]
+        else:
+            geo, rows, os_stride = self.gen_geo[Mc], self.gen_rows.data_ptr(), (Mc + KPAD) * self.gen_Os.shape[2]
+        self.gen_Mc, self.gen_cur = Mc, (geo, rows, os_stride)
+        if getattr(self, "_compact_entry", None) is not None:
+            fn, a, name, keep, sid = self.plan_fwd_train[self._compact_entry]
+            self.plan_fwd_train[self._compact_entry] = (fn, a[:3] + (Mc,) + a[4:], name, keep, sid)
+        P = self.plan_loss_train
+        ii = self._sweep_entry
+        fn, a, name, keep, sid = P[ii]
+        P[ii] = (fn, a[:8] + (Mc,) + a[9:15] + (rows,), name, keep, sid)
+        fn, a, name, keep, sid = P[ii + 1]
+        P[ii + 1] = (fn, a[:6] + (Mc,) + a[7:22] + (os_stride, rows), name, keep, sid)
+        self._bwd_tokens = None               # the backward plan follows in backward_plan()
+
+    def _patch_bwd_tokens(self):
+        if self._bwd_tokens == self.gen_Mc or not self.gen_fused or not hasattr(self, "_dwg_gemm"):
+            return
+        (ns, vps, mpad), rows, os_stride = self.gen_cur
+        a = self._dwg_gemm
+        a.K, a.b_batch_rows, a.b_batch_stride = (self._dwg_K0 if self.gen_Mc == self.M else self.gen_Mc), vps, os_stride
+        if a.colsum_w:
+            a.colsum_w_stride = mpad
+        P = self.plan_bwd
+        fn, args, name, keep, sid = P[self._finish_entry]
+        P[self._finish_entry] = (fn, args[:7] + (self.gen_Mc,) + args[8:15] + (rows,), name, keep, sid)
+        self._bwd_tokens = self.gen_Mc
+
     def backward_plan(self, inv_norm, batch_global, kl_mult, use_freebits, margin, drop):
         key = (bool(drop), bool(self.e.reparam_grad))      # the only STRUCTURAL inputs; every scalar is patched below
         if self._bwd_key != key:
@@ -408,6 +474,8 @@ class Workspace(BackwardPlan, ConditionalPlans):
         for ii, pos in self._patch.values():
             fn, args, name, keep, sid = P[ii]
             P[ii] = (fn, args[:pos] + (float(inv_norm),) + args[pos + 1:], name, keep, sid)
+        if self.gen_fused and getattr(self, "_bwd_tokens", 0) != self.gen_Mc:
+            self._patch_bwd_tokens()
         return P
 
     def ones_col(self):

@@ -84,7 +84,7 @@ class NMTVIModel(nn.Module):
                 self._tables[k] = torch.as_tensor(v).to(device=self.engine.dev, dtype=torch.float32).contiguous()
 
     def forward(self, src, tgt, lengths, tgt_lengths, img_feats, img_vecs=None, dec_state=None, padding_token=None,
-                img_indices=None, img_table=None, eps=None, masks=None):
+                img_indices=None, img_table=None, eps=None, masks=None, n_tgt_tokens=None):
         """Same positional contract as the reference (Models.py:850).  `img_feats` may be a [B, D] tensor (reference
         behaviour) or None when `img_indices` + `img_table` select rows of an HBM-resident table."""
         if src.dim() == 3:
@@ -99,7 +99,7 @@ class NMTVIModel(nn.Module):
         else:
             table = img_table
         ws = e.forward(src, lengths, tgt, img_indices, training=self.training, eps=eps, masks=masks, table=table,
-                       tgt_len=tgt_lengths if self.conditional else None)
+                       tgt_len=tgt_lengths if self.conditional else None, n_tgt_tokens=n_tgt_tokens)
         S, Tp, H = src.shape[0], tgt.shape[0] - 1, self.dims.hid
         ob = ws.O if (self.training and self.dims.dropout > 0) else ws.AH
         out = ob.t.as_strided((Tp, B, H), (B * ob.ld, ob.ld, 1))

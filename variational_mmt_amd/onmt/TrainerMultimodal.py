@@ -307,7 +307,8 @@ class TrainerMultimodal(object):
                 # a per-rank loader: ONE blocking all-reduce for both figures (slow path, kept for compatibility)
                 self.train_loss.batch_global, norm = self.dp.global_sizes(batch.batch_size, normalization)
             outputs, attns, _ = self.model(src, tgt, src_lengths, tgt_lengths, None, img_indices=batch.indices,
-                                           img_table=self.model._tables["train"], padding_token=self.train_loss.padding_idx)
+                                           img_table=self.model._tables["train"], padding_token=self.train_loss.padding_idx,
+                                           n_tgt_tokens=getattr(batch, "n_tgt_tokens", None))
             batch_stats = self.train_loss.sharded_compute_loss(batch, outputs, attns, 0, tgt.shape[0], self.shard_size, norm)
             self.model_updates += 1
             self.dp.all_reduce()

@@ -345,6 +345,8 @@ class Batch(object):
             if tail:
                 arr[raw + head, np.arange(B)] = stoi[f.eos_token]
             lens = raw + head + tail
+            if name == "tgt":       # decoder rows that carry a target (every position but <s>): the engine's generator runs over these only
+                self.n_tgt_tokens = int(lens.sum()) - B
             parts.append((name, arr, lens if f.include_lengths else None))
             total += arr.size + (B if f.include_lengths else 0)
         on_gpu = device is not None and device != -1 and torch.device(device if not isinstance(device, int) else "cuda:%d" % device).type == "cuda"
