@@ -559,6 +559,18 @@ class Engine(StepAPI):
         ts = (main, side, aux, tgt)
         hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream, tgt.cuda_stream)
         trace, last = self.trace, None
+        if trace is None:
+            # (the host's share of a step is ~100 of these iterations: kernel launches take the short way, everything else _exec)
+            single = side is main
+            for entry in plan:
+                fn = entry[0]
+                if fn is not None:
+                    rc = fn(*entry[1], hs[entry[4]])
+                    if rc != 0:
+                        L.check(rc, entry[2])
+                else:
+                    self._exec(entry, ts, hs, events, single)
+            return
         for entry in plan:
             fn, args, name, _keep, sid = entry
             if trace is not None and sid == 0 and name != last:     # tools/phase_times.py: timing events at phase changes
