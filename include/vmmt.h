@@ -272,7 +272,8 @@ int vmmt_gen_dW_finish(int dtype, const void* P, int64_t ldp, const float* cs, c
                        int K, float inv_norm, float* dW, int64_t lddw, float* dbias, int colsum_done, const int32_t* rows, void* stream);
 /* COMPACTED tokens (rows != NULL in the three calls above): pads carry loss weight zero (Loss.py:163-165) but a dense sweep spends FLOPs on
  * them -- 26 % of the decoder rows at target lengths U[10, 20].  vmmt_compact_nonpad lists the rows with y != pad in order (rows[j], j < n;
- * -1 for n <= j < Mc; count, optional, receives n; one workgroup, deterministic).  The generator calls then take M = Mc (n rounded up, e.g.
+ * -1 for n <= j < Mc; count, optional int32[2]: [0] receives n, [1] is set to 1 -- and never cleared -- when n > Mc, i.e. when tokens were
+ * left out; one workgroup, deterministic).  The generator calls then take M = Mc (n rounded up, e.g.
  * to 128) and `rows`: token m of the launch is row rows[m] of O, y, lse, tok_nll and dO (rows not listed are NOT written: clear them
  * beforehand), while P, y32, cs, Os, tgt_logit and the workspace are indexed by m; the dWg product runs over K = Mc tokens.  Same sums as the
  * dense calls up to the order of the f32 additions over tokens. */

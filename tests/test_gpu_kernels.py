@@ -475,11 +475,16 @@ def test_compact_nonpad_lists_the_target_rows_in_order():
         n = want.numel()
         Mc = max(128, (n + 127) // 128 * 128)
         rows = torch.full((Mc + 5,), 77, dtype=torch.int32, device="cuda")
-        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
         yd = y.cuda()
         L.check(lib.vmmt_compact_nonpad(C.c_void_p(yd.data_ptr()), M, 1, Mc, C.c_void_p(rows.data_ptr()), C.c_void_p(cnt.data_ptr()), None), "compact")
         torch.cuda.synchronize()
-        assert int(cnt.item()) == n
+        assert cnt.tolist() == [n, 0]
+        if n > 128:         # a caller that promises too few tokens: the list is cut, the flag is raised (and stays)
+            short = torch.zeros(128, dtype=torch.int32, device="cuda")
+            L.check(lib.vmmt_compact_nonpad(C.c_void_p(yd.data_ptr()), M, 1, 128, C.c_void_p(short.data_ptr()), C.c_void_p(cnt.data_ptr()), None), "compact")
+            torch.cuda.synchronize()
+            assert cnt.tolist() == [n, 1] and torch.equal(short.cpu(), want[:128])
         assert torch.equal(rows[:n].cpu(), want) and (rows[n:Mc] == -1).all() and (rows[Mc:] == 77).all()
 
 

@@ -431,3 +431,25 @@ def test_minimal_and_extreme_shapes(dtype, B, S, T, brnn, layers, hid):
             continue
         got, want = e.grads[k].cpu().double(), g[k].double()
         assert (got - want).norm().item() <= tg * max(want.norm().item(), 1e-12), (k, (got - want).norm().item(), want.norm().item())
+
+
+def test_too_small_token_count_is_reported():
+    """forward(n_tgt_tokens=) smaller than the batch's number of targets: the generator drops rows -- Engine.check_async_errors() says so"""
+    from variational_mmt_amd.engine import Dims, Engine
+    c = O.Cfg(vs=300, vt=400, emb=64, hid=256, z=32, layers=1, brnn=True)
+    p = O.init_params(c, seed=1)
+    bt = O.synth_batch(c, B=128, S=12, T=13, n_img=16, seed=3, fixed_len=False)
+    e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="bf16", device="cuda")
+    e.load_state_dict(p)
+    e.set_image_table(bt["table"])
+    n = int((bt["tgt"][1:] != 1).sum())
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"].cuda(), bt["indices"], training=True, eps=bt["eps"], n_tgt_tokens=n)
+    if not (ws.gen_fused and ws.gen_Mc < ws.M):
+        pytest.skip("shape not served by the compacted generator")
+    e.loss_backward(ws, normalization=128)
+    e.check_async_errors()
+    assert n > 1024 + 16
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"].cuda(), bt["indices"], training=True, eps=bt["eps"], n_tgt_tokens=1024)
+    e.loss_backward(ws, normalization=128)
+    with pytest.raises(RuntimeError, match="n_tgt_tokens"):
+        e.check_async_errors()

@@ -998,7 +998,10 @@ __global__ void __launch_bounds__(1024) compact_nonpad_kernel(const long long* _
     if (y[i] != pad) { if (pos < Mc) rows[pos] = i; ++pos; }
   const int nt = total;
   for (int j = nt + tid; j < Mc; j += 1024) rows[j] = -1;
-  if (tid == 0 && count) *count = nt;
+  if (tid == 0 && count) {
+    count[0] = nt;
+    if (nt > Mc) count[1] = 1;          // sticky: the caller promised fewer tokens than the batch holds (its last ones were dropped)
+  }
 }
 
 // vocabulary slices of the forward sweep: about 256 workgroups in all, whole groups of 8 tiles (256 rows) per slice so that

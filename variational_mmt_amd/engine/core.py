@@ -497,6 +497,11 @@ class Engine(StepAPI):
         if bad:
             raise RuntimeError("persistent LSTM launch(es) %s reported a hand-off timeout (error words %s): results invalid; "
                                "rerun with VMMT_PERSISTENT_LSTM=0" % (bad, [self.lstm_seq_errors()[i] for i in bad]))
+        # ... or if a step was told fewer target tokens than its batch held (forward(n_tgt_tokens=)): the generator left rows out
+        short = [k for k, w in self.ws.items() if isinstance(w, Workspace) and getattr(w, "gen_cnt", None) is not None and int(w.gen_cnt[1].item())]
+        if short:
+            raise RuntimeError("forward(n_tgt_tokens=) was smaller than the number of non-pad targets in a batch of shape(s) %s: "
+                               "the loss of those steps is wrong" % short)
 
     def _zero(self, plan, tensors):
         """plan entry: clear all `tensors` (contiguous device tensors) with ONE vmmt_zero_multi launch"""

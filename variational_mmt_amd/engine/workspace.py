@@ -108,7 +108,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
             # generator's calls run over that many tokens (rounded up to 128) instead of all T' B rows.  The vocabulary slices follow the
             # token count (fewer token blocks -> more slices), so the per-slice buffers are sized for the worst count
             self.gen_rows = torch.full((M + 256,), -1, dtype=torch.int32, device=dev)
-            self.gen_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.gen_cnt = torch.zeros(2, dtype=torch.int32, device=dev)      # [token rows of the last step, sticky "rows were left out" flag]
             self.gen_geo = {}
             Kp = _ru(H, KPAD)
             need_cs, need_os, need_ws = self.gen_ns * self.gen_mpad, self.gen_ns * Mk * Kp, nws
