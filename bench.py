@@ -179,6 +179,44 @@ def cpu_baseline(seconds_budget=10.0):
                        "%.3f s, clip + Adam %.3f s" % (b["steps"], best, b["seconds"], b["fwd_s"], b["loss_bwd_s"], b["optim_s"]))
 
 
+def parity_gate(dev, dtype, dropout):
+    """the parity figures that go with every number.  ONE training step at BASELINE config 1's shape (batch 40,
+    src/tgt length 20, V = 30 000, 1-layer biLSTM 512, z 256 -- the cpu_baseline's own batch, `oracle.synth_batch(seed 7)`) on the HIP
+    path in the benchmark's arithmetic (dtype, dropout), and the same step on the CPU oracle with the sample eps and the device's own
+    dropout mask injected: |dELBO| / |ELBO|, |dKL| / |KL|, max |d per-token NLL| (reference statistics: onmt/VILoss.py:478-485).
+    The oracle is the checker here, never the thing measured."""
+    from oracle import vi1_oracle as O
+    from variational_mmt_amd.engine import Dims, Engine
+    c = O.Cfg(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=dropout)
+    p = O.init_params(c, seed=0)
+    B, S, T = 40, 20, 21
+    bt = O.synth_batch(c, B, S, T, n_img=512, seed=7)
+    e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, dropout), dtype=dtype, device=dev, seed=0)
+    e.load_state_dict(p)
+    e.set_image_table(bt["table"])
+    ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+    e.loss_backward(ws, normalization=B)
+    torch.cuda.synchronize()
+    st = e.read_stats(ws)
+    masks = {"dec_out": ws.out_mask.view().float().cpu().view(T - 1, B, c.hid)} if dropout > 0 else None
+    tok = ws.tok_nll.float().cpu().view(T - 1, B)
+    img = bt["table"][bt["indices"]]
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    with torch.no_grad():
+        r = O.forward(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], True, masks, False)
+        Lo = O.loss(p, c, r, bt["tgt"], img)
+    elbo, kl = float(Lo["elbo"]), float(Lo["kl_before"])
+    out = {"elbo_rel": abs(st["elbo"] - elbo) / abs(elbo), "kl_rel": abs(st["td_kl_before"] - kl) / abs(kl),
+           "tok_nll_max_abs": float((tok - Lo["tok_nll"]).abs().max()), "nll_rel": abs(st["nmt"] - float(Lo["nll"])) / abs(float(Lo["nll"])),
+           "elbo": round(st["elbo"], 4), "elbo_oracle": round(elbo, 4), "n_words": st["n_words"], "n_words_oracle": int(Lo["n_words"]),
+           "vs": "oracle (CPU restatement pinned to the reference), cfg-1 shape, B 40, %s, dropout %.1f with the device's mask injected" % (dtype, dropout)}
+    for k in ("elbo_rel", "kl_rel", "tok_nll_max_abs", "nll_rel"):
+        out[k] = float("%.3g" % out[k])
+    del e
+    torch.cuda.empty_cache()
+    return out
+
+
 def through_trainer(a, dev, rank, world):
     """`--through-trainer`: the drop-in surface end to end.  A synthetic dataset of 29 000 triplets (Multi30k's size; source /
     target lengths U[10, 20], word ids Zipf-distributed over 30 k-word vocabularies) is walked by onmt.io.OrderedIterator (pools of 100
@@ -305,6 +343,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (one cfg-1-shaped step against the CPU oracle)")
     ap.add_argument("--no-side-stream", action="store_true", help="profiling aid: issue the whole step on one stream")
     ap.add_argument("--conditional", action="store_true", help="the --conditional prior variant (SURVEY.md 8f-1) instead of the fixed prior")
     ap.add_argument("--n-img", type=int, default=0, help="rows of the resident image-feature table (default: the configuration's; 290000 = "
@@ -364,9 +403,10 @@ def main():
     eng = Engine(d, dtype=a.dtype, device=dev, seed=0)
     if a.no_side_stream:
         eng.use_side_stream = False
-    if os.environ.get("VMMT_BENCH_ONE_GPU") == "1" and world > 1:
+    if os.environ.get("VMMT_BENCH_ONE_GPU") == "1" and world > 1 and os.environ.get("VMMT_PERSISTENT_LSTM") is None:
         # rehearsal only: the persistent recurrence kernels need every workgroup of a launch resident at once, which two processes
-        # sharing one GPU cannot both have (the launches then run into their 2-second hand-off bound and the run fails loudly)
+        # sharing one GPU cannot both have (the launches would run into their 2-second hand-off bound, and the engine would fall
+        # back to the per-step kernels by itself after two slow steps: Engine._seq_timeout_fallback)
         eng.persistent_lstm = False
     n_img = a.n_img or cf["n_img"]
     if n_img <= 100000:
@@ -447,7 +487,22 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     st = eng.read_stats(ws, batch_global=B)
-    eng.check_async_errors()           # a persistent-kernel hand-off that timed out would have produced a fast, wrong step
+    eng.check_async_errors()           # settles a persistent-kernel hand-off that timed out (fallback + warning; reported below)
+    dp_block = None
+    if sync.active():
+        # the multi-GPU line must be auditable: which backend ran, which form of each collective, how many ranks it saw, and what every
+        # segment's collective cost -- timed over a few EXTRA steps behind the timed region (events on the step would perturb it)
+        sync.timing, sync.exposed = [], []
+        for i in range(min(10, max(3, a.steps))):
+            sync.step_event = torch.cuda.Event(enable_timing=True)
+            sync.step_event.record()
+            step(a.warmup + a.steps + i)
+        segs, exposed = sync.timing_report()
+        sync.timing = None
+        dp_block = {"backend": sync.backend, "world_seen": dist.get_world_size() if dist is not None else sync.world, "sharded_optimizer": bool(sync.sharded),
+                    "native_collectives": sync.native_collectives(), "branches": ["%s: %s (%s)" % b_ for b_ in sync.branch_log],
+                    "segments": segs, "exposed_ms": round(sum(exposed.values()), 4), "exposed_by_wait_ms": exposed,
+                    "persistent_lstm": bool(eng.persistent_lstm)}
 
     if rank == 0:
         fl = flops_per_triplet(d, S, Tp)
@@ -496,7 +551,12 @@ def main():
                          "ms_fwd": round(t_f, 4), "ms_bwd": round(t_b, 4),
                          "step_tflops": round(3 * fl["total"] * Bg / (dt / a.steps) / 1e12, 2)},
             "elbo_per_sentence": round(st["elbo"] / B, 4),
+            "seq_fallbacks": eng.seq_fallbacks, "steps_skipped": eng.steps_skipped,
         }
+        if dp_block is not None:
+            out["dp"] = dp_block
+        if world == 1 and not a.no_parity:
+            out["parity"] = parity_gate(dev, a.dtype, a.dropout)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -161,6 +161,11 @@ int vmmt_lstm_chain_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd
  * order of the f32 partial sums, <= 1 bf16 ulp), which this call falls back to when the persistent kernel does not apply (fp32, H not
  * in {64,128,256,512,1024}, more workgroups than CUs -- (B / 32) (H / 16) ndir > 256: cut the batch into row chunks --, unaligned rows, steps not
  * chained h_prev[t] == h_out[t-1] / c_prev[t] == c_out[t-1]). */
+/* words VMMT_SEQ_GUARD_WORD, +1 of `sync` (8-byte aligned): an optional device pointer to a uint32 GUARD word of the caller, written
+ * by the host once after the scratch is zeroed (0 = none).  A launch whose bounded wait runs out stores its error code there as well:
+ * vmmt_adam_step(skip = guard) then leaves the parameters of that step alone (the recurrence's outputs are garbage) until the host has
+ * seen the word, switched to the per-step kernels and cleared it. */
+#define VMMT_SEQ_GUARD_WORD (4 + 2 * 256)
 int vmmt_lstm_seq_sync_words(void);
 int64_t vmmt_lstm_seq_xchg_bytes(int ndir, int B, int H);
 int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd* dirs, const vmmt_lstm_dir_fwd* dirs_dev,
@@ -436,9 +441,12 @@ int vmmt_standardise_rows(float* X, int64_t ld, const float* mean, const float* 
 #define VMMT_SUMSQ_SCRATCH (2 * VMMT_SUMSQ_SLOTS + VMMT_SUMSQ_SLOTS * VMMT_SUMSQ_MAXBLOCKS)
 int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, void* stream);
 /* max_blocks > 0 caps the grid (grid-stride loop).  shadow_bf16 (optional): the bf16 compute copy of THIS parameter range, same
- * flat layout (a 2-D weight whose shadow rows are unpadded): written along with p, so the shadow refresh need not read p back */
+ * flat layout (a 2-D weight whose shadow rows are unpadded): written along with p, so the shadow refresh need not read p back.
+ * skip (optional): device int32[2]; skip[0] != 0 -> the launch changes NOTHING (p, m, v, shadow) and adds 1 to skip[1] -- the guard
+ * word of the persistent recurrences (VMMT_SEQ_GUARD_WORD): a step whose gradients are known to be garbage is not applied. */
 int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                   int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16, void* stream);
+                   int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16,
+                   const int32_t* skip, void* stream);
 
 /* ---- embedding tables: gradient bookkeeping by row -----------------------------------------------------------------------------
  * nn.Embedding tables (modules/Embeddings.py:118,181) receive gradient only in the rows a batch looks up, yet the dense path clears,
@@ -449,11 +457,12 @@ int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
  *   vmmt_sumsq_rows     ||g||^2 over the flagged rows into slot `slot` of the norm scratch (deterministic); rowsq f32 [R] scratch
  *   vmmt_adam_rows_step vmmt_adam_step over the WHOLE table (every row moves under Adam, with or without gradient), reading g for
  *                       flagged rows only (zero elsewhere); clears the flags.  Bit-identical to vmmt_adam_step on a gradient that
- *                       is zero outside the flagged rows.  C % 4 == 0, rows 16-byte aligned. */
+ *                       is zero outside the flagged rows.  C % 4 == 0, rows 16-byte aligned.  skip: as vmmt_adam_step (the flags are
+ *                       kept then). */
 int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, void* stream);
 int vmmt_rows_zero(float* g, int R, int C, const int32_t* flags, void* stream);
 int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, float lr, float beta1, float beta2,
-                        float eps, int step, float max_norm, const float* sumsq, float grad_scale, void* stream);
+                        float eps, int step, float max_norm, const float* sumsq, float grad_scale, const int32_t* skip, void* stream);
 int vmmt_sumsq_rows(const float* g, int R, int C, const int32_t* flags, float* rowsq, float* scratch, int slot, void* stream);
 
 #ifdef __cplusplus

@@ -434,3 +434,110 @@ def test_script_as_written_conditional(B):
         assert abs(s16[k] - s32[k]) <= 5e-3 * abs(s32[k]), (k, s16[k], s32[k])
     g32, g16 = e32.flat_g[:e32.n_opt].double(), e16.flat_g[:e16.n_opt].double()
     assert ((g16 - g32).norm() / g32.norm()).item() <= 3e-2
+
+
+def test_bench_configuration_against_the_oracle():
+    """The configuration `python bench.py` times AS IT RUNS THERE: bf16, dropout 0.5, every sentence at full
+    length 20 (so the generator's sweep is the DENSE one: gen_Mc == M, no compaction), batch 256, V 30 000 -- against the CPU oracle
+    with the device's own dropout mask and the sample eps injected: ELBO / NLL / KL at the bf16 tolerance, per-token NLL, and the
+    whole-arena gradient (relative L2) against the oracle's autograd."""
+    from variational_mmt_amd.engine import Dims, Engine
+    c = O.Cfg(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.5)
+    p = O.init_params(c, seed=0)
+    B, S, T = 256, 20, 21
+    bt = O.synth_batch(c, B=B, S=S, T=T, n_img=1000, seed=7, fixed_len=True)
+    e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.5), dtype="bf16", device="cuda:0")
+    e.load_state_dict(p)
+    e.set_image_table(bt["table"])
+    # the way bench.py calls it: ids on the device, the token count told by the "loader"
+    dev = torch.device("cuda:0")
+    n_tok = int((bt["tgt"][1:] != 1).sum())
+    assert n_tok == (T - 1) * B
+    ws = e.forward(bt["src"].to(dev), bt["src_len"].to(dev), bt["tgt"].to(dev), bt["indices"].to(dev), training=True, eps=bt["eps"],
+                   n_tgt_tokens=n_tok)
+    e.loss_backward(ws, normalization=B, batch_global=B)
+    torch.cuda.synchronize()
+    st = e.read_stats(ws)
+    # the kernels of the headline number: dense fused sweep, persistent recurrences, fused q(z|x)
+    assert ws.gen_fused and ws.gen_Mc == ws.M == (T - 1) * B and ws.fused_q
+    names = [en[2] for en in ws.plan_fwd_train]
+    assert "vmmt_lstm_seq_fwd" in names and not any(e.lstm_seq_errors())
+    mask = ws.out_mask.view().float().cpu().view(T - 1, B, c.hid)
+    keep = mask.ne(0).float().mean().item()
+    assert 0.49 < keep < 0.51 and set(mask.unique().tolist()) == {0.0, 2.0}
+    img = bt["table"][bt["indices"]]
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], masks={"dec_out": mask})
+    # ---- statistics at the bf16 tolerance (DESIGN.md section 2)
+    for k, ok in (("nmt", "nll"), ("td_kl_before", "kl_before"), ("elbo", "elbo")):
+        ref = float(Lo[ok])
+        assert abs(st[k] - ref) <= 2e-3 * abs(ref), (k, st[k], ref)
+    assert st["n_words"] == Lo["n_words"] == n_tok
+    tok = ws.tok_nll.float().cpu().view(T - 1, B)
+    d_tok = (tok - Lo["tok_nll"]).abs()
+    assert d_tok.max().item() <= 0.15 and d_tok.mean().item() <= 1e-2, (d_tok.max().item(), d_tok.mean().item())     # per-token NLL ~ 10.3 nats each
+    assert abs(float(tok.double().sum()) - st["nmt"]) <= 1e-5 * st["nmt"]
+    # ---- gradients: the whole arena against the oracle's autograd, relative L2 (the image-network class of DESIGN.md section 2 apart)
+    ill = ("inf_net_image.location.fc1", "inf_net_image.gate_affine_transform")
+    num = den = 0.0
+    worst = {}
+    for k in g:
+        if k.startswith(ill):
+            continue
+        got, ref = e.grads[k].cpu().double(), g[k].double()
+        num += float((got - ref).pow(2).sum())
+        den += float(ref.pow(2).sum())
+        worst[k] = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    assert (num / den) ** 0.5 <= 2e-2, ((num / den) ** 0.5, sorted(worst.items(), key=lambda kv: -kv[1])[:5])
+    assert max(worst.values()) <= 6e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    for k in g:
+        if k.startswith(ill):
+            got, ref = e.grads[k].cpu().double(), g[k].double()
+            assert ((got - ref).norm() / ref.norm()).item() <= 0.15, k
+
+
+def test_cfg4_table_290k():
+    """BASELINE config 4 (run_additional_data.sh:72-144: the 290 K-triplet set): a 290 000 x 2048 image table resident in HBM (2.4 GB),
+    rows drawn over the WHOLE index range with repeats inside a batch; the device gather is bit-exact, and the training step's
+    statistics and gradients equal those of the same step on a compacted table that holds only the batch's rows."""
+    from variational_mmt_amd.engine import Dims, Engine
+    c = O.Cfg(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True)
+    p = O.init_params(c, seed=0)
+    B, N = 256, 290000
+    bt = O.synth_batch(c, B=B, S=20, T=21, n_img=1000, seed=9, fixed_len=False)
+    dev = torch.device("cuda:0")
+    gd = torch.Generator(device=dev).manual_seed(5)
+    table = torch.empty(N, c.img, dtype=torch.float32, device=dev)
+    for lo in range(0, N, 65536):
+        table[lo:lo + 65536].uniform_(0.0, 1.0, generator=gd)
+    g = torch.Generator().manual_seed(6)
+    idx = torch.randint(0, N, (B,), generator=g)
+    idx[0], idx[1], idx[2] = 0, N - 1, 29000            # both ends, and the first row beyond the 29 000-row Multi30k table
+    idx[10:20] = idx[30]                                 # repeats inside the batch
+    assert int(idx.max()) == N - 1 and int((idx > 29000).sum()) > 200
+
+    def run(tab, indices):
+        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="bf16", device=dev)
+        e.load_state_dict(p)
+        e.set_image_table(tab)
+        ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], indices, training=True, eps=bt["eps"])
+        e.loss_backward(ws, normalization=B)
+        torch.cuda.synchronize()
+        return e, ws, e.read_stats(ws)
+    e_big, ws_big, s_big = run(table, idx)
+    assert e_big.img_table.data_ptr() == table.data_ptr() and e_big.img_table.shape == (N, 2048)      # resident: no copy, no host array
+    rows = table[idx.to(dev)]
+    assert torch.equal(ws_big.img.view()[:B, :2048], rows)                                            # gather: bit-exact
+    # the same step on a 256-row table that holds exactly these rows
+    e_small, ws_small, s_small = run(rows.clone(), torch.arange(B))
+    assert torch.equal(ws_small.img.view()[:B, :2048], rows)
+    for k in ("nmt", "td_kl_before", "elbo", "img_feats_loss", "img_feats_cos"):
+        assert abs(s_big[k] - s_small[k]) <= 1e-6 * abs(s_small[k]), (k, s_big[k], s_small[k])        # (float atomics in the statistics)
+    assert s_big["n_words"] == s_small["n_words"] and s_big["n_correct"] == s_small["n_correct"]
+    a, b = e_big.flat_g[:e_big.n_opt].double(), e_small.flat_g[:e_small.n_opt].double()
+    assert ((a - b).norm() / b.norm()).item() <= 1e-5
+    # the image term really depends on the rows: another index set moves it
+    _, _, s_other = run(table, torch.randint(0, N, (B,), generator=g))
+    assert abs(s_other["img_feats_loss"] - s_big["img_feats_loss"]) > 1e-6 * abs(s_big["img_feats_loss"])
+    del table
+    torch.cuda.empty_cache()

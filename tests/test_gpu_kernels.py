@@ -117,9 +117,16 @@ def test_adam_and_sumsq():
         assert torch.equal(ss[:L.SUMSQ_SLOTS], first)
     sh = torch.full((n + 8,), 9.0, device="cuda", dtype=torch.bfloat16)        # the optional bf16 shadow of the updated parameters
     L.check(lib.vmmt_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 0.002, 0.9, 0.999, 1e-9, 3, 5.0,
-                               ss.data_ptr(), 1.0, 0, sh.data_ptr(), None), "adam")
+                               ss.data_ptr(), 1.0, 0, sh.data_ptr(), None, None), "adam")
     torch.cuda.synchronize()
     assert torch.equal(sh[:n], pd.to(torch.bfloat16)) and (sh[n:] == 9.0).all()
+    # the guard word (vmmt.h: `skip`): set -> the launch changes nothing and counts itself; clear -> the same update as without it
+    keep = [t.clone() for t in (pd, md, vd, sh)]
+    guard = torch.tensor([0x300, 0], device="cuda", dtype=torch.int32)
+    L.check(lib.vmmt_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 0.002, 0.9, 0.999, 1e-9, 4, 5.0,
+                               ss.data_ptr(), 1.0, 0, sh.data_ptr(), guard.data_ptr(), None), "adam")
+    torch.cuda.synchronize()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(keep, (pd, md, vd, sh))) and guard.tolist() == [0x300, 1]
     coef = min(1.0, 5.0 / (tot ** 0.5 + 1e-6))
     gg = g.double() * coef
     m2 = 0.9 * m.double() + 0.1 * gg

@@ -53,9 +53,9 @@ def test_rows_kernels_bit_identical_to_dense_adam():
         assert abs(a - b) <= 2e-6 * a, (step, a, b)             # the same norm up to the order of summation
         # the same clip coefficient for both (the bit-level claim is about the update, not about the norm's summation order)
         L.check(lib.vmmt_adam_step(dense["p"].data_ptr(), grad_d.data_ptr(), dense["m"].data_ptr(), dense["v"].data_ptr(), R * Cc, lr, b1, b2,
-                                   eps, step, max_norm, sq_d.data_ptr(), 1.0, 0, None, st), "adam")
+                                   eps, step, max_norm, sq_d.data_ptr(), 1.0, 0, None, None, st), "adam")
         L.check(lib.vmmt_adam_rows_step(rows_["p"].data_ptr(), grad_r.data_ptr(), rows_["m"].data_ptr(), rows_["v"].data_ptr(), R, Cc,
-                                        flags.data_ptr(), lr, b1, b2, eps, step, max_norm, sq_d.data_ptr(), 1.0, st), "rows_step")
+                                        flags.data_ptr(), lr, b1, b2, eps, step, max_norm, sq_d.data_ptr(), 1.0, None, st), "rows_step")
         torch.cuda.synchronize()
         assert int(flags.sum()) == 0
         for k in ("p", "m", "v"):

@@ -17,6 +17,7 @@ TILE_128_ONE_PER_CU = 129
 (STAT_NLL, STAT_NWORDS, STAT_NCORRECT, STAT_KL_SUM, STAT_IMG_LOGPROB, STAT_IMG_COS, STAT_GRAD_SUMSQ) = range(7)
 STAT_COUNT = 8
 SUMSQ_SLOTS, SUMSQ_MAXBLOCKS = 8, 768
+SEQ_GUARD_WORD = 4 + 2 * 256                                        # vmmt.h: VMMT_SEQ_GUARD_WORD
 SUMSQ_SCRATCH = 2 * SUMSQ_SLOTS + SUMSQ_SLOTS * SUMSQ_MAXBLOCKS      # vmmt.h: VMMT_SUMSQ_SCRATCH
 
 vp, i64, i32, f32, u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
@@ -121,10 +122,10 @@ _SIGS = {
     "vmmt_history_append": (i32, [vp, i32, vp, i32, i32, vp]),
     "vmmt_standardise_rows": (i32, [vp, i64, vp, vp, i64, i32, vp]),
     "vmmt_sumsq": (i32, [vp, i64, vp, i32, vp]),
-    "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp, vp]),
+    "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp, vp, vp]),
     "vmmt_rows_mark": (i32, [vp, i64, vp, i32, vp]),
     "vmmt_rows_zero": (i32, [vp, i32, i32, vp, vp]),
-    "vmmt_adam_rows_step": (i32, [vp, vp, vp, vp, i32, i32, vp, f32, f32, f32, f32, i32, f32, vp, f32, vp]),
+    "vmmt_adam_rows_step": (i32, [vp, vp, vp, vp, i32, i32, vp, f32, f32, f32, f32, i32, f32, vp, f32, vp, vp]),
     "vmmt_sumsq_rows": (i32, [vp, i32, i32, vp, vp, vp, i32, vp]),
 }
 

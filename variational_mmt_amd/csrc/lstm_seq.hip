@@ -88,6 +88,15 @@ __device__ __forceinline__ SeqDirF load_desc(const SeqDirF* steps, long idx) {
 
 __device__ __forceinline__ bool timed_out(unsigned long long t0) { return wall_clock64() - t0 > 200000000ull; }   // 2 s at 100 MHz
 
+// A bounded wait ran out: the launch's own error word, and -- when the caller left a pointer in the sync words (vmmt.h:
+// VMMT_SEQ_GUARD_WORD) -- the caller's sticky GUARD word, which vmmt_adam_step reads: the optimiser update of a step whose recurrence
+// produced garbage is skipped on the device, long before the host learns of it (Engine._seq_timeout_fallback)
+__device__ __forceinline__ void seq_fail(unsigned* sync, unsigned code) {
+  __hip_atomic_store(sync + 2, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned* guard = *reinterpret_cast<unsigned* const*>(sync + VMMT_SEQ_GUARD_WORD);
+  if (guard) __hip_atomic_store(guard, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int H> struct SeqCfg {
   static constexpr int ROWB = H * 2;                           // bytes per staged W_hh row (the whole reduction length)
   static constexpr int NCH = ROWB / 16;
@@ -157,7 +166,7 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
           f = __builtin_popcount(__hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
           break;
         }
-        if (timed_out(t0)) { __hip_atomic_store(err, 0x300u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); f = -1; break; }
+        if (timed_out(t0)) { seq_fail(a.sync, 0x300u); f = -1; break; }
         __builtin_amdgcn_s_sleep(2);
       }
       *flag = f;
@@ -286,7 +295,7 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
           }
           if (__all(lane >= S / 2 || (unsigned)(g >> 32) == want)) break;
           if (timed_out(t_start)) {
-            if (lane == 0) __hip_atomic_store(err, 0x200u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) seq_fail(a.sync, 0x200u + (unsigned)t);
             alive = false;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -317,7 +326,7 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
           }
         if (__all(ok) || !alive) break;
         if (timed_out(t_start)) {
-          if (lane == 0) __hip_atomic_store(err, 0x100u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) seq_fail(a.sync, 0x100u + (unsigned)t);
           alive = false;
           break;
         }
@@ -540,7 +549,7 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
           f = __builtin_popcount(__hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
           break;
         }
-        if (timed_out(t0)) { __hip_atomic_store(err, 0x400u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); f = -1; break; }
+        if (timed_out(t0)) { seq_fail(a.sync, 0x400u); f = -1; break; }
         __builtin_amdgcn_s_sleep(2);
       }
       *flag = f;
@@ -646,7 +655,7 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
             }
             if (__all(ok)) break;
             if (timed_out(t_start)) {
-              if (lane == 0) __hip_atomic_store(err, 0x500u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (lane == 0) seq_fail(a.sync, 0x500u + (unsigned)t);
               alive = false;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -786,7 +795,7 @@ static bool al16s(const void* p, long ld_elems) { return (((uintptr_t)p) & 15) =
 // allocates them and never touched by it again.  Same results as nsteps vmmt_lstm_step_fwd calls -- which is what this function
 // issues when the persistent kernel does not apply (fp32, H not in {64,128,256,512,1024}, more workgroups than CUs, unaligned rows,
 // or steps that are not chained h_prev[t] == h_out[t-1]).
-extern "C" int vmmt_lstm_seq_sync_words(void) { return 4 + 2 * 256; }   // epoch, finish count, error, pad; per group: arrivals, XCC mask
+extern "C" int vmmt_lstm_seq_sync_words(void) { return VMMT_SEQ_GUARD_WORD + 4; }   // epoch, finish count, error, pad; per group: arrivals, XCC mask; guard pointer
 extern "C" int64_t vmmt_lstm_seq_xchg_bytes(int ndir, int B, int H) {
   if (ndir < 1 || B < 1 || H < 1) return 0;
   return (int64_t)ndir * ((B + 31) / 32) * 2 * 32 * H * 4;

@@ -77,7 +77,11 @@ __device__ __forceinline__ void adam_elem(float& p, float ge, float& m, float& v
 // written here, so that the shadow refresh does not have to read the 15 M-element generator weight back
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2, float max_norm,
-                            const float* __restrict__ sumsq, float grad_scale, bf16_t* __restrict__ shadow) {
+                            const float* __restrict__ sumsq, float grad_scale, bf16_t* __restrict__ shadow, int* __restrict__ skip) {
+  if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {      // vmmt.h: the step is not applied
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1);
+    return;
+  }
   float coef = grad_scale;
   if (max_norm > 0.f) {
     float ss = 0.f;
@@ -162,7 +166,11 @@ __global__ void __launch_bounds__(256) rows_zero_kernel(float* __restrict__ g, i
 __global__ void __launch_bounds__(256) adam_rows_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int R, int C, int* __restrict__ flags, float b1, float b2,
                                                         float eps, float step_size, float inv_sqrt_bc2, float max_norm,
-                                                        const float* __restrict__ sumsq, float grad_scale) {
+                                                        const float* __restrict__ sumsq, float grad_scale, int* __restrict__ skip) {
+  if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1);
+    return;
+  }
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   const bool has_g = flags[row] != 0;
@@ -244,7 +252,8 @@ extern "C" int vmmt_rows_zero(float* g, int R, int C, const int32_t* flags, void
 }
 
 extern "C" int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, float lr, float beta1,
-                                   float beta2, float eps, int step, float max_norm, const float* sumsq, float grad_scale, void* stream) {
+                                   float beta2, float eps, int step, float max_norm, const float* sumsq, float grad_scale, const int32_t* skip,
+                                   void* stream) {
   using namespace vmmt;
   if (!p || !g || !m || !v || !flags || R <= 0 || C <= 0 || C % 4 != 0 || step < 1 || (max_norm > 0.f && !sumsq) ||
       ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15))
@@ -252,7 +261,7 @@ extern "C" int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v,
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));        // as vmmt_adam_step
   hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, R, C, flags, beta1, beta2,
-                     eps, step_size, inv_sqrt_bc2, max_norm, sumsq, grad_scale);
+                     eps, step_size, inv_sqrt_bc2, max_norm, sumsq, grad_scale, const_cast<int*>(skip));
   return check_launch();
 }
 
@@ -281,7 +290,7 @@ extern "C" int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, v
 
 extern "C" int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                               float eps, int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks,
-                              void* shadow_bf16, void* stream) {
+                              void* shadow_bf16, const int32_t* skip, void* stream) {
   using namespace vmmt;
   if (!p || !g || !m || !v || n < 0 || step < 1 || (max_norm > 0.f && !sumsq)) return VMMT_EINVAL;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return VMMT_EINVAL;
@@ -294,7 +303,7 @@ extern "C" int vmmt_adam_step(float* p, const float* g, float* m, float* v, int6
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;   // throttle: a background update must not saturate HBM
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1,
-                     beta2, eps, inv_sqrt_bc2, max_norm, sumsq, grad_scale, (bf16_t*)shadow_bf16);
+                     beta2, eps, inv_sqrt_bc2, max_norm, sumsq, grad_scale, (bf16_t*)shadow_bf16, const_cast<int*>(skip));
   return check_launch();
 }
 

@@ -14,6 +14,8 @@ averaged) -- see SURVEY.md section 8e.  What crosses ranks per step:
   * nothing else: the global batch size / token count come from the loader (`onmt.io.OrderedIterator(dp_rank=, dp_world=)`
     cuts every global minibatch into the ranks' shares on the host), the gradient norm is a deterministic reduction of the
     (bit-identical) reduced gradients on every rank, and eps / dropout streams are offset by the rank."""
+import os
+
 import torch
 
 
@@ -24,29 +26,95 @@ class GradSync(object):
         all-reduce it replaces (an all-reduce IS a reduce-scatter followed by an all-gather), but the optimiser's 28 B/param of HBM
         traffic shrinks world-fold and the all-gather half moves behind Adam, where the decoder-side half of it overlaps the next
         step's encoder.  sharded=False: all-reduce + replicated Adam."""
-        import os
         self.engine = engine
         self._flat = flat
         self.bucket_elems = bucket_elems
         self.dist = None
         self.world = 1
         self.rank = 0
+        self.backend = None
         self.sharded = (os.environ.get("VMMT_DP_SHARDED", "1") == "1") if sharded is None else bool(sharded)
         self._native = {}
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                self.dist = dist
-                self.world = dist.get_world_size()
-                self.rank = dist.get_rank()
-                if engine is not None and engine.dp is None:
-                    engine.drop_workspaces()           # (plans built for one process carry the row-wise gradient bookkeeping of the embedding tables: engine._build_row_tables)
-                    engine.dp = self
-                    # the seed is shared (identical initial parameters); the noise streams must not be: each replica draws
-                    # its own eps ~ N(0, I) and dropout masks (counter-based RNG: disjoint counter ranges per rank)
-                    engine.rng_counter += self.rank * (1 << 40)
-        except Exception:
-            pass
+        self.timing, self.exposed, self.step_event, self._tstream = None, [], None, None     # bench.py switches the timing on for a few steps
+        self.branch_log = []           # (collective, "native" | "fallback", reason): which form of each collective this run uses
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("VMMT_DP_FORCE", "0") == "1"):
+            # (VMMT_DP_FORCE=1: attach to a world of ONE as well -- every collective then runs through the backend with itself as the
+            #  only peer: the one-GPU rehearsal of the RCCL code path, tests/test_gpu_nccl_world1.py)
+            self.dist = dist
+            self.world = dist.get_world_size()
+            self.rank = dist.get_rank()
+            self.backend = dist.get_backend()
+            if engine is not None and getattr(engine, "dense_optimizer", False):
+                self.sharded = False               # torch's dense optimisers (-optim sgd|adagrad|adadelta) read the whole reduced gradient
+            if engine is not None and engine.dp is None:
+                # an error here must stop the run: `world` / `rank` set without `engine.dp` would train unsynchronised replicas
+                engine.drop_workspaces()           # (plans built for one process carry the row-wise gradient bookkeeping of the embedding tables: engine._build_row_tables)
+                engine.dp = self
+                # the seed is shared (identical initial parameters); the noise streams must not be: each replica draws
+                # its own eps ~ N(0, I) and dropout masks (counter-based RNG: disjoint counter ranges per rank)
+                engine.rng_counter += self.rank * (1 << 40)
+
+    # ---- timing of the collectives (bench.py: the "dp" block of a multi-GPU line) ------------------------------------------------
+    def time_begin(self, stream):
+        """-> start event on `stream` in front of a collective, or None when timing is off (the default: no events on the step)"""
+        if self.timing is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    def time_end(self, start, work, what, lo, hi):
+        """end event of the collective behind `work` (taken on a stream of its own that waits for the work: the collective runs on the
+        backend's stream, not on the one it was issued from)"""
+        if start is None:
+            return
+        if self._tstream is None:
+            self._tstream = torch.cuda.Stream(device=self.flat.device)
+        with torch.cuda.stream(self._tstream):
+            work.wait()
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(self._tstream)
+        self.timing.append((what, lo, hi, start, end, self.step_event))
+
+    def timed_wait(self, what, fn):
+        """run fn() (a wait of the compute stream for collectives) between two events when timing is on: the EXPOSED part"""
+        if self.timing is None:
+            return fn()
+        st = torch.cuda.current_stream(self.flat.device)
+        a = torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        out = fn()
+        b = torch.cuda.Event(enable_timing=True)
+        b.record(st)
+        self.exposed.append((what, a, b))
+        return out
+
+    def timing_report(self):
+        """[{collective, elems, bytes, ms, GB/s (bus: bytes (w-1)/w per rank), issued_at_us}] averaged per segment, exposed ms per step"""
+        torch.cuda.synchronize()
+        by = {}
+        for what, lo, hi, s, e, t0 in self.timing:
+            d = by.setdefault((what, lo, hi), dict(ms=[], at=[]))
+            d["ms"].append(s.elapsed_time(e))
+            if t0 is not None:
+                d["at"].append(t0.elapsed_time(s) * 1e3)
+        segs = []
+        for (what, lo, hi), d in sorted(by.items(), key=lambda kv: (min(kv[1]["at"]) if kv[1]["at"] else 0.0)):
+            ms = sum(d["ms"]) / len(d["ms"])
+            nbytes = 4 * (hi - lo)
+            wire = nbytes * (self.world - 1) / max(1, self.world) * (2 if what == "all_reduce" else 1)
+            segs.append({"collective": what, "bytes": nbytes, "ms": round(ms, 4), "GB/s": round(wire / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                         "issued_at_us": round(sum(d["at"]) / len(d["at"]), 1) if d["at"] else None, "samples": len(d["ms"])})
+        steps = max(1, max((len(d["ms"]) for d in by.values()), default=1))
+        ex = {}
+        for what, a, b in self.exposed:
+            ex[what] = ex.get(what, 0.0) + a.elapsed_time(b)
+        return segs, {k: round(v / steps, 4) for k, v in ex.items()}
+
+    def active(self):
+        """True when collectives are issued at all (world > 1, or a forced world of one)"""
+        return self.dist is not None
 
     @property
     def flat(self):
@@ -74,10 +142,10 @@ class GradSync(object):
         networks, generator, attention+decoder, encoder) right behind the kernels that produced it, so that the
         collectives overlap the rest of backward; here the compute stream only waits for them.  A bare flat tensor
         (no engine) is reduced bucket by bucket."""
-        if self.world == 1:
+        if not self.active():
             return
         if self.engine is not None:
-            self.engine.finish_allreduce()
+            self.timed_wait("gradient_wait", self.engine.finish_allreduce)
             return
         for o, e in self.buckets():
             self.dist.all_reduce(self.flat[o:e])
@@ -98,9 +166,16 @@ class GradSync(object):
         return n % self.world == 0 and (n // self.world) % 64 == 0
 
     def _probe(self, what, t):
-        """does the backend provide the tensor form of this collective?  (RCCL does; gloo lacks reduce_scatter)"""
+        """does the backend provide the tensor form of this collective?  (RCCL does; gloo lacks reduce_scatter.)  The answer is logged
+        (`branch_log`, one line on stderr) and anything but the backend saying "not supported" is an error: a probe that fails for
+        another reason on RCCL would otherwise degrade every step to `world` broadcasts per segment without a word"""
         key = (what, t.device.type)
         if key not in self._native:
+            forced = os.environ.get("VMMT_DP_NATIVE")            # "1": the tensor collectives or an error; "0": the fallback
+            if forced == "0":
+                self._native[key] = False
+                self._log(what, "fallback", "VMMT_DP_NATIVE=0")
+                return False
             try:
                 buf = torch.zeros(self.world * 64, dtype=torch.float32, device=t.device)
                 if what == "reduce_scatter":
@@ -108,9 +183,25 @@ class GradSync(object):
                 else:
                     self.dist.all_gather_into_tensor(buf, buf[self.rank * 64:(self.rank + 1) * 64].clone())
                 self._native[key] = True
-            except Exception:
+                self._log(what, "native", "%s on %s" % (self.backend, t.device.type))
+            except (RuntimeError, NotImplementedError) as ex:
+                msg = str(ex)
+                unsupported = isinstance(ex, NotImplementedError) or any(m in msg.lower() for m in ("not support", "unsupported", "not implemented", "no backend type"))
+                if not unsupported or forced == "1" or self.backend == "nccl":
+                    raise RuntimeError("data-parallel %s probe failed on backend %s: %s" % (what, self.backend, msg)) from ex
                 self._native[key] = False
+                self._log(what, "fallback", "%s: %s" % (self.backend, msg.splitlines()[0][:120]))
         return self._native[key]
+
+    def _log(self, what, branch, why):
+        self.branch_log.append((what, branch, why))
+        if self.rank == 0:
+            import sys
+            print("[vmmt dp] %s: %s (%s)" % (what, branch, why), file=sys.stderr, flush=True)
+
+    def native_collectives(self):
+        """{collective: bool} for the forms probed so far (bench.py prints it next to the multi-GPU number)"""
+        return {k[0]: v for k, v in self._native.items()}
 
     def reduce_scatter(self, flat, lo, hi):
         """sum flat[lo:hi] over the ranks; afterwards this rank's shard (self.shard) of it holds the sum, IN PLACE (the rest of the
@@ -127,7 +218,10 @@ class GradSync(object):
         """every rank's shard of flat[lo:hi] -> the whole segment on every rank, in place"""
         if self._even(lo, hi) and self._probe("all_gather", flat):
             a, b = self.shard(lo, hi)
-            return self.dist.all_gather_into_tensor(flat[lo:hi], flat[a:b], async_op=True)
+            t0 = self.time_begin(torch.cuda.current_stream(flat.device)) if flat.is_cuda else None
+            w = self.dist.all_gather_into_tensor(flat[lo:hi], flat[a:b], async_op=True)
+            self.time_end(t0, w, "all_gather", lo, hi)
+            return w
         works = []
         for r in range(self.world):          # uneven tail or a backend without the tensor form: one broadcast per owner
             a, b = GradSync.shard(_As(self, r), lo, hi)
@@ -145,7 +239,7 @@ class GradSync(object):
     def gather_moments(self):
         """sharded optimiser: every rank keeps Adam's moments for its shards only; before a checkpoint is written (or the sharding
         is switched off) every rank collects the full moment arenas"""
-        if self.world == 1 or self.engine is None or not self.sharded:
+        if not self.active() or self.engine is None or not self.sharded:
             return
         e = self.engine
         for t in (e.flat_m, e.flat_v):
@@ -155,17 +249,21 @@ class GradSync(object):
     def broadcast_replica(self, src=0):
         """re-synchronise the replicas (parameters + Adam moments) from rank `src`.  Replicas stay bit-identical by
         construction (identical reduced gradients, deterministic norm); the trainer calls this every few thousand updates as
-        cheap insurance (240 MB x 3 over xGMI) and right after a checkpoint is loaded."""
-        if self.world == 1 or self.engine is None:
+        cheap insurance (240 MB x 3 over xGMI) and right after a checkpoint is loaded.  Sharded optimiser: a rank maintains Adam's
+        moments for ITS shards only, so rank `src` first collects the live moments from their owners (gather_moments) -- broadcasting
+        its own stale copies would reset the other ranks' optimiser history (tests/test_dp_gloo.py)."""
+        if not self.active() or self.engine is None:
             return
         e = self.engine
+        e.wait_background()
+        self.gather_moments()
         for t in (e.flat_p, e.flat_m, e.flat_v):
             self.dist.broadcast(t, src)
         e.shadows_dirty = True
 
     def replicas_identical(self):
         """debug / test aid: True when every rank holds bit-identical parameters (one 8-byte all-reduce pair)"""
-        if self.world == 1 or self.engine is None:
+        if not self.active() or self.engine is None:
             return True
         p = self.engine.flat_p
         h = torch.stack([p.double().sum(), p.double().abs().sum()])

@@ -102,6 +102,13 @@ class Engine(StepAPI):
         self.decode_graphs = _os_env.get("VMMT_DECODE_GRAPHS", "0") == "1"
         self.persistent_lstm = _os_env.get("VMMT_PERSISTENT_LSTM", "1") == "1"     # plans are built per workspace: set before the first forward
         self.seq_syncs = []
+        # GUARD word of the persistent recurrences (vmmt.h: VMMT_SEQ_GUARD_WORD): [0] error code of a hand-off that timed out (sticky),
+        # [1] optimiser launches skipped because of it.  vmmt_adam_step reads it on the device, the host sees a pinned copy one or two
+        # steps later (optim_step) and then continues on the per-step kernels (_seq_timeout_fallback)
+        self._guard = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        self._guard_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self.seq_fallback = _os_env.get("VMMT_SEQ_FALLBACK", "1") == "1"          # 0: a timeout raises (check_async_errors) as before round 4
+        self.seq_fallbacks, self.steps_skipped, self._adam_launches, self._guard_clear_pending = 0, 0, 1, False
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
         self._works = []
 
@@ -175,21 +182,44 @@ class Engine(StepAPI):
         and missed step, in front of the embedding lookup) cost more than the traffic: 2.11 against 1.92 ms through the trainer.  Not
         kept: DESIGN.md section 6.)"""
         names = ("encoder.embeddings.make_embedding.emb_luts.0.weight", "decoder.embeddings.make_embedding.emb_luts.0.weight")
-        self.row_adam = _os_env.get("VMMT_ROW_ADAM", "0") == "1" and not self.d.conditional
+        self._row_adam = _os_env.get("VMMT_ROW_ADAM", "0") == "1" and not self.d.conditional
         self.row_tables = []
         if self.d.conditional:
             return
         for n in names:          # (the flag arrays are always there -- 240 KB -- so that the switch can be set after construction)
             off, (R, Cc) = self.offsets[n]
             if Cc % 4 or off % 4:
-                self.row_adam, self.row_tables = False, []
+                self._row_adam, self.row_tables = False, []
                 return
             self.row_tables.append(dict(name=n, off=off, R=R, C=Cc, end=off + R * Cc,
                                         flags=torch.zeros(R, dtype=torch.int32, device=self.dev),
                                         rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev)))
 
+    @property
+    def row_adam(self):
+        return self._row_adam
+
+    @row_adam.setter
+    def row_adam(self, on):
+        """the switch may be set after construction: the cached launch plans carry (or omit) the row mark / zero / norm entries, and with
+        the bookkeeping OFF the dense kernels expect a fully cleared table gradient -- rows flagged by earlier batches still hold theirs
+        (vmmt_rows_zero clears the CURRENT batch's rows only).  So a change drops the plans and clears the tables' gradients and flags"""
+        on = bool(on) and not self.d.conditional and bool(self.row_tables)
+        if on == getattr(self, "_row_adam", False):
+            return
+        self._row_adam = on
+        if hasattr(self, "ws"):
+            self.drop_workspaces()
+            for t in self.row_tables:
+                self.flat_g[t["off"]:t["end"]].zero_()
+                t["flags"].zero_()
+
+    def dp_on(self):
+        """collectives are part of the step: torch.distributed with > 1 rank (or the forced one-rank rehearsal, dp.GradSync)"""
+        return self.dp is not None and self.dp.active()
+
     def rows_active(self):
-        return bool(self.row_tables) and self.row_adam and not (self.dp is not None and self.dp.world > 1)
+        return bool(self.row_tables) and self.row_adam and not self.dp_on()
 
     def _row_mark_entries(self, plan, table_index, ids_ptr, n_ids):
         """plan entries (training forward, off the critical path): flag the batch's rows of an embedding table and clear their
@@ -454,7 +484,7 @@ class Engine(StepAPI):
             return
         if self.persistent_lstm:
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
-            sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
+            sync = self._seq_sync()
             xchg = torch.zeros(max(16, self.lib.vmmt_lstm_seq_xchg_bytes(ndir, B, H)), dtype=torch.uint8, device=self.dev)
             plan.append((self.lib.vmmt_lstm_seq_fwd, (self.dt, ndir, nsteps, arr, dev.data_ptr(), lens_ptr, B, H, sync.data_ptr(), xchg.data_ptr()),
                          "vmmt_lstm_seq_fwd", (arr, dev, sync, xchg), self._sid))
@@ -472,7 +502,7 @@ class Engine(StepAPI):
             return
         if self.persistent_lstm:
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
-            sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
+            sync = self._seq_sync()
             xchg = torch.zeros(max(16, self.lib.vmmt_lstm_seq_xchg_bytes_bwd(ndir, B, H)), dtype=torch.uint8, device=self.dev)
             plan.append((self.lib.vmmt_lstm_seq_bwd, (self.dt, ndir, nsteps, arr, dev.data_ptr(), lens_ptr, B, H, with_dh0, sync.data_ptr(),
                                                       xchg.data_ptr()), "vmmt_lstm_seq_bwd", (arr, dev, sync, xchg), self._sid))
@@ -483,20 +513,75 @@ class Engine(StepAPI):
                 last = C.cast(C.byref(arr, nsteps * ndir * C.sizeof(L.LstmDirBwd)), C.POINTER(L.LstmDirBwd))
                 plan.append((self.lib.vmmt_lstm_step_bwd, (self.dt, ndir, last, lens_ptr, B, H, 1), "vmmt_lstm_step_bwd", arr, self._sid))
 
+    def _seq_sync(self):
+        """sync words of one persistent launch site, the engine's guard pointer in their last words"""
+        sync = torch.zeros(self.lib.vmmt_lstm_seq_sync_words(), dtype=torch.int32, device=self.dev)
+        sync.view(torch.int64)[L.SEQ_GUARD_WORD // 2] = self._guard.data_ptr()
+        return sync
+
     def lstm_seq_errors(self):
         """error words of the persistent recurrence launches so far (0 = every in-launch wait completed); synchronises"""
         torch.cuda.synchronize(self.dev)
-        words = self.lib.vmmt_lstm_seq_sync_words()
         return [int(s[2].item()) for s in self.seq_syncs]            # [launch epoch, finish count, error word]
 
+    def _seq_timeout_fallback(self, where, in_step=False):
+        """An in-launch wait of a persistent recurrence ran into its 2-second bound (a workgroup of the row group was not resident:
+        another process on the GPU, a CU mask, collective kernels holding CUs).  The device has already protected the model -- every
+        optimiser launch since then saw the guard word and changed nothing -- so the run CONTINUES on the per-step kernels (one launch
+        per time step: slower, no residency requirement) and says so, instead of aborting the job."""
+        import sys
+        torch.cuda.synchronize(self.dev)
+        codes = [w for w in (int(s[2].item()) for s in self.seq_syncs) if w]
+        g = self._guard.tolist()
+        skipped = g[1] // max(1, self._adam_launches)
+        if not self.seq_fallback:
+            raise RuntimeError("persistent LSTM launch(es) reported a hand-off timeout (error words %s, guard 0x%x): results invalid; "
+                               "rerun with VMMT_PERSISTENT_LSTM=0" % ([hex(c) for c in codes], g[0]))
+        self.persistent_lstm = False
+        self.seq_syncs = []
+        self.drop_workspaces()
+        self.step_count = max(0, self.step_count - skipped)       # Adam's step counter: those updates never happened
+        if in_step:
+            # called from optim_step: the step at hand ran its recurrences on the persistent kernels as well (they may have timed out
+            # too, and the synchronisation above has just let them finish): the guard stays set through THIS update -- skipped on the
+            # device like the ones before it, consistently on every data-parallel rank -- and is cleared behind it (optim_step)
+            self._guard_clear_pending = True
+            skipped += 1
+        else:
+            self._guard.zero_()
+        self._guard_host.zero_()
+        self.seq_fallbacks += 1
+        self.steps_skipped += skipped
+        print("[vmmt] WARNING (%s): a persistent LSTM recurrence timed out waiting for its row group (error words %s, guard 0x%x); "
+              "%d optimiser step(s) were skipped on the device, nothing wrong was applied.  Continuing with one launch per time step "
+              "(VMMT_PERSISTENT_LSTM=0) for the rest of the run." % (where, [hex(c) for c in codes], g[0], skipped), file=sys.stderr, flush=True)
+
+    def poll_guard(self, where="optim_step"):
+        """host side of the guard: a pinned copy of the word, refreshed asynchronously behind every optimiser step -- reading it costs no
+        synchronisation; the first step that sees it set switches the engine over"""
+        if int(self._guard_host[0]) != 0:
+            self._seq_timeout_fallback(where, in_step=True)
+            return True
+        return False
+
+    def _publish_guard(self, stream):
+        """end of an optimiser step, on the stream that carries its last Adam launch: clear the guard if the host has just dealt with it,
+        refresh the host's pinned copy"""
+        with torch.cuda.stream(stream):
+            if getattr(self, "_guard_clear_pending", False):
+                self._guard.zero_()
+                self._guard_clear_pending = False
+                self.step_count = max(0, self.step_count - 1)      # (the update that was skipped with the guard still set)
+            self._guard_host.copy_(self._guard, non_blocking=True)
+
     def check_async_errors(self):
-        """raise if an in-launch wait of a persistent recurrence kernel ever ran into its 2-second bound (a workgroup of the row group
-        was not resident: another process on the GPU, a CU mask): the results of that step are then wrong.  Synchronises; the trainer
-        mirror calls it at the end of every epoch and before a checkpoint is written, bench.py after its timed region."""
-        bad = [i for i, x in enumerate(self.lstm_seq_errors()) if x != 0]
-        if bad:
-            raise RuntimeError("persistent LSTM launch(es) %s reported a hand-off timeout (error words %s): results invalid; "
-                               "rerun with VMMT_PERSISTENT_LSTM=0" % (bad, [self.lstm_seq_errors()[i] for i in bad]))
+        """Synchronises and settles everything the device reports asynchronously: a persistent recurrence that timed out (-> the engine
+        falls back to the per-step kernels with a warning, _seq_timeout_fallback; VMMT_SEQ_FALLBACK=0: raises) and a step that was told
+        fewer target tokens than its batch held.  The trainer mirror calls it at the end of every epoch and before a checkpoint is
+        written, bench.py after its timed region."""
+        torch.cuda.synchronize(self.dev)
+        if int(self._guard[0].item()) != 0 or any(self.lstm_seq_errors()):
+            self._seq_timeout_fallback("check_async_errors")
         # ... or if a step was told fewer target tokens than its batch held (forward(n_tgt_tokens=)): the generator left rows out
         short = [k for k, w in self.ws.items() if isinstance(w, Workspace) and getattr(w, "gen_cnt", None) is not None and int(w.gen_cnt[1].item())]
         if short:
@@ -589,7 +674,7 @@ class Engine(StepAPI):
         fn, args, name, _keep, sid = entry
         if fn is None:
             if name == "SUMSQ":
-                if self.dp is not None and self.dp.world > 1 and self.dp.sharded:
+                if self.dp_on() and self.dp.sharded:
                     return          # sharded optimiser: every rank takes the norm of ITS shards in optim_step
                 lo, hi, slot = args
                 if self._works:
@@ -607,20 +692,23 @@ class Engine(StepAPI):
                                                  self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq_rows")
                 return
             if name == "KL_ALLREDUCE":
-                if self.dp is not None and self.dp.world > 1:
+                if self.dp_on():
                     ws = self._cur_ws
                     with torch.cuda.stream(ts[sid]):
                         ws.kl_global.copy_(ws.stats[L.STAT_KL_SUM:L.STAT_KL_SUM + 1])
                         self.dp.dist.all_reduce(ws.kl_global, async_op=True).wait()
                 return
             if name == "ALLREDUCE":
-                if self.dp is not None and self.dp.world > 1:
+                if self.dp_on():
                     lo, hi = args
                     with torch.cuda.stream(ts[sid]):
+                        t0 = self.dp.time_begin(ts[sid])
                         if self.dp.sharded:     # each rank receives the sum of ITS 1/world of the segment (in place)
-                            self._works.append(self.dp.reduce_scatter(self.flat_g, lo, hi))
+                            w = self.dp.reduce_scatter(self.flat_g, lo, hi)
                         else:
-                            self._works.append(self.dp.dist.all_reduce(self.flat_g[lo:hi], async_op=True))
+                            w = self.dp.dist.all_reduce(self.flat_g[lo:hi], async_op=True)
+                        self._works.append(w)
+                        self.dp.time_end(t0, w, "reduce_scatter" if self.dp.sharded else "all_reduce", lo, hi)
                 return
             if single_stream:
                 return

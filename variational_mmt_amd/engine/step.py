@@ -146,12 +146,30 @@ class StepAPI(object):
         phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights."""
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
-        if self.dp is not None and self.dp.world > 1 and self.dp.sharded:
+        self.poll_guard()               # a recurrence hand-off timed out a step or two ago: continue on the per-step kernels
+        guard = self._guard.data_ptr()
+        n_launch = [0]
+        if self.dp_on() and self.dp.sharded:
             return self._optim_step_sharded(lr, max_grad_norm, beta1, beta2, eps, grad_scale)
+        if self.dp_on():                # replicated data-parallel update: every rank must skip the same steps
+            self.dp.dist.all_reduce(self._guard[:1], op=self.dp.dist.ReduceOp.MAX)
         if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
-            # (a dense pass is right with the row bookkeeping too: the rows it has not flagged hold zeros)
             self._sumsq[:L.SUMSQ_SLOTS].zero_()
-            L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), 0, st), "vmmt_sumsq")
+            if self.rows_active():
+                # row bookkeeping: rows flagged by EARLIER batches keep their old gradient (only the current batch's rows are cleared),
+                # so the tables are normed by flagged row and everything between them densely -- the same pieces the plan entries take
+                cur, slot = 0, 0
+                for k, t in enumerate(sorted(self.row_tables, key=lambda t: t["off"])):
+                    if t["off"] > cur:
+                        L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * cur, t["off"] - cur, self._sumsq.data_ptr(), slot, st), "vmmt_sumsq")
+                        slot += 1
+                    L.check(self.lib.vmmt_sumsq_rows(self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr(),
+                                                     t["rowsq"].data_ptr(), self._sumsq.data_ptr(), 3 + self.row_tables.index(t), st), "vmmt_sumsq_rows")
+                    cur = t["end"]
+                if self.n_opt > cur:
+                    L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * cur, self.n_opt - cur, self._sumsq.data_ptr(), slot, st), "vmmt_sumsq")
+            else:
+                L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), 0, st), "vmmt_sumsq")
         self._sumsq_by_plan = False
         self.step_count += 1
         split = self.offsets[self.first_enc_name][0]
@@ -167,7 +185,8 @@ class StepAPI(object):
                 L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
                                                 self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, lr, beta1, beta2,
                                                 eps, self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
-                                                blocks, shadow, stream), "vmmt_adam_step")
+                                                blocks, shadow, guard, stream), "vmmt_adam_step")
+                n_launch[0] += 1
 
         rows = self.rows_active()
 
@@ -175,8 +194,9 @@ class StepAPI(object):
             o = 4 * t["off"]
             L.check(self.lib.vmmt_adam_rows_step(self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o,
                                                  self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), lr, beta1, beta2, eps,
-                                                 self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, stream),
+                                                 self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, guard, stream),
                     "vmmt_adam_rows_step")
+            n_launch[0] += 1
 
         def adam(lo, hi, stream):
             # the big unpadded bf16 shadows (generator weight, image network fc2) are written by the update itself: their range is
@@ -207,11 +227,14 @@ class StepAPI(object):
                 adam(0, split, side.cuda_stream)
                 self._pack_part(3, side.cuda_stream)
                 self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
+                self._publish_guard(side)
             background()
         else:
             adam(0, self.n_opt, st)
             self._pack_part(2, st)
             self._pack_part(3, st)
+            self._publish_guard(main)
+        self._adam_launches = max(1, n_launch[0])
         self.shadows_dirty = False
 
     def _optim_step_sharded(self, lr, max_grad_norm, beta1, beta2, eps, grad_scale):
@@ -229,31 +252,37 @@ class StepAPI(object):
         dp = self.dp
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
-        self.finish_allreduce()                           # the reduce-scatters of the backward plan
+        guard = self._guard.data_ptr()
+        n_launch = [0]
+        dp.timed_wait("gradient_wait", self.finish_allreduce)      # the reduce-scatters of the backward plan
         self._sumsq_by_plan = False
         self.step_count += 1
         segs = self.segments
         own = [dp.shard(lo, hi) for lo, hi in segs]
+        self._sumsq[:L.SUMSQ_SLOTS].zero_()
         if max_grad_norm:
-            self._sumsq[:L.SUMSQ_SLOTS].zero_()
             for i, (a, b) in enumerate(own):
                 if b > a:
                     L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * a, b - a, self._sumsq.data_ptr(), i, st), "vmmt_sumsq")
-            tot = dp.all_gather_rows(self._sumsq[:L.SUMSQ_SLOTS])           # [world][SLOTS]
-            self._sumsq[:L.SUMSQ_SLOTS].zero_()
-            self._sumsq[0:1].copy_(tot.sum(dim=1).sum(dim=0, keepdim=True))  # fixed order: slots of a rank, then the ranks
+        # ONE small all-gather carries the ranks' norm partials and their guard words (a rank whose recurrence timed out must not be
+        # the only one that skips the update: the replicas would part)
+        row = torch.cat([self._sumsq[:L.SUMSQ_SLOTS], self._guard[:1].to(torch.float32)])
+        tot = dp.timed_wait("norm_all_gather", lambda: dp.all_gather_rows(row))          # [world][SLOTS + 1]
+        self._sumsq[:L.SUMSQ_SLOTS].zero_()
+        self._sumsq[0:1].copy_(tot[:, :L.SUMSQ_SLOTS].sum(dim=1).sum(dim=0, keepdim=True))  # fixed order: slots of a rank, then the ranks
+        self._guard[:1].copy_(tot[:, L.SUMSQ_SLOTS].max().to(torch.int32).reshape(1))
 
         def adam(a, b, stream):
             if b > a:
                 L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * a, self.flat_g.data_ptr() + 4 * a, self.flat_m.data_ptr() + 4 * a,
                                                 self.flat_v.data_ptr() + 4 * a, b - a, lr, beta1, beta2, eps, self.step_count,
-                                                float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, 0, None, stream),
+                                                float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, 0, None, guard, stream),
                         "vmmt_adam_step")
+                n_launch[0] += 1
         fg, bg = (2, 3), (0, 1)                           # foreground: encoder + inference networks; background: generator, decoder
         for i in fg:
             adam(own[i][0], own[i][1], st)
-        for i in fg:
-            dp.all_gather(self.flat_p, *segs[i]).wait()
+        dp.timed_wait("param_all_gather_foreground", lambda: [dp.all_gather(self.flat_p, *segs[i]).wait() for i in fg])
         self._pack_part(0, st)
         ev = self.global_events.setdefault("adam_main_done", torch.cuda.Event())
         ev.record(main)
@@ -267,4 +296,6 @@ class StepAPI(object):
             self._pack_part(1, side.cuda_stream)
         if side is not main:
             self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
+        self._publish_guard(side)
+        self._adam_launches = max(1, n_launch[0])
         self.shadows_dirty = False

@@ -410,7 +410,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
     def kl_sum_ptr(self):
         """the KL sum the backward weighs against the free-bits margin: this rank's statistic, or under data parallelism its
         all-reduced copy (`kl_global`, filled by the KL_ALLREDUCE entry of the backward plan)"""
-        if self.e.dp is not None and self.e.dp.world > 1:
+        if self.e.dp_on():
             return self.kl_global.data_ptr()
         return self.stats.data_ptr() + 4 * L.STAT_KL_SUM
 

@@ -99,6 +99,11 @@ class Optim(object):
         elif self.method in ("sgd", "adagrad", "adadelta"):
             # not on the hot path (every reference recipe uses adam): thin delegation to torch on the arena views
             self.engine.row_adam = False           # torch's dense optimisers on the arena views read / clear the whole gradient
+            # ... and the whole REDUCED gradient under data parallelism: all-reduce + replicated update instead of the sharded
+            # optimiser's reduce-scatter (which leaves the sum in this rank's 1 / world of every segment only)
+            self.engine.dense_optimizer = True
+            if self.engine.dp is not None:
+                self.engine.dp.sharded = False
             self.engine.drop_workspaces()
             cls = {"sgd": torch.optim.SGD, "adagrad": torch.optim.Adagrad, "adadelta": torch.optim.Adadelta}[self.method]
             self.optimizer = cls(self.params, lr=self.lr)

@@ -158,7 +158,7 @@ class _CheckpointWriter(object):
         while True:
             job = self.q.get()
             try:
-                if job is not None and self.err is None:
+                if job is not None and self.err is None:     # (after a failure nothing more is written; put() raises it at the next hand-over)
                     obj, fname = job
                     tmp = fname + ".partial"
                     torch.save(obj, tmp)
@@ -169,6 +169,11 @@ class _CheckpointWriter(object):
                 self.q.task_done()
 
     def put(self, obj, fname):
+        """hand a snapshot over; a failure of an EARLIER write (disk full, bad path) is raised here, at the next checkpoint, instead of
+        hours later at the end of the run while every checkpoint in between was silently dropped"""
+        if self.err is not None:
+            err, self.err = self.err, None
+            raise err
         self.q.put((obj, fname))
 
     def wait(self):
@@ -313,7 +318,7 @@ class TrainerMultimodal(object):
             self.model_updates += 1
             self.dp.all_reduce()
             self.optim.step()
-            if world > 1 and self.dp_resync_every and self.model_updates % self.dp_resync_every == 0:
+            if self.dp.active() and self.dp_resync_every and self.model_updates % self.dp_resync_every == 0:
                 self.dp.broadcast_replica(0)
             total_stats.update(batch_stats)
             report_stats.update(batch_stats)
@@ -321,20 +326,12 @@ class TrainerMultimodal(object):
     def drop_checkpoint(self, opt, epoch, fields, valid_stats, train_stats=None, overwrite=False, checkpoint_type="last",
                         temporary=False):
         """Same checkpoint dict as the reference (TrainerMultimodal.py:554-622): keys model / generator / vocab / opt /
-        epoch / optim; parameter names per SURVEY.md Appendix B."""
+        epoch / optim; parameter names per SURVEY.md Appendix B.
+        Data parallelism: EVERY rank calls this at the same point of the run -- collecting the sharded optimiser's moments is a
+        collective (dp.gather_moments) -- and rank 0 alone snapshots and writes the file (the other ranks return its name)."""
         assert checkpoint_type in ("last", "best")
         self.model.engine.check_async_errors()         # never write parameters that a timed-out device hand-off may have corrupted
         self.dp.gather_moments()                       # sharded data-parallel optimiser: collect Adam's moments from their owners
-        sd = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}          # (device -> host: a new tensor each)
-        model_sd = {k: v for k, v in sd.items() if "generator" not in k}
-        gen_sd = {k[len("generator."):]: v for k, v in sd.items() if k.startswith("generator.")}
-        self.optim._ckpt_cpu = sd          # Optim.__getstate__ wraps these same tensors: one copy of each in the file
-        # the optimiser's state (learning-rate schedule + Adam's moments, read from the device) is taken HERE, on the training thread;
-        # what goes to the writer is host memory only and pickles as the same `onmt.Optim.Optim`
-        frozen = _PickledAs(type(self.optim), self.optim.__getstate__())
-        self.optim._ckpt_cpu = None
-        checkpoint = {"model": model_sd, "generator": gen_sd, "vocab": io.save_fields_to_vocab(fields), "opt": opt,
-                      "epoch": epoch, "optim": frozen}
         if not overwrite:
             fname = "%s_acc_%.2f_ppl_%.2f_e%d.pt" % (opt.save_model, valid_stats.accuracy(), valid_stats.ppl(), epoch)
         elif checkpoint_type == "best":
@@ -344,6 +341,20 @@ class TrainerMultimodal(object):
             fname = "%s_BestModel%s.pt" % (opt.save_model, crit.capitalize())
         else:
             fname = "%s_MostCurrentModel.pt" % opt.save_model
+        if self.dp.rank != 0:
+            return (None, fname) if temporary else fname
+        # (state_dict() clones on the device, .cpu() makes a new host tensor of each; an entry that already lives on the host would be
+        #  aliased by .cpu() while training continues under the background writer, hence the explicit copy)
+        sd = {k: (v.detach().cpu() if v.is_cuda else v.detach().clone()) for k, v in self.model.state_dict().items()}
+        model_sd = {k: v for k, v in sd.items() if "generator" not in k}
+        gen_sd = {k[len("generator."):]: v for k, v in sd.items() if k.startswith("generator.")}
+        self.optim._ckpt_cpu = sd          # Optim.__getstate__ wraps these same tensors: one copy of each in the file
+        # the optimiser's state (learning-rate schedule + Adam's moments, read from the device) is taken HERE, on the training thread;
+        # what goes to the writer is host memory only and pickles as the same `onmt.Optim.Optim`
+        frozen = _PickledAs(type(self.optim), self.optim.__getstate__())
+        self.optim._ckpt_cpu = None
+        checkpoint = {"model": model_sd, "generator": gen_sd, "vocab": io.save_fields_to_vocab(fields), "opt": opt,
+                      "epoch": epoch, "optim": frozen}
         if temporary:
             tf = tempfile.NamedTemporaryFile(delete=False)
             tf.close()
@@ -370,6 +381,8 @@ class TrainerMultimodal(object):
         (`<save_model>_MostCurrentModel.pkl`)."""
         assert checkpoint_type in ("last", "best")
         es = self.early_stop
+        if getattr(getattr(self, "dp", None), "rank", 0) != 0:      # data parallelism: one writer (every rank holds the same scores)
+            return "%s_%s.pkl" % (opt.save_model, "MostCurrentModel" if checkpoint_type == "last" else "BestModel" + str(es.early_stop_criteria).capitalize())
         rec = {}
         if checkpoint_type == "best":
             if es.early_stop_criteria == "bleu":

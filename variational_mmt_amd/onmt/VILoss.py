@@ -42,7 +42,7 @@ class NMTVIModel1LossCompute(LossComputeBase):
     def _stats(self, ws, mult):
         st = ws.stats.clone()
         dp = ws.e.dp
-        has_global = dp is not None and dp.world > 1 and ws.training
+        has_global = dp is not None and dp.active() and ws.training
         if has_global:
             st[-1] = ws.kl_global[0]       # the all-reduced KL sum the backward compared with the free-bits margin (spare slot)
         return VIStatistics(self.multimodal_model_type, pending=(st, ws.B, float(self.batch_global or ws.B), mult,

@@ -154,7 +154,13 @@ def main(argv=None):
     device = torch.device("cuda", opt.gpuid[0])
     print("Using GPU")
     if world > 1 and not torch.distributed.is_initialized():
-        torch.distributed.init_process_group("nccl", device_id=device)
+        # RCCL ("nccl" on ROCm) over xGMI, one process per GPU.  VMMT_DP_BACKEND=gloo: rehearsal of the multi-rank driver with every
+        # rank on ONE GPU (RCCL refuses two ranks on one device), tests/test_gpu_driver_cli.py
+        backend = os.environ.get("VMMT_DP_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
     train_feats, valid_feats = _image_tables(opt, device)
 
     # ---- where to start from: -train_from continues a run (its options, its optimiser), with -finetune only the weights are kept
@@ -235,14 +241,14 @@ def main(argv=None):
         print("Validation image feats nll (avg.): %g" % (vs.image_feats_loss / n))
         print("Validation image fests cosine (avg.): %g" % (vs.image_feats_cos / n))
         trainer.epoch_step(vs.ppl(), epoch)
-        if rank == 0:
-            if trainer.early_stop.early_stop_criteria in ("perplexity", None):
-                if epoch >= opt.start_checkpoint_at:
-                    trainer.drop_checkpoint(model_opt, epoch, fields, vs, overwrite=opt.overwrite_model_file)
-            else:    # BLEU / METEOR model selection writes the best model itself; keep the latest one for continuing the run
-                trainer.drop_checkpoint(model_opt, epoch, fields, vs, overwrite=opt.overwrite_model_file, checkpoint_type="last")
-                trainer.drop_metric_scores(model_opt, epoch, fields, vs, overwrite=True, checkpoint_type="last")
-                print("")
+        # every rank calls drop_checkpoint (collecting the sharded optimiser's moments is a collective); rank 0 writes the file
+        if trainer.early_stop.early_stop_criteria in ("perplexity", None):
+            if epoch >= opt.start_checkpoint_at:
+                trainer.drop_checkpoint(model_opt, epoch, fields, vs, overwrite=opt.overwrite_model_file)
+        else:    # BLEU / METEOR model selection writes the best model itself; keep the latest one for continuing the run
+            trainer.drop_checkpoint(model_opt, epoch, fields, vs, overwrite=opt.overwrite_model_file, checkpoint_type="last")
+            trainer.drop_metric_scores(model_opt, epoch, fields, vs, overwrite=True, checkpoint_type="last")
+            print("")
         if trainer.early_stop.signal_early_stopping:
             print("WARNING: Early stopping!")
             break
