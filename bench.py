@@ -384,6 +384,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    if world == 1 and os.environ.get("VMMT_DP_FORCE") == "1":
+        # one-GPU rehearsal of the RCCL path: a process group of ONE rank on the `nccl` backend; dp.GradSync attaches to it and every
+        # collective of the step runs through RCCL with itself as the only peer (the "dp" block of the line then shows real RCCL calls)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group(os.environ.get("VMMT_BENCH_BACKEND", "nccl"), rank=0, world_size=1, device_id=dev)
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("VMMT_BENCH_BACKEND", "nccl")

@@ -469,13 +469,15 @@ def test_bench_configuration_against_the_oracle():
     torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
     r, Lo, g = O.step_grads(p, c, bt["src"], bt["src_len"], bt["tgt"], img, bt["eps"], masks={"dec_out": mask})
     # ---- statistics at the bf16 tolerance
-    for k, ok in (("nmt", "nll"), ("td_kl_before", "kl_before"), ("elbo", "elbo")):
+    # (measured on MI355X: ELBO 3.8e-6, KL 2.3e-5 relative; per-token NLL max 0.012 / mean 0.0019 nats of ~10.3 per token; whole-arena
+    #  gradient 4.8e-3 relative L2, worst tensor 7.8e-3)
+    for k, ok, tol in (("nmt", "nll", 2e-4), ("td_kl_before", "kl_before", 5e-4), ("elbo", "elbo", 2e-4)):
         ref = float(Lo[ok])
-        assert abs(st[k] - ref) <= 2e-3 * abs(ref), (k, st[k], ref)
+        assert abs(st[k] - ref) <= tol * abs(ref), (k, st[k], ref)
     assert st["n_words"] == Lo["n_words"] == n_tok
     tok = ws.tok_nll.float().cpu().view(T - 1, B)
     d_tok = (tok - Lo["tok_nll"]).abs()
-    assert d_tok.max().item() <= 0.15 and d_tok.mean().item() <= 1e-2, (d_tok.max().item(), d_tok.mean().item())     # per-token NLL ~ 10.3 nats each
+    assert d_tok.max().item() <= 0.05 and d_tok.mean().item() <= 5e-3, (d_tok.max().item(), d_tok.mean().item())
     assert abs(float(tok.double().sum()) - st["nmt"]) <= 1e-5 * st["nmt"]
     # ---- gradients: the whole arena against the oracle's autograd, relative L2 (the image-network class of DESIGN.md section 2 apart)
     ill = ("inf_net_image.location.fc1", "inf_net_image.gate_affine_transform")
@@ -488,8 +490,11 @@ def test_bench_configuration_against_the_oracle():
         num += float((got - ref).pow(2).sum())
         den += float(ref.pow(2).sum())
         worst[k] = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    print("bench configuration vs oracle: ELBO rel %.2e, KL rel %.2e, per-token NLL max / mean abs %.3f / %.4f, arena gradient rel-L2 %.2e, "
+          "worst tensor %.2e" % (abs(st["elbo"] - float(Lo["elbo"])) / abs(float(Lo["elbo"])), abs(st["td_kl_before"] - float(Lo["kl_before"])) /
+                                 abs(float(Lo["kl_before"])), d_tok.max().item(), d_tok.mean().item(), (num / den) ** 0.5, max(worst.values())))
     assert (num / den) ** 0.5 <= 2e-2, ((num / den) ** 0.5, sorted(worst.items(), key=lambda kv: -kv[1])[:5])
-    assert max(worst.values()) <= 6e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    assert max(worst.values()) <= 3e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
     for k in g:
         if k.startswith(ill):
             got, ref = e.grads[k].cpu().double(), g[k].double()
@@ -538,6 +543,6 @@ def test_cfg4_table_290k():
     assert ((a - b).norm() / b.norm()).item() <= 1e-5
     # the image term really depends on the rows: another index set moves it
     _, _, s_other = run(table, torch.randint(0, N, (B,), generator=g))
-    assert abs(s_other["img_feats_loss"] - s_big["img_feats_loss"]) > 1e-6 * abs(s_big["img_feats_loss"])
+    assert s_other["img_feats_loss"] != s_big["img_feats_loss"] and s_other["img_feats_cos"] != s_big["img_feats_cos"]
     del table
     torch.cuda.empty_cache()

@@ -74,8 +74,10 @@ def test_timeout_skips_the_update_and_falls_back_to_per_step_kernels(capfd):
     e.check_async_errors()
     assert e.step_count == twin.step_count == 3
     n = e.n_opt
-    scale = max(1.0, twin.flat_p[:n].abs().max().item())
-    assert (e.flat_p[:n] - twin.flat_p[:n]).abs().max().item() <= 2e-3 * scale          # (float atomics in the gradient products; as tests/test_gpu_row_adam.py)
+    # (two runs of the step differ by their float atomics; Adam's first updates turn an element whose gradient is rounding noise into
+    #  +- lr either way: a handful of elements may differ by ~lr per update, the arena as a whole must not)
+    d = (e.flat_p[:n] - twin.flat_p[:n]).abs()
+    assert d.max().item() <= 3 * 0.002 * 1.01 and d.mean().item() <= 2e-6, (d.max().item(), d.mean().item())
 
 
 def test_timeout_found_at_the_end_of_an_epoch(capfd):

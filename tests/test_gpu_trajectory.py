@@ -8,7 +8,7 @@ the sample eps injected:
     feeds back through the next forward.  The bound therefore GROWS with the step count k (stated below: MAX_DP(k)); what it must
     catch is a systematic error -- a wrong bias correction, a clip that is applied twice, moments that are not carried -- which
     shows up as a difference of the order of lr * k, two orders of magnitude above it;
-  * bf16 throughput mode against fp32 mode: the ELBO curve within 1 % at every step;
+  * bf16 throughput mode against fp32 mode: the ELBO curve within 1 % at every step (measured: 1.3e-4);
   * the row-wise Adam bookkeeping (VMMT_ROW_ADAM=1) on and off: same trajectory."""
 import pytest
 import torch
@@ -22,14 +22,23 @@ CHECK_AT = (1, 5, 10, 25, 50)
 
 
 def MAX_DP(k):
-    """bound on max |p_gpu - p_oracle| after k updates (fp32 mode), lr = 0.002: 2e-5 at the first step (fp32 rounding of one update:
-    lr x relative error of m / sqrt(v)), growing linearly to 4e-4 = 0.2 lr at step 50 -- a systematic error would be ~ lr k = 0.1"""
-    return 2e-5 + 7.6e-6 * k
+    """bound on max |p_gpu - p_oracle| after k updates (fp32 mode, lr = 0.002).  Measured on MI355X: 5.8e-5 from the FIRST update on
+    (one element of decoder.rnn.weight_ih_l0 whose gradient is of the order of Adam's eps = 1e-9: m / (sqrt(v) + eps) turns rounding
+    noise into 0.03 lr; 9.5e-5 on another box), 6.0e-5 / 9.8e-5 after 50.  Bound: 2e-4 + 2e-6 k, i.e. 0.1 -> 0.15 lr; a systematic error
+    is ~ lr k = 0.1"""
+    return 2e-4 + 2e-6 * k
+
+
+def MEAN_DP(k):
+    """bound on mean |p_gpu - p_oracle| over the optimised parameters: measured 2.7e-10 (k = 1) ... 6.2e-9 (k = 50), i.e. 3e-6 lr after
+    fifty updates; bound 2e-9 + 5e-10 k"""
+    return 2e-9 + 5e-10 * k
 
 
 def MAX_DELBO(k):
-    """relative bound on |ELBO_gpu - ELBO_oracle| at update k (fp32 mode): the single-step tolerance 3e-5 growing to 1e-3"""
-    return 3e-5 + 2e-5 * k
+    """relative bound on |ELBO_gpu - ELBO_oracle| at update k (fp32 mode): measured <= 2.5e-7 over the 50 updates; bound 1e-5 + 1e-6 k
+    (the single-step tolerance of the parity tests is 2e-5)"""
+    return 1e-5 + 1e-6 * k
 
 
 def _engine(c, p, dtype, rows=False):
@@ -96,12 +105,14 @@ def test_fifty_updates_against_the_oracle_loop():
             d = (snaps["f32"][k][n].cpu() - ref).abs().max().item()
             if d > worst:
                 worst, where = d, n
-        report.append((k, worst, where))
-        assert worst <= MAX_DP(k), ("parameters fp32 vs oracle", k, worst, where, MAX_DP(k))
-        # untouched embedding rows never move, on either side
-    print("trajectory: max |dp| vs oracle at steps", [(k, "%.2e" % w) for k, w, _ in report],
+        tot = sum(float((snaps["f32"][k][n].cpu() - ref).abs().sum()) for n, ref in snap_o[k].items() if n in engines["f32"].grads)
+        cnt = sum(ref.numel() for n, ref in snap_o[k].items() if n in engines["f32"].grads)
+        report.append((k, worst, where, tot / cnt))
+    print("trajectory: max / mean |dp| vs oracle at steps", [(k, "%.2e" % w, wh, "%.2e" % mean) for k, w, wh, mean in report],
           "| max rel dELBO fp32", "%.2e" % max(abs(a - b) / abs(b) for a, b in zip(cur["f32"], elbo_o)),
           "| bf16 vs fp32", "%.2e" % max(abs(a - b) / abs(b) for a, b in zip(cur["bf16"], cur["f32"])))
+    for k, worst, where, mean in report:
+        assert worst <= MAX_DP(k) and mean <= MEAN_DP(k), ("parameters fp32 vs oracle", k, worst, where, mean, MAX_DP(k), MEAN_DP(k))
     # bf16 against fp32: within 1 % at every step
     for k in range(STEPS):
         assert abs(cur["bf16"][k] - cur["f32"][k]) <= 1e-2 * abs(cur["f32"][k]), ("ELBO bf16 vs fp32", k + 1, cur["bf16"][k], cur["f32"][k])

@@ -106,7 +106,7 @@ class Engine(StepAPI):
         # [1] optimiser launches skipped because of it.  vmmt_adam_step reads it on the device, the host sees a pinned copy one or two
         # steps later (optim_step) and then continues on the per-step kernels (_seq_timeout_fallback)
         self._guard = torch.zeros(2, dtype=torch.int32, device=self.dev)
-        self._guard_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._guard_host = torch.zeros(2, dtype=torch.int32, device="cpu").pin_memory()      # (explicit device: a driver may have made CUDA the default tensor type)
         self.seq_fallback = _os_env.get("VMMT_SEQ_FALLBACK", "1") == "1"          # 0: a timeout raises (check_async_errors) as before round 4
         self.seq_fallbacks, self.steps_skipped, self._adam_launches, self._guard_clear_pending = 0, 0, 1, False
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
