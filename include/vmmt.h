@@ -448,6 +448,16 @@ int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16,
                    const int32_t* skip, void* stream);
 
+/* Data parallelism with the optimiser state sharded over the ranks (one process per GPU; the reference has no multi-GPU path,
+ * train_mm_vi_model1.py:73-75 -- the norm reproduced is clip_grad_norm's over ALL gradients of the global batch, Optim.py:94-95):
+ * every rank norms its shards with vmmt_sumsq (one slot per arena segment);
+ *   vmmt_dp_norm_pack   row[0 .. SLOTS) = the slot totals, row[SLOTS] = the bits of guard[0] (0 without a guard): the rank's 36-byte
+ *                       contribution to ONE all-gather
+ *   vmmt_dp_norm_fold   rows f32 [world][SLOTS + 1] (the gathered rows) -> sumsq[0] = sum over ranks of (sum over slots), in that fixed
+ *                       order on every rank (identical clip coefficient everywhere), sumsq[1 .. SLOTS) = 0, guard[0] = max over ranks */
+int vmmt_dp_norm_pack(const float* sumsq, const int32_t* guard, float* row, void* stream);
+int vmmt_dp_norm_fold(const float* rows, int world, float* sumsq, int32_t* guard, void* stream);
+
 /* ---- embedding tables: gradient bookkeeping by row -----------------------------------------------------------------------------
  * nn.Embedding tables (modules/Embeddings.py:118,181) receive gradient only in the rows a batch looks up, yet the dense path clears,
  * norms and reads the whole gradient of each table at every step (loss.backward()'s zero-filled .grad, clip_grad_norm, Adam:

@@ -9,10 +9,19 @@ eng = Engine(d, dtype="bf16", device="cuda", seed=0)
 eng.set_image_table(torch.rand(29000, d.img))
 eng.use_side_stream = os.environ.get("SIDE", "1") == "1"
 bs = bench.make_batches(d, 256, 20, 21, 29000, 4, "cuda", 1)
+sync = None
+if os.environ.get("VMMT_DP_FORCE") == "1":       # the data-parallel step through RCCL with a world of one rank (SHARDED=0: replicated update)
+    import torch.distributed as dist
+    from variational_mmt_amd.dp import GradSync
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29546")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    sync = GradSync(eng, sharded=os.environ.get("SHARDED", "1") == "1")
 def step(i):
     src, sl, tgt, idx, _tl, _ntok = bs[i % 4]
     ws = eng.forward(src, sl, tgt, idx, training=True)
     eng.loss_backward(ws, normalization=256, batch_global=256)
+    if sync is not None:
+        sync.all_reduce()
     eng.optim_step()
 for i in range(8): step(i)
 torch.cuda.synchronize()

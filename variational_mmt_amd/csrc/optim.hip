@@ -234,7 +234,48 @@ __global__ void __launch_bounds__(1024) rows_sumsq_total_kernel(const float* __r
   }
 }
 
+// Data-parallel clip norm with the optimiser state sharded over the ranks: every rank norms ITS shards (sumsq_kernel, one slot per arena
+// segment), the ranks exchange ONE row [slot totals | guard word] (an all-gather of 36 bytes), and every rank folds the rows in the same
+// fixed order -- slots of a rank, then the ranks -- so that all of them compute the same clip coefficient bit for bit.  The guard word of
+// the persistent recurrences (vmmt.h: VMMT_SEQ_GUARD_WORD) rides along as raw bits and is folded with max(): a rank whose recurrence timed
+// out must not be the only one that skips the update.
+__global__ void dp_norm_pack_kernel(const float* __restrict__ sumsq, const int* __restrict__ guard, float* __restrict__ row) {
+  const int t = threadIdx.x;
+  if (t < VMMT_SUMSQ_SLOTS) row[t] = sumsq[t];
+  else if (t == VMMT_SUMSQ_SLOTS) row[t] = __int_as_float(guard ? guard[0] : 0);
+}
+__global__ void dp_norm_fold_kernel(const float* __restrict__ rows, int world, float* __restrict__ sumsq, int* __restrict__ guard) {
+  if (threadIdx.x != 0) return;
+  float tot = 0.f;
+  int g = 0;
+  for (int r = 0; r < world; ++r) {
+    const float* row = rows + (long)r * (VMMT_SUMSQ_SLOTS + 1);
+    float s = 0.f;
+    for (int k = 0; k < VMMT_SUMSQ_SLOTS; ++k) s += row[k];
+    tot += s;
+    const int gr = __float_as_int(row[VMMT_SUMSQ_SLOTS]);
+    g = gr > g ? gr : g;
+  }
+  sumsq[0] = tot;
+  for (int k = 1; k < VMMT_SUMSQ_SLOTS; ++k) sumsq[k] = 0.f;
+  if (guard) guard[0] = g;
+}
+
 }  // namespace vmmt
+
+extern "C" int vmmt_dp_norm_pack(const float* sumsq, const int32_t* guard, float* row, void* stream) {
+  using namespace vmmt;
+  if (!sumsq || !row) return VMMT_EINVAL;
+  hipLaunchKernelGGL(dp_norm_pack_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq, (const int*)guard, row);
+  return check_launch();
+}
+
+extern "C" int vmmt_dp_norm_fold(const float* rows, int world, float* sumsq, int32_t* guard, void* stream) {
+  using namespace vmmt;
+  if (!rows || !sumsq || world < 1) return VMMT_EINVAL;
+  hipLaunchKernelGGL(dp_norm_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rows, world, sumsq, (int*)guard);
+  return check_launch();
+}
 
 extern "C" int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, void* stream) {
   using namespace vmmt;

@@ -35,7 +35,7 @@ class GradSync(object):
         self.backend = None
         self.sharded = (os.environ.get("VMMT_DP_SHARDED", "1") == "1") if sharded is None else bool(sharded)
         self._native = {}
-        self.timing, self.exposed, self.step_event, self._tstream = None, [], None, None     # bench.py switches the timing on for a few steps
+        self.timing, self.exposed, self.step_event, self._comm = None, [], None, None     # bench.py switches the timing on for a few steps
         self.branch_log = []           # (collective, "native" | "fallback", reason): which form of each collective this run uses
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("VMMT_DP_FORCE", "0") == "1"):
@@ -64,17 +64,12 @@ class GradSync(object):
         ev.record(stream)
         return ev
 
-    def time_end(self, start, work, what, lo, hi):
-        """end event of the collective behind `work` (taken on a stream of its own that waits for the work: the collective runs on the
-        backend's stream, not on the one it was issued from)"""
+    def time_end(self, start, stream, what, lo, hi):
+        """end event of a collective on the stream it ran on (the collectives are synchronous operations on explicit streams)"""
         if start is None:
             return
-        if self._tstream is None:
-            self._tstream = torch.cuda.Stream(device=self.flat.device)
-        with torch.cuda.stream(self._tstream):
-            work.wait()
-            end = torch.cuda.Event(enable_timing=True)
-            end.record(self._tstream)
+        end = torch.cuda.Event(enable_timing=True)
+        end.record(stream)
         self.timing.append((what, lo, hi, start, end, self.step_event))
 
     def timed_wait(self, what, fn):
@@ -127,6 +122,7 @@ class GradSync(object):
         if self.world == 1:
             return tuple(float(v) for v in local_values)
         t = torch.tensor([float(v) for v in local_values], device=self.flat.device, dtype=torch.float64)
+        self.serialize()
         self.dist.all_reduce(t)
         return tuple(t.tolist())
 
@@ -203,31 +199,75 @@ class GradSync(object):
         """{collective: bool} for the forms probed so far (bench.py prints it next to the multi-GPU number)"""
         return {k[0]: v for k, v in self._native.items()}
 
+    # Every collective is a SYNCHRONOUS operation of torch.distributed issued under an explicit stream: the backend then launches it
+    # on that stream (observed with RCCL on torch 2.10: the copy kernel of a one-rank all-gather runs on the issuing stream), not on
+    # an internal stream of its own behind two event hops.  With `async_op=True` the backend's one internal stream sat blocked on
+    # whichever producer it had been told to wait for, and -- the GPU exposes 4 hardware queues to a process, streams share them --
+    # held up the main stream's persistent recurrences behind it: 2.2-2.9 ms per step in the one-rank RCCL rehearsal against 1.75 ms
+    # without data parallelism.  One communicator must not run two collectives at once, so they are kept in ONE order by stream
+    # dependencies: gradient segments and the KL float on the COMM stream (each behind its producer), the norm row and the foreground
+    # parameter all-gathers on the main stream behind the COMM stream, the background all-gathers on the side stream behind those, and
+    # the next step's KL float behind the background all-gathers (Engine: KL_ALLREDUCE waits for `opt_side_done`).
+    def comm_stream(self):
+        if self._comm is None:
+            try:
+                lo_pri = max(torch.cuda.Stream.priority_range())
+            except Exception:
+                lo_pri = 0
+            self._comm = torch.cuda.Stream(device=self.flat.device, priority=lo_pri)
+        return self._comm
+
+    def on_comm(self, after, fn, what=None, lo=0, hi=0):
+        """run the collective(s) fn() on the COMM stream, behind everything `after` (a stream) has been given so far"""
+        comm = self.comm_stream()
+        comm.wait_stream(after)
+        with torch.cuda.stream(comm):
+            t0 = self.time_begin(comm) if what else None
+            fn()
+            self.time_end(t0, comm, what, lo, hi)
+        return comm
+
     def reduce_scatter(self, flat, lo, hi):
         """sum flat[lo:hi] over the ranks; afterwards this rank's shard (self.shard) of it holds the sum, IN PLACE (the rest of the
-        segment is scratch).  Returns a work handle (wait() makes the current stream wait).  One RCCL reduce-scatter when the
-        segment splits evenly; otherwise (or on a backend without it: gloo in the tests) an all-reduce, whose result restricted to
-        the shard is the same numbers"""
+        segment is scratch).  Synchronous on the current stream.  One RCCL reduce-scatter when the segment splits evenly; otherwise
+        (or on a backend without the tensor form) an all-reduce, whose result restricted to the shard is the same numbers"""
         seg = flat[lo:hi]
         if self._even(lo, hi) and self._probe("reduce_scatter", flat):
             a, b = self.shard(lo, hi)
-            return self.dist.reduce_scatter_tensor(flat[a:b], seg, async_op=True)
-        return self.dist.all_reduce(seg, async_op=True)
+            self.dist.reduce_scatter_tensor(flat[a:b], seg)
+        else:
+            self.dist.all_reduce(seg)
+        return _Done()
+
+    def reduce_segment(self, flat, lo, hi, producer):
+        """the gradient collective of one arena segment from inside the backward plan: on the COMM stream, behind `producer` (the plan
+        stream whose kernels completed the segment).  Nothing waits for it here: Engine.finish_allreduce / the shard norms do"""
+        if self.sharded:
+            return self.on_comm(producer, lambda: self.reduce_scatter(flat, lo, hi), "reduce_scatter", lo, hi)
+        return self.on_comm(producer, lambda: self.dist.all_reduce(flat[lo:hi]), "all_reduce", lo, hi)
 
     def all_gather(self, flat, lo, hi):
-        """every rank's shard of flat[lo:hi] -> the whole segment on every rank, in place"""
+        """every rank's shard of flat[lo:hi] -> the whole segment on every rank, in place; synchronous on the current stream"""
+        st = torch.cuda.current_stream(flat.device) if flat.is_cuda else None
+        t0 = self.time_begin(st) if st is not None else None
         if self._even(lo, hi) and self._probe("all_gather", flat):
             a, b = self.shard(lo, hi)
-            t0 = self.time_begin(torch.cuda.current_stream(flat.device)) if flat.is_cuda else None
-            w = self.dist.all_gather_into_tensor(flat[lo:hi], flat[a:b], async_op=True)
-            self.time_end(t0, w, "all_gather", lo, hi)
-            return w
-        works = []
-        for r in range(self.world):          # uneven tail or a backend without the tensor form: one broadcast per owner
-            a, b = GradSync.shard(_As(self, r), lo, hi)
-            if b > a:
-                works.append(self.dist.broadcast(flat[a:b], r, async_op=True))
-        return _Works(works)
+            self.dist.all_gather_into_tensor(flat[lo:hi], flat[a:b])
+        else:
+            for r in range(self.world):          # uneven tail or a backend without the tensor form: one broadcast per owner
+                a, b = GradSync.shard(_As(self, r), lo, hi)
+                if b > a:
+                    self.dist.broadcast(flat[a:b], r)
+        self.time_end(t0, st, "all_gather", lo, hi)
+        return _Done()
+
+    def serialize(self):
+        """the current stream waits for every collective issued so far (COMM stream, background half of the optimiser step): call before
+        a collective that is issued outside the step's own ordering (statistics, replica checks, checkpoints)"""
+        if self.engine is not None and self.flat.is_cuda:
+            self.engine.wait_background()
+            if self._comm is not None:
+                torch.cuda.current_stream(self.flat.device).wait_stream(self._comm)
 
     def all_gather_rows(self, row):
         """[n] on every rank -> [world][n] on every rank (the ranks' norm partials)"""
@@ -236,15 +276,24 @@ class GradSync(object):
         self.dist.all_gather(parts, row.contiguous())
         return torch.stack(parts)
 
+    def all_gather_row_into(self, out, row):
+        """row [n] on every rank -> out [world][n] on every rank, no temporaries: ONE tensor all-gather where the backend has it"""
+        if self._probe("all_gather", row):
+            self.dist.all_gather_into_tensor(out.view(-1), row)
+        else:
+            self.dist.all_gather(list(out.unbind(0)), row)
+        return out
+
     def gather_moments(self):
         """sharded optimiser: every rank keeps Adam's moments for its shards only; before a checkpoint is written (or the sharding
         is switched off) every rank collects the full moment arenas"""
         if not self.active() or self.engine is None or not self.sharded:
             return
         e = self.engine
+        self.serialize()
         for t in (e.flat_m, e.flat_v):
             for lo, hi in e.segments:
-                self.all_gather(t, lo, hi).wait()
+                self.all_gather(t, lo, hi)
 
     def broadcast_replica(self, src=0):
         """re-synchronise the replicas (parameters + Adam moments) from rank `src`.  Replicas stay bit-identical by
@@ -255,7 +304,7 @@ class GradSync(object):
         if not self.active() or self.engine is None:
             return
         e = self.engine
-        e.wait_background()
+        self.serialize()
         self.gather_moments()
         for t in (e.flat_p, e.flat_m, e.flat_v):
             self.dist.broadcast(t, src)
@@ -265,6 +314,7 @@ class GradSync(object):
         """debug / test aid: True when every rank holds bit-identical parameters (one 8-byte all-reduce pair)"""
         if not self.active() or self.engine is None:
             return True
+        self.serialize()
         p = self.engine.flat_p
         h = torch.stack([p.double().sum(), p.double().abs().sum()])
         lo, hi = h.clone(), h.clone()
@@ -278,6 +328,7 @@ class GradSync(object):
         if self.world == 1:
             return list(values)
         t = torch.tensor(list(values), device=self.flat.device, dtype=torch.float64)
+        self.serialize()
         self.dist.all_reduce(t)
         return t.tolist()
 
@@ -289,10 +340,8 @@ class _As(object):
         self.world, self.rank = sync.world, rank
 
 
-class _Works(object):
-    def __init__(self, works):
-        self.works = works
+class _Done(object):
+    """what a synchronous collective returns where callers used to get a work handle"""
 
     def wait(self):
-        for w in self.works:
-            w.wait()
+        return None

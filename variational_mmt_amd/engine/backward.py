@@ -211,8 +211,17 @@ class BackwardPlan(object):
         # kernels go out first instead of behind the ~20 small launches of the aux chain (tools/ab.py: 2.009 against 2.037 ms, equal
         # in a second run); the conditional model keeps the aux chain first, it IS the critical path there (4.42 against 4.45 ms)
         main_first = bool(self.gen_fused and not d.conditional and e.bwd_main_first)
+        # data parallelism: the backend runs every collective of a process group on ONE stream, in the order the HOST issued them.  The
+        # KL all-reduce at the head of the aux chain is due ~0.3 ms into the step, the generator segment's reduce-scatter only when the
+        # dWg product is through (~1.2 ms): issued in that order the one float waited for the 60 MB behind the product, and the aux
+        # chain -- gated by the KL sum -- moved from underneath the decoder's forward into the backward recurrences (world-1 RCCL
+        # rehearsal: 2.46 against 1.75 ms per step).  So with ranks attached the aux chain is issued BEFORE the side stream's products:
+        # collectives then reach the backend in the order their inputs become ready (KL, inference networks, generator, decoder, encoder)
+        aux_before_side = bool(main_first and e.dp_on())
         if main_first:
             main_head()
+            if aux_before_side:
+                aux_chain()
         else:
             aux_chain()
         # side: dWg = G^T O as soon as G^T exists, underneath dO = G Wg of the main stream (measured, tools/ab.py: issuing it behind dR,
@@ -249,7 +258,8 @@ class BackwardPlan(object):
                 e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
         e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
         if main_first:
-            aux_chain()
+            if not aux_before_side:
+                aux_chain()
         else:
             main_head()
         e._sid = SIDE

@@ -60,7 +60,10 @@ class Engine(StepAPI):
         self.use_aux_stream = _os_env.get("VMMT_AUX_STREAM", "1") == "1"
         # fourth stream (conditional model only): encoder_tgt's backward recurrence, 2 x B dependent steps that would otherwise hold
         # up everything queued behind them on the aux stream
-        self.tgt_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
+        # (created on first use -- two-layer / conditional models only: every stream is one more hardware queue for the GPU's scheduler to
+        #  rotate, and with six of them the persistent recurrences' launches were seen waiting 0.2-0.4 ms for their queue to be mapped)
+        self._lo_pri, self._hi_pri = lo_pri, hi_pri
+        self._tgt_stream = None
         # workgroups of the BACKGROUND half of Adam (side stream, underneath the next step's encoder recurrence).  Unthrottled it takes
         # the memory system for ~200 us and the latency-bound persistent LSTM kernel next to it runs at half speed; one workgroup per
         # CU still finishes before the decoder-side weights are needed.  tools/ab.py, ms per step: 4096 wgs 1.958-2.007 | 384: 1.957 |
@@ -81,7 +84,8 @@ class Engine(StepAPI):
         self.bwd_layers_parallel = _os_env.get("VMMT_BWD_LAYERS_PARALLEL", "1") == "1"   # >= 2 layers: top encoder layer next to the lower decoder layers
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
-        self.compute_stream = torch.cuda.Stream(device=self.dev, priority=hi_pri)
+        self._compute_stream = None
+        self._plan_tgt = {}           # id(plan) -> (entries, whether it uses the fourth stream)
         self.use_side_stream = True
         # the generator's calls over the decoder rows that carry a target only (pads compacted away) when forward() knows their number
         self.gen_compact = _os_env.get("VMMT_GEN_COMPACT", "1") == "1"
@@ -93,6 +97,7 @@ class Engine(StepAPI):
         self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
         self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
         self._sumsq_by_plan = False
+        self._normed = set()         # sharded data parallelism: arena segments whose shard the backward plan has normed (step.py)
         self.fused_qnet = _os_env.get("VMMT_FUSED_QNET", "1") == "1"
         self.qnet_split = _os_env.get("VMMT_QNET_SPLIT", "1") == "1"     # location / scale networks in separate workgroups (csrc/qnet.hip)
         self.gen_fused = _os_env.get("VMMT_GEN_FUSED", "1") == "1"       # csrc/generator_fused.hip where it applies (bf16, H = 512 / 256)
@@ -111,6 +116,26 @@ class Engine(StepAPI):
         self.seq_fallbacks, self.steps_skipped, self._adam_launches, self._guard_clear_pending = 0, 0, 1, False
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
         self._works = []
+
+    @property
+    def tgt_stream(self):
+        if self._tgt_stream is None:
+            self._tgt_stream = torch.cuda.Stream(device=self.dev, priority=self._lo_pri)
+        return self._tgt_stream
+
+    @tgt_stream.setter
+    def tgt_stream(self, s):
+        self._tgt_stream = s
+
+    @property
+    def compute_stream(self):        # (tools/ab.py only)
+        if self._compute_stream is None:
+            self._compute_stream = torch.cuda.Stream(device=self.dev, priority=self._hi_pri)
+        return self._compute_stream
+
+    @compute_stream.setter
+    def compute_stream(self, s):
+        self._compute_stream = s
 
     def set_side_cu_mask(self, mask_words):
         """restrict the side stream to the CUs set in `mask_words` (list of 32-bit words, bit i = CU i); None restores the
@@ -636,16 +661,19 @@ class Engine(StepAPI):
         plan.append((None, (lo, hi, slot), "SUMSQ", None, self._sid))
 
     def finish_allreduce(self):
-        """make the current stream wait for every outstanding gradient all-reduce (call before optim_step)"""
-        for w in self._works:
-            w.wait()
-        self._works = []
+        """make the current stream wait for every gradient collective of the backward plan (call before optim_step)"""
+        if self.dp_on() and self.dp._comm is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.dp._comm)
 
     def _run(self, plan, events=None):
         main = torch.cuda.current_stream(self.dev)
         side = self.side_stream if self.use_side_stream else main
         aux = self.aux_stream if (self.use_side_stream and self.use_aux_stream) else side
-        tgt = self.tgt_stream if aux is self.aux_stream else aux
+        uses_tgt = self._plan_tgt.get(id(plan))
+        if uses_tgt is None or uses_tgt[0] != len(plan):
+            uses_tgt = self._plan_tgt[id(plan)] = (len(plan), any(en[4] == 3 for en in plan))
+        uses_tgt = uses_tgt[1]
+        tgt = (self.tgt_stream if aux is self.aux_stream else aux) if uses_tgt else aux
         ts = (main, side, aux, tgt)
         hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream, tgt.cuda_stream)
         trace, last = self.trace, None
@@ -675,13 +703,10 @@ class Engine(StepAPI):
         if fn is None:
             if name == "SUMSQ":
                 if self.dp_on() and self.dp.sharded:
-                    return          # sharded optimiser: every rank takes the norm of ITS shards in optim_step
+                    return          # sharded optimiser: every rank takes the norm of ITS shards behind the segment's reduce-scatter
                 lo, hi, slot = args
-                if self._works:
-                    with torch.cuda.stream(ts[sid]):
-                        for w in self._works:
-                            w.wait()
-                    self._works = []
+                if self.dp_on():    # replicated data-parallel update: behind the segments' all-reduces (COMM stream)
+                    ts[sid].wait_stream(self.dp.comm_stream())
                 L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * lo, hi - lo, self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq")
                 self._sumsq_by_plan = True
                 return
@@ -693,22 +718,30 @@ class Engine(StepAPI):
                 return
             if name == "KL_ALLREDUCE":
                 if self.dp_on():
+                    # one float, on the COMM stream like the gradient segments (one communicator: one collective at a time), behind the
+                    # background half of the last optimiser step, whose parameter all-gathers run on the side stream
                     ws = self._cur_ws
                     with torch.cuda.stream(ts[sid]):
                         ws.kl_global.copy_(ws.stats[L.STAT_KL_SUM:L.STAT_KL_SUM + 1])
-                        self.dp.dist.all_reduce(ws.kl_global, async_op=True).wait()
+                    comm = self.dp.comm_stream()
+                    ev = self.global_events.get("opt_side_done")
+                    if ev is not None:
+                        comm.wait_event(ev)
+                    self.dp.on_comm(ts[sid], lambda: self.dp.dist.all_reduce(ws.kl_global))
+                    ts[sid].wait_stream(comm)
                 return
             if name == "ALLREDUCE":
                 if self.dp_on():
                     lo, hi = args
-                    with torch.cuda.stream(ts[sid]):
-                        t0 = self.dp.time_begin(ts[sid])
-                        if self.dp.sharded:     # each rank receives the sum of ITS 1/world of the segment (in place)
-                            w = self.dp.reduce_scatter(self.flat_g, lo, hi)
-                        else:
-                            w = self.dp.dist.all_reduce(self.flat_g[lo:hi], async_op=True)
-                        self._works.append(w)
-                        self.dp.time_end(t0, w, "reduce_scatter" if self.dp.sharded else "all_reduce", lo, hi)
+                    comm = self.dp.reduce_segment(self.flat_g, lo, hi, ts[sid])
+                    if self.dp.sharded and (lo, hi) in self.segments:
+                        # the norm of this rank's shard of the segment right behind the collective, on the same stream: only the
+                        # LAST segment's norm is left for the step's tail (optim_step).  Slots were cleared by the forward plan
+                        a, b = self.dp.shard(lo, hi)
+                        if b > a:
+                            L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * a, b - a, self._sumsq.data_ptr(),
+                                                        self.segments.index((lo, hi)), comm.cuda_stream), "vmmt_sumsq")
+                        self._normed.add(self.segments.index((lo, hi)))
                 return
             if single_stream:
                 return

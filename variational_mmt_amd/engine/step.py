@@ -152,6 +152,7 @@ class StepAPI(object):
         if self.dp_on() and self.dp.sharded:
             return self._optim_step_sharded(lr, max_grad_norm, beta1, beta2, eps, grad_scale)
         if self.dp_on():                # replicated data-parallel update: every rank must skip the same steps
+            self.finish_allreduce()
             self.dp.dist.all_reduce(self._guard[:1], op=self.dp.dist.ReduceOp.MAX)
         if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
             self._sumsq[:L.SUMSQ_SLOTS].zero_()
@@ -255,34 +256,37 @@ class StepAPI(object):
         guard = self._guard.data_ptr()
         n_launch = [0]
         dp.timed_wait("gradient_wait", self.finish_allreduce)      # the reduce-scatters of the backward plan
-        self._sumsq_by_plan = False
         self.step_count += 1
         segs = self.segments
         own = [dp.shard(lo, hi) for lo, hi in segs]
-        self._sumsq[:L.SUMSQ_SLOTS].zero_()
-        if max_grad_norm:
+        if len(self._normed) != len(segs):      # (normally the backward plan normed every segment's shard behind its reduce-scatter)
+            self._sumsq[:L.SUMSQ_SLOTS].zero_()
             for i, (a, b) in enumerate(own):
                 if b > a:
                     L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * a, b - a, self._sumsq.data_ptr(), i, st), "vmmt_sumsq")
-        # ONE small all-gather carries the ranks' norm partials and their guard words (a rank whose recurrence timed out must not be
-        # the only one that skips the update: the replicas would part)
-        row = torch.cat([self._sumsq[:L.SUMSQ_SLOTS], self._guard[:1].to(torch.float32)])
-        tot = dp.timed_wait("norm_all_gather", lambda: dp.all_gather_rows(row))          # [world][SLOTS + 1]
-        self._sumsq[:L.SUMSQ_SLOTS].zero_()
-        self._sumsq[0:1].copy_(tot[:, :L.SUMSQ_SLOTS].sum(dim=1).sum(dim=0, keepdim=True))  # fixed order: slots of a rank, then the ranks
-        self._guard[:1].copy_(tot[:, L.SUMSQ_SLOTS].max().to(torch.int32).reshape(1))
+        self._sumsq_by_plan = False
+        self._normed = set()
+        # ONE 36-byte all-gather carries the ranks' norm partials and their guard words (a rank whose recurrence timed out must not be
+        # the only one that skips the update: the replicas would part); folded in a fixed order on every rank (csrc/optim.hip)
+        if getattr(self, "_dp_row", None) is None or self._dp_rows.shape[0] != dp.world:
+            self._dp_row = torch.zeros(L.SUMSQ_SLOTS + 1, dtype=torch.float32, device=self.dev)
+            self._dp_rows = torch.zeros(dp.world, L.SUMSQ_SLOTS + 1, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.vmmt_dp_norm_pack(self._sumsq.data_ptr(), guard, self._dp_row.data_ptr(), st), "vmmt_dp_norm_pack")
+        dp.timed_wait("norm_all_gather", lambda: dp.all_gather_row_into(self._dp_rows, self._dp_row))
+        L.check(self.lib.vmmt_dp_norm_fold(self._dp_rows.data_ptr(), dp.world, self._sumsq.data_ptr(), guard, st), "vmmt_dp_norm_fold")
 
         def adam(a, b, stream):
             if b > a:
                 L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * a, self.flat_g.data_ptr() + 4 * a, self.flat_m.data_ptr() + 4 * a,
                                                 self.flat_v.data_ptr() + 4 * a, b - a, lr, beta1, beta2, eps, self.step_count,
-                                                float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, 0, None, guard, stream),
+                                                float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
+                                                int(self.bg_adam_blocks) if stream != st else 0, None, guard, stream),
                         "vmmt_adam_step")
                 n_launch[0] += 1
         fg, bg = (2, 3), (0, 1)                           # foreground: encoder + inference networks; background: generator, decoder
         for i in fg:
             adam(own[i][0], own[i][1], st)
-        dp.timed_wait("param_all_gather_foreground", lambda: [dp.all_gather(self.flat_p, *segs[i]).wait() for i in fg])
+        dp.timed_wait("param_all_gather_foreground", lambda: [dp.all_gather(self.flat_p, *segs[i]) for i in fg])
         self._pack_part(0, st)
         ev = self.global_events.setdefault("adam_main_done", torch.cuda.Event())
         ev.record(main)
@@ -292,7 +296,7 @@ class StepAPI(object):
             for i in bg:
                 adam(own[i][0], own[i][1], side.cuda_stream)
             for i in bg:
-                dp.all_gather(self.flat_p, *segs[i]).wait()
+                dp.all_gather(self.flat_p, *segs[i])
             self._pack_part(1, side.cuda_stream)
         if side is not main:
             self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
