@@ -98,6 +98,14 @@ typedef struct vmmt_gemm_args {
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
 int vmmt_gemm_colsum_applies(const vmmt_gemm_args* args);
+/* n independent products in one call: the same results as n vmmt_gemm calls (in any order: members must ACCUMULATE into C with
+ * atomics, split_k >= 2; several may share one C).  When every member is a bf16 TN product that vmmt_gemm would run on its two-stage
+ * 128 x 128 LDS-DMA tiles -- the weight-gradient products dW = dY^T X of the LSTM and attention layers, the backward of nn.LSTM /
+ * nn.Linear in onmt/Models.py:124-129, onmt/VI_Model1.py:149-152, modules/GlobalAttention.py:106-118 -- and 2 <= n <= VMMT_GEMM_GROUP_MAX,
+ * the tiles of all of them go out as ONE grid (vmmt_gemm_group_applies() == 1); otherwise one launch per member. */
+#define VMMT_GEMM_GROUP_MAX 8
+int vmmt_gemm_group(const vmmt_gemm_args* args, int n, void* stream);
+int vmmt_gemm_group_applies(const vmmt_gemm_args* args, int n);
 
 /* ---- LSTM time steps ------------------------------------------------------------------------------------------
  * One launch per time step (both directions of a bidirectional layer in the same launch).  The input projection

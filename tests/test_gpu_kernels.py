@@ -558,3 +558,74 @@ def test_generator_over_compacted_tokens_equals_the_dense_calls(M, V, H):
     assert (comp["dO"] - dense["dO"]).abs().max().item() <= 2e-3 * dense["dO"].abs().max().item()
     assert (comp["dW"] - dense["dW"]).norm().item() <= 2e-3 * dense["dW"].norm().item()
     assert (comp["db"] - dense["db"]).abs().max().item() <= 2e-3 * max(1e-6, dense["db"].abs().max().item())
+
+
+def test_gemm_group_equals_separate_launches():
+    """vmmt_gemm_group: the weight-gradient products of a layer as ONE grid -- five products of different shapes (ragged rows / columns,
+    a short reduction, two members accumulating into the SAME C, plain column sums riding in one of them, a padded row-block map)
+    against fp64 math and against the same products issued one by one; a group with an ineligible member falls back to one launch
+    per member with the same results"""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(8)
+    T = torch.bfloat16
+    K1, K2 = 4864, 256
+    A1 = (torch.randn(K1, 1024, generator=g) * 0.5).to(T).cuda()          # "dgates" of steps 1.. (K-strided)
+    B1 = (torch.randn(K1, 256, generator=g) * 0.5).to(T).cuda()           # h_prev
+    A2 = (torch.randn(K2, 1024, generator=g) * 0.5).to(T).cuda()          # step 0
+    B2 = (torch.randn(K2, 256, generator=g) * 0.5).to(T).cuda()
+    A3 = (torch.randn(5120, 1024, generator=g) * 0.5).to(T).cuda()        # all steps
+    B3 = (torch.randn(5120, 512, generator=g) * 0.5).to(T).cuda()         # x (500 valid columns)
+    A4 = (torch.randn(5120, 512, generator=g) * 0.5).to(T).cuda()
+    B4 = (torch.randn(5120, 1024, generator=g) * 0.5).to(T).cuda()
+
+    def problems(Chh, Cih, Cw, b1, b2, Cpad):
+        def mk(A, lda, Bm, ldb, Cd, ldc, M, N, K, split):
+            return L.GemmArgs(L.BF16, L.GEMM_TN, A.data_ptr(), lda, Bm.data_ptr(), ldb, Cd.data_ptr(), ldc, M, N, K, 0, 0, None, 0, 0, 0, L.ACT_NONE,
+                              1, 0, 1.0, None, 1, 0, split, 0, 0)
+        ps = [mk(A1, 1024, B1, 256, Chh, 256, 1000, 256, K1, 4),          # dW_hh, steps 1..     (ragged rows)
+              mk(A2, 1024, B2, 256, Chh, 256, 1000, 256, K2, 2),          # dW_hh, step 0: the SAME C
+              mk(A3, 1024, B3, 512, Cih, 500, 1000, 500, 5120, 4),        # dW_ih + both bias gradients
+              mk(A4, 512, B4, 1024, Cw, 1000, 512, 1000, 5120, 4),        # an attention-shaped product
+              mk(A3, 1024, B3, 512, Cpad, 500, 1024, 500, 5120, 3)]       # padded gate blocks: 4 x 256 rows computed, 4 x 250 stored
+        ps[2].colsum_out, ps[2].colsum_out2 = b1.data_ptr(), b2.data_ptr()
+        ps[4].c_row_blk, ps[4].c_row_valid = 256, 250
+        return ps
+
+    def buffers():
+        return (torch.zeros(1000, 256, device="cuda"), torch.zeros(1000, 500, device="cuda"), torch.zeros(512, 1000, device="cuda"),
+                torch.zeros(1008, device="cuda"), torch.zeros(1008, device="cuda"), torch.zeros(1000, 500, device="cuda"))
+    one, grp = buffers(), buffers()
+    ps1, psg = problems(*one), problems(*grp)
+    for a in ps1:
+        L.check(lib.vmmt_gemm(C.byref(a), None), "gemm")
+    arr = (L.GemmArgs * len(psg))(*psg)
+    assert lib.vmmt_gemm_group_applies(arr, len(psg)) == 1
+    L.check(lib.vmmt_gemm_group(arr, len(psg), None), "gemm_group")
+    torch.cuda.synchronize()
+    want_hh = A1[:, :1000].double().t() @ B1.double() + A2[:, :1000].double().t() @ B2.double()
+    want_ih = A3[:, :1000].double().t() @ B3[:, :500].double()
+    want_w = A4.double().t() @ B4[:, :1000].double()
+    full = A3.double().t() @ B3[:, :500].double()
+    want_pad = torch.cat([full[q * 256:q * 256 + 250] for q in range(4)])
+    want_b = A3[:, :1000].double().sum(0)
+    for name, got, want in (("hh", grp[0], want_hh), ("ih", grp[1], want_ih), ("w", grp[2], want_w), ("pad", grp[5], want_pad)):
+        err = (got.double().cpu() - want.cpu()).abs().max().item()
+        assert err <= 2e-3 * want.abs().max().item(), (name, err)                      # bf16 operands, f32 accumulation
+        # against the one-by-one launches: the same tiles and splits, another order of the atomic adds
+        one_t = one[{"hh": 0, "ih": 1, "w": 2, "pad": 5}[name]]
+        assert (got - one_t).abs().max().item() <= 1e-5 * want.abs().max().item(), name
+    for b in (grp[3], grp[4]):
+        assert (b[:1000].double().cpu() - want_b.cpu()).abs().max().item() <= 1e-4 * want_b.abs().max().item() and (b[1000:] == 0).all()
+    # a member that is not a grouped kind (no split: plain store) -> one launch per member, same numbers
+    Cs = torch.zeros(512, 1000, device="cuda")
+    mixed = [psg[3], psg[3]]
+    mixed[1] = L.GemmArgs(L.BF16, L.GEMM_TN, A4.data_ptr(), 512, B4.data_ptr(), 1024, Cs.data_ptr(), 1000, 512, 1000, 5120, 0, 0, None, 0, 0, 0,
+                          L.ACT_NONE, 1, 0, 1.0, None, 1, 0, 1, 0, 0)
+    grp[2].zero_()
+    arr2 = (L.GemmArgs * 2)(*mixed)
+    assert lib.vmmt_gemm_group_applies(arr2, 2) == 0
+    L.check(lib.vmmt_gemm_group(arr2, 2, None), "gemm_group fallback")
+    torch.cuda.synchronize()
+    for got in (grp[2], Cs):
+        assert (got.double().cpu() - want_w.cpu()).abs().max().item() <= 2e-3 * want_w.abs().max().item()

@@ -47,6 +47,9 @@ def test_gemms_fit_beside_the_persistent_recurrences(res):
     assert bwd512 + max(tn, nn, nt) <= 512, (bwd512, tn, nn, nt)
     # the encoder's directions (H = 256) leave room for every product
     assert max(fwd256, bwd256) + max(tn, nn, nt) <= 512, (fwd256, bwd256, tn, nn, nt)
+    # the grouped weight-gradient launch (vmmt_gemm_group) is a guest of the backward recurrences like the products it replaces
+    grp = _find(res, "gemm_group_kernelItLi128ELi128ELi64ELi64ELb0ELb0")
+    assert bwd512 + grp <= 512 and grp <= tn, (bwd512, grp, tn)
 
 
 def test_one_wave_per_simd_kernels_stay_within_the_file(res):

@@ -66,6 +66,8 @@ _SIGS = {
     "vmmt_stream_create_masked": (i32, [vp, i32, i32, vp]),
     "vmmt_stream_destroy": (i32, [vp]),
     "vmmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "vmmt_gemm_group": (i32, [C.POINTER(GemmArgs), i32, vp]),
+    "vmmt_gemm_group_applies": (i32, [C.POINTER(GemmArgs), i32]),
     "vmmt_lstm_step_fwd": (i32, [i32, i32, C.POINTER(LstmDirFwd), vp, i32, i32, vp]),
     "vmmt_lstm_step_bwd": (i32, [i32, i32, C.POINTER(LstmDirBwd), vp, i32, i32, i32, vp]),
     "vmmt_lstm_chain_fwd": (i32, [i32, i32, i32, C.POINTER(LstmDirFwd), vp, i32, i32, vp]),

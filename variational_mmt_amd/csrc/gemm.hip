@@ -83,15 +83,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
   }
 }
 
-template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, int GL = 0>
-__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
-gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B_, long ldb, int M, int N, int K, int a_kmod,
-            int b_kmod, int tiles_n, int kper, GemmEpi epi) {
+// one output tile of one product: `tile` = its index among the product's tiles, `split` = which part of the reduction
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK, bool DB, int GL>
+__device__ __forceinline__ void gemm_tile(const T* __restrict__ A, long lda, const T* __restrict__ B_, long ldb, int M, int N, int K, int a_kmod,
+                                          int b_kmod, int tiles_n, int kper, GemmEpi& epi, const int tile, const int split) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr int TI = WM / 32, TJ = WN / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   // per-row-block B (vmmt_gemm_args.b_batch_rows): every row of a tile belongs to one block (checked by vmmt_gemm)
@@ -111,7 +110,7 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B_, long ld
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   LinearMap amap{m0, M}, bmap{n0, N};
-  const int kbeg = blockIdx.y * kper;                 // split-K: this block reduces over [kbeg, kend)
+  const int kbeg = split * kper;                      // split-K: this block reduces over [kbeg, kend)
   const int kend = min(K, kbeg + kper);
   if constexpr (GL == 3) {   // LDS-DMA main loops (glds_gemm.hpp); preconditions checked by launch_layout
     // the weighted column sums of A ride along in the workgroups of the first column tile (one pass over A per launch)
@@ -129,8 +128,48 @@ gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B_, long ld
     gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ, LinearMap, LinearMap, DB>(A, lda, amap, B, ldb, bmap, kend, a_kmod,
                                                                                     b_kmod, aoff, boff, acc, smem, kbeg);
   }
-  if (blockIdx.y != 0) epi.add_rows = 0;             // the addend is added once
+  if (split != 0) epi.add_rows = 0;                  // the addend is added once
   gemm_epilogue<T, TI, TJ>(epi, acc, aoff, boff, m0, n0, M, N, lane);
+}
+
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, int GL = 0>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64)
+gemm_kernel(const T* __restrict__ A, long lda, const T* __restrict__ B_, long ldb, int M, int N, int K, int a_kmod,
+            int b_kmod, int tiles_n, int kper, GemmEpi epi) {
+  gemm_tile<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB, GL>(A, lda, B_, ldb, M, N, K, a_kmod, b_kmod, tiles_n, kper, epi,
+                                                       xcd_remap(blockIdx.x, gridDim.x), blockIdx.y);
+}
+
+// ---- GROUPED launch: the tiles of up to VMMT_GEMM_GROUP_MAX independent products in ONE grid (vmmt_gemm_group).  The weight-gradient
+// products of an LSTM layer (dW_hh and dW_ih of each direction, ~20 us each on a quarter of the chip) used to be five launches on two
+// streams at the end of the backward pass; as one grid of ~400 workgroups they are a single round on the 256 CUs.  The descriptors
+// travel in the kernel-argument segment (uniform: scalar loads); a workgroup finds its product by comparing its index with the
+// products' first-workgroup table.
+struct GemmGroupItem {
+  const void* A; long lda; const void* B; long ldb;
+  int M, N, K, tiles_n, ntiles, kper;
+  GemmEpi epi;
+};
+struct GemmGroupArgs {
+  int n;
+  int start[VMMT_GEMM_GROUP_MAX + 1];          // first workgroup of product i; start[n] = the grid
+  GemmGroupItem item[VMMT_GEMM_GROUP_MAX];
+};
+
+template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK, bool DB, int GL>
+__global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_group_kernel(const GemmGroupArgs ga) {
+  const int bid = blockIdx.x;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < VMMT_GEMM_GROUP_MAX; ++i)
+    if (i < ga.n && bid >= ga.start[i]) g = i;
+  g = __builtin_amdgcn_readfirstlane(g);
+  const GemmGroupItem& it = ga.item[g];
+  const int local = bid - ga.start[g];
+  const int split = local / it.ntiles, tl = local - split * it.ntiles;
+  GemmEpi epi = it.epi;
+  gemm_tile<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB, GL>((const T*)it.A, it.lda, (const T*)it.B, it.ldb, it.M, it.N, it.K, 0, 0, it.tiles_n,
+                                                       it.kper, epi, xcd_remap(tl, it.ntiles), split);
 }
 
 template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 32, bool DB = true, int GL = 0>
@@ -206,6 +245,8 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
 int gemm_launch_nt(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st);
 int gemm_launch_tn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st);
 int gemm_launch_nn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st);
+int gemm_group_launch_tn(const vmmt_gemm_args* args, const GemmEpi* epis, int n, hipStream_t st);
+bool gemm_group_ok_tn(const vmmt_gemm_args* a);
 
 template <bool A_KC, bool B_KC>
 static int launch_by_dtype(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) {
@@ -218,6 +259,50 @@ int gemm_launch_nt(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) 
 #endif
 #if VMMT_GEMM_PART == -1 || VMMT_GEMM_PART == 1
 int gemm_launch_tn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) { return launch_by_dtype<false, false>(a, epi, st); }
+
+// would launch_layout run this TN product on the two-stage 128 x 128 LDS-DMA configuration?  (the grouped kernel is that configuration)
+static bool group_member_ok(const vmmt_gemm_args* a) {
+  if (a->dtype != VMMT_BF16 || a->layout != VMMT_GEMM_TN || a->scatter_ids || !a->out_f32 || a->act != VMMT_ACT_NONE || a->addend) return false;
+  if (a->b_batch_rows || a->colsum_w || a->tile != 0 || a->M <= 0 || a->N <= 0) return false;
+  const bool gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
+                     ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
+  if (!gl_ok || a->split_k < 2) return false;                       // members accumulate with atomics: several may share one C
+  const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128) * a->split_k;
+  return !(t128 >= 768 && a->K >= 512);                             // (that one takes the 256 x 128 three-stage configuration)
+}
+
+int gemm_group_launch_tn(const vmmt_gemm_args* args, const GemmEpi* epis, int n, hipStream_t st) {
+  constexpr int BM = 128, BN = 128, BK = 64;
+  GemmGroupArgs ga;
+  ga.n = n;
+  int start = 0;
+  for (int i = 0; i < n; ++i) {
+    const vmmt_gemm_args* a = &args[i];
+    GemmGroupItem& it = ga.item[i];
+    const int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
+    int splits = a->split_k;
+    int kper = ((a->K + splits - 1) / splits + BK - 1) / BK * BK;
+    if (kper < BK) kper = BK;
+    splits = (a->K + kper - 1) / kper;
+    it.A = a->A; it.lda = (long)a->lda; it.B = a->B; it.ldb = (long)a->ldb;
+    it.M = a->M; it.N = a->N; it.K = a->K; it.tiles_n = tn; it.ntiles = tm * tn; it.kper = kper;
+    it.epi = epis[i];
+    it.epi.atomic = 1;
+    ga.start[i] = start;
+    start += tm * tn * splits;
+  }
+  for (int i = n; i <= VMMT_GEMM_GROUP_MAX; ++i) ga.start[i] = start;
+  const size_t smem = (size_t)glds_smem_bytes<BM, BN>();
+  static bool allowed = false;
+  if (!allowed) {
+    (void)hipFuncSetAttribute((const void*)gemm_group_kernel<bf16_t, 128, 128, 64, 64, false, false, 64, true, 1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    allowed = true;
+  }
+  hipLaunchKernelGGL((gemm_group_kernel<bf16_t, 128, 128, 64, 64, false, false, 64, true, 1>), dim3(start), dim3(256), smem, st, ga);
+  return check_launch();
+}
+bool gemm_group_ok_tn(const vmmt_gemm_args* a) { return group_member_ok(a); }
 #endif
 #if VMMT_GEMM_PART == -1 || VMMT_GEMM_PART == 2
 int gemm_launch_nn(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st) { return launch_by_dtype<true, false>(a, epi, st); }
@@ -243,13 +328,12 @@ extern "C" int vmmt_gemm_colsum_applies(const vmmt_gemm_args* a) {
   return (t128path && !big) ? 1 : 0;
 }
 
-extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
+// validates the arguments and fills the kernel-side epilogue description; VMMT_OK, or VMMT_EINVAL
+static int gemm_make_epi(const vmmt_gemm_args* a, vmmt::GemmEpi& e) {
   using namespace vmmt;
   if (!a || !a->A || !a->B || !a->C || a->M < 0 || a->N < 0 || a->K < 0) return VMMT_EINVAL;
-  if (a->M == 0 || a->N == 0) return VMMT_OK;
   if (a->scatter_ids && !a->out_f32) return VMMT_EINVAL;
   if (a->split_k > 1 && (!a->out_f32 || a->act != VMMT_ACT_NONE || a->scatter_ids)) return VMMT_EINVAL;
-  GemmEpi e;
   e.C = a->C; e.ldc = a->ldc; e.addend = a->addend; e.ld_add = a->ld_add; e.add_rows = a->addend ? a->add_rows : 0;
   e.add_is_T = a->add_is_T; e.act = a->act; e.out_f32 = a->out_f32; e.accumulate = a->accumulate;
   e.alpha = a->alpha; e.scatter_ids = (const long long*)a->scatter_ids; e.pad_id = a->pad_id;
@@ -263,6 +347,15 @@ extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
   if (e.rblk && a->colsum_w) return VMMT_EINVAL;                 // the weighted sums (generator bias) have no padded blocks
   if ((a->colsum_w || a->colsum_out || a->colsum_out2) && (!a->colsum_out || !vmmt_gemm_colsum_applies(a))) return VMMT_EINVAL;
   if (a->b_batch_rows < 0 || (a->b_batch_rows > 0 && a->b_batch_rows % 256 != 0)) return VMMT_EINVAL;   // whole tiles (<= 256 rows) per block
+  return VMMT_OK;
+}
+
+extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
+  using namespace vmmt;
+  GemmEpi e;
+  const int rc = gemm_make_epi(a, e);
+  if (rc != VMMT_OK) return rc;
+  if (a->M == 0 || a->N == 0) return VMMT_OK;
   hipStream_t st = (hipStream_t)stream;
   switch (a->layout) {
     case VMMT_GEMM_NT: return gemm_launch_nt(a, e, st);
@@ -270,5 +363,32 @@ extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {
     case VMMT_GEMM_NN: return gemm_launch_nn(a, e, st);
     default: return VMMT_EINVAL;
   }
+}
+
+// n independent products, results as n vmmt_gemm calls in any order (members ACCUMULATE into C with atomics: split_k >= 2).  When every
+// member is a bf16 TN product of the two-stage 128 x 128 configuration (what the weight-gradient products of the LSTM / attention layers
+// are) their tiles go out as ONE grid; otherwise one launch per member.
+extern "C" int vmmt_gemm_group(const vmmt_gemm_args* args, int n, void* stream) {
+  using namespace vmmt;
+  if (!args || n < 0) return VMMT_EINVAL;
+  if (n == 0) return VMMT_OK;
+  GemmEpi epis[VMMT_GEMM_GROUP_MAX];
+  bool grouped = n >= 2 && n <= VMMT_GEMM_GROUP_MAX;
+  for (int i = 0; i < n && grouped; ++i) {
+    if (gemm_make_epi(&args[i], epis[i]) != VMMT_OK) return VMMT_EINVAL;
+    grouped = gemm_group_ok_tn(&args[i]);
+  }
+  if (grouped) return gemm_group_launch_tn(args, epis, n, (hipStream_t)stream);
+  for (int i = 0; i < n; ++i) {
+    const int rc = vmmt_gemm(&args[i], stream);
+    if (rc != VMMT_OK) return rc;
+  }
+  return VMMT_OK;
+}
+extern "C" int vmmt_gemm_group_applies(const vmmt_gemm_args* args, int n) {
+  if (!args || n < 2 || n > VMMT_GEMM_GROUP_MAX) return 0;
+  for (int i = 0; i < n; ++i)
+    if (!vmmt::gemm_group_ok_tn(&args[i])) return 0;
+  return 1;
 }
 #endif

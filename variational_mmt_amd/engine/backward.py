@@ -263,12 +263,14 @@ class BackwardPlan(object):
         else:
             main_head()
         e._sid = SIDE
+        grp = [] if (e.group_wgrads and dt == L.BF16) else None          # the two attention weight gradients: one grid
         e._wait(P, "dPre")
         e._gemm(P, L.GEMM_TN, self.dPre.p(), self.dPre.ld, self.cat.p(), self.cat.ld, e.gp("decoder.attn.linear_out.weight"), 2 * H,
-                H, 2 * Hp, M, out_f32=1, split_k=-1, cmap=(Hp, H))
+                H, 2 * Hp, M, out_f32=1, split_k=-1, cmap=(Hp, H), group=grp)
         e._wait(P, "dQ")
         e._gemm(P, L.GEMM_TN, self.dQ.p(), self.dQ.ld, self.cat.p(0, Hp), self.cat.ld, e.gp("decoder.attn.linear_in.weight"), H,
-                H, H, M, out_f32=1, split_k=-1)
+                H, H, M, out_f32=1, split_k=-1, group=grp)
+        e._gemm_group(P, grp)
         # the decoder's parameter gradients and the first-half norm go to the AUX stream, which is idle once its own chain (image /
         # q(z|x) networks) is through: behind the generator's products on the side stream they reached into the step's tail
         dec_on_aux = bool(e.dec_grads_on_aux and not rp and not d.conditional and e.use_aux_stream)
@@ -317,16 +319,19 @@ class BackwardPlan(object):
             e._sid = AUX if dec_on_aux else SIDE
             e._wait(P, "dec_dg%d" % l)
             gw = "decoder.rnn.weight_hh_l%d" % l
+            grp = [] if (e.group_wgrads and dt == L.BF16) else None      # dW_hh (two pieces) and dW_ih of the layer: one grid
             if Tp > 1:
                 e._gemm(P, L.GEMM_TN, dg.p(B), dg.ld, outb.p(0, ocol), outb.ld, e.gp(gw), H, 4 * Hp, H, (Tp - 1) * B, out_f32=1, split_k=-1,
-                        rmap=gmap_d)
-            e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * Hp, H, B, out_f32=1, split_k=-1, rmap=gmap_d)
+                        rmap=gmap_d, group=grp)
+            e._gemm(P, L.GEMM_TN, dg.p(0), dg.ld, self.hn[l].p(), self.hn[l].ld, e.gp(gw), H, 4 * Hp, H, B, out_f32=1, split_k=-1, rmap=gmap_d,
+                    group=grp)
             gi = "decoder.rnn.weight_ih_l%d" % l
             # the bias gradient (column sums of dgates) rides in the dW_ih product, which reads all M rows of dgates anyway
             bsum = (None, 0, e.gp("decoder.rnn.bias_ih_l%d" % l), e.gp("decoder.rnn.bias_hh_l%d" % l)) if e.lstm_db_in_gemm else None
             if l == 0:
                 fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * Hp, E, M, out_f32=1, split_k=-1,
-                                  colsum=bsum, rmap=gmap_d)
+                                  colsum=bsum, rmap=gmap_d, group=grp)
+                e._gemm_group(P, grp)
                 e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * Hp, Z, M, out_f32=1, split_k=-1, b_kmod=B,
                         rmap=gmap_d)
                 we = e.sh["dec_wih_l0_e"]
@@ -337,7 +342,8 @@ class BackwardPlan(object):
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * Hp, H, M, out_f32=1, split_k=-1, colsum=bsum,
-                                  rmap=gmap_d)
+                                  rmap=gmap_d, group=grp)
+                e._gemm_group(P, grp)
             if not fused_b:
                 e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * Hp, Hp if Hp != H else 0, H, e.gp("decoder.rnn.bias_ih_l%d" % l),
                         e.gp("decoder.rnn.bias_hh_l%d" % l))
@@ -384,9 +390,18 @@ class BackwardPlan(object):
             xin = (self.Xs if l == 0 else (self.enc_xdrop[l - 1] if drop else self.enc_out[l - 1]))
             xcols = E if l == 0 else H
             tog = [e._sid]
+            grp = [] if (e.group_wgrads and dt == L.BF16) else None      # dW_hh and dW_ih of both directions: one grid on the side stream
+            if grp is not None and l == 0:
+                # ... next to the embedding product, which goes out FIRST on the main stream (the grid of the group fills the chip)
+                assert all(r == (0, S) for r in ranges)
+                e._sid = MAIN
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.dXs.p(), self.dXs.ld, MS, E, dirs * 4 * Hdp, out_f32=1)
+                e._call(P, lib.vmmt_scatter_add_rows, self.dXs.p(), self.dXs.ld, self.src.data_ptr(), PAD,
+                        e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E, MS, E)
+                e._sid = SIDE
 
             def alt():
-                if alternate:
+                if alternate and grp is None:
                     tog[0] = MAIN if tog[0] == SIDE else SIDE
                     e._sid = tog[0]
             for k, suf in enumerate([""] + (["_reverse"] if d.brnn else [])):
@@ -397,20 +412,21 @@ class BackwardPlan(object):
                     t0 = max(lo, 1)
                     if hi > t0:
                         e._gemm(P, L.GEMM_TN, dg.p(t0 * B, k * 4 * Hdp), dg.ld, self.enc_out[l].p((t0 - 1) * B, k * Hdp), self.enc_out[l].ld,
-                                e.gp(gw), Hd, 4 * Hdp, Hd, (hi - t0) * B, out_f32=1, split_k=-1, rmap=gmap_e)
+                                e.gp(gw), Hd, 4 * Hdp, Hd, (hi - t0) * B, out_f32=1, split_k=-1, rmap=gmap_e, group=grp)
                 else:           # h_prev[t] = out[t+1]: t in [lo, min(hi, S-1))
                     t1 = min(hi, S - 1)
                     if t1 > lo:
                         e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hdp), dg.ld, self.enc_out[l].p((lo + 1) * B, k * Hdp), self.enc_out[l].ld,
-                                e.gp(gw), Hd, 4 * Hdp, Hd, (t1 - lo) * B, out_f32=1, split_k=-1, rmap=gmap_e)
+                                e.gp(gw), Hd, 4 * Hdp, Hd, (t1 - lo) * B, out_f32=1, split_k=-1, rmap=gmap_e, group=grp)
                 alt()           # (alternating: main = the two dW_hh and the embedding product behind them, side = dW_ih + bias sums)
                 bih, bhh = e.gp("encoder.rnn.bias_ih_l%d%s" % (l, suf)), e.gp("encoder.rnn.bias_hh_l%d%s" % (l, suf))
                 fused_b = e._gemm(P, L.GEMM_TN, dg.p(lo * B, k * 4 * Hdp), dg.ld, xin.p(lo * B), xin.ld, e.gp("encoder.rnn.weight_ih_l%d%s" % (l, suf)),
                                   xcols, 4 * Hdp, xcols, (hi - lo) * B, out_f32=1, split_k=-1, rmap=gmap_e,
-                                  colsum=(None, 0, bih, bhh) if e.lstm_db_in_gemm else None)      # bias gradient: see the decoder's
+                                  colsum=(None, 0, bih, bhh) if e.lstm_db_in_gemm else None, group=grp)      # bias gradient: see the decoder's
                 if not fused_b:
                     e._call(P, lib.vmmt_colsum, dt, dg.p(lo * B, k * 4 * Hdp), dg.ld, (hi - lo) * B, 4 * Hdp, Hdp if Hdp != Hd else 0, Hd, bih, bhh)
-            if l == 0:                                # embedding gradient: one product over both directions, last on the main stream
+            e._gemm_group(P, grp)
+            if l == 0 and grp is None:                # embedding gradient: one product over both directions, last on the main stream
                 assert all(r == (0, S) for r in ranges)
                 e._sid = MAIN
                 # (as the GEMM's own atomic epilogue the scatter costs 47 us on top of a 28 us product in isolation; in the step the two

@@ -82,6 +82,8 @@ class Engine(StepAPI):
         self.dec_grads_on_aux = _os_env.get("VMMT_DEC_GRADS_ON_AUX", "1") == "1"
         self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
         self.bwd_layers_parallel = _os_env.get("VMMT_BWD_LAYERS_PARALLEL", "1") == "1"   # >= 2 layers: top encoder layer next to the lower decoder layers
+        # the weight-gradient products of a layer (dW_hh / dW_ih of each direction; attention's two) as ONE grid each (vmmt_gemm_group)
+        self.group_wgrads = _os_env.get("VMMT_GROUP_WGRADS", "1") == "1"
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self._compute_stream = None
@@ -430,13 +432,16 @@ class Engine(StepAPI):
     # ------------------------------------------------------------------------------------------------ helpers
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
               act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
-              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None):
+              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None, group=None):
         """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out[, out2]): the column sums of the K-strided A operand from the same
-        pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached"""
+        pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached.
+        group (a list): the product is not issued but collected -- _gemm_group() sends the list out as ONE grid (vmmt_gemm_group)"""
         if split_k == -1:
             # weight-gradient heuristic: enough workgroups to fill 256 CUs, >= 256 reduction steps each, at most max_split_k splits
             tiles = ((M + 63) // 64) * ((N + 63) // 64)
             split_k = max(1, min(K // 256, (1024 + tiles - 1) // tiles, int(self.max_split_k)))
+            if group is not None and K >= 128:
+                split_k = max(2, split_k)       # members of a grouped launch accumulate with atomics (several may share one C)
             if split_k == 1:
                 accumulate = 1          # gradients always ACCUMULATE into the arena (zeroed at the start of a step)
         if a_kmod == 0 and b_kmod == 0:
@@ -456,8 +461,25 @@ class Engine(StepAPI):
             attached = bool(self.lib.vmmt_gemm_colsum_applies(C.byref(a)))
             if not attached:
                 a.colsum_w, a.colsum_w_stride, a.colsum_out, a.colsum_out2 = None, 0, None, None
+        if group is not None:
+            group.append(a)
+            return attached
         plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
         return attached
+
+    def _gemm_group(self, plan, group):
+        """plan entry: the products collected in `group` (_gemm(group=)) as one vmmt_gemm_group call -- one grid where the library
+        groups them (bf16 weight-gradient products on 128 x 128 tiles), one launch per product otherwise"""
+        if not group:
+            return
+        if len(group) == 1 or len(group) > 8:
+            for a in group:
+                plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
+            return
+        arr = (L.GemmArgs * len(group))()
+        for i, a in enumerate(group):
+            C.memmove(C.byref(arr, i * C.sizeof(L.GemmArgs)), C.byref(a), C.sizeof(L.GemmArgs))
+        plan.append((self.lib.vmmt_gemm_group, (arr, len(group)), "gemm_group", arr, self._sid))
 
     def _call(self, plan, fn, *args):
         # plan entries are positional ctypes calls: at least the COUNT is checked against the declared signature when the plan is built
