@@ -257,6 +257,11 @@ class BackwardPlan(object):
             if not fuse_db:
                 e._call(P, lib.vmmt_rowsum, dt, self.GT.p(), self.GT.ld, V, M, e.gp("generator.0.bias"))
         e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
+        # the generator's share of the gradient norm (a quarter of the arena) right behind its product, on this stream, instead of in the
+        # norm of the whole first half at the end of the decoder's parameter gradients (slot 7: free outside the conditional model)
+        gen_norm_early = bool(not d.conditional and not e.rows_active() and _os_env.get("VMMT_GEN_NORM_EARLY", "1") == "1")
+        if gen_norm_early:
+            e._sumsq_entry(P, "generator.0.weight", "decoder.attn.linear_out.weight", 7)
         if main_first:
             if not aux_before_side:
                 aux_chain()
@@ -274,8 +279,6 @@ class BackwardPlan(object):
         # the decoder's parameter gradients and the first-half norm go to the AUX stream, which is idle once its own chain (image /
         # q(z|x) networks) is through: behind the generator's products on the side stream they reached into the step's tail
         dec_on_aux = bool(e.dec_grads_on_aux and not rp and not d.conditional and e.use_aux_stream)
-        if dec_on_aux:
-            e._record(P, "side_first")              # generator + attention products issued on the side stream
         # ================= decoder LSTM backward (main) + its parameter gradients (side / aux) ====================
         dh_above = self.dR
         for l in reversed(range(Lyr)):
@@ -329,16 +332,30 @@ class BackwardPlan(object):
             # the bias gradient (column sums of dgates) rides in the dW_ih product, which reads all M rows of dgates anyway
             bsum = (None, 0, e.gp("decoder.rnn.bias_ih_l%d" % l), e.gp("decoder.rnn.bias_hh_l%d" % l)) if e.lstm_db_in_gemm else None
             if l == 0:
-                fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * Hp, E, M, out_f32=1, split_k=-1,
-                                  colsum=bsum, rmap=gmap_d, group=grp)
-                e._gemm_group(P, grp)
-                e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * Hp, Z, M, out_f32=1, split_k=-1, b_kmod=B,
-                        rmap=gmap_d)
+                if self.z_in_Xt:
+                    # dW_ih [4H][E + Z] = dgates^T [emb ; z]: one product over the rows of Xt (z repeated over the steps from column Ep on);
+                    # the column blocks [0, Ep) / [Ep, Ep + Z) land at columns [0, E) / [E, E + Z) of the gradient
+                    fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * Hp, self.Ep + Z, M, out_f32=1,
+                                      split_k=-1, colsum=bsum, rmap=gmap_d, cmap=(self.Ep, E), group=grp)
+                    e._gemm_group(P, grp)
+                else:
+                    fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.Xt.p(), self.Xt.ld, e.gp(gi, 0, 0), E + Z, 4 * Hp, E, M, out_f32=1, split_k=-1,
+                                      colsum=bsum, rmap=gmap_d, group=grp)
+                    e._gemm_group(P, grp)
+                    e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, self.zT.p(), self.zT.ld, e.gp(gi, 0, E), E + Z, 4 * Hp, Z, M, out_f32=1, split_k=-1, b_kmod=B,
+                            rmap=gmap_d)
                 we = e.sh["dec_wih_l0_e"]
-                # dX = dgates W_e, then its rows scattered into the embedding gradient (pad row dropped)
+                # dX = dgates W_e, then its rows scattered into the embedding gradient (pad row dropped) -- on the SIDE stream, idle while
+                # the encoder's backward recurrence runs, next to this stream's weight gradients instead of behind them
+                dxt_side = dec_on_aux and _os_env.get("VMMT_DXT_ON_SIDE", "1") == "1"
+                if dxt_side:
+                    e._sid = SIDE
+                    e._wait(P, "dec_dg%d" % l)
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, self.dXt.p(), self.dXt.ld, M, E, 4 * Hp, out_f32=1)
                 e._call(P, lib.vmmt_scatter_add_rows, self.dXt.p(), self.dXt.ld, self.tgt_in.data_ptr(), PAD,
                         e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E, M, E)
+                if dxt_side:
+                    e._sid = AUX
             else:
                 xin = self.dec_xdrop[l - 1] if drop else self.dec_out[l - 1]
                 fused_b = e._gemm(P, L.GEMM_TN, dg.p(), dg.ld, xin.p(), xin.ld, e.gp(gi), H, 4 * Hp, H, M, out_f32=1, split_k=-1, colsum=bsum,
@@ -359,12 +376,15 @@ class BackwardPlan(object):
                     self.gate.data_ptr(), e.pp("inf_net_image.gate_affine_transform.weight"), self.dz.p(), B, Z)
             kl_and_q_backward()
         e._sid = SIDE
+        if dec_on_aux:
+            e._record(P, "side_first")              # generator + attention products and the target-embedding gradient issued on the side stream
 
         def finish_first_half():
             e._allreduce(P, "decoder.attn.linear_out.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1))
-            # gradient norm of everything that is final by now (generator, attention, decoder, inference networks): off the
-            # critical path, underneath the encoder chain
-            e._sumsq_entry(P, "generator.0.weight", "encoder.rnn.weight_ih_l%d" % (Lyr - 1), 0)
+            # gradient norm of everything that is final by now (attention, decoder, inference networks; the generator's went out behind
+            # its own product): off the critical path, underneath the encoder chain
+            e._sumsq_entry(P, "decoder.attn.linear_out.weight" if gen_norm_early else "generator.0.weight",
+                           "encoder.rnn.weight_ih_l%d" % (Lyr - 1), 0)
             e._wait(P, "aux_done")
             e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None, 2)
         if dec_on_aux:

@@ -53,7 +53,14 @@ class Workspace(BackwardPlan, ConditionalPlans):
         self.zT = nb(B, Z)
         self.kl_b = torch.zeros(B, dtype=f32, device=dev)
         # decoder
-        self.Xt = nb(M, E)
+        # target embeddings [M][E], and -- in the same rows, from column Ep on -- the sample z repeated over the decoder steps: the
+        # backward's dW_ih = dgates^T [emb ; z] (VI_Model1.py:99-100: the decoder input is the concatenation) is then ONE product over
+        # the rows of this buffer instead of a second one that walks z with a row modulus (2.6 MB at the benchmark shape; the FORWARD
+        # still adds z W_z once per sentence and never reads these columns)
+        self.Ep = _ru(E, KPAD)
+        self.z_in_Xt = bool(Z <= E) and _os_env.get("VMMT_Z_IN_XT", "1") == "1"
+        self.Xt = nb(M, E, ld=self.Ep + _ru(Z, KPAD)) if self.z_in_Xt else nb(M, E)
+        self.zrep_ids = (torch.arange(M, dtype=i64) % B).to(dev) if self.z_in_Xt else None
         self.zx = nb(B, 4 * Hp, f32)
         self.dec_gx = [nb(M, 4 * Hp, f32) for _ in range(Lyr)]
         self.dec_gates = [nb(M, 4 * Hp) for _ in range(Lyr)]
@@ -317,6 +324,8 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._record(P, "z_ready")
         e._sid = SIDE
         e._wait(P, "z_ready")
+        if training and self.z_in_Xt:       # z over the decoder steps next to the target embeddings (see Xt): for the backward's dW_ih
+            e._call(P, lib.vmmt_gather_rows, dt, self.z32.p(), self.z32.ld, self.zrep_ids.data_ptr(), self.Xt.p(0, self.Ep), self.Xt.ld, M, Z)
         e._call(P, lib.vmmt_gate_fwd, dt, self.z32.p(), e.pp("inf_net_image.gate_affine_transform.weight"),
                 e.pp("inf_net_image.gate_affine_transform.bias"), self.gate.data_ptr(), self.zt.p(), self.zt.ld, B, Z)
         w1, w2 = e.sh["iv_w1"], e.sh["iv_w2"]
