@@ -206,7 +206,7 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
   // 64 x 64 configuration, so for long reductions it is also the lower-LATENCY choice when there are fewer tiles than CUs
   // (M = 256 products of the inference networks at K = 2048: 20 us instead of 26-32 us); below K = 1024 the 64 x 64
   // configuration starts faster (tools/gemm_ab.py).
-  if (a->tile == 128 || a->tile == VMMT_TILE_128_ONE_PER_CU || (a->tile == 0 && (t128 >= 192 || (gl_ok && a->K >= 1024 && t128 >= 8)))) {
+  if (a->tile == 128 || a->tile == 256 || a->tile == VMMT_TILE_128_ONE_PER_CU || (a->tile == 0 && (t128 >= 192 || (gl_ok && a->K >= 1024 && t128 >= 8)))) {
     // ONE_PER_CU: an 88-KiB LDS request admits one workgroup per CU (2 x 88 > 160 KiB) and leaves 72 KiB plus half of the
     // registers for a 64-KiB workgroup of another stream (the LSTM step kernels of the critical path)
     const size_t lds_min = a->tile == VMMT_TILE_128_ONE_PER_CU ? 88 * 1024 : 0;
@@ -218,7 +218,7 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
       // (column sums of A: weighted ones ride in the 256 x 128 loop, plain ones in the two-stage 128 x 128 loop; anything else is
       //  refused -- vmmt_gemm_colsum_applies() says beforehand which it will be)
       const bool cs_w = epi.colsum_w != nullptr, cs_1 = epi.colsum_out != nullptr && !cs_w;
-      if (gl_ok && lds_min == 0 && a->tile == 0 && t128 >= 768 && a->K >= 512) {
+      if (gl_ok && lds_min == 0 && ((a->tile == 0 && t128 >= 768) || a->tile == 256) && a->K >= 512) {   // (tile = 256: forced, tools / large weight gradients)
         if (cs_1) return VMMT_EINVAL;
         return launch_cfg<T, 256, 128, 64, 64, A_KC, B_KC, 64, true, 3>(a, epi, st);
       }

@@ -73,6 +73,7 @@ class Engine(StepAPI):
         # the extra workgroups and atomics get in the way of everything that runs next to them (tools/ab.py, ms per step by cap: 64:
         # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)
         self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
+        self.wgrad_target_tiles = int(_os_env.get("VMMT_WGRAD_TARGET_TILES", "1024"))     # 64 x 64 output tiles x splits a weight-gradient product aims at
         self.cond_aux_early = _os_env.get("VMMT_COND_AUX_EARLY", "1") == "1"
         self.cond_emb_fg = _os_env.get("VMMT_COND_EMB_FG", "1") == "1"
         self.aux_early = _os_env.get("VMMT_AUX_EARLY", "1") == "1"
@@ -439,9 +440,14 @@ class Engine(StepAPI):
         if split_k == -1:
             # weight-gradient heuristic: enough workgroups to fill 256 CUs, >= 256 reduction steps each, at most max_split_k splits
             tiles = ((M + 63) // 64) * ((N + 63) // 64)
-            split_k = max(1, min(K // 256, (1024 + tiles - 1) // tiles, int(self.max_split_k)))
+            split_k = max(1, min(K // 256, (self.wgrad_target_tiles + tiles - 1) // tiles, int(self.max_split_k)))
             if group is not None and K >= 128:
-                split_k = max(2, split_k)       # members of a grouped launch accumulate with atomics (several may share one C)
+                if split_k == 1 and 2.0 * M * N * K > 8e9:
+                    # a product that fills the chip by itself (config 5: [4096 x 1024 x 16384]) keeps its plain store -- as a member of a
+                    # group it would have to accumulate with atomics (17.65 -> 17.85 ms per step): the group is issued one by one then
+                    group.append(None)
+                else:
+                    split_k = max(2, split_k)   # members of a grouped launch accumulate with atomics (several may share one C)
             if split_k == 1:
                 accumulate = 1          # gradients always ACCUMULATE into the arena (zeroed at the start of a step)
         if a_kmod == 0 and b_kmod == 0:
@@ -472,7 +478,9 @@ class Engine(StepAPI):
         groups them (bf16 weight-gradient products on 128 x 128 tiles), one launch per product otherwise"""
         if not group:
             return
-        if len(group) == 1 or len(group) > 8:
+        solo = any(a is None for a in group)         # (a member asked to stay on its own: see _gemm)
+        group[:] = [a for a in group if a is not None]
+        if solo or len(group) == 1 or len(group) > 8:
             for a in group:
                 plan.append((self.lib.vmmt_gemm, (C.byref(a),), "gemm", a, self._sid))
             return
