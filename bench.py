@@ -555,6 +555,10 @@ def main():
                                     "gen_kernel (vocab projection + log-softmax/NLL pass, slower of fwd/bwd)"),
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         # what the sweep must read at least -- Wg once, O once (bf16) -- against which `traffic` is to be judged: the rest of
+                         # it is the softmax weights P [tokens][V] (bf16) + per-slice partials written for the dWg product, which reads P back
+                         "traffic_operands": (d.vt * d.hid + M * d.hid) * 2 if fused else None,
+                         "traffic_P_written": (M * d.vt * 2) if fused else None,
                          "ms_fwd": round(t_f, 4), "ms_bwd": round(t_b, 4),
                          "step_tflops": round(3 * fl["total"] * Bg / (dt / a.steps) / 1e12, 2)},
             "elbo_per_sentence": round(st["elbo"] / B, 4),

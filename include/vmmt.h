@@ -95,9 +95,15 @@ typedef struct vmmt_gemm_args {
                   column sums (colsum_out / colsum_out2) follow the same map */
   int c_col_blk, c_col_valid; /* the same for the N output columns (e.g. dW_out [H][2H] of GlobalAttention.py:187 from a [c ; r]
                   buffer whose halves are padded) */
+  const void* mask; int64_t ld_mask; void* C2; int64_t ldc2; /* mask != NULL: a SECOND output C2[m][n] = T(C[m][n] * mask[m][n]) from the
+                  same epilogue (T = the storage type; mask as vmmt_dropout_mask writes it): nn.Dropout behind tanh(W_o [c ; r])
+                  (onmt/VI_Model1.py:132 on top of modules/GlobalAttention.py:187-190), whose input the backward still needs.  Only
+                  where vmmt_gemm_mask_applies() returns 1 (bf16, layout NT, T output, no split / scatter / block maps); otherwise
+                  VMMT_EINVAL */
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
 int vmmt_gemm_colsum_applies(const vmmt_gemm_args* args);
+int vmmt_gemm_mask_applies(const vmmt_gemm_args* args);
 /* n independent products in one call: the same results as n vmmt_gemm calls (in any order: members must ACCUMULATE into C with
  * atomics, split_k >= 2; several may share one C).  When every member is a bf16 TN product that vmmt_gemm would run on its two-stage
  * 128 x 128 LDS-DMA tiles -- the weight-gradient products dW = dY^T X of the LSTM and attention layers, the backward of nn.LSTM /

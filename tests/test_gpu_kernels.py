@@ -629,3 +629,38 @@ def test_gemm_group_equals_separate_launches():
     torch.cuda.synchronize()
     for got in (grp[2], Cs):
         assert (got.double().cpu() - want_w.cpu()).abs().max().item() <= 2e-3 * want_w.abs().max().item()
+
+
+def test_gemm_masked_second_output():
+    """vmmt_gemm_args.mask: C = act(A B^T) and C2 = C * mask from ONE epilogue -- tanh(W_o [c ; r]) and the dropout behind it
+    (VI_Model1.py:132): bit-identical to the product followed by vmmt_mul, ragged edges untouched"""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(9)
+    T = torch.bfloat16
+    M, N, K = 5000, 500, 1024
+    A = (torch.randn(M, K, generator=g) * 0.1).to(T).cuda()
+    Bm = (torch.randn(N, K, generator=g) * 0.1).to(T).cuda()
+    ldo = 512
+    mask = torch.zeros(M, ldo, dtype=T, device="cuda")
+    L.check(lib.vmmt_dropout_mask(L.BF16, mask.data_ptr(), M * ldo, 0.5, 77, None), "mask")
+    C1, C2 = torch.full((M, ldo), 3.0, dtype=T, device="cuda"), torch.full((M, ldo), 5.0, dtype=T, device="cuda")
+    a = L.GemmArgs(L.BF16, L.GEMM_NT, A.data_ptr(), K, Bm.data_ptr(), K, C1.data_ptr(), ldo, M, N, K, 0, 0, None, 0, 0, 0, L.ACT_TANH, 0, 0, 1.0)
+    a.mask, a.ld_mask, a.C2, a.ldc2 = mask.data_ptr(), ldo, C2.data_ptr(), ldo
+    assert lib.vmmt_gemm_mask_applies(C.byref(a)) == 1
+    L.check(lib.vmmt_gemm(C.byref(a), None), "gemm")
+    # the two-pass form
+    R1, R2 = torch.full((M, ldo), 3.0, dtype=T, device="cuda"), torch.full((M, ldo), 5.0, dtype=T, device="cuda")
+    b = L.GemmArgs(L.BF16, L.GEMM_NT, A.data_ptr(), K, Bm.data_ptr(), K, R1.data_ptr(), ldo, M, N, K, 0, 0, None, 0, 0, 0, L.ACT_TANH, 0, 0, 1.0)
+    L.check(lib.vmmt_gemm(C.byref(b), None), "gemm")
+    L.check(lib.vmmt_mul(L.BF16, R1.data_ptr(), ldo, mask.data_ptr(), ldo, R2.data_ptr(), ldo, M, N, None), "mul")
+    torch.cuda.synchronize()
+    assert torch.equal(C1, R1) and torch.equal(C2[:, :N], R2[:, :N])
+    assert (C2[:, N:] == 5.0).all() and (C1[:, N:] == 3.0).all()
+    want = torch.tanh(A.float() @ Bm.float().t())
+    assert (C1[:, :N].float() - want).abs().max().item() <= 1e-2
+    kept = mask[:, :N] != 0
+    assert 0.45 < kept.float().mean().item() < 0.55 and (C2[:, :N][~kept] == 0).all()
+    # where it does not apply the library says so instead of ignoring the mask
+    a.out_f32 = 1
+    assert lib.vmmt_gemm_mask_applies(C.byref(a)) == 0 and lib.vmmt_gemm(C.byref(a), None) != 0

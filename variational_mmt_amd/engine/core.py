@@ -85,6 +85,10 @@ class Engine(StepAPI):
         self.bwd_layers_parallel = _os_env.get("VMMT_BWD_LAYERS_PARALLEL", "1") == "1"   # >= 2 layers: top encoder layer next to the lower decoder layers
         # the weight-gradient products of a layer (dW_hh / dW_ih of each direction; attention's two) as ONE grid each (vmmt_gemm_group)
         self.group_wgrads = _os_env.get("VMMT_GROUP_WGRADS", "1") == "1"
+        # the output dropout (VI_Model1.py:132) out of the epilogue of tanh(W_o [c ; r]) instead of a pass of its own (vmmt_gemm_args.mask).
+        # OPT-IN: bit-identical, and measured 10-15 us per step SLOWER than the 12-us vmmt_mul pass it removes (same box, three pairs:
+        # 1.722 / 1.722 / 1.740 against 1.715 / 1.708 / 1.724 ms) -- the second output costs the product's epilogue more than the pass
+        self.fuse_out_dropout = _os_env.get("VMMT_FUSE_OUT_DROPOUT", "0") == "1"
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self._compute_stream = None
@@ -433,7 +437,7 @@ class Engine(StepAPI):
     # ------------------------------------------------------------------------------------------------ helpers
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
               act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
-              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None, group=None):
+              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None, group=None, mask=None):
         """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out[, out2]): the column sums of the K-strided A operand from the same
         pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached.
         group (a list): the product is not issued but collected -- _gemm_group() sends the list out as ONE grid (vmmt_gemm_group)"""
@@ -460,6 +464,10 @@ class Engine(StepAPI):
             a.c_row_blk, a.c_row_valid = rmap
         if cmap is not None and cmap[0] != cmap[1]:
             a.c_col_blk, a.c_col_valid = cmap
+        if mask is not None:        # (mask, ld_mask, C2, ldc2): the dropped-out copy of the output from the same epilogue (vmmt_gemm_args.mask)
+            a.mask, a.ld_mask, a.C2, a.ldc2 = mask
+            if not self.lib.vmmt_gemm_mask_applies(C.byref(a)):
+                raise RuntimeError("vmmt_gemm: the masked second output does not apply to this product")
         attached = False
         if colsum is not None:
             a.colsum_w, a.colsum_w_stride, a.colsum_out = colsum[:3]

@@ -380,10 +380,17 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._gemm(P, L.GEMM_NT, self.cat.p(0, Hp), self.cat.ld, wa.p(), wa.ld, self.Q.p(), self.Q.ld, M, H, H)
         e._call(P, lib.vmmt_attn_fwd, dt, self.Q.p(), self.Q.ld, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.cat.p(), self.cat.ld,
                 self.probs.data_ptr(), Tp, B, S, Hp)
-        e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * Hp, act=L.ACT_TANH)
-        if drop:
+        probe = L.GemmArgs(dt, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, _ru(2 * Hp, KPAD))
+        if drop and e.fuse_out_dropout and lib.vmmt_gemm_mask_applies(C.byref(probe)):
+            # AH = tanh(W_o [c ; r]) and O = AH * mask from ONE epilogue (the mask was drawn on the side stream at the head of the step)
             e._wait(P, "out_mask")
-            e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
+            e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * Hp, act=L.ACT_TANH,
+                    mask=(self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld))
+        else:
+            e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * Hp, act=L.ACT_TANH)
+            if drop:
+                e._wait(P, "out_mask")
+                e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
         e._wait(P, "img_fwd")            # join: the loss plans read mu_v
         return P
 
