@@ -212,7 +212,7 @@ class Engine(StepAPI):
         and tail.  (The LAZY variant -- rows updated only when used, missed zero-gradient steps replayed -- saves 0.7 GB per step and
         was 1.5 % faster on the benchmark's recurring batches, but with Zipf-distributed ids the replays (sqrt + division per element
         and missed step, in front of the embedding lookup) cost more than the traffic: 2.11 against 1.92 ms through the trainer.  Not
-        kept: DESIGN.md section 6.)"""
+        kept: LABNOTES.md, rounds 1-3, section 6.)"""
         names = ("encoder.embeddings.make_embedding.emb_luts.0.weight", "decoder.embeddings.make_embedding.emb_luts.0.weight")
         self._row_adam = _os_env.get("VMMT_ROW_ADAM", "0") == "1" and not self.d.conditional
         self.row_tables = []
