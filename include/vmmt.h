@@ -326,6 +326,13 @@ int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, int dy_f32, c
  * kl_b[b] = sum_k 0.5(mu^2+sigma^2-1) - log sigma (VILoss.py:446-456); stats[KL_SUM] += sum_b kl_b. */
 int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT, int64_t ldz,
                     float* kl_b, float* stats, int B, int Z, int training, void* stream);
+/* vmmt_latent_fwd AND zx = z W_z^T + bias in one launch (bf16): the per-sentence part of the decoder LSTM's input projection -- the
+ * decoder input is [emb(y_t) ; z] at every step (onmt/VI_Model1.py:99-100), so z's share is computed once per sentence.  Same z32 / zT /
+ * kl_b / stats bits as vmmt_latent_fwd; zx f32 [B][ldzx] = what vmmt_gemm(NT, zT, wz, addend = bias, out_f32) gives.  wz: bf16 [N][ldw],
+ * k = z contiguous, zero beyond Z up to Z rounded up to 128; N % 256 == 0. */
+int vmmt_latent_zx(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT, int64_t ldz, float* kl_b,
+                   float* stats, const void* wz, int64_t ldw, const float* bias, float* zx, int64_t ldzx, int B, int Z, int N,
+                   int training, void* stream);
 /* q(z|x) forward in ONE launch: hbar = masked mean over time of the (detached) encoder memory (NormalVariationalEncoder.py:65-84),
  * h1 = relu(hbar W1^T + b1), out = h1 W2^T + b2 for the location and the scale network (:12-43; scale: Softplus), then
  * vmmt_latent_fwd's sample and KL.  bf16 only; H % 256 == 0, Z % 128 == 0, Z <= 512; returns 1 (invalid argument)

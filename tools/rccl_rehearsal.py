@@ -19,7 +19,7 @@ n = 61 * 1024 * 1024 // 4 * 4
 flat = torch.randn(n, device=dev)
 ref = flat.clone()
 s = GradSync(flat=flat, sharded=True)
-s.dist, s.world, s.rank = dist, 1, 0                     # (a world of one never attaches by itself)
+s.dist, s.world, s.rank, s.backend = dist, 1, 0, dist.get_backend()      # (a world of one never attaches by itself; or VMMT_DP_FORCE=1)
 side = torch.cuda.Stream(device=dev)
 segs = [(0, 1 << 20), (1 << 20, 15 * (1 << 20)), (15 * (1 << 20), n)]
 
@@ -60,7 +60,15 @@ def ar():
         w.wait()
 
 
+def seg_on_comm():
+    # the form the backward plan uses since round 4: a synchronous collective on the COMM stream behind its producer stream
+    for lo, hi in segs:
+        s.reduce_segment(flat, lo, hi, torch.cuda.current_stream())
+    torch.cuda.current_stream().wait_stream(s.comm_stream())
+
+
 assert s._probe("reduce_scatter", flat) and s._probe("all_gather", flat), "RCCL lacks the tensor collectives?"
+timed("reduce_segment x3 (COMM stream, synchronous ops)", seg_on_comm)
 timed("reduce_scatter_tensor x3 segments (in place)", rs)
 timed("all_gather_into_tensor x3 segments (in place)", ag)
 timed("all_reduce x3 segments (async)", ar)

@@ -112,6 +112,7 @@ _SIGS = {
     "vmmt_qnet_fwd": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp,
                             i32, i32, i32, i32, i32, i32, i32, vp]),
     "vmmt_latent_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),
+    "vmmt_latent_zx": (i32, [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
     "vmmt_latent_bwd": (i32, [i32, vp, vp, vp, f32, f32, i32, f32, f32, vp, vp, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_gate_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "vmmt_gate_bwd": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, vp]),

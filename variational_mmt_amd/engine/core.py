@@ -107,6 +107,11 @@ class Engine(StepAPI):
         self._normed = set()         # sharded data parallelism: arena segments whose shard the backward plan has normed (step.py)
         self.fused_qnet = _os_env.get("VMMT_FUSED_QNET", "1") == "1"
         self.qnet_split = _os_env.get("VMMT_QNET_SPLIT", "1") == "1"     # location / scale networks in separate workgroups (csrc/qnet.hip)
+        # sample + KL + z W_z^T + b in one launch (vmmt_latent_zx).  OPT-IN: same bits, and 20 us per step SLOWER than the two launches it
+        # replaces (1.727 / 1.724 / 1.720 against 1.709 / 1.702 / 1.701 ms, same box): 128 workgroups walking 16 sentences each are a
+        # longer chain of dependent memory round trips than 256 one-sentence workgroups + a GEMM, and the sample -- which the side
+        # and aux streams wait for -- comes later.  A launch boundary costs less here than one more round trip inside a kernel
+        self.fuse_latent_zx = _os_env.get("VMMT_LATENT_ZX", "0") == "1"
         self.gen_fused = _os_env.get("VMMT_GEN_FUSED", "1") == "1"       # csrc/generator_fused.hip where it applies (bf16, H = 512 / 256)
         # decode.py: a decoded position as ONE hipGraph, replayed -- built, bit-identical, and measured SLOWER than issuing its ~15 launches
         # one by one (tools/decode_bench.py, ms per 24 positions, graph / plain: beam 5 x 30 sentences 3.87 / 3.62, arg-max x 256 3.68 / 2.92:

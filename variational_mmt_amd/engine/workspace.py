@@ -289,7 +289,16 @@ class Workspace(BackwardPlan, ConditionalPlans):
                     self.hbar.ld, self.q_h1["location"].p(), self.q_h1["scale"].p(), self.q_h1["location"].ld, self.mu.p(),
                     self.sigma.p(), self.z32.p(), self.zT.p(), self.zT.ld, self.kl_b.data_ptr(), self.stats.data_ptr(), B, S, Hp, Zp, Z,
                     1 if training else 0, 1 if e.qnet_split else 0)
-            if e.qnet_split:        # the two networks ran in separate workgroups: the sample and the KL in a small launch of their own
+            wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
+            self.latent_zx = bool(e.qnet_split and e.fuse_latent_zx and (4 * Hp) % 256 == 0 and wz.ld >= _ru(Z, 128))
+            if self.latent_zx:
+                # sample + KL + zx = z W_z^T + b in ONE launch (csrc/qnet.hip): between the two forward recurrences every launch boundary
+                # is exposed.  W_z is a decoder-side weight: behind the background half of the last optimiser step
+                e._wait(P, "opt_side_done")
+                e._call(P, lib.vmmt_latent_zx, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
+                        self.kl_b.data_ptr(), self.stats.data_ptr(), wz.p(), wz.ld, bsum.p(), self.zx.p(), self.zx.ld, B, Z, 4 * Hp,
+                        1 if training else 0)
+            elif e.qnet_split:      # the two networks ran in separate workgroups: the sample and the KL in a small launch of their own
                 e._call(P, lib.vmmt_latent_fwd, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
                         self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
         else:
@@ -337,9 +346,10 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._sid = MAIN
         # a6 decoder: gx[t] = emb(y_t) W_e^T (side stream, above) ; zx = z W_z^T + b is added inside the step kernel
         e._wait(P, "opt_side_done")      # decoder / attention / generator parameters + shadows of the previous update
-        wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
-        e._gemm(P, L.GEMM_NT, self.zT.p(), self.zT.ld, wz.p(), wz.ld, self.zx.p(), self.zx.ld, B, 4 * Hp, Z,
-                addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+        if not getattr(self, "latent_zx", False):
+            wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
+            e._gemm(P, L.GEMM_NT, self.zT.p(), self.zT.ld, wz.p(), wz.ld, self.zx.p(), self.zx.ld, B, 4 * Hp, Z,
+                    addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
         x, xcols = self.Xt, E
         for l in range(Lyr):
             if l == 0:
