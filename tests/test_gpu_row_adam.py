@@ -116,3 +116,33 @@ def test_engine_row_bookkeeping_equals_dense_over_many_steps(dtype):
     names = [en[2] for en in a.workspace(6, 5, 5).plan_fwd_train]
     assert names.count("vmmt_rows_mark") == 2 and names.count("vmmt_rows_zero") == 2
     assert "vmmt_rows_mark" not in [en[2] for en in a.workspace(6, 5, 5).plan_fwd_eval]
+
+
+def test_row_bookkeeping_switched_on_and_off_between_updates():
+    """`Engine.row_adam` may be set after construction: the cached launch plans carry or omit the row entries, and with the
+    bookkeeping off the dense kernels expect fully cleared table gradients -- a change drops the plans and clears the tables' gradients
+    and flags.  Six updates with the switch flipped twice against six dense updates."""
+    from variational_mmt_amd.engine import Dims, Engine
+    c = O.Cfg(vs=97, vt=89, emb=24, hid=32, z=8, layers=1, brnn=True)
+    p = O.init_params(c, seed=2)
+    a = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda", seed=1)
+    b = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda", seed=1)
+    for e in (a, b):
+        e.load_state_dict(p)
+    for step in range(6):
+        if step == 2:
+            a.row_adam = True
+            assert a.rows_active() and not a.ws                      # plans dropped
+        if step == 4:
+            a.row_adam = False
+            assert not a.rows_active() and all(int(t["flags"].sum()) == 0 for t in a.row_tables)
+        bt = O.synth_batch(c, 6, 5 + step % 3, 6 + step % 2, n_img=12, seed=70 + step, fixed_len=False)
+        for e in (a, b):
+            e.set_image_table(bt["table"])
+            ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+            e.loss_backward(ws, normalization=6)
+            e.optim_step(lr=0.01, max_grad_norm=0.5)
+    torch.cuda.synchronize()
+    n = a.n_opt
+    assert (a.flat_p[:n] - b.flat_p[:n]).abs().max().item() <= 5e-6 * max(1.0, b.flat_p[:n].abs().max().item())
+    assert (a.flat_m[:n] - b.flat_m[:n]).abs().max().item() <= 5e-6 * max(1.0, b.flat_m[:n].abs().max().item())
