@@ -567,7 +567,10 @@ def main():
         if dp_block is not None:
             out["dp"] = dp_block
         if world == 1 and not a.no_parity:
-            out["parity"] = parity_gate(dev, a.dtype, a.dropout)
+            try:
+                out["parity"] = parity_gate(dev, a.dtype, a.dropout)
+            except Exception as ex:          # the gate failing to RUN must not take the measured line with it; it is reported as such
+                out["parity"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
