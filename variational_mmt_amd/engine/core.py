@@ -69,6 +69,9 @@ class Engine(StepAPI):
         # CU still finishes before the decoder-side weights are needed.  tools/ab.py, ms per step: 4096 wgs 1.958-2.007 | 384: 1.957 |
         # 288: 1.972 | 256: 1.921-1.951 | 224: 1.908 | 192: 1.987 | 128: 2.051 | 64: 2.324 (a faster two-chunk kernel at 256: 1.98)
         self.bg_adam_blocks = int(_os_env.get("VMMT_BG_ADAM_BLOCKS", "256"))
+        # ... and of the FOREGROUND half (0 = uncapped, 4096).  Alone on the chip the kernel streams 5.6 TB/s uncapped and 6.0 TB/s from 512
+        # workgroups (tools/hbm_kernels.py: 108.5 -> 101.1 us for the 21.8 M parameters of that half)
+        self.fg_adam_blocks = int(_os_env.get("VMMT_FG_ADAM_BLOCKS", "0"))
         # cap of the weight-gradient products' split-K.  On an idle chip 4, 8 and 16 splits cost the same (tools/gemm_split.py), in the step
         # the extra workgroups and atomics get in the way of everything that runs next to them (tools/ab.py, ms per step by cap: 64:
         # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)

@@ -181,7 +181,7 @@ class StepAPI(object):
             split = self.offsets["decoder.embeddings.make_embedding.emb_luts.0.weight"][0]
 
         def adam_range(lo, hi, stream, shadow=None):
-            blocks = int(self.bg_adam_blocks) if stream != st else 0
+            blocks = int(self.bg_adam_blocks) if stream != st else int(self.fg_adam_blocks)
             if hi > lo:
                 L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
                                                 self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, lr, beta1, beta2,
