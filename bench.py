@@ -299,7 +299,29 @@ def through_trainer(a, dev, rank, world):
                "host_busy_share": round(t_host / dt, 3), "shape_buckets": buckets, "workspace_evictions": eng.ws_evictions,
                "workspace_gb": round(eng.workspace_bytes() / 2 ** 30, 2),
                "train_ppl": round(st.ppl(), 2), "elbo_per_sentence": round(st.elbo_loss / N, 3)}
-        print(json.dumps(out), flush=True)
+        emit(out)
+
+
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """From here on everything that libraries print on stdout goes to stderr (RCCL prints a version banner on stdout when its first
+    communicator comes up; MIOpen / the loader have their own lines): the run's stdout carries ONE line, the result (emit)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
 
 
 def _free_port():
@@ -359,6 +381,7 @@ def main():
     if a.gpus > 1 and "RANK" not in os.environ:
         launch_ranks(a)           # does not return
 
+    quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -375,7 +398,7 @@ def main():
             assert int(t.item()) == world
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"selftest": world}), flush=True)
+            emit({"selftest": world})
         return
     # rehearsal knobs (never set by the driver): VMMT_BENCH_ONE_GPU=1 puts every rank on cuda:0 and VMMT_BENCH_BACKEND=gloo
     # replaces RCCL, so that the N > 1 code path can be run end to end on a one-GPU box (RCCL refuses two ranks on one device)
@@ -573,7 +596,7 @@ def main():
                 out["parity"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
