@@ -4,11 +4,13 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from variational_mmt_amd.engine import Dims, Engine
 import bench
-d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.5)
+cf = bench.CONFIGS[os.environ.get("CONFIG", "2")]          # CONFIG=script BATCH=40: the run scripts' own shape and batch
+BATCH = int(os.environ.get("BATCH", "256"))
+d = Dims(vs=cf["vs"], vt=cf["vt"], emb=cf["emb"], hid=cf["hid"], z=cf["z"], img=cf["img"], layers=cf["layers"], brnn=cf["brnn"], dropout=0.5)
 eng = Engine(d, dtype="bf16", device="cuda", seed=0)
 eng.set_image_table(torch.rand(29000, d.img))
 eng.use_side_stream = os.environ.get("SIDE", "1") == "1"
-bs = bench.make_batches(d, 256, 20, 21, 29000, 4, "cuda", 1)
+bs = bench.make_batches(d, BATCH, cf["S"], cf["T"], 29000, 4, "cuda", 1)
 sync = None
 if os.environ.get("VMMT_DP_FORCE") == "1":       # the data-parallel step through RCCL with a world of one rank (SHARDED=0: replicated update)
     import torch.distributed as dist
@@ -19,7 +21,7 @@ if os.environ.get("VMMT_DP_FORCE") == "1":       # the data-parallel step throug
 def step(i):
     src, sl, tgt, idx, _tl, _ntok = bs[i % 4]
     ws = eng.forward(src, sl, tgt, idx, training=True)
-    eng.loss_backward(ws, normalization=256, batch_global=256)
+    eng.loss_backward(ws, normalization=BATCH, batch_global=BATCH)
     if sync is not None:
         sync.all_reduce()
     eng.optim_step()

@@ -266,8 +266,9 @@ class GradSync(object):
         a collective that is issued outside the step's own ordering (statistics, replica checks, checkpoints)"""
         if self.engine is not None and self.flat.is_cuda:
             self.engine.wait_background()
-            if self._comm is not None:
-                torch.cuda.current_stream(self.flat.device).wait_stream(self._comm)
+            owner = self.engine.dp if getattr(self.engine, "dp", None) is not None else self      # (the GradSync whose COMM stream the plans use)
+            for comm in {id(c): c for c in (self._comm, owner._comm) if c is not None}.values():
+                torch.cuda.current_stream(self.flat.device).wait_stream(comm)
 
     def all_gather_rows(self, row):
         """[n] on every rank -> [world][n] on every rank (the ranks' norm partials)"""
