@@ -279,10 +279,8 @@ class BackwardPlan(object):
         # the decoder's parameter gradients and the first-half norm go to the AUX stream, which is idle once its own chain (image /
         # q(z|x) networks) is through: behind the generator's products on the side stream they reached into the step's tail
         dec_on_aux = bool(e.dec_grads_on_aux and not rp and not d.conditional and e.use_aux_stream)
-        # (experiment switch: the decoder's weight gradients and the first-half norm held back until the encoder's backward recurrence
-        #  is through, so that both backward recurrences run without guests -- tools/ab_env.sh)
-        wgrads_late = bool(dec_on_aux and _os_env.get("VMMT_WGRADS_LATE", "0") == "1")
-        Pd = []
+        # (the decoder's weight gradients held back until the encoder's backward recurrence is through -- both backward recurrences
+        #  without guests, everything in the tail -- was measured in round 4: 1.80 against 1.735 ms per step; LABNOTES.md)
         # ================= decoder LSTM backward (main) + its parameter gradients (side / aux) ====================
         dh_above = self.dR
         for l in reversed(range(Lyr)):
@@ -324,9 +322,6 @@ class BackwardPlan(object):
                 dh_above = self.dec_dx[l - 1]
             # ---- side / aux: parameter gradients of this layer
             e._sid = AUX if dec_on_aux else SIDE
-            Pm = P                  # (the plan as a whole; P below = where this layer's products go: the late list when deferred)
-            if wgrads_late:
-                P = Pd
             e._wait(P, "dec_dg%d" % l)
             gw = "decoder.rnn.weight_hh_l%d" % l
             grp = [] if (e.group_wgrads and dt == L.BF16) else None      # dW_hh (two pieces) and dW_ih of the layer: one grid
@@ -355,12 +350,11 @@ class BackwardPlan(object):
                 # dX = dgates W_e, then its rows scattered into the embedding gradient (pad row dropped) -- on the SIDE stream, idle while
                 # the encoder's backward recurrence runs, next to this stream's weight gradients instead of behind them
                 dxt_side = dec_on_aux and _os_env.get("VMMT_DXT_ON_SIDE", "1") == "1"
-                Px = Pm if dxt_side else P
                 if dxt_side:
                     e._sid = SIDE
-                    e._wait(Px, "dec_dg%d" % l)
-                e._gemm(Px, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, self.dXt.p(), self.dXt.ld, M, E, 4 * Hp, out_f32=1)
-                e._call(Px, lib.vmmt_scatter_add_rows, self.dXt.p(), self.dXt.ld, self.tgt_in.data_ptr(), PAD,
+                    e._wait(P, "dec_dg%d" % l)
+                e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, self.dXt.p(), self.dXt.ld, M, E, 4 * Hp, out_f32=1)
+                e._call(P, lib.vmmt_scatter_add_rows, self.dXt.p(), self.dXt.ld, self.tgt_in.data_ptr(), PAD,
                         e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E, M, E)
                 if dxt_side:
                     e._sid = AUX
@@ -372,7 +366,6 @@ class BackwardPlan(object):
             if not fused_b:
                 e._call(P, lib.vmmt_colsum, dt, dg.p(), dg.ld, M, 4 * Hp, Hp if Hp != H else 0, H, e.gp("decoder.rnn.bias_ih_l%d" % l),
                         e.gp("decoder.rnn.bias_hh_l%d" % l))
-            P = Pm
         if rp:
             # reparameterised gradient (H2 switched off): dL/dz = sum_t dgates_t W_z (decoder input, VI_Model1.py:99-100) + the image
             # network's gate path; it joins the KL gradient at mu / sigma, so the q(z|x) networks' backward can only start here,
@@ -398,13 +391,9 @@ class BackwardPlan(object):
             e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None, 2)
         if dec_on_aux:
             e._sid = AUX
-            Pm = P
-            if wgrads_late:
-                P = Pd
             e._wait(P, "side_first")
             finish_first_half()
             e._record(P, "aux_end")
-            P = Pm
             e._sid = SIDE
         elif not d.conditional:
             finish_first_half()
@@ -530,10 +519,6 @@ class BackwardPlan(object):
             e._sid = SIDE
             e._wait(P, "aux_done")
             finish_first_half()
-        if wgrads_late:
-            e._sid = AUX
-            e._wait(P, "enc_dg0")
-            P.extend(Pd)
         # join
         e._sid = SIDE
         e._record(P, "side_done")
