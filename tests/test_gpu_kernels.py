@@ -701,3 +701,46 @@ def test_latent_zx_equals_latent_fwd_plus_gemm(B, Z, N, training):
     assert (zx2 - zx1).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
     if not training:
         assert torch.equal(z2, mu)
+
+
+def test_mul_and_act_bwd_vector_paths_equal_the_scalar_kernels():
+    """vmmt_mul / vmmt_act_bwd take eight bf16 elements per thread where rows are 16-byte aligned; the same data in buffers whose leading
+    dimension breaks the alignment goes through the scalar kernels: identical bits, and the padding columns stay untouched"""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(12)
+    T = torch.bfloat16
+    R, Cc = 777, 504
+    a = (torch.randn(R, Cc, generator=g)).to(T)
+    mk = ((torch.rand(R, Cc, generator=g) > 0.5).float() * 2.0).to(T)
+    yv = torch.tanh(torch.randn(R, Cc, generator=g)).to(T)
+    dy32 = torch.randn(R, Cc, generator=g)
+
+    def buf(src, ld, dt):
+        t = torch.full((R, ld), 7.0, dtype=dt, device="cuda")
+        t[:, :Cc] = src.to(dt).cuda()
+        return t
+    outs = {}
+    for ld in (512, 513):                 # 512: vector path; 513: rows not 16-byte aligned -> scalar kernels
+        A, M, Y, D32, Db = buf(a, ld, T), buf(mk, ld, T), buf(yv, ld, T), buf(dy32, ld, torch.float32), buf(dy32, ld, T)
+        o_mul = torch.full((R, ld), 3.0, dtype=T, device="cuda")
+        L.check(lib.vmmt_mul(L.BF16, A.data_ptr(), ld, M.data_ptr(), ld, o_mul.data_ptr(), ld, R, Cc, None), "mul")
+        res = [o_mul]
+        for act in (L.ACT_TANH, L.ACT_RELU, L.ACT_SIGMOID, L.ACT_SOFTPLUS):
+            for dyb, f32 in ((D32, 1), (Db, 0)):
+                for m in (M, None):
+                    o = torch.full((R, ld), 3.0, dtype=T, device="cuda")
+                    L.check(lib.vmmt_act_bwd(L.BF16, act, dyb.data_ptr(), ld, f32, Y.data_ptr(), ld, m.data_ptr() if m is not None else None, ld if m is not None else 0,
+                                             o.data_ptr(), ld, R, Cc, None), "act_bwd")
+                    res.append(o)
+        # in place (dropout backward between layers: x = x * mask)
+        L.check(lib.vmmt_mul(L.BF16, A.data_ptr(), ld, M.data_ptr(), ld, A.data_ptr(), ld, R, Cc, None), "mul in place")
+        res.append(A)
+        torch.cuda.synchronize()
+        assert all((o[:, Cc:] == (7.0 if o is A else 3.0)).all() for o in res)
+        outs[ld] = [o[:, :Cc].clone() for o in res]
+    assert all(torch.equal(x, y_) for x, y_ in zip(outs[512], outs[513]))
+    want = (a.float() * mk.float()).to(T)
+    assert torch.equal(outs[512][0].cpu(), want)
+    want_t = (dy32 * mk.float() * (1 - yv.float() ** 2)).to(T)
+    assert (outs[512][1].cpu().float() - want_t.float()).abs().max().item() <= 2e-2 * want_t.float().abs().max().item()

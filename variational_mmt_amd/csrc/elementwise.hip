@@ -133,6 +133,71 @@ __global__ void mul_kernel(const T* __restrict__ a, long lda, const T* __restric
   out[(long)r * ldo + c] = from_f<T>(to_f<T>(a[(long)r * lda + c]) * to_f<T>(b[(long)r * ldb + c]));
 }
 
+// ... eight bf16 elements per thread (16-byte loads / stores) where rows are 16-byte aligned and C % 8 == 0: the scalar kernel moves
+// 1.5 TB/s, and both element-wise passes sit on the step's critical path (dropout between layers / behind the attentional output;
+// the output layer's tanh + dropout backward).  Same arithmetic per element: same bits.
+__global__ void __launch_bounds__(256) mul8_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
+                                                   bf16_t* __restrict__ out, long ldo, int R, int C8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * C8) return;
+  const int r = (int)(i / C8), c = (int)(i - (long)r * C8) * 8;
+  const u32x4 va = *reinterpret_cast<const u32x4*>(a + (long)r * lda + c), vb = *reinterpret_cast<const u32x4*>(b + (long)r * ldb + c);
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float lo = __uint_as_float(va[e] << 16) * __uint_as_float(vb[e] << 16);
+    const float hi = __uint_as_float(va[e] & 0xffff0000u) * __uint_as_float(vb[e] & 0xffff0000u);
+    o[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  }
+  *reinterpret_cast<u32x4*>(out + (long)r * ldo + c) = o;
+}
+
+template <class TD>        // TD = float (a split-K accumulated gradient) or bf16_t
+__global__ void __launch_bounds__(256) act_bwd8_kernel(int act, const TD* __restrict__ dy, long lddy, const bf16_t* __restrict__ y, long ldy,
+                                                       const bf16_t* __restrict__ mask, long ldm, bf16_t* __restrict__ out, long ldo, int R, int C8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * C8) return;
+  const int r = (int)(i / C8), c = (int)(i - (long)r * C8) * 8;
+  float g[8];
+  if constexpr (sizeof(TD) == 4) {
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + (long)r * lddy + c), d1 = *reinterpret_cast<const f32x4*>(dy + (long)r * lddy + c + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[e] = d0[e]; g[4 + e] = d1[e]; }
+  } else {
+    const u32x4 d = *reinterpret_cast<const u32x4*>(dy + (long)r * lddy + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[2 * e] = __uint_as_float(d[e] << 16); g[2 * e + 1] = __uint_as_float(d[e] & 0xffff0000u); }
+  }
+  if (mask) {
+    const u32x4 m = *reinterpret_cast<const u32x4*>(mask + (long)r * ldm + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[2 * e] *= __uint_as_float(m[e] << 16); g[2 * e + 1] *= __uint_as_float(m[e] & 0xffff0000u); }
+  }
+  float yy[8];
+  if (y) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(y + (long)r * ldy + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { yy[2 * e] = __uint_as_float(v[e] << 16); yy[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) yy[e] = 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    switch (act) {
+      case VMMT_ACT_RELU: g[e] = yy[e] > 0.f ? g[e] : 0.f; break;
+      case VMMT_ACT_TANH: g[e] *= 1.f - yy[e] * yy[e]; break;
+      case VMMT_ACT_SOFTPLUS: g[e] *= 1.f - __expf(-yy[e]); break;
+      case VMMT_ACT_SIGMOID: g[e] *= yy[e] * (1.f - yy[e]); break;
+      default: break;
+    }
+  }
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(g[2 * e]) | ((uint32_t)f2bf(g[2 * e + 1]) << 16);
+  *reinterpret_cast<u32x4*>(out + (long)r * ldo + c) = o;
+}
+
 // out = dy * mask * act'(y), with act' expressed through the activation OUTPUT y
 template <class T, class TD>
 __global__ void act_bwd_kernel(int act, const TD* __restrict__ dy, long lddy, const T* __restrict__ y, long ldy,
@@ -528,7 +593,10 @@ extern "C" int vmmt_mul(int dtype, const void* a, int64_t lda, const void* b, in
   if (!a || !b || !out || R < 0 || C < 0) return VMMT_EINVAL;
   long n = (long)R * C;
   if (n == 0) return VMMT_OK;
-  if (dtype == VMMT_F32) hipLaunchKernelGGL(mul_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, (const float*)a, (long)lda, (const float*)b, (long)ldb, (float*)out, (long)ldo, R, C);
+  const bool vec8 = dtype == VMMT_BF16 && C % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0 &&
+                    ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) == 0;
+  if (vec8) hipLaunchKernelGGL(mul8_kernel, BLOCKS(n / 8, 256), dim3(256), 0, ST, (const bf16_t*)a, (long)lda, (const bf16_t*)b, (long)ldb, (bf16_t*)out, (long)ldo, R, C / 8);
+  else if (dtype == VMMT_F32) hipLaunchKernelGGL(mul_kernel<float>, BLOCKS(n, 256), dim3(256), 0, ST, (const float*)a, (long)lda, (const float*)b, (long)ldb, (float*)out, (long)ldo, R, C);
   else if (dtype == VMMT_BF16) hipLaunchKernelGGL(mul_kernel<bf16_t>, BLOCKS(n, 256), dim3(256), 0, ST, (const bf16_t*)a, (long)lda, (const bf16_t*)b, (long)ldb, (bf16_t*)out, (long)ldo, R, C);
   else return VMMT_EINVAL;
   return check_launch();
@@ -539,7 +607,11 @@ extern "C" int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, in
   if (!dy || !out || R < 0 || C < 0 || (act != VMMT_ACT_NONE && !y)) return VMMT_EINVAL;
   long n = (long)R * C;
   if (n == 0) return VMMT_OK;
-  if (dtype == VMMT_F32) hipLaunchKernelGGL((act_bwd_kernel<float, float>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const float*)y, (long)ldy, (const float*)mask, (long)ldm, (float*)out, (long)ldo, R, C);
+  const bool vec8 = dtype == VMMT_BF16 && C % 8 == 0 && lddy % (dy_f32 ? 4 : 8) == 0 && (!y || ldy % 8 == 0) && (!mask || ldm % 8 == 0) && ldo % 8 == 0 &&
+                    ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)mask) | ((uintptr_t)out)) & 15) == 0;
+  if (vec8 && dy_f32) hipLaunchKernelGGL(act_bwd8_kernel<float>, BLOCKS(n / 8, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C / 8);
+  else if (vec8) hipLaunchKernelGGL(act_bwd8_kernel<bf16_t>, BLOCKS(n / 8, 256), dim3(256), 0, ST, act, (const bf16_t*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C / 8);
+  else if (dtype == VMMT_F32) hipLaunchKernelGGL((act_bwd_kernel<float, float>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const float*)y, (long)ldy, (const float*)mask, (long)ldm, (float*)out, (long)ldo, R, C);
   else if (dtype == VMMT_BF16 && dy_f32) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, float>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C);
   else if (dtype == VMMT_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, bf16_t>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const bf16_t*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C);
   else return VMMT_EINVAL;
