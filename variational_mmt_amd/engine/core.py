@@ -87,7 +87,10 @@ class Engine(StepAPI):
         self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
         self.bwd_layers_parallel = _os_env.get("VMMT_BWD_LAYERS_PARALLEL", "1") == "1"   # >= 2 layers: top encoder layer next to the lower decoder layers
         # the weight-gradient products of a layer (dW_hh / dW_ih of each direction; attention's two) as ONE grid each (vmmt_gemm_group)
-        self.group_wgrads = _os_env.get("VMMT_GROUP_WGRADS", "1") == "1"
+        # -- not with the --conditional prior: there the step's length is encoder_tgt's chain (2 x B = 512 sequential LSTM steps at batch 20,
+        # 0.86 + 1.5 ms) and every weight gradient runs underneath it; a grouped grid takes more of the chip at once and slows that chain
+        # (same box, three pairs: 3.73 / 3.72 / 3.80 ms grouped against 3.47 / 3.45 / 3.49 ms solo; profiles/r4_conditional_grouping.txt)
+        self.group_wgrads = _os_env.get("VMMT_GROUP_WGRADS", "0" if dims.conditional else "1") == "1"
         # the output dropout (VI_Model1.py:132) out of the epilogue of tanh(W_o [c ; r]) instead of a pass of its own (vmmt_gemm_args.mask).
         # OPT-IN: bit-identical, and measured 10-15 us per step SLOWER than the 12-us vmmt_mul pass it removes (same box, three pairs:
         # 1.722 / 1.722 / 1.740 against 1.715 / 1.708 / 1.724 ms) -- the second output costs the product's epilogue more than the pass
