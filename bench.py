@@ -454,6 +454,8 @@ def main():
     from variational_mmt_amd.dp import GradSync
     sync = GradSync(eng)          # attaches itself to the engine when torch.distributed runs with > 1 rank
 
+    eng.hold_back = True               # a training loop: every update is followed by a forward (TrainerMultimodal._train_loop sets the same)
+
     def step(i):
         src, sl, tgt, idx, tlen, n_tok = batches[i % len(batches)]
         ws = eng.forward(src, sl, tgt, idx, training=True, tgt_len=tlen if a.conditional else None, n_tgt_tokens=n_tok)
@@ -506,6 +508,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         ws = step(a.warmup + i)
+    eng.wait_background()              # (a half of the last update that the engine held back for the next forward: inside the timed region)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -20,3 +20,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _gpu_quiet_between_tests(request):
+    """The engine runs part of a step on streams of its own (side / AUX / COMM).  A test that drops its engine while those still run would
+    hand their buffers back to torch's caching allocator, and the next test's tensors could be written by the previous test's kernels:
+    every GPU test ends with the device idle."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()

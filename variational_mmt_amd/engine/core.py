@@ -13,7 +13,29 @@ from .step import StepAPI
 from .workspace import Workspace
 
 
+def _behind_background(name):
+    """attribute that the side-stream half of an optimiser step writes (master parameters, Adam moments): reading it from outside issues
+    a held-back half first (Engine.bg_after_head) and orders the current stream behind it, so `engine.params[...]` after optim_step() is
+    the updated value in every mode"""
+    priv = "_" + name
+
+    def get(self):
+        dd = self.__dict__
+        if dd.get("_pending_bg") and not dd.get("_in_flush"):
+            self.wait_background()
+        return dd[priv]
+
+    def put(self, value):
+        self.__dict__[priv] = value
+    return property(get, put)
+
+
 class Engine(StepAPI):
+    params = _behind_background("params")
+    flat_p = _behind_background("flat_p")
+    flat_m = _behind_background("flat_m")
+    flat_v = _behind_background("flat_v")
+
     def __init__(self, dims, dtype="bf16", device="cuda", seed=0, param_init=0.1, batch_global=None):
         self.d = dims
         self.dev = torch.device(device)
@@ -108,6 +130,16 @@ class Engine(StepAPI):
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
         self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
+        # the side-stream half of Adam held back until the NEXT forward's head (source gather + the encoder's first input projection) is
+        # through: next to 200 us of optimiser streaming that product takes 112 instead of 30 us (profiles/r4_step_timeline.txt)
+        # Default: models of two or more layers (scripts' shape at batch 40 / 256: 1.86 -> 1.73 / 2.68 -> 2.55 ms, config 5: 17.49 -> 17.26;
+        # config 2 with its one encoder layer: 1.738 against 1.741 -- its encoder phase is shorter than that half of the update).  The plans
+        # are laid out for it when this is set; an update is only HELD BACK while `hold_back` is set, which the owner of a training loop
+        # does (TrainerMultimodal._train_loop, bench.py) and clears at the loop's end: outside such a loop optim_step() issues everything
+        bah = _os_env.get("VMMT_BG_AFTER_HEAD", "auto")
+        self.bg_after_head = (dims.layers >= 2) if bah == "auto" else bah == "1"
+        self.hold_back = False
+        self._pending_bg = None
         self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
         self._sumsq_by_plan = False
         self._normed = set()         # sharded data parallelism: arena segments whose shard the backward plan has normed (step.py)
@@ -252,6 +284,7 @@ class Engine(StepAPI):
             return
         self._row_adam = on
         if hasattr(self, "ws"):
+            self._flush_bg()
             self.drop_workspaces()
             for t in self.row_tables:
                 self.flat_g[t["off"]:t["end"]].zero_()
@@ -285,9 +318,40 @@ class Engine(StepAPI):
 
     def wait_background(self, stream=None):
         """`stream` (default: the current one) waits for the half of the last optimiser step that runs on the side stream"""
-        ev = self.global_events.get("opt_side_done")
-        if ev is not None:
-            (stream if stream is not None else torch.cuda.current_stream(self.dev)).wait_event(ev)
+        self._flush_bg()
+        for name in ("opt_side_done", "opt_gen_done"):
+            ev = self.global_events.get(name)
+            if ev is not None:
+                (stream if stream is not None else torch.cuda.current_stream(self.dev)).wait_event(ev)
+
+    def _flush_bg(self, after=None, parts=None, stream=None):
+        """issue the side-stream half of the last optimiser step if it was held back (bg_after_head): its first `parts` pieces (default:
+        all that are left); `after`: a stream whose work issued so far it must stay behind"""
+        bg = self._pending_bg
+        if bg:
+            if after is not None:
+                ev = self.global_events.setdefault("bg_head", torch.cuda.Event())
+                ev.record(after)
+                self.side_stream.wait_event(ev)
+            self._in_flush = True
+            try:
+                for _ in range(len(bg) if parts is None else min(parts, len(bg))):
+                    bg.pop(0)(stream)
+            finally:
+                self._in_flush = False
+        if not bg:
+            self._pending_bg = None
+
+    def _bg_cut_ok(self):
+        """may the generator's third of the arena be updated BEHIND the shadow refresh of the side-stream half?  Only if that refresh reads
+        nothing of it (the generator weight's shadow is written by the update itself in the bf16 layouts: _fused_shadows)"""
+        if not hasattr(self, "_bg_cut"):
+            base, lim = self.flat_p.data_ptr(), self.flat_p.data_ptr() + 4 * self.segments[1][0]
+            fused = set(d for _, _, d in self._fused_shadows())
+            enc_lo = self.offsets[self.first_enc_name][0]
+            sel = [c for c in self.pack_calls if (c[1] - base) // 4 < enc_lo and c[4] not in fused]
+            self._bg_cut = all(not (base <= q < lim) for c in sel for q in (c[1], c[2]) if q)
+        return self._bg_cut
 
     def load_state_dict(self, sd):
         self.wait_background()
@@ -604,6 +668,7 @@ class Engine(StepAPI):
         optimiser launch since then saw the guard word and changed nothing -- so the run CONTINUES on the per-step kernels (one launch
         per time step: slower, no residency requirement) and says so, instead of aborting the job."""
         import sys
+        self._flush_bg()
         torch.cuda.synchronize(self.dev)
         codes = [w for w in (int(s[2].item()) for s in self.seq_syncs) if w]
         g = self._guard.tolist()
@@ -653,6 +718,7 @@ class Engine(StepAPI):
         falls back to the per-step kernels with a warning, _seq_timeout_fallback; VMMT_SEQ_FALLBACK=0: raises) and a step that was told
         fewer target tokens than its batch held.  The trainer mirror calls it at the end of every epoch and before a checkpoint is
         written, bench.py after its timed region."""
+        self._flush_bg()            # (a held-back half of the last update reads the guard: it goes out before the guard is settled)
         torch.cuda.synchronize(self.dev)
         if int(self._guard[0].item()) != 0 or any(self.lstm_seq_errors()):
             self._seq_timeout_fallback("check_async_errors")
@@ -722,6 +788,8 @@ class Engine(StepAPI):
         if uses_tgt is None or uses_tgt[0] != len(plan):
             uses_tgt = self._plan_tgt[id(plan)] = (len(plan), any(en[4] == 3 for en in plan))
         uses_tgt = uses_tgt[1]
+        if self._pending_bg is not None and not any(en[2] == "BG_FLUSH" for en in plan):
+            self.wait_background()  # (a plan that does not place the held-back half of the optimiser step itself: issue it first, all of it)
         tgt = (self.tgt_stream if aux is self.aux_stream else aux) if uses_tgt else aux
         ts = (main, side, aux, tgt)
         hs = (main.cuda_stream, side.cuda_stream, aux.cuda_stream, tgt.cuda_stream)
@@ -792,6 +860,12 @@ class Engine(StepAPI):
                                                         self.segments.index((lo, hi)), comm.cuda_stream), "vmmt_sumsq")
                         self._normed.add(self.segments.index((lo, hi)))
                 return
+            if name == "BG_FLUSH":
+                self._flush_bg(ts[0], parts=1)
+                return
+            if name == "BG_FLUSH2":
+                self._flush_bg(stream=None if single_stream else ts[sid])
+                return
             if single_stream:
                 return
             if name == "EV_RECORD":
@@ -800,6 +874,8 @@ class Engine(StepAPI):
                     ev = events[args] = torch.cuda.Event()
                 ev.record(ts[sid])
             else:
+                if args == "opt_side_done":
+                    self._flush_bg()
                 ev = events.get(args) if args in events else self.global_events.get(args)
                 if ev is not None:
                     ts[sid].wait_event(ev)

@@ -146,6 +146,7 @@ class StepAPI(object):
         phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights."""
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
+        self._flush_bg()                # (two updates without a forward between them)
         self.poll_guard()               # a recurrence hand-off timed out a step or two ago: continue on the per-step kernels
         guard = self._guard.data_ptr()
         n_launch = [0]
@@ -180,12 +181,14 @@ class StepAPI(object):
             # FOREGROUND: encoder_tgt's forward recurrence, the step's first long chain, gathers from it right at the start of the step
             split = self.offsets["decoder.embeddings.make_embedding.emb_luts.0.weight"][0]
 
+        t_adam = self.step_count         # (by value: a held-back half of this update runs after optim_step has returned)
+
         def adam_range(lo, hi, stream, shadow=None):
             blocks = int(self.bg_adam_blocks) if stream != st else int(self.fg_adam_blocks)
             if hi > lo:
                 L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
                                                 self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, lr, beta1, beta2,
-                                                eps, self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
+                                                eps, t_adam, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
                                                 blocks, shadow, guard, stream), "vmmt_adam_step")
                 n_launch[0] += 1
 
@@ -195,7 +198,7 @@ class StepAPI(object):
             o = 4 * t["off"]
             L.check(self.lib.vmmt_adam_rows_step(self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o,
                                                  self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), lr, beta1, beta2, eps,
-                                                 self.step_count, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, guard, stream),
+                                                 t_adam, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, guard, stream),
                     "vmmt_adam_rows_step")
             n_launch[0] += 1
 
@@ -223,13 +226,34 @@ class StepAPI(object):
             self._pack_part(2, st)
             side = self.side_stream
 
-            def background():
+            defer = bool(self.hold_back and self.bg_after_head and not self.d.conditional and not self.dp_on())
+            # held back (bg_after_head): [attention | decoder | target embeddings] and their shadows first -- `opt_side_done`, what the
+            # decoder's forward waits for -- and the generator's third of the arena, which nothing reads before the vocabulary sweep, behind
+            # the decoder's input projection (`opt_gen_done`)
+            cut = self.segments[1][0] if (defer and self._bg_cut_ok()) else 0
+
+            def part_a(stream=None):
                 side.wait_event(ev)
-                adam(0, split, side.cuda_stream)
+                adam(cut, split, side.cuda_stream)
+                if cut == 0:
+                    self.global_events.setdefault("opt_gen_done", torch.cuda.Event()).record(side)
                 self._pack_part(3, side.cuda_stream)
                 self.global_events.setdefault("opt_side_done", torch.cuda.Event()).record(side)
-                self._publish_guard(side)
-            background()
+
+            def part_b(stream=None):
+                s2 = stream if stream is not None else side        # (the forward plan places the generator's part on its AUX stream)
+                if s2 is not side:
+                    s2.wait_event(self.global_events["opt_side_done"])
+                if cut > 0:
+                    adam(0, cut, s2.cuda_stream)
+                    self.global_events.setdefault("opt_gen_done", torch.cuda.Event()).record(s2)
+                self._publish_guard(s2)
+                self._adam_launches = max(1, n_launch[0])
+            if defer:
+                self._pending_bg = [part_a, part_b]     # issued by the next forward plan (BG_FLUSH / BG_FLUSH2), or by whoever waits for them
+            else:
+                part_a()
+                part_b()
         else:
             adam(0, self.n_opt, st)
             self._pack_part(2, st)

@@ -179,11 +179,41 @@ class Workspace(BackwardPlan, ConditionalPlans):
         MAIN, SIDE = 0, 1
         e._sid = MAIN
         e._record(P, "fwd_begin")
+        # (bg_after_head) the head of the main stream first -- source rows and the encoder's first input projection -- and only behind it the
+        # side-stream half of the last optimiser step (BG_FLUSH) and the side stream's own work, the decoder's input projection first
+        early_head = bool(training and e.bg_after_head and not d.conditional and e.use_side_stream)
+        if early_head:
+            e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                    self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
+            wih, bsum = e.sh["enc_wih_l0"], e.sh["enc_b_l0"]
+            e._gemm(P, L.GEMM_NT, self.Xs.p(), self.Xs.ld, wih.p(), wih.ld, self.enc_gx[0].p(), self.enc_gx[0].ld, MS, dirs * 4 * Hdp,
+                    E, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+            e._record(P, "fwd_begin")
+            P.append((None, None, "BG_FLUSH", None, MAIN))
+
+        def side_dec_gx():
+            e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                    self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
+            we = e.sh["dec_wih_l0_e"]
+            e._gemm(P, L.GEMM_NT, self.Xt.p(), self.Xt.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * Hp, E, out_f32=1)
+            if training:
+                # row-wise gradient bookkeeping of the embedding tables: flag this batch's rows and clear their gradient rows -- for the
+                # backward plan's scatter-adds and the optimiser step; in front of `dec_gx`, which every later stream waits for
+                e._row_mark_entries(P, 1, self.tgt_in.data_ptr(), M)
+                e._row_mark_entries(P, 0, self.src.data_ptr(), MS)
+            e._record(P, "dec_gx")
         # ---- side stream, underneath the encoder: zero the gradient arena (every gradient writer of the backward plan
         #      runs on the side stream), target embeddings and the time-parallel part of the decoder input projection
         e._sid = SIDE
         e._wait(P, "fwd_begin")
         e._record(P, "side_fwd")
+        if early_head:
+            # the generator's third of the optimiser step, the gradient zeroing behind it and the small preparations of the loss move to
+            # the AUX stream (idle in the forward): the side stream keeps the decoder's input projection and the image network
+            side_dec_gx()
+            e._sid = 2
+            e._wait(P, "dec_gx")
+            P.append((None, None, "BG_FLUSH2", None, 2))
         if training:
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             # ... together with the small accumulators of the backward plan (off the critical path instead of in front of
@@ -210,16 +240,11 @@ class Workspace(BackwardPlan, ConditionalPlans):
             self._mask_entries["dec_out"] = (len(P), self.out_mask)
             e._call(P, lib.vmmt_dropout_mask, dt, self.out_mask.p(), self.out_mask.rows * self.out_mask.ld, d.dropout, 0)
             e._record(P, "out_mask")
-        e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
-        we = e.sh["dec_wih_l0_e"]
-        e._gemm(P, L.GEMM_NT, self.Xt.p(), self.Xt.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * Hp, E, out_f32=1)
-        if training:
-            # row-wise gradient bookkeeping of the embedding tables: flag this batch's rows and clear their gradient rows -- for the
-            # backward plan's scatter-adds and the optimiser step; in front of `dec_gx`, which every later stream waits for
-            e._row_mark_entries(P, 1, self.tgt_in.data_ptr(), M)
-            e._row_mark_entries(P, 0, self.src.data_ptr(), MS)
-        e._record(P, "dec_gx")
+        if early_head:
+            e._record(P, "aux_fwd")
+            e._sid = SIDE
+        else:
+            side_dec_gx()
         if d.conditional:
             self._cond_forward_aux(P, training)
         # a1 image rows (TrainerMultimodal.py:632-639) -- table pointer is patched in at run time (set_image_table).  Fixed prior: only
@@ -233,14 +258,16 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._call(P, lib.vmmt_gather_rows, L.F32, None, D, self.img_idx.data_ptr(), self.img.p(), self.img.ld, B, D)
         e._sid = MAIN
         # a2 source embeddings
-        e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
+        if not early_head:
+            e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                    self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
         # a3 encoder
         x, xcols = self.Xs, E
         for l in range(Lyr):
             wih, bsum = e.sh["enc_wih_l%d" % l], e.sh["enc_b_l%d" % l]
-            e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hdp,
-                    xcols, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+            if not (early_head and l == 0):
+                e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hdp,
+                        xcols, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
             seq = (L.LstmDirFwd * (S * dirs))()                 # the whole recurrence: step-major, then direction
             if not hasattr(self, "hzero"):
                 self.hzero = Buf(B, H, e.T, e.dev)              # first step: h_prev reads zeros
@@ -342,6 +369,8 @@ class Workspace(BackwardPlan, ConditionalPlans):
                 addend=e.pp("inf_net_image.location.fc1.bias"), ld_add=D, add_rows=1, act=L.ACT_RELU)
         e._gemm(P, L.GEMM_NT, self.h1v.p(), self.h1v.ld, w2.p(), w2.ld, self.mu_v.p(), self.mu_v.ld, B, D, D,
                 addend=e.pp("inf_net_image.location.fc2.bias"), ld_add=D, add_rows=1, out_f32=1)
+        if early_head:
+            e._wait(P, "aux_fwd")        # (join: whoever is behind the side stream's forward is behind the gradient zeroing as well)
         e._record(P, "img_fwd")
         e._sid = MAIN
         # a6 decoder: gx[t] = emb(y_t) W_e^T (side stream, above) ; zx = z W_z^T + b is added inside the step kernel
@@ -409,6 +438,8 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e, d, lib = self.e, self.e.d, self.e.lib
         P = []
         wg = e.sh["wg"]
+        e._sid = 0
+        e._wait(P, "opt_gen_done")       # the generator's third of the last optimiser step (side stream; behind `opt_side_done` when held back)
         O = self.O if (training and d.dropout > 0) else self.AH      # eval: nn.Dropout is the identity
         if training:
             self._loss_patch = None

@@ -64,6 +64,7 @@ class NMTVIModel(nn.Module):
         pass          # the gradient arena is zeroed by the training forward plan (side stream)
 
     def state_dict(self, *args, **kwargs):
+        self.engine.wait_background()       # (the decoder-side half of the last update runs on, or is held back for, the side stream)
         return super(NMTVIModel, self).state_dict(*args, **kwargs)
 
     def load_state_dict(self, state_dict, strict=True):

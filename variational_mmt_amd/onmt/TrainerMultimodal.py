@@ -250,6 +250,18 @@ class TrainerMultimodal(object):
         return self._train_loop(train_iter, epoch, report_func, total_stats, report_stats, num_batches)
 
     def _train_loop(self, train_iter, epoch, report_func, total_stats, report_stats, num_batches):
+        # inside this loop an update is followed by the next batch's forward: the engine may hold the side-stream half of an update back
+        # until that forward's head is through (Engine.bg_after_head); whoever reads parameters inside the loop (a checkpoint, a
+        # translation) goes through state_dict() / the launch plans, which issue it first
+        eng = self.model.engine
+        eng.hold_back = True
+        try:
+            return self._train_batches(train_iter, epoch, report_func, total_stats, report_stats, num_batches)
+        finally:
+            eng.hold_back = False
+            eng.wait_background()
+
+    def _train_batches(self, train_iter, epoch, report_func, total_stats, report_stats, num_batches):
         for idx, batch in enumerate(train_iter):
             if hasattr(train_iter, "get_cur_dataset"):
                 self.train_loss.cur_dataset = train_iter.get_cur_dataset()
