@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from variational_mmt_amd import _lib as L
 lib = L.lib()
 H, M = (1024, 50 * 256) if "--config5" in sys.argv else (512, 20 * 256)
+if "--m" in sys.argv:            # e.g. --config5 --m 16384: config 5 as bench.py runs it (batch 512 x 32 target positions)
+    M = int(sys.argv[sys.argv.index("--m") + 1])
 V = 30000
 keep_idx = "idx" in sys.argv
 T = torch.bfloat16

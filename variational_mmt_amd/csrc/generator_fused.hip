@@ -491,7 +491,10 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
 // k-steps, all in registers: 128).  The two partial S^T meet through 4 KiB of LDS per wave (a + b and b + a are the same number, so
 // both waves go on with bit-identical logits, statistics and softmax weights) and each wave runs the second product for its columns.
 // A workgroup is 2 token groups x 2 column halves = 64 tokens; a tile of Wg is 32 rows x 2 KiB = 64 KiB, the ring two of them.
-// Per wave and tile that is the H = 512 kernel's 32 + 32 MFMAs plus the exchange (one more barrier), for twice the L2 -> LDS bytes.
+// Per wave and tile that is the H = 512 kernel's 32 + 32 MFMAs plus the exchange (one more barrier), for twice the L2 -> LDS bytes:
+// 64 KiB per tile and CU at the ~13 B per clock an operand byte reaches a CU's LDS is ~5000 cycles, and a tile takes ~5500 (probe build,
+// tools/gen_one.py --config5: wait 172, barrier 120, first product 2029, exchange 608, element-wise 989, second product 1377, tail 190)
+// -- at H = 1024 the sweep is bound by its operand stream, where the H = 512 kernel (32 KiB per ~4600 cycles) is bound by LDS reads.
 struct G2W {
   static constexpr int D = 1024, BC = 32, NSLOT = 2;
   static constexpr int ROWB = 2048, TILEB = BC * ROWB;      // 64 KiB
@@ -597,11 +600,19 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
 
   // (a wave none of whose 16 stored rows exists issues no store: it must not leave a DMA piece in flight instead)
   const bool stores = HASP && R0 + 16 * dh < a.nrows;
+#if defined(VMMT_EXP_PROBE)
+  const bool probe = blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long ps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = last_, r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int t = t0; t < t1; ++t) {
+    G2_STAMP(5);
     // tile t has landed (the only younger operation is the store of P behind the previous tile's last DMA piece)
     if (stores) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G2_STAMP(0);
     __syncthreads();
+    G2_STAMP(1);
     const int cur = (t - t0) & 1, sx = cur << 16;
     const int tn = t + 1;
     const char* yn = yt + tile_step;
@@ -628,10 +639,14 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
         sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks % PD], xf[ks], sT, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (ks + PD < C::KS) rd(ks + PD);
-        if ((ks & 3) == 1) issue_piece(yn, tn, cur ^ 1, ks >> 2);          // pieces 0..7; 8..15 ride in the second product
+        // all 16 pieces of the next tile under the FIRST product: they have the exchange, the element-wise phase and the second product to
+        // land.  (Half of them under the second product, the last one three MFMAs before the tile's end: 728 instead of 172 cycles of
+        // waiting at the top of every tile, 2.34 against 2.27 ms per launch at M 16384 / V 30000 -- tools/gen_one.py --config5, probe build.)
+        if ((ks & 1) == 1) issue_piece(yn, tn, cur ^ 1, ks >> 1);
         if (ks == 3) issue_piece(yn, tn, cur ^ 1, C::PER);
       }
     }
+    G2_STAMP(2);
     // ---- the partner's half
 #pragma unroll
     for (int i = 0; i < 4; ++i) g2_lds_write_b128(ex_mine + i * 1024, f32x4{sT[4 * i], sT[4 * i + 1], sT[4 * i + 2], sT[4 * i + 3]});
@@ -648,6 +663,7 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
         for (int e = 0; e < 4; ++e) sT[4 * i + e] += o[i][e];
     }
 
+    G2_STAMP(8);
     constexpr int PD = 4, NM = C::HB * 2;
     fs16x4 fl[PD], fh[PD];
     auto rd = [&](auto ic) {
@@ -726,6 +742,7 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
       seg = g2_lds_read_b128(patch + (q >> 2) * C::PPITCH + (q & 3) * 16);
     }
 
+    G2_STAMP(3);
     // ---- this wave's columns of acc^T[h][r] += sum_c Y[c][h] P[r][c]
     {
       g2_static_for<0, NM>([&](auto ic) {
@@ -740,7 +757,6 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
         acc[G2_HB(i)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), pf[G2_KK(i)], acc[G2_HB(i)], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i + PD < NM) rd(std::integral_constant<int, i + PD>{});
-        if constexpr ((i & 3) == 1) issue_piece(yn, tn, cur ^ 1, 8 + (i >> 2));
         if constexpr (i == NM - 2 && HASP) {
           // behind the tile's last DMA piece: the wait at the top of the next tile may leave exactly this store in flight
           const int q = lane + 64 * dh, prow = q >> 2, ch = q & 3;
@@ -751,8 +767,17 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
     }
 #pragma unroll
     for (int hb = 0; hb < C::HB; ++hb) asm volatile("" : "+a"(acc[hb]));
+    G2_STAMP(4);
     yt = yn;
   }
+#if defined(VMMT_EXP_PROBE)
+  if (probe) {
+    for (int i = 0; i < 6; ++i) g2_probe[i] = ps[i];
+    for (int i = 8; i < 11; ++i) g2_probe[i] = ps[i];
+    g2_probe[6] = (unsigned long long)(t1 - t0);
+    g2_probe[7] = (__builtin_amdgcn_s_memtime() - t_begin) * 100ull / (__builtin_amdgcn_s_memrealtime() - r_begin);
+  }
+#endif
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (row < a.nrows) {
