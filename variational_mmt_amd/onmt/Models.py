@@ -67,6 +67,10 @@ class NMTVIModel(nn.Module):
         self.engine.wait_background()       # (the decoder-side half of the last update runs on, or is held back for, the side stream)
         return super(NMTVIModel, self).state_dict(*args, **kwargs)
 
+    def named_parameters(self, *args, **kwargs):
+        self.engine.wait_background()       # (parameters() goes through here: whoever asks for the tensors gets the updated arena)
+        return super(NMTVIModel, self).named_parameters(*args, **kwargs)
+
     def load_state_dict(self, state_dict, strict=True):
         out = super(NMTVIModel, self).load_state_dict(state_dict, strict=strict)
         self.engine.shadows_dirty = True
