@@ -129,7 +129,7 @@ class Engine(StepAPI):
         self.q_parallel = _os.environ.get("VMMT_QPAR", "1") == "1"    # q(z|x): scale branch on the side stream next to the location branch
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
-        self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
+        self.split_optim = _os_env.get("VMMT_SPLIT_OPTIM", "1") == "1"      # run the decoder-side half of Adam + shadow refresh on the side stream
         # the side-stream half of Adam held back until the NEXT forward's head (source gather + the encoder's first input projection) is
         # through: next to 200 us of optimiser streaming that product takes 112 instead of 30 us (profiles/r4_step_timeline.txt)
         # Default: models of two or more layers (scripts' shape at batch 40 / 256: 1.86 -> 1.73 / 2.68 -> 2.55 ms, config 5: 17.49 -> 17.26;
