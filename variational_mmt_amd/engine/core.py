@@ -23,7 +23,10 @@ def _behind_background(name):
         dd = self.__dict__
         if dd.get("_pending_bg") and not dd.get("_in_flush"):
             self.wait_background()
-        return dd[priv]
+        try:
+            return dd[priv]
+        except KeyError:
+            raise AttributeError(name)
 
     def put(self, value):
         self.__dict__[priv] = value
