@@ -156,3 +156,57 @@ def test_conditional_model_through_the_onmt_surface(tmp_path):
         assert d < 5e-4, (k, d)
     vs = trainer.validate([_Batch(batches[0], "cuda")])
     assert np.isfinite(vs.ppl())
+
+
+def test_two_layer_model_one_epoch_through_the_trainer_loop(tmp_path):
+    """The scripts' kind of model (two uni-directional layers) through ONE call of TrainerMultimodal.train over four batches: inside the
+    loop the engine holds the side-stream half of every update back until the next batch's forward (Engine.bg_after_head, the default for
+    two or more layers; TrainerMultimodal._train_loop sets `hold_back`).  Four updates against the oracle's loop
+    (onmt/TrainerMultimodal.py:679-711, onmt/Optim.py:78-96); every batch has a shape of its own, so that each workspace still holds the
+    sample eps of ITS step afterwards."""
+    import variational_mmt_amd
+    onmt = variational_mmt_amd.install_as_onmt()
+    c = O.Cfg(vs=43, vt=47, emb=16, hid=32, z=8, img=2048, layers=2, brnn=False)
+    p = O.init_params(c, seed=5)
+    B = 7
+    shapes = [(6, 8), (7, 9), (5, 7), (8, 10)]
+    batches = [O.synth_batch(c, B, S, T, n_img=20, seed=300 + i, fixed_len=False) for i, (S, T) in enumerate(shapes)]
+    table = batches[0]["table"]
+    fields = {"src": types.SimpleNamespace(vocab=_Vocab(c.vs, False)), "tgt": types.SimpleNamespace(vocab=_Vocab(c.vt, True))}
+    opt = _opt(c, tmp_path)
+    model = onmt.ModelConstructor.make_vi_model_mmt(opt, fields, True, None)
+    model.load_state_dict({k: v for k, v in p.items()})
+    eng = model.engine
+    assert eng.bg_after_head and not eng.hold_back
+    train_loss = onmt.VILoss.NMTVIModel1LossCompute(model.generator, fields["tgt"].vocab)
+    valid_loss = onmt.VILoss.NMTVIModel1LossCompute(model.generator, fields["tgt"].vocab)
+    optim = onmt.Optim("adam", 0.002, 5.0, lr_decay=0.5, start_decay_at=8)
+    optim.set_parameters(model.parameters())
+    trainer = onmt.TrainerMultimodal(model, train_loss, valid_loss, optim, 0, 32, "text", "sents", 1, train_img_feats=table.numpy(),
+                                     valid_img_feats=table.numpy(), multimodal_model_type="vi-model1", model_opt=opt, fields=fields)
+    held = []
+    real_step = eng.optim_step
+
+    def spy(*a, **k):
+        out = real_step(*a, **k)
+        held.append(bool(eng.hold_back) and bool(eng._pending_bg))
+        return out
+    eng.optim_step = spy
+    stats = trainer.train([_Batch(bt, "cuda") for bt in batches], 1, None)
+    eng.optim_step = real_step
+    assert held == [True] * 4                                   # every update of the loop left its side-stream half for the next forward
+    assert not eng.hold_back and eng._pending_bg is None          # ... and the loop's end issued the last one
+    # the oracle's loop with each step's own sample
+    po, state, nll, nw = {k: v.clone() for k, v in p.items()}, {}, 0.0, 0
+    for bt, (S, T) in zip(batches, shapes):
+        eps = eng.workspace(B, S, T - 1).eps.view().cpu().clone()
+        r, Lo, g = O.step_grads(po, c, bt["src"], bt["src_len"], bt["tgt"], table[bt["indices"]], eps)
+        nll += float(Lo["nll"])
+        nw += Lo["n_words"]
+        po, _ = O.clip_and_adam(po, g, state, lr=0.002, max_grad_norm=5.0)
+    assert stats.n_words == nw and abs(stats.nmt_loss - nll) <= 5e-5 * abs(nll)
+    sd = model.state_dict()
+    worst = max((sd[k].cpu() - po[k]).abs().max().item() for k in eng.grads
+                if not k.startswith(("inf_net_image.location.fc1", "inf_net_image.gate_affine_transform")))
+    assert worst < 5e-4, worst                                  # (four updates of lr 0.002: a systematic error is ~ 8e-3)
+    assert eng.step_count == 4
