@@ -16,11 +16,13 @@ pytestmark = pytest.mark.gpu
 LR = 0.002
 
 
-def _engine(c, p, after_head, hold, dtype="bf16"):
+def _engine(c, p, after_head, hold, dtype="bf16", rows=False):
     from variational_mmt_amd.engine import Dims, Engine
     e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype=dtype, device="cuda", seed=3)
     e.bg_after_head = after_head
     e.hold_back = hold
+    e.row_adam = rows                                 # (the opt-in row bookkeeping of the embedding tables: its flags are read by the update)
+    assert e.rows_active() == rows
     e.load_state_dict(p)
     return e
 
@@ -38,15 +40,16 @@ def _close(a, b, n_updates):
     assert d.max().item() <= n_updates * LR * 1.01 and d.mean().item() <= 2e-6 * n_updates, (d.max().item(), d.mean().item())
 
 
-@pytest.mark.parametrize("layers,brnn,dtype", [(2, False, "bf16"), (1, True, "bf16"), (2, False, "f32")])
-def test_held_back_update_is_the_same_update(layers, brnn, dtype):
+@pytest.mark.parametrize("layers,brnn,dtype,rows", [(2, False, "bf16", False), (1, True, "bf16", False), (2, False, "f32", False),
+                                                    (2, False, "bf16", True)])
+def test_held_back_update_is_the_same_update(layers, brnn, dtype, rows):
     c = O.Cfg(vs=61, vt=300, emb=64, hid=256, z=128, layers=layers, brnn=brnn)
     p = O.init_params(c, seed=1)
     B = 32
     bts = [O.synth_batch(c, B=B, S=7, T=8, n_img=40, seed=60 + i, fixed_len=False) for i in range(4)]
-    ref = _engine(c, p, False, False, dtype)         # every update issued at once, the classic plan layout
-    lay = _engine(c, p, True, False, dtype)          # the new plan layout, nothing held back
-    held = _engine(c, p, True, True, dtype)          # held back
+    ref = _engine(c, p, False, False, dtype)         # every update issued at once, the classic plan layout, dense Adam
+    lay = _engine(c, p, True, False, dtype, rows)    # the new plan layout, nothing held back
+    held = _engine(c, p, True, True, dtype, rows)    # held back
     for e in (ref, lay, held):
         e.set_image_table(bts[0]["table"])
     assert "BG_FLUSH" in [en[2] for en in _step(held, bts[0], B).plan_fwd_train]
