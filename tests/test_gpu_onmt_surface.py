@@ -177,7 +177,8 @@ def test_two_layer_model_one_epoch_through_the_trainer_loop(tmp_path):
     model = onmt.ModelConstructor.make_vi_model_mmt(opt, fields, True, None)
     model.load_state_dict({k: v for k, v in p.items()})
     eng = model.engine
-    assert eng.bg_after_head and not eng.hold_back
+    import os
+    assert eng.bg_after_head and eng.hold_back == (os.environ.get("VMMT_HOLD_BACK", "0") == "1")     # (off until a loop's owner sets it)
     train_loss = onmt.VILoss.NMTVIModel1LossCompute(model.generator, fields["tgt"].vocab)
     valid_loss = onmt.VILoss.NMTVIModel1LossCompute(model.generator, fields["tgt"].vocab)
     optim = onmt.Optim("adam", 0.002, 5.0, lr_decay=0.5, start_decay_at=8)

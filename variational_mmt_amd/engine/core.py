@@ -141,7 +141,7 @@ class Engine(StepAPI):
         # does (TrainerMultimodal._train_loop, bench.py) and clears at the loop's end: outside such a loop optim_step() issues everything
         bah = _os_env.get("VMMT_BG_AFTER_HEAD", "auto")
         self.bg_after_head = (dims.layers >= 2) if bah == "auto" else bah == "1"
-        self.hold_back = False
+        self.hold_back = _os_env.get("VMMT_HOLD_BACK", "0") == "1"      # (the environment switch is for bug hunts: the whole test suite held back)
         self._pending_bg = None
         self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
         self._sumsq_by_plan = False
