@@ -589,6 +589,9 @@ def main():
                          "step_tflops": round(3 * fl["total"] * Bg / (dt / a.steps) / 1e12, 2)},
             "elbo_per_sentence": round(st["elbo"] / B, 4),
             "seq_fallbacks": eng.seq_fallbacks, "steps_skipped": eng.steps_skipped,
+            # how the engine scheduled the optimiser step in this run: the side-stream half of an update held back until the next forward's
+            # head is through (two or more layers, one rank) or issued at once; the last one is flushed inside the timed region
+            "held_back_update": bool(eng.hold_back and eng.bg_after_head and not a.conditional and not sync.active()),
         }
         if dp_block is not None:
             out["dp"] = dp_block
