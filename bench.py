@@ -84,6 +84,51 @@ def make_batches(d, B, S, T, n_img, n_batches, device, seed, ragged=False):
     return out
 
 
+def gpu_state():
+    """what the box lets an ordinary user read about its GPUs without starting another program: per card, from sysfs, the active shader
+    / memory clock (MHz), the socket power (W), the busy percentage.  A list with one entry per card that exposes a clock table."""
+    import glob
+    out = []
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        d_ = os.path.dirname(f)
+        ent = {"card": os.path.basename(os.path.dirname(d_))}
+
+        def active(path):
+            try:
+                for ln in open(path):
+                    if "*" in ln:
+                        return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()) or 0)
+            except (OSError, IndexError, ValueError):
+                pass
+            return None
+        ent["sclk"], ent["mclk"] = active(f), active(os.path.join(d_, "pp_dpm_mclk"))
+        for name, key, scale in (("power1_average", "watts", 1e-6), ("power1_input", "watts", 1e-6), ("temp1_input", "temp_c", 1e-3)):
+            if key in ent:
+                continue
+            for h in glob.glob(os.path.join(d_, "hwmon", "hwmon*", name)):
+                try:
+                    ent[key] = round(int(open(h).read().strip()) * scale, 1)
+                except (OSError, ValueError):
+                    pass
+        try:
+            ent["busy"] = int(open(os.path.join(d_, "gpu_busy_percent")).read().strip())
+        except (OSError, ValueError):
+            pass
+        out.append(ent)
+    return out
+
+
+def step_summary(dev_ms, host_ms):
+    """{min, median, p90, max, list} of the per-step device times of a timed region + the steps that stand out"""
+    import statistics
+    srt = sorted(dev_ms)
+    med = statistics.median(srt)
+    p90 = srt[min(len(srt) - 1, int(round(0.9 * (len(srt) - 1))))]
+    slow = [{"step": i, "ms": round(x, 3), "host_ms": round(host_ms[i], 3)} for i, x in enumerate(dev_ms) if x > 1.5 * med]
+    return {"min": round(srt[0], 4), "median": round(med, 4), "p90": round(p90, 4), "max": round(srt[-1], 4),
+            "list": [round(x, 3) for x in dev_ms]}, slow, med
+
+
 def host_cpu():
     """model name, physical cores, logical CPUs of the host (from /proc/cpuinfo; no extra tools needed)"""
     model, phys, logical = "?", set(), 0
@@ -364,6 +409,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions run back to back in the same process; the FIRST is the metric, the "
+                    "others are reported beside it (`repeats_ms`) to show whether it was typical for the box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (one cfg-1-shaped step against the CPU oracle)")
     ap.add_argument("--no-side-stream", action="store_true", help="profiling aid: issue the whole step on one stream")
@@ -492,29 +539,51 @@ def main():
         if name in ("vmmt_gen_fwd_dO", "vmmt_gen_loss_fwd"):
             wrap(ws0.plan_loss_train, j, "gen_fwd")
 
-    for i in range(a.warmup):
+    # warm-up: the W steps asked for, and at least one pass over the whole batch rotation, so that no input tensor (and no workspace
+    # bucket of the ragged rotation) is seen for the first time inside the timed region
+    n_warm = max(a.warmup, len(batches), 1)
+    state0 = gpu_state()
+    for i in range(n_warm):
         step(i)
-    if a.warmup == 0:
-        step(0)                   # the backward plan is built by the first step
     # backward plan exists now: hook the gen_loss_bwd entry
     for j, (fn, args, name, keep, sid) in enumerate(ws0.plan_bwd):
         if name in ("vmmt_gen_loss_bwd", "vmmt_gen_loss_bwd_db"):
             wrap(ws0.plan_bwd, j, "gen_bwd")
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dom["on"] = True
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        ws = step(a.warmup + i)
-    eng.wait_background()              # (a half of the last update that the engine held back for the next forward: inside the timed region)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dom["on"] = False
+
+    def timed_region(first, hooks):
+        """EXACTLY a.steps steps between barrier + synchronize on both sides (one perf_counter pair = the metric), plus what explains a
+        slow region: one event per step on the main stream (device time of each step) and the host clock after each step's enqueue"""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dom["on"] = hooks
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        host = [0.0] * a.steps
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evs[0].record()
+        ws_ = None
+        for i in range(a.steps):
+            ws_ = step(first + i)
+            evs[i + 1].record()
+            host[i] = time.perf_counter()
+        t_enq = time.perf_counter()
+        eng.wait_background()          # (a half of the last update that the engine held back for the next forward: inside the timed region)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        dom["on"] = False
+        dev_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps)]
+        host_ms = [(host[i] - (host[i - 1] if i else t0)) * 1e3 for i in range(a.steps)]
+        return dt_, ws_, dev_ms, host_ms, (t_enq - t0) * 1e3
+
+    regions = []
+    n_rep = max(1, a.repeats)
+    for r_ in range(n_rep):            # the FIRST region is the official one; the others show whether it was typical for the box
+        regions.append(timed_region(n_warm + r_ * a.steps, hooks=(r_ == 0)) + (gpu_state(),))
+    dt, ws, dev_ms, host_ms, enq_ms = regions[0][:5]
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -541,6 +610,23 @@ def main():
         fl = flops_per_triplet(d, S, Tp)
         ms = dt / a.steps * 1e3
         value = Bg * a.steps / dt
+        step_sum, slow_steps, step_med = step_summary(dev_ms, host_ms)
+        # the line says by itself when the whole-region value is not what the box does step after step
+        diagnosis = "steady: whole-region ms/step within 5 %% of the median step (%.3f ms)" % step_med
+        if ms > 1.05 * step_med:
+            lost = ms * a.steps - step_med * a.steps
+            if slow_steps:
+                diagnosis = ("STALL: %d of %d steps took > 1.5 x the median step (%.3f ms) and account for %.1f of the %.1f ms the region "
+                             "lost against %d median steps; " % (len(slow_steps), a.steps, step_med, sum(x["ms"] - step_med for x in slow_steps), lost, a.steps)) + \
+                    ("the host was late there (enqueue took longer than the step)" if any(x["host_ms"] > x["ms"] * 0.8 for x in slow_steps)
+                     else "the host was ahead: the device itself stalled")
+            elif enq_ms > 0.9 * ms * a.steps:
+                diagnosis = "HOST-BOUND: enqueueing the region took %.1f of its %.1f ms" % (enq_ms, ms * a.steps)
+            else:
+                diagnosis = "region %.3f ms/step against a median step of %.3f ms with no single slow step: time lost at the region's ends (first launch / last flush)" % (ms, step_med)
+        reps = [r_[0] / a.steps * 1e3 for r_ in regions]
+        if len(reps) > 1 and ms > 1.10 * min(reps[1:]):
+            diagnosis += "; the same region repeated ran at %s ms/step: the official (first) region was NOT typical for this box" % ", ".join("%.3f" % x for x in reps[1:])
         # dominant kernel = the fused vocabulary projection (+log-softmax+NLL) GEMM passes: 2*M*V*H FLOP per launch
         M = Tp * B
         fused = bool(getattr(ws0, "gen_fused", False))
@@ -587,6 +673,15 @@ def main():
                          "traffic_P_written": (M * d.vt * 2) if fused else None,
                          "ms_fwd": round(t_f, 4), "ms_bwd": round(t_b, 4),
                          "step_tflops": round(3 * fl["total"] * Bg / (dt / a.steps) / 1e12, 2)},
+            # what explains the value: device time of every step of the official region (events on the main stream), the host's time to
+            # enqueue it, the same region repeated, the steps that took > 1.5 x the median, the box's clocks before / after
+            "step_ms": step_sum, "value_median": round(Bg / (step_med * 1e-3), 1),
+            "host_enqueue_ms": {"total": round(enq_ms, 3), "per_step_median": round(sorted(host_ms)[len(host_ms) // 2], 4),
+                                "per_step_max": round(max(host_ms), 4)},
+            "repeats_ms": [round(r_[0] / a.steps * 1e3, 4) for r_ in regions],
+            "repeats_step_median_ms": [step_summary(r_[2], r_[3])[0]["median"] for r_ in regions],
+            "slow_steps": slow_steps, "diagnosis": diagnosis, "warmup_run": n_warm,
+            "gpu_state": {"before_warmup": state0, "after_each_region": [r_[5] for r_ in regions]},
             "elbo_per_sentence": round(st["elbo"] / B, 4),
             "seq_fallbacks": eng.seq_fallbacks, "steps_skipped": eng.steps_skipped,
             # how the engine scheduled the optimiser step in this run: the side-stream half of an update held back until the next forward's
