@@ -118,6 +118,58 @@ def gpu_state():
     return out
 
 
+def host_sched():
+    """what the kernel says about this thread's and this container's share of the host: ms this thread spent runnable but waiting for a
+    CPU (/proc/thread-self/schedstat), involuntary context switches, and the container's CPU-quota throttling (cgroup cpu.stat)"""
+    out = {}
+    try:
+        on_cpu, waited, _ = open("/proc/thread-self/schedstat").read().split()[:3]
+        out["on_cpu_ms"], out["runq_wait_ms"] = int(on_cpu) / 1e6, int(waited) / 1e6
+    except (OSError, ValueError):
+        pass
+    try:
+        for ln in open("/proc/thread-self/status"):
+            if ln.startswith("nonvoluntary_ctxt_switches"):
+                out["preempted"] = int(ln.split()[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    try:            # the whole process (HIP's helper threads signal the synchronize's return)
+        tot = 0
+        for t_ in os.listdir("/proc/self/task"):
+            tot += int(open("/proc/self/task/%s/schedstat" % t_).read().split()[1])
+        out["runq_wait_all_threads_ms"] = tot / 1e6
+    except (OSError, ValueError, IndexError):
+        pass
+    for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            for ln in open(f):
+                k, _, v = ln.partition(" ")
+                if k in ("nr_throttled", "throttled_usec", "throttled_time"):
+                    out["cgroup_" + ("throttled_ms" if k != "nr_throttled" else k)] = int(v) / (1.0 if k == "nr_throttled" else 1e3 if k == "throttled_usec" else 1e6)
+            break
+        except (OSError, ValueError):
+            continue
+    return out
+
+
+def sched_delta(a_, b_):
+    return {k: round(b_[k] - a_[k], 3) for k in b_ if k in a_}
+
+
+def cpu_quota():
+    """the container's CPU quota in CPUs (cgroup v2 cpu.max / v1 cfs_quota), None = unlimited or unreadable"""
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p_), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        return None if q <= 0 else round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def step_summary(dev_ms, host_ms):
     """{min, median, p90, max, list} of the per-step device times of a timed region + the steps that stand out"""
     import statistics
@@ -429,6 +481,10 @@ def main():
         launch_ranks(a)           # does not return
 
     quiet_stdout()
+    # the host side of the product is ONE enqueueing thread; torch's CPU pool (one thread per core of the HOST, 128 here, spinning for
+    # milliseconds after every parallel region) only serves the synthetic data and the parameter initialisation: inside a container with a
+    # CPU quota that pool can spend the quota and get the enqueueing thread throttled with it (cpu_baseline sets its own thread counts)
+    torch.set_num_threads(min(8, os.cpu_count() or 8))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -560,6 +616,7 @@ def main():
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
         host = [0.0] * a.steps
         torch.cuda.synchronize()
+        sch0 = host_sched()
         t0 = time.perf_counter()
         evs[0].record()
         ws_ = None
@@ -574,16 +631,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
+        sch = sched_delta(sch0, host_sched())
         dom["on"] = False
         dev_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps)]
         host_ms = [(host[i] - (host[i - 1] if i else t0)) * 1e3 for i in range(a.steps)]
-        return dt_, ws_, dev_ms, host_ms, (t_enq - t0) * 1e3
+        # the device's own span of the region: first event (recorded right behind t0) to the last step's event; what the region's
+        # wall clock has beyond it is launch latency in front and the synchronize's return behind
+        sch["device_span_ms"] = round(evs[0].elapsed_time(evs[a.steps]), 3)
+        sch["region_ms"] = round(dt_ * 1e3, 3)
+        return dt_, ws_, dev_ms, host_ms, (t_enq - t0) * 1e3, sch
 
+    # the host's collector out of the timed regions: a full collection of a process that has imported torch walks ~10^6 objects (tens of
+    # ms, the length of the whole 20-step region); nothing the steps allocate is cyclic, reference counting frees it
+    import gc
+    gc.collect()
+    gc.freeze()
     regions = []
     n_rep = max(1, a.repeats)
     for r_ in range(n_rep):            # the FIRST region is the official one; the others show whether it was typical for the box
         regions.append(timed_region(n_warm + r_ * a.steps, hooks=(r_ == 0)) + (gpu_state(),))
-    dt, ws, dev_ms, host_ms, enq_ms = regions[0][:5]
+    dt, ws, dev_ms, host_ms, enq_ms, sched = regions[0][:6]
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -615,7 +682,13 @@ def main():
         diagnosis = "steady: whole-region ms/step within 5 %% of the median step (%.3f ms)" % step_med
         if ms > 1.05 * step_med:
             lost = ms * a.steps - step_med * a.steps
-            if slow_steps:
+            ends = sched["region_ms"] - sched["device_span_ms"]
+            if sched.get("cgroup_nr_throttled", 0) > 0 or sched.get("runq_wait_ms", 0.0) > 0.5 * lost:
+                diagnosis = ("HOST DESCHEDULED: while it enqueued the region this thread waited %.1f ms for a CPU (%d preemptions) and the container's CPU quota "
+                             "throttled it for %.1f ms (%d times); the region lost %.1f ms against %d median steps of %.3f ms" %
+                             (sched.get("runq_wait_ms", 0.0), sched.get("preempted", 0), sched.get("cgroup_throttled_ms", 0.0), sched.get("cgroup_nr_throttled", 0),
+                              lost, a.steps, step_med))
+            elif slow_steps:
                 diagnosis = ("STALL: %d of %d steps took > 1.5 x the median step (%.3f ms) and account for %.1f of the %.1f ms the region "
                              "lost against %d median steps; " % (len(slow_steps), a.steps, step_med, sum(x["ms"] - step_med for x in slow_steps), lost, a.steps)) + \
                     ("the host was late there (enqueue took longer than the step)" if any(x["host_ms"] > x["ms"] * 0.8 for x in slow_steps)
@@ -623,7 +696,8 @@ def main():
             elif enq_ms > 0.9 * ms * a.steps:
                 diagnosis = "HOST-BOUND: enqueueing the region took %.1f of its %.1f ms" % (enq_ms, ms * a.steps)
             else:
-                diagnosis = "region %.3f ms/step against a median step of %.3f ms with no single slow step: time lost at the region's ends (first launch / last flush)" % (ms, step_med)
+                diagnosis = ("region %.3f ms/step against a median step of %.3f ms with no single slow step: the device ran the %d steps in %.1f ms, the region's "
+                             "wall clock has %.1f ms more at its ends (first launch, the synchronize's return)" % (ms, step_med, a.steps, sched["device_span_ms"], ends))
         reps = [r_[0] / a.steps * 1e3 for r_ in regions]
         if len(reps) > 1 and ms > 1.10 * min(reps[1:]):
             diagnosis += "; the same region repeated ran at %s ms/step: the official (first) region was NOT typical for this box" % ", ".join("%.3f" % x for x in reps[1:])
@@ -681,7 +755,8 @@ def main():
             "repeats_ms": [round(r_[0] / a.steps * 1e3, 4) for r_ in regions],
             "repeats_step_median_ms": [step_summary(r_[2], r_[3])[0]["median"] for r_ in regions],
             "slow_steps": slow_steps, "diagnosis": diagnosis, "warmup_run": n_warm,
-            "gpu_state": {"before_warmup": state0, "after_each_region": [r_[5] for r_ in regions]},
+            "host_sched": dict(sched, cpu_quota=cpu_quota(), repeats=[r_[5] for r_ in regions[1:]]),
+            "gpu_state": {"before_warmup": state0, "after_each_region": [r_[6] for r_ in regions]},
             "elbo_per_sentence": round(st["elbo"] / B, 4),
             "seq_fallbacks": eng.seq_fallbacks, "steps_skipped": eng.steps_skipped,
             # how the engine scheduled the optimiser step in this run: the side-stream half of an update held back until the next forward's

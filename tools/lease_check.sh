@@ -1,7 +1,7 @@
 #!/bin/bash
 # One lease: the driver's exact bench command, then the same step loop with and without a monitoring tool sampling the card next to it
 # (the driver's round-end run keeps smi.<unix time>.json samples every 5 s beside the bench: tools/lease_check.sh finds out what such a
-# sampler costs a 35-ms timed region).   usage: tools/lease_check.sh <tag> [driver|smi|all]
+# sampler costs a 35-ms timed region).   usage: tools/lease_check.sh <tag> [driver|smi|hog|all]
 set -o pipefail
 tag=${1:-lease}; what=${2:-all}
 out=gpurun_out/r5_${tag}; mkdir -p $out
@@ -19,6 +19,15 @@ if [ "$what" = smi ] || [ "$what" = all ]; then
     kill $sp; wait $sp 2>/dev/null
     [ $rc = 0 ] || exit 1
   done
+fi
+if [ "$what" = hog ] || [ "$what" = all ]; then
+  # a busy host: 3 spinning processes per CPU this box gives us, next to the bench's one enqueueing thread
+  short="--gpus 1 --steps 20 --warmup 5 --repeats 6 --no-cpu-baseline --no-parity"
+  n=${HOGS:-48}; pids=""      # (nproc shows the whole host: 256; the box gives one GPU's lease a share of 16)
+  for i in $(seq $n); do ( exec timeout 120 sh -c 'while :; do :; done' ) & pids="$pids $!"; done
+  python bench.py $short > $out/with_host_hogs_x$n.json 2> $out/with_host_hogs.err; rc=$?
+  kill $pids 2>/dev/null; wait 2>/dev/null
+  [ $rc = 0 ] || exit 1
 fi
 python - "$out" <<'PY'
 import json, sys, glob, os
