@@ -685,7 +685,7 @@ def main():
             ends = sched["region_ms"] - sched["device_span_ms"]
             if sched.get("cgroup_nr_throttled", 0) > 0 or sched.get("runq_wait_ms", 0.0) > 0.5 * lost:
                 diagnosis = ("HOST DESCHEDULED: while it enqueued the region this thread waited %.1f ms for a CPU (%d preemptions) and the container's CPU quota "
-                             "throttled it for %.1f ms (%d times); the region lost %.1f ms against %d median steps of %.3f ms" %
+                             "throttled it (%.1f ms summed over its threads, %d periods); the region lost %.1f ms against %d median steps of %.3f ms" %
                              (sched.get("runq_wait_ms", 0.0), sched.get("preempted", 0), sched.get("cgroup_throttled_ms", 0.0), sched.get("cgroup_nr_throttled", 0),
                               lost, a.steps, step_med))
             elif slow_steps:
