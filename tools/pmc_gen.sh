@@ -15,8 +15,8 @@ if not f: print("no counter file for $TAG")
 else:
     for r in csv.DictReader(open(f[0])):
         k = r['Kernel_Name']
-        if 'gen_kernel' in k or 'gen2_kernel' in k:
-            mode = 'gen2' if 'gen2_kernel' in k else ('bwd' if 'gen_kernel_q<1>' in k else 'fwd')
+        if 'gen_kernel' in k or 'gen2_kernel' in k or 'gen2p_kernel' in k:
+            mode = 'gen2' if ('gen2_kernel' in k or 'gen2p_kernel' in k) else ('bwd' if 'gen_kernel_q<1>' in k else 'fwd')
             agg[(mode, r['Counter_Name'])].append(float(r['Counter_Value']))
     for k, v in sorted(agg.items()): print("%-4s %-30s %16.0f" % (k[0], k[1], sum(v[2:]) / max(1, len(v[2:]))))
 PY

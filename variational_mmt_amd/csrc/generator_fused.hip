@@ -34,6 +34,7 @@
 //
 // Per byte fetched from L2 this does 4x the MFMA work of the 128 x 128-tile kernels (a 32 KB tile of Y feeds 2 x 4.2 MFLOP),
 // which is what bounded them.
+#include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
 #include "vmmt.h"
@@ -480,6 +481,449 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[hb][4 * i + e];
         *reinterpret_cast<f32x4*>(dst + 32 * hb + 8 * i + 4 * half) = v;
+      }
+  }
+}
+
+// ---- H = 512, software-pipelined across tiles (the product kernel at H = 512) ------------------------------------------------------
+// gen2_kernel above runs its three phases -- S^T (32 MFMAs), element-wise (exp, P), second product (32 MFMAs) -- one after the other in
+// the ONE instruction stream a SIMD has at 512 registers per lane: the matrix unit idles under the element-wise phase, and the first
+// operands of every product are waited for (profiles/r4_gen2_kernel_counters.txt: matrix pipe busy 49 % of the wave's cycles).  Here
+// the phases of NEIGHBOURING tiles overlap inside that one stream.  Iteration i:
+//     A(i):  S^T(i)                               32 MFMAs, operands by rows from tile i, the LDS-DMA of tile i + 2 in their shadow
+//     B(i):  acc^T += Y(i-1)^T P(i-1)^T           32 MFMAs, transposed reads of tile i - 1,
+//            with element-wise(i) -- max, exp, row sums, bf16 P(i), the P patch and its stores -- issued BETWEEN those MFMAs: a VALU /
+//            LDS instruction behind an independent MFMA issues while the matrix unit works on it.
+// What that costs: tiles i - 1 and i are both alive while i + 1 and i + 2 are landing: a FOUR-deep ring of 32-KiB tiles (128 KiB), which
+// fits because the resident operand O lives in registers alone (128 per lane, as gen2w_kernel keeps its half: no LDS part, no
+// second LDS read per MFMA of the S^T phase); two generations of P fragments (16 registers); and a lazy reference that moves in the
+// element-wise phase of tile i rescales the accumulators only once B(i) has added tile i - 1 in the old units (`fpend`).
+// One workgroup barrier per tile, as before.  vmcnt counts in issue order (gfx9: loads and stores on one counter): at the top of
+// iteration i the operations younger than tile i's DMA pieces are the stores of P(i-2), the pieces of tile i + 1, the stores of P(i-1).
+#ifndef G2P_PDA
+#define G2P_PDA 5
+#endif
+#ifndef G2P_KR
+#define G2P_KR 28
+#endif
+#ifndef G2P_PDB
+#define G2P_PDB 6
+#endif
+#ifndef G2P_NSLOT
+#define G2P_NSLOT 4
+#endif
+struct G2P {
+  static constexpr int D = 512, BC = 32, NSLOT = G2P_NSLOT, PF = NSLOT - 2;   // ring depth; tiles a DMA runs ahead of its S^T phase
+  static constexpr int ROWB = 1024, TILEB = BC * ROWB;        // 32 KiB
+  static constexpr int PER = 8;                               // 1-KiB LDS-DMA pieces (= rows) per wave and tile
+  static constexpr int KS = 32, HB = 16;
+  static constexpr int KR = G2P_KR, KL = KS - KR;             // k-steps of the resident operand in registers / in LDS ([k-step][lane] 16-byte
+                                                              // entries per wave: written and read by the same lane, linear, conflict-free)
+  static constexpr int SMALLB = 4 * 256;                      // per ring slot: every wave's copy of the tile's 32 column constants
+  static constexpr int SOFF = NSLOT * TILEB;
+  static constexpr int XOFF = SOFF + NSLOT * SMALLB, XWAVEB = KL * 1024;
+  static constexpr int LDSB = XOFF + 4 * XWAVEB;
+  static_assert(LDSB <= 160 * 1024, "LDS of one CU");
+  // phase B: the element-wise phase of tile i takes the steps EW0 .. EW0 + 15 (one exp each)
+  static constexpr int PDB = G2P_PDB, NM = 32, EW0 = 2;
+};
+// LDS operations younger than operand pair k when MFMA k of phase B is due (LDS returns in order; lgkmcnt has 4 bits)
+constexpr int g2p_inflight(int k) {
+  using C = G2P;
+  return 2 * ((C::PDB - 1) < (C::NM - 1 - k) ? (C::PDB - 1) : (C::NM - 1 - k));
+}
+
+// S^T += A B with the accumulator in the VALU half of the register file.  Through the builtin every MFMA of a kernel that uses AGPRs at all
+// gets an AGPR accumulator: S^T would take 16 of the 256 that acc^T fills, the allocator would park one block of acc^T in VGPRs during
+// phase A and move both back and forth -- 64 v_accvgpr moves per tile in an instruction stream that has no slot to spare.  The compiler does
+// not see this instruction: the wait states between the chain's last MFMA and the first VALU read of S^T are written out (g2p_mfma_done).
+__device__ __forceinline__ void g2p_mfma_v(f32x16& c, bf16x8 a_, bf16x8 b_) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a_), "v"(b_));
+}
+__device__ __forceinline__ void g2p_mfma_done(f32x16& c) {
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c));          // 8 passes: the result is in the registers 18 cycles after the issue at the latest
+}
+
+// phase A: LDS operations younger than the fragment(s) of k-step ks when its MFMA is due.  Issue order: 4 constants, the fragments of
+// k-steps 0 .. PDA-1, then behind MFMA j: the fragment(s) of k-step j + PDA (one read; two from k-step KR on: the LDS part of the resident
+// operand), then [EARLY, j >= KS - PDB] one operand pair of phase B (two reads)
+template <bool EARLY>
+constexpr int g2p_a_inflight(int ks) {
+  using C = G2P;
+  constexpr int PD = G2P_PDA;
+  int n = 0;
+  for (int m = ks + 1; m < ks + PD && m < C::KS; ++m) n += 1 + (m >= C::KR ? 1 : 0);
+  if (EARLY)
+    for (int jj = (ks - PD > 0 ? ks - PD : 0); jj <= ks - 1; ++jj)
+      if (jj >= C::KS - C::PDB) n += 2;
+  return n;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 g2_lds_read_b128o(unsigned addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+
+template <bool HASP>
+__global__ void __launch_bounds__(256, 1) gen2p_kernel(Gen2Args a) {
+  using C = G2P;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, half = lane >> 5, r31 = lane & 31;
+  const int nwg = (int)gridDim.x, nblk = nwg / a.nsplit;
+  const int j = (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;     // see gen2_kernel
+  const int split = j / nblk, rt = j - split * nblk;
+  const int R0 = rt * 128 + wave * 32;
+  const int row = R0 + r31;
+  const int rowi = row < a.nrows ? row : a.nrows - 1;
+  const int rmap = a.rows ? a.rows[rowi] : rowi;
+  const int rowc = rmap < 0 ? 0 : rmap;
+  const int ntall = (a.ncols + C::BC - 1) / C::BC;
+  const int t0 = split * a.tiles_per_split, t1 = min(ntall, t0 + a.tiles_per_split);
+  const int nt = t1 - t0;
+
+  // LDS-DMA: piece jj (0..7) of this wave = row 4 jj + wave of the tile, whose swizzle is swz(row) = (wave << 2) | (jj & 3): one
+  // per-lane offset serves all pieces (gen2w_kernel); the consts piece = the tile's 32 column constants, one copy per wave.  Tiles
+  // beyond the vocabulary's last one are fetched from the tile right behind it (the caller's w_rows covers that one: vmmt_gen_fwd_dO).
+  char* const small = smem + C::SOFF;
+  const unsigned voff0 = (unsigned)(((lane ^ (wave << 2)) & 63) * 16);
+  const long row4 = 4 * a.ldy * 2, tile_step = (long)C::BC * a.ldy * 2;
+  const char* const ybase = reinterpret_cast<const char*>(a.Y + (long)wave * a.ldy);
+  auto issue_piece = [&](const char* yb, int tsrc, int slot, int jj) {
+    if (jj < C::PER) {
+      const char* src = yb + jj * row4 + (voff0 ^ (unsigned)((jj & 3) << 4));
+      __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)src, (f_lds_void_t*)(smem + slot * C::TILEB + (4 * jj + wave) * C::ROWB), 16, 0, 0);
+    } else {
+      int c = tsrc * C::BC + r31;
+      c = c < a.ncols ? c : a.ncols - 1;
+      const void* src = (const void*)(a.cvec + c);
+      __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)src, (f_lds_void_t*)(small + slot * C::SMALLB + wave * 256), 4, 0, 0);
+    }
+  };
+  if (nt > 0) {
+#pragma unroll
+    for (int d = 0; d < C::PF; ++d) {
+      const int ts = min(t0 + d, ntall);
+      const char* yb = ybase + (long)ts * tile_step;
+#pragma unroll
+      for (int jj = 0; jj <= C::PER; ++jj) issue_piece(yb, ts, d, jj);
+    }
+  }
+
+  // resident operand, all of it in registers: B-operand fragments (lane = row r31, k = 16 ks + 8 half + 0..7)
+  bf16x8 xf[C::KR];
+  char* const xl = smem + C::XOFF + wave * C::XWAVEB + lane * 16;
+  {
+    const bf16_t* xr = a.X + (long)rowc * a.ldx + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < C::KR; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 16);
+#pragma unroll
+    for (int k = 0; k < C::KL; ++k) *reinterpret_cast<bf16x8*>(xl + k * 1024) = *reinterpret_cast<const bf16x8*>(xr + (C::KR + k) * 16);
+  }
+  f32x16 acc[C::HB];
+#pragma unroll
+  for (int hb = 0; hb < C::HB; ++hb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[hb][r] = 0.f;
+
+  // fragment addressing (gen2w_kernel's three constants; the fragment index enters as an XOR, the ring slot as a sum)
+  int ua0, ul0, uh0;
+  {
+    const int sw = g2_swz(r31);
+    ua0 = r31 * C::ROWB + ((half ^ sw) * 16);
+    const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, g1 = (lane >> 4) & 1;
+    const int tw = 2 * g1 + (p4 >> 1);
+    const int x_lo = (q << 2) | half, x_hi = (q << 2) | (half + 2);
+    ul0 = (4 * half + q) * C::ROWB + (p4 & 1) * 8 + ((tw ^ x_lo) * 16);
+    uh0 = (4 * half + q + 8) * C::ROWB + (p4 & 1) * 8 + ((tw ^ x_hi) * 16);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  float ref = -INFINITY, nrl = 0.f, lsum = 0.f, rmax = -INFINITY;
+  int ym = (row < a.nrows && rmap >= 0) ? (int)a.y[rowc] : -1;
+  asm volatile("" : "+v"(ym));
+  const bool stores = HASP && R0 < a.nrows;                 // (a wave without a single row issues no store: its waits must not count one)
+  const bool rowok = row < a.nrows;
+  const unsigned poff = (unsigned)(((long)rowi * a.ldp + 8 * half) * 2);      // this lane's byte offset into a row-major P (< 4 GB: checked by the host)
+
+  bf16x8 pfo[2];                                            // P(i-1)^T: B-operand fragments of the second product
+  pfo[0] = pfo[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 sT;
+
+  // ---- A(i): S^T(i)[c][r] = sum_h Y[c][h] X[r][h] + column constants; DMA of tile i + PF; [EARLY] the first PDB operand pairs of B(i)
+  // Every LDS read of the phase is inline assembly with a counted wait in front of its MFMA (g2p_a_inflight): the compiler does not see the
+  // asm MFMA as the reads' consumer in LDS-return order and waits for lgkmcnt(0) -- all the prefetched fragments -- every few MFMAs.
+  fs16x4 fl[C::PDB], fh[C::PDB];                            // operand pairs of the second product (ring of PDB)
+  unsigned ulq[4], uhq[4];                                  // their addresses: eight per tile instead of an XOR in front of every read
+  auto rdB = [&](auto ic) {
+    constexpr int k = decltype(ic)::value, hb = G2_HB(k), kk = G2_KK(k);
+    constexpr int off = (hb >> 2) * 256 + kk * 16 * C::ROWB;
+#if defined(G2P_EXP_NOLDSB)
+    asm volatile("" : "=v"(fl[k % C::PDB]), "=v"(fh[k % C::PDB]) : "v"(ulq[hb & 3]), "v"(uhq[hb & 3]));
+#else
+    fl[k % C::PDB] = g2_tr_read<off>(ulq[hb & 3]);
+    fh[k % C::PDB] = g2_tr_read<off>(uhq[hb & 3]);
+#endif
+  };
+  // P[m][c0 .. c0+31] of tile ip, row-major, straight out of the fragment registers.  A lane holds, of ONE token, the entries
+  // 8 q + 4 half + 0..3 (q = 0..3): pfo[j] = [q = 2j: two packed registers | q = 2j + 1: two].  v_permlane32_swap (lanes 32..63 of the first
+  // operand <-> lanes 0..31 of the second) on the register pairs (q even, q odd) leaves lane t with the 8 consecutive entries 16 j .. 16 j + 7
+  // of token t and lane 32 + t with 16 j + 8 .. 16 j + 15, in register order: one 16-byte store per lane, 32 contiguous bytes per token
+  // and instruction.  Issued at the head of phase A of the NEXT tile (the fragments live until that tile's phase B is over): the S^T phase
+  // has instruction slots to spare, phase B has none.
+  auto storeP = [&](int ip) {
+    if constexpr (HASP) {
+      u32x4 pw[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const u32x4 v = __builtin_bit_cast(u32x4, pfo[jj]);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+        pw[jj] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+      if (rowok) {
+        char* pb = reinterpret_cast<char*>(a.p_out + (t0 + ip) * C::BC) + poff;
+        *reinterpret_cast<u32x4*>(pb) = pw[0];
+        *reinterpret_cast<u32x4*>(pb + 32) = pw[1];
+      }
+    }
+  };
+  auto phaseA = [&](auto early, int i) {
+    constexpr bool EARLY = decltype(early)::value;
+    if constexpr (EARLY) storeP(i - 1);
+    constexpr int PD = G2P_PDA;
+    const int slot = i % C::NSLOT;
+    const unsigned sb = lds0 + C::SOFF + slot * C::SMALLB + wave * 256 + half * 16;
+    u32x4 cv[4];
+    g2_static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; cv[q] = g2_lds_read_b128o<q * 32>(sb); });
+    unsigned uaq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) uaq[e] = (lds0 + ua0 + slot * C::TILEB) ^ (e << 5);
+    if constexpr (EARLY) {
+      const unsigned sprev = lds0 + (unsigned)(((i + C::NSLOT - 1) % C::NSLOT) * C::TILEB);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ulq[q] = (sprev + ul0) ^ (q << 6); uhq[q] = (sprev + uh0) ^ (q << 6); }
+    }
+    const unsigned xla = lds0 + C::XOFF + wave * C::XWAVEB + lane * 16;
+    const int tn = min(t0 + i + C::PF, ntall), sn = (i + C::PF) % C::NSLOT;
+    const char* yn = ybase + (long)tn * tile_step;
+    u32x4 fa[PD], fx[PD < C::KL ? C::KL : PD];
+    auto rd = [&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+#if defined(G2P_EXP_NOLDSA)
+      fa[ks % PD] = u32x4{uaq[0], uaq[1], uaq[2], uaq[3]};
+      if constexpr (ks >= C::KR) fx[ks % PD] = u32x4{uaq[0], uaq[1], uaq[2], uaq[3]};
+#else
+      fa[ks % PD] = g2_lds_read_b128o<(ks >> 3) * 256>(uaq[ks & 7]);
+      if constexpr (ks >= C::KR) fx[ks % PD] = g2_lds_read_b128o<(ks - C::KR) * 1024>(xla);
+#endif
+    };
+    g2_static_for<0, PD>([&](auto kc) { rd(kc); });
+    g2_static_for<0, C::KS>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      constexpr int inflight = g2p_a_inflight<EARLY>(ks);
+      static_assert(inflight <= 15, "lgkmcnt is a 4-bit counter");
+      if constexpr (ks == 0) {
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]), "+v"(fa[0]) : "n"(inflight));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sT[4 * q + e] = __uint_as_float(cv[q][e]);
+      } else if constexpr (ks >= C::KR) {
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[ks % PD]), "+v"(fx[ks % PD]) : "n"(inflight));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fa[ks % PD]) : "n"(inflight));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks < C::KR) g2p_mfma_v(sT, __builtin_bit_cast(bf16x8, fa[ks % PD]), xf[ks < C::KR ? ks : 0]);
+      else g2p_mfma_v(sT, __builtin_bit_cast(bf16x8, fa[ks % PD]), __builtin_bit_cast(bf16x8, fx[ks % PD]));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks + PD < C::KS) rd(std::integral_constant<int, ks + PD>{});
+      if constexpr (EARLY && ks >= C::KS - C::PDB) rdB(std::integral_constant<int, ks - (C::KS - C::PDB)>{});
+#if !defined(G2P_EXP_NODMA)
+      if constexpr ((ks & 3) == 1) issue_piece(yn, tn, sn, ks >> 2);
+      if constexpr (ks == 3) issue_piece(yn, tn, sn, C::PER);
+#endif
+    });
+    g2p_mfma_done(sT);
+  };
+
+  // ---- B: [WITH2] acc^T += Y(i-1)^T P(i-1)^T with [WITHEW] the element-wise phase of tile i between its MFMAs
+  auto phaseB = [&](auto with2, auto withew, int i) {
+    constexpr bool WITH2 = decltype(with2)::value, WITHEW = decltype(withew)::value;
+    constexpr int PD = C::PDB, NM = C::NM;
+    const int c0 = (t0 + i) * C::BC;                        // first vocabulary entry of tile i (element-wise)
+    auto rd = rdB;
+    if constexpr (WITH2 && !WITHEW) {                       // (the epilogue: no phase A in front of it that has requested the first pairs)
+      const unsigned sprev = lds0 + (unsigned)(((i + C::NSLOT - 1) % C::NSLOT) * C::TILEB);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ulq[q] = (sprev + ul0) ^ (q << 6); uhq[q] = (sprev + uh0) ^ (q << 6); }
+      g2_static_for<0, PD>([&](auto ic) { rd(ic); });
+    }
+
+    bf16x8 pfn[2];
+    float tmax = -INFINITY, fpend = 1.f, pe = 0.f;
+    bool moved = false;
+    if constexpr (WITHEW) {
+      if (c0 + C::BC > a.ncols) {                           // last tile of the vocabulary: rows >= V do not exist
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (c0 + (r & 3) + 8 * (r >> 2) + 4 * half >= a.ncols) sT[r] = -INFINITY;
+      }
+    }
+    g2_static_for<0, NM>([&](auto ic) {
+      constexpr int k = decltype(ic)::value;
+      if constexpr (WITH2) {
+        constexpr int inflight = g2p_inflight(k);
+        static_assert(inflight <= 15, "lgkmcnt is a 4-bit counter");
+        g2_wait_lgkm<inflight>(fl[k % PD], fh[k % PD]);
+        const fs16x8 v = __builtin_shufflevector(fl[k % PD], fh[k % PD], 0, 1, 2, 3, 4, 5, 6, 7);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[G2_HB(k)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), pfo[G2_KK(k)], acc[G2_HB(k)], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (k + PD < NM) rd(std::integral_constant<int, k + PD>{});
+      }
+      if constexpr (WITHEW) {
+        if constexpr (k == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sT[r]), sT[r + 1]);
+          rmax = fmaxf(rmax, tmax);
+        }
+        if constexpr (k == 1) {
+          if (__any(tmax > ref + G2_THR)) {                 // the reference moves (always in the first tile; hardly ever later)
+            const float nm = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            moved = nm > ref + G2_THR;
+            fpend = moved ? __expf(ref - nm) : 1.f;
+            if (moved) { ref = nm; nrl = -nm * G2_L2E; }
+            lsum *= fpend;
+          }
+        }
+        if constexpr (k >= C::EW0 && k < C::EW0 + 16) {
+          constexpr int r = k - C::EW0;
+#if defined(G2P_EXP_NOEW)
+          const float pv = sT[r];
+#else
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[r], G2_L2E, nrl));
+#endif
+          lsum += pv;
+          if constexpr ((r & 1) == 0) pe = pv;
+          else {
+            pfn[r >> 3][(r & 7) - 1] = (__bf16)pe;
+            pfn[r >> 3][r & 7] = (__bf16)pv;
+          }
+        }
+      }
+    });
+#pragma unroll
+    for (int hb = 0; hb < C::HB; ++hb) asm volatile("" : "+a"(acc[hb]));
+    if constexpr (WITHEW) {
+      if (__any(ym >= c0 && ym < c0 + C::BC)) {             // a target of this wave's tokens lies in tile i: keep its logit
+        float tl = 0.f;
+        bool hit = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool h = c0 + (r & 3) + 8 * (r >> 2) + 4 * half == ym;
+          tl = h ? sT[r] : tl;
+          hit = hit || h;
+        }
+        if (hit) a.tgt_logit[row] = tl;
+      }
+      if constexpr (WITH2) {
+        if (__any(moved)) {
+          // (practically never behind the first tile)  acc holds the tiles up to i - 1 in units of the OLD reference, and so do the weights
+          // stored for them: rescale, rewrite.  The second product's last MFMAs may still be in flight: the accumulator reads below are
+          // inline assembly, which the compiler's hazard recogniser does not see
+          asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+          for (int hb = 0; hb < C::HB; ++hb) g2_scale_acc(acc[hb], fpend);
+          if constexpr (HASP) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (moved && row < a.nrows) {
+              bf16_t* pr = a.p_out + (long)row * a.ldp;
+              for (int v = t0 * C::BC + half * 8; v < c0; v += 16) {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = __hip_atomic_load(reinterpret_cast<uint32_t*>(pr + v) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float lo = __uint_as_float(w[e] << 16) * fpend, hi = __uint_as_float(w[e] & 0xffff0000u) * fpend;
+                  w[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+                }
+                *reinterpret_cast<u32x4*>(pr + v) = u32x4{w[0], w[1], w[2], w[3]};
+              }
+            }
+          }
+        }
+      }
+      pfo[0] = pfn[0];
+      pfo[1] = pfn[1];
+    }
+  };
+
+  if (nt > 0) {
+    // iteration 0: nothing to add yet
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    phaseA(std::false_type{}, 0);
+    phaseB(std::false_type{}, std::true_type{}, 0);
+#if defined(VMMT_EXP_PROBE)
+    // (scalar stamps of wave 0 of workgroup 0: a per-lane array of counters would cost this kernel the registers it does not have)
+    const bool probe = blockIdx.x == 0 && wave == 0;
+    unsigned long long ps[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = last_, r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int i = 1; i < nt; ++i) {
+      G2_STAMP(5);
+      // tile i has landed (its pieces went out in phase A(i - PF); younger: per later phase A the two stores of P and 9 pieces)
+      if (stores) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((C::PF - 1) * (2 + C::PER + 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((C::PF - 1) * (C::PER + 1)) : "memory");
+      G2_STAMP(0);
+      // ... for every wave; and every wave is done with tile i - 2.  (The bare barrier: __syncthreads()'s fence makes the compiler wait
+      //  for vmcnt(0) here -- the two tiles in flight.  Everything the barrier orders is waited for by hand: the DMA above, phase B's
+      //  transposed reads in front of their MFMAs)
+      __builtin_amdgcn_s_barrier();
+      G2_STAMP(1);
+#if defined(G2P_EXP_NOB)
+      phaseA(std::false_type{}, i);
+#elif defined(G2P_EXP_NOA)
+      if (i == 1) phaseA(std::true_type{}, i);
+#else
+      phaseA(std::true_type{}, i);
+#endif
+      G2_STAMP(2);
+#if !defined(G2P_EXP_NOB)
+      phaseB(std::true_type{}, std::true_type{}, i);
+#endif
+      G2_STAMP(4);
+    }
+#if defined(VMMT_EXP_PROBE)
+    if (probe && lane == 0) {
+      for (int q = 0; q < 6; ++q) g2_probe[q] = ps[q];
+      g2_probe[3] = 0;
+      g2_probe[6] = (unsigned long long)(nt - 1);
+      g2_probe[7] = (__builtin_amdgcn_s_memtime() - t_begin) * 100ull / (__builtin_amdgcn_s_memrealtime() - r_begin);
+    }
+#endif
+    storeP(nt - 1);
+    __syncthreads();
+    phaseB(std::true_type{}, std::false_type{}, nt);
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may outlive the workgroup's LDS allocation
+  if (row < a.nrows) {
+    const long pr = (long)split * a.mpad + row;
+    float* dst = a.p_acc + pr * C::D;
+    const float lt = lsum + __shfl_xor(lsum, 32, 64), mt = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    if (half == 0) { a.p_ref[pr] = ref; a.p_l[pr] = lt; a.p_max[pr] = mt; }
+#pragma unroll
+    for (int hb = 0; hb < C::HB; ++hb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[hb][4 * q + e];
+        *reinterpret_cast<f32x4*>(dst + 32 * hb + 8 * q + 4 * half) = v;
       }
   }
 }
@@ -1073,6 +1517,17 @@ static int g2_launch(const Gen2Args& a, int grid, hipStream_t st) {
 }
 
 template <bool HASP>
+static int g2p_launch(const Gen2Args& a, int grid, hipStream_t st) {
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)gen2p_kernel<HASP>, hipFuncAttributeMaxDynamicSharedMemorySize, G2P::LDSB) != hipSuccess) return VMMT_ELAUNCH;
+    done = true;
+  }
+  hipLaunchKernelGGL((gen2p_kernel<HASP>), dim3(grid), dim3(256), G2P::LDSB, st, a);
+  return check_launch();
+}
+
+template <bool HASP>
 static int g2w_launch(const Gen2Args& a, int grid, hipStream_t st) {
   static bool done = false;
   if (!done) {
@@ -1139,6 +1594,9 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows
   a.rows = rows;
   hipStream_t st = (hipStream_t)stream;
   if (K == 1024) return Pw ? g2w_launch<true>(a, (M + 63) / 64 * ns, st) : g2w_launch<false>(a, (M + 63) / 64 * ns, st);
+  static const bool classic = getenv("VMMT_GEN2_CLASSIC") != nullptr;      // (development A/B only)
+  // (gen2p_kernel addresses P with 32-bit byte offsets from a per-tile base)
+  if (K == 512 && !classic && (!Pw || (int64_t)M * ldp * 2 < (int64_t)0xffff0000ll)) return Pw ? g2p_launch<true>(a, nmt * ns, st) : g2p_launch<false>(a, nmt * ns, st);
   if (Pw) return K == 512 ? g2_launch<512, true>(a, nmt * ns, st) : g2_launch<256, true>(a, nmt * ns, st);
   return K == 512 ? g2_launch<512, false>(a, nmt * ns, st) : g2_launch<256, false>(a, nmt * ns, st);
 }
