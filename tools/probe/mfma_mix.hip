@@ -74,13 +74,26 @@ int main() {
     RUN(9, 1, 1, 0, 0, false, false);
     RUN(10, 0, 0, 1, 0, true, false);
     RUN(11, 3, 1, 2, 0, true, true);
+    RUN(12, 1, 0, 0, 1, true, false);      // phase A + VALU: b128 read per MFMA + 1 fma
+    RUN(13, 2, 0, 0, 1, true, false);
+    RUN(14, 4, 0, 0, 1, true, false);
+    RUN(15, 0, 1, 0, 1, true, false);      // + 1 exp
+    RUN(16, 1, 1, 0, 1, true, false);
+    RUN(17, 2, 1, 0, 1, true, false);
+    RUN(18, 6, 0, 0, 0, false, false);
+    RUN(19, 2, 0, 2, 0, true, true);
+    RUN(20, 1, 0, 2, 0, true, true);
+    RUN(21, 0, 1, 2, 0, true, true);
   }
   hipDeviceSynchronize();
-  unsigned long long h[16]; hipMemcpy(h, cyc, 16 * 8, hipMemcpyDeviceToHost);
+  unsigned long long h[32]; hipMemcpy(h, cyc, 32 * 8, hipMemcpyDeviceToHost);
   const double n = 32.0 * iters;
   printf("cycles per step, one wave per SIMD, 4 waves per CU in lockstep:\n");
   printf("  MFMA alone %.1f | + 2 tr reads (no wait) %.1f | + counted wait %.1f | + MFMA consumes them %.1f | 1 tr read + wait %.1f\n", h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[10] / n);
   printf("  consume + 1 fma + 1 exp %.1f | + 2 fma + 1 exp %.1f | + 3 fma + 1 exp %.1f | + 4 fma %.1f | (1 fma + 1 exp, no LDS: %.1f)\n", h[4] / n, h[5] / n, h[11] / n, h[8] / n, h[9] / n);
   printf("  1 ds_read_b128 per MFMA: waited %.1f | not waited %.1f\n", h[6] / n, h[7] / n);
+  printf("  b128 read per MFMA + 1 fma %.1f | + 2 fma %.1f | + 4 fma %.1f | + 1 exp %.1f | + 1 fma + 1 exp %.1f | + 2 fma + 1 exp %.1f | (6 fma, no LDS: %.1f)\n",
+         h[12] / n, h[13] / n, h[14] / n, h[15] / n, h[16] / n, h[17] / n, h[18] / n);
+  printf("  2 tr reads consumed + 1 fma %.1f | + 2 fma %.1f | + 1 exp %.1f\n", h[20] / n, h[19] / n, h[21] / n);
   return 0;
 }

@@ -275,7 +275,9 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
     G2_STAMP(5);
     // tile t has landed.  vmcnt counts in issue order: the only operations younger than its DMA pieces are the two stores of P behind
     // the previous tile's element-wise phase, which may stay in flight (waiting for their acknowledgement costs ~0.5 us per tile)
-    if (HASP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // (a wave none of whose rows exists issues no store -- its exec mask is empty and the compiler branches around them: it must not
+    //  leave two DMA pieces in flight instead)
+    if (HASP && R0 < a.nrows) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G2_STAMP(0);
     __syncthreads();                                        // ... for every wave; and every wave is done with tile t-1
@@ -490,16 +492,26 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
 // the ONE instruction stream a SIMD has at 512 registers per lane: the matrix unit idles under the element-wise phase, and the first
 // operands of every product are waited for (profiles/r4_gen2_kernel_counters.txt: matrix pipe busy 49 % of the wave's cycles).  Here
 // the phases of NEIGHBOURING tiles overlap inside that one stream.  Iteration i:
-//     A(i):  S^T(i)                               32 MFMAs, operands by rows from tile i, the LDS-DMA of tile i + 2 in their shadow
-//     B(i):  acc^T += Y(i-1)^T P(i-1)^T           32 MFMAs, transposed reads of tile i - 1,
-//            with element-wise(i) -- max, exp, row sums, bf16 P(i), the P patch and its stores -- issued BETWEEN those MFMAs: a VALU /
-//            LDS instruction behind an independent MFMA issues while the matrix unit works on it.
-// What that costs: tiles i - 1 and i are both alive while i + 1 and i + 2 are landing: a FOUR-deep ring of 32-KiB tiles (128 KiB), which
-// fits because the resident operand O lives in registers alone (128 per lane, as gen2w_kernel keeps its half: no LDS part, no
-// second LDS read per MFMA of the S^T phase); two generations of P fragments (16 registers); and a lazy reference that moves in the
-// element-wise phase of tile i rescales the accumulators only once B(i) has added tile i - 1 in the old units (`fpend`).
+//     A(i):  the two stores of P(i-1); S^T(i): 32 MFMAs, operands by rows from tile i, the LDS-DMA of tile i + 2 in their shadow; behind
+//            the last ones the first operand pairs of B(i) are requested
+//     B(i):  acc^T += Y(i-1)^T P(i-1)^T: 32 MFMAs, transposed reads of tile i - 1, with element-wise(i) -- max, exp, row sums, bf16 P(i) --
+//            issued BETWEEN those MFMAs
+// What a wave's stream can hold next to an MFMA was measured (tools/probe/mfma_mix.hip, mfma_valu.hip, mfma_chain.hip; one wave per
+// SIMD, cycles of issue): v_mfma_f32_32x32x16_bf16 4 (the matrix unit then works 32), a VALU instruction ~5, v_exp_f32 ~13,
+// ds_read_b128 ~16, ds_read_b64_tr_b16 ~14, each after the other -- LDS reads do NOT issue in parallel with VALU work of the same wave.
+// Phase A (MFMA + one row read) leaves ~12 cycles per MFMA free, phase B (MFMA + two transposed reads) none: the sweep is bound by the
+// instruction issue of its one wave per SIMD (~2 700 cycles per tile of issue against 2 048 of MFMA), not by LDS latency (deeper
+// prefetch changes nothing) nor by dependent MFMAs (a chain on one accumulator runs at 32 cycles per MFMA).  What this kernel removes
+// against gen2_kernel: the waits in front of each product's first operands, 16 LDS reads of the resident operand per tile (28 of its
+// 32 k-steps live in registers, 4 in LDS), the P patch in LDS (v_permlane32_swap instead), 64 v_accvgpr moves per tile (S^T accumulates
+// in VGPRs through an inline-asm MFMA), an XOR in front of every LDS read (eight addresses per tile and phase).  Measured, same box,
+// M 5120 x V 30 000: 332 against 368 us (P stored), 299 against 331 us (no P).  The exps moved into phase A's free slots were measured
+// too (LABNOTES round 5): slower -- pinned between asm MFMAs they cost hazard nops, and phase A is held up by its DMA and store issues.
+// What that costs: tiles i - 1 and i are both alive while i + 1 and i + 2 are landing: a FOUR-deep ring of 32-KiB tiles (128 KiB);
+// two generations of P fragments (16 registers); and a lazy reference that moves in the element-wise phase of tile i rescales the
+// accumulators only once B(i) has added tile i - 1 in the old units (`fpend`).
 // One workgroup barrier per tile, as before.  vmcnt counts in issue order (gfx9: loads and stores on one counter): at the top of
-// iteration i the operations younger than tile i's DMA pieces are the stores of P(i-2), the pieces of tile i + 1, the stores of P(i-1).
+// iteration i the operations younger than tile i's DMA pieces are, per later phase A, two stores of P and nine pieces.
 #ifndef G2P_PDA
 #define G2P_PDA 5
 #endif
@@ -659,12 +671,8 @@ __global__ void __launch_bounds__(256, 1) gen2p_kernel(Gen2Args a) {
   auto rdB = [&](auto ic) {
     constexpr int k = decltype(ic)::value, hb = G2_HB(k), kk = G2_KK(k);
     constexpr int off = (hb >> 2) * 256 + kk * 16 * C::ROWB;
-#if defined(G2P_EXP_NOLDSB)
-    asm volatile("" : "=v"(fl[k % C::PDB]), "=v"(fh[k % C::PDB]) : "v"(ulq[hb & 3]), "v"(uhq[hb & 3]));
-#else
     fl[k % C::PDB] = g2_tr_read<off>(ulq[hb & 3]);
     fh[k % C::PDB] = g2_tr_read<off>(uhq[hb & 3]);
-#endif
   };
   // P[m][c0 .. c0+31] of tile ip, row-major, straight out of the fragment registers.  A lane holds, of ONE token, the entries
   // 8 q + 4 half + 0..3 (q = 0..3): pfo[j] = [q = 2j: two packed registers | q = 2j + 1: two].  v_permlane32_swap (lanes 32..63 of the first
@@ -711,13 +719,8 @@ __global__ void __launch_bounds__(256, 1) gen2p_kernel(Gen2Args a) {
     u32x4 fa[PD], fx[PD < C::KL ? C::KL : PD];
     auto rd = [&](auto kc) {
       constexpr int ks = decltype(kc)::value;
-#if defined(G2P_EXP_NOLDSA)
-      fa[ks % PD] = u32x4{uaq[0], uaq[1], uaq[2], uaq[3]};
-      if constexpr (ks >= C::KR) fx[ks % PD] = u32x4{uaq[0], uaq[1], uaq[2], uaq[3]};
-#else
       fa[ks % PD] = g2_lds_read_b128o<(ks >> 3) * 256>(uaq[ks & 7]);
       if constexpr (ks >= C::KR) fx[ks % PD] = g2_lds_read_b128o<(ks - C::KR) * 1024>(xla);
-#endif
     };
     g2_static_for<0, PD>([&](auto kc) { rd(kc); });
     g2_static_for<0, C::KS>([&](auto kc) {
@@ -741,10 +744,8 @@ __global__ void __launch_bounds__(256, 1) gen2p_kernel(Gen2Args a) {
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (ks + PD < C::KS) rd(std::integral_constant<int, ks + PD>{});
       if constexpr (EARLY && ks >= C::KS - C::PDB) rdB(std::integral_constant<int, ks - (C::KS - C::PDB)>{});
-#if !defined(G2P_EXP_NODMA)
       if constexpr ((ks & 3) == 1) issue_piece(yn, tn, sn, ks >> 2);
       if constexpr (ks == 3) issue_piece(yn, tn, sn, C::PER);
-#endif
     });
     g2p_mfma_done(sT);
   };
@@ -801,11 +802,7 @@ __global__ void __launch_bounds__(256, 1) gen2p_kernel(Gen2Args a) {
         }
         if constexpr (k >= C::EW0 && k < C::EW0 + 16) {
           constexpr int r = k - C::EW0;
-#if defined(G2P_EXP_NOEW)
-          const float pv = sT[r];
-#else
           const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[r], G2_L2E, nrl));
-#endif
           lsum += pv;
           if constexpr ((r & 1) == 0) pe = pv;
           else {
@@ -884,17 +881,9 @@ __global__ void __launch_bounds__(256, 1) gen2p_kernel(Gen2Args a) {
       //  transposed reads in front of their MFMAs)
       __builtin_amdgcn_s_barrier();
       G2_STAMP(1);
-#if defined(G2P_EXP_NOB)
-      phaseA(std::false_type{}, i);
-#elif defined(G2P_EXP_NOA)
-      if (i == 1) phaseA(std::true_type{}, i);
-#else
       phaseA(std::true_type{}, i);
-#endif
       G2_STAMP(2);
-#if !defined(G2P_EXP_NOB)
       phaseB(std::true_type{}, std::true_type{}, i);
-#endif
       G2_STAMP(4);
     }
 #if defined(VMMT_EXP_PROBE)
@@ -1594,7 +1583,11 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows
   a.rows = rows;
   hipStream_t st = (hipStream_t)stream;
   if (K == 1024) return Pw ? g2w_launch<true>(a, (M + 63) / 64 * ns, st) : g2w_launch<false>(a, (M + 63) / 64 * ns, st);
-  static const bool classic = getenv("VMMT_GEN2_CLASSIC") != nullptr;      // (development A/B only)
+#if defined(VMMT_EXP_CLASSIC)      // probe build (tools/exp_build.sh generator_fused.hip CLASSIC): the unpipelined H = 512 sweep, for same-box comparisons
+  constexpr bool classic = true;
+#else
+  constexpr bool classic = false;
+#endif
   // (gen2p_kernel addresses P with 32-bit byte offsets from a per-tile base)
   if (K == 512 && !classic && (!Pw || (int64_t)M * ldp * 2 < (int64_t)0xffff0000ll)) return Pw ? g2p_launch<true>(a, nmt * ns, st) : g2p_launch<false>(a, nmt * ns, st);
   if (Pw) return K == 512 ? g2_launch<512, true>(a, nmt * ns, st) : g2_launch<256, true>(a, nmt * ns, st);
