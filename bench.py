@@ -715,19 +715,22 @@ def main():
         if fused and dom.get("gen_fwd_tokens"):      # per launch as issued: 4 H V x the launch's own token count over its own time
             tsum = sum(s.elapsed_time(e_) for s, e_ in dom["gen_fwd"])
             ach = 4.0 * sum(dom["gen_fwd_tokens"]) * d.vt * d.hid / (tsum * 1e-3) / 1e12 if tsum > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json).  The entry names the
-        # kernel source it was measured on (sha256 of the .hip file); if that file has changed since, the figure is withheld
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json).  The entry names the source
+        # text it was measured on -- the kernel's own region of its .hip file (tools/traffic_key.py), so that an edit elsewhere in the
+        # file does not void it, and tests/test_traffic_json.py fails while the region and the entry disagree
         traffic, traffic_note = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["config%s" % a.config]
             if B == 256 and a.dtype == "bf16" and not a.conditional and a.lengths == "fixed":
-                import hashlib
-                src_file = os.path.join(ROOT, tj["kernel_source"])
-                sha = hashlib.sha256(open(src_file, "rb").read()).hexdigest()[:16]
-                if sha == tj["kernel_source_sha16"]:
-                    traffic = tj["read_bytes"] + tj["write_bytes"]
-                else:
-                    traffic_note = "profiles/traffic.json is stale: %s changed since the PMC pass (%s != %s)" % (tj["kernel_source"], sha, tj["kernel_source_sha16"])
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import traffic_key
+                traffic = tj["read_bytes"] + tj["write_bytes"]
+                sha = traffic_key.key_hash(tj["kernel_region"])
+                if sha != tj["kernel_region_sha16"]:
+                    traffic_note = ("measured on an EARLIER revision of %s's source region (%s, now %s): re-run tools/pmc.sh" %
+                                    (tj["kernel_region"], tj["kernel_region_sha16"], sha))
+            else:
+                traffic_note = "the PMC pass was taken at batch 256, bf16, fixed lengths, fixed prior: no figure for this variation"
         except Exception as ex:
             traffic_note = "no PMC figure for this configuration (%s)" % type(ex).__name__
         out = {

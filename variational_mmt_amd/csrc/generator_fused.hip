@@ -41,6 +41,7 @@
 
 namespace vmmt {
 
+// >>> traffic-key common   (tools/traffic_key.py: profiles/traffic.json names the source text its PMC figures were measured on)
 typedef __attribute__((address_space(3))) void f_lds_void_t;
 typedef __attribute__((address_space(1))) const void f_glb_cvoid_t;
 typedef short fs16x4 __attribute__((ext_vector_type(4)));
@@ -157,6 +158,8 @@ __device__ unsigned long long g2_probe[16];
 #define G2_STAMP(i) do { } while (0)
 #endif
 
+// <<< traffic-key common
+// >>> traffic-key gen2
 template <int D, bool HASP>          // HASP: the softmax weights P are stored (a.p_out != NULL)
 __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   using C = G2<D>;
@@ -487,6 +490,8 @@ __global__ void __launch_bounds__(256, 1) gen2_kernel(Gen2Args a) {
   }
 }
 
+// <<< traffic-key gen2
+// >>> traffic-key gen2p
 // ---- H = 512, software-pipelined across tiles (the product kernel at H = 512) ------------------------------------------------------
 // gen2_kernel above runs its three phases -- S^T (32 MFMAs), element-wise (exp, P), second product (32 MFMAs) -- one after the other in
 // the ONE instruction stream a SIMD has at 512 registers per lane: the matrix unit idles under the element-wise phase, and the first
@@ -917,6 +922,8 @@ __global__ void __launch_bounds__(256, 1) gen2p_kernel(Gen2Args a) {
   }
 }
 
+// <<< traffic-key gen2p
+// >>> traffic-key gen2w
 // ---- the same sweep at H = 1024 ------------------------------------------------------------------------------------------------
 // acc^T for 32 tokens x 1024 columns would be 512 accumulator registers per lane.  Here TWO waves share a group of 32 tokens: wave
 // (tg, dh) owns the columns [512 dh, 512 dh + 512) of acc^T (256 accumulator registers, as at H = 512) and -- the k range of S^T being
@@ -1230,6 +1237,7 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
   }
 }
 
+// <<< traffic-key gen2w
 // combine of pass F: 8 tokens per workgroup (32 threads per token).  Folds the vocabulary slices' (ref, l, max, acc) and writes
 //   lse, tok_nll, the statistics (NLL, words, correct), y32 (targets as int32, -1 at pads; whole 32-token tiles),
 //   dO[m][h] = s_m (sum_s w_s acc_s[m][h] / l* - Wg[y_m][h]),  w_s = exp(ref_s - ref*).
