@@ -309,3 +309,72 @@ def test_sharded_run_survives_a_replica_resync(tmp_path):
     r = torch.load(out)
     # (a reset of rank 1's moments at step 3 would show as a parameter difference of the order of lr = 1e-2)
     assert r["same"] and r["p_err"] <= 1e-5 and r["m_err"] <= 1e-6, r
+
+
+def _worker_guard_skew(rank, world, port, out):
+    """a recurrence hand-off 'times out' on ONE rank (its guard word is set by hand behind step 2's backward) while the hosts run ahead of
+    their devices by different amounts: both ranks must skip the same updates, switch to the per-step kernels on the same step, clear the
+    guard once, and go on training with bit-identical replicas (the advisor's livelock: rank A clears, rank B's still-set guard folds back)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    import torch.distributed as dist
+    from oracle import vi1_oracle as O
+    from variational_mmt_amd.dp import GradSync
+    from variational_mmt_amd.engine import Dims, Engine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = O.Cfg(vs=41, vt=43, emb=16, hid=32, z=8, img=2048, layers=1, brnn=True)
+    p = O.init_params(c, seed=6)
+    Bg = 10
+    bt = O.synth_batch(c, Bg, 6, 7, n_img=16, seed=8, fixed_len=False)
+    sl = slice(rank * Bg // world, (rank + 1) * Bg // world)
+    res = {}
+    for sharded in (True, False):
+        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda:0")
+        e.persistent_lstm = False          # (two processes share the GPU: the persistent kernels cannot both be resident; the guard is set by hand)
+        e.load_state_dict(p)
+        e.set_image_table(bt["table"])
+        sync = GradSync(e, sharded=sharded)
+        fell, moved = [], []
+        for k in range(9):
+            before = e.flat_p.clone()
+            ws = e.forward(bt["src"][:, sl], bt["src_len"][sl], bt["tgt"][:, sl], bt["indices"][sl], training=True, eps=bt["eps"][sl])
+            e.loss_backward(ws, normalization=Bg, batch_global=Bg)
+            if k == 2 and rank == 0:
+                e._guard[0] = 0x51          # "timed out" on this rank only
+            if rank == 1:
+                torch.cuda.synchronize()    # this rank's host sees its device's copies at once; the other one runs ahead
+            else:
+                time.sleep(0.01 * (k % 2))
+            sync.all_reduce()
+            n0 = e.seq_fallbacks
+            e.optim_step(lr=0.002, max_grad_norm=5.0)
+            fell.append(e.seq_fallbacks - n0)
+            torch.cuda.synchronize()
+            moved.append(bool((e.flat_p != before).any()))
+        e.check_async_errors()
+        flat_p = e.flat_p.cpu().clone()
+        gathered = [torch.zeros_like(flat_p) for _ in range(world)]
+        dist.all_gather(gathered, flat_p)
+        info = torch.tensor([float(sum(fell)), float(fell.index(1) if 1 in fell else -1), float(e.steps_skipped), float(e.step_count)])
+        infos = [torch.zeros_like(info) for _ in range(world)]
+        dist.all_gather(infos, info)
+        res[sharded] = {"same_params": bool(torch.equal(gathered[0], gathered[1])), "infos": [t.tolist() for t in infos], "moved": moved}
+        del e, sync
+    if rank == 0:
+        torch.save(res, out)
+    dist.destroy_process_group()
+
+
+def test_guard_set_on_one_rank_is_settled_on_the_same_step_by_all(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 25000 + (os.getpid() % 2000)
+    mp.spawn(_worker_guard_skew, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    for sharded, r in res.items():
+        a, b = r["infos"]
+        assert a == b, (sharded, r)                      # fallbacks, the step they happened on, skipped updates, Adam's step counter
+        assert a[0] == 1.0 and a[1] >= 2, (sharded, r)   # ONE fallback (no ping-pong), at or behind the step that set the guard
+        assert r["same_params"], sharded
+        assert r["moved"][0] and r["moved"][1] and r["moved"][-1] and r["moved"][-2], (sharded, r)     # training went on afterwards
+        assert not all(r["moved"]), (sharded, r)         # ... and at least one update was skipped in between

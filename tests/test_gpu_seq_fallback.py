@@ -50,7 +50,7 @@ def test_timeout_skips_the_update_and_falls_back_to_per_step_kernels(capfd):
     torch.cuda.synchronize()
     assert e.persistent_lstm and e.seq_fallbacks == 0
     assert torch.equal(e.flat_p, p1) and torch.equal(e.flat_m, m1)
-    assert int(e._guard[1]) == e._adam_launches and int(e._guard_host[0]) == 0x300
+    assert int(e._guard[1]) == e._adam_launches and int(e._guard_host[:, 0].max()) == 0x300
 
     # step 3: its update is where the host notices: fall back, skip this one too (it ran on the persistent kernels), clear the guard
     _step(e, bts[2], B)
@@ -59,7 +59,7 @@ def test_timeout_skips_the_update_and_falls_back_to_per_step_kernels(capfd):
     assert "timed out" in err and "one launch per time step" in err
     assert not e.persistent_lstm and e.seq_fallbacks == 1 and e.steps_skipped == 2
     assert torch.equal(e.flat_p, p1) and torch.equal(e.flat_m, m1) and e.step_count == steps1
-    assert e._guard.tolist() == [0, 0] and e._guard_host.tolist() == [0, 0]
+    assert e._guard.tolist() == [0, 0] and not e._guard_host.any()
 
     # steps 4, 5 run on the per-step kernels and are applied; a twin that never used the persistent kernels and did not see the
     # two skipped batches ends in the same place (same sample, no dropout; the persistent kernels are bit-identical to the per-step ones)

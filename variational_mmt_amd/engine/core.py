@@ -164,7 +164,12 @@ class Engine(StepAPI):
         # [1] optimiser launches skipped because of it.  vmmt_adam_step reads it on the device, the host sees a pinned copy one or two
         # steps later (optim_step) and then continues on the per-step kernels (_seq_timeout_fallback)
         self._guard = torch.zeros(2, dtype=torch.int32, device=self.dev)
-        self._guard_host = torch.zeros(2, dtype=torch.int32, device="cpu").pin_memory()      # (explicit device: a driver may have made CUDA the default tensor type)
+        # the host's view of it: a ring of three pinned copies, one written behind every optimiser step, each with its event.  One process
+        # reads whatever has arrived; data-parallel ranks all read the copy of TWO steps ago (waiting for its event: it has long
+        # arrived) -- the folded guard is the same number on every rank, so every rank switches over, skips and clears on the same step
+        self._guard_host = torch.zeros(3, 2, dtype=torch.int32, device="cpu").pin_memory()      # (explicit device: a driver may have made CUDA the default tensor type)
+        self._guard_events = [torch.cuda.Event() for _ in range(3)]
+        self._guard_pub = 0
         self.seq_fallback = _os_env.get("VMMT_SEQ_FALLBACK", "1") == "1"          # 0: a timeout raises (check_async_errors) as before round 4
         self.seq_fallbacks, self.steps_skipped, self._adam_launches, self._guard_clear_pending = 0, 0, 1, False
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
@@ -339,7 +344,8 @@ class Engine(StepAPI):
             self._in_flush = True
             try:
                 for _ in range(len(bg) if parts is None else min(parts, len(bg))):
-                    bg.pop(0)(stream)
+                    bg[0](stream)              # (popped when it has gone out: a part that raises is neither lost nor left half-issued
+                    bg.pop(0)                  #  behind a later part -- the error surfaces, the update is still whole on the next flush)
             finally:
                 self._in_flush = False
         if not bg:
@@ -676,7 +682,9 @@ class Engine(StepAPI):
         codes = [w for w in (int(s[2].item()) for s in self.seq_syncs) if w]
         g = self._guard.tolist()
         skipped = g[1] // max(1, self._adam_launches)
-        if not self.seq_fallback:
+        # (-optim sgd|adagrad|adadelta: torch's dense optimisers do not read the guard -- the steps since the timeout may have applied
+        #  garbage gradients: nothing to continue from)
+        if not self.seq_fallback or getattr(self, "dense_optimizer", False):
             raise RuntimeError("persistent LSTM launch(es) reported a hand-off timeout (error words %s, guard 0x%x): results invalid; "
                                "rerun with VMMT_PERSISTENT_LSTM=0" % ([hex(c) for c in codes], g[0]))
         self.persistent_lstm = False
@@ -701,7 +709,16 @@ class Engine(StepAPI):
     def poll_guard(self, where="optim_step"):
         """host side of the guard: a pinned copy of the word, refreshed asynchronously behind every optimiser step -- reading it costs no
         synchronisation; the first step that sees it set switches the engine over"""
-        if int(self._guard_host[0]) != 0:
+        if self.dp_on():
+            # every rank publishes once and polls once per optimiser step: the same slot, the same (folded) value, the same decision
+            if self._guard_pub < 2:
+                return False
+            k = (self._guard_pub - 2) % 3
+            self._guard_events[k].synchronize()
+            seen = int(self._guard_host[k, 0]) != 0
+        else:
+            seen = bool((self._guard_host[:, 0] != 0).any())
+        if seen:
             self._seq_timeout_fallback(where, in_step=True)
             return True
         return False
@@ -714,7 +731,10 @@ class Engine(StepAPI):
                 self._guard.zero_()
                 self._guard_clear_pending = False
                 self.step_count = max(0, self.step_count - 1)      # (the update that was skipped with the guard still set)
-            self._guard_host.copy_(self._guard, non_blocking=True)
+            k = self._guard_pub % 3
+            self._guard_host[k].copy_(self._guard, non_blocking=True)
+            self._guard_events[k].record(stream)
+            self._guard_pub += 1
 
     def check_async_errors(self):
         """Synchronises and settles everything the device reports asynchronously: a persistent recurrence that timed out (-> the engine
@@ -907,6 +927,7 @@ class Engine(StepAPI):
         """evict cached training workspaces (oldest first), keeping the `keep_last` most recently used"""
         keys = [k for k, v in self.ws.items() if isinstance(v, Workspace)]
         victims = keys[:max(0, len(keys) - keep_last)]
+        self._plan_tgt.clear()              # (keyed by id(plan): a freed plan's id may be handed to a new one)
         if victims:
             torch.cuda.synchronize(self.dev)      # their buffers may still be in use on the side streams
             for k in victims:

@@ -156,6 +156,15 @@ class Optim(object):
             self.engine.optim_step(lr=self.lr, max_grad_norm=self.max_grad_norm or 0.0, beta1=self.betas[0], beta2=self.betas[1],
                                    eps=1e-9)
         else:
+            # torch's dense optimisers know nothing of the engine's guard word (a persistent recurrence that timed out left garbage
+            # gradients; the arena Adam kernels read the guard on the device and skip): look before every update -- a synchronisation,
+            # off the hot path (every reference recipe uses adam) -- and on every data-parallel rank together
+            e = self.engine
+            if e.dp_on():
+                e.finish_allreduce()
+                e.dp.dist.all_reduce(e._guard[:1], op=e.dp.dist.ReduceOp.MAX)
+            if int(e._guard[0].item()) != 0:
+                e.check_async_errors()             # raises (Engine._seq_timeout_fallback with a dense optimiser)
             if self.max_grad_norm:
                 torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
             self.optimizer.step()

@@ -252,7 +252,9 @@ class TrainerMultimodal(object):
     def _train_loop(self, train_iter, epoch, report_func, total_stats, report_stats, num_batches):
         # inside this loop an update is followed by the next batch's forward: the engine may hold the side-stream half of an update back
         # until that forward's head is through (Engine.bg_after_head); whoever reads parameters inside the loop (a checkpoint, a
-        # translation) goes through state_dict() / the launch plans, which issue it first
+        # translation) goes through state_dict() / the launch plans, which issue it first.  The model's nn.Parameter objects ALIAS the arena
+        # (Models.py): code that reads them directly inside this loop (Optim.params, a hook) must call engine.wait_background() first, or
+        # it sees the decoder half one update behind
         eng = self.model.engine
         eng.hold_back = True
         try:
