@@ -95,15 +95,9 @@ typedef struct vmmt_gemm_args {
                   column sums (colsum_out / colsum_out2) follow the same map */
   int c_col_blk, c_col_valid; /* the same for the N output columns (e.g. dW_out [H][2H] of GlobalAttention.py:187 from a [c ; r]
                   buffer whose halves are padded) */
-  const void* mask; int64_t ld_mask; void* C2; int64_t ldc2; /* mask != NULL: a SECOND output C2[m][n] = T(C[m][n] * mask[m][n]) from the
-                  same epilogue (T = the storage type; mask as vmmt_dropout_mask writes it): nn.Dropout behind tanh(W_o [c ; r])
-                  (onmt/VI_Model1.py:132 on top of modules/GlobalAttention.py:187-190), whose input the backward still needs.  Only
-                  where vmmt_gemm_mask_applies() returns 1 (bf16, layout NT, T output, no split / scatter / block maps); otherwise
-                  VMMT_EINVAL */
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
 int vmmt_gemm_colsum_applies(const vmmt_gemm_args* args);
-int vmmt_gemm_mask_applies(const vmmt_gemm_args* args);
 /* n independent products in one call: the same results as n vmmt_gemm calls (in any order: members must ACCUMULATE into C with
  * atomics, split_k >= 2; several may share one C).  When every member is a bf16 TN product that vmmt_gemm would run on its two-stage
  * 128 x 128 LDS-DMA tiles -- the weight-gradient products dW = dY^T X of the LSTM and attention layers, the backward of nn.LSTM /
@@ -326,13 +320,6 @@ int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, int dy_f32, c
  * kl_b[b] = sum_k 0.5(mu^2+sigma^2-1) - log sigma (VILoss.py:446-456); stats[KL_SUM] += sum_b kl_b. */
 int vmmt_latent_fwd(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT, int64_t ldz,
                     float* kl_b, float* stats, int B, int Z, int training, void* stream);
-/* vmmt_latent_fwd AND zx = z W_z^T + bias in one launch (bf16): the per-sentence part of the decoder LSTM's input projection -- the
- * decoder input is [emb(y_t) ; z] at every step (onmt/VI_Model1.py:99-100), so z's share is computed once per sentence.  Same z32 / zT /
- * kl_b / stats bits as vmmt_latent_fwd; zx f32 [B][ldzx] = what vmmt_gemm(NT, zT, wz, addend = bias, out_f32) gives.  wz: bf16 [N][ldw],
- * k = z contiguous, zero beyond Z up to Z rounded up to 128; N % 256 == 0. */
-int vmmt_latent_zx(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT, int64_t ldz, float* kl_b,
-                   float* stats, const void* wz, int64_t ldw, const float* bias, float* zx, int64_t ldzx, int B, int Z, int N,
-                   int training, void* stream);
 /* q(z|x) forward in ONE launch: hbar = masked mean over time of the (detached) encoder memory (NormalVariationalEncoder.py:65-84),
  * h1 = relu(hbar W1^T + b1), out = h1 W2^T + b2 for the location and the scale network (:12-43; scale: Softplus), then
  * vmmt_latent_fwd's sample and KL.  bf16 only; H % 256 == 0, Z % 128 == 0, Z <= 512; returns 1 (invalid argument)

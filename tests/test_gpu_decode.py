@@ -58,35 +58,6 @@ def test_translator_mirror_beam1():
         TranslatorMultimodalVI(model, fields, beam_size=5, copy_attn=True)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_graph_replay_equals_launch_by_launch(dtype):
-    """decode.py: a position is one hipGraph, replayed (Engine.decode_graphs) -- same launches, same arguments, same bits as issuing
-    them one by one; arg-max decoding and beam search, twice through the same workspace (the second call replays the captured graph
-    on re-initialised state)"""
-    from variational_mmt_amd.engine import Dims, Engine
-    from variational_mmt_amd.decode import beam_decode, greedy_decode
-    c, p, bt, z, (B, S, max_len) = load("greedy_bi_l1")
-    out = {}
-    for graphs in (True, False):
-        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0, conditional=c.conditional), dtype=dtype,
-                   device="cuda", seed=1)
-        e.load_state_dict(p)
-        e.decode_graphs = graphs
-        res = []
-        for rep in range(2):
-            src = bt["src"] if rep == 0 else bt["src"].flip(1)[:, :B]
-            sl = bt["src_len"] if rep == 0 else bt["src_len"]
-            toks, scores = greedy_decode(e, src, sl, max_len=max_len)
-            res += [toks.cpu().clone(), scores.cpu().clone()]
-            rec = beam_decode(e, src, sl, 4, max_len=max_len, min_length=2)
-            res += [rec["scores"], rec["prev"], rec["next"], rec["attn"]]
-        torch.cuda.synchronize()
-        assert any("graph" in v for k, v in e.ws.items() if isinstance(k, tuple) and k[0] in ("decode", "beam")) == graphs
-        out[graphs] = res
-    for a, b_ in zip(out[True], out[False]):
-        assert torch.equal(a, b_)
-
-
 def test_history_append_kernel():
     """vmmt_history_append: history[counter] <- staging buffers for up to six segments, then counter += bump; nothing is written once
     the counter has reached the limit"""

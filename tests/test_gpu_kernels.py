@@ -631,78 +631,6 @@ def test_gemm_group_equals_separate_launches():
         assert (got.double().cpu() - want_w.cpu()).abs().max().item() <= 2e-3 * want_w.abs().max().item()
 
 
-def test_gemm_masked_second_output():
-    """vmmt_gemm_args.mask: C = act(A B^T) and C2 = C * mask from ONE epilogue -- tanh(W_o [c ; r]) and the dropout behind it
-    (VI_Model1.py:132): bit-identical to the product followed by vmmt_mul, ragged edges untouched"""
-    from variational_mmt_amd import _lib as L
-    lib = L.lib()
-    g = torch.Generator().manual_seed(9)
-    T = torch.bfloat16
-    M, N, K = 5000, 500, 1024
-    A = (torch.randn(M, K, generator=g) * 0.1).to(T).cuda()
-    Bm = (torch.randn(N, K, generator=g) * 0.1).to(T).cuda()
-    ldo = 512
-    mask = torch.zeros(M, ldo, dtype=T, device="cuda")
-    L.check(lib.vmmt_dropout_mask(L.BF16, mask.data_ptr(), M * ldo, 0.5, 77, None), "mask")
-    C1, C2 = torch.full((M, ldo), 3.0, dtype=T, device="cuda"), torch.full((M, ldo), 5.0, dtype=T, device="cuda")
-    a = L.GemmArgs(L.BF16, L.GEMM_NT, A.data_ptr(), K, Bm.data_ptr(), K, C1.data_ptr(), ldo, M, N, K, 0, 0, None, 0, 0, 0, L.ACT_TANH, 0, 0, 1.0)
-    a.mask, a.ld_mask, a.C2, a.ldc2 = mask.data_ptr(), ldo, C2.data_ptr(), ldo
-    assert lib.vmmt_gemm_mask_applies(C.byref(a)) == 1
-    L.check(lib.vmmt_gemm(C.byref(a), None), "gemm")
-    # the two-pass form
-    R1, R2 = torch.full((M, ldo), 3.0, dtype=T, device="cuda"), torch.full((M, ldo), 5.0, dtype=T, device="cuda")
-    b = L.GemmArgs(L.BF16, L.GEMM_NT, A.data_ptr(), K, Bm.data_ptr(), K, R1.data_ptr(), ldo, M, N, K, 0, 0, None, 0, 0, 0, L.ACT_TANH, 0, 0, 1.0)
-    L.check(lib.vmmt_gemm(C.byref(b), None), "gemm")
-    L.check(lib.vmmt_mul(L.BF16, R1.data_ptr(), ldo, mask.data_ptr(), ldo, R2.data_ptr(), ldo, M, N, None), "mul")
-    torch.cuda.synchronize()
-    assert torch.equal(C1, R1) and torch.equal(C2[:, :N], R2[:, :N])
-    assert (C2[:, N:] == 5.0).all() and (C1[:, N:] == 3.0).all()
-    want = torch.tanh(A.float() @ Bm.float().t())
-    assert (C1[:, :N].float() - want).abs().max().item() <= 1e-2
-    kept = mask[:, :N] != 0
-    assert 0.45 < kept.float().mean().item() < 0.55 and (C2[:, :N][~kept] == 0).all()
-    # where it does not apply the library says so instead of ignoring the mask
-    a.out_f32 = 1
-    assert lib.vmmt_gemm_mask_applies(C.byref(a)) == 0 and lib.vmmt_gemm(C.byref(a), None) != 0
-
-
-@pytest.mark.parametrize("B,Z,N,training", [(256, 256, 2048, 1), (37, 500, 2048, 1), (16, 128, 256, 0)])
-def test_latent_zx_equals_latent_fwd_plus_gemm(B, Z, N, training):
-    """vmmt_latent_zx = vmmt_latent_fwd (same bits: z, bf16 z, per-sentence KL) + zx = z W_z^T + bias (the decoder's per-sentence input
-    term, VI_Model1.py:99-100) in one launch; ragged B, z 500 inside 512-wide weight rows, evaluation mode (z = mu)"""
-    from variational_mmt_amd import _lib as L
-    lib = L.lib()
-    g = torch.Generator().manual_seed(B + Z)
-    mu = torch.randn(B, Z, generator=g).cuda()
-    sigma = (torch.rand(B, Z, generator=g) + 0.1).cuda()
-    eps = torch.randn(B, Z, generator=g).cuda()
-    ldw = (Z + 63) // 64 * 64
-    W = torch.zeros(N, ldw, dtype=torch.bfloat16, device="cuda")
-    W[:, :Z] = (torch.randn(N, Z, generator=g) * 0.1).to(torch.bfloat16).cuda()
-    bias = torch.randn(N, generator=g).cuda()
-
-    def bufs():
-        return (torch.zeros(B, Z, device="cuda"), torch.zeros(B + 64, ldw, dtype=torch.bfloat16, device="cuda"), torch.zeros(B, device="cuda"),
-                torch.zeros(8, device="cuda"), torch.full((B, N), 7.0, device="cuda"))
-    z1, zT1, kl1, st1, zx1 = bufs()
-    z2, zT2, kl2, st2, zx2 = bufs()
-    L.check(lib.vmmt_latent_fwd(L.BF16, mu.data_ptr(), sigma.data_ptr(), eps.data_ptr(), z1.data_ptr(), zT1.data_ptr(), ldw, kl1.data_ptr(),
-                                st1.data_ptr(), B, Z, training, None), "latent_fwd")
-    a = L.GemmArgs(L.BF16, L.GEMM_NT, zT1.data_ptr(), ldw, W.data_ptr(), ldw, zx1.data_ptr(), N, B, N, ldw, 0, 0, bias.data_ptr(), N, 1, 0,
-                   L.ACT_NONE, 1, 0, 1.0)
-    L.check(lib.vmmt_gemm(C.byref(a), None), "gemm")
-    L.check(lib.vmmt_latent_zx(L.BF16, mu.data_ptr(), sigma.data_ptr(), eps.data_ptr(), z2.data_ptr(), zT2.data_ptr(), ldw, kl2.data_ptr(),
-                               st2.data_ptr(), W.data_ptr(), ldw, bias.data_ptr(), zx2.data_ptr(), N, B, Z, N, training, None), "latent_zx")
-    torch.cuda.synchronize()
-    assert torch.equal(z1, z2) and torch.equal(zT1, zT2) and torch.equal(kl1, kl2)
-    assert abs(float(st1[L.STAT_KL_SUM]) - float(st2[L.STAT_KL_SUM])) <= 1e-5 * abs(float(st1[L.STAT_KL_SUM]))      # (atomics order)
-    want = zT1[:B, :Z].double() @ W[:, :Z].double().t() + bias.double()
-    assert (zx2.double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
-    assert (zx2 - zx1).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
-    if not training:
-        assert torch.equal(z2, mu)
-
-
 def test_mul_and_act_bwd_vector_paths_equal_the_scalar_kernels():
     """vmmt_mul / vmmt_act_bwd take eight bf16 elements per thread where rows are 16-byte aligned; the same data in buffers whose leading
     dimension breaks the alignment goes through the scalar kernels: identical bits, and the padding columns stay untouched"""

@@ -88,7 +88,7 @@ def test_engine_row_bookkeeping_equals_dense_over_many_steps(dtype):
     engines = {}
     for rows in (True, False):
         e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype=dtype, device="cuda", seed=1)
-        e.row_adam = rows                       # (opt-in: VMMT_ROW_ADAM=1; set before the first forward builds the plans)
+        e.row_adam = rows                       # (opt-in: set before the first forward builds the plans)
         assert e.rows_active() == rows
         e.load_state_dict(p)
         engines[rows] = e

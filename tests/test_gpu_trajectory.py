@@ -9,7 +9,7 @@ the sample eps injected:
     catch is a systematic error -- a wrong bias correction, a clip that is applied twice, moments that are not carried -- which
     shows up as a difference of the order of lr * k, two orders of magnitude above it;
   * bf16 throughput mode against fp32 mode: the ELBO curve within 1 % at every step (measured: 1.3e-4);
-  * the row-wise Adam bookkeeping (VMMT_ROW_ADAM=1) on and off: same trajectory."""
+  * the row-wise Adam bookkeeping (Engine.row_adam) on and off: same trajectory."""
 import pytest
 import torch
 

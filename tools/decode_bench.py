@@ -8,10 +8,7 @@ d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=T
 e = Engine(d, dtype="bf16", device="cuda", seed=0)
 g = torch.Generator().manual_seed(0)
 S, L = 20, 24
-for graphs in (False, True):
-    e.decode_graphs = graphs
-    e.drop_workspaces()
-    print("position = %s" % ("one hipGraph, replayed (Engine.decode_graphs)" if graphs else "plain launches (default)"))
+if True:
     for B, K in ((1, 1), (64, 1), (256, 1), (1, 5), (16, 5), (30, 5), (64, 5)):
         src = torch.randint(2, d.vs, (S, B), generator=g)
         sl = torch.full((B,), S, dtype=torch.int64)
@@ -23,7 +20,6 @@ for graphs in (False, True):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         print("  batch %4d beam %d: %7.2f ms per batch of %d positions = %8.0f sentences/s, %9.0f target positions/s" % (B, K, dt * 1e3, L, B / dt, B * L / dt))
-e.decode_graphs = False
 e.drop_workspaces()
 
 # the translator mirror on top (host Beam replay + stopping rule every 8 positions): what onmt.translate.TranslatorMultimodalVI.translate_batch costs

@@ -5,7 +5,6 @@ from variational_mmt_amd.engine import Dims, Engine
 from variational_mmt_amd.decode import beam_decode, greedy_decode
 d = Dims(vs=30000, vt=30000, emb=500, hid=512, z=256, img=2048, layers=1, brnn=True, dropout=0.0)
 e = Engine(d, dtype="bf16", device="cuda", seed=0)
-e.decode_graphs = False
 g = torch.Generator().manual_seed(0)
 S, L = 20, 24
 B, K = int(sys.argv[1]), int(sys.argv[2])

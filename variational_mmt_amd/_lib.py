@@ -30,8 +30,7 @@ class GemmArgs(C.Structure):
                 ("out_f32", i32), ("accumulate", i32), ("alpha", f32), ("scatter_ids", vp), ("pad_id", i32),
                 ("tile", i32), ("split_k", i32), ("b_batch_rows", i32), ("b_batch_stride", i64),
                 ("colsum_w", vp), ("colsum_w_stride", i64), ("colsum_out", vp), ("colsum_out2", vp),
-                ("c_row_blk", i32), ("c_row_valid", i32), ("c_col_blk", i32), ("c_col_valid", i32),
-                ("mask", vp), ("ld_mask", i64), ("C2", vp), ("ldc2", i64)]
+                ("c_row_blk", i32), ("c_row_valid", i32), ("c_col_blk", i32), ("c_col_valid", i32)]
 
 
 class LstmDirFwd(C.Structure):
@@ -67,7 +66,6 @@ _SIGS = {
     "vmmt_stream_create_masked": (i32, [vp, i32, i32, vp]),
     "vmmt_stream_destroy": (i32, [vp]),
     "vmmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
-    "vmmt_gemm_mask_applies": (i32, [C.POINTER(GemmArgs)]),
     "vmmt_gemm_group": (i32, [C.POINTER(GemmArgs), i32, vp]),
     "vmmt_gemm_group_applies": (i32, [C.POINTER(GemmArgs), i32]),
     "vmmt_lstm_step_fwd": (i32, [i32, i32, C.POINTER(LstmDirFwd), vp, i32, i32, vp]),
@@ -112,7 +110,6 @@ _SIGS = {
     "vmmt_qnet_fwd": (i32, [i32, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp,
                             i32, i32, i32, i32, i32, i32, i32, vp]),
     "vmmt_latent_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, vp]),
-    "vmmt_latent_zx": (i32, [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
     "vmmt_latent_bwd": (i32, [i32, vp, vp, vp, f32, f32, i32, f32, f32, vp, vp, vp, i64, vp, i64, i32, i32, vp]),
     "vmmt_gate_fwd": (i32, [i32, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "vmmt_gate_bwd": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, vp]),

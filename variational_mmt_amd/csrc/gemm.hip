@@ -20,7 +20,6 @@ struct GemmEpi {
   const float* colsum_w; long colsum_w_stride; float* colsum_out; // K-strided A only: colsum_out[m] += sum_k A[k][m] w[k] (w per B block)
   float* colsum_out2;                                            // unit weights (colsum_w == NULL): a second destination of the same sums
   int rblk, rvalid, cblk, cvalid;                                // output row / column block map (vmmt_gemm_args.c_row_blk): 0 = identity
-  const void* mask; long ld_mask; void* C2; long ldc2;           // EPI == 1 only: C2 = T(act(...) * mask) next to C (vmmt_gemm_args.mask)
 };
 
 // The epilogue runs as a few small, fully unrolled passes over the accumulator registers (static indices only:
@@ -79,15 +78,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
     else { VMMT_FOR_ACC(C[(long)row * e.ldc + col] = v;) }
   } else {
     T* C = reinterpret_cast<T*>(e.C);
-    if constexpr (EPI == 1) {
-      // the activation AND its dropped-out copy from one epilogue (vmmt_gemm_args.mask): C = T(v), C2 = T(T(v) * mask) -- the product of
-      // the two stored values, as the separate vmmt_mul pass computed it.  An instantiation of its own: the second output costs the
-      // kernel 16 registers, which the plain NT product cannot spare (it runs beside lstm_seq_fwd_kernel<512>: 280 + 224 of 512)
-      const T* mk = reinterpret_cast<const T*>(e.mask);
-      T* C2 = reinterpret_cast<T*>(e.C2);
-      VMMT_FOR_ACC(const T c = from_f<T>(v); C[(long)row * e.ldc + col] = c;
-                   C2[(long)row * e.ldc2 + col] = from_f<T>(to_f<T>(c) * to_f<T>(mk[(long)row * e.ld_mask + col]));)
-    } else if (e.accumulate) { VMMT_FOR_ACC(T* p = C + (long)row * e.ldc + col; *p = from_f<T>(to_f<T>(*p) + v);) }
+    if (e.accumulate) { VMMT_FOR_ACC(T* p = C + (long)row * e.ldc + col; *p = from_f<T>(to_f<T>(*p) + v);) }
     else { VMMT_FOR_ACC(C[(long)row * e.ldc + col] = from_f<T>(v);) }
   }
 }
@@ -122,9 +113,10 @@ __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, long lda, con
   const int kbeg = split * kper;                      // split-K: this block reduces over [kbeg, kend)
   const int kend = min(K, kbeg + kper);
   if constexpr (GL == 3) {   // LDS-DMA main loops (glds_gemm.hpp); preconditions checked by launch_layout
-    // the weighted column sums of A ride along in the workgroups of the first column tile (one pass over A per launch)
-    const float* cw = (epi.colsum_w && tn == 0) ? epi.colsum_w + (epi.b_batch_rows > 0 ? (long)(m0 / epi.b_batch_rows) * epi.colsum_w_stride : 0L) : nullptr;
-    gemm_mainloop_glds3<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, cw, epi.colsum_out);
+    // the weighted column sums of A ride along, shared out over the column tiles of a row slab (one pass over A per launch)
+    const float* cw = epi.colsum_w ? epi.colsum_w + (epi.b_batch_rows > 0 ? (long)(m0 / epi.b_batch_rows) * epi.colsum_w_stride : 0L) : nullptr;
+    gemm_mainloop_glds3<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, cw, epi.colsum_out,
+                                                             tn, tiles_n);
   } else if constexpr (GL == 4) {   // half-depth slabs, both operands K-contiguous (glds_gemm.hpp)
     static_assert(GL != 4 || (A_KC && B_KC), "the half-depth loop stages K-contiguous operands");
     gemm_mainloop_hglds3<BM, BN, NT / 64, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
@@ -211,14 +203,6 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
   if constexpr (sizeof(T) == 2)
     gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
             ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
-  if (epi.mask) {
-    // the masked second output exists for bf16 NT products on the 128 x 128 LDS-DMA tiles only (vmmt_gemm_mask_applies)
-    if constexpr (sizeof(T) == 2 && A_KC && B_KC) {
-      if (gl_ok && !epi.atomic && !epi.scatter_ids && !a->out_f32 && !epi.accumulate && !(epi.rblk | epi.cblk) && !epi.colsum_out && a->tile == 0)
-        return launch_cfg<T, 128, 128, 64, 64, true, true, 64, true, 1, 1>(a, epi, st);
-    }
-    return VMMT_EINVAL;
-  }
   // With the LDS-DMA loop a 128 x 128 workgroup retires a 64-deep slab in ~0.55 us against ~0.4 us per 32-deep slab of the
   // 64 x 64 configuration, so for long reductions it is also the lower-LATENCY choice when there are fewer tiles than CUs
   // (M = 256 products of the inference networks at K = 2048: 20 us instead of 26-32 us); below K = 1024 the 64 x 64
@@ -358,8 +342,6 @@ static int gemm_make_epi(const vmmt_gemm_args* a, vmmt::GemmEpi& e) {
   e.b_batch_rows = a->b_batch_rows; e.b_batch_stride = (long)a->b_batch_stride;
   e.colsum_w = a->colsum_w; e.colsum_w_stride = (long)a->colsum_w_stride; e.colsum_out = a->colsum_out; e.colsum_out2 = a->colsum_out2;
   e.rblk = a->c_row_blk; e.rvalid = a->c_row_valid; e.cblk = a->c_col_blk; e.cvalid = a->c_col_valid;
-  e.mask = a->mask; e.ld_mask = (long)a->ld_mask; e.C2 = a->C2; e.ldc2 = (long)a->ldc2;
-  if ((a->mask != nullptr) != (a->C2 != nullptr)) return VMMT_EINVAL;
   if (e.rblk < 0 || e.cblk < 0 || (e.rblk > 0 && (e.rvalid <= 0 || e.rvalid > e.rblk)) || (e.cblk > 0 && (e.cvalid <= 0 || e.cvalid > e.cblk)))
     return VMMT_EINVAL;
   if ((e.rblk | e.cblk) && (!a->out_f32 || a->scatter_ids || a->act != VMMT_ACT_NONE)) return VMMT_EINVAL;
@@ -367,14 +349,6 @@ static int gemm_make_epi(const vmmt_gemm_args* a, vmmt::GemmEpi& e) {
   if ((a->colsum_w || a->colsum_out || a->colsum_out2) && (!a->colsum_out || !vmmt_gemm_colsum_applies(a))) return VMMT_EINVAL;
   if (a->b_batch_rows < 0 || (a->b_batch_rows > 0 && a->b_batch_rows % 256 != 0)) return VMMT_EINVAL;   // whole tiles (<= 256 rows) per block
   return VMMT_OK;
-}
-
-// 1 when vmmt_gemm would produce the masked second output (mask / C2) for these arguments
-extern "C" int vmmt_gemm_mask_applies(const vmmt_gemm_args* a) {
-  if (!a || a->dtype != VMMT_BF16 || a->layout != VMMT_GEMM_NT || a->scatter_ids || a->out_f32 || a->accumulate || a->split_k > 1 || a->tile != 0) return 0;
-  if (a->c_row_blk || a->c_col_blk || a->colsum_out || a->colsum_w) return 0;
-  return (a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
-          ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0) ? 1 : 0;
 }
 
 extern "C" int vmmt_gemm(const vmmt_gemm_args* a, void* stream) {

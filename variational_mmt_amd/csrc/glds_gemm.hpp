@@ -292,10 +292,15 @@ template <int BM, int BN, int NW, bool A_KC, bool B_KC, int TI, int TJ>
 __device__ __forceinline__ void gemm_mainloop_glds3(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
                                                     long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
                                                     const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem,
-                                                    const float* __restrict__ colsum_w = nullptr, float* __restrict__ colsum_out = nullptr) {
+                                                    const float* __restrict__ colsum_w = nullptr, float* __restrict__ colsum_out = nullptr,
+                                                    int cs_phase = 0, int cs_mod = 1) {
+  // (the weighted column sums of the A slab are shared out over the workgroups that read it -- the cs_mod column tiles of one row slab:
+  //  the one with column tile t takes the K slabs s % cs_mod == t.  All of them in the first column tile made that workgroup fall behind
+  //  the others of its slab, which then miss the slab in L2: 661 MB fetched for 312 MB of operands at the generator's dWg, round 4)
   constexpr int ABYTES = BM * GBK * 2, BBYTES = BN * GBK * 2, BUF = ABYTES + BBYTES;
   constexpr bool CS_OK = !A_KC && BM == 256 && NW == 8;          // the only shape glds_colsum_slab is written for
   const bool cs_on = CS_OK && colsum_w != nullptr;
+  int cs_left = cs_phase;                                      // slabs until this workgroup's next turn
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
   using GA = GldsOperand<BM, A_KC, NW>;
   using GB = GldsOperand<BN, B_KC, NW>;
@@ -325,7 +330,10 @@ __device__ __forceinline__ void gemm_mainloop_glds3(const bf16_t* __restrict__ A
       ga.issue(smem + (NXT2) * BUF, wave);                                                             \
       gb.issue(smem + (NXT2) * BUF + ABYTES, wave);                                                    \
     }                                                                                                  \
-    if (cs_on) glds_colsum_slab(smem + (CUR) * BUF, colsum_w + kbeg + s * GBK, wave, lane, csum);       \
+    if (cs_on) {                                                                                       \
+      if (cs_left == 0) { glds_colsum_slab(smem + (CUR) * BUF, colsum_w + kbeg + s * GBK, wave, lane, csum); cs_left = cs_mod; } \
+      --cs_left;                                                                                       \
+    }                                                                                                  \
     glds_slab<BM, BN, A_KC, B_KC, TI, TJ>(smem + (CUR) * BUF, smem + (CUR) * BUF + ABYTES, fa, fb, aoff, boff, acc); \
     ++s;                                                                                               \
   }

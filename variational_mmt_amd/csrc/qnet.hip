@@ -183,94 +183,7 @@ __global__ void __launch_bounds__(512) qnet_fwd_kernel(QnetArgs a) {
   }
 }
 
-// ---- sample + KL + the decoder's per-sentence input term in ONE launch ------------------------------------------------------------
-// z = mu + sigma * eps (training) | mu; KL_b (vmmt_latent_fwd's arithmetic and summation order: same bits); zx = z W_z^T + b, the part
-// of the decoder LSTM's input projection that is the same at every time step (VI_Model1.py:99-100: the input is [emb(y_t) ; z]).
-// Between the encoder's and the decoder's recurrence nothing else runs on the critical path, so every launch boundary there is
-// exposed: this kernel replaces vmmt_latent_fwd + a [B x 4H x Z] vmmt_gemm.  Workgroup (16 sentences, 256 output columns): z of its
-// sentences into LDS (every column block recomputes it: 3 x 16 KB of loads), then 16x16x32 MFMAs against W_z rows streamed from L2
-// in fragment shape (mm16); the workgroups of column block 0 also write z32 / zT / KL.
-struct LatentZxArgs {
-  const float* mu; const float* sigma; const float* eps;
-  float* z32; bf16_t* zT; long ldz; float* kl_b; float* stats;
-  const bf16_t* wz; long ldw; const float* bias; float* zx; long ldzx;
-  int B, Zv, Zk, N, training;
-};
-
-__global__ void __launch_bounds__(256) latent_zx_kernel(LatentZxArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int PZ = a.Zk + 8;
-  bf16_t* zs = reinterpret_cast<bf16_t*>(smem);                        // [16][PZ]
-  float* red = reinterpret_cast<float*>(zs + 16 * PZ);                 // [16][4]
-  const int r0 = blockIdx.x * 16, c0 = blockIdx.y * 256;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, kg = lane >> 4;
-  const bool first = blockIdx.y == 0;
-#pragma unroll 4
-  for (int row = 0; row < 16; ++row) {
-    const int b = r0 + row;
-    float kl = 0.f;
-    for (int k = threadIdx.x; k < a.Zk; k += 256) {
-      float z = 0.f;
-      if (b < a.B && k < a.Zv) {
-        const long i = (long)b * a.Zv + k;
-        const float m = a.mu[i], sg = a.sigma[i];
-        z = a.training ? m + sg * a.eps[i] : m;
-        if (first) {
-          a.z32[i] = z;
-          a.zT[(long)b * a.ldz + k] = f2bf(z);
-          kl += 0.5f * (m * m + sg * sg - 1.f) - logf(sg);
-        }
-      }
-      zs[row * PZ + k] = f2bf(z);
-    }
-    if (first) {
-      kl = wave_sum(kl);
-      if (lane == 0) red[row * 4 + wave] = kl;
-    }
-  }
-  __syncthreads();
-  if (first && threadIdx.x < 16 && r0 + (int)threadIdx.x < a.B) {
-    const int row = threadIdx.x;
-    float t = 0.f;
-    for (int w = 0; w < 4; ++w) t += red[row * 4 + w];
-    a.kl_b[r0 + row] = t;
-    atomicAdd(a.stats + VMMT_STAT_KL_SUM, t);
-  }
-  f32x4_q acc[4];
-  const int n0 = c0 + wave * 64;
-  mm16<4>(zs, PZ, a.wz, a.ldw, n0, a.Zk, acc);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = n0 + j * 16 + n;
-    if (col >= a.N) continue;
-    const float bias = a.bias[col];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = r0 + kg * 4 + r;
-      if (row < a.B) a.zx[(long)row * a.ldzx + col] = acc[j][r] + bias;
-    }
-  }
-}
-
 }  // namespace vmmt
-
-// bf16 only.  mu / sigma / eps / z32: f32 [B][Z]; zT bf16 [B][ldz]; wz bf16 [N][ldw] (k = z contiguous, readable and ZERO beyond Z up to
-// Zk = Z rounded up to 128); bias f32 [N] (b_ih + b_hh); zx f32 [B][ldzx].  N % 256 == 0, rows 16-byte aligned.
-extern "C" int vmmt_latent_zx(int dtype, const float* mu, const float* sigma, const float* eps, float* z32, void* zT, int64_t ldz, float* kl_b,
-                              float* stats, const void* wz, int64_t ldw, const float* bias, float* zx, int64_t ldzx, int B, int Z, int N,
-                              int training, void* stream) {
-  using namespace vmmt;
-  if (dtype != VMMT_BF16 || !mu || !sigma || !z32 || !zT || !kl_b || !stats || !wz || !bias || !zx || (training && !eps) || B <= 0 || Z <= 0 || N <= 0)
-    return VMMT_EINVAL;
-  const int Zk = (Z + 127) / 128 * 128;
-  if (N % 256 != 0 || ldw < Zk || ldw % 8 || (((uintptr_t)wz) & 15) || Zk > 1024) return VMMT_EINVAL;
-  LatentZxArgs a;
-  a.mu = mu; a.sigma = sigma; a.eps = eps; a.z32 = z32; a.zT = (bf16_t*)zT; a.ldz = ldz; a.kl_b = kl_b; a.stats = stats;
-  a.wz = (const bf16_t*)wz; a.ldw = ldw; a.bias = bias; a.zx = zx; a.ldzx = ldzx; a.B = B; a.Zv = Z; a.Zk = Zk; a.N = N; a.training = training;
-  const size_t sm = (size_t)16 * (Zk + 8) * 2 + 16 * 4 * 4;
-  hipLaunchKernelGGL(latent_zx_kernel, dim3((B + 15) / 16, N / 256), dim3(256), sm, (hipStream_t)stream, a);
-  return check_launch();
-}
 
 // dtype must be VMMT_BF16; H % 256 == 0 and Z % 128 == 0 (8 waves x 16-column tiles, K in chunks of 128), LDS <= 64 KiB; all row
 // starts 16-byte aligned.  Returns VMMT_EINVAL otherwise (the caller then issues the separate kernels).

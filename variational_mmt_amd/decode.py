@@ -7,13 +7,11 @@ sentences of a batch with no host synchronisation inside a block of positions, a
 (scores, parents, tokens, attention); `onmt/translate/Beam.py` (host mirror) replays the records into the reference's
 bookkeeping (finished list, stopping rule, n-best extraction).
 
-A position is written as ONE launch sequence with FIXED arguments -- tokens ping through a pair of fixed buffers, the per-position
-records go through staging buffers into history[counter] with the counter on the device (vmmt_history_append) -- so that it can be
-captured once per decoding workspace as a hipGraph and replayed (`Engine.decode_graphs`, VMMT_DECODE_GRAPHS=1; torch.cuda.CUDAGraph is
-the capture plumbing).  Bit-identical to the plain launches (tests/test_gpu_decode.py) and, measured, SLOWER than them on this stack
-(tools/decode_bench.py: beam 5 x 30 sentences 3.87 against 3.62 ms per 24 positions, arg-max x 256 sentences 3.68 against 2.92), so the
-default issues the launches one by one: a position is bound by the dependent-kernel turnaround on the GPU, not by the host.  What did
-pay was the two kernels the profile showed (tools/decode_profile.py): Beam.advance as (row x vocabulary chunk) workgroups instead of one
+A position is ONE launch sequence with fixed arguments -- tokens ping through a pair of fixed buffers, the per-position records go
+through staging buffers into history[counter] with the counter on the device (vmmt_history_append) -- issued launch by launch: a position
+is bound by the dependent-kernel turnaround on the GPU, not by the host (replaying it as a captured hipGraph was built in round 3,
+bit-identical and measured slower -- LABNOTES -- and removed in round 5).  What did pay was the two kernels the profile showed
+(tools/decode_profile.py): Beam.advance as (row x vocabulary chunk) workgroups instead of one
 per sentence (216 -> 39 us per position) and the arg-max fold as a wave per token (74 -> 5 us)."""
 import ctypes as C
 
@@ -130,28 +128,6 @@ def _hist(eng, segs, counter, limit):
     L.check(eng.lib.vmmt_history_append(arr, len(segs), counter.data_ptr(), limit, 1, eng.stream()), "vmmt_history_append")
 
 
-def _position_graph(eng, b, position, init):
-    """the launch sequence `position()` of decoding workspace `b` as a replayable graph (None: graphs are switched off).  Captured
-    once per workspace; the warm-up position runs on the state `init()` prepares (valid lengths and tokens: garbage would put NaNs
-    into the padding lanes of the state buffers, which no later `init()` rewrites), and the caller runs `init()` again afterwards."""
-    if not getattr(eng, "decode_graphs", True):
-        return None
-    if "graph" not in b:
-        init()
-        cur = torch.cuda.current_stream(eng.dev)
-        side = torch.cuda.Stream(device=eng.dev)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            position()                           # first calls of a kernel set its attributes (LDS size): not capturable
-        cur.wait_stream(side)
-        torch.cuda.synchronize(eng.dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-            position()
-        b["graph"] = g
-    return b["graph"]
-
-
 def greedy_decode(eng, src, src_len, max_len=50, bos=2, eos=None, check_every=16):
     """src [S,B] int64, src_len [B] (sorted descending).  Returns (tokens [n,B] int64, log-probs [n,B] f32) on the device, n <=
     max_len positions (the host cuts every sentence at its first </s>).  eos=None: all max_len positions, no host synchronisation
@@ -170,7 +146,7 @@ def greedy_decode(eng, src, src_len, max_len=50, bos=2, eos=None, check_every=16
                  vmax=torch.zeros(max_len, B, dtype=f32, device=dev), lse=torch.zeros(max_len, B, dtype=f32, device=dev),
                  st_vmax=torch.zeros(B, dtype=f32, device=dev), st_lse=torch.zeros(B, dtype=f32, device=dev),
                  counter=torch.zeros(1, dtype=torch.int32, device=dev), npart=lib.vmmt_gen_npart(V),
-                 # the source-side operands in buffers of this workspace: the graph holds their addresses
+                 # the source-side operands in buffers of this workspace (a position runs on fixed addresses)
                  ctx=Buf(S * B, enc.t.shape[1], eng.T, dev, ld=enc.ld), zx=Buf(B, ws.zx.t.shape[1], f32, dev, ld=ws.zx.ld),
                  src_len=torch.zeros(B, dtype=torch.int64, device=dev))
         n = b["npart"] * B
@@ -206,14 +182,10 @@ def greedy_decode(eng, src, src_len, max_len=50, bos=2, eos=None, check_every=16
             hb, ho = sp.h_buf(l, 0)
             hb.t[:B, ho:ho + H].copy_(ws.hn[l].view())
 
-    graph = _position_graph(eng, b, position, init)
     init()
     n = max_len
     for t in range(max_len):
-        if graph is not None:
-            graph.replay()
-        else:
-            position()
+        position()
         if eos is not None and (t + 1) % check_every == 0 and t + 1 < max_len and bool((b["tokens"][:t + 1] == eos).any(0).all()):
             n = t + 1
             break
@@ -278,15 +250,11 @@ def beam_decode(eng, src, src_len, beam_size, max_len=100, min_length=0, bos=2, 
         b["scores"].zero_()
         b["counter"].zero_()
 
-    graph = _position_graph(eng, b, position, init)
     init()
     n = 0
     for t in range(max_len):
         first, mask_eos = int(t == 0), int(t + 1 < min_length)
-        if graph is not None and not first and not mask_eos:
-            graph.replay()
-        else:
-            position(first, mask_eos)         # the first position scores beam 0 only; positions below min_length mask </s>
+        position(first, mask_eos)             # the first position scores beam 0 only; positions below min_length mask </s>
         n = t + 1
         if stop is not None and (n % check_every == 0 or n == max_len):
             rec = dict(scores=b["h_score"][:n].cpu(), prev=b["h_prev"][:n].cpu(), next=b["h_next"][:n].cpu(), attn=None)

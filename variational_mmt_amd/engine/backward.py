@@ -30,7 +30,7 @@ class BackwardPlan(object):
         e._sid = MAIN
         # (the bias gradient = row sums of G^T comes out of the same kernel; the gradient arena was zeroed on the side stream in
         #  front of `dec_gx`, which the main stream has waited for)
-        fuse_db = _os_env.get("VMMT_FUSE_DB", "1") == "1"
+        fuse_db = True
         # entries that carry run-time scalars (1 / normalization, KL weights): patched per step by backward_plan(), so that
         # token normalisation (a different value every batch) does not rebuild the plan
         # (walking the vocabulary in 2-6 chunks, so that a chunk of G^T is consumed by dO / dWg while it is still in the Infinity
@@ -259,7 +259,7 @@ class BackwardPlan(object):
         e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
         # the generator's share of the gradient norm (a quarter of the arena) right behind its product, on this stream, instead of in the
         # norm of the whole first half at the end of the decoder's parameter gradients (slot 7: free outside the conditional model)
-        gen_norm_early = bool(not d.conditional and not e.rows_active() and _os_env.get("VMMT_GEN_NORM_EARLY", "1") == "1")
+        gen_norm_early = bool(not d.conditional and not e.rows_active() )
         if gen_norm_early:
             e._sumsq_entry(P, "generator.0.weight", "decoder.attn.linear_out.weight", 7)
         if main_first:
@@ -349,7 +349,7 @@ class BackwardPlan(object):
                 we = e.sh["dec_wih_l0_e"]
                 # dX = dgates W_e, then its rows scattered into the embedding gradient (pad row dropped) -- on the SIDE stream, idle while
                 # the encoder's backward recurrence runs, next to this stream's weight gradients instead of behind them
-                dxt_side = dec_on_aux and _os_env.get("VMMT_DXT_ON_SIDE", "1") == "1"
+                dxt_side = dec_on_aux
                 if dxt_side:
                     e._sid = SIDE
                     e._wait(P, "dec_dg%d" % l)

@@ -82,7 +82,7 @@ class Engine(StepAPI):
         self.aux_stream = torch.cuda.Stream(device=self.dev, priority=lo_pri)
         # measured (tools/sched_ab.py, fixed prior): 2.53 ms/step with that work on the side stream vs 2.59 ms on a stream of
         # its own; the conditional model keeps it (encoder_tgt's 2 x B-step recurrences would otherwise block the side stream)
-        self.use_aux_stream = _os_env.get("VMMT_AUX_STREAM", "1") == "1"
+        self.use_aux_stream = True
         # fourth stream (conditional model only): encoder_tgt's backward recurrence, 2 x B dependent steps that would otherwise hold
         # up everything queued behind them on the aux stream
         # (created on first use -- two-layer / conditional models only: every stream is one more hardware queue for the GPU's scheduler to
@@ -93,46 +93,42 @@ class Engine(StepAPI):
         # the memory system for ~200 us and the latency-bound persistent LSTM kernel next to it runs at half speed; one workgroup per
         # CU still finishes before the decoder-side weights are needed.  tools/ab.py, ms per step: 4096 wgs 1.958-2.007 | 384: 1.957 |
         # 288: 1.972 | 256: 1.921-1.951 | 224: 1.908 | 192: 1.987 | 128: 2.051 | 64: 2.324 (a faster two-chunk kernel at 256: 1.98)
-        self.bg_adam_blocks = int(_os_env.get("VMMT_BG_ADAM_BLOCKS", "256"))
+        self.bg_adam_blocks = 256
         # ... and of the FOREGROUND half (0 = uncapped, 4096).  Alone on the chip the kernel streams 5.6 TB/s uncapped and 6.0 TB/s from 512
         # workgroups (tools/hbm_kernels.py: 108.5 -> 101.1 us for the 21.8 M parameters of that half)
-        self.fg_adam_blocks = int(_os_env.get("VMMT_FG_ADAM_BLOCKS", "0"))
+        self.fg_adam_blocks = 0
         # cap of the weight-gradient products' split-K.  On an idle chip 4, 8 and 16 splits cost the same (tools/gemm_split.py), in the step
         # the extra workgroups and atomics get in the way of everything that runs next to them (tools/ab.py, ms per step by cap: 64:
         # 1.854, 8: 1.834-1.843, 6: 1.798, 5: 1.782, 4: 1.792-1.812, 3: 1.815, 2: 1.848, 1: 2.003)
-        self.max_split_k = int(_os_env.get("VMMT_MAX_SPLIT_K", "4"))
-        self.wgrad_target_tiles = int(_os_env.get("VMMT_WGRAD_TARGET_TILES", "1024"))     # 64 x 64 output tiles x splits a weight-gradient product aims at
-        self.cond_aux_early = _os_env.get("VMMT_COND_AUX_EARLY", "1") == "1"
-        self.cond_emb_fg = _os_env.get("VMMT_COND_EMB_FG", "1") == "1"
-        self.aux_early = _os_env.get("VMMT_AUX_EARLY", "1") == "1"
-        self.aux_kl_first = _os_env.get("VMMT_AUX_KL_FIRST", "1") == "1"
-        self.gen_db_in_gemm = _os_env.get("VMMT_GEN_DB_IN_GEMM", "1") == "1"
-        self.lstm_db_in_gemm = _os_env.get("VMMT_LSTM_DB_IN_GEMM", "1") == "1"
-        self.dec_grads_on_aux = _os_env.get("VMMT_DEC_GRADS_ON_AUX", "1") == "1"
-        self.bwd_main_first = _os_env.get("VMMT_BWD_MAIN_FIRST", "1") == "1"      # issue order of the backward plan (see _plan_backward)
-        self.bwd_layers_parallel = _os_env.get("VMMT_BWD_LAYERS_PARALLEL", "1") == "1"   # >= 2 layers: top encoder layer next to the lower decoder layers
+        self.max_split_k = 4
+        self.wgrad_target_tiles = 1024     # 64 x 64 output tiles x splits a weight-gradient product aims at
+        self.cond_aux_early = True
+        self.cond_emb_fg = True
+        self.aux_early = True
+        self.aux_kl_first = True
+        self.gen_db_in_gemm = True
+        self.lstm_db_in_gemm = True
+        self.dec_grads_on_aux = True
+        self.bwd_main_first = True      # issue order of the backward plan (see _plan_backward)
+        self.bwd_layers_parallel = True   # >= 2 layers: top encoder layer next to the lower decoder layers
         # the weight-gradient products of a layer (dW_hh / dW_ih of each direction; attention's two) as ONE grid each (vmmt_gemm_group)
         # -- not with the --conditional prior: there the step's length is encoder_tgt's chain (2 x B = 512 sequential LSTM steps at batch 20,
         # 0.86 + 1.5 ms) and every weight gradient runs underneath it; a grouped grid takes more of the chip at once and slows that chain
         # (same box, three pairs: 3.73 / 3.72 / 3.80 ms grouped against 3.47 / 3.45 / 3.49 ms solo; profiles/r4_conditional_grouping.txt)
         self.group_wgrads = _os_env.get("VMMT_GROUP_WGRADS", "0" if dims.conditional else "1") == "1"
-        # the output dropout (VI_Model1.py:132) out of the epilogue of tanh(W_o [c ; r]) instead of a pass of its own (vmmt_gemm_args.mask).
-        # OPT-IN: bit-identical, and measured 10-15 us per step SLOWER than the 12-us vmmt_mul pass it removes (same box, three pairs:
-        # 1.722 / 1.722 / 1.740 against 1.715 / 1.708 / 1.724 ms) -- the second output costs the product's epilogue more than the pass
-        self.fuse_out_dropout = _os_env.get("VMMT_FUSE_OUT_DROPOUT", "0") == "1"
         # (a high-priority stream for the critical path was measured and is slightly SLOWER than the default stream:
         #  tools/sched_ab.py, 3.249 vs 3.226 ms/step)
         self._compute_stream = None
         self._plan_tgt = {}           # id(plan) -> (entries, whether it uses the fourth stream)
         self.use_side_stream = True
         # the generator's calls over the decoder rows that carry a target only (pads compacted away) when forward() knows their number
-        self.gen_compact = _os_env.get("VMMT_GEN_COMPACT", "1") == "1"
+        self.gen_compact = True
         self._masked_streams = []
         import os as _os
-        self.q_parallel = _os.environ.get("VMMT_QPAR", "1") == "1"    # q(z|x): scale branch on the side stream next to the location branch
+        self.q_parallel = True    # q(z|x): scale branch on the side stream next to the location branch
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
-        self.split_optim = _os_env.get("VMMT_SPLIT_OPTIM", "1") == "1"      # run the decoder-side half of Adam + shadow refresh on the side stream
+        self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
         # the side-stream half of Adam held back until the NEXT forward's head (source gather + the encoder's first input projection) is
         # through: next to 200 us of optimiser streaming that product takes 112 instead of 30 us (profiles/r4_step_timeline.txt)
         # Default: models of two or more layers (scripts' shape at batch 40 / 256: 1.86 -> 1.73 / 2.68 -> 2.55 ms, config 5: 17.49 -> 17.26;
@@ -146,18 +142,9 @@ class Engine(StepAPI):
         self._sumsq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=self.dev)   # slot totals | tickets | partials (vmmt.h)
         self._sumsq_by_plan = False
         self._normed = set()         # sharded data parallelism: arena segments whose shard the backward plan has normed (step.py)
-        self.fused_qnet = _os_env.get("VMMT_FUSED_QNET", "1") == "1"
-        self.qnet_split = _os_env.get("VMMT_QNET_SPLIT", "1") == "1"     # location / scale networks in separate workgroups (csrc/qnet.hip)
-        # sample + KL + z W_z^T + b in one launch (vmmt_latent_zx).  OPT-IN: same bits, and 20 us per step SLOWER than the two launches it
-        # replaces (1.727 / 1.724 / 1.720 against 1.709 / 1.702 / 1.701 ms, same box): 128 workgroups walking 16 sentences each are a
-        # longer chain of dependent memory round trips than 256 one-sentence workgroups + a GEMM, and the sample -- which the side
-        # and aux streams wait for -- comes later.  A launch boundary costs less here than one more round trip inside a kernel
-        self.fuse_latent_zx = _os_env.get("VMMT_LATENT_ZX", "0") == "1"
+        self.fused_qnet = True
+        self.qnet_split = True     # location / scale networks in separate workgroups (csrc/qnet.hip)
         self.gen_fused = _os_env.get("VMMT_GEN_FUSED", "1") == "1"       # csrc/generator_fused.hip where it applies (bf16, H = 512 / 256)
-        # decode.py: a decoded position as ONE hipGraph, replayed -- built, bit-identical, and measured SLOWER than issuing its ~15 launches
-        # one by one (tools/decode_bench.py, ms per 24 positions, graph / plain: beam 5 x 30 sentences 3.87 / 3.62, arg-max x 256 3.68 / 2.92:
-        # a position is bound by the GPU's dependent-kernel turnaround, not by the host, and a replay does not overlap the next one's launch)
-        self.decode_graphs = _os_env.get("VMMT_DECODE_GRAPHS", "0") == "1"
         self.persistent_lstm = _os_env.get("VMMT_PERSISTENT_LSTM", "1") == "1"     # plans are built per workspace: set before the first forward
         self.seq_syncs = []
         # GUARD word of the persistent recurrences (vmmt.h: VMMT_SEQ_GUARD_WORD): [0] error code of a hand-off that timed out (sticky),
@@ -174,6 +161,14 @@ class Engine(StepAPI):
         self.seq_fallbacks, self.steps_skipped, self._adam_launches, self._guard_clear_pending = 0, 0, 1, False
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
         self._works = []
+        # ONE switch for experiments instead of one per schedule knob: VMMT_ENGINE_ATTRS="bg_adam_blocks=224,aux_early=0" sets attributes of
+        # this object (the schedule knobs above: what tools/ab.py sets programmatically) before the first plan is built
+        for kv in filter(None, _os_env.get("VMMT_ENGINE_ATTRS", "").split(",")):
+            k, _, v = kv.partition("=")
+            if not hasattr(self, k.strip()):
+                raise RuntimeError("VMMT_ENGINE_ATTRS: the engine has no attribute %r" % k.strip())
+            cur = getattr(self, k.strip())
+            setattr(self, k.strip(), (v.strip() not in ("0", "false", "False", "")) if isinstance(cur, bool) else type(cur)(v.strip()))
 
     @property
     def tgt_stream(self):
@@ -257,7 +252,7 @@ class Engine(StepAPI):
         gradient decay, its parameter follows them): bit-identical to dense Adam (tests/test_gpu_row_adam.py).  Off under data
         parallelism (the flagged set would have to be the union over the ranks) and for the conditional model (two streams flag
         rows of the shared target table).
-        OPT-IN (VMMT_ROW_ADAM=1): measured on MI355X it does not pay at these sizes -- 1.787 against 1.746 ms per step at BASELINE
+        OPT-IN (Engine.row_adam = True): measured on MI355X it does not pay at these sizes -- 1.787 against 1.746 ms per step at BASELINE
         config 2, 2.704 against 2.728 at the run scripts' shape, 1.867 against 1.863 through the trainer: the dense streams run at
         6.7 TB/s, half of them underneath the next step's encoder, while the row kernels add six small launches to the step's head
         and tail.  (The LAZY variant -- rows updated only when used, missed zero-gradient steps replayed -- saves 0.7 GB per step and
@@ -265,7 +260,7 @@ class Engine(StepAPI):
         and missed step, in front of the embedding lookup) cost more than the traffic: 2.11 against 1.92 ms through the trainer.  Not
         kept: LABNOTES.md, rounds 1-3, section 6.)"""
         names = ("encoder.embeddings.make_embedding.emb_luts.0.weight", "decoder.embeddings.make_embedding.emb_luts.0.weight")
-        self._row_adam = _os_env.get("VMMT_ROW_ADAM", "0") == "1" and not self.d.conditional
+        self._row_adam = False               # (Engine.row_adam = True switches it on: measured slower, see above)
         self.row_tables = []
         if self.d.conditional:
             return
@@ -521,7 +516,7 @@ class Engine(StepAPI):
     # ------------------------------------------------------------------------------------------------ helpers
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
               act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
-              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None, group=None, mask=None):
+              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None, group=None):
         """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out[, out2]): the column sums of the K-strided A operand from the same
         pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached.
         group (a list): the product is not issued but collected -- _gemm_group() sends the list out as ONE grid (vmmt_gemm_group)"""
@@ -548,10 +543,6 @@ class Engine(StepAPI):
             a.c_row_blk, a.c_row_valid = rmap
         if cmap is not None and cmap[0] != cmap[1]:
             a.c_col_blk, a.c_col_valid = cmap
-        if mask is not None:        # (mask, ld_mask, C2, ldc2): the dropped-out copy of the output from the same epilogue (vmmt_gemm_args.mask)
-            a.mask, a.ld_mask, a.C2, a.ldc2 = mask
-            if not self.lib.vmmt_gemm_mask_applies(C.byref(a)):
-                raise RuntimeError("vmmt_gemm: the masked second output does not apply to this product")
         attached = False
         if colsum is not None:
             a.colsum_w, a.colsum_w_stride, a.colsum_out = colsum[:3]

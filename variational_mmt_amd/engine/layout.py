@@ -36,7 +36,7 @@ class Dims(object):
         # (a bidirectional ENCODER with an odd per-direction size keeps the general kernels.)  The conditional model's encoder_tgt is
         # always bidirectional with hid / 2 units per direction (250 -> 256): its output is laid out [fwd | pad | bwd | pad], 2 * htp
         # wide, and feeds the posterior network's input [h_x : hp | h_y : 2 htp | v : img] (qin_p columns).
-        self.pad = (not self.brnn) and hid % 32 != 0 and _os_env.get("VMMT_PAD_HIDDEN", "1") == "1"
+        self.pad = (not self.brnn) and hid % 32 != 0
         self.hp = _ru(hid, 32) if self.pad else hid
         self.hdp = self.hp // self.dirs
         self.htp = _ru(self.ht, 32) if self.pad else self.ht

@@ -58,7 +58,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
         # the rows of this buffer instead of a second one that walks z with a row modulus (2.6 MB at the benchmark shape; the FORWARD
         # still adds z W_z once per sentence and never reads these columns)
         self.Ep = _ru(E, KPAD)
-        self.z_in_Xt = bool(Z <= E) and _os_env.get("VMMT_Z_IN_XT", "1") == "1"
+        self.z_in_Xt = bool(Z <= E)
         self.Xt = nb(M, E, ld=self.Ep + _ru(Z, KPAD)) if self.z_in_Xt else nb(M, E)
         self.zrep_ids = (torch.arange(M, dtype=i64) % B).to(dev) if self.z_in_Xt else None
         self.zx = nb(B, 4 * Hp, f32)
@@ -316,16 +316,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
                     self.hbar.ld, self.q_h1["location"].p(), self.q_h1["scale"].p(), self.q_h1["location"].ld, self.mu.p(),
                     self.sigma.p(), self.z32.p(), self.zT.p(), self.zT.ld, self.kl_b.data_ptr(), self.stats.data_ptr(), B, S, Hp, Zp, Z,
                     1 if training else 0, 1 if e.qnet_split else 0)
-            wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
-            self.latent_zx = bool(e.qnet_split and e.fuse_latent_zx and (4 * Hp) % 256 == 0 and wz.ld >= _ru(Z, 128))
-            if self.latent_zx:
-                # sample + KL + zx = z W_z^T + b in ONE launch (csrc/qnet.hip): between the two forward recurrences every launch boundary
-                # is exposed.  W_z is a decoder-side weight: behind the background half of the last optimiser step
-                e._wait(P, "opt_side_done")
-                e._call(P, lib.vmmt_latent_zx, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
-                        self.kl_b.data_ptr(), self.stats.data_ptr(), wz.p(), wz.ld, bsum.p(), self.zx.p(), self.zx.ld, B, Z, 4 * Hp,
-                        1 if training else 0)
-            elif e.qnet_split:      # the two networks ran in separate workgroups: the sample and the KL in a small launch of their own
+            if e.qnet_split:        # the two networks ran in separate workgroups: the sample and the KL in a small launch of their own
                 e._call(P, lib.vmmt_latent_fwd, dt, self.mu.p(), self.sigma.p(), self.eps.p(), self.z32.p(), self.zT.p(), self.zT.ld,
                         self.kl_b.data_ptr(), self.stats.data_ptr(), B, Z, 1 if training else 0)
         else:
@@ -375,10 +366,9 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._sid = MAIN
         # a6 decoder: gx[t] = emb(y_t) W_e^T (side stream, above) ; zx = z W_z^T + b is added inside the step kernel
         e._wait(P, "opt_side_done")      # decoder / attention / generator parameters + shadows of the previous update
-        if not getattr(self, "latent_zx", False):
-            wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
-            e._gemm(P, L.GEMM_NT, self.zT.p(), self.zT.ld, wz.p(), wz.ld, self.zx.p(), self.zx.ld, B, 4 * Hp, Z,
-                    addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+        wz, bsum = e.sh["dec_wih_l0_z"], e.sh["dec_b_l0"]
+        e._gemm(P, L.GEMM_NT, self.zT.p(), self.zT.ld, wz.p(), wz.ld, self.zx.p(), self.zx.ld, B, 4 * Hp, Z,
+                addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
         x, xcols = self.Xt, E
         for l in range(Lyr):
             if l == 0:
@@ -419,17 +409,10 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._gemm(P, L.GEMM_NT, self.cat.p(0, Hp), self.cat.ld, wa.p(), wa.ld, self.Q.p(), self.Q.ld, M, H, H)
         e._call(P, lib.vmmt_attn_fwd, dt, self.Q.p(), self.Q.ld, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.cat.p(), self.cat.ld,
                 self.probs.data_ptr(), Tp, B, S, Hp)
-        probe = L.GemmArgs(dt, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, _ru(2 * Hp, KPAD))
-        if drop and e.fuse_out_dropout and lib.vmmt_gemm_mask_applies(C.byref(probe)):
-            # AH = tanh(W_o [c ; r]) and O = AH * mask from ONE epilogue (the mask was drawn on the side stream at the head of the step)
+        e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * Hp, act=L.ACT_TANH)
+        if drop:
             e._wait(P, "out_mask")
-            e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * Hp, act=L.ACT_TANH,
-                    mask=(self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld))
-        else:
-            e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * Hp, act=L.ACT_TANH)
-            if drop:
-                e._wait(P, "out_mask")
-                e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
+            e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
         e._wait(P, "img_fwd")            # join: the loss plans read mu_v
         return P
 
