@@ -34,13 +34,14 @@ def _worker(rank, port, out):
     bts = [O.synth_batch(c, B=B, S=7, T=8, n_img=40, seed=80 + i, fixed_len=False) for i in range(3)]
     res = {}
     finals = {}
-    for mode in ("plain", "sharded", "replicated"):
+    for mode in ("plain", "sharded", "replicated", "sharded_c10d"):
         e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="bf16", device=dev, seed=2)
         e.load_state_dict(p)
         e.set_image_table(bts[0]["table"])
         sync = None
         if mode != "plain":
-            sync = GradSync(e, sharded=(mode == "sharded"))
+            # (direct=False: torch.distributed's own tensor collectives instead of the direct RCCL calls -- the path a failed self-check leaves)
+            sync = GradSync(e, sharded=(mode != "replicated"), direct=(mode != "sharded_c10d"))
             assert e.dp is sync and sync.active() and sync.world == 1 and sync.backend == "nccl"
         for i in range(3):
             bt = bts[i]
@@ -65,7 +66,7 @@ def _worker(rank, port, out):
         e.check_async_errors()
         res[mode]["fallbacks"] = e.seq_fallbacks
         finals[mode] = (e.flat_p[:e.n_opt].cpu().clone(), e.flat_m[:e.n_opt].cpu().clone())
-    for mode in ("sharded", "replicated"):
+    for mode in ("sharded", "replicated", "sharded_c10d"):
         res[mode]["p_err"] = float((finals[mode][0] - finals["plain"][0]).abs().max())
         res[mode]["m_rel"] = float((finals[mode][1] - finals["plain"][1]).norm() / finals["plain"][1].norm())
     torch.save(res, out)
@@ -77,14 +78,15 @@ def test_world_one_nccl_group_runs_every_collective_natively(tmp_path):
     port = 26000 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(port, out), nprocs=1, join=True)
     r = torch.load(out)
-    for mode in ("plain", "sharded", "replicated"):
+    for mode in ("plain", "sharded", "replicated", "sharded_c10d"):
         assert r[mode]["persistent"] and r[mode]["fused"] and not any(r[mode]["errors"]) and r[mode]["fallbacks"] == 0, (mode, r[mode])
     # the backward plan issued one gradient collective per arena segment + the KL all-reduce
     assert r["sharded"]["collectives"].count("ALLREDUCE") == 4 and "KL_ALLREDUCE" in r["sharded"]["collectives"]
     # the branch RCCL takes: the tensor collectives, in place -- not gloo's fallback
-    assert r["sharded"]["native"] == {"reduce_scatter": True, "all_gather": True}, r["sharded"]
-    assert all(b[1] == "native" for b in r["sharded"]["branches"])
-    for mode in ("sharded", "replicated"):
+    assert r["sharded"]["native"] == {"direct_rccl": True}, r["sharded"]            # the step's collectives straight through RCCL's C API
+    assert r["sharded_c10d"]["native"] == {"reduce_scatter": True, "all_gather": True, "direct_rccl": False}, r["sharded_c10d"]
+    assert all(b[1] == "native" for b in r["sharded_c10d"]["branches"])
+    for mode in ("sharded", "replicated", "sharded_c10d"):
         x = r[mode]
         assert x["identical"] and abs(x["kl_global"] - x["kl_local"]) <= 1e-6 * abs(x["kl_local"]), (mode, x)
         # one rank: every collective is the identity -> the same three updates as without data parallelism (float atomics apart)

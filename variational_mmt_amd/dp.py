@@ -19,8 +19,90 @@ import os
 import torch
 
 
+class _Rccl(object):
+    """The step's collectives straight through RCCL's C API (ctypes on the librccl.so torch itself has loaded), on a communicator of this
+    object's own.  Why: a torch.distributed call costs the host ~50 us (argument checks, work objects, stream bookkeeping) and a step
+    issues ten of them -- the one-rank rehearsal on one MI355X was HOST-bound at 2.25 ms per step against 1.72 ms without data
+    parallelism (bench.py: host_enqueue_ms); an ncclReduceScatter call is a few microseconds.  The unique id travels through the process
+    group that is already up.  Everything here is checked against torch.distributed's own result when the communicator comes up
+    (GradSync._direct_selfcheck); any failure leaves the run on torch.distributed, with a line on stderr."""
+    F32, I32, SUM, MAX = 7, 2, 0, 2
+
+    def __init__(self, dist, device):
+        import ctypes as C
+        import os as _os
+        cand = [_os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "/opt/rocm/lib/librccl.so"]
+        self.lib = None
+        for c in cand:
+            try:
+                self.lib = C.CDLL(c)
+                break
+            except OSError:
+                continue
+        if self.lib is None:
+            raise RuntimeError("librccl.so not found")
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        L = self.lib
+        L.ncclGetUniqueId.argtypes, L.ncclGetUniqueId.restype = [C.POINTER(UniqueId)], C.c_int
+        L.ncclCommInitRank.argtypes, L.ncclCommInitRank.restype = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int], C.c_int
+        L.ncclCommDestroy.argtypes, L.ncclCommDestroy.restype = [C.c_void_p], C.c_int
+        L.ncclGetErrorString.argtypes, L.ncclGetErrorString.restype = [C.c_int], C.c_char_p
+        L.ncclReduceScatter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        for f in (L.ncclReduceScatter, L.ncclAllGather, L.ncclAllReduce):
+            f.restype = C.c_int
+        world, rank = dist.get_world_size(), dist.get_rank()
+        uid = UniqueId()
+        if rank == 0:
+            self._ok(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+        dist.broadcast(t, 0)
+        raw = bytes(t.cpu().numpy().tobytes())
+        C.memmove(C.byref(uid), raw, 128)
+        self.comm = C.c_void_p()
+        torch.cuda.synchronize(device)
+        self._ok(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+        self.world, self.rank = world, rank
+
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
+
+    @staticmethod
+    def _stream(t):
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    def reduce_scatter(self, seg, n_per_rank):
+        """seg [world * n] f32 in place: this rank's piece seg[rank * n : (rank + 1) * n] receives the sum (RCCL's in-place form)"""
+        p = seg.data_ptr()
+        self._ok(self.lib.ncclReduceScatter(p, p + 4 * self.rank * n_per_rank, n_per_rank, self.F32, self.SUM, self.comm, self._stream(seg)), "ncclReduceScatter")
+
+    def all_gather(self, seg, n_per_rank):
+        """seg [world * n] f32 in place: every rank's piece -> the whole on every rank"""
+        p = seg.data_ptr()
+        self._ok(self.lib.ncclAllGather(p + 4 * self.rank * n_per_rank, p, n_per_rank, self.F32, self.comm, self._stream(seg)), "ncclAllGather")
+
+    def all_gather_into(self, out, row):
+        self._ok(self.lib.ncclAllGather(row.data_ptr(), out.data_ptr(), row.numel(), self.F32, self.comm, self._stream(row)), "ncclAllGather")
+
+    def all_reduce(self, t, op="sum"):
+        dt = {torch.float32: self.F32, torch.int32: self.I32}[t.dtype]
+        self._ok(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, self.SUM if op == "sum" else self.MAX, self.comm, self._stream(t)), "ncclAllReduce")
+
+    def close(self):
+        if getattr(self, "comm", None):
+            try:
+                self.lib.ncclCommDestroy(self.comm)
+            except Exception:
+                pass
+            self.comm = None
+
+
 class GradSync(object):
-    def __init__(self, engine=None, flat=None, bucket_elems=16 * 1024 * 1024, sharded=None):
+    def __init__(self, engine=None, flat=None, bucket_elems=16 * 1024 * 1024, sharded=None, direct=None):
         """sharded (default: on, VMMT_DP_SHARDED=0 switches it off): reduce-scatter the gradients, run clip + Adam on this rank's
         1 / world of every arena segment, all-gather the parameters (Engine._optim_step_sharded) -- the same bytes on the wire as the
         all-reduce it replaces (an all-reduce IS a reduce-scatter followed by an all-gather), but the optimiser's 28 B/param of HBM
@@ -35,6 +117,7 @@ class GradSync(object):
         self.backend = None
         self.sharded = (os.environ.get("VMMT_DP_SHARDED", "1") == "1") if sharded is None else bool(sharded)
         self._native = {}
+        self._direct = None            # _Rccl: the step's collectives straight through RCCL's C API (backend nccl)
         self.timing, self.exposed, self.step_event, self._comm = None, [], None, None     # bench.py switches the timing on for a few steps
         self.branch_log = []           # (collective, "native" | "fallback", reason): which form of each collective this run uses
         import torch.distributed as dist
@@ -45,6 +128,9 @@ class GradSync(object):
             self.world = dist.get_world_size()
             self.rank = dist.get_rank()
             self.backend = dist.get_backend()
+            self._direct = None
+            if direct is not False and self.backend == "nccl" and os.environ.get("VMMT_DP_NATIVE", "1") != "0" and self.flat.is_cuda:
+                self._direct_up()
             if engine is not None and getattr(engine, "dense_optimizer", False):
                 self.sharded = False               # torch's dense optimisers (-optim sgd|adagrad|adadelta) read the whole reduced gradient
             if engine is not None and engine.dp is None:
@@ -189,6 +275,59 @@ class GradSync(object):
                 self._log(what, "fallback", "%s: %s" % (self.backend, msg.splitlines()[0][:120]))
         return self._native[key]
 
+    def _direct_up(self):
+        """bring up the communicator of the direct RCCL path and check it against torch.distributed on small tensors; on ANY failure the
+        run stays on torch.distributed (every rank takes the same decision: the verdict is all-reduced through torch.distributed)"""
+        dev = self.flat.device
+        ok, why = 1, "ok"
+        try:
+            r = _Rccl(self.dist, dev)
+            n = 64
+            base = (torch.arange(self.world * n, device=dev, dtype=torch.float32) * 0.25 + self.rank).contiguous()
+            a, b = base.clone(), base.clone()
+            r.reduce_scatter(a, n)
+            self.dist.reduce_scatter_tensor(b[self.rank * n:(self.rank + 1) * n], b.clone())
+            same = torch.equal(a[self.rank * n:(self.rank + 1) * n], b[self.rank * n:(self.rank + 1) * n])
+            a2, b2 = a.clone(), a.clone()
+            r.all_gather(a2, n)
+            self.dist.all_gather_into_tensor(b2, a[self.rank * n:(self.rank + 1) * n].clone())
+            same = same and torch.equal(a2, b2)
+            k1 = torch.tensor([1.5 + self.rank], device=dev)
+            k2 = k1.clone()
+            r.all_reduce(k1)
+            self.dist.all_reduce(k2)
+            g1 = torch.tensor([self.rank + 3], device=dev, dtype=torch.int32)
+            g2 = g1.clone()
+            r.all_reduce(g1, "max")
+            self.dist.all_reduce(g2, op=self.dist.ReduceOp.MAX)
+            rows = torch.zeros(self.world, 9, device=dev)
+            rows2 = torch.zeros(self.world, 9, device=dev)
+            row = torch.arange(9, device=dev, dtype=torch.float32) + self.rank
+            r.all_gather_into(rows, row)
+            self.dist.all_gather_into_tensor(rows2.view(-1), row)
+            torch.cuda.synchronize(dev)
+            same = same and torch.equal(k1, k2) and torch.equal(g1, g2) and torch.equal(rows, rows2)
+            if not same:
+                ok, why = 0, "results differ from torch.distributed"
+        except Exception as ex:          # noqa: BLE001  (whatever went wrong: the run continues on torch.distributed)
+            ok, why, r = 0, "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:160] if str(ex) else ""), None
+        v = torch.tensor([ok], device=dev, dtype=torch.int32)
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MIN)
+        if int(v.item()) == 1:
+            self._direct = r
+            self._log("step collectives", "direct RCCL (ncclReduceScatter / ncclAllGather / ncclAllReduce on a communicator of their own)", "checked against torch.distributed")
+        else:
+            if r is not None:
+                r.close()
+            self._log("step collectives", "torch.distributed", "direct RCCL not used on this rank: " + why)
+
+    def all_reduce_tensor(self, t, op="sum"):
+        """small tensors of the step (the KL float, the guard word): synchronous on the current stream"""
+        if self._direct is not None and t.is_cuda and t.dtype in (torch.float32, torch.int32):
+            self._direct.all_reduce(t, op)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX)
+
     def _log(self, what, branch, why):
         self.branch_log.append((what, branch, why))
         if self.rank == 0:
@@ -197,7 +336,9 @@ class GradSync(object):
 
     def native_collectives(self):
         """{collective: bool} for the forms probed so far (bench.py prints it next to the multi-GPU number)"""
-        return {k[0]: v for k, v in self._native.items()}
+        out = {k[0]: v for k, v in self._native.items()}
+        out["direct_rccl"] = self._direct is not None
+        return out
 
     # Every collective is a SYNCHRONOUS operation of torch.distributed issued under an explicit stream: the backend then launches it
     # on that stream (observed with RCCL on torch 2.10: the copy kernel of a one-rank all-gather runs on the issuing stream), not on
@@ -232,7 +373,9 @@ class GradSync(object):
         segment is scratch).  Synchronous on the current stream.  One RCCL reduce-scatter when the segment splits evenly; otherwise
         (or on a backend without the tensor form) an all-reduce, whose result restricted to the shard is the same numbers"""
         seg = flat[lo:hi]
-        if self._even(lo, hi) and self._probe("reduce_scatter", flat):
+        if self._direct is not None and self._even(lo, hi) and flat.is_cuda and flat.dtype == torch.float32:
+            self._direct.reduce_scatter(seg, (hi - lo) // self.world)
+        elif self._even(lo, hi) and self._probe("reduce_scatter", flat):
             a, b = self.shard(lo, hi)
             self.dist.reduce_scatter_tensor(flat[a:b], seg)
         else:
@@ -244,13 +387,15 @@ class GradSync(object):
         stream whose kernels completed the segment).  Nothing waits for it here: Engine.finish_allreduce / the shard norms do"""
         if self.sharded:
             return self.on_comm(producer, lambda: self.reduce_scatter(flat, lo, hi), "reduce_scatter", lo, hi)
-        return self.on_comm(producer, lambda: self.dist.all_reduce(flat[lo:hi]), "all_reduce", lo, hi)
+        return self.on_comm(producer, lambda: self.all_reduce_tensor(flat[lo:hi]), "all_reduce", lo, hi)
 
     def all_gather(self, flat, lo, hi):
         """every rank's shard of flat[lo:hi] -> the whole segment on every rank, in place; synchronous on the current stream"""
         st = torch.cuda.current_stream(flat.device) if flat.is_cuda else None
         t0 = self.time_begin(st) if st is not None else None
-        if self._even(lo, hi) and self._probe("all_gather", flat):
+        if self._direct is not None and self._even(lo, hi) and flat.is_cuda and flat.dtype == torch.float32:
+            self._direct.all_gather(flat[lo:hi], (hi - lo) // self.world)
+        elif self._even(lo, hi) and self._probe("all_gather", flat):
             a, b = self.shard(lo, hi)
             self.dist.all_gather_into_tensor(flat[lo:hi], flat[a:b])
         else:
@@ -279,7 +424,9 @@ class GradSync(object):
 
     def all_gather_row_into(self, out, row):
         """row [n] on every rank -> out [world][n] on every rank, no temporaries: ONE tensor all-gather where the backend has it"""
-        if self._probe("all_gather", row):
+        if self._direct is not None and row.is_cuda and row.dtype == torch.float32 and out.is_contiguous():
+            self._direct.all_gather_into(out, row)
+        elif self._probe("all_gather", row):
             self.dist.all_gather_into_tensor(out.view(-1), row)
         else:
             self.dist.all_gather(list(out.unbind(0)), row)

@@ -858,7 +858,7 @@ class Engine(StepAPI):
                     ev = self.global_events.get("opt_side_done")
                     if ev is not None:
                         comm.wait_event(ev)
-                    self.dp.on_comm(ts[sid], lambda: self.dp.dist.all_reduce(ws.kl_global))
+                    self.dp.on_comm(ts[sid], lambda: self.dp.all_reduce_tensor(ws.kl_global))
                     ts[sid].wait_stream(comm)
                 return
             if name == "ALLREDUCE":

@@ -154,7 +154,7 @@ class StepAPI(object):
             return self._optim_step_sharded(lr, max_grad_norm, beta1, beta2, eps, grad_scale)
         if self.dp_on():                # replicated data-parallel update: every rank must skip the same steps
             self.finish_allreduce()
-            self.dp.dist.all_reduce(self._guard[:1], op=self.dp.dist.ReduceOp.MAX)
+            self.dp.all_reduce_tensor(self._guard[:1], "max")
         if max_grad_norm and not self._sumsq_by_plan:      # the backward plan normally accumulates the norm segment by segment
             self._sumsq[:L.SUMSQ_SLOTS].zero_()
             if self.rows_active():
