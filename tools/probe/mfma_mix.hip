@@ -8,14 +8,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-template <int NF, int NE, int NT, int NB, bool WAIT, bool USE>
-__global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc, int slot, int iters) {
+template <int NF, int NE, int NT, int NB, bool WAIT, bool USE, int TPB = 256>
+__global__ void __launch_bounds__(TPB, 1) k(float* out, unsigned long long* cyc, int slot, int iters) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 65536 / 4; i += 256) reinterpret_cast<float*>(lds)[i] = (float)(i & 7);
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+  for (int i = threadIdx.x; i < 65536 / 4; i += TPB) reinterpret_cast<float*>(lds)[i] = (float)(i & 7);
   __syncthreads();
-  f32x16 acc[16];
-  for (int j = 0; j < 16; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  constexpr int NACC = TPB == 512 ? 6 : 16;      // (two waves per SIMD: 256 registers per lane)
+  f32x16 acc[NACC];
+  for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   bf16x8 a, b;
   for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(lane + e); b[e] = (__bf16)(float)(lane - e); }
   float x[4] = {1.f + lane, 2.f, 3.f, 4.f}, y = 0.999f, z[2] = {0.5f, 0.25f};
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc,
       bf16x8 av = a;
       if (USE && NT == 2) av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(fl[i % PD], fh[i % PD], 0, 1, 2, 3, 4, 5, 6, 7));
       __builtin_amdgcn_sched_barrier(0);
-      acc[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b, acc[i >> 1], 0, 0, 0);
+      acc[(i >> 1) % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b, acc[(i >> 1) % NACC], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int v = 0; v < NF; ++v) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[v & 3]) : "v"(y));
@@ -51,10 +52,12 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc,
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = x[0] + x[1] + x[2] + x[3] + z[0] + z[1];
   for (int i = 0; i < PD; ++i) s += (float)fl[i][0] + (float)fh[i][0] + (float)q[i][0];
-  for (int j = 0; j < 16; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+  for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
   out[blockIdx.x * 256 + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[slot] = t1 - t0;
 }
+#define RUN2(slot, ...) do { hipFuncSetAttribute((const void*)k<__VA_ARGS__, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+  hipLaunchKernelGGL((k<__VA_ARGS__, 512>), dim3(256), dim3(512), 65536, 0, out, cyc, slot, iters); } while (0)
 #define RUN(slot, ...) do { hipFuncSetAttribute((const void*)k<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
   hipLaunchKernelGGL((k<__VA_ARGS__>), dim3(256), dim3(256), 65536, 0, out, cyc, slot, iters); } while (0)
 int main() {
@@ -84,8 +87,15 @@ int main() {
     RUN(19, 2, 0, 2, 0, true, true);
     RUN(20, 1, 0, 2, 0, true, true);
     RUN(21, 0, 1, 2, 0, true, true);
+    RUN2(22, 0, 0, 0, 0, false, false);     // TWO waves per SIMD (512 threads): MFMA alone
+    RUN2(23, 0, 0, 2, 0, true, true);       // + 2 tr reads consumed
+    RUN2(24, 1, 1, 2, 0, true, true);       // + 1 fma + 1 exp
+    RUN2(25, 2, 1, 2, 0, true, true);
+    RUN2(26, 4, 2, 2, 0, true, true);
+    RUN2(27, 2, 1, 0, 1, true, false);      // phase A mix: b128 + 2 fma + 1 exp
+    RUN2(28, 6, 2, 2, 1, true, true);
   }
-  hipDeviceSynchronize();
+  { hipError_t e_ = hipDeviceSynchronize(); if (e_ != hipSuccess) printf("sync error: %s\n", hipGetErrorString(e_)); e_ = hipGetLastError(); if (e_ != hipSuccess) printf("last error: %s\n", hipGetErrorString(e_)); }
   unsigned long long h[32]; hipMemcpy(h, cyc, 32 * 8, hipMemcpyDeviceToHost);
   const double n = 32.0 * iters;
   printf("cycles per step, one wave per SIMD, 4 waves per CU in lockstep:\n");
@@ -95,5 +105,8 @@ int main() {
   printf("  b128 read per MFMA + 1 fma %.1f | + 2 fma %.1f | + 4 fma %.1f | + 1 exp %.1f | + 1 fma + 1 exp %.1f | + 2 fma + 1 exp %.1f | (6 fma, no LDS: %.1f)\n",
          h[12] / n, h[13] / n, h[14] / n, h[15] / n, h[16] / n, h[17] / n, h[18] / n);
   printf("  2 tr reads consumed + 1 fma %.1f | + 2 fma %.1f | + 1 exp %.1f\n", h[20] / n, h[19] / n, h[21] / n);
+  printf("TWO waves per SIMD, cycles per step of ONE wave (the SIMD retires two MFMAs per step):\n");
+  printf("  MFMA alone %.1f | + 2 tr consumed %.1f | + 1 fma + 1 exp %.1f | + 2 fma + 1 exp %.1f | + 4 fma + 2 exp %.1f | b128 + 2 fma + 1 exp %.1f | 2 tr + b128 + 6 fma + 2 exp %.1f\n",
+         h[22] / n, h[23] / n, h[24] / n, h[25] / n, h[26] / n, h[27] / n, h[28] / n);
   return 0;
 }
