@@ -124,14 +124,6 @@ __device__ __forceinline__ u32x4 g2_lds_read_b128(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
   return r;
 }
-__device__ __forceinline__ void g2_lds_write_b128(unsigned addr, f32x4 v) {
-  asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ f32x4 g2_lds_read_f128(unsigned addr) {
-  f32x4 r;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
-  return r;
-}
 template <int N>
 __device__ __forceinline__ void g2_wait_lgkm_seg(fs16x4& a, fs16x4& b, u32x4& c, u32x4& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
@@ -931,311 +923,6 @@ __global__ void __launch_bounds__(256, 1) gen2p_kernel(Gen2Args a) {
 }
 
 // <<< traffic-key gen2p
-// >>> traffic-key gen2s
-// ---- H = 512 with TWO waves per SIMD -----------------------------------------------------------------------------------------------
-// tools/probe/mfma_2w.hip: the instruction mixes of this sweep's phases cost ONE wave per SIMD 46-57 cycles per MFMA and two waves 32.5 --
-// the matrix unit's rate: a second wave's LDS reads, exps and address arithmetic issue while the first one's MFMA runs.  256 registers
-// per lane then: gen2w_kernel's column split at H = 512.  Eight waves; wave (tg, dh) shares the 32 tokens of group tg with its partner,
-// owns the columns [256 dh, 256 dh + 256) of acc^T (128 accumulators) and computes the half of the S^T reduction over those columns: 16
-// k-steps, its half of O in 40 registers + 6 k-steps in LDS.  The partial S^T meet through 4 KiB of LDS per wave (a + b = b + a: both
-// waves go on with bit-identical logits, statistics and weights), both run the element-wise phase, each stores half of P's columns.
-#ifndef G2S_KR
-#define G2S_KR 10
-#endif
-#ifndef G2S_PD
-#define G2S_PD 3
-#endif
-struct G2S {
-  static constexpr int D = 512, BC = 32, NSLOT = 2;
-  static constexpr int ROWB = 1024, TILEB = BC * ROWB;      // 32 KiB
-  static constexpr int PER = 4;                             // 1-KiB LDS-DMA pieces (= rows) per wave and tile
-  static constexpr int KS = 16, HB = 8;                     // per wave: k-steps of its half of S^T, 32-column blocks of its half of acc^T
-  static constexpr int KR = G2S_KR, KL = KS - KR;           // k-steps of the wave's half of O in registers / in LDS
-  static constexpr int SMALLB = 8 * 256;                    // per ring slot: every wave's copy of the tile's 32 column constants
-  static constexpr int SOFF = NSLOT * TILEB;
-  static constexpr int EOFF = SOFF + NSLOT * SMALLB;        // exchange of the partial S^T: 4 KiB per wave
-  static constexpr int XOFF = EOFF + 8 * 4096, XWAVEB = KL * 1024;
-  static constexpr int LDSB = XOFF + 8 * XWAVEB;
-  static constexpr int PD = G2S_PD, NM = 16;
-  static_assert(LDSB <= 160 * 1024, "LDS of one CU");
-};
-// LDS operations younger than the fragment(s) of k-step ks when its MFMA is due: 4 constants, fragments 0 .. PD-1, then behind MFMA j the
-// fragment(s) of k-step j + PD (two reads from k-step KR on)
-constexpr int g2s_a_inflight(int ks) {
-  using C = G2S;
-  int n = 0;
-  for (int m = ks + 1; m < ks + C::PD && m < C::KS; ++m) n += 1 + (m >= C::KR ? 1 : 0);
-  return n;
-}
-constexpr int g2s_b_inflight(int k) {
-  using C = G2S;
-  return 2 * ((C::PD - 1) < (C::NM - 1 - k) ? (C::PD - 1) : (C::NM - 1 - k));
-}
-
-template <bool HASP>
-__global__ void __launch_bounds__(512) gen2s_kernel(Gen2Args a) {
-  using C = G2S;
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tg = wave >> 1, dh = wave & 1;
-  const int lane = threadIdx.x & 63, half = lane >> 5, r31 = lane & 31;
-  const int nwg = (int)gridDim.x, nblk = nwg / a.nsplit;
-  const int j = (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;     // see gen2_kernel
-  const int split = j / nblk, rt = j - split * nblk;
-  const int R0 = rt * 128 + tg * 32;
-  const int row = R0 + r31;
-  const int rowi = row < a.nrows ? row : a.nrows - 1;
-  const int rmap = a.rows ? a.rows[rowi] : rowi;
-  const int rowc = rmap < 0 ? 0 : rmap;
-  const int ntall = (a.ncols + C::BC - 1) / C::BC;
-  const int t0 = split * a.tiles_per_split, t1 = min(ntall, t0 + a.tiles_per_split);
-
-  // LDS-DMA: piece jj (0..3) of this wave = row 4 (2 jj + (wave >> 2)) + (wave & 3) of the tile, swizzle ((wave & 3) << 2) | ((2 jj + (wave >> 2)) & 3)
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int wq = wave & 3, wh = wave >> 2;
-  const unsigned voff0 = (unsigned)(((lane ^ (wq << 2)) & 63) * 16);
-  const long row4 = 4 * a.ldy * 2, tile_step = (long)C::BC * a.ldy * 2;
-  const char* yt = reinterpret_cast<const char*>(a.Y + (long)(t0 * C::BC + wq) * a.ldy);
-  auto issue_piece = [&](const char* yb, int t, int slot, int jj) {
-    if (jj < C::PER) {
-      const int r = 2 * jj + wh;
-      const char* src = yb + r * row4 + (voff0 ^ (unsigned)((r & 3) << 4));
-      __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)src, (f_lds_void_t*)(smem + slot * C::TILEB + (4 * r + wq) * C::ROWB), 16, 0, 0);
-    } else {
-      int c = t * C::BC + r31;
-      c = c < a.ncols ? c : a.ncols - 1;
-      const void* src = (const void*)(a.cvec + c);
-      __builtin_amdgcn_global_load_lds((f_glb_cvoid_t*)src, (f_lds_void_t*)(smem + C::SOFF + slot * C::SMALLB + wave * 256), 4, 0, 0);
-    }
-  };
-  if (t0 < t1) {
-#pragma unroll
-    for (int jj = 0; jj <= C::PER; ++jj) issue_piece(yt, t0, 0, jj);
-  }
-
-  // resident operand: this wave's half of the k range (k = 256 dh + 16 ks + 8 half + 0..7): KR k-steps in registers, KL in LDS
-  bf16x8 xf[C::KR];
-  const unsigned xla = lds0 + C::XOFF + wave * C::XWAVEB + lane * 16;
-  {
-    const bf16_t* xr = a.X + (long)rowc * a.ldx + dh * 256 + half * 8;
-#pragma unroll
-    for (int ks = 0; ks < C::KR; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xr + ks * 16);
-#pragma unroll
-    for (int k = 0; k < C::KL; ++k)
-      *reinterpret_cast<bf16x8*>(smem + C::XOFF + wave * C::XWAVEB + lane * 16 + k * 1024) = *reinterpret_cast<const bf16x8*>(xr + (C::KR + k) * 16);
-  }
-  f32x16 acc[C::HB];
-#pragma unroll
-  for (int hb = 0; hb < C::HB; ++hb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[hb][r] = 0.f;
-
-  unsigned ua0, ul0, uh0;
-  {
-    const int sw = g2_swz(r31);
-    ua0 = lds0 + r31 * C::ROWB + dh * 512 + ((half ^ sw) * 16);
-    const int i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, g1 = (lane >> 4) & 1;
-    const int tw = 2 * g1 + (p4 >> 1);
-    const int x_lo = (q << 2) | half, x_hi = (q << 2) | (half + 2);
-    ul0 = lds0 + (4 * half + q) * C::ROWB + dh * 512 + (p4 & 1) * 8 + ((tw ^ x_lo) * 16);
-    uh0 = lds0 + (4 * half + q + 8) * C::ROWB + dh * 512 + (p4 & 1) * 8 + ((tw ^ x_hi) * 16);
-  }
-  const unsigned ex_mine = lds0 + C::EOFF + wave * 4096 + lane * 16, ex_other = lds0 + C::EOFF + (wave ^ 1) * 4096 + lane * 16;
-  const float bsel = dh == 0 ? 1.f : 0.f;                   // the column constants enter through ONE of the two partial sums
-
-  float ref = -INFINITY, nrl = 0.f, lsum = 0.f, rmax = -INFINITY;
-  int ym = (row < a.nrows && rmap >= 0) ? (int)a.y[rowc] : -1;
-  asm volatile("" : "+v"(ym));
-  const bool stores = HASP && R0 < a.nrows;                 // (a wave without a single row issues no store)
-  const bool rowok = row < a.nrows;
-  const unsigned poff = (unsigned)(((long)rowi * a.ldp + 16 * dh + 8 * half) * 2);
-
-  for (int t = t0; t < t1; ++t) {
-    // tile t has landed (the only younger operation is the store of P behind the previous tile's last DMA piece)
-    if (stores) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int cur = (t - t0) & 1;
-    const unsigned sx = (unsigned)cur * C::TILEB;
-    const int tn = t + 1;
-    const char* yn = yt + tile_step;
-    const int c0 = t * C::BC;
-
-    // ---- this wave's half of S^T[c][r] = sum_h Y[c][h] X[r][h]: every LDS read inline assembly with a counted wait (see gen2p_kernel)
-    f32x16 sT;
-    {
-      constexpr int PD = C::PD;
-      const unsigned sb = lds0 + C::SOFF + cur * C::SMALLB + wave * 256 + half * 16;
-      u32x4 cv[4];
-      g2_static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; cv[q] = g2_lds_read_b128o<q * 32>(sb); });
-      const unsigned uas = ua0 + sx;
-      u32x4 fa[PD], fx[PD];
-      auto rd = [&](auto kc) {
-        constexpr int ks = decltype(kc)::value;
-        fa[ks % PD] = g2_lds_read_b128o<(ks >> 3) * 256>(uas ^ ((ks & 7) << 5));
-        if constexpr (ks >= C::KR) fx[ks % PD] = g2_lds_read_b128o<(ks - C::KR) * 1024>(xla);
-      };
-      g2_static_for<0, PD>([&](auto kc) { rd(kc); });
-      g2_static_for<0, C::KS>([&](auto kc) {
-        constexpr int ks = decltype(kc)::value;
-        constexpr int inflight = g2s_a_inflight(ks);
-        if constexpr (ks == 0) {
-          asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]), "+v"(fa[0]) : "n"(inflight));
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sT[4 * q + e] = __uint_as_float(cv[q][e]) * bsel;
-        } else if constexpr (ks >= C::KR) {
-          asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[ks % PD]), "+v"(fx[ks % PD]) : "n"(inflight));
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fa[ks % PD]) : "n"(inflight));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ks < C::KR) g2p_mfma_v(sT, __builtin_bit_cast(bf16x8, fa[ks % PD]), xf[ks < C::KR ? ks : 0]);
-        else g2p_mfma_v(sT, __builtin_bit_cast(bf16x8, fa[ks % PD]), __builtin_bit_cast(bf16x8, fx[ks % PD]));
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ks + PD < C::KS) rd(std::integral_constant<int, ks + PD>{});
-        if constexpr ((ks & 3) == 1) issue_piece(yn, tn, cur ^ 1, ks >> 2);
-        if constexpr (ks == 3) issue_piece(yn, tn, cur ^ 1, C::PER);
-      });
-      g2p_mfma_done(sT);
-    }
-    // ---- the partner's half
-#pragma unroll
-    for (int i = 0; i < 4; ++i) g2_lds_write_b128(ex_mine + i * 1024, f32x4{sT[4 * i], sT[4 * i + 1], sT[4 * i + 2], sT[4 * i + 3]});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    {
-      f32x4 o[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = g2_lds_read_f128(ex_other + i * 1024);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sT[4 * i + e] += o[i][e];
-    }
-
-    // the first operand pairs of the second product, in front of the element-wise phase
-    constexpr int PD = C::PD, NM = C::NM;
-    fs16x4 fl[PD], fh[PD];
-    const unsigned ulp = ul0 + sx, uhp = uh0 + sx;
-    auto rd2 = [&](auto ic) {
-      constexpr int i = decltype(ic)::value, hb = G2_HB(i), kk = G2_KK(i);
-      constexpr int off = (hb >> 2) * 256 + kk * 16 * C::ROWB;
-      fl[i % PD] = g2_tr_read<off>(ulp ^ ((hb & 3) << 6));
-      fh[i % PD] = g2_tr_read<off>(uhp ^ ((hb & 3) << 6));
-    };
-    g2_static_for<0, PD>([&](auto ic) { rd2(ic); });
-
-    // ---- element-wise (both waves of the pair, on identical numbers)
-    bf16x8 pf[2];
-    if (c0 + C::BC > a.ncols) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (c0 + (r & 3) + 8 * (r >> 2) + 4 * half >= a.ncols) sT[r] = -INFINITY;
-    }
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sT[r]), sT[r + 1]);
-    rmax = fmaxf(rmax, tmax);
-    if (__any(tmax > ref + G2_THR)) {
-      const float nm = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const bool mv = nm > ref + G2_THR;
-      const float f = mv ? __expf(ref - nm) : 1.f;
-      if (mv) { ref = nm; nrl = -nm * G2_L2E; }
-      lsum *= f;
-#pragma unroll
-      for (int hb = 0; hb < C::HB; ++hb) g2_scale_acc(acc[hb], f);
-      if constexpr (HASP) {
-        if (t > t0) {
-          // (practically never, see gen2_kernel)  Each wave rewrites the COLUMNS it stored: entries 16 dh .. 16 dh + 15 of every tile
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (mv && row < a.nrows) {
-            bf16_t* pr = a.p_out + (long)row * a.ldp;
-            for (int v = t0 * C::BC + 16 * dh + half * 8; v < c0; v += 32) {
-              uint32_t w[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) w[e] = __hip_atomic_load(reinterpret_cast<uint32_t*>(pr + v) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(w[e] << 16) * f, hi = __uint_as_float(w[e] & 0xffff0000u) * f;
-                w[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
-              }
-              *reinterpret_cast<u32x4*>(pr + v) = u32x4{w[0], w[1], w[2], w[3]};
-            }
-          }
-        }
-      }
-    }
-    if (__any(ym >= c0 && ym < c0 + C::BC)) {
-      float tl = 0.f;
-      bool hit = false;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool h = c0 + (r & 3) + 8 * (r >> 2) + 4 * half == ym;
-        tl = h ? sT[r] : tl;
-        hit = hit || h;
-      }
-      if (hit && dh == 0) a.tgt_logit[row] = tl;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[r], G2_L2E, nrl));
-      lsum += pv;
-      pf[r >> 3][r & 7] = (__bf16)pv;
-    }
-    u32x4 pw;
-    if constexpr (HASP) {
-      // this wave's half of P[m][c0 .. c0+31]: entries 16 dh .. 16 dh + 15, out of the fragment registers (see gen2p_kernel: storeP)
-      const u32x4 v0 = __builtin_bit_cast(u32x4, pf[0]), v1 = __builtin_bit_cast(u32x4, pf[1]);
-      u32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = dh ? v1[e] : v0[e];          // (element by element: `dh ? pf[1] : pf[0]` indexes the pair through scratch)
-      const auto s0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
-      const auto s1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
-      pw = u32x4{s0[0], s1[0], s0[1], s1[1]};
-    }
-
-    // ---- this wave's columns of acc^T[h][r] += sum_c Y[c][h] P[r][c]
-    g2_static_for<0, NM>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      constexpr int inflight = g2s_b_inflight(i);
-      g2_wait_lgkm<inflight>(fl[i % PD], fh[i % PD]);
-      const fs16x8 v = __builtin_shufflevector(fl[i % PD], fh[i % PD], 0, 1, 2, 3, 4, 5, 6, 7);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[G2_HB(i)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v), pf[G2_KK(i)], acc[G2_HB(i)], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (i + PD < NM) rd2(std::integral_constant<int, i + PD>{});
-      if constexpr (i == NM - 2 && HASP) {
-        // behind the tile's last DMA piece: the wait at the top of the next tile may leave exactly this store in flight
-        if (rowok) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.p_out + c0) + poff) = pw;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    });
-#pragma unroll
-    for (int hb = 0; hb < C::HB; ++hb) asm volatile("" : "+a"(acc[hb]));
-    yt = yn;
-  }
-
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (row < a.nrows) {
-    const long pr = (long)split * a.mpad + row;
-    float* dst = a.p_acc + pr * C::D + dh * 256;
-    const float lt = lsum + __shfl_xor(lsum, 32, 64), mt = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-    if (half == 0 && dh == 0) { a.p_ref[pr] = ref; a.p_l[pr] = lt; a.p_max[pr] = mt; }
-#pragma unroll
-    for (int hb = 0; hb < C::HB; ++hb)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[hb][4 * i + e];
-        *reinterpret_cast<f32x4*>(dst + 32 * hb + 8 * i + 4 * half) = v;
-      }
-  }
-}
-// <<< traffic-key gen2s
 // >>> traffic-key gen2w
 // ---- the same sweep at H = 1024 ------------------------------------------------------------------------------------------------
 // acc^T for 32 tokens x 1024 columns would be 512 accumulator registers per lane.  Here TWO waves share a group of 32 tokens: wave
@@ -1262,6 +949,14 @@ struct G2W {
   static_assert(LDSB <= 160 * 1024, "LDS of one CU");
 };
 
+__device__ __forceinline__ void g2_lds_write_b128(unsigned addr, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 g2_lds_read_f128(unsigned addr) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
 template <int N>
 __device__ __forceinline__ void g2_wait_lgkm_seg1(fs16x4& a, fs16x4& b, u32x4& c) {
   asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
@@ -1830,17 +1525,6 @@ static int g2p_launch(const Gen2Args& a, int grid, hipStream_t st) {
 }
 
 template <bool HASP>
-static int g2s_launch(const Gen2Args& a, int grid, hipStream_t st) {
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute((const void*)gen2s_kernel<HASP>, hipFuncAttributeMaxDynamicSharedMemorySize, G2S::LDSB) != hipSuccess) return VMMT_ELAUNCH;
-    done = true;
-  }
-  hipLaunchKernelGGL((gen2s_kernel<HASP>), dim3(grid), dim3(512), G2S::LDSB, st, a);
-  return check_launch();
-}
-
-template <bool HASP>
 static int g2w_launch(const Gen2Args& a, int grid, hipStream_t st) {
   static bool done = false;
   if (!done) {
@@ -1912,8 +1596,6 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows
 #else
   constexpr bool classic = false;
 #endif
-  static const bool two_waves = getenv("VMMT_GEN2S") != nullptr;      // (development A/B only)
-  if (K == 512 && two_waves && (!Pw || (int64_t)M * ldp * 2 < (int64_t)0xffff0000ll)) return Pw ? g2s_launch<true>(a, nmt * ns, st) : g2s_launch<false>(a, nmt * ns, st);
   // (gen2p_kernel addresses P with 32-bit byte offsets from a per-tile base)
   if (K == 512 && !classic && (!Pw || (int64_t)M * ldp * 2 < (int64_t)0xffff0000ll)) return Pw ? g2p_launch<true>(a, nmt * ns, st) : g2p_launch<false>(a, nmt * ns, st);
   if (Pw) return K == 512 ? g2_launch<512, true>(a, nmt * ns, st) : g2_launch<256, true>(a, nmt * ns, st);
