@@ -641,6 +641,29 @@ def main():
         sch["region_ms"] = round(dt_ * 1e3, 3)
         return dt_, ws_, dev_ms, host_ms, (t_enq - t0) * 1e3, sch
 
+    # self-check of the schedule on THIS box: the step is 3.4 ms of kernel time packed into ~1.7 ms by three streams of different priority
+    # and persistent kernels that need their workgroups co-resident.  A few steps with everything on ONE stream against a few steps as
+    # scheduled: a box (a driver, a queue configuration) on which the packing is lost shows a ratio near 1 and the line says so
+    overlap = None
+    if world == 1 and not a.no_side_stream:
+        def timed_steps(n, first):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(n):
+                step(first + i)
+            eng.wait_background()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        eng.use_side_stream = False
+        timed_steps(2, 0)
+        serial = timed_steps(4, 2)
+        eng.use_side_stream = True
+        timed_steps(3, 0)
+        packed = timed_steps(4, 3)
+        overlap = {"one_stream_ms": round(serial, 3), "as_scheduled_ms": round(packed, 3), "ratio": round(serial / packed, 3),
+                   "verdict": "streams overlap" if serial / packed > 1.12 else "NO OVERLAP: the side / aux streams' work does not run beside the main stream's on this box"}
     # the host's collector out of the timed regions: a full collection of a process that has imported torch walks ~10^6 objects (tens of
     # ms, the length of the whole 20-step region); nothing the steps allocate is cyclic, reference counting frees it
     import gc
@@ -698,6 +721,8 @@ def main():
             else:
                 diagnosis = ("region %.3f ms/step against a median step of %.3f ms with no single slow step: the device ran the %d steps in %.1f ms, the region's "
                              "wall clock has %.1f ms more at its ends (first launch, the synchronize's return)" % (ms, step_med, a.steps, sched["device_span_ms"], ends))
+        if overlap is not None and overlap["ratio"] <= 1.12:
+            diagnosis += "; " + overlap["verdict"]
         reps = [r_[0] / a.steps * 1e3 for r_ in regions]
         if len(reps) > 1 and ms > 1.10 * min(reps[1:]):
             diagnosis += "; the same region repeated ran at %s ms/step: the official (first) region was NOT typical for this box" % ", ".join("%.3f" % x for x in reps[1:])
@@ -757,7 +782,7 @@ def main():
                                 "per_step_max": round(max(host_ms), 4)},
             "repeats_ms": [round(r_[0] / a.steps * 1e3, 4) for r_ in regions],
             "repeats_step_median_ms": [step_summary(r_[2], r_[3])[0]["median"] for r_ in regions],
-            "slow_steps": slow_steps, "diagnosis": diagnosis, "warmup_run": n_warm,
+            "slow_steps": slow_steps, "diagnosis": diagnosis, "warmup_run": n_warm, "stream_overlap": overlap,
             "host_sched": dict(sched, cpu_quota=cpu_quota(), repeats=[r_[5] for r_ in regions[1:]]),
             "gpu_state": {"before_warmup": state0, "after_each_region": [r_[6] for r_ in regions]},
             "elbo_per_sentence": round(st["elbo"] / B, 4),
