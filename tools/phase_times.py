@@ -18,6 +18,7 @@ if os.environ.get("VMMT_DP_FORCE") == "1":       # the data-parallel step throug
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29546")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     sync = GradSync(eng, sharded=os.environ.get("SHARDED", "1") == "1")
+eng.hold_back = os.environ.get("HOLD", "0") == "1"       # HOLD=1: as inside a training loop (the side-stream half of an update may be held back)
 def step(i):
     src, sl, tgt, idx, _tl, _ntok = bs[i % 4]
     ws = eng.forward(src, sl, tgt, idx, training=True)
