@@ -599,8 +599,7 @@ def main():
     # bucket of the ragged rotation) is seen for the first time inside the timed region
     n_warm = max(a.warmup, len(batches), 1)
     state0 = gpu_state()
-    for i in range(n_warm):
-        step(i)
+    step(0)                            # builds the launch plans (the backward plan exists behind the first step)
     # backward plan exists now: hook the gen_loss_bwd entry
     for j, (fn, args, name, keep, sid) in enumerate(ws0.plan_bwd):
         if name in ("vmmt_gen_loss_bwd", "vmmt_gen_loss_bwd_db"):
@@ -669,6 +668,10 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    # the W warm-up steps LAST, right in front of the timed region: the collection above leaves the GPU idle for ~0.1 s, and a region that
+    # starts behind an idle gap ran its first ten steps 3-10 % slow (clock ramp: step_ms lists of round 5's first leases)
+    for i in range(n_warm):
+        step(i)
     regions = []
     n_rep = max(1, a.repeats)
     for r_ in range(n_rep):            # the FIRST region is the official one; the others show whether it was typical for the box
