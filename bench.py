@@ -181,6 +181,34 @@ def step_summary(dev_ms, host_ms):
             "list": [round(x, 3) for x in dev_ms]}, slow, med
 
 
+def diagnose(ms, steps, step_med, slow_steps, enq_ms, sched, reps, overlap):
+    """one sentence: is the whole-region ms/step what the box does step after step, and if not, what took the rest (tests/test_bench_diagnosis.py)"""
+    out = "steady: whole-region ms/step within 5 %% of the median step (%.3f ms)" % step_med
+    if ms > 1.05 * step_med:
+        lost = ms * steps - step_med * steps
+        ends = sched.get("region_ms", ms * steps) - sched.get("device_span_ms", step_med * steps)
+        if sched.get("cgroup_nr_throttled", 0) > 0 or sched.get("runq_wait_ms", 0.0) > 0.5 * lost:
+            out = ("HOST DESCHEDULED: while it enqueued the region this thread waited %.1f ms for a CPU (%d preemptions) and the container's CPU quota "
+                   "throttled it (%.1f ms summed over its threads, %d periods); the region lost %.1f ms against %d median steps of %.3f ms" %
+                   (sched.get("runq_wait_ms", 0.0), sched.get("preempted", 0), sched.get("cgroup_throttled_ms", 0.0), sched.get("cgroup_nr_throttled", 0),
+                    lost, steps, step_med))
+        elif slow_steps:
+            out = ("STALL: %d of %d steps took > 1.5 x the median step (%.3f ms) and account for %.1f of the %.1f ms the region "
+                   "lost against %d median steps; " % (len(slow_steps), steps, step_med, sum(x["ms"] - step_med for x in slow_steps), lost, steps)) + \
+                ("the host was late there (enqueue took longer than the step)" if any(x["host_ms"] > x["ms"] * 0.8 for x in slow_steps)
+                 else "the host was ahead: the device itself stalled")
+        elif enq_ms > 0.9 * ms * steps:
+            out = "HOST-BOUND: enqueueing the region took %.1f of its %.1f ms" % (enq_ms, ms * steps)
+        else:
+            out = ("region %.3f ms/step against a median step of %.3f ms with no single slow step: the device ran the %d steps in %.1f ms, the region's "
+                   "wall clock has %.1f ms more at its ends (first launch, the synchronize's return)" % (ms, step_med, steps, sched.get("device_span_ms", 0.0), ends))
+    if overlap is not None and overlap["ratio"] <= 1.12:
+        out += "; " + overlap["verdict"]
+    if len(reps) > 1 and ms > 1.10 * min(reps[1:]):
+        out += "; the same region repeated ran at %s ms/step: the official (first) region was NOT typical for this box" % ", ".join("%.3f" % x for x in reps[1:])
+    return out
+
+
 def host_cpu():
     """model name, physical cores, logical CPUs of the host (from /proc/cpuinfo; no extra tools needed)"""
     model, phys, logical = "?", set(), 0
@@ -704,31 +732,8 @@ def main():
         ms = dt / a.steps * 1e3
         value = Bg * a.steps / dt
         step_sum, slow_steps, step_med = step_summary(dev_ms, host_ms)
-        # the line says by itself when the whole-region value is not what the box does step after step
-        diagnosis = "steady: whole-region ms/step within 5 %% of the median step (%.3f ms)" % step_med
-        if ms > 1.05 * step_med:
-            lost = ms * a.steps - step_med * a.steps
-            ends = sched["region_ms"] - sched["device_span_ms"]
-            if sched.get("cgroup_nr_throttled", 0) > 0 or sched.get("runq_wait_ms", 0.0) > 0.5 * lost:
-                diagnosis = ("HOST DESCHEDULED: while it enqueued the region this thread waited %.1f ms for a CPU (%d preemptions) and the container's CPU quota "
-                             "throttled it (%.1f ms summed over its threads, %d periods); the region lost %.1f ms against %d median steps of %.3f ms" %
-                             (sched.get("runq_wait_ms", 0.0), sched.get("preempted", 0), sched.get("cgroup_throttled_ms", 0.0), sched.get("cgroup_nr_throttled", 0),
-                              lost, a.steps, step_med))
-            elif slow_steps:
-                diagnosis = ("STALL: %d of %d steps took > 1.5 x the median step (%.3f ms) and account for %.1f of the %.1f ms the region "
-                             "lost against %d median steps; " % (len(slow_steps), a.steps, step_med, sum(x["ms"] - step_med for x in slow_steps), lost, a.steps)) + \
-                    ("the host was late there (enqueue took longer than the step)" if any(x["host_ms"] > x["ms"] * 0.8 for x in slow_steps)
-                     else "the host was ahead: the device itself stalled")
-            elif enq_ms > 0.9 * ms * a.steps:
-                diagnosis = "HOST-BOUND: enqueueing the region took %.1f of its %.1f ms" % (enq_ms, ms * a.steps)
-            else:
-                diagnosis = ("region %.3f ms/step against a median step of %.3f ms with no single slow step: the device ran the %d steps in %.1f ms, the region's "
-                             "wall clock has %.1f ms more at its ends (first launch, the synchronize's return)" % (ms, step_med, a.steps, sched["device_span_ms"], ends))
-        if overlap is not None and overlap["ratio"] <= 1.12:
-            diagnosis += "; " + overlap["verdict"]
         reps = [r_[0] / a.steps * 1e3 for r_ in regions]
-        if len(reps) > 1 and ms > 1.10 * min(reps[1:]):
-            diagnosis += "; the same region repeated ran at %s ms/step: the official (first) region was NOT typical for this box" % ", ".join("%.3f" % x for x in reps[1:])
+        diagnosis = diagnose(ms, a.steps, step_med, slow_steps, enq_ms, sched, reps, overlap)
         # dominant kernel = the fused vocabulary projection (+log-softmax+NLL) GEMM passes: 2*M*V*H FLOP per launch
         M = Tp * B
         fused = bool(getattr(ws0, "gen_fused", False))
