@@ -166,8 +166,12 @@ __global__ void __launch_bounds__((BM / WM) * (BN / WN) * 64) gemm_group_kernel(
     if (i < ga.n && bid >= ga.start[i]) g = i;
   g = __builtin_amdgcn_readfirstlane(g);
   const GemmGroupItem& it = ga.item[g];
+  // every (product, K split) owns a range of workgroup indices that starts on a multiple of 8: workgroups are dealt to the 8 XCDs round-robin
+  // by index, and xcd_remap() counts on (tile index & 7) being the XCD.  The <= 7 workgroups at the end of a range exit
   const int local = bid - ga.start[g];
-  const int split = local / it.ntiles, tl = local - split * it.ntiles;
+  const int stride8 = (it.ntiles + 7) & ~7;
+  const int split = local / stride8, tl = local - split * stride8;
+  if (tl >= it.ntiles) return;
   GemmEpi epi = it.epi;
   gemm_tile<T, BM, BN, WM, WN, A_KC, B_KC, BK, DB, GL>((const T*)it.A, it.lda, (const T*)it.B, it.ldb, it.M, it.N, it.K, 0, 0, it.tiles_n,
                                                        it.kper, epi, xcd_remap(tl, it.ntiles), split);
@@ -290,7 +294,7 @@ int gemm_group_launch_tn(const vmmt_gemm_args* args, const GemmEpi* epis, int n,
     it.epi = epis[i];
     it.epi.atomic = 1;
     ga.start[i] = start;
-    start += tm * tn * splits;
+    start += ((tm * tn + 7) & ~7) * splits;
   }
   for (int i = n; i <= VMMT_GEMM_GROUP_MAX; ++i) ga.start[i] = start;
   const size_t smem = (size_t)glds_smem_bytes<BM, BN>();
