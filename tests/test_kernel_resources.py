@@ -39,21 +39,24 @@ def test_no_kernel_spills(res):
 def test_gemms_fit_beside_the_persistent_recurrences(res):
     g = "gemm_kernelItLi128ELi128ELi64ELi64E"        # bf16, 128 x 128 tiles, LDS-DMA loop (the trailing ...Li1E)
     nt, tn, nn = (_find(res, g + lay + "ELi64ELb1ELi1ELi0E") for lay in ("Lb1ELb1", "Lb0ELb0", "Lb1ELb0"))        # (...Li0E: the plain epilogue)
-    fwd512, bwd512 = _find(res, "lstm_seq_fwd_kernelILi512E"), _find(res, "lstm_seq_bwd_kernelILi512E")
-    fwd256, bwd256 = _find(res, "lstm_seq_fwd_kernelILi256E"), _find(res, "lstm_seq_bwd_kernelILi256E")
+    # (H <= 512: the 16-row shapes, lstm_seq_fwd16_kernel / lstm_seq_bwd16_kernel, their W_hh fragments in registers)
+    fwd512, bwd512 = _find(res, "lstm_seq_fwd16_kernelILi512E"), _find(res, "lstm_seq_bwd16_kernelILi512E")
+    fwd256, bwd256 = _find(res, "lstm_seq_fwd16_kernelILi256E"), _find(res, "lstm_seq_bwd16_kernelILi256E")
     # forward: the decoder's recurrence (H = 512) runs beside NT products (image network, target-side input projection)
     assert fwd512 + nt <= 512, (fwd512, nt)
-    # backward: weight gradients (TN) and input gradients (NN) beside both backward recurrences
-    assert bwd512 + max(tn, nn, nt) <= 512, (bwd512, tn, nn, nt)
-    # the encoder's directions (H = 256) leave room for every product
+    # backward at H = 512: the recurrence holds its SIMDs ALONE, by measurement (LABNOTES round 5: with a quarter / three eighths / half of
+    # its fragments in LDS so that the products fit beside it again -- 280 / 264 / 248 registers -- the step was equal / 20 us / 25 us
+    # slower, in five configurations): it only has to fit the file
+    assert bwd512 <= 512, bwd512
+    # the encoder's directions (H = 256) DO host every product (made exclusive by an LDS pad, the step lost 65 us)
     assert max(fwd256, bwd256) + max(tn, nn, nt) <= 512, (fwd256, bwd256, tn, nn, nt)
     # the grouped weight-gradient launch (vmmt_gemm_group) is a guest of the backward recurrences like the products it replaces
     grp = _find(res, "gemm_group_kernelItLi128ELi128ELi64ELi64ELb0ELb0")
-    assert bwd512 + grp <= 512 and grp <= tn, (bwd512, grp, tn)
+    assert bwd256 + grp <= 512 and grp <= tn, (bwd256, grp, tn)
 
 
 def test_one_wave_per_simd_kernels_stay_within_the_file(res):
-    for name in ("gen2_kernelILi512ELb1E", "gen2w_kernelILb1E", "lstm_seq_fwd_kernelILi1024E", "lstm_seq_bwd_kernelILi1024E"):
+    for name in ("gen2_kernelILi512ELb1E", "gen2w_kernelILb1E", "lstm_seq_fwd_kernelILi1024E", "lstm_seq_bwd_kernelILi1024E", "lstm_seq_bwd16_kernelILi512E"):
         assert _find(res, name) <= 512, name
 
 

@@ -59,18 +59,31 @@ __device__ __forceinline__ LstmCell lstm_cell_math(float pi, float pf, float pg,
 }
 // ... and its backward: gradients of the four gate pre-activations and of c_{t-1}, given dL/dh and the dL/dc arriving from t+1
 struct LstmCellGrad { float di, df, dg, d_o, dc_prev; };
-__device__ __forceinline__ LstmCellGrad lstm_cell_bwd_math(float i, float f, float g, float o, float c, float cp, float dh, float dc) {
+// (in two halves: what depends only on the SAVED forward values -- the persistent backward recurrence computes it while it waits for the
+// step's dgates -- and what needs dL/dh; lstm_cell_bwd_math is their composition, so every caller produces the same bits)
+struct LstmCellBwdPre { float tc, omt2, omi, omf, omo, omg2; };
+__device__ __forceinline__ LstmCellBwdPre lstm_cell_bwd_pre(float i, float f, float g, float o, float c) {
+  LstmCellBwdPre p;
+  p.tc = tanhf_(c);
+  p.omt2 = __builtin_fmaf(-p.tc, p.tc, 1.f);
+  p.omi = 1.f - i; p.omf = 1.f - f; p.omo = 1.f - o;
+  p.omg2 = __builtin_fmaf(-g, g, 1.f);
+  return p;
+}
+__device__ __forceinline__ LstmCellGrad lstm_cell_bwd_post(const LstmCellBwdPre& p, float i, float f, float g, float o, float cp, float dh, float dc) {
   LstmCellGrad r;
-  const float tc = tanhf_(c);
-  const float d_o = dh * tc;
-  dc = __builtin_fmaf(dh * o, __builtin_fmaf(-tc, tc, 1.f), dc);
+  const float d_o = dh * p.tc;
+  dc = __builtin_fmaf(dh * o, p.omt2, dc);
   const float d_i = dc * g, d_f = dc * cp, d_g = dc * i;
-  r.di = d_i * i * (1.f - i);
-  r.df = d_f * f * (1.f - f);
-  r.dg = d_g * __builtin_fmaf(-g, g, 1.f);
-  r.d_o = d_o * o * (1.f - o);
+  r.di = d_i * i * p.omi;
+  r.df = d_f * f * p.omf;
+  r.dg = d_g * p.omg2;
+  r.d_o = d_o * o * p.omo;
   r.dc_prev = dc * f;
   return r;
+}
+__device__ __forceinline__ LstmCellGrad lstm_cell_bwd_math(float i, float f, float g, float o, float c, float cp, float dh, float dc) {
+  return lstm_cell_bwd_post(lstm_cell_bwd_pre(i, f, g, o, c), i, f, g, o, cp, dh, dc);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -446,6 +446,273 @@ static int launch_seq_fwd(const SeqArgsF& a, hipStream_t st) {
 }
 
 // ==============================================================================================================
+// Forward recurrence, the shape used for 128 <= H <= 512: a workgroup owns 16 sentences x 32 hidden units (4 gates x 32 = 128 columns
+// of the gate product).  Same protocol, same bits; what a workgroup sweeps per step is HALF of the 32-row shape's (16 x H tagged
+// granules = 32 KiB at H = 512), and the sweep -- out of an L2 that every CU of the chip reads at once, beside the GEMMs of the other
+// streams -- is the largest piece of a step.  Wave w multiplies K QUARTER w (H/4 units of h_{t-1}: the k-step blocks of H/128
+// producers) against all 128 columns: its 8 * H/128 B fragments of W_hh come straight from memory into registers, once (128 at
+// H = 512; no LDS copy of the slice).  A producer's h tile (16 x 32) is ONE k-step block of the consumers' order: wave 0 stores its
+// "lo" KiB, wave 1 its "hi" KiB.  Fold: every wave leaves its quarter's 16 x 128 sums in LDS (32 KiB), a cell adds the four in
+// lstm_step_fwd_fast's order ((q0 + q1) + q2) + q3.
+// ==============================================================================================================
+template <int H> struct SeqCfg16 {
+  static constexpr int NKS = H / 32, KQ = NKS / 4, S = H / 32;
+  static constexpr int RED_BYTES = 4 * 8 * 4 * 64 * 4;         // [quarter = wave][gate][unit half][reg][lane] f32
+  static constexpr int HROW = 40;                              // h tile [16 rows][32 units] bf16, rows padded to 80 bytes
+  static constexpr int HT_BYTES = 16 * HROW * 2;
+  static constexpr int LDS = RED_BYTES + HT_BYTES;
+  static constexpr long SLOT = (long)NKS * 2048;               // one step's h in fragment order: [k-step][lo / hi][64 lanes] x 16 bytes
+  static_assert(H % 128 == 0, "a K quarter is a whole number of k-steps");
+};
+
+template <int H>
+__global__ void __launch_bounds__(256) lstm_seq_fwd16_kernel(SeqArgsF a) {
+  using Cf = SeqCfg16<H>;
+  constexpr int KQ = Cf::KQ, S = Cf::S, HROW = Cf::HROW;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* red = reinterpret_cast<float*>(lds);
+  bf16_t* htile = reinterpret_cast<bf16_t*>(lds + Cf::RED_BYTES);
+  const int B = a.B, ndir = a.ndir;
+  const int total = gridDim.x, bid = blockIdx.x;
+  int grp, slice;                                               // role mapping and transport choice: see lstm_seq_fwd_kernel
+  if (total % 8 == 0 && (total / 8) % S == 0) { grp = (bid % 8) + 8 * ((bid / 8) / S); slice = (bid / 8) % S; }
+  else { grp = bid / S; slice = bid % S; }
+  const int k = grp / a.ngroups, rg = grp % a.ngroups;
+  const int m0 = rg * 16, u0 = slice * 32;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int uh = wave & 1, rp = wave >> 1;                      // the two cells of a lane: rows 4*kg + 2*rp + e, unit u0 + 16*uh + n
+  const int n = lane & 15, kg = lane >> 4;
+  const int u = u0 + uh * 16 + n;
+  const unsigned tag0 = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 4096u;
+  char* xg = reinterpret_cast<char*>(a.xchg) + (long)grp * (2 * Cf::SLOT);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(xg);
+  {
+    int* flag = reinterpret_cast<int*>(lds);
+    if (threadIdx.x == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned* arrive = a.sync + 4 + 2 * grp;
+      __hip_atomic_fetch_or(arrive + 1, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = wall_clock64();
+      int f = 0;
+      for (;;) {
+        if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)S) {
+          f = __builtin_popcount(__hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
+          break;
+        }
+        if (timed_out(t0)) { seq_fail(a.sync, 0x300u); f = -1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      *flag = f;
+#ifdef VMMT_SEQ_PROBE
+      vmmt_seq_xcc[bid & 511] = (xcc & 15u) | ((unsigned)(f & 3) << 8);
+#endif
+    }
+  }
+  bool alive = true, same_xcd = false;
+  // ---- this wave's B fragments of W_hh -> registers, once: rows g*H + u0 + 16*h2 + n (gate g, unit), columns (wave*KQ + q)*32 + kg*8 .. +8
+  bf16x8 wreg[KQ][4][2];
+  {
+    const SeqDirF d0 = load_desc(a.steps, k);
+    const bf16_t* wp = reinterpret_cast<const bf16_t*>(d0.w_hh);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+          wreg[q][g][h2] = *reinterpret_cast<const bf16x8*>(wp + ((long)g * H + u0 + h2 * 16 + n) * d0.ld_w + (wave * KQ + q) * 32 + kg * 8);
+  }
+  int rows[2];
+  long long len[2];
+  float c_reg[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    rows[e] = m0 + kg * 4 + 2 * rp + e;
+    const int rr = rows[e] < B ? rows[e] : B - 1;
+    len[e] = a.lens ? a.lens[rr] : 0;
+    c_reg[e] = 0.f;
+  }
+  const int arow = min(m0 + n, B - 1);                          // the h_{t-1} row this lane's A fragments come from (step 0)
+  __syncthreads();
+  {
+    const int f = *reinterpret_cast<volatile int*>(lds);
+    same_xcd = f == 1;
+    alive = f >= 0;
+  }
+  __syncthreads();                                              // the flag word is part of the fold buffer
+
+  float gxn[2][4];                                              // x W_ih^T + b of the cells' gates, NEXT step's (they do not depend on the recurrence)
+  auto fetch_gx = [&](const SeqDirF& dd) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int rr = rows[e] < B ? rows[e] : B - 1;
+      const float* gx = dd.gx + (long)rr * dd.ld_gx + u;
+      gxn[e][0] = gx[0]; gxn[e][1] = gx[H]; gxn[e][2] = gx[2 * H]; gxn[e][3] = gx[3 * (long)H];
+      if (dd.gx2) {
+        const float* g2 = dd.gx2 + (long)rr * dd.ld_gx2 + u;
+        gxn[e][0] += g2[0]; gxn[e][1] += g2[H]; gxn[e][2] += g2[2 * H]; gxn[e][3] += g2[3 * (long)H];
+      }
+    }
+  };
+  fetch_gx(load_desc(a.steps, k));
+
+  for (int t = 0; t < a.nsteps; ++t) {
+    const SeqDirF d = load_desc(a.steps, (long)t * ndir + k);
+    SEQ_TS(0);
+    float gxv[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gxv[e][g] = gxn[e][g];
+      const int rr = rows[e] < B ? rows[e] : B - 1;
+      if (t == 0) c_reg[e] = d.c_prev ? d.c_prev[(long)rr * d.ld_cprev + u] : 0.f;
+    }
+    // ---- A fragments of h_{t-1}: 16 rows x this wave's K quarter (KQ k-steps of 32 units)
+    u32x4 af[KQ];
+    if (t == 0) {                                               // the initial state: an ordinary [B][ld] bf16 buffer of an earlier kernel
+      const __amdgpu_buffer_rsrc_t hr = make_rsrc(d.h_prev);
+      const unsigned abase = (unsigned)(((long)arow * d.ld_hprev + kg * 8) * 2);
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) af[q] = load16_sc1(hr, abase + (unsigned)((wave * KQ + q) * 64));
+    } else {
+      const unsigned want = tag0 + (unsigned)t;                 // tag of step t-1
+      const unsigned gbase = (unsigned)(((t - 1) & 1) * Cf::SLOT + (long)(wave * KQ) * 2048 + lane * 16);
+      const unsigned long long t_start = wall_clock64();
+      // cheap poll first: ONE granule per producer of this wave's quarter (the last of its "hi" block), so that the waiting waves do
+      // not sweep: the full sweep repeated by 1024 waves would by itself saturate the memory system the hand-off travels through
+      {
+        const unsigned pbase = (unsigned)(((t - 1) & 1) * Cf::SLOT + (long)(wave * KQ + lane) * 2048 + 1024 + 63 * 16 + 8);
+        while (alive) {
+          unsigned long long g = 0;
+          if (lane < KQ) g = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(xg + pbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all(lane >= KQ || (unsigned)(g >> 32) == want)) break;
+          if (timed_out(t_start)) {
+            if (lane == 0) seq_fail(a.sync, 0x200u + (unsigned)t);
+            alive = false;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      SEQ_TS(1);
+      for (;;) {
+        u32x4 lo[KQ], hi[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          lo[q] = load16_sc1(xr, gbase + (unsigned)(q * 2048));
+          hi[q] = load16_sc1(xr, gbase + (unsigned)(q * 2048 + 1024));
+        }
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          ok = ok && lo[q][1] == want && lo[q][3] == want && hi[q][1] == want && hi[q][3] == want;
+          af[q] = u32x4{lo[q][0], lo[q][2], hi[q][0], hi[q][2]};
+        }
+        if (__all(ok) || !alive) break;
+        if (timed_out(t_start)) {
+          if (lane == 0) seq_fail(a.sync, 0x100u + (unsigned)t);
+          alive = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    SEQ_TS(2);
+    if (t + 1 < a.nsteps) fetch_gx(load_desc(a.steps, (long)(t + 1) * ndir + k));
+    f32x4_s acc[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { acc[g][0] = f32x4_s{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4_s{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+          acc[g][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[q]), wreg[q][g][h2], acc[g][h2], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(((wave * 4 + g) * 2 + h2) * 4 + r) * 64 + lane] = acc[g][h2][r];
+    SEQ_TS(3);
+    __syncthreads();
+    SEQ_TS(4);
+    LstmCell cellv[2];
+    bool valid[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      float p[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float* rq = red + ((g * 2 + uh) * 4 + 2 * rp + e) * 64 + lane;
+        const float q0 = rq[0], q1 = rq[32 * 64], q2 = rq[64 * 64], q3 = rq[96 * 64];
+        p[g] = (((0.f + q0) + q1) + q2) + q3;                   // lstm_step_fwd_fast's fold order
+      }
+      cellv[e] = lstm_cell_math(p[0] + gxv[e][0], p[1] + gxv[e][1], p[2] + gxv[e][2], p[3] + gxv[e][3], c_reg[e]);
+      const float cp = c_reg[e];
+      valid[e] = !a.lens || d.t < len[e];
+      c_reg[e] = valid[e] ? cellv[e].c : cp;                    // frozen state at pads (packed-sequence semantics)
+      htile[(kg * 4 + 2 * rp + e) * HROW + uh * 16 + n] = f2bf(valid[e] ? cellv[e].h : 0.f);
+    }
+    SEQ_TS(5);
+    __syncthreads();
+    SEQ_TS(6);
+    // ---- publish h_t.  Waves 0-1: the tile as tagged granules = k-step block `slice` of the row group's order, wave 0 its "lo" KiB
+    //      (units 8*kg + 0..3 of row n: two granules), wave 1 its "hi" KiB (units 8*kg + 4..7); wave 2: the layer's output buffer
+    if (wave < 2) {
+      const unsigned* hw = reinterpret_cast<const unsigned*>(htile + n * HROW + kg * 8 + wave * 4);
+      const unsigned tg = tag0 + (unsigned)t + 1u;
+      const unsigned off = (unsigned)((t & 1) * Cf::SLOT + (long)slice * 2048 + wave * 1024 + lane * 16);
+      const u32x4 v = u32x4{hw[0], tg, hw[1], tg};
+      if (same_xcd) *reinterpret_cast<u32x4*>(xg + off) = v;   // stays in the group's L2
+      else store16_sc1(xr, off, v);                             // write-through: visible to every XCD
+    } else if (wave == 2) {
+      const int r = lane >> 2, o = lane & 3;
+      if (m0 + r < B)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d.h_out) + ((long)(m0 + r)) * d.ld_h + u0 + o * 8) =
+            *reinterpret_cast<const u32x4*>(htile + r * HROW + o * 8);
+    }
+    // ---- what only later kernels read (saved gate activations, cell state, captured final state): behind the publish
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int b = rows[e];
+      if (b < B) {
+        const LstmCell& cl = cellv[e];
+        bf16_t* gs = reinterpret_cast<bf16_t*>(d.gates) + (long)b * d.ld_gates + u;
+        gs[0] = f2bf(cl.i); gs[H] = f2bf(cl.f); gs[2 * H] = f2bf(cl.g); gs[3 * (long)H] = f2bf(cl.o);
+        d.c_out[(long)b * d.ld_c + u] = c_reg[e];
+        const bool cap = d.capture == 3 || (d.capture == 1 && d.t == len[e] - 1) || (d.capture == 2 && d.t == 0);
+        if (cap && d.h_n) {
+          reinterpret_cast<bf16_t*>(d.h_n)[(long)b * d.ld_hn + u] = f2bf(cl.h);
+          d.c_n[(long)b * d.ld_cn + u] = cl.c;
+        }
+      }
+    }
+    SEQ_TS(7);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)total - 1) {
+      __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int g2 = 0; g2 < a.ndir * a.ngroups; ++g2) {
+        __hip_atomic_store(a.sync + 4 + 2 * g2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sync + 5 + 2 * g2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int H>
+static int launch_seq_fwd16(const SeqArgsF& a, hipStream_t st) {
+  constexpr int sm = SeqCfg16<H>::LDS;
+  hipLaunchKernelGGL(lstm_seq_fwd16_kernel<H>, dim3(a.ngroups * (H / 32) * a.ndir), dim3(256), sm, st, a);
+  return check_launch();
+}
+
+// ==============================================================================================================
 // Backward recurrence, same structure: dh_t[32 x 16] = dgates_{t+1}[32 x 4H] W_hh^T slice[16 x 4H]^T, then the cell backward.
 // What the workgroups of a row group exchange is dgates (4H values per sentence and step, 4x the forward's payload): every
 // workgroup reads the whole 32 x 4H tile of its group at every step, and that traffic is what bounds the step.  So the tile travels
@@ -785,6 +1052,275 @@ static int launch_seq_bwd(const SeqArgsB& a, hipStream_t st) {
   return check_launch();
 }
 
+// ==============================================================================================================
+// Backward recurrence, the shape used for H <= 512: a workgroup owns 16 sentences x 32 hidden units.  The kernel above is bound by
+// what every workgroup sweeps per step -- its row group's whole dgates tile, 32 x 4H -- out of an L2 that 256 workgroups sweep at
+// once (32 MiB per step chip-wide at H = 512: 2.0 of the 4.3-5.1 us of a step on an idle chip, and the part that grows when GEMMs of
+// other streams stream through the same L2).  Half the rows per workgroup and twice the units: the same number of workgroups, the
+// same MFMAs per wave, HALF the sweep (16 x 4H = 64 KiB per workgroup and step).  What changes with it:
+//   * wave w multiplies K QUARTER w -- which is gate w's H columns -- against both 16-unit halves of the slice: its 2 * H/32 B
+//     fragments of W_hh^T live in REGISTERS for the whole sequence (128 at H = 512; the sweep holds 64 where the 32-row shape
+//     held 128), no LDS copy of the slice at all: 13 KiB of LDS per workgroup instead of 81
+//   * a producer wave g stores gate g's 16 x 32 block = ONE 1-KiB k-step block of the consumers' fragment order (one store
+//     instruction, 8 full lines), and a consumer wave w waits only for the S = H/32 flags of the producers' waves w
+//   * fold: every wave leaves its quarter's 16 x 32 sums in LDS, the cells (two per lane) add the four in lstm_step_bwd_fast's
+//     order ((q0 + q1) + q2) + q3 with q = even + odd k-step accumulators: the same bits as the 32-row shape and the per-step kernels.
+// ==============================================================================================================
+template <int H> struct SeqCfgB16 {
+  static constexpr int K = 4 * H, NKS = K / 32, KQ = NKS / 4, S = H / 32;
+  static constexpr int RED_BYTES = 4 * 2 * 4 * 64 * 4;         // [quarter = wave][unit half][reg][lane] f32
+  static constexpr int DROW = 4 * 32 + 8;                      // dgates tile [16 rows][4 gates][32 units] bf16, rows padded by 16 bytes
+  static constexpr int DT_BYTES = 16 * DROW * 2;
+  static constexpr int LDS = RED_BYTES + DT_BYTES;
+  static constexpr long DSLOT = (long)NKS * 1024;              // one step's tile in fragment order: [k-step][64 lanes] x 16 bytes
+  static constexpr long GROUP_BYTES = 4L * NKS * 1024;         // per (direction, row group of 16): two slots, then the flags
+  static constexpr int NFLAG = 4 * S;                          // per slot: [producer wave = gate][producer slice]
+  static_assert(2 * DSLOT + 2 * NFLAG * 4 <= GROUP_BYTES, "flags must fit behind the data");
+};
+
+template <int H>
+__global__ void __launch_bounds__(256) lstm_seq_bwd16_kernel(SeqArgsB a) {
+  using Cf = SeqCfgB16<H>;
+  constexpr int KQ = Cf::KQ, S = Cf::S, DROW = Cf::DROW, NFLAG = Cf::NFLAG;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* red = reinterpret_cast<float*>(lds);
+  bf16_t* dtile = reinterpret_cast<bf16_t*>(lds + Cf::RED_BYTES);
+  const int B = a.B, ndir = a.ndir;
+  const int total = gridDim.x, bid = blockIdx.x;
+  int grp, slice;                                               // role mapping and transport choice: see lstm_seq_fwd_kernel
+  if (total % 8 == 0 && (total / 8) % S == 0) { grp = (bid % 8) + 8 * ((bid / 8) / S); slice = (bid / 8) % S; }
+  else { grp = bid / S; slice = bid % S; }
+  const int k = grp / a.ngroups, rg = grp % a.ngroups;
+  const int m0 = rg * 16, u0 = slice * 32;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int uh = wave & 1, rp = wave >> 1;                      // the two cells of a lane: rows 4*kg + 2*rp + e, unit u0 + 16*uh + n
+  const int n = lane & 15, kg = lane >> 4;
+  const int u = u0 + uh * 16 + n;
+  const unsigned tag0 = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 4096u;
+  char* xg = reinterpret_cast<char*>(a.xchg) + (long)grp * Cf::GROUP_BYTES;
+  constexpr unsigned FLAG_OFF = (unsigned)(2 * Cf::DSLOT);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(xg);
+  {
+    int* flag = reinterpret_cast<int*>(lds);
+    if (threadIdx.x == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned* arrive = a.sync + 4 + 2 * grp;
+      __hip_atomic_fetch_or(arrive + 1, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = wall_clock64();
+      int f = 0;
+      for (;;) {
+        if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)S) {
+          f = __builtin_popcount(__hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
+          break;
+        }
+        if (timed_out(t0)) { seq_fail(a.sync, 0x400u); f = -1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      *flag = f;
+#ifdef VMMT_SEQ_PROBE
+      vmmt_seq_xcc[bid & 511] = (xcc & 15u) | ((unsigned)(f & 3) << 8);
+#endif
+    }
+  }
+  bool alive = true, same_xcd = false;
+  // ---- this wave's B fragments of W_hh^T -> registers, once: units u0 + 16*h2 + n, columns (wave*KQ + q)*32 + kg*8 .. +8
+  bf16x8 wreg[KQ][2];
+  {
+    const SeqDirB d0 = load_desc_b(a.steps, k);
+    const bf16_t* wp = reinterpret_cast<const bf16_t*>(d0.w_hh_t);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+        wreg[q][h2] = *reinterpret_cast<const bf16x8*>(wp + (long)(u0 + h2 * 16 + n) * d0.ld_wt + (wave * KQ + q) * 32 + kg * 8);
+  }
+  int rows[2];
+  long long len[2];
+  float dcc[2];                                                 // dL/dc flowing to the previous step: in registers for the whole sequence
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    rows[e] = m0 + kg * 4 + 2 * rp + e;
+    const int rr = rows[e] < B ? rows[e] : B - 1;
+    len[e] = a.lens ? a.lens[rr] : 0;
+    dcc[e] = 0.f;
+  }
+  __syncthreads();
+  {
+    const int f = *reinterpret_cast<volatile int*>(lds);
+    same_xcd = f == 1;
+    alive = f >= 0;
+  }
+  __syncthreads();                                              // the flag word is part of the fold buffer
+
+  float nx[2][9];                                               // the cell backward's inputs of the NEXT step (they do not depend on the recurrence)
+  auto fetch_in = [&](const SeqDirB& dd) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const long bb = rows[e] < B ? rows[e] : B - 1;
+      const bf16_t* gs = reinterpret_cast<const bf16_t*>(dd.gates) + bb * dd.ld_gates + u;
+      nx[e][0] = bf2f(gs[0]); nx[e][1] = bf2f(gs[H]); nx[e][2] = bf2f(gs[2 * H]); nx[e][3] = bf2f(gs[3 * (long)H]);
+      nx[e][4] = dd.c_t[bb * dd.ld_ct + u];
+      nx[e][5] = dd.c_prev ? dd.c_prev[bb * dd.ld_cp + u] : 0.f;
+      nx[e][6] = dd.dh_above ? bf2f(reinterpret_cast<const bf16_t*>(dd.dh_above)[bb * dd.ld_dha + u]) : 0.f;
+      nx[e][7] = dd.dh_n ? dd.dh_n[bb * dd.ld_dhn + u] : 0.f;
+      nx[e][8] = dd.dh_n ? dd.dc_n[bb * dd.ld_dcn + u] : 0.f;
+    }
+  };
+  fetch_in(load_desc_b(a.steps, k));
+
+  for (int t = 0; t < a.nsteps + a.with_dh0; ++t) {
+    const SeqDirB d = load_desc_b(a.steps, (long)t * ndir + k);
+    const bool dh0_step = t == a.nsteps;                        // the gradient of the initial hidden state: GEMM only
+    SEQ_TS(0);
+    float gi[2], gf[2], gg[2], go[2], cc[2], cpv[2], dha[2], dhn[2], dcn[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      gi[e] = nx[e][0]; gf[e] = nx[e][1]; gg[e] = nx[e][2]; go[e] = nx[e][3]; cc[e] = nx[e][4]; cpv[e] = nx[e][5];
+      dha[e] = nx[e][6]; dhn[e] = nx[e][7]; dcn[e] = nx[e][8];
+      const long bb = rows[e] < B ? rows[e] : B - 1;
+      if (t == 0) dcc[e] = d.dc_carry[bb * d.ld_dcc + u];
+    }
+    // everything of the cell backward that does not need dL/dh: computed below while the wave waits for the step's dgates, and held there
+    // (the compiler would otherwise sink it behind the fold's barrier, onto the step's critical path)
+    LstmCellBwdPre pre[2];
+    bool valid[2], inj[2];
+    auto cell_pre = [&]() {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        pre[e] = lstm_cell_bwd_pre(gi[e], gf[e], gg[e], go[e], cc[e]);
+        asm volatile("" : "+v"(pre[e].tc), "+v"(pre[e].omt2), "+v"(pre[e].omi), "+v"(pre[e].omf), "+v"(pre[e].omo), "+v"(pre[e].omg2));
+        valid[e] = !a.lens || d.t < len[e];
+        inj[e] = d.inject == 3 || (d.inject == 1 && d.t == len[e] - 1) || (d.inject == 2 && d.t == 0);
+      }
+    };
+    f32x4_s acc[2][2];                                          // [unit half][even / odd K step of the quarter]
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) { acc[h2][0] = f32x4_s{0.f, 0.f, 0.f, 0.f}; acc[h2][1] = f32x4_s{0.f, 0.f, 0.f, 0.f}; }
+    if (d.dgates_next) {
+      u32x4 af[KQ];
+      if (t == 0) {
+        // a chain CONTINUED from an earlier launch: the previous step's dgates are in its plain [B][4H] buffer
+        const long rr = (m0 + n) < B ? (m0 + n) : B - 1;
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(d.dgates_next) + rr * d.ld_dgn + kg * 8;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) af[q] = *reinterpret_cast<const u32x4*>(src + (wave * KQ + q) * 32);
+      } else {
+        const unsigned want = tag0 + (unsigned)t;               // tag of the step processed just before
+        const unsigned long long t_start = wall_clock64();
+        {   // gate `wave` of that step, from every slice of the row group: S tags, contiguous
+          const unsigned* fp = reinterpret_cast<const unsigned*>(xg + FLAG_OFF) + ((t - 1) & 1) * NFLAG + wave * S;
+          while (alive) {
+            unsigned g = want;
+            if (lane < S) g = __hip_atomic_load(fp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(g == want)) break;
+            if (timed_out(t_start)) {
+              if (lane == 0) seq_fail(a.sync, 0x500u + (unsigned)t);
+              alive = false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        SEQ_TS(1);
+        const unsigned gbase = (unsigned)(((t - 1) & 1) * Cf::DSLOT + (long)(wave * KQ) * 1024 + lane * 16);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) af[q] = load16_sc1(xr, gbase + (unsigned)(q * 1024));
+      }
+      if (t + 1 < a.nsteps) fetch_in(load_desc_b(a.steps, (long)(t + 1) * ndir + k));
+      cell_pre();                                               // in the shadow of the sweep's latency
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+          acc[h2][q & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[q]), wreg[q][h2], acc[h2][q & 1], 0, 0, 0);
+    } else {
+      if (t + 1 < a.nsteps) fetch_in(load_desc_b(a.steps, (long)(t + 1) * ndir + k));
+      cell_pre();
+    }
+    SEQ_TS(2);
+    // ---- fold: this wave's quarter sums (even + odd accumulator, as lstm_step_bwd_fast) to LDS; the cells add the four in order
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * 2 + h2) * 4 + r) * 64 + lane] = acc[h2][0][r] + acc[h2][1][r];
+    SEQ_TS(3);
+    __syncthreads();
+    SEQ_TS(4);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float* rq = red + (uh * 4 + 2 * rp + e) * 64 + lane;
+      const float q0 = rq[0], q1 = rq[8 * 64], q2 = rq[16 * 64], q3 = rq[24 * 64];
+      float dh = (((0.f + q0) + q1) + q2) + q3;
+      if (dh0_step) {
+        if (rows[e] < B) d.dh0_out[(long)rows[e] * d.ld_dh0 + u] = dh;
+        continue;
+      }
+      // branch-free: a padded position computes on whatever it read and stores zeros
+      bf16_t* dt = dtile + (kg * 4 + 2 * rp + e) * DROW + uh * 16 + n;
+      float dc = dcc[e];
+      dh += dha[e];
+      const float dh_inj = dh + dhn[e], dc_inj = dc + dcn[e];
+      dh = inj[e] ? dh_inj : dh;
+      dc = inj[e] ? dc_inj : dc;
+      const LstmCellGrad gr = lstm_cell_bwd_post(pre[e], gi[e], gf[e], gg[e], go[e], cpv[e], dh, dc);
+      dt[0] = valid[e] ? f2bf(gr.di) : (bf16_t)0; dt[32] = valid[e] ? f2bf(gr.df) : (bf16_t)0;
+      dt[64] = valid[e] ? f2bf(gr.dg) : (bf16_t)0; dt[96] = valid[e] ? f2bf(gr.d_o) : (bf16_t)0;
+      dcc[e] = valid[e] ? gr.dc_prev : 0.f;
+    }
+    if (dh0_step) break;                                        // (uniform) nothing to publish
+    SEQ_TS(5);
+    __syncthreads();
+    SEQ_TS(6);
+    // ---- publish dgates_t: wave g stores gate g's block (lane = (8-unit piece o, row r): 1 KiB contiguous = k-step g*S + slice of the
+    //      consumers' order), flags it once the store is acknowledged; then the plain [B][4H] buffer for the kernels that follow
+    {
+      const unsigned tg = tag0 + (unsigned)t + 1u;
+      {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(dtile + (lane & 15) * DROW + wave * 32 + (lane >> 4) * 8);
+        const unsigned off = (unsigned)((t & 1) * Cf::DSLOT + (long)(wave * S + slice) * 1024 + lane * 16);
+        if (same_xcd) *reinterpret_cast<u32x4*>(xg + off) = v;   // stays in the group's L2
+        else store16_sc1(xr, off, v);                             // write-through: visible to every XCD
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's block has reached the L2 (or memory)
+      if (lane == 0) {
+        unsigned* fl = reinterpret_cast<unsigned*>(xg + FLAG_OFF) + (t & 1) * NFLAG + wave * S + slice;
+        if (same_xcd) *reinterpret_cast<volatile unsigned*>(fl) = tg;
+        else __hip_atomic_store(fl, tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      // plain copy: 16 rows x 4 gates x 64 bytes = 256 x 16 bytes
+      const int r = threadIdx.x >> 4, g = (threadIdx.x >> 2) & 3, o = threadIdx.x & 3;
+      if (m0 + r < B)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d.dgates_out) + ((long)(m0 + r)) * d.ld_dgo + (long)g * H + u0 + o * 8) =
+            *reinterpret_cast<const u32x4*>(dtile + r * DROW + g * 32 + o * 8);
+    }
+    if (t == a.nsteps - 1) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (rows[e] < B) d.dc_carry[(long)rows[e] * d.ld_dcc + u] = dcc[e];
+    }
+    SEQ_TS(7);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)total - 1) {
+      __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int g2 = 0; g2 < a.ndir * a.ngroups; ++g2) {
+        __hip_atomic_store(a.sync + 4 + 2 * g2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sync + 5 + 2 * g2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int H>
+static int launch_seq_bwd16(const SeqArgsB& a, hipStream_t st) {
+  constexpr int sm = SeqCfgB16<H>::LDS;
+  hipLaunchKernelGGL(lstm_seq_bwd16_kernel<H>, dim3(a.ngroups * (H / 32) * a.ndir), dim3(256), sm, st, a);
+  return check_launch();
+}
+
 static bool al16s(const void* p, long ld_elems) { return (((uintptr_t)p) & 15) == 0 && (ld_elems * 2) % 16 == 0; }
 
 }  // namespace vmmt
@@ -824,6 +1360,16 @@ extern "C" int vmmt_lstm_seq_fwd(int dtype, int ndir, int nsteps, const vmmt_lst
   a.steps = reinterpret_cast<const SeqDirF*>(dirs_dev); a.lens = (const long long*)lens; a.sync = sync;
   a.xchg = reinterpret_cast<unsigned long long*>(xchg);
   a.B = B; a.nsteps = nsteps; a.ndir = ndir; a.ngroups = ngroups;
+#ifndef VMMT_EXP_FWD32      // (probe build: the 32-row shape at every H, for same-box comparisons)
+  if (H >= 128 && H <= 512) {   // 16 sentences x 32 units per workgroup: never more workgroups, never more exchange bytes than the 32-row shape
+    a.ngroups = (B + 15) / 16;
+    switch (H) {
+      case 512: return launch_seq_fwd16<512>(a, (hipStream_t)stream);
+      case 256: return launch_seq_fwd16<256>(a, (hipStream_t)stream);
+      default: return launch_seq_fwd16<128>(a, (hipStream_t)stream);
+    }
+  }
+#endif
   switch (H) {
     case 1024: return launch_seq_fwd<1024>(a, (hipStream_t)stream);
     case 512: return launch_seq_fwd<512>(a, (hipStream_t)stream);
@@ -879,6 +1425,17 @@ extern "C" int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lst
   a.steps = reinterpret_cast<const SeqDirB*>(dirs_dev); a.lens = (const long long*)lens; a.sync = sync;
   a.xchg = reinterpret_cast<unsigned long long*>(xchg);
   a.B = B; a.nsteps = nsteps; a.ndir = ndir; a.ngroups = ngroups;
+#ifndef VMMT_EXP_BWD32      // (probe build: the 32-row shape at every H, for same-box comparisons)
+  if (H <= 512) {           // 16 sentences x 32 units per workgroup: never more workgroups, never more exchange bytes than the 32-row shape
+    a.ngroups = (B + 15) / 16;
+    switch (H) {
+      case 512: return launch_seq_bwd16<512>(a, (hipStream_t)stream);
+      case 256: return launch_seq_bwd16<256>(a, (hipStream_t)stream);
+      case 128: return launch_seq_bwd16<128>(a, (hipStream_t)stream);
+      default: return launch_seq_bwd16<64>(a, (hipStream_t)stream);
+    }
+  }
+#endif
   switch (H) {
     case 1024: return launch_seq_bwd<1024>(a, (hipStream_t)stream);
     case 512: return launch_seq_bwd<512>(a, (hipStream_t)stream);

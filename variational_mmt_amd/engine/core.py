@@ -126,6 +126,7 @@ class Engine(StepAPI):
         self._masked_streams = []
         import os as _os
         self.q_parallel = True    # q(z|x): scale branch on the side stream next to the location branch
+        self.dec_gx_first = True  # side stream of the forward: the decoder's input projection in front of the gradient zeroing / masks
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
         self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream

@@ -214,6 +214,8 @@ class Workspace(BackwardPlan, ConditionalPlans):
             e._sid = 2
             e._wait(P, "dec_gx")
             P.append((None, None, "BG_FLUSH2", None, 2))
+        elif e.dec_gx_first:
+            side_dec_gx()
         if training:
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             # ... together with the small accumulators of the backward plan (off the critical path instead of in front of
@@ -243,7 +245,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
         if early_head:
             e._record(P, "aux_fwd")
             e._sid = SIDE
-        else:
+        elif not e.dec_gx_first:
             side_dec_gx()
         if d.conditional:
             self._cond_forward_aux(P, training)
