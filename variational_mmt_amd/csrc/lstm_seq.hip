@@ -63,6 +63,7 @@ __device__ unsigned vmmt_seq_xcc[512];          // [block] = XCC id | transport 
 typedef __attribute__((address_space(3))) void lds_void_seq;
 typedef __attribute__((address_space(1))) const void glb_cvoid_seq;
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
+typedef float f32x2_s __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
@@ -84,6 +85,21 @@ __device__ __forceinline__ SeqDirF load_desc(const SeqDirF* steps, long idx) {
 #else
   return steps[idx];
 #endif
+}
+
+// What a step needs of the NEXT step's descriptor while it runs (the operands it prefetches), read with scalar loads at the TOP of
+// the step -- where their latency (a miss of the scalar cache: 0.3-0.5 us) hides behind the wait for the row group -- together with
+// one word of each of the descriptor's other cache lines, so that the full read one step later hits.
+struct SeqNextF { const void* h_prev; const float* gx; long ld_gx; const float* gx2; long ld_gx2; void* h_out; int t; };
+__device__ __forceinline__ SeqNextF load_next(const SeqDirF* steps, long idx) {
+  SeqNextF r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const SeqDirFConstPtr p = reinterpret_cast<SeqDirFConstPtr>(reinterpret_cast<uintptr_t>(steps)) + idx;
+#else
+  const SeqDirF* p = steps + idx;
+#endif
+  r.h_prev = p->h_prev; r.gx = p->gx; r.ld_gx = p->ld_gx; r.gx2 = p->gx2; r.ld_gx2 = p->ld_gx2; r.h_out = p->h_out; r.t = p->t;
+  return r;
 }
 
 __device__ __forceinline__ bool timed_out(unsigned long long t0) { return wall_clock64() - t0 > 200000000ull; }   // 2 s at 100 MHz
@@ -543,8 +559,11 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd16_kernel(SeqArgsF a) {
   }
   __syncthreads();                                              // the flag word is part of the fold buffer
 
-  float gxn[2][4];                                              // x W_ih^T + b of the cells' gates, NEXT step's (they do not depend on the recurrence)
-  auto fetch_gx = [&](const SeqDirF& dd) {
+  // x W_ih^T + b of the cells' gates (and the decoder's z W_z^T + b beside it), NEXT step's: they do not depend on the recurrence.  Requested
+  // behind the sweep; the two are only added where they are used (the add would wait for the loads), and the step descriptor they come
+  // from is read at the TOP of the step before -- a scalar load that misses its cache took 0.3-0.5 us between the sweep and the MFMAs
+  float gxn[2][4], gx2n[2][4];
+  auto fetch_gx = [&](const SeqNextF& dd) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int rr = rows[e] < B ? rows[e] : B - 1;
@@ -552,20 +571,25 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd16_kernel(SeqArgsF a) {
       gxn[e][0] = gx[0]; gxn[e][1] = gx[H]; gxn[e][2] = gx[2 * H]; gxn[e][3] = gx[3 * (long)H];
       if (dd.gx2) {
         const float* g2 = dd.gx2 + (long)rr * dd.ld_gx2 + u;
-        gxn[e][0] += g2[0]; gxn[e][1] += g2[H]; gxn[e][2] += g2[2 * H]; gxn[e][3] += g2[3 * (long)H];
+        gx2n[e][0] = g2[0]; gx2n[e][1] = g2[H]; gx2n[e][2] = g2[2 * H]; gx2n[e][3] = g2[3 * (long)H];
       }
     }
   };
-  fetch_gx(load_desc(a.steps, k));
+  SeqNextF dnext = load_next(a.steps, k);
+  fetch_gx(dnext);
 
   for (int t = 0; t < a.nsteps; ++t) {
     const SeqDirF d = load_desc(a.steps, (long)t * ndir + k);
+    if (t + 1 < a.nsteps) {
+      dnext = load_next(a.steps, (long)(t + 1) * ndir + k);
+      asm volatile("" :: "s"(dnext.h_prev), "s"(dnext.h_out), "s"(dnext.t));       // (the words that are only read for their cache lines)
+    }
     SEQ_TS(0);
     float gxv[2][4];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) gxv[e][g] = gxn[e][g];
+      for (int g = 0; g < 4; ++g) gxv[e][g] = d.gx2 ? gxn[e][g] + gx2n[e][g] : gxn[e][g];
       const int rr = rows[e] < B ? rows[e] : B - 1;
       if (t == 0) c_reg[e] = d.c_prev ? d.c_prev[(long)rr * d.ld_cprev + u] : 0.f;
     }
@@ -619,7 +643,7 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd16_kernel(SeqArgsF a) {
       }
     }
     SEQ_TS(2);
-    if (t + 1 < a.nsteps) fetch_gx(load_desc(a.steps, (long)(t + 1) * ndir + k));
+    if (t + 1 < a.nsteps) fetch_gx(dnext);
     f32x4_s acc[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { acc[g][0] = f32x4_s{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4_s{0.f, 0.f, 0.f, 0.f}; }
@@ -630,26 +654,28 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd16_kernel(SeqArgsF a) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
           acc[g][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[q]), wreg[q][g][h2], acc[g][h2], 0, 0, 0);
+    // (fold buffer: [quarter = wave][gate][unit half][lane] x f32x4 -- one 16-byte write per accumulator; a lane's two cells are rows
+    //  2*rp, 2*rp + 1 of its own lane slot: one 8-byte read per (gate, quarter))
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[(((wave * 4 + g) * 2 + h2) * 4 + r) * 64 + lane] = acc[g][h2][r];
+      for (int h2 = 0; h2 < 2; ++h2) reinterpret_cast<f32x4_s*>(red)[((wave * 4 + g) * 2 + h2) * 64 + lane] = acc[g][h2];
     SEQ_TS(3);
     __syncthreads();
     SEQ_TS(4);
     LstmCell cellv[2];
     bool valid[2];
+    float pq[2][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x2_s* rq = reinterpret_cast<const f32x2_s*>(red + (((g * 2 + uh) * 64 + lane) * 4 + 2 * rp));
+      const f32x2_s q0 = rq[0], q1 = rq[8 * 64 * 2], q2 = rq[16 * 64 * 2], q3 = rq[24 * 64 * 2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) pq[e][g] = (((0.f + q0[e]) + q1[e]) + q2[e]) + q3[e];      // lstm_step_fwd_fast's fold order
+    }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      float p[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float* rq = red + ((g * 2 + uh) * 4 + 2 * rp + e) * 64 + lane;
-        const float q0 = rq[0], q1 = rq[32 * 64], q2 = rq[64 * 64], q3 = rq[96 * 64];
-        p[g] = (((0.f + q0) + q1) + q2) + q3;                   // lstm_step_fwd_fast's fold order
-      }
+      const float* p = pq[e];
       cellv[e] = lstm_cell_math(p[0] + gxv[e][0], p[1] + gxv[e][1], p[2] + gxv[e][2], p[3] + gxv[e][3], c_reg[e]);
       const float cp = c_reg[e];
       valid[e] = !a.lens || d.t < len[e];
@@ -1168,10 +1194,12 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd16_kernel(SeqArgsB a) {
       nx[e][8] = dd.dh_n ? dd.dc_n[bb * dd.ld_dcn + u] : 0.f;
     }
   };
-  fetch_in(load_desc_b(a.steps, k));
+  SeqDirB dnext = load_desc_b(a.steps, k);                     // (the NEXT step's descriptor is read at the top of a step: see lstm_seq_fwd16_kernel)
+  fetch_in(dnext);
 
   for (int t = 0; t < a.nsteps + a.with_dh0; ++t) {
-    const SeqDirB d = load_desc_b(a.steps, (long)t * ndir + k);
+    const SeqDirB d = dnext;
+    if (t + 1 < a.nsteps + a.with_dh0) dnext = load_desc_b(a.steps, (long)(t + 1) * ndir + k);
     const bool dh0_step = t == a.nsteps;                        // the gradient of the initial hidden state: GEMM only
     SEQ_TS(0);
     float gi[2], gf[2], gg[2], go[2], cc[2], cpv[2], dha[2], dhn[2], dcn[2];
@@ -1227,7 +1255,7 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd16_kernel(SeqArgsB a) {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) af[q] = load16_sc1(xr, gbase + (unsigned)(q * 1024));
       }
-      if (t + 1 < a.nsteps) fetch_in(load_desc_b(a.steps, (long)(t + 1) * ndir + k));
+      if (t + 1 < a.nsteps) fetch_in(dnext);
       cell_pre();                                               // in the shadow of the sweep's latency
 #pragma unroll
       for (int q = 0; q < KQ; ++q)
@@ -1235,23 +1263,26 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd16_kernel(SeqArgsB a) {
         for (int h2 = 0; h2 < 2; ++h2)
           acc[h2][q & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[q]), wreg[q][h2], acc[h2][q & 1], 0, 0, 0);
     } else {
-      if (t + 1 < a.nsteps) fetch_in(load_desc_b(a.steps, (long)(t + 1) * ndir + k));
+      if (t + 1 < a.nsteps) fetch_in(dnext);
       cell_pre();
     }
     SEQ_TS(2);
     // ---- fold: this wave's quarter sums (even + odd accumulator, as lstm_step_bwd_fast) to LDS; the cells add the four in order
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
+    for (int h2 = 0; h2 < 2; ++h2) {        // [quarter = wave][unit half][lane] x f32x4: one 16-byte write each, one 8-byte read per quarter below
+      f32x4_s qs;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wave * 2 + h2) * 4 + r) * 64 + lane] = acc[h2][0][r] + acc[h2][1][r];
+      for (int r = 0; r < 4; ++r) qs[r] = acc[h2][0][r] + acc[h2][1][r];
+      reinterpret_cast<f32x4_s*>(red)[(wave * 2 + h2) * 64 + lane] = qs;
+    }
     SEQ_TS(3);
     __syncthreads();
     SEQ_TS(4);
+    const f32x2_s* rq2 = reinterpret_cast<const f32x2_s*>(red + ((uh * 64 + lane) * 4 + 2 * rp));
+    const f32x2_s fq0 = rq2[0], fq1 = rq2[2 * 64 * 2], fq2 = rq2[4 * 64 * 2], fq3 = rq2[6 * 64 * 2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const float* rq = red + (uh * 4 + 2 * rp + e) * 64 + lane;
-      const float q0 = rq[0], q1 = rq[8 * 64], q2 = rq[16 * 64], q3 = rq[24 * 64];
-      float dh = (((0.f + q0) + q1) + q2) + q3;
+      float dh = (((0.f + fq0[e]) + fq1[e]) + fq2[e]) + fq3[e];
       if (dh0_step) {
         if (rows[e] < B) d.dh0_out[(long)rows[e] * d.ld_dh0 + u] = dh;
         continue;
