@@ -159,15 +159,15 @@ int vmmt_lstm_chain_fwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_fwd
 int vmmt_lstm_chain_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* dirs, const int64_t* lens, int B, int H,
                         int mode, void* stream);
 
-/* a whole FORWARD recurrence in ONE LAUNCH (persistent kernel): every workgroup keeps its W_hh slice in LDS for the whole
- * sequence and the workgroups of a 32-sentence row group hand h_t to each other in-launch as tagged 8-byte granules
+/* a whole FORWARD recurrence in ONE LAUNCH (persistent kernel): every workgroup (16 sentences x 32 hidden units) keeps its W_hh slice in
+ * registers for the whole sequence and the workgroups of a 16-sentence row group hand h_t to each other in-launch as tagged 8-byte granules
  * ({two bf16 | tag}, one sc1 write-through store each; consumers re-read with sc1 loads until the tags match; bounded spins).
  * `dirs` = the nsteps x ndir step descriptors in HOST memory (validated here), `dirs_dev` = the same array in DEVICE memory
  * (read by the kernel); `sync` (vmmt_lstm_seq_sync_words() uint32: launch epoch, finish count, error code -- 0 = every wait
  * completed) and `xchg` (vmmt_lstm_seq_xchg_bytes() bytes, 16-byte aligned): device scratch private to the call site, zeroed
  * ONCE when allocated and then left alone.  Same semantics and BITS as vmmt_lstm_chain_fwd (H = 1024: the same numbers up to the
  * order of the f32 partial sums, <= 1 bf16 ulp), which this call falls back to when the persistent kernel does not apply (fp32, H not
- * in {64,128,256,512,1024}, more workgroups than CUs -- (B / 32) (H / 16) ndir > 256: cut the batch into row chunks --, unaligned rows, steps not
+ * in {64,128,256,512,1024}, more workgroups than CUs -- (B / 16) (H / 32) ndir > 256: cut the batch into row chunks --, unaligned rows, steps not
  * chained h_prev[t] == h_out[t-1] / c_prev[t] == c_out[t-1]). */
 /* words VMMT_SEQ_GUARD_WORD, +1 of `sync` (8-byte aligned): an optional device pointer to a uint32 GUARD word of the caller, written
  * by the host once after the scratch is zeroed (0 = none).  A launch whose bounded wait runs out stores its error code there as well:

@@ -39,9 +39,9 @@ def test_no_kernel_spills(res):
 def test_gemms_fit_beside_the_persistent_recurrences(res):
     g = "gemm_kernelItLi128ELi128ELi64ELi64E"        # bf16, 128 x 128 tiles, LDS-DMA loop (the trailing ...Li1E)
     nt, tn, nn = (_find(res, g + lay + "ELi64ELb1ELi1ELi0E") for lay in ("Lb1ELb1", "Lb0ELb0", "Lb1ELb0"))        # (...Li0E: the plain epilogue)
-    # (H <= 512: the 16-row shapes, lstm_seq_fwd16_kernel / lstm_seq_bwd16_kernel, their W_hh fragments in registers)
-    fwd512, bwd512 = _find(res, "lstm_seq_fwd16_kernelILi512E"), _find(res, "lstm_seq_bwd16_kernelILi512E")
-    fwd256, bwd256 = _find(res, "lstm_seq_fwd16_kernelILi256E"), _find(res, "lstm_seq_bwd16_kernelILi256E")
+    # (16 sentences x 32 units per workgroup, the W_hh fragments in registers)
+    fwd512, bwd512 = _find(res, "lstm_seq_fwd_kernelILi512E"), _find(res, "lstm_seq_bwd_kernelILi512E")
+    fwd256, bwd256 = _find(res, "lstm_seq_fwd_kernelILi256E"), _find(res, "lstm_seq_bwd_kernelILi256E")
     # forward: the decoder's recurrence (H = 512) runs beside NT products (image network, target-side input projection)
     assert fwd512 + nt <= 512, (fwd512, nt)
     # backward at H = 512: the recurrence holds its SIMDs ALONE, by measurement (LABNOTES round 5: with a quarter / three eighths / half of
@@ -56,7 +56,7 @@ def test_gemms_fit_beside_the_persistent_recurrences(res):
 
 
 def test_one_wave_per_simd_kernels_stay_within_the_file(res):
-    for name in ("gen2_kernelILi512ELb1E", "gen2w_kernelILb1E", "lstm_seq_fwd_kernelILi1024E", "lstm_seq_bwd_kernelILi1024E", "lstm_seq_bwd16_kernelILi512E"):
+    for name in ("gen2_kernelILi512ELb1E", "gen2w_kernelILb1E", "lstm_seq_fwd_kernelILi1024E", "lstm_seq_bwd_kernelILi1024E"):
         assert _find(res, name) <= 512, name
 
 

@@ -586,17 +586,17 @@ class Engine(StepAPI):
               ("dc_carry", "ld_dcc", 4), ("dgates_out", "ld_dgo", None), ("dh_n", "ld_dhn", 4), ("dc_n", "ld_dcn", 4), ("dh0_out", "ld_dh0", 4))
 
     def _seq_row_chunks(self, arr, fields, ndir, B, H):
-        """A persistent recurrence needs all of its workgroups resident at once: (B / 32 row groups) x (H / 16 unit slices) x directions
+        """A persistent recurrence needs all of its workgroups resident at once: (B / 16 row groups) x (H / 32 unit slices) x directions
         <= 256.  Sentences are independent in a recurrence, so a batch that does not fit is cut into ROW chunks, one persistent launch
-        each, one after the other (BASELINE config 5: H = 1024 -> 64 slices -> 128 sentences per launch; the per-step kernels it
+        each, one after the other (BASELINE config 5: H = 1024 -> 32 slices -> 128 sentences per launch; the per-step kernels it
         replaces re-read their W_hh slice from L2 at every step: 35 us per backward step against 8).  -> [(descriptors, row offset,
         rows)], or None when the persistent kernel does not serve this size at all."""
         if H not in (64, 128, 256, 512, 1024):
             return None
-        groups = 256 // ((H // 16) * ndir)
+        groups = 256 // ((H // 32) * ndir)
         if groups < 1:
             return None
-        rows = 32 * groups
+        rows = 16 * groups
         if B <= rows:
             return [(arr, 0, B)]
         out = []
@@ -614,7 +614,7 @@ class Engine(StepAPI):
 
     def _lstm_seq_fwd(self, plan, arr, ndir, nsteps, lens_ptr, B, H):
         """plan entry: a whole forward recurrence (nsteps x ndir step descriptors in `arr`).  persistent_lstm: ONE launch of the
-        persistent kernel (W_hh resident in LDS, in-launch hand-off of h_t: csrc/lstm_seq.hip), which falls back by itself to the
+        persistent kernel (W_hh resident in registers, in-launch hand-off of h_t: csrc/lstm_seq.hip), which falls back by itself to the
         per-step kernels where it does not apply; otherwise the per-step kernels issued from one host call."""
         chunks = self._seq_row_chunks(arr, self._SEQ_F, ndir, B, H) if (self.persistent_lstm and self.dt == L.BF16) else None
         if chunks is not None and len(chunks) > 1:
