@@ -116,7 +116,10 @@ __device__ __forceinline__ bool timed_out(unsigned long long t0) { return wall_c
 // produced garbage is skipped on the device, long before the host learns of it (Engine._seq_timeout_fallback)
 __device__ __forceinline__ void seq_fail(unsigned* sync, unsigned code) {
   __hip_atomic_store(sync + 2, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned* guard = *reinterpret_cast<unsigned* const*>(sync + VMMT_SEQ_GUARD_WORD);
+  // (a GLOBAL store, spelled out: through the generic pointer it is a FLAT instruction, and a flat access that may be pending on some path
+  //  into a block makes the compiler wait with vmcnt(0) there instead of counting -- the sweeps' waits sit behind such paths)
+  typedef __attribute__((address_space(1))) unsigned glb_u32_seq;
+  glb_u32_seq* guard = (glb_u32_seq*)*reinterpret_cast<unsigned* const*>(sync + VMMT_SEQ_GUARD_WORD);
   if (guard) __hip_atomic_store(guard, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
   const int arow = min(m0 + n, B - 1);                          // the h_{t-1} row this lane's A fragments come from (step 0)
   __syncthreads();
   {
-    const int f = *reinterpret_cast<volatile int*>(lds);
+    const int f = *reinterpret_cast<const int*>(lds);              // (not through a volatile generic pointer: that is a FLAT load, see seq_fail)
     same_xcd = f == 1;
     alive = f >= 0;
   }
@@ -232,16 +235,20 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
   // behind the sweep; the two are only added where they are used (the add would wait for the loads), and the step descriptor they come
   // from is read at the TOP of the step before -- a scalar load that misses its cache took 0.3-0.5 us between the sweep and the MFMAs
   float gxn[2][4], gx2n[2][4];
+  // (buffer loads: a scalar base per operand, one 32-bit offset per cell, the gate as scalar offset; branch-free -- without a second
+  //  addend the first is read twice -- so that the compiler can count these loads out of the wait for the sweep's)
   auto fetch_gx = [&](const SeqNextF& dd) {
+    const bool two = dd.gx2 != nullptr;
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(dd.gx), g2r = make_rsrc(two ? dd.gx2 : dd.gx);
+    const int ld1 = (int)dd.ld_gx, ld2 = two ? (int)dd.ld_gx2 : ld1;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int rr = rows[e] < B ? rows[e] : B - 1;
-      const float* gx = dd.gx + (long)rr * dd.ld_gx + u;
-      gxn[e][0] = gx[0]; gxn[e][1] = gx[H]; gxn[e][2] = gx[2 * H]; gxn[e][3] = gx[3 * (long)H];
-      if (dd.gx2) {
-        const float* g2 = dd.gx2 + (long)rr * dd.ld_gx2 + u;
-        gx2n[e][0] = g2[0]; gx2n[e][1] = g2[H]; gx2n[e][2] = g2[2 * H]; gx2n[e][3] = g2[3 * (long)H];
-      }
+      const int off = (rr * ld1 + u) * 4, off2 = (rr * ld2 + u) * 4;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gxn[e][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off, g * H * 4, 0));
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gx2n[e][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g2r, off2, g * H * 4, 0));
     }
   };
   SeqNextF dnext = load_next(a.steps, k);
@@ -264,6 +271,7 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
     }
     // ---- A fragments of h_{t-1}: 16 rows x this wave's K quarter (KQ k-steps of 32 units)
     u32x4 af[KQ];
+    bool gx_fetched = false;
     if (t == 0) {                                               // the initial state: an ordinary [B][ld] bf16 buffer of an earlier kernel
       const __amdgpu_buffer_rsrc_t hr = make_rsrc(d.h_prev);
       const unsigned abase = (unsigned)(((long)arow * d.ld_hprev + kg * 8) * 2);
@@ -290,8 +298,8 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
         }
       }
       SEQ_TS(1);
-      for (;;) {
-        u32x4 lo[KQ], hi[KQ];
+      u32x4 lo[KQ], hi[KQ];
+      auto sweep = [&]() {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           if (has_k(q)) {
@@ -301,23 +309,36 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
             lo[q] = hi[q] = u32x4{0u, want, 0u, want};
           }
         }
+      };
+      auto complete = [&]() {
         bool ok = true;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           ok = ok && lo[q][1] == want && lo[q][3] == want && hi[q][1] == want && hi[q][3] == want;
           af[q] = u32x4{lo[q][0], lo[q][2], hi[q][0], hi[q][2]};
         }
-        if (__all(ok) || !alive) break;
+        return __all(ok);
+      };
+      // first attempt (behind the cheap poll it nearly always succeeds), straight-line: the next step's gate operands are requested
+      // behind the sweep's loads -- which return first: the compiler counts these 16 out of the wait for the tags -- and in their shadow
+      // (issued behind the completed sweep they cost the step 0.4 us of address arithmetic and issue)
+      sweep();
+      fetch_gx(dnext);                                          // (last step: the last descriptor's once more, unused)
+      gx_fetched = true;
+      bool done = complete();
+      while (!done && alive) {
         if (timed_out(t_start)) {
           if (lane == 0) seq_fail(a.sync, 0x100u + (unsigned)t);
           alive = false;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
+        sweep();
+        done = complete();
       }
     }
     SEQ_TS(2);
-    if (t + 1 < a.nsteps) fetch_gx(dnext);
+    if (!gx_fetched) fetch_gx(dnext);                           // (step 0)
     f32x4_s acc[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) { acc[g][0] = f32x4_s{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4_s{0.f, 0.f, 0.f, 0.f}; }
@@ -444,6 +465,23 @@ __device__ __forceinline__ SeqDirB load_desc_b(const SeqDirB* steps, long idx) {
   return steps[idx];
 #endif
 }
+// (what a step prefetches of the NEXT cell step, and one word of each of that descriptor's other cache lines: see SeqNextF)
+struct SeqNextB {
+  const void* dgates_next; const void* dh_above; long ld_dha; const void* gates; long ld_gates; const float* c_t; long ld_ct;
+  const float* c_prev; long ld_cp; void* dgates_out; const float* dh_n; long ld_dhn; const float* dc_n; long ld_dcn; int t;
+};
+__device__ __forceinline__ SeqNextB load_next_b(const SeqDirB* steps, long idx) {
+  SeqNextB r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const SeqDirBConstPtr p = reinterpret_cast<SeqDirBConstPtr>(reinterpret_cast<uintptr_t>(steps)) + idx;
+#else
+  const SeqDirB* p = steps + idx;
+#endif
+  r.dgates_next = p->dgates_next; r.dh_above = p->dh_above; r.ld_dha = p->ld_dha; r.gates = p->gates; r.ld_gates = p->ld_gates;
+  r.c_t = p->c_t; r.ld_ct = p->ld_ct; r.c_prev = p->c_prev; r.ld_cp = p->ld_cp; r.dgates_out = p->dgates_out;
+  r.dh_n = p->dh_n; r.ld_dhn = p->ld_dhn; r.dc_n = p->dc_n; r.ld_dcn = p->ld_dcn; r.t = p->t;
+  return r;
+}
 struct SeqArgsB {
   const SeqDirB* steps;
   const long long* lens;
@@ -549,39 +587,60 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
   }
   __syncthreads();
   {
-    const int f = *reinterpret_cast<volatile int*>(lds);
+    const int f = *reinterpret_cast<const int*>(lds);              // (not through a volatile generic pointer: that is a FLAT load, see seq_fail)
     same_xcd = f == 1;
     alive = f >= 0;
   }
   __syncthreads();                                              // the flag word is part of the fold buffer
 
-  float nx[2][9];                                               // the cell backward's inputs of the NEXT step (they do not depend on the recurrence)
-  auto fetch_in = [&](const SeqDirB& dd) {
+  // the cell backward's inputs of the NEXT step (they do not depend on the recurrence), requested behind the sweep's loads.  RAW: a
+  // conversion here would wait for its load here; branch-free: an operand the step does not have is read from one it has and dropped
+  // where it is used -- both so that the compiler can count these 18 loads out of the wait for the sweep; buffer loads: a scalar base per
+  // operand, one 32-bit offset per cell
+  unsigned short nxg[2][4], nxa[2];
+  float nxf[2][4];
+  auto fetch_in = [&](const SeqNextB& dd) {
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(dd.gates), rc = make_rsrc(dd.c_t), rp_ = make_rsrc(dd.c_prev ? dd.c_prev : dd.c_t),
+                                 ra = make_rsrc(dd.dh_above ? dd.dh_above : dd.gates), rh = make_rsrc(dd.dh_n ? dd.dh_n : dd.c_t),
+                                 rn = make_rsrc(dd.dh_n ? dd.dc_n : dd.c_t);
+    const int ldp = dd.c_prev ? (int)dd.ld_cp : (int)dd.ld_ct, lda = dd.dh_above ? (int)dd.ld_dha : (int)dd.ld_gates,
+              ldh = dd.dh_n ? (int)dd.ld_dhn : (int)dd.ld_ct, ldn = dd.dh_n ? (int)dd.ld_dcn : (int)dd.ld_ct;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const long bb = rows[e] < B ? rows[e] : B - 1;
-      const bf16_t* gs = reinterpret_cast<const bf16_t*>(dd.gates) + bb * dd.ld_gates + u;
-      nx[e][0] = bf2f(gs[0]); nx[e][1] = bf2f(gs[H]); nx[e][2] = bf2f(gs[2 * H]); nx[e][3] = bf2f(gs[3 * (long)H]);
-      nx[e][4] = dd.c_t[bb * dd.ld_ct + u];
-      nx[e][5] = dd.c_prev ? dd.c_prev[bb * dd.ld_cp + u] : 0.f;
-      nx[e][6] = dd.dh_above ? bf2f(reinterpret_cast<const bf16_t*>(dd.dh_above)[bb * dd.ld_dha + u]) : 0.f;
-      nx[e][7] = dd.dh_n ? dd.dh_n[bb * dd.ld_dhn + u] : 0.f;
-      nx[e][8] = dd.dh_n ? dd.dc_n[bb * dd.ld_dcn + u] : 0.f;
+      const int bb = rows[e] < B ? rows[e] : B - 1;
+      const int og = (bb * (int)dd.ld_gates + u) * 2;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) nxg[e][g] = __builtin_amdgcn_raw_buffer_load_b16(rg, og, g * H * 2, 0);
+      nxf[e][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (bb * (int)dd.ld_ct + u) * 4, 0, 0));
+      nxf[e][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp_, (bb * ldp + u) * 4, 0, 0));
+      nxa[e] = __builtin_amdgcn_raw_buffer_load_b16(ra, (bb * lda + u) * 2, 0, 0);
+      nxf[e][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (bb * ldh + u) * 4, 0, 0));
+      nxf[e][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rn, (bb * ldn + u) * 4, 0, 0));
     }
   };
-  SeqDirB dnext = load_desc_b(a.steps, k);                     // (the NEXT step's descriptor is read at the top of a step: see lstm_seq_fwd_kernel)
+  SeqNextB dnext = load_next_b(a.steps, k);
   fetch_in(dnext);
 
   for (int t = 0; t < a.nsteps + a.with_dh0; ++t) {
-    const SeqDirB d = dnext;
-    if (t + 1 < a.nsteps + a.with_dh0) dnext = load_desc_b(a.steps, (long)(t + 1) * ndir + k);
+    const SeqDirB d = load_desc_b(a.steps, (long)t * ndir + k);
+    // the next CELL step's operands (the last cell step and the dh0 step fetch the last cell step's once more, unused: the prefetch below
+    // is issued without a branch); read here, where a miss of the scalar cache hides behind the wait for the row group
+    dnext = load_next_b(a.steps, (long)(t + 1 < a.nsteps ? t + 1 : a.nsteps - 1) * ndir + k);
+    asm volatile("" :: "s"(dnext.dgates_next), "s"(dnext.dgates_out), "s"(dnext.t));       // (the words that are only read for their cache lines)
     const bool dh0_step = t == a.nsteps;                        // the gradient of the initial hidden state: GEMM only
     SEQ_TS(0);
+    // this step's operands out of last step's prefetch, HERE (the top of the step, where nothing younger than them is in flight): left to
+    // the compiler the copies sink to just in front of the next prefetch, behind the sweep's loads, and wait for those
     float gi[2], gf[2], gg[2], go[2], cc[2], cpv[2], dha[2], dhn[2], dcn[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      gi[e] = nx[e][0]; gf[e] = nx[e][1]; gg[e] = nx[e][2]; go[e] = nx[e][3]; cc[e] = nx[e][4]; cpv[e] = nx[e][5];
-      dha[e] = nx[e][6]; dhn[e] = nx[e][7]; dcn[e] = nx[e][8];
+      gi[e] = bf2f(nxg[e][0]); gf[e] = bf2f(nxg[e][1]); gg[e] = bf2f(nxg[e][2]); go[e] = bf2f(nxg[e][3]);
+      cc[e] = nxf[e][0];
+      cpv[e] = d.c_prev ? nxf[e][1] : 0.f;
+      dha[e] = d.dh_above ? bf2f(nxa[e]) : 0.f;
+      dhn[e] = d.dh_n ? nxf[e][2] : 0.f;
+      dcn[e] = d.dh_n ? nxf[e][3] : 0.f;
+      asm volatile("" : "+v"(gi[e]), "+v"(gf[e]), "+v"(gg[e]), "+v"(go[e]), "+v"(cc[e]), "+v"(cpv[e]), "+v"(dha[e]), "+v"(dhn[e]), "+v"(dcn[e]));
       const long bb = rows[e] < B ? rows[e] : B - 1;
       if (t == 0) dcc[e] = d.dc_carry[bb * d.ld_dcc + u];
     }
@@ -630,7 +689,7 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) af[q] = load16_sc1(xr, gbase + (unsigned)(q * 1024));
       }
-      if (t + 1 < a.nsteps) fetch_in(dnext);
+      fetch_in(dnext);
       cell_pre();                                               // in the shadow of the sweep's latency
 #pragma unroll
       for (int q = 0; q < KQ; ++q)
@@ -638,7 +697,7 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
         for (int h2 = 0; h2 < 2; ++h2)
           acc[h2][q & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[q]), wreg[q][h2], acc[h2][q & 1], 0, 0, 0);
     } else {
-      if (t + 1 < a.nsteps) fetch_in(dnext);
+      fetch_in(dnext);
       cell_pre();
     }
     SEQ_TS(2);
@@ -689,9 +748,10 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
         else store16_sc1(xr, off, v);                             // write-through: visible to every XCD
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's block has reached the L2 (or memory)
-      if (lane == 0) {
-        unsigned* fl = reinterpret_cast<unsigned*>(xg + FLAG_OFF) + (t & 1) * NFLAG + wave * S + slice;
-        if (same_xcd) *reinterpret_cast<volatile unsigned*>(fl) = tg;
+      if (lane == 0) {              // (global stores, spelled out: see seq_fail)
+        typedef __attribute__((address_space(1))) unsigned glb_u32_seq;
+        glb_u32_seq* fl = (glb_u32_seq*)(reinterpret_cast<unsigned*>(xg + FLAG_OFF) + (t & 1) * NFLAG + wave * S + slice);
+        if (same_xcd) __hip_atomic_store(fl, tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_store(fl, tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       // plain copy: 16 rows x 4 gates x 64 bytes = 256 x 16 bytes
