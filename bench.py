@@ -773,7 +773,7 @@ def main():
             "config": {"workload": (cf["name"] % B) + ", dropout %.1f, Adam%s%s" % (a.dropout, ", --conditional prior" if a.conditional else "",
                                                                                     ", lengths U[10,20]" if a.lengths == "ragged" else ""),
                        "global_batch": Bg, "parallelism": "dp%d" % world, "image_rows": n_img},
-            "roofline": {"bound": "mfma", "kernel": (("gen2w_kernel" if d.hid > 512 else "gen2p_kernel" if d.hid == 512 else "gen2_kernel") + " (fused vocabulary sweep: logits + softmax statistics + dO, softmax weights stored for the dWg GEMM)" if fused else
+            "roofline": {"bound": "mfma", "kernel": (("gen2w_kernel" if d.hid > 512 else "gen2p_kernel" if d.hid > 256 else "gen2_kernel") + " (fused vocabulary sweep: logits + softmax statistics + dO, softmax weights stored for the dWg GEMM)" if fused else
                                     "gen_kernel (vocab projection + log-softmax/NLL pass, slower of fwd/bwd)"),
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
