@@ -46,10 +46,10 @@ __device__ __forceinline__ void cell_fwd(const StepDirF& d, const long long* len
     const float* g2 = d.gx2 + (long)b * d.ld_gx2 + u;
     pi += g2[0]; pf += g2[H]; pg += g2[2 * H]; po += g2[3 * (long)H];
   }
-  float i = sigmoidf_(pi), f = sigmoidf_(pf), g = tanhf_(pg), o = sigmoidf_(po);
+  float i = cell_sigmoid_(pi), f = cell_sigmoid_(pf), g = cell_tanh_(pg), o = cell_sigmoid_(po);
   float cp = d.c_prev ? d.c_prev[(long)b * d.ld_cprev + u] : 0.f;
   float c = f * cp + i * g;
-  float h = o * tanhf_(c);
+  float h = o * cell_tanh_(c);
   bool valid = true;
   long long len = 0;
   if (lens) { len = lens[b]; valid = d.t < len; }
@@ -139,7 +139,7 @@ __device__ __forceinline__ void cell_bwd(const StepDirB& d, const long long* len
   float i = to_f<T>(gs[0]), f = to_f<T>(gs[H]), g = to_f<T>(gs[2 * H]), o = to_f<T>(gs[3 * (long)H]);
   float c = d.c_t[(long)b * d.ld_ct + u];
   float cp = d.c_prev ? d.c_prev[(long)b * d.ld_cp + u] : 0.f;
-  float tc = tanhf_(c);
+  float tc = cell_tanh_(c);
   float d_o = dh * tc;
   dc += dh * o * (1.f - tc * tc);
   float d_i = dc * g, d_f = dc * cp, d_g = dc * i;
