@@ -128,6 +128,7 @@ class Engine(StepAPI):
         self.q_parallel = True    # q(z|x): scale branch on the side stream next to the location branch
         self.dec_gx_first = True  # side stream of the forward: the decoder's input projection in front of the gradient zeroing / masks
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
+        self.trace_only = None       # ... of these entry names only (every event costs the stream ~10 us: tools/phase_times.py COARSE=1)
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
         self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
         # the side-stream half of Adam held back until the NEXT forward's head (source gather + the encoder's first input projection) is
@@ -823,7 +824,7 @@ class Engine(StepAPI):
             return
         for entry in plan:
             fn, args, name, _keep, sid = entry
-            if trace is not None and sid == 0 and name != last:     # tools/phase_times.py: timing events at phase changes
+            if trace is not None and sid == 0 and name != last and (self.trace_only is None or name in self.trace_only):     # tools/phase_times.py: timing events at phase changes
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(main)
                 trace.append((name, ev))
