@@ -1,4 +1,4 @@
-"""GPU: the persistent recurrence kernel (csrc/lstm_seq.hip: one launch per sequence, W_hh resident in LDS, in-launch hand-off of
+"""GPU: the persistent recurrence kernel (csrc/lstm_seq.hip: one launch per sequence, W_hh resident in registers, in-launch hand-off of
 h_t between the workgroups of a row group) against the per-step kernels it replaces -- BIT-identical outputs (same MFMA chains,
 same fold order, same cell arithmetic), at the benchmark shape, with ragged lengths, both directions, several row groups, and
 repeated launches on the same buffers (stale-line hazards show up as mismatches on a re-run)."""
@@ -21,6 +21,8 @@ def _engine(c, p, persistent, dropout=0.0):
 @pytest.mark.parametrize("hid,layers,brnn,B,S,T,cond", [(512, 1, True, 256, 20, 21, False), (256, 2, True, 70, 9, 12, False),
                                                         (128, 1, False, 33, 7, 8, False), (512, 2, False, 40, 6, 7, False),
                                                         (128, 1, True, 24, 6, 9, True),
+                                                        # H = 64: two k-steps for the four waves' K quarters (two of them stay empty)
+                                                        (64, 1, False, 35, 6, 7, False),
                                                         # H = 1024 (BASELINE config 5's decoder; its encoder: 2 x 512): 64 unit slices per row
                                                         # group, so 200 sentences run as two persistent launches of <= 128 rows
                                                         (1024, 2, True, 200, 7, 6, False), (1024, 1, False, 40, 5, 6, False)])
