@@ -50,6 +50,11 @@ def test_gemms_fit_beside_the_persistent_recurrences(res):
     assert bwd512 <= 512, bwd512
     # the encoder's directions (H = 256) DO host every product (made exclusive by an LDS pad, the step lost 65 us)
     assert max(fwd256, bwd256) + max(tn, nn, nt) <= 512, (fwd256, bwd256, tn, nn, nt)
+    # --conditional: encoder_tgt's recurrences (2 x 256, a stream of their own, ~1 ms each way) are still running when the decoder's start.  Two
+    # persistent launches that cannot share a SIMD place their workgroups around each other -- the later one spins until the earlier one is
+    # through (+60 us on the decoder's backward, profiles timeline) and, launched at the same moment, two partially placed grids could wait
+    # for each other until the hand-off bound: they must fit one register file together
+    assert bwd512 + bwd256 <= 512 and fwd512 + fwd256 <= 512 and 2 * max(fwd256, bwd256) <= 512, (fwd512, fwd256, bwd512, bwd256)
     # the grouped weight-gradient launch (vmmt_gemm_group) is a guest of the backward recurrences like the products it replaces
     grp = _find(res, "gemm_group_kernelItLi128ELi128ELi64ELi64ELb0ELb0")
     assert bwd256 + grp <= 512 and grp <= tn, (bwd256, grp, tn)

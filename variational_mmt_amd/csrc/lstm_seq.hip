@@ -213,13 +213,13 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
     }
   }
   int rows[2];
-  long long len[2];
+  int len[2];                                                   // (sentence lengths fit 31 bits; two registers less than long long)
   float c_reg[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     rows[e] = m0 + kg * 4 + 2 * rp + e;
     const int rr = rows[e] < B ? rows[e] : B - 1;
-    len[e] = a.lens ? a.lens[rr] : 0;
+    len[e] = a.lens ? (int)a.lens[rr] : 0;
     c_reg[e] = 0.f;
   }
   const int arow = min(m0 + n, B - 1);                          // the h_{t-1} row this lane's A fragments come from (step 0)
@@ -576,13 +576,13 @@ __global__ void __launch_bounds__(256) lstm_seq_bwd_kernel(SeqArgsB a) {
         wreg[q][h2] = *reinterpret_cast<const bf16x8*>(wp + (long)(u0 + h2 * 16 + n) * d0.ld_wt + (wave * KQ + q) * 32 + kg * 8);
   }
   int rows[2];
-  long long len[2];
+  int len[2];                                                   // (sentence lengths fit 31 bits; two registers less than long long)
   float dcc[2];                                                 // dL/dc flowing to the previous step: in registers for the whole sequence
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     rows[e] = m0 + kg * 4 + 2 * rp + e;
     const int rr = rows[e] < B ? rows[e] : B - 1;
-    len[e] = a.lens ? a.lens[rr] : 0;
+    len[e] = a.lens ? (int)a.lens[rr] : 0;
     dcc[e] = 0.f;
   }
   __syncthreads();
