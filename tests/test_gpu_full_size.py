@@ -537,7 +537,9 @@ def test_cfg4_table_290k():
     e_small, ws_small, s_small = run(rows.clone(), torch.arange(B))
     assert torch.equal(ws_small.img.view()[:B, :2048], rows)
     for k in ("nmt", "td_kl_before", "elbo", "img_feats_loss"):
-        assert abs(s_big[k] - s_small[k]) <= 5e-6 * abs(s_small[k]), (k, s_big[k], s_small[k])        # (f32 atomics in the statistics: 256 adds in arrival order)
+        # (f32 atomics in the statistics: 256 adds in ARRIVAL order, which differs between two runs of the same step -- up to ~256 x 6e-8 relative;
+        #  5e-6 held in hundreds of runs and failed once, behind other tests in one process)
+        assert abs(s_big[k] - s_small[k]) <= 2e-5 * abs(s_small[k]), (k, s_big[k], s_small[k])
     assert abs(s_big["img_feats_cos"] - s_small["img_feats_cos"]) <= 1e-7                           # (a mean of cancelling terms ~ 5e-4)
     assert s_big["n_words"] == s_small["n_words"] and s_big["n_correct"] == s_small["n_correct"]
     a, b = e_big.flat_g[:e_big.n_opt].double(), e_small.flat_g[:e_small.n_opt].double()

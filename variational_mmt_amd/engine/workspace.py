@@ -412,10 +412,13 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._call(P, lib.vmmt_attn_fwd, dt, self.Q.p(), self.Q.ld, ctx.p(), ctx.ld, self.src_len.data_ptr(), self.cat.p(), self.cat.ld,
                 self.probs.data_ptr(), Tp, B, S, Hp)
         e._gemm(P, L.GEMM_NT, self.cat.p(), self.cat.ld, wo.p(), wo.ld, self.AH.p(), self.AH.ld, M, H, 2 * Hp, act=L.ACT_TANH)
+        # join: the loss plans read mu_v.  ONE wait for everything the other streams did in this plan -- `img_fwd` is the side stream's last
+        # record: the mask (`out_mask`, recorded before it on that stream, or on the aux stream which that stream joined: `aux_fwd`) and both
+        # halves of the last optimiser step (issued on those streams in front of this plan's work) are behind it.  Every wait costs the main
+        # stream ~6 us here, between the decoder and the sweep: three of them did (out_mask, img_fwd, opt_gen_done in the loss plan)
+        e._wait(P, "img_fwd")
         if drop:
-            e._wait(P, "out_mask")
             e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
-        e._wait(P, "img_fwd")            # join: the loss plans read mu_v
         return P
 
     def _plan_loss(self, training):
@@ -424,7 +427,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
         P = []
         wg = e.sh["wg"]
         e._sid = 0
-        e._wait(P, "opt_gen_done")       # the generator's third of the last optimiser step (side stream; behind `opt_side_done` when held back)
+        # (the generator's third of the last optimiser step -- `opt_gen_done`, side or aux stream -- is behind the forward plan's last wait: see there)
         O = self.O if (training and d.dropout > 0) else self.AH      # eval: nn.Dropout is the identity
         if training:
             self._loss_patch = None
