@@ -95,12 +95,6 @@ typedef struct vmmt_gemm_args {
                   column sums (colsum_out / colsum_out2) follow the same map */
   int c_col_blk, c_col_valid; /* the same for the N output columns (e.g. dW_out [H][2H] of GlobalAttention.py:187 from a [c ; r]
                   buffer whose halves are padded) */
-  const int64_t* a_row_ids; /* != NULL (layout NT, bf16, the 128 x 128 LDS-DMA configuration: K % 64 == 0, lda % 4 == 0; VMMT_EINVAL otherwise):
-                  row m of the A operand is row a_row_ids[m] of the TABLE at A (lda = the table's row stride) -- the embedding lookup
-                  (modules/Embeddings.py:169-188) as the A-operand fetch of the LSTM's input projection (Models.py:124-129): the product's
-                  LDS staging reads the table rows by token id, no [tokens x E] copy is written or read.  Every id must be a row of the
-                  table; a row stride that is not a multiple of 8 elements is fine (the LDS-DMA takes any 4-byte aligned source), the
-                  K - lda columns read beyond a row's end must be finite and meet zero columns of B */
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
 int vmmt_gemm_colsum_applies(const vmmt_gemm_args* args);
@@ -461,12 +455,6 @@ int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, void* stream
 int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16,
                    const int32_t* skip, void* stream);
-/* vmmt_adam_step over a [R x C] table (C % 4 == 0) whose bf16 shadow has PADDED rows (row stride ld_shadow >= C elements; the padding is never
- * written): the embedding table's compute copy -- the A operand that the LSTM's input projection fetches by token id (vmmt_gemm_args.a_row_ids;
- * modules/Embeddings.py:169-188 -> Models.py:124-129) -- written by the update itself (Optim.py:94-96) instead of by a pass of its own */
-int vmmt_adam_step_table(float* p, const float* g, float* m, float* v, int R, int C, float lr, float beta1, float beta2, float eps, int step,
-                         float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16, int64_t ld_shadow,
-                         const int32_t* skip, void* stream);
 
 /* Data parallelism with the optimiser state sharded over the ranks (one process per GPU; the reference has no multi-GPU path,
  * train_mm_vi_model1.py:73-75 -- the norm reproduced is clip_grad_norm's over ALL gradients of the global batch, Optim.py:94-95):

@@ -77,8 +77,7 @@ __device__ __forceinline__ void adam_elem(float& p, float ge, float& m, float& v
 // written here, so that the shadow refresh does not have to read the 15 M-element generator weight back
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2, float max_norm,
-                            const float* __restrict__ sumsq, float grad_scale, bf16_t* __restrict__ shadow, int* __restrict__ skip,
-                            unsigned sh_cols = 0, unsigned sh_ld = 0) {      // sh_cols > 0: the shadow's rows are padded (element i -> row i / sh_cols)
+                            const float* __restrict__ sumsq, float grad_scale, bf16_t* __restrict__ shadow, int* __restrict__ skip) {
   if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {      // vmmt.h: the step is not applied
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1);
     return;
@@ -123,9 +122,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
       if (shadow) {
         typedef unsigned short us4 __attribute__((ext_vector_type(4)));
         const us4 h = {f2bf(pp[0]), f2bf(pp[1]), f2bf(pp[2]), f2bf(pp[3])};
-        long o = i;
-        if (sh_cols) { const unsigned r = (unsigned)i / sh_cols; o = (long)r * sh_ld + ((unsigned)i - r * sh_cols); }     // (sh_cols % 4 == 0: the four stay in one row)
-        *reinterpret_cast<us4*>(shadow + o) = h;
+        *reinterpret_cast<us4*>(shadow + i) = h;
       }
     } else {
       for (long k = i; k < n; ++k) {
@@ -133,7 +130,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         adam_elem(pk, g[k] * coef, mk, vk, step_size, b1, b2, eps, inv_sqrt_bc2);
         m[k] = mk; v[k] = vk;
         p[k] = pk;
-        if (shadow) shadow[sh_cols ? (long)((unsigned)k / sh_cols) * sh_ld + ((unsigned)k % sh_cols) : k] = f2bf(pk);
+        if (shadow) shadow[k] = f2bf(pk);
       }
     }
   }
@@ -348,31 +345,6 @@ extern "C" int vmmt_adam_step(float* p, const float* g, float* m, float* v, int6
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1,
                      beta2, eps, inv_sqrt_bc2, max_norm, sumsq, grad_scale, (bf16_t*)shadow_bf16, const_cast<int*>(skip));
-  return check_launch();
-}
-
-// vmmt_adam_step over a [R x C] table (C % 4 == 0, R * C < 2^32) whose bf16 shadow has PADDED rows (row stride ld_shadow >= C elements): the
-// embedding table's compute copy, the A operand the LSTM's input projection fetches by token id (vmmt_gemm_args.a_row_ids), written by
-// the update itself -- no pass of its own over the 15 M-element table
-extern "C" int vmmt_adam_step_table(float* p, const float* g, float* m, float* v, int R, int Cc, float lr, float beta1, float beta2, float eps,
-                                    int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16,
-                                    int64_t ld_shadow, const int32_t* skip, void* stream) {
-  using namespace vmmt;
-  const long n = (long)R * Cc;
-  if (!p || !g || !m || !v || R < 0 || Cc <= 0 || Cc % 4 || step < 1 || (max_norm > 0.f && !sumsq) || !shadow_bf16 || ld_shadow < Cc || ld_shadow % 4 ||
-      n >= (1L << 32))
-    return VMMT_EINVAL;
-  if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return VMMT_EINVAL;
-  if (((uintptr_t)shadow_bf16) & 7) return VMMT_EINVAL;
-  if (n == 0) return VMMT_OK;
-  double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-  long blocks = (n / 4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, beta1,
-                     beta2, eps, inv_sqrt_bc2, max_norm, sumsq, grad_scale, (bf16_t*)shadow_bf16, const_cast<int*>(skip), (unsigned)Cc, (unsigned)ld_shadow);
   return check_launch();
 }
 

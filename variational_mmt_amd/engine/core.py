@@ -127,7 +127,6 @@ class Engine(StepAPI):
         import os as _os
         self.q_parallel = True    # q(z|x): scale branch on the side stream next to the location branch
         self.dec_gx_first = True  # side stream of the forward: the decoder's input projection in front of the gradient zeroing / masks
-        self.fuse_emb_gemm = True # the source embeddings as the gathered A operand of the encoder's first input projection (no [S B x E] copy in front of it)
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.trace_only = None       # ... of these entry names only (every event costs the stream ~10 us: tools/phase_times.py COARSE=1)
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
@@ -380,7 +379,7 @@ class Engine(StepAPI):
         self.sh = {}
         self.pack_calls = []
 
-        def shadow(key, rows, cols, src, c0=0, ncols=None, transpose=False, dtype=None, src2=None, row_off=0, col_off=0, gate=None, flat=False):
+        def shadow(key, rows, cols, src, c0=0, ncols=None, transpose=False, dtype=None, src2=None, row_off=0, col_off=0, gate=None):
             """one compute copy (or one piece of it).  (row_off, col_off): position of the piece in the shadow as stored, i.e. AFTER the
             transpose.  gate = (h, hp), h != hp: the source's 4h rows (a bias: its 4h entries) are nn.LSTM's gate blocks i, f, g, o; block
             g lands at g * hp of the shadow (Dims.hp): one pack descriptor per block"""
@@ -392,7 +391,7 @@ class Engine(StepAPI):
             R = shp[0] if two_d else 1
             Cc = ncols if ncols is not None else (shp[1] if two_d else shp[0])
             if key not in self.sh:
-                self.sh[key] = Buf(rows, cols, dt, dev, ld=cols if flat else None)      # flat: unpadded rows (the parameter's own layout)
+                self.sh[key] = Buf(rows, cols, dt, dev)
             b = self.sh[key]
             blocks = [(0, 0)] if (gate is None or gate[0] == gate[1]) else [(g * gate[0], g * gate[1]) for g in range(4)]
             for s0, d0 in blocks:
@@ -466,30 +465,19 @@ class Engine(StepAPI):
         shadow("iv_w1", d.img, d.z, "inf_net_image.location.fc1.weight")
         shadow("iv_w2", d.img, d.img, "inf_net_image.location.fc2.weight")
         shadow("wg", d.vt, d.hid, "generator.0.weight")
-        # the source embedding table in the compute type, rows padded to whole K slabs (16-byte aligned rows: from the parameter's own flat
-        # rows of E = 500 elements the product's LDS-DMA works -- any 4-byte aligned source does -- but every 16-byte piece then straddles two
-        # lines: the product took 155 instead of 110 us and the optimiser stream beside it twice its time): the A operand of the encoder's
-        # first input projection, fetched by token id inside the product (vmmt_gemm_args.a_row_ids) -- north_star's "embedding gather fused
-        # into the gate GEMM".  Written by the optimiser step itself (vmmt_adam_step_table; _fused_shadows), not by a pass of its own
-        if T == torch.bfloat16 and d.emb % 4 == 0:
-            shadow("enc_emb", d.vs, d.emb, "encoder.embeddings.make_embedding.emb_luts.0.weight")
 
     def _fused_shadows(self):
         """[(lo, hi, shadow pointer)] in arena order: optimised 2-D weights of at least 2 M elements whose bf16 shadow has unpadded rows
         and no second source -- the shadow then has the parameter's flat layout and vmmt_adam_step writes it (optim_step)"""
         if not hasattr(self, "_fused_sh"):
             self._fused_sh = []
-            self._fused_tab = {}          # shadow pointer -> (R, C, ld) of a shadow with PADDED rows (the embedding table: vmmt_adam_step_table)
             base = self.flat_p.data_ptr()
-            emb = self.sh["enc_emb"].p() if "enc_emb" in self.sh else None
             for code, sp, s2, lds, dst, ldd, R, Cc, tr in self.pack_calls:
                 o = (sp - base) // 4
                 whole = any(off == o and len(shp) == 2 and shp[0] * shp[1] == R * Cc for off, shp in self.offsets.values())
-                if code == L.BF16 and not tr and s2 is None and (ldd == Cc or dst == emb) and lds == Cc and whole and R * Cc >= (1 << 21) and \
-                        o + R * Cc <= self.n_opt and dst % 8 == 0 and Cc % 4 == 0:
+                if code == L.BF16 and not tr and s2 is None and ldd == Cc and lds == Cc and whole and R * Cc >= (1 << 21) and \
+                        o + R * Cc <= self.n_opt and dst % 8 == 0:
                     self._fused_sh.append((o, o + R * Cc, dst))
-                    if ldd != Cc:
-                        self._fused_tab[dst] = (R, Cc, ldd)
             self._fused_sh.sort()
         return self._fused_sh
 
@@ -497,17 +485,13 @@ class Engine(StepAPI):
         """descriptor tables for vmmt_pack_multi.  Parts 0 / 1: every shadow of [encoder + inference networks] / [generator + attention +
         decoder] (after load_state_dict / a replica broadcast); parts 2 / 3: the same without the shadows the optimiser step writes
         itself (_fused_shadows): what optim_step refreshes"""
-        if not hasattr(self, "_pack_tab") or getattr(self, "_pack_tab_dp", None) != self.dp_on():
+        if not hasattr(self, "_pack_tab"):
             self._pack_tab = []
-            self._pack_tab_dp = self.dp_on()
             enc_lo = self.offsets[self.first_enc_name][0]
             base = self.flat_p.data_ptr()
             fused = set(d for _, _, d in self._fused_shadows())
-            # (data parallelism: the sharded update writes no shadows itself and refreshes them all in a pass of its own -- the embedding
-            #  table's 30 000 x 512 copy would cost that pass 78 us per step; the forward gathers there as before, the copy is left alone)
-            unused = set(self._fused_tab) if self.dp_on() else set()
             for part in (0, 1, 2, 3):
-                sel = [c for c in self.pack_calls if ((c[1] - base) // 4 >= enc_lo) == (part % 2 == 0) and (part < 2 or c[4] not in fused) and c[4] not in unused]
+                sel = [c for c in self.pack_calls if ((c[1] - base) // 4 >= enc_lo) == (part % 2 == 0) and (part < 2 or c[4] not in fused)]
                 arr = (L.PackDesc * max(1, len(sel)))()
                 start = 0
                 for k, (code, sp, s2, lds, dst, ldd, R, Cc, tr) in enumerate(sel):
@@ -534,7 +518,7 @@ class Engine(StepAPI):
     # ------------------------------------------------------------------------------------------------ helpers
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
               act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
-              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None, group=None, a_row_ids=None):
+              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None, group=None):
         """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out[, out2]): the column sums of the K-strided A operand from the same
         pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached.
         group (a list): the product is not issued but collected -- _gemm_group() sends the list out as ONE grid (vmmt_gemm_group)"""
@@ -556,7 +540,6 @@ class Engine(StepAPI):
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
                        add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k, b_batch_rows, b_batch_stride,
                        None, 0, None, None)
-        a.a_row_ids = a_row_ids       # (NT: row m of A is row a_row_ids[m] of the table at A -- the embedding lookup as the product's operand fetch)
         # rmap / cmap = (blk, valid): output rows / columns computed in padded blocks, stored densely (vmmt_gemm_args.c_row_blk)
         if rmap is not None and rmap[0] != rmap[1]:
             a.c_row_blk, a.c_row_valid = rmap

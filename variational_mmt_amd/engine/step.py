@@ -185,15 +185,7 @@ class StepAPI(object):
 
         def adam_range(lo, hi, stream, shadow=None):
             blocks = int(self.bg_adam_blocks) if stream != st else int(self.fg_adam_blocks)
-            if hi > lo and shadow in self._fused_tab:        # a shadow with padded rows (the embedding table's compute copy)
-                R, Cc, ld = self._fused_tab[shadow]
-                assert hi - lo == R * Cc
-                L.check(self.lib.vmmt_adam_step_table(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
-                                                      self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, R, Cc, lr, beta1, beta2,
-                                                      eps, t_adam, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
-                                                      blocks, shadow, ld, guard, stream), "vmmt_adam_step_table")
-                n_launch[0] += 1
-            elif hi > lo:
+            if hi > lo:
                 L.check(self.lib.vmmt_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
                                                 self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, lr, beta1, beta2,
                                                 eps, t_adam, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,

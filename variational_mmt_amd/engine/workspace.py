@@ -182,25 +182,12 @@ class Workspace(BackwardPlan, ConditionalPlans):
         # (bg_after_head) the head of the main stream first -- source rows and the encoder's first input projection -- and only behind it the
         # side-stream half of the last optimiser step (BG_FLUSH) and the side stream's own work, the decoder's input projection first
         early_head = bool(training and e.bg_after_head and not d.conditional and e.use_side_stream)
-        # the source embeddings: the A operand of the encoder's first input projection is fetched from the table (its bf16 shadow) by token
-        # id inside the product; the [S B x E] copy the backward multiplies (dW_ih) is written later, on the side stream
-        fuse_emb = bool(e.fuse_emb_gemm and dt == L.BF16 and "enc_emb" in e.sh and e.use_side_stream and not e.dp_on())
-        def src_gather():
+        if early_head:
             e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                     self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
-        def enc_gx0():
             wih, bsum = e.sh["enc_wih_l0"], e.sh["enc_b_l0"]
-            if fuse_emb:
-                tab = e.sh["enc_emb"]
-                e._gemm(P, L.GEMM_NT, tab.p(), tab.ld, wih.p(), wih.ld, self.enc_gx[0].p(), self.enc_gx[0].ld, MS, dirs * 4 * Hdp,
-                        E, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1, a_row_ids=self.src.data_ptr())
-            else:
-                e._gemm(P, L.GEMM_NT, self.Xs.p(), self.Xs.ld, wih.p(), wih.ld, self.enc_gx[0].p(), self.enc_gx[0].ld, MS, dirs * 4 * Hdp,
-                        E, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
-        if early_head:
-            if not fuse_emb:
-                src_gather()
-            enc_gx0()
+            e._gemm(P, L.GEMM_NT, self.Xs.p(), self.Xs.ld, wih.p(), wih.ld, self.enc_gx[0].p(), self.enc_gx[0].ld, MS, dirs * 4 * Hdp,
+                    E, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
             e._record(P, "fwd_begin")
             P.append((None, None, "BG_FLUSH", None, MAIN))
 
@@ -215,8 +202,6 @@ class Workspace(BackwardPlan, ConditionalPlans):
                 e._row_mark_entries(P, 1, self.tgt_in.data_ptr(), M)
                 e._row_mark_entries(P, 0, self.src.data_ptr(), MS)
             e._record(P, "dec_gx")
-            if training and fuse_emb:
-                src_gather()            # (for the backward's dW_ih product only; joined with the rest of this stream's forward by `img_fwd`)
         # ---- side stream, underneath the encoder: zero the gradient arena (every gradient writer of the backward plan
         #      runs on the side stream), target embeddings and the time-parallel part of the decoder input projection
         e._sid = SIDE
@@ -275,16 +260,14 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._call(P, lib.vmmt_gather_rows, L.F32, None, D, self.img_idx.data_ptr(), self.img.p(), self.img.ld, B, D)
         e._sid = MAIN
         # a2 source embeddings
-        if not early_head and not fuse_emb:
-            src_gather()
+        if not early_head:
+            e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
+                    self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
         # a3 encoder
         x, xcols = self.Xs, E
         for l in range(Lyr):
             wih, bsum = e.sh["enc_wih_l%d" % l], e.sh["enc_b_l%d" % l]
-            if l == 0:
-                if not early_head:
-                    enc_gx0()
-            else:
+            if not (early_head and l == 0):
                 e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hdp,
                         xcols, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
             seq = (L.LstmDirFwd * (S * dirs))()                 # the whole recurrence: step-major, then direction
