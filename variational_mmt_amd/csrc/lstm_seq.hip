@@ -272,14 +272,31 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
       const int rr = rows[e] < B ? rows[e] : B - 1;
       if (t == 0) c_reg[e] = d.c_prev ? d.c_prev[(long)rr * d.ld_cprev + u] : 0.f;
     }
-    // ---- A fragments of h_{t-1}: 16 rows x this wave's K quarter (KQ k-steps of 32 units)
-    u32x4 af[KQ];
-    bool gx_fetched = false;
+    // ---- gates = h_{t-1} W_hh^T for this wave's K quarter (KQ k-steps of 32 units) against all 128 columns
+    f32x4_s acc[4][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { acc[g][0] = f32x4_s{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4_s{0.f, 0.f, 0.f, 0.f}; }
+    };
+    auto mfma_q = [&](int q, const u32x4& afq) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+          acc[g][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afq), wreg[q][g][h2], acc[g][h2], 0, 0, 0);
+    };
+    zero_acc();
     if (t == 0) {                                               // the initial state: an ordinary [B][ld] bf16 buffer of an earlier kernel
       const __amdgpu_buffer_rsrc_t hr = make_rsrc(d.h_prev);
       const unsigned abase = (unsigned)(((long)arow * d.ld_hprev + kg * 8) * 2);
+      u32x4 af[KQ];
 #pragma unroll
       for (int q = 0; q < KQ; ++q) af[q] = has_k(q) ? load16_sc1(hr, abase + (unsigned)((wave * KQ + q) * 64)) : u32x4{0u, 0u, 0u, 0u};
+      fetch_gx(dnext);
+      SEQ_TS(2);
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+        if (has_k(q)) mfma_q(q, af[q]);
     } else {
       const unsigned want = tag0 + (unsigned)t;                 // tag of step t-1
       const unsigned gbase = (unsigned)(((t - 1) & 1) * Cf::SLOT + (long)(wave * KQ) * 2048 + lane * 16);
@@ -313,22 +330,24 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
           }
         }
       };
-      auto complete = [&]() {
+      // the tags are checked k-step by k-step and every k-step's MFMAs go out as soon as ITS granules are in (loads return in order: the
+      // waits are counted): the products run under the rest of the sweep instead of behind the last tag.  A sweep that meets a granule of the
+      // step before -- behind the cheap poll that is rare -- has multiplied it already: the accumulators start over
+      auto multiply = [&]() {
         bool ok = true;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           ok = ok && lo[q][1] == want && lo[q][3] == want && hi[q][1] == want && hi[q][3] == want;
-          af[q] = u32x4{lo[q][0], lo[q][2], hi[q][0], hi[q][2]};
+          if (has_k(q)) mfma_q(q, u32x4{lo[q][0], lo[q][2], hi[q][0], hi[q][2]});
         }
         return __all(ok);
       };
-      // first attempt (behind the cheap poll it nearly always succeeds), straight-line: the next step's gate operands are requested
-      // behind the sweep's loads -- which return first: the compiler counts these 16 out of the wait for the tags -- and in their shadow
-      // (issued behind the completed sweep they cost the step 0.4 us of address arithmetic and issue)
+      // first attempt, straight-line: the next step's gate operands are requested behind the sweep's loads -- which return first: the compiler
+      // counts these 16 out of the waits for the granules -- and in their shadow (issued behind the completed sweep they cost the step 0.4 us
+      // of address arithmetic and issue)
       sweep();
       fetch_gx(dnext);                                          // (last step: the last descriptor's once more, unused)
-      gx_fetched = true;
-      bool done = complete();
+      bool done = multiply();
       while (!done && alive) {
         if (timed_out(t_start)) {
           if (lane == 0) seq_fail(a.sync, 0x100u + (unsigned)t);
@@ -337,22 +356,11 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd_kernel(SeqArgsF a) {
         }
         __builtin_amdgcn_s_sleep(1);
         sweep();
-        done = complete();
+        zero_acc();
+        done = multiply();
       }
+      SEQ_TS(2);
     }
-    SEQ_TS(2);
-    if (!gx_fetched) fetch_gx(dnext);                           // (step 0)
-    f32x4_s acc[4][2];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) { acc[g][0] = f32x4_s{0.f, 0.f, 0.f, 0.f}; acc[g][1] = f32x4_s{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int q = 0; q < KQ; ++q)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-          if (has_k(q))
-            acc[g][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[q]), wreg[q][g][h2], acc[g][h2], 0, 0, 0);
     // (fold buffer: [quarter = wave][gate][unit half][lane] x f32x4 -- one 16-byte write per accumulator; a lane's two cells are rows
     //  2*rp, 2*rp + 1 of its own lane slot: one 8-byte read per (gate, quarter))
 #pragma unroll
