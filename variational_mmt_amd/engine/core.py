@@ -127,6 +127,7 @@ class Engine(StepAPI):
         import os as _os
         self.q_parallel = True    # q(z|x): scale branch on the side stream next to the location branch
         self.dec_gx_first = True  # side stream of the forward: the decoder's input projection in front of the gradient zeroing / masks
+        self.zero_on_aux = True   # ... and the zeroing / masks on the AUX stream (idle at that point of the forward) instead of behind it
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self.trace_only = None       # ... of these entry names only (every event costs the stream ~10 us: tools/phase_times.py COARSE=1)
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)

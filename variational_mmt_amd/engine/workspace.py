@@ -216,6 +216,13 @@ class Workspace(BackwardPlan, ConditionalPlans):
             P.append((None, None, "BG_FLUSH2", None, 2))
         elif e.dec_gx_first:
             side_dec_gx()
+        # the side stream's chain -- the last update's background half, the decoder's input projection, zeroing, masks, the image network -- ends
+        # where the main stream's does (`img_fwd`, in front of the sweep) and is the longer of the two (tools/critical.py: the step without the
+        # zeroing is 27 us shorter, without the encoder's recurrence 3 us): the zeroing and the masks go to the AUX stream, idle at that point
+        aux_zero = bool(not early_head and e.dec_gx_first and e.zero_on_aux and e.use_side_stream and e.use_aux_stream and training)
+        if aux_zero:
+            e._sid = 2
+            e._wait(P, "side_fwd")       # (behind the side-stream half of the last update, which reads the gradients)
         if training:
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             # ... together with the small accumulators of the backward plan (off the critical path instead of in front of
@@ -242,7 +249,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
             self._mask_entries["dec_out"] = (len(P), self.out_mask)
             e._call(P, lib.vmmt_dropout_mask, dt, self.out_mask.p(), self.out_mask.rows * self.out_mask.ld, d.dropout, 0)
             e._record(P, "out_mask")
-        if early_head:
+        if early_head or aux_zero:
             e._record(P, "aux_fwd")
             e._sid = SIDE
         elif not e.dec_gx_first:
@@ -362,7 +369,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
                 addend=e.pp("inf_net_image.location.fc1.bias"), ld_add=D, add_rows=1, act=L.ACT_RELU)
         e._gemm(P, L.GEMM_NT, self.h1v.p(), self.h1v.ld, w2.p(), w2.ld, self.mu_v.p(), self.mu_v.ld, B, D, D,
                 addend=e.pp("inf_net_image.location.fc2.bias"), ld_add=D, add_rows=1, out_f32=1)
-        if early_head:
+        if early_head or aux_zero:
             e._wait(P, "aux_fwd")        # (join: whoever is behind the side stream's forward is behind the gradient zeroing as well)
         e._record(P, "img_fwd")
         e._sid = MAIN
