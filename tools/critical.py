@@ -53,6 +53,28 @@ for pname in ("plan_fwd_train", "plan_loss_train", "plan_bwd"):
         t = timed(16)
         plan[j] = entry
         rows.append((base - t, pname[5:], j, sid, name))
+# the optimiser step's launches are not plan entries: the k-th vmmt_adam_step / vmmt_pack_multi call of a step left out in turn
+for fname in ("vmmt_adam_step", "vmmt_pack_multi", "vmmt_sumsq"):
+    real = getattr(eng.lib, fname)
+    calls = [0]
+
+    def counting(*x, _real=real, _c=calls):
+        _c[0] += 1
+        return _real(*x)
+    setattr(eng.lib, fname, counting)
+    step(0)
+    per_step = calls[0]
+    for k in range(per_step):
+        state = [0]
+
+        def skipping(*x, _real=real, _s=state, _k=k, _n=per_step):
+            i = _s[0] % _n
+            _s[0] += 1
+            return 0 if i == _k else _real(*x)
+        setattr(eng.lib, fname, skipping)
+        t = timed(16)
+        rows.append((base - t, "optim", k, -1, "%s call %d of %d" % (fname, k, per_step)))
+    setattr(eng.lib, fname, real)
 base2 = timed()
 print("step as it is, measured again at the end: %.1f us" % base2)
 print("%8s  %-10s %4s %6s  %s" % ("saves us", "plan", "#", "stream", "entry"))
