@@ -219,8 +219,10 @@ class Workspace(BackwardPlan, ConditionalPlans):
         # the side stream's chain -- the last update's background half, the decoder's input projection, zeroing, masks, the image network -- ends
         # where the main stream's does (`img_fwd`, in front of the sweep) and is the longer of the two (tools/critical.py: the step without the
         # zeroing is 27 us shorter, without the encoder's recurrence 3 us): the zeroing and the masks go to the AUX stream, idle at that point
-        # (not under data parallelism: the aux stream's chain starts with the KL all-reduce there -- one-rank RCCL rehearsal 2.07 against 1.93 ms)
-        aux_zero = bool(not early_head and e.dec_gx_first and e.zero_on_aux and e.use_side_stream and e.use_aux_stream and training and not e.dp_on())
+        # (not under data parallelism: the aux stream's chain starts with the KL all-reduce there -- one-rank RCCL rehearsal 2.07 against 1.93 ms;
+        #  not for the conditional model, whose aux stream starts the step's longest chain, encoder_tgt's backward: 2.77 against 2.68 ms)
+        aux_zero = bool(not early_head and e.dec_gx_first and e.zero_on_aux and e.use_side_stream and e.use_aux_stream and training and not e.dp_on() and
+                        not d.conditional)
         if aux_zero:
             e._sid = 2
             e._wait(P, "side_fwd")       # (behind the side-stream half of the last update, which reads the gradients)
