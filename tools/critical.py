@@ -43,6 +43,23 @@ for i in range(8):
 base = min(timed(), timed())
 print("step as it is: %.1f us   (config %s, batch %d)" % (base, cfg, BATCH))
 rows = []
+# GROUP="bwd:15-27": these entries of one plan left out TOGETHER (what a fused kernel for that stretch could save at most)
+grp = os.environ.get("GROUP")
+if grp:
+    pn, rng = grp.split(":")
+    lo, hi = (int(x) for x in rng.split("-"))
+    plan = getattr(ws, "plan_" + pn if pn.startswith("bwd") else "plan_" + pn)
+    saved = {}
+    for j in range(lo, hi + 1):
+        fn, args, name, keep, sid = plan[j]
+        if fn is not None:
+            saved[j] = plan[j]
+            plan[j] = ((lambda *x: 0), args, name, keep, sid)
+    t = min(timed(), timed())
+    for j, en in saved.items():
+        plan[j] = en
+    print("without %s entries %d..%d (%s): %.1f us, saves %.1f us" % (pn, lo, hi, ", ".join(sorted(set(e[2] for e in saved.values()))), t, base - t))
+    sys.exit(0)
 for pname in ("plan_fwd_train", "plan_loss_train", "plan_bwd"):
     plan = getattr(ws, pname)
     for j, entry in enumerate(plan):

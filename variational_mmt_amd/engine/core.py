@@ -129,6 +129,7 @@ class Engine(StepAPI):
         self.dec_gx_first = True  # side stream of the forward: the decoder's input projection in front of the gradient zeroing / masks
         self.zero_on_aux = True   # ... and the zeroing / masks on the AUX stream (idle at that point of the forward) instead of behind it
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
+        self._kl_sum_needed = True   # set per step by Workspace.backward_plan: does the latent backward read the (global) KL sum?
         self.trace_only = None       # ... of these entry names only (every event costs the stream ~10 us: tools/phase_times.py COARSE=1)
         self.global_events = {}      # events that outlive a plan run (optimizer <-> next forward)
         self.split_optim = True      # run the decoder-side half of Adam + shadow refresh on the side stream
@@ -851,7 +852,9 @@ class Engine(StepAPI):
                                                  self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq_rows")
                 return
             if name == "KL_ALLREDUCE":
-                if self.dp_on():
+                # (only the free-bits test reads the KL sum -- latent_bwd_kernel: without it the latent backward needs nothing from the other
+                #  ranks and the aux stream's chain starts without a collective in front of it)
+                if self.dp_on() and self._kl_sum_needed:
                     # one float, on the COMM stream like the gradient segments (one communicator: one collective at a time), behind the
                     # background half of the last optimiser step, whose parameter all-gathers run on the side stream
                     ws = self._cur_ws

@@ -219,7 +219,8 @@ class Workspace(BackwardPlan, ConditionalPlans):
         # the side stream's chain -- the last update's background half, the decoder's input projection, zeroing, masks, the image network -- ends
         # where the main stream's does (`img_fwd`, in front of the sweep) and is the longer of the two (tools/critical.py: the step without the
         # zeroing is 27 us shorter, without the encoder's recurrence 3 us): the zeroing and the masks go to the AUX stream, idle at that point
-        # (not under data parallelism: the aux stream's chain starts with the KL all-reduce there -- one-rank RCCL rehearsal 2.07 against 1.93 ms;
+        # (not under data parallelism: one-rank RCCL rehearsal 2.07 against 1.93 ms, and 2.02 against 1.89 once the KL all-reduce had gone from
+        #  the head of the aux stream's chain;
         #  not for the conditional model, whose aux stream starts the step's longest chain, encoder_tgt's backward: 2.77 against 2.68 ms)
         aux_zero = bool(not early_head and e.dec_gx_first and e.zero_on_aux and e.use_side_stream and e.use_aux_stream and training and not e.dp_on() and
                         not d.conditional)
@@ -524,6 +525,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
             self.plan_bwd = self._plan_backward(inv_norm, batch_global, kl_mult, use_freebits, margin, drop)
             self._bwd_key = key
         P = self.plan_bwd
+        self.e._kl_sum_needed = bool(use_freebits)
         fn, _, name, keep, sid = P[self._latent_bwd_index]
         P[self._latent_bwd_index] = (fn, self._latent_bwd_args(batch_global, kl_mult, use_freebits, margin, inv_norm), name, keep, sid)
         for ii, pos in self._patch.values():
