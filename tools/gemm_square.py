@@ -20,13 +20,17 @@ for M, N, K in ((8192, 8192, 8192), (4096, 4096, 4096), (30000, 512, 5120), (300
     A = torch.randn(M, K, device="cuda").to(T); B = torch.randn(N, K, device="cuda").to(T)
     Bt = B.t()
     res = []
-    for tile in (256, 128):
+    tiles = [int(x) for x in os.environ.get("TILES", "256,128").split(",")]       # 512 / 513: the probe build (tools/exp_build.sh gemm.hip TILE512)
+    ref = torch.matmul(A, Bt).float()
+    for tile in tiles:
         Cc = torch.zeros(M, N, device="cuda", dtype=T)
         a = L.GemmArgs()
         a.dtype, a.layout, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N, a.K = L.BF16, L.GEMM_NT, A.data_ptr(), K, B.data_ptr(), K, Cc.data_ptr(), N, M, N, K
         a.out_f32, a.alpha, a.tile = 0, 1.0, tile
         res.append(timeit(lambda: L.check(lib.vmmt_gemm(C.byref(a), None), "g")))
+        err = float((Cc.float() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-2 or os.environ.get("NOCHECK") == "1", (tile, err)
     t2 = timeit(lambda: torch.matmul(A, Bt))
     fl = 2.0 * M * N * K / 1e6
-    print("%6d x %5d x %5d  ours 256x128: %7.1f us %5.0f TF | 128x128: %7.1f us %5.0f TF | torch.matmul %7.1f us %5.0f TF" %
-          (M, N, K, res[0], fl / res[0], res[1], fl / res[1], t2, fl / t2))
+    print("%6d x %5d x %5d  " % (M, N, K) + " | ".join("tile %d: %7.1f us %5.0f TF" % (t, r, fl / r) for t, r in zip(tiles, res)) +
+          " | torch.matmul %7.1f us %5.0f TF" % (t2, fl / t2))

@@ -117,9 +117,9 @@ __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, long lda, con
     const float* cw = epi.colsum_w ? epi.colsum_w + (epi.b_batch_rows > 0 ? (long)(m0 / epi.b_batch_rows) * epi.colsum_w_stride : 0L) : nullptr;
     gemm_mainloop_glds3<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, cw, epi.colsum_out,
                                                              tn, tiles_n);
-  } else if constexpr (GL == 4) {   // half-depth slabs, both operands K-contiguous (glds_gemm.hpp)
-    static_assert(GL != 4 || (A_KC && B_KC), "the half-depth loop stages K-contiguous operands");
-    gemm_mainloop_hglds3<BM, BN, NT / 64, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
+  } else if constexpr (GL == 4 || GL == 5) {   // half-depth slabs, both operands K-contiguous (glds_gemm.hpp); 5: four stages
+    static_assert((GL != 4 && GL != 5) || (A_KC && B_KC), "the half-depth loop stages K-contiguous operands");
+    gemm_mainloop_hglds3<BM, BN, NT / 64, TI, TJ, GL == 5 ? 4 : 3>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
   } else if constexpr (GL == 1) {
     // plain column sums of A (unit weights) in the workgroups of the first column tile, every K split adds its share
     float* co = (epi.colsum_out && !epi.colsum_w && tn == 0) ? epi.colsum_out : nullptr;
@@ -130,6 +130,23 @@ __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, long lda, con
                                                                                     b_kmod, aoff, boff, acc, smem, kbeg);
   }
   if (split != 0) epi.add_rows = 0;                  // the addend is added once
+#if defined(VMMT_EXP_TILE512)
+  if constexpr (GL == 4 || GL == 5 || (BM == 256 && BN == 256)) {                // probe: plain store only (the general epilogue spills beside 128 accumulators)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + aoff[i] + acc_row(r, lane), col = n0 + boff[j] + acc_col(lane);
+          if (row < M && col < N) {
+            if (epi.out_f32) reinterpret_cast<float*>(epi.C)[(long)row * epi.ldc + col] = acc[i][j][r];
+            else reinterpret_cast<T*>(epi.C)[(long)row * epi.ldc + col] = from_f<T>(acc[i][j][r]);
+          }
+        }
+    return;
+  }
+#endif
   gemm_epilogue<T, TI, TJ, EPI>(epi, acc, aoff, boff, m0, n0, M, N, lane);
 }
 
@@ -181,7 +198,7 @@ template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK 
 static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st, size_t lds_min = 0) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
-  size_t smem = GL == 4 ? (size_t)hglds3_smem_bytes<BM, BN>() : GL == 3 ? (size_t)glds3_smem_bytes<BM, BN>() : GL ? (size_t)glds_smem_bytes<BM, BN>() : gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
+  size_t smem = GL == 5 ? (size_t)hglds3_smem_bytes<BM, BN, 4>() : GL == 4 ? (size_t)hglds3_smem_bytes<BM, BN>() : GL == 3 ? (size_t)glds3_smem_bytes<BM, BN>() : GL ? (size_t)glds_smem_bytes<BM, BN>() : gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
   if (smem < lds_min) smem = lds_min;          // occupancy cap by LDS request (VMMT_TILE_128_ONE_PER_CU)
   if (smem > 64 * 1024) {
     static size_t allowed = 0;
@@ -211,6 +228,16 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
   // 64 x 64 configuration, so for long reductions it is also the lower-LATENCY choice when there are fewer tiles than CUs
   // (M = 256 products of the inference networks at K = 2048: 20 us instead of 26-32 us); below K = 1024 the 64 x 64
   // configuration starts faster (tools/gemm_ab.py).
+#if defined(VMMT_EXP_TILE512)        // probe (tools/exp_build.sh gemm.hip TILE512): 256 x 256 tiles, 8 waves of 128 x 64, 32-deep slabs, four / three stages
+  if constexpr (sizeof(T) == 2 && A_KC && B_KC) {
+    if (a->tile >= 512 && a->tile <= 515 && a->K % 32 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0) {
+      if (a->tile == 512) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 32, true, 5>(a, epi, st);
+      if (a->tile == 514 && a->K % 64 == 0) return launch_cfg<T, 256, 256, 128, 128, A_KC, B_KC, 64, true, 1>(a, epi, st);    // 4 waves of 128 x 128, two 64-deep stages
+      if (a->tile == 515 && a->K % 64 == 0) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);     // 8 waves of 128 x 64, two 64-deep stages
+      return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 32, true, 4>(a, epi, st);
+    }
+  }
+#endif
   if (a->tile == 128 || a->tile == 256 || a->tile == VMMT_TILE_128_ONE_PER_CU || (a->tile == 0 && (t128 >= 192 || (gl_ok && a->K >= 1024 && t128 >= 8)))) {
     // ONE_PER_CU: an 88-KiB LDS request admits one workgroup per CU (2 x 88 > 160 KiB) and leaves 72 KiB plus half of the
     // registers for a 64-KiB workgroup of another stream (the LSTM step kernels of the critical path)

@@ -389,11 +389,11 @@ struct HalfOperand {
   }
 };
 
-template <int BM, int BN>
-constexpr int hglds3_smem_bytes() { return 3 * (BM + BN) * HBK * 2; }
+template <int BM, int BN, int NS = 3>
+constexpr int hglds3_smem_bytes() { return NS * (BM + BN) * HBK * 2; }
 
 // C_tile += A_tile * B_tile^T over k in [kbeg, kend), kend - kbeg a positive multiple of 32; both operands K-contiguous.
-template <int BM, int BN, int NW, int TI, int TJ>
+template <int BM, int BN, int NW, int TI, int TJ, int NS = 3>
 __device__ __forceinline__ void gemm_mainloop_hglds3(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
                                                      long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
                                                      const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem) {
@@ -414,36 +414,47 @@ __device__ __forceinline__ void gemm_mainloop_hglds3(const bf16_t* __restrict__ 
   }
   const int nslab = (kend - kbeg) / HBK;
   if (nslab <= 0) return;
-  ga.issue(smem, wave);
-  gb.issue(smem + ABYTES, wave);
-  if (nslab > 1) {
-    ga.issue(smem + BUF, wave);
-    gb.issue(smem + BUF + ABYTES, wave);
-  }
+  // NS stages: NS - 1 slabs in flight (the slab of step s + NS - 1 goes into the buffer step s - 1 has just left)
+#pragma unroll
+  for (int q = 0; q < NS - 1; ++q)
+    if (q < nslab) {
+      ga.issue(smem + q * BUF, wave);
+      gb.issue(smem + q * BUF + ABYTES, wave);
+    }
   int cur = 0;
   for (int s = 0; s < nslab; ++s) {
-    if (s + 1 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();
+    const int ahead = nslab - 1 - s;             // slabs requested behind this one
+    if constexpr (NS == 4) {
+      if (ahead >= 2) glds_wait_vm<2 * PW>(); else if (ahead == 1) glds_wait_vm<PW>(); else glds_wait_vm<0>();
+    } else {
+      if (ahead >= 1) glds_wait_vm<PW>(); else glds_wait_vm<0>();
+    }
     __builtin_amdgcn_s_barrier();
-    if (s + 2 < nslab) {
-      const int nb = cur == 0 ? 2 : cur - 1;
+    if (s + NS - 1 < nslab) {
+      const int nb = cur == 0 ? NS - 1 : cur - 1;
       ga.issue(smem + nb * BUF, wave);
       gb.issue(smem + nb * BUF + ABYTES, wave);
     }
     const char* As = smem + cur * BUF;
     const char* Bs = As + ABYTES;
+    // fragments of K-step 1 are requested before the MFMAs of K-step 0 (register double buffer, as glds_slab)
+    bf16x8 fa_[2][TI], fb_[2][TJ];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa_[TI], fb_[TJ];
+    for (int i = 0; i < TI; ++i) fa_[0][i] = *reinterpret_cast<const bf16x8*>(As + foff[0] + aoff[i] * 64);
 #pragma unroll
-      for (int i = 0; i < TI; ++i) fa_[i] = *reinterpret_cast<const bf16x8*>(As + foff[ks] + aoff[i] * 64);
+    for (int j = 0; j < TJ; ++j) fb_[0][j] = *reinterpret_cast<const bf16x8*>(Bs + foff[0] + boff[j] * 64);
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) fb_[j] = *reinterpret_cast<const bf16x8*>(Bs + foff[ks] + boff[j] * 64);
+    for (int i = 0; i < TI; ++i) fa_[1][i] = *reinterpret_cast<const bf16x8*>(As + foff[1] + aoff[i] * 64);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) fb_[1][j] = *reinterpret_cast<const bf16x8*>(Bs + foff[1] + boff[j] * 64);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);
-    }
-    cur = cur == 2 ? 0 : cur + 1;
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[ks][i], fb_[ks][j], acc[i][j], 0, 0, 0);
+    cur = cur == NS - 1 ? 0 : cur + 1;
   }
   __builtin_amdgcn_s_barrier();      // the staging buffers may be reused by the caller's epilogue
 }
