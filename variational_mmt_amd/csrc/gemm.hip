@@ -230,8 +230,10 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
   // configuration starts faster (tools/gemm_ab.py).
 #if defined(VMMT_EXP_TILE512)        // probe (tools/exp_build.sh gemm.hip TILE512): 256 x 256 tiles, 8 waves of 128 x 64, 32-deep slabs, four / three stages
   if constexpr (sizeof(T) == 2 && A_KC && B_KC) {
-    if (a->tile >= 512 && a->tile <= 515 && a->K % 32 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0) {
+    if (a->tile >= 512 && a->tile <= 517 && a->K % 32 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0) {
       if (a->tile == 512) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 32, true, 5>(a, epi, st);
+      if (a->tile == 516) return launch_cfg<T, 256, 256, 128, 128, A_KC, B_KC, 32, true, 5>(a, epi, st);      // 4 waves of 128 x 128 (one per SIMD), four 32-deep stages
+      if (a->tile == 517) return launch_cfg<T, 256, 256, 128, 128, A_KC, B_KC, 32, true, 4>(a, epi, st);      // ... three stages
       if (a->tile == 514 && a->K % 64 == 0) return launch_cfg<T, 256, 256, 128, 128, A_KC, B_KC, 64, true, 1>(a, epi, st);    // 4 waves of 128 x 128, two 64-deep stages
       if (a->tile == 515 && a->K % 64 == 0) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 64, true, 1>(a, epi, st);     // 8 waves of 128 x 64, two 64-deep stages
       return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 32, true, 4>(a, epi, st);
