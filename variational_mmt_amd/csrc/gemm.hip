@@ -117,6 +117,10 @@ __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, long lda, con
     const float* cw = epi.colsum_w ? epi.colsum_w + (epi.b_batch_rows > 0 ? (long)(m0 / epi.b_batch_rows) * epi.colsum_w_stride : 0L) : nullptr;
     gemm_mainloop_glds3<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, cw, epi.colsum_out,
                                                              tn, tiles_n);
+#if defined(VMMT_EXP_TILE512)
+  } else if constexpr (GL == 6) {
+    gemm_mainloop_hglds_pipe<BM, BN, NT / 64, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
+#endif
   } else if constexpr (GL == 4 || GL == 5) {   // half-depth slabs, both operands K-contiguous (glds_gemm.hpp); 5: four stages
     static_assert((GL != 4 && GL != 5) || (A_KC && B_KC), "the half-depth loop stages K-contiguous operands");
     gemm_mainloop_hglds3<BM, BN, NT / 64, TI, TJ, GL == 5 ? 4 : 3>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
@@ -131,7 +135,7 @@ __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, long lda, con
   }
   if (split != 0) epi.add_rows = 0;                  // the addend is added once
 #if defined(VMMT_EXP_TILE512)
-  if constexpr (GL == 4 || GL == 5 || (BM == 256 && BN == 256)) {                // probe: plain store only (the general epilogue spills beside 128 accumulators)
+  if constexpr (GL == 4 || GL == 5 || GL == 6 || (BM == 256 && BN == 256)) {                // probe: plain store only (the general epilogue spills beside 128 accumulators)
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -198,7 +202,7 @@ template <class T, int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK 
 static int launch_cfg(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_t st, size_t lds_min = 0) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   int tm = (a->M + BM - 1) / BM, tn = (a->N + BN - 1) / BN;
-  size_t smem = GL == 5 ? (size_t)hglds3_smem_bytes<BM, BN, 4>() : GL == 4 ? (size_t)hglds3_smem_bytes<BM, BN>() : GL == 3 ? (size_t)glds3_smem_bytes<BM, BN>() : GL ? (size_t)glds_smem_bytes<BM, BN>() : gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
+  size_t smem = (GL == 5 || GL == 6) ? (size_t)hglds3_smem_bytes<BM, BN, 4>() : GL == 4 ? (size_t)hglds3_smem_bytes<BM, BN>() : GL == 3 ? (size_t)glds3_smem_bytes<BM, BN>() : GL ? (size_t)glds_smem_bytes<BM, BN>() : gemm_smem_elems<T, BM, BN, BK, A_KC, B_KC, DB>() * sizeof(T);
   if (smem < lds_min) smem = lds_min;          // occupancy cap by LDS request (VMMT_TILE_128_ONE_PER_CU)
   if (smem > 64 * 1024) {
     static size_t allowed = 0;
@@ -230,8 +234,9 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
   // configuration starts faster (tools/gemm_ab.py).
 #if defined(VMMT_EXP_TILE512)        // probe (tools/exp_build.sh gemm.hip TILE512): 256 x 256 tiles, 8 waves of 128 x 64, 32-deep slabs, four / three stages
   if constexpr (sizeof(T) == 2 && A_KC && B_KC) {
-    if (a->tile >= 512 && a->tile <= 517 && a->K % 32 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0) {
+    if (a->tile >= 512 && a->tile <= 518 && a->K % 32 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0) {
       if (a->tile == 512) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 32, true, 5>(a, epi, st);
+      if (a->tile == 518) return launch_cfg<T, 256, 256, 128, 128, A_KC, B_KC, 32, true, 6>(a, epi, st);      // ... hand-ordered across slabs (gemm_mainloop_hglds_pipe)
       if (a->tile == 516) return launch_cfg<T, 256, 256, 128, 128, A_KC, B_KC, 32, true, 5>(a, epi, st);      // 4 waves of 128 x 128 (one per SIMD), four 32-deep stages
       if (a->tile == 517) return launch_cfg<T, 256, 256, 128, 128, A_KC, B_KC, 32, true, 4>(a, epi, st);      // ... three stages
       if (a->tile == 514 && a->K % 64 == 0) return launch_cfg<T, 256, 256, 128, 128, A_KC, B_KC, 64, true, 1>(a, epi, st);    // 4 waves of 128 x 128, two 64-deep stages

@@ -459,4 +459,97 @@ __device__ __forceinline__ void gemm_mainloop_hglds3(const bf16_t* __restrict__ 
   __builtin_amdgcn_s_barrier();      // the staging buffers may be reused by the caller's epilogue
 }
 
+#if defined(VMMT_EXP_TILE512)
+// Probe: one wave per SIMD (4 waves of 128 x 128 on a 256 x 256 tile), four 32-deep stages, ONE loop body with a run-time stage index.  The
+// fragment reads are inline assembly with counted lgkmcnt waits (hipcc does not see them: no s_waitcnt vmcnt(0) in front of reads it cannot tell
+// from the LDS-DMA's destinations, no lgkmcnt(0) per group), requested one K-step ahead ACROSS slabs and issued between the MFMAs.
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pipe_read(gu32x4& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr) : "memory"); }
+template <int N>
+__device__ __forceinline__ void pipe_wait_lgkm(gu32x4 (&a)[4], gu32x4 (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
+template <int BM, int BN, int NW, int TI, int TJ>
+__device__ __forceinline__ void gemm_mainloop_hglds_pipe(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
+                                                         long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
+                                                         const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem) {
+  static_assert(TI == 4 && TJ == 4, "written for 128 x 128 per wave");
+  constexpr int NS = 4;
+  constexpr int ABYTES = BM * HBK * 2, BBYTES = BN * HBK * 2, BUF = ABYTES + BBYTES;
+  using GA = HalfOperand<BM, NW>;
+  using GB = HalfOperand<BN, NW>;
+  constexpr int PW = GA::PER + GB::PER;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  GA ga;
+  GB gb;
+  ga.init(A, lda, m0, M, kbeg, wave, lane);
+  gb.init(B, ldb, n0, N, kbeg, wave, lane);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned fo[2];                          // byte offset of this lane's 16 bytes in a 32-row block, K-step 0 / 1 (swizzled as HalfOperand fills it)
+  {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fo[ks] = (unsigned)(r * 64 + (((2 * ks + h) ^ sw) * 16));
+  }
+  unsigned ao[4], bo[4];                   // + this wave's four row blocks of each operand
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ao[i] = (unsigned)(aoff[i] * 64); bo[i] = (unsigned)(ABYTES + boff[i] * 64); }
+  const int nslab = (kend - kbeg) / HBK;
+  if (nslab <= 0) return;
+#pragma unroll
+  for (int q = 0; q < NS - 1; ++q)
+    if (q < nslab) {
+      ga.issue(smem + q * BUF, wave);
+      gb.issue(smem + q * BUF + ABYTES, wave);
+    }
+  if (nslab >= 3) glds_wait_vm<2 * PW>(); else if (nslab == 2) glds_wait_vm<PW>(); else glds_wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  gu32x4 f0a[4], f0b[4], f1a[4], f1b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { pipe_read(f0a[i], lds0 + fo[0] + ao[i]); pipe_read(f0b[i], lds0 + fo[0] + bo[i]); }
+  int cur = 0;
+  for (int s = 0; s < nslab; ++s) {
+    const unsigned base = lds0 + (unsigned)(cur * BUF);
+    const int nxt = cur == NS - 1 ? 0 : cur + 1;
+    // ---- K-step 0 of slab s: its fragments were requested one K-step ago; the requests of K-step 1 go out between its MFMAs
+    pipe_wait_lgkm<0>(f0a, f0b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0a[i]), __builtin_bit_cast(bf16x8, f0b[j]), acc[i][j], 0, 0, 0);
+      pipe_read(f1a[i], base + fo[1] + ao[i]);
+      pipe_read(f1b[i], base + fo[1] + bo[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- slab s + 1 must have landed in every wave's share (only slab s + 2 may still be on its way); behind the barrier every wave is past its
+    //      last read of slab s - 1, whose buffer takes slab s + 3
+    if (s + 2 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + NS - 1 < nslab) {
+      const int nb = cur == 0 ? NS - 1 : cur - 1;
+      ga.issue(smem + nb * BUF, wave);
+      gb.issue(smem + nb * BUF + ABYTES, wave);
+    }
+    // ---- K-step 1 of slab s, the requests of slab s + 1 / K-step 0 between its MFMAs
+    pipe_wait_lgkm<0>(f1a, f1b);
+    const unsigned nbase = lds0 + (unsigned)(nxt * BUF);
+    const bool more = s + 1 < nslab;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1a[i]), __builtin_bit_cast(bf16x8, f1b[j]), acc[i][j], 0, 0, 0);
+      if (more) {
+        pipe_read(f0a[i], nbase + fo[0] + ao[i]);
+        pipe_read(f0b[i], nbase + fo[0] + bo[i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cur = nxt;
+  }
+  __builtin_amdgcn_s_barrier();
+}
+#endif
+
 }  // namespace vmmt
