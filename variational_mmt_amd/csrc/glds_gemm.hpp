@@ -387,6 +387,10 @@ struct HalfOperand {
       src[j] += HBK * 2;
     }
   }
+  __device__ __forceinline__ void issue_piece(char* lds, int wave, int j) {      // (j a compile-time constant after unrolling)
+    __builtin_amdgcn_global_load_lds((g_glb_cvoid_t*)src[j], (g_lds_void_t*)(lds + (wave * PER + j) * 1024), 16, 0, 0);
+    src[j] += HBK * 2;
+  }
 };
 
 template <int BM, int BN, int NS = 3>
@@ -511,35 +515,39 @@ __device__ __forceinline__ void gemm_mainloop_hglds_pipe(const bf16_t* __restric
   for (int s = 0; s < nslab; ++s) {
     const unsigned base = lds0 + (unsigned)(cur * BUF);
     const int nxt = cur == NS - 1 ? 0 : cur + 1;
-    // ---- K-step 0 of slab s: its fragments were requested one K-step ago; the requests of K-step 1 go out between its MFMAs
+    // ---- K-step 0 of slab s: its fragments were requested one K-step ago; the requests of K-step 1 go out between its MFMAs, and so does the
+    //      B half of slab s + 2's LDS-DMA (its A half went out between the MFMAs of the previous K-step: one request per four MFMAs --
+    //      a burst of eight behind the barrier keeps this wave, the SIMD's only one, from issuing MFMAs while the requests queue up)
     pipe_wait_lgkm<0>(f0a, f0b);
+    const bool fillb = s >= 1 && s + NS - 2 < nslab;
+    char* const pb = smem + (cur >= 2 ? cur - 2 : cur + 2) * BUF + ABYTES;      // buffer of slab s + 2 = (cur + 2) % 4
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0a[i]), __builtin_bit_cast(bf16x8, f0b[j]), acc[i][j], 0, 0, 0);
+      if (fillb) gb.issue_piece(pb, wave, i);
       pipe_read(f1a[i], base + fo[1] + ao[i]);
       pipe_read(f1b[i], base + fo[1] + bo[i]);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- slab s + 1 must have landed in every wave's share (only slab s + 2 may still be on its way); behind the barrier every wave is past its
     //      last read of slab s - 1, whose buffer takes slab s + 3
+    //      (outstanding at this point, in issue order: slab s + 1, then slab s + 2 whole -- its B half went out just now)
     if (s + 2 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    if (s + NS - 1 < nslab) {
-      const int nb = cur == 0 ? NS - 1 : cur - 1;
-      ga.issue(smem + nb * BUF, wave);
-      gb.issue(smem + nb * BUF + ABYTES, wave);
-    }
-    // ---- K-step 1 of slab s, the requests of slab s + 1 / K-step 0 between its MFMAs
+    // ---- K-step 1 of slab s, the requests of slab s + 1 / K-step 0 and the A half of slab s + 3's LDS-DMA between its MFMAs
     pipe_wait_lgkm<0>(f1a, f1b);
     const unsigned nbase = lds0 + (unsigned)(nxt * BUF);
     const bool more = s + 1 < nslab;
+    const bool filla = s + NS - 1 < nslab;
+    char* const pa = smem + (cur == 0 ? NS - 1 : cur - 1) * BUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1a[i]), __builtin_bit_cast(bf16x8, f1b[j]), acc[i][j], 0, 0, 0);
+      if (filla) ga.issue_piece(pa, wave, i);
       if (more) {
         pipe_read(f0a[i], nbase + fo[0] + ao[i]);
         pipe_read(f0b[i], nbase + fo[0] + bo[i]);
