@@ -464,6 +464,37 @@ __device__ __forceinline__ void gemm_mainloop_hglds3(const bf16_t* __restrict__ 
 }
 
 #if defined(VMMT_EXP_TILE512)
+// HalfOperand through the BUFFER form of the LDS-DMA (buffer_load_dwordx4 ... offen lds, what hipBLASLt's kernels use): the K position is a
+// scalar offset that advances once per slab -- no 64-bit VALU add per request, half the address registers
+template <int ROWS, int NW>
+struct HalfOperandBuf {
+  static constexpr int NP = ROWS / 16, PER = NP / NW;
+  static_assert(NP % NW == 0, "pieces must divide over the waves");
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff[PER];
+  int soff;
+  __device__ __forceinline__ void init(const bf16_t* P, long ld, int row0, int limit, int k0, int wave, int lane) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int row = (wave * PER + j) * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      int g = row0 + row;
+      g = g < limit ? g : limit - 1;
+      voff[j] = (unsigned)((long)g * ld * 2 + chunk * 16);
+    }
+    soff = k0 * 2;
+  }
+  __device__ __forceinline__ void issue_piece(char* lds, int wave, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (g_lds_void_t*)(lds + (wave * PER + j) * 1024), 16, voff[j], soff, 0, 0);
+    if (j == PER - 1) soff += HBK * 2;
+  }
+  __device__ __forceinline__ void issue(char* lds, int wave) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) issue_piece(lds, wave, j);
+  }
+};
+
 // Probe: one wave per SIMD (4 waves of 128 x 128 on a 256 x 256 tile), four 32-deep stages, ONE loop body with a run-time stage index.  The
 // fragment reads are inline assembly with counted lgkmcnt waits (hipcc does not see them: no s_waitcnt vmcnt(0) in front of reads it cannot tell
 // from the LDS-DMA's destinations, no lgkmcnt(0) per group), requested one K-step ahead ACROSS slabs and issued between the MFMAs.
@@ -480,8 +511,8 @@ __device__ __forceinline__ void gemm_mainloop_hglds_pipe(const bf16_t* __restric
   static_assert(TI == 4 && TJ == 4, "written for 128 x 128 per wave");
   constexpr int NS = 4;
   constexpr int ABYTES = BM * HBK * 2, BBYTES = BN * HBK * 2, BUF = ABYTES + BBYTES;
-  using GA = HalfOperand<BM, NW>;
-  using GB = HalfOperand<BN, NW>;
+  using GA = HalfOperandBuf<BM, NW>;
+  using GB = HalfOperandBuf<BN, NW>;
   constexpr int PW = GA::PER + GB::PER;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   GA ga;
@@ -509,11 +540,15 @@ __device__ __forceinline__ void gemm_mainloop_hglds_pipe(const bf16_t* __restric
   if (nslab >= 3) glds_wait_vm<2 * PW>(); else if (nslab == 2) glds_wait_vm<PW>(); else glds_wait_vm<0>();
   __builtin_amdgcn_s_barrier();
   gu32x4 f0a[4], f0b[4], f1a[4], f1b[4];
+  // fragment addresses: one register per operand and K-step + an immediate per 32-row block (2 KiB apart): no VALU add per read
+  const unsigned wa = lds0 + ao[0], wb = lds0 + bo[0];
+#define PIPE_READ1(DST, ADDR, I) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"((I) * 2048) : "memory")
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { pipe_read(f0a[i], lds0 + fo[0] + ao[i]); pipe_read(f0b[i], lds0 + fo[0] + bo[i]); }
+  for (int i = 0; i < 4; ++i) { PIPE_READ1(f0a[i], wa + fo[0], i); PIPE_READ1(f0b[i], wb + fo[0], i); }
   int cur = 0;
   for (int s = 0; s < nslab; ++s) {
-    const unsigned base = lds0 + (unsigned)(cur * BUF);
+    const unsigned off = (unsigned)(cur * BUF);
+    const unsigned a1 = wa + off + fo[1], b1 = wb + off + fo[1];
     const int nxt = cur == NS - 1 ? 0 : cur + 1;
     // ---- K-step 0 of slab s: its fragments were requested one K-step ago; the requests of K-step 1 go out between its MFMAs, and so does the
     //      B half of slab s + 2's LDS-DMA (its A half went out between the MFMAs of the previous K-step: one request per four MFMAs --
@@ -527,8 +562,8 @@ __device__ __forceinline__ void gemm_mainloop_hglds_pipe(const bf16_t* __restric
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0a[i]), __builtin_bit_cast(bf16x8, f0b[j]), acc[i][j], 0, 0, 0);
       if (fillb) gb.issue_piece(pb, wave, i);
-      pipe_read(f1a[i], base + fo[1] + ao[i]);
-      pipe_read(f1b[i], base + fo[1] + bo[i]);
+      PIPE_READ1(f1a[i], a1, i);
+      PIPE_READ1(f1b[i], b1, i);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- slab s + 1 must have landed in every wave's share (only slab s + 2 may still be on its way); behind the barrier every wave is past its
@@ -538,7 +573,8 @@ __device__ __forceinline__ void gemm_mainloop_hglds_pipe(const bf16_t* __restric
     __builtin_amdgcn_s_barrier();
     // ---- K-step 1 of slab s, the requests of slab s + 1 / K-step 0 and the A half of slab s + 3's LDS-DMA between its MFMAs
     pipe_wait_lgkm<0>(f1a, f1b);
-    const unsigned nbase = lds0 + (unsigned)(nxt * BUF);
+    const unsigned noff = (unsigned)(nxt * BUF);
+    const unsigned a0 = wa + noff + fo[0], b0 = wb + noff + fo[0];
     const bool more = s + 1 < nslab;
     const bool filla = s + NS - 1 < nslab;
     char* const pa = smem + (cur == 0 ? NS - 1 : cur - 1) * BUF;
@@ -549,13 +585,14 @@ __device__ __forceinline__ void gemm_mainloop_hglds_pipe(const bf16_t* __restric
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1a[i]), __builtin_bit_cast(bf16x8, f1b[j]), acc[i][j], 0, 0, 0);
       if (filla) ga.issue_piece(pa, wave, i);
       if (more) {
-        pipe_read(f0a[i], nbase + fo[0] + ao[i]);
-        pipe_read(f0b[i], nbase + fo[0] + bo[i]);
+        PIPE_READ1(f0a[i], a0, i);
+        PIPE_READ1(f0b[i], b0, i);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     cur = nxt;
   }
+#undef PIPE_READ1
   __builtin_amdgcn_s_barrier();
 }
 #endif
