@@ -14,8 +14,12 @@ bufs = {
     "NT": (torch.randn(M, K, device="cuda").to(T), K, torch.randn(N, K, device="cuda").to(T), K, L.GEMM_NT),
 }
 Cc = torch.zeros(M, N, device="cuda")
-for tile in (256, 128):
+TILES = [int(x) for x in os.environ.get("TILES", "256,128").split(",")]      # 520 (TN only): the probe build's one-wave-per-SIMD pipeline for K-strided operands
+ref = None
+for tile in TILES:
     for name, (A, lda, B, ldb, lay) in bufs.items():
+        if tile == 520 and name != "TN":
+            continue
         a = L.GemmArgs()
         a.dtype, a.layout, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N, a.K = L.BF16, lay, A.data_ptr(), lda, B.data_ptr(), ldb, Cc.data_ptr(), N, M, N, K
         a.out_f32, a.alpha, a.tile = 1, 1.0, tile
@@ -29,4 +33,11 @@ for tile in (256, 128):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
-        print("tile %d %s: %.1f us  %.0f TFLOP/s" % (tile, name, us, 2.0 * M * N * K / us / 1e6))
+        chk = ""
+        if name == "TN":                       # the layouts share no operands: only TN is checked against torch (bf16 products, f32 sums)
+            if ref is None:
+                ref = torch.matmul(A[:, :M].t().float(), B.float())
+            err = float((Cc - ref).abs().max() / ref.abs().max())
+            assert err < 2e-2, (tile, err)
+            chk = "  (max err %.1e of max)" % err
+        print("tile %d %s: %.1f us  %.0f TFLOP/s%s" % (tile, name, us, 2.0 * M * N * K / us / 1e6, chk))

@@ -119,7 +119,10 @@ __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, long lda, con
                                                              tn, tiles_n);
 #if defined(VMMT_EXP_TILE512)
   } else if constexpr (GL == 6) {
-    gemm_mainloop_hglds_pipe<BM, BN, NT / 64, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
+    if constexpr (A_KC && B_KC)
+      gemm_mainloop_hglds_pipe<BM, BN, NT / 64, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
+    else
+      gemm_mainloop_hglds_pipe_t<BM, BN, NT / 64, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw);
 #endif
   } else if constexpr (GL == 4 || GL == 5) {   // half-depth slabs, both operands K-contiguous (glds_gemm.hpp); 5: four stages
     static_assert((GL != 4 && GL != 5) || (A_KC && B_KC), "the half-depth loop stages K-contiguous operands");
@@ -233,6 +236,10 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
   // (M = 256 products of the inference networks at K = 2048: 20 us instead of 26-32 us); below K = 1024 the 64 x 64
   // configuration starts faster (tools/gemm_ab.py).
 #if defined(VMMT_EXP_TILE512)        // probe (tools/exp_build.sh gemm.hip TILE512): 256 x 256 tiles, 8 waves of 128 x 64, 32-deep slabs, four / three stages
+  if constexpr (sizeof(T) == 2 && !A_KC && !B_KC) {      // 520: probe 518's pipeline for K-strided operands (dWg's layout)
+    if (a->tile == 520 && a->K % 32 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0)
+      return launch_cfg<T, 256, 256, 128, 128, A_KC, B_KC, 32, true, 6>(a, epi, st);
+  }
   if constexpr (sizeof(T) == 2 && A_KC && B_KC) {
     if (a->tile >= 512 && a->tile <= 518 && a->K % 32 == 0 && a->lda % 8 == 0 && a->ldb % 8 == 0) {
       if (a->tile == 512) return launch_cfg<T, 256, 256, 128, 64, A_KC, B_KC, 32, true, 5>(a, epi, st);

@@ -595,6 +595,132 @@ __device__ __forceinline__ void gemm_mainloop_hglds_pipe(const bf16_t* __restric
 #undef PIPE_READ1
   __builtin_amdgcn_s_barrier();
 }
+
+// Probe 520: the same pipeline for K-STRIDED operands (TN: A stored [K][M], B [K][N] -- dWg's layout).  Image of a 32-deep slab of one operand:
+// two sub-images of [32 k-rows][128 columns] (256 B per k-row, 16 chunks of 16 B, chunk ^= (k-row & 3) * 4 on the source side as in GldsOperand),
+// fragments by two ds_read_b64_tr_b16 each (GldsFrag's lane mapping).
+template <int COLS, int NW>
+struct HalfOperandBufT {
+  static constexpr int NP = COLS / 16, PER = NP / NW;           // 1-KiB pieces (4 k-rows x 128 columns) per slab / per wave
+  static_assert(NP % NW == 0 && COLS % 128 == 0, "pieces must divide over the waves");
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff[PER];
+  int soff, sstep;
+  __device__ __forceinline__ void init(const bf16_t* P, long ld, int col0, int limit, int k0, int wave, int lane) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(P), 0, 0x7fffffff, 0x00020000);
+    const int cmax = ((limit - 1) / 8) * 8;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int pc = wave * PER + j, sub = pc >> 3, kq = pc & 7;
+      const int kr = lane >> 4, ch = lane & 15;
+      const int krow = kq * 4 + kr;
+      int col = col0 + sub * 128 + ((ch ^ (kr * 4)) * 8);
+      col = col < cmax ? col : cmax;
+      voff[j] = (unsigned)(((long)krow * ld + col) * 2);
+    }
+    soff = (int)((long)k0 * ld * 2);
+    sstep = (int)(ld * HBK * 2);
+  }
+  __device__ __forceinline__ void issue_piece(char* lds, int wave, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (g_lds_void_t*)(lds + (wave * PER + j) * 1024), 16, voff[j], soff, 0, 0);
+    if (j == PER - 1) soff += sstep;
+  }
+  __device__ __forceinline__ void issue(char* lds, int wave) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) issue_piece(lds, wave, j);
+  }
+};
+typedef unsigned gu32x2_ __attribute__((ext_vector_type(2)));
+template <int BM, int BN, int NW, int TI, int TJ>
+__device__ __forceinline__ void gemm_mainloop_hglds_pipe_t(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
+                                                           long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
+                                                           const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem) {
+  static_assert(TI == 4 && TJ == 4, "written for 128 x 128 per wave");
+  constexpr int NS = 4;
+  constexpr int ABYTES = BM * HBK * 2, BBYTES = BN * HBK * 2, BUF = ABYTES + BBYTES;
+  using GA = HalfOperandBufT<BM, NW>;
+  using GB = HalfOperandBufT<BN, NW>;
+  constexpr int PW = GA::PER + GB::PER;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  GA ga;
+  GB gb;
+  ga.init(A, lda, m0, M, kbeg, wave, lane);
+  gb.init(B, ldb, n0, N, kbeg, wave, lane);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned ta[4], tb[4];                   // this lane's byte offset for 32-column block t of this wave's sub-image (K-step and half: immediates)
+  {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int chunk = t * 4 + 2 * (g & 1) + (pp >> 1);
+      const unsigned o = (unsigned)((8 * (g >> 1) + q) * 256 + ((chunk ^ (q * 4)) * 16) + (pp & 1) * 8);
+      ta[t] = lds0 + (unsigned)((aoff[0] >> 7) * 8192) + o;
+      tb[t] = lds0 + (unsigned)(ABYTES + (boff[0] >> 7) * 8192) + o;
+    }
+  }
+  const int nslab = (kend - kbeg) / HBK;
+  if (nslab <= 0) return;
+#pragma unroll
+  for (int q = 0; q < NS - 1; ++q)
+    if (q < nslab) {
+      ga.issue(smem + q * BUF, wave);
+      gb.issue(smem + q * BUF + ABYTES, wave);
+    }
+  if (nslab >= 3) glds_wait_vm<2 * PW>(); else if (nslab == 2) glds_wait_vm<PW>(); else glds_wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  gu32x2_ f0a[4][2], f0b[4][2], f1a[4][2], f1b[4][2];
+#define PIPET_READ(DST, ADDR, KS)                                                                                          \
+  {                                                                                                                        \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST[0]) : "v"(ADDR), "n"((KS) * 4096) : "memory");           \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST[1]) : "v"(ADDR), "n"((KS) * 4096 + 1024) : "memory");    \
+  }
+#define PIPET_WAIT(F, G)                                                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[3][0]), \
+               "+v"(F[3][1]), "+v"(G[0][0]), "+v"(G[0][1]), "+v"(G[1][0]), "+v"(G[1][1]), "+v"(G[2][0]), "+v"(G[2][1]), "+v"(G[3][0]), "+v"(G[3][1]))
+#define PIPET_FRAG(F) __builtin_bit_cast(bf16x8, __builtin_shufflevector(F[0], F[1], 0, 1, 2, 3))
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { PIPET_READ(f0a[i], ta[i], 0); PIPET_READ(f0b[i], tb[i], 0); }
+  int cur = 0;
+  for (int s = 0; s < nslab; ++s) {
+    const unsigned off = (unsigned)(cur * BUF);
+    const int nxt = cur == NS - 1 ? 0 : cur + 1;
+    PIPET_WAIT(f0a, f0b);
+    const bool fillb = s >= 1 && s + NS - 2 < nslab;
+    char* const pb = smem + (cur >= 2 ? cur - 2 : cur + 2) * BUF + ABYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PIPET_FRAG(f0a[i]), PIPET_FRAG(f0b[j]), acc[i][j], 0, 0, 0);
+      if (fillb) gb.issue_piece(pb, wave, i);
+      PIPET_READ(f1a[i], ta[i] + off, 1);
+      PIPET_READ(f1b[i], tb[i] + off, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s + 2 < nslab) glds_wait_vm<PW>(); else glds_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    PIPET_WAIT(f1a, f1b);
+    const unsigned noff = (unsigned)(nxt * BUF);
+    const bool more = s + 1 < nslab;
+    const bool filla = s + NS - 1 < nslab;
+    char* const pa = smem + (cur == 0 ? NS - 1 : cur - 1) * BUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PIPET_FRAG(f1a[i]), PIPET_FRAG(f1b[j]), acc[i][j], 0, 0, 0);
+      if (filla) ga.issue_piece(pa, wave, i);
+      if (more) {
+        PIPET_READ(f0a[i], ta[i] + noff, 0);
+        PIPET_READ(f0b[i], tb[i] + noff, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cur = nxt;
+  }
+#undef PIPET_READ
+#undef PIPET_WAIT
+#undef PIPET_FRAG
+  __builtin_amdgcn_s_barrier();
+}
 #endif
 
 }  // namespace vmmt
