@@ -494,6 +494,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (one cfg-1-shaped step against the CPU oracle)")
     ap.add_argument("--no-side-stream", action="store_true", help="profiling aid: issue the whole step on one stream")
+    ap.add_argument("--no-overlap-probe", action="store_true", help="profiling aid (tools/prof.sh, tools/pmc.sh): leave out the stream-overlap "
+                    "self-check, whose 13 extra steps -- 6 of them on ONE stream -- would be averaged into a kernel profile of the run")
     ap.add_argument("--conditional", action="store_true", help="the --conditional prior variant (SURVEY.md 8f-1) instead of the fixed prior")
     ap.add_argument("--n-img", type=int, default=0, help="rows of the resident image-feature table (default: the configuration's; 290000 = "
                     "BASELINE config 4's 290 K-triplet set, 1000000 = config 5's synthetic 1 M triplets: 8.2 GB of HBM)")
@@ -587,7 +589,11 @@ def main():
 
     eng.hold_back = True               # a training loop: every update is followed by a forward (TrainerMultimodal._train_loop sets the same)
 
+    executed = {"steps": 0, "one_stream": 0}      # every step this process runs, timed or not: what a profile of the run is averaged over
+
     def step(i):
+        executed["steps"] += 1
+        executed["one_stream"] += 0 if eng.use_side_stream else 1
         src, sl, tgt, idx, tlen, n_tok = batches[i % len(batches)]
         ws = eng.forward(src, sl, tgt, idx, training=True, tgt_len=tlen if a.conditional else None, n_tgt_tokens=n_tok)
         eng.loss_backward(ws, normalization=Bg, batch_global=Bg)
@@ -672,7 +678,7 @@ def main():
     # and persistent kernels that need their workgroups co-resident.  A few steps with everything on ONE stream against a few steps as
     # scheduled: a box (a driver, a queue configuration) on which the packing is lost shows a ratio near 1 and the line says so
     overlap = None
-    if world == 1 and not a.no_side_stream:
+    if world == 1 and not a.no_side_stream and not a.no_overlap_probe:
         def timed_steps(n, first):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
@@ -791,6 +797,9 @@ def main():
             "repeats_ms": [round(r_[0] / a.steps * 1e3, 4) for r_ in regions],
             "repeats_step_median_ms": [step_summary(r_[2], r_[3])[0]["median"] for r_ in regions],
             "slow_steps": slow_steps, "diagnosis": diagnosis, "warmup_run": n_warm, "stream_overlap": overlap,
+            # every step this process has run up to here (plan-building step, overlap probe, warm-up, all timed regions): the divisor of a
+            # per-step kernel profile of this very command (tools/prof.sh reads it; a once-per-step kernel must then show 1.0 calls / step)
+            "steps_executed": dict(executed),
             "host_sched": dict(sched, cpu_quota=cpu_quota(), repeats=[r_[5] for r_ in regions[1:]]),
             "gpu_state": {"before_warmup": state0, "after_each_region": [r_[6] for r_ in regions]},
             "elbo_per_sentence": round(st["elbo"] / B, 4),

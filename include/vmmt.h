@@ -466,22 +466,36 @@ int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 int vmmt_dp_norm_pack(const float* sumsq, const int32_t* guard, float* row, void* stream);
 int vmmt_dp_norm_fold(const float* rows, int world, float* sumsq, int32_t* guard, void* stream);
 
-/* ---- embedding tables: gradient bookkeeping by row -----------------------------------------------------------------------------
- * nn.Embedding tables (modules/Embeddings.py:118,181) receive gradient only in the rows a batch looks up, yet the dense path clears,
- * norms and reads the whole gradient of each table at every step (loss.backward()'s zero-filled .grad, clip_grad_norm, Adam:
- * TrainerMultimodal.py:628-629, Optim.py:94-96).  `flags` int32 [R]: rows of the batch(es) since the last optimiser step.
- *   vmmt_rows_mark      flags[ids[i]] = 1
- *   vmmt_rows_zero      g[r][:] = 0 for flagged rows (before the batch's scatter-add)
+/* ---- embedding tables: exact lazy Adam by row -----------------------------------------------------------------------------------
+ * nn.Embedding tables (modules/Embeddings.py:118,181) receive gradient only in the rows a batch looks up, yet the reference clears,
+ * norms and updates every element of each table at every step (loss.backward()'s zero-filled .grad, clip_grad_norm, torch.optim.Adam:
+ * TrainerMultimodal.py:628-629, Optim.py:68-70,94-96): 36 B per element.  A row WITHOUT gradient still moves under Adam (m *= beta1,
+ * v *= beta2, p -= step(m, v)), but that step depends only on the row's own state and the step's scalars: these entry points apply it
+ * later, with the dense kernel's arithmetic in the dense kernel's order -- parameters and moments are BIT-identical to vmmt_adam_step
+ * on a gradient that is zero outside the batch's rows (tests/test_gpu_row_adam.py) -- and touch only the rows a batch uses plus a
+ * rolling 1 / roll of the table per step (no row is ever more than ~roll steps behind, whatever the distribution of the ids).
+ *   flags int32 [R]                      generation numbers: row r is flagged for update t when flags[r] == t; never cleared
+ *   last  int32 [R]                      the optimiser step each row is current for
+ *   hist  int32 [VMMT_LAZY_HIST_WORDS]   [0] the last recorded step, [1] error word (0 = fine: a replay never met an overwritten
+ *                                        entry), then a ring of VMMT_LAZY_HIST (step_size, 1 / sqrt(bc2), applied, step) entries
+ *   vmmt_rows_mark      flags[ids[i]] = hist[0] + 1 (the next update)
+ *   vmmt_rows_catchup   mode 0: flagged rows are brought up to step hist[0] and their gradient rows cleared (between vmmt_rows_mark and
+ *                       the lookup / the backward's scatter-add); mode 1: EVERY row is brought up to hist[0] (flush: checkpoints,
+ *                       evaluation, before the dense kernels take over)
  *   vmmt_sumsq_rows     ||g||^2 over the flagged rows into slot `slot` of the norm scratch (deterministic); rowsq f32 [R] scratch
- *   vmmt_adam_rows_step vmmt_adam_step over the WHOLE table (every row moves under Adam, with or without gradient), reading g for
- *                       flagged rows only (zero elsewhere); clears the flags.  Bit-identical to vmmt_adam_step on a gradient that
- *                       is zero outside the flagged rows.  C % 4 == 0, rows 16-byte aligned.  skip: as vmmt_adam_step (the flags are
- *                       kept then). */
-int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, void* stream);
-int vmmt_rows_zero(float* g, int R, int C, const int32_t* flags, void* stream);
-int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, float lr, float beta1, float beta2,
-                        float eps, int step, float max_norm, const float* sumsq, float grad_scale, const int32_t* skip, void* stream);
-int vmmt_sumsq_rows(const float* g, int R, int C, const int32_t* flags, float* rowsq, float* scratch, int slot, void* stream);
+ *   vmmt_adam_rows_step update `step` (= hist[0] + 1): flagged rows with their gradient, rows r % roll == step % roll without one
+ *                       (roll = 0: none; <= VMMT_LAZY_HIST / 4), records the step in the ring.  skip: as vmmt_adam_step -- the step
+ *                       is recorded as skipped and replays leave it out.  C % 4 == 0, p / g / m / v 16-byte aligned. */
+#define VMMT_LAZY_HIST 128
+#define VMMT_LAZY_HIST_WORDS (4 + 4 * VMMT_LAZY_HIST)
+int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, const int32_t* hist, void* stream);
+int vmmt_rows_catchup(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last, int32_t* hist,
+                      float beta1, float beta2, float eps, int mode, void* stream);
+int vmmt_adam_rows_step(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last, int32_t* hist,
+                        float lr, float beta1, float beta2, float eps, int step, int roll, float max_norm, const float* sumsq,
+                        float grad_scale, const int32_t* skip, void* stream);
+int vmmt_sumsq_rows(const float* g, int R, int C, const int32_t* flags, const int32_t* hist, float* rowsq, float* scratch, int slot,
+                    void* stream);
 
 #ifdef __cplusplus
 }

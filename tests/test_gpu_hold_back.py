@@ -21,7 +21,7 @@ def _engine(c, p, after_head, hold, dtype="bf16", rows=False):
     e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype=dtype, device="cuda", seed=3)
     e.bg_after_head = after_head
     e.hold_back = hold
-    e.row_adam = rows                                 # (the opt-in row bookkeeping of the embedding tables: its flags are read by the update)
+    e.row_adam = rows                                 # (the lazy update of the embedding tables: the held-back half carries the target table's share)
     assert e.rows_active() == rows
     e.load_state_dict(p)
     return e

@@ -19,6 +19,8 @@ STAT_COUNT = 8
 SUMSQ_SLOTS, SUMSQ_MAXBLOCKS = 8, 768
 SEQ_GUARD_WORD = 4 + 2 * 256                                        # vmmt.h: VMMT_SEQ_GUARD_WORD
 SUMSQ_SCRATCH = 2 * SUMSQ_SLOTS + SUMSQ_SLOTS * SUMSQ_MAXBLOCKS      # vmmt.h: VMMT_SUMSQ_SCRATCH
+LAZY_HIST = 128                                                     # vmmt.h: VMMT_LAZY_HIST
+LAZY_HIST_WORDS = 4 + 4 * LAZY_HIST                                  # vmmt.h: VMMT_LAZY_HIST_WORDS
 
 vp, i64, i32, f32, u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
 
@@ -127,10 +129,10 @@ _SIGS = {
     "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp, vp, vp]),
     "vmmt_dp_norm_pack": (i32, [vp, vp, vp, vp]),
     "vmmt_dp_norm_fold": (i32, [vp, i32, vp, vp, vp]),
-    "vmmt_rows_mark": (i32, [vp, i64, vp, i32, vp]),
-    "vmmt_rows_zero": (i32, [vp, i32, i32, vp, vp]),
-    "vmmt_adam_rows_step": (i32, [vp, vp, vp, vp, i32, i32, vp, f32, f32, f32, f32, i32, f32, vp, f32, vp, vp]),
-    "vmmt_sumsq_rows": (i32, [vp, i32, i32, vp, vp, vp, i32, vp]),
+    "vmmt_rows_mark": (i32, [vp, i64, vp, i32, vp, vp]),
+    "vmmt_rows_catchup": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, i32, vp]),
+    "vmmt_adam_rows_step": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, f32, i32, i32, f32, vp, f32, vp, vp]),
+    "vmmt_sumsq_rows": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp]),
 }
 
 EXPORTS = sorted(_SIGS)

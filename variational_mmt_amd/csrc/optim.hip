@@ -69,7 +69,11 @@ __device__ __forceinline__ void adam_elem(float& p, float ge, float& m, float& v
                                           float inv_sqrt_bc2) {
   m = b1 * m + (1.f - b1) * ge;
   v = b2 * v + (1.f - b2) * ge * ge;
-  p -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+  // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sqrtf and division, which expand to ~35 instructions per element:
+  // the dense kernel hides them under its HBM streams, the lazy rows' replays (no memory traffic between steps) were bound by them -- 31 us
+  // of catch-up in front of the lookups.  The update term carries a relative error of ~2e-7: 5e-10 of a parameter at lr 0.002, below
+  // half an ulp of the parameter it is subtracted from.  (denominator >= eps = 1e-9: a normal number; a denormal v flushes to 0 < eps ulp)
+  p -= (step_size * m) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * inv_sqrt_bc2 + eps);
 }
 #pragma clang fp contract(fast)
 
@@ -137,43 +141,164 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Embedding tables: gradient bookkeeping by ROW.  An embedding table [R][C] receives gradient in the rows of the current batch only
-// (<= 5120 of 30 000 at the benchmark shape), but the dense path clears, norms and reads the whole 60 MB gradient of each table every
-// step.  With one flag per row (set for the batch's rows by rows_mark_kernel) only the flagged rows' gradient is cleared
-// (rows_zero_kernel), summed into the norm (rows_sumsq_kernel) and read by the update (adam_rows_kernel: g = 0 for the other rows
-// without touching memory).  EVERY row is still updated at every step with the dense kernel's arithmetic (adam_elem): a row without
-// gradient moves under Adam too (its moments decay, the parameter follows them), so results are bit-identical to the dense kernels.
-// (A lazy variant -- rows brought up to date only when a batch uses them, replaying the missed zero-gradient steps -- was built and
-//  measured: bit-identical as well and 1.5 % faster on the benchmark's eight recurring batches, but on Zipf-distributed word ids most
-//  rows come back after hundreds of steps and the replays -- a sqrt and a division per element and missed step, on the critical path in
-//  front of the embedding lookup -- cost more than the 28 B/element they save: 2.11 against 1.92 ms per step through the trainer.)
-__global__ void rows_mark_kernel(const long long* __restrict__ ids, long n, int* __restrict__ flags, int R) {
+// Embedding tables: EXACT LAZY Adam by row.  An embedding table [R][C] receives gradient in the rows of the current batch only
+// (<= 5120 of 30 000 at the benchmark shape), yet the dense path clears, norms and streams p, m, v, g of the whole table at every step:
+// 36 B per element.  A row without gradient still moves under dense Adam (its moments decay, the parameter follows them) -- but that
+// zero-gradient step depends on nothing but the row's own m, v and the step's scalars, so it can be applied LATER, bit for bit:
+//   last[r]         the optimiser step row r is current for
+//   hist            a ring of the last VMMT_LAZY_HIST steps' scalars (step_size, 1 / sqrt(bias correction 2), applied or skipped)
+//   flags[r]        generation number: row r is "flagged" for the update t when flags[r] == t (nothing ever clears a flag)
+// rows_mark flags the batch's rows, rows_catchup replays the zero-gradient steps last + 1 .. t - 1 of the flagged rows in registers
+// (adam_elem with g = 0: the dense kernel's arithmetic in the dense kernel's order) in front of the lookup and clears their gradient rows,
+// the update touches the flagged rows -- and a ROLLING 1 / roll of the table (rows r % roll == t % roll), so that no row is ever more
+// than ~roll steps behind: the replay in front of a lookup stays a few microseconds whatever the distribution of the word ids (the
+// first lazy variant, rounds 1-3, replayed hundreds of steps for the rare words of a Zipf distribution and lost what it saved).
+#define VMMT_LAZY_HDR 4
+__device__ __forceinline__ const float* lazy_entry(const int* hist, int s) { return reinterpret_cast<const float*>(hist + VMMT_LAZY_HDR + 4 * (s & (VMMT_LAZY_HIST - 1))); }
+
+__global__ void rows_mark_kernel(const long long* __restrict__ ids, long n, int* __restrict__ flags, int R, const int* __restrict__ hist) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long long id = ids[i];
-  if (id >= 0 && id < R) flags[id] = 1;
+  if (id >= 0 && id < R) flags[id] = hist[0] + 1;
 }
 
-// g[r][:] = 0 for the flagged rows (one wave per row; the rows are about to receive this batch's scatter-add)
-__global__ void __launch_bounds__(256) rows_zero_kernel(float* __restrict__ g, int R, int C, const int* __restrict__ flags) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= R || !flags[row]) return;
-  float* x = g + (long)row * C;
-  for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<f32x4*>(x + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-}
+// The row kernels share one shape: a workgroup owns a block of 64 rows -- every wave reads the block's flags / `last` words with one
+// coalesced load each and ballots the rows that have work -- and its waves take those rows in turn, a whole row per wave (C / 4 lanes x
+// 16 bytes per array and pass).  One wave per (row, chunk) over the whole table meant 60 000 waves of which 50 000 found nothing to do
+// after three dependent memory round trips each: 69 us for an update that moves 90 MB.
+#define VMMT_ROWS_WAVES 8
 
-// Adam over a whole table, one wave per row; the gradient is read for flagged rows only (zero elsewhere); flags are cleared
-__global__ void __launch_bounds__(256) adam_rows_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, int R, int C, int* __restrict__ flags, float b1, float b2,
-                                                        float eps, float step_size, float inv_sqrt_bc2, float max_norm,
-                                                        const float* __restrict__ sumsq, float grad_scale, int* __restrict__ skip) {
-  if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1);
-    return;
+// the scalars of the steps from + 1 .. from + n (n <= 64) out of the ring: lane j takes step from + 1 + j's entry -- ONE load per wave
+// instead of one per replayed step (a memory round trip of 1-3 us in every iteration of a loop whose arithmetic takes 0.2 us)
+__device__ __forceinline__ f32x4 lazy_entries(const int* __restrict__ hist, int from, int n) {
+  const int lane = threadIdx.x & 63;
+  f32x4 en = {0.f, 0.f, 0.f, 0.f};
+  if (lane < n) en = *reinterpret_cast<const f32x4*>(lazy_entry(hist, from + 1 + lane));
+  return en;
+}
+// ... and the zero-gradient steps themselves on four elements per lane, the scalars handed round by v_readlane (all 64 lanes take part:
+// lanes beyond the row's end carry zeros).  An entry that has been overwritten (a row further behind than the ring is long: the caller's
+// rolling / flush policy was not kept) sets the error word instead of applying another step's scalars.
+__device__ __forceinline__ void lazy_replay(f32x4& pp, f32x4& mm, f32x4& vv, const f32x4& en, int from, int n, int* __restrict__ hist, float b1,
+                                            float b2, float eps) {
+  for (int j = 0; j < n; ++j) {
+    const float ss = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(en[0]), j));
+    const float ib = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(en[1]), j));
+    const float applied = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(en[2]), j));
+    const int sid = __builtin_amdgcn_readlane(__float_as_int(en[3]), j);
+    if (sid != from + 1 + j) { if ((threadIdx.x & 63) == 0) hist[1] = from + 1 + j; continue; }
+    if (applied == 0.f) continue;             // a step the guard word skipped: nothing moved
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = pp[e], me = mm[e], ve = vv[e];
+      adam_elem(pe, 0.f, me, ve, ss, b1, b2, eps, ib);
+      pp[e] = pe; mm[e] = me; vv[e] = ve;
+    }
   }
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= R) return;
-  const bool has_g = flags[row] != 0;
+}
+
+// one row brought from step `from` up to `upto` by zero-gradient steps and -- STEP -- through the update `upto + 1` with gradient
+// g * coef (has_g) or without one; ZERO_G: the row's gradient is cleared.  Two 256-column chunks per pass, their loads issued together.
+template <bool STEP, bool ZERO_G>
+__device__ __forceinline__ void lazy_row(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long base, int C,
+                                         int from, int upto, int* __restrict__ hist, float b1, float b2, float eps, bool has_g, float coef,
+                                         float step_size, float inv_sqrt_bc2) {
+  const int lane = threadIdx.x & 63;
+  const bool behind = from < upto;
+  if (!STEP && !behind && !ZERO_G) return;
+  for (int cb = 0; cb < C; cb += 512) {
+    const int ca = cb + lane * 4, cc = ca + 256;
+    const bool la = ca < C, lb = cc < C;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pa = z4, ma = z4, va = z4, ga = z4, pb = z4, mb = z4, vb = z4, gb = z4;
+    if (STEP || behind) {
+      if (la) { pa = *reinterpret_cast<f32x4*>(p + base + ca); ma = *reinterpret_cast<f32x4*>(m + base + ca); va = *reinterpret_cast<f32x4*>(v + base + ca); }
+      if (lb) { pb = *reinterpret_cast<f32x4*>(p + base + cc); mb = *reinterpret_cast<f32x4*>(m + base + cc); vb = *reinterpret_cast<f32x4*>(v + base + cc); }
+      if (STEP && has_g) {
+        if (la) ga = *reinterpret_cast<const f32x4*>(g + base + ca);
+        if (lb) gb = *reinterpret_cast<const f32x4*>(g + base + cc);
+      }
+      for (int f0 = from; f0 < upto; f0 += 64) {              // (at most one round under the rolling policy)
+        const int n = upto - f0 < 64 ? upto - f0 : 64;
+        const f32x4 en = lazy_entries(hist, f0, n);
+        lazy_replay(pa, ma, va, en, f0, n, hist, b1, b2, eps);
+        if (cc - lane * 4 < C) lazy_replay(pb, mb, vb, en, f0, n, hist, b1, b2, eps);
+      }
+      if (STEP) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pe = pa[e], me = ma[e], ve = va[e];
+          adam_elem(pe, ga[e] * coef, me, ve, step_size, b1, b2, eps, inv_sqrt_bc2);
+          pa[e] = pe; ma[e] = me; va[e] = ve;
+          pe = pb[e]; me = mb[e]; ve = vb[e];
+          adam_elem(pe, gb[e] * coef, me, ve, step_size, b1, b2, eps, inv_sqrt_bc2);
+          pb[e] = pe; mb[e] = me; vb[e] = ve;
+        }
+      }
+      if (la) { *reinterpret_cast<f32x4*>(p + base + ca) = pa; *reinterpret_cast<f32x4*>(m + base + ca) = ma; *reinterpret_cast<f32x4*>(v + base + ca) = va; }
+      if (lb) { *reinterpret_cast<f32x4*>(p + base + cc) = pb; *reinterpret_cast<f32x4*>(m + base + cc) = mb; *reinterpret_cast<f32x4*>(v + base + cc) = vb; }
+    }
+    if (ZERO_G) {
+      if (la) *reinterpret_cast<f32x4*>(g + base + ca) = z4;
+      if (lb) *reinterpret_cast<f32x4*>(g + base + cc) = z4;
+    }
+  }
+}
+
+// mode 0: the flagged rows (flags[r] == hist[0] + 1) are brought up to step hist[0] and their gradient rows cleared -- call between
+// rows_mark and the lookup / the backward's scatter-add; mode 1: every row is brought up to hist[0] (flush: before anything else reads
+// the table -- checkpoints, evaluation, the dense kernels)
+template <int MODE>
+__global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_catchup_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                                            float* __restrict__ v, int R, int C, const int* __restrict__ flags,
+                                                                            int* __restrict__ last, int* __restrict__ hist, float b1, float b2, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r0 = blockIdx.x * 64;
+  const int upto = hist[0];
+  int lst = upto;
+  bool act = false;
+  if (r0 + lane < R) {
+    lst = last[r0 + lane];
+    act = MODE == 0 ? flags[r0 + lane] == upto + 1 : lst < upto;
+  }
+  unsigned long long todo = __ballot(act);
+  for (int k = 0; todo; ++k) {
+    const int b = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    if (k % VMMT_ROWS_WAVES != wave) continue;
+    const int from = __builtin_amdgcn_readlane(lst, b);
+    lazy_row<false, MODE == 0>(p, g, m, v, (long)(r0 + b) * C, C, from, upto, hist, b1, b2, eps, false, 0.f, 0.f, 0.f);
+    if (lane == 0 && from < upto) last[r0 + b] = upto;
+  }
+}
+
+// the update `step`: flagged rows take their gradient (after any zero-gradient steps still missing), the rolling rows
+// (r % roll == step % roll, not flagged) are brought up to `step` without one; workgroup 0 records the step in the ring.
+// A skipped step (guard word set) is recorded as such and changes nothing else.
+__global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                                         float* __restrict__ v, int R, int C, const int* __restrict__ flags,
+                                                                         int* __restrict__ last, int* __restrict__ hist, int step, int roll, float b1, float b2,
+                                                                         float eps, float step_size, float inv_sqrt_bc2, float max_norm,
+                                                                         const float* __restrict__ sumsq, float grad_scale, int* __restrict__ skip) {
+  const bool skipped = skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float* en = const_cast<float*>(lazy_entry(hist, step));
+    en[0] = step_size; en[1] = inv_sqrt_bc2; en[2] = skipped ? 0.f : 1.f; en[3] = __int_as_float(step);
+    hist[0] = step;         // (read by the NEXT forward's mark / catch-up launches only: nothing in this launch looks at it)
+    if (skipped) atomicAdd(skip + 1, 1);
+  }
+  if (skipped) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r0 = blockIdx.x * 64;
+  int lst = step;
+  bool hg = false, act = false;
+  if (r0 + lane < R) {
+    lst = last[r0 + lane];
+    hg = flags[r0 + lane] == step;
+    act = hg || (roll > 0 && (r0 + lane) % roll == step % roll && lst < step);
+  }
+  unsigned long long todo = __ballot(act);
+  const unsigned long long with_g = __ballot(hg);
+  if (!todo) return;
   float coef = grad_scale;
   if (max_norm > 0.f) {
     float ss = 0.f;
@@ -182,39 +307,35 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(float* __restrict__ p, c
     const float c = max_norm / (sqrtf(ss) * grad_scale + 1e-6f);
     if (c < 1.f) coef *= c;
   }
-  const long base = (long)row * C;
-  for (int c0 = lane * 4; c0 < C; c0 += 256) {
-    f32x4 pp = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + base + c0));
-    f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + base + c0));
-    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + base + c0));
-    f32x4 gg = {0.f, 0.f, 0.f, 0.f};
-    if (has_g) gg = *reinterpret_cast<const f32x4*>(g + base + c0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float pe = pp[e], me = mm[e], ve = vv[e];
-      adam_elem(pe, gg[e] * coef, me, ve, step_size, b1, b2, eps, inv_sqrt_bc2);
-      pp[e] = pe; mm[e] = me; vv[e] = ve;
-    }
-    __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(p + base + c0));
-    __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m + base + c0));
-    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + base + c0));
+  for (int k = 0; todo; ++k) {
+    const int b = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    if (k % VMMT_ROWS_WAVES != wave) continue;
+    const int from = __builtin_amdgcn_readlane(lst, b);
+    lazy_row<true, false>(p, g, m, v, (long)(r0 + b) * C, C, from, step - 1, hist, b1, b2, eps, (with_g >> b) & 1, coef, step_size, inv_sqrt_bc2);
+    if (lane == 0) last[r0 + b] = step;
   }
-  if (lane == 0 && has_g) flags[row] = 0;
 }
 
-// ||g||^2 over the flagged rows (the other rows hold zeros): per-row sums by one wave each, then ONE workgroup adds the R row sums in a
-// fixed order into the slot total: deterministic, like sumsq_kernel
-__global__ void __launch_bounds__(256) rows_sumsq_kernel(const float* __restrict__ g, int R, int C, const int* __restrict__ flags,
-                                                         float* __restrict__ rowsq) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= R) return;
-  float a = 0.f;
-  if (flags[row]) {
-    const float* x = g + (long)row * C;
+// ||g||^2 over the flagged rows (the other rows hold whatever an earlier step left): per-row sums by one wave each, then ONE workgroup
+// adds the R row sums in a fixed order into the slot total: deterministic, like sumsq_kernel
+__global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_sumsq_kernel(const float* __restrict__ g, int R, int C, const int* __restrict__ flags,
+                                                                          const int* __restrict__ hist, float* __restrict__ rowsq) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r0 = blockIdx.x * 64;
+  const int gen = hist[0] + 1;
+  const bool act = r0 + lane < R && flags[r0 + lane] == gen;
+  if (wave == 0 && r0 + lane < R && !act) rowsq[r0 + lane] = 0.f;
+  unsigned long long todo = __ballot(act);
+  for (int k = 0; todo; ++k) {
+    const int b = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    if (k % VMMT_ROWS_WAVES != wave) continue;
+    const float* x = g + (long)(r0 + b) * C;
+    float a = 0.f;
     for (int c = lane * 4; c < C; c += 256) { const f32x4 q = *reinterpret_cast<const f32x4*>(x + c); a += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]; }
     a = wave_sum(a);
+    if (lane == 0) rowsq[r0 + b] = a;
   }
-  if (lane == 0) rowsq[row] = a;
 }
 __global__ void __launch_bounds__(1024) rows_sumsq_total_kernel(const float* __restrict__ rowsq, int R, float* __restrict__ total) {
   // a fixed order with independent loads in flight (a chain of 30 dependent loads per thread cost 17 us)
@@ -277,40 +398,48 @@ extern "C" int vmmt_dp_norm_fold(const float* rows, int world, float* sumsq, int
   return check_launch();
 }
 
-extern "C" int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, void* stream) {
+extern "C" int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, const int32_t* hist, void* stream) {
   using namespace vmmt;
-  if (!ids || !flags || n < 0 || R <= 0) return VMMT_EINVAL;
+  if (!ids || !flags || !hist || n < 0 || R <= 0) return VMMT_EINVAL;
   if (n == 0) return VMMT_OK;
-  hipLaunchKernelGGL(rows_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, (long)n, flags, R);
+  hipLaunchKernelGGL(rows_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, (long)n, flags, R, hist);
   return check_launch();
 }
 
-extern "C" int vmmt_rows_zero(float* g, int R, int C, const int32_t* flags, void* stream) {
+static bool lazy_rows_ok(const void* p, const void* g, const void* m, const void* v, int R, int C) {
+  return p && m && v && R > 0 && C > 0 && C % 4 == 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+}
+
+extern "C" int vmmt_rows_catchup(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last, int32_t* hist,
+                                 float beta1, float beta2, float eps, int mode, void* stream) {
   using namespace vmmt;
-  if (!g || !flags || R <= 0 || C <= 0 || C % 4 != 0 || (((uintptr_t)g) & 15)) return VMMT_EINVAL;
-  hipLaunchKernelGGL(rows_zero_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, R, C, flags);
+  if (!lazy_rows_ok(p, g, m, v, R, C) || !last || !hist || (mode != 0 && mode != 1) || (mode == 0 && (!flags || !g))) return VMMT_EINVAL;
+  const dim3 grid((unsigned)((R + 63) / 64)), block(64 * VMMT_ROWS_WAVES);
+  if (mode == 0) hipLaunchKernelGGL(rows_catchup_kernel<0>, grid, block, 0, (hipStream_t)stream, p, g, m, v, R, C, flags, last, hist, beta1, beta2, eps);
+  else hipLaunchKernelGGL(rows_catchup_kernel<1>, grid, block, 0, (hipStream_t)stream, p, g, m, v, R, C, flags, last, hist, beta1, beta2, eps);
   return check_launch();
 }
 
-extern "C" int vmmt_adam_rows_step(float* p, const float* g, float* m, float* v, int R, int C, int32_t* flags, float lr, float beta1,
-                                   float beta2, float eps, int step, float max_norm, const float* sumsq, float grad_scale, const int32_t* skip,
-                                   void* stream) {
+extern "C" int vmmt_adam_rows_step(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last,
+                                   int32_t* hist, float lr, float beta1, float beta2, float eps, int step, int roll, float max_norm,
+                                   const float* sumsq, float grad_scale, const int32_t* skip, void* stream) {
   using namespace vmmt;
-  if (!p || !g || !m || !v || !flags || R <= 0 || C <= 0 || C % 4 != 0 || step < 1 || (max_norm > 0.f && !sumsq) ||
-      ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15))
+  if (!lazy_rows_ok(p, g, m, v, R, C) || !g || !flags || !last || !hist || step < 1 || roll < 0 || roll > VMMT_LAZY_HIST / 4 ||
+      (max_norm > 0.f && !sumsq))
     return VMMT_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));        // as vmmt_adam_step
-  hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, R, C, flags, beta1, beta2,
-                     eps, step_size, inv_sqrt_bc2, max_norm, sumsq, grad_scale, const_cast<int*>(skip));
+  hipLaunchKernelGGL(adam_rows_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64 * VMMT_ROWS_WAVES), 0, (hipStream_t)stream, p, g, m, v, R, C, flags,
+                     last, hist, step, roll, beta1, beta2, eps, step_size, inv_sqrt_bc2, max_norm, sumsq, grad_scale, const_cast<int*>(skip));
   return check_launch();
 }
 
-extern "C" int vmmt_sumsq_rows(const float* g, int R, int C, const int32_t* flags, float* rowsq, float* scratch, int slot, void* stream) {
+extern "C" int vmmt_sumsq_rows(const float* g, int R, int C, const int32_t* flags, const int32_t* hist, float* rowsq, float* scratch, int slot,
+                               void* stream) {
   using namespace vmmt;
-  if (!g || !flags || !rowsq || !scratch || R <= 0 || C <= 0 || slot < 0 || slot >= VMMT_SUMSQ_SLOTS || (((uintptr_t)g) & 15) || C % 4 != 0)
+  if (!g || !flags || !hist || !rowsq || !scratch || R <= 0 || C <= 0 || slot < 0 || slot >= VMMT_SUMSQ_SLOTS || (((uintptr_t)g) & 15) || C % 4 != 0)
     return VMMT_EINVAL;
-  hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, R, C, flags, rowsq);
+  hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64 * VMMT_ROWS_WAVES), 0, (hipStream_t)stream, g, R, C, flags, hist, rowsq);
   hipLaunchKernelGGL(rows_sumsq_total_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rowsq, R, scratch + slot);
   return check_launch();
 }

@@ -135,7 +135,12 @@ class GradSync(object):
                 self.sharded = False               # torch's dense optimisers (-optim sgd|adagrad|adadelta) read the whole reduced gradient
             if engine is not None and engine.dp is None:
                 # an error here must stop the run: `world` / `rank` set without `engine.dp` would train unsynchronised replicas
-                engine.drop_workspaces()           # (plans built for one process carry the row-wise gradient bookkeeping of the embedding tables: engine._build_row_tables)
+                # plans built for one process carry the lazy row-wise update of the embedding tables (engine._build_row_tables): every
+                # row is brought up to date and the tables' gradients cleared before the dense, sharded optimiser takes over
+                engine.flush_lazy_rows()
+                engine.drop_workspaces()
+                for t in engine.row_tables:
+                    engine.flat_g[t["off"]:t["end"]].zero_()
                 engine.dp = self
                 # the seed is shared (identical initial parameters); the noise streams must not be: each replica draws
                 # its own eps ~ N(0, I) and dropout masks (counter-based RNG: disjoint counter ranges per rank)

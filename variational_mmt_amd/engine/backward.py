@@ -259,7 +259,7 @@ class BackwardPlan(object):
         e._allreduce(P, "generator.0.weight", "decoder.attn.linear_out.weight")
         # the generator's share of the gradient norm (a quarter of the arena) right behind its product, on this stream, instead of in the
         # norm of the whole first half at the end of the decoder's parameter gradients (slot 7: free outside the conditional model)
-        gen_norm_early = bool(not d.conditional and not e.rows_active() )
+        gen_norm_early = bool(not d.conditional)
         if gen_norm_early:
             e._sumsq_entry(P, "generator.0.weight", "decoder.attn.linear_out.weight", 7)
         if main_first:

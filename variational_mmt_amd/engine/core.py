@@ -23,6 +23,8 @@ def _behind_background(name):
         dd = self.__dict__
         if dd.get("_pending_bg") and not dd.get("_in_flush"):
             self.wait_background()
+        if dd.get("_lazy_dirty") and not dd.get("_in_step"):
+            self.flush_lazy_rows()          # (the embedding tables' rows are brought up to date lazily: _build_row_tables)
         try:
             return dd[priv]
         except KeyError:
@@ -61,7 +63,8 @@ class Engine(StepAPI):
         self.ws_evictions = 0
         self._shared = {}
         self.shadows_dirty = True
-        self.step_count = 0          # Adam step counter
+        self._step_count = 0         # Adam step counter (property step_count: the lazy embedding tables follow a value set from outside)
+        self._adam_consts = (0.9, 0.999, 1e-9)      # beta1, beta2, eps of the run (Optim.py:68-70); optim_step refuses to change them under lazy rows
         self.seed = seed
         self.rng_counter = 1234567 + seed      # dp.GradSync offsets it by the rank: eps / dropout masks differ between replicas
         # H2: as executed the reference detaches the latent sample (Dists.py:21-26, Models.py:930-933): mu / sigma get gradient only
@@ -165,14 +168,61 @@ class Engine(StepAPI):
         self.seq_fallbacks, self.steps_skipped, self._adam_launches, self._guard_clear_pending = 0, 0, 1, False
         self.dp = None               # dp.GradSync when torch.distributed runs with > 1 rank
         self._works = []
-        # ONE switch for experiments instead of one per schedule knob: VMMT_ENGINE_ATTRS="bg_adam_blocks=224,aux_early=0" sets attributes of
-        # this object (the schedule knobs above: what tools/ab.py sets programmatically) before the first plan is built
-        for kv in filter(None, _os_env.get("VMMT_ENGINE_ATTRS", "").split(",")):
-            k, _, v = kv.partition("=")
-            if not hasattr(self, k.strip()):
-                raise RuntimeError("VMMT_ENGINE_ATTRS: the engine has no attribute %r" % k.strip())
-            cur = getattr(self, k.strip())
-            setattr(self, k.strip(), (v.strip() not in ("0", "false", "False", "")) if isinstance(cur, bool) else type(cur)(v.strip()))
+        # ONE switch for experiments instead of one per schedule knob: VMMT_ENGINE_ATTRS="bg_adam_blocks=224;aux_early=0" sets schedule
+        # attributes of this object (what tools/ab.py sets programmatically) before the first plan is built.  Only the knobs listed
+        # in _ATTR_KNOBS, each with its parser; pairs are separated by ';' (or ',': tools/ab_env.sh separates its ARMS by commas)
+        for kv in filter(None, _os_env.get("VMMT_ENGINE_ATTRS", "").replace(";", ",").split(",")):
+            k, _, v = (x.strip() for x in kv.partition("="))
+            if k not in self._ATTR_KNOBS:
+                raise RuntimeError("VMMT_ENGINE_ATTRS: %r is not a schedule knob of the engine (knobs: %s)" % (k, ", ".join(sorted(self._ATTR_KNOBS))))
+            try:
+                setattr(self, k, self._ATTR_KNOBS[k](v))
+            except ValueError:
+                raise RuntimeError("VMMT_ENGINE_ATTRS: %s=%r does not parse as %s" % (k, v, self._ATTR_KNOBS[k].__name__))
+        gone = sorted(n for n in _os_env if n in self._REMOVED_SWITCHES)
+        if gone:
+            import sys
+            print("[vmmt] WARNING: %s no longer exist as environment switches and are IGNORED; the schedule knobs are attributes now: "
+                  "VMMT_ENGINE_ATTRS=\"name=value;...\" (DESIGN.md section 10)" % ", ".join(gone), file=sys.stderr, flush=True)
+
+    def _knob_bool(v):
+        if v.lower() in ("1", "true", "on", "yes"):
+            return True
+        if v.lower() in ("0", "false", "off", "no", ""):
+            return False
+        raise ValueError(v)
+    _knob_bool.__name__ = "bool"
+    # the schedule knobs an experiment may set through VMMT_ENGINE_ATTRS (name -> parser); everything else is refused
+    _ATTR_KNOBS = dict(
+        bg_adam_blocks=int, fg_adam_blocks=int, max_split_k=int, wgrad_target_tiles=int, lazy_roll=int, shape_bucket=int,
+        cond_aux_early=_knob_bool, cond_emb_fg=_knob_bool, aux_early=_knob_bool, aux_kl_first=_knob_bool, gen_db_in_gemm=_knob_bool,
+        lstm_db_in_gemm=_knob_bool, dec_grads_on_aux=_knob_bool, bwd_main_first=_knob_bool, bwd_layers_parallel=_knob_bool,
+        group_wgrads=_knob_bool, use_side_stream=_knob_bool, use_aux_stream=_knob_bool, gen_compact=_knob_bool, q_parallel=_knob_bool,
+        dec_gx_first=_knob_bool, zero_on_aux=_knob_bool, split_optim=_knob_bool, bg_after_head=_knob_bool, hold_back=_knob_bool,
+        fused_qnet=_knob_bool, qnet_split=_knob_bool, gen_fused=_knob_bool, persistent_lstm=_knob_bool, seq_fallback=_knob_bool,
+        row_adam=_knob_bool, reparam_grad=_knob_bool)
+    # environment switches of rounds 2-4 that became attributes (or went with their kernels) in round 5: setting one is a mistake worth a line
+    _REMOVED_SWITCHES = frozenset((
+        "VMMT_LATENT_ZX", "VMMT_FUSE_OUT_DROPOUT", "VMMT_DECODE_GRAPHS", "VMMT_BG_ADAM_BLOCKS", "VMMT_FG_ADAM_BLOCKS", "VMMT_MAX_SPLIT_K",
+        "VMMT_WGRAD_TARGET_TILES", "VMMT_AUX_EARLY", "VMMT_AUX_KL_FIRST", "VMMT_COND_AUX_EARLY", "VMMT_COND_EMB_FG", "VMMT_COND_EMB_FIRST",
+        "VMMT_COND_DEC_STEPS", "VMMT_GEN_DB_IN_GEMM", "VMMT_LSTM_DB_IN_GEMM", "VMMT_DEC_GRADS_ON_AUX", "VMMT_BWD_MAIN_FIRST",
+        "VMMT_BWD_LAYERS_PARALLEL", "VMMT_QPAR", "VMMT_QNET_SPLIT", "VMMT_FUSED_QNET", "VMMT_AUX_STREAM", "VMMT_SPLIT_OPTIM", "VMMT_GEN_COMPACT",
+        "VMMT_FUSE_DB", "VMMT_DEFER_BG_ADAM", "VMMT_PAD_HIDDEN", "VMMT_LAZY_EMB_ADAM"))
+
+    @property
+    def use_side_stream(self):
+        return self._use_side_stream
+
+    @use_side_stream.setter
+    def use_side_stream(self, on):
+        """changed between steps (bench.py's overlap self-check, a profiling run): a held-back half of the last update goes out first and the
+        device drains -- in single-stream mode the plans skip every cross-stream wait, `opt_side_done` included, so work still running on
+        the side / aux streams would race the next step's main-stream kernels"""
+        on = bool(on)
+        if "_use_side_stream" in self.__dict__ and on != self._use_side_stream and hasattr(self, "ws"):
+            self.wait_background()
+            torch.cuda.synchronize(self.dev)
+        self._use_side_stream = on
 
     @property
     def tgt_stream(self):
@@ -248,34 +298,42 @@ class Engine(StepAPI):
 
     # ------------------------------------------------------------------------------------------------ embedding tables by row
     def _build_row_tables(self):
-        """Row-wise gradient bookkeeping for the two embedding tables (csrc/optim.hip: vmmt_rows_mark / _zero / vmmt_sumsq_rows /
+        """EXACT LAZY Adam for the two embedding tables (csrc/optim.hip, include/vmmt.h: vmmt_rows_mark / _catchup / vmmt_sumsq_rows /
         vmmt_adam_rows_step).  The tables are 54 % of the optimised parameters and a step's gradient lives in the <= S B + T' B rows
-        the batch looked up (17 % of 30 000 at the benchmark shape): with one flag per row, the gradient is cleared, normed and read
-        for those rows only -- 12 of the 36 B per element and step the dense path moves (4 zeroing + 4 norm + 28 Adam), and the
-        zero-fill and the norm stop touching 200 MB each.  Every row is still UPDATED at every step (the moments of a row without
-        gradient decay, its parameter follows them): bit-identical to dense Adam (tests/test_gpu_row_adam.py).  Off under data
-        parallelism (the flagged set would have to be the union over the ranks) and for the conditional model (two streams flag
-        rows of the shared target table).
-        OPT-IN (Engine.row_adam = True): measured on MI355X it does not pay at these sizes -- 1.787 against 1.746 ms per step at BASELINE
-        config 2, 2.704 against 2.728 at the run scripts' shape, 1.867 against 1.863 through the trainer: the dense streams run at
-        6.7 TB/s, half of them underneath the next step's encoder, while the row kernels add six small launches to the step's head
-        and tail.  (The LAZY variant -- rows updated only when used, missed zero-gradient steps replayed -- saves 0.7 GB per step and
-        was 1.5 % faster on the benchmark's recurring batches, but with Zipf-distributed ids the replays (sqrt + division per element
-        and missed step, in front of the embedding lookup) cost more than the traffic: 2.11 against 1.92 ms through the trainer.  Not
-        kept: LABNOTES.md, rounds 1-3, section 6.)"""
+        the batch looked up (17 % of 30 000 at the benchmark shape), yet torch.optim.Adam (Optim.py:68-70,94-96) -- and the dense
+        kernels here -- clear, norm and stream all of g, p, m, v at every step: 36 B per element, 1.08 of the step's 2.2 GB.  A row
+        without gradient still moves under Adam (its moments decay, the parameter follows them), but that zero-gradient step needs
+        nothing but the row's own state and the step's scalars: it is applied LATER with the dense kernel's arithmetic in the dense
+        kernel's order, so parameters and moments stay bit-identical to the dense update (tests/test_gpu_row_adam.py):
+          * the training forward flags the batch's rows and brings them up to date in front of the lookup (mark + catch-up), clearing
+            their gradient rows for the backward's scatter-add;
+          * the norm and the update touch the flagged rows -- and a ROLLING 1 / lazy_roll of each table per step, so that no row is
+            ever more than lazy_roll steps behind: the replay in front of a lookup is a few microseconds whatever the distribution of
+            the word ids.  (Rounds 1-3 had the lazy update without that bound: with Zipf-distributed ids the rare words' rows came
+            back after hundreds of steps and their replays, in front of the lookup, cost more than the traffic saved.)
+          * everything that reads the tables from outside a training step -- state_dict(), `engine.params / flat_p / flat_m / flat_v`,
+            evaluation and decoding plans, checkpoints, the dense optimisers, data parallelism -- flushes first (every row up to date).
+        Off under data parallelism (the flagged set would have to be the union over the ranks) and for the conditional model (two
+        streams flag rows of the shared target table).  `Engine.row_adam = False` restores the dense kernels."""
         names = ("encoder.embeddings.make_embedding.emb_luts.0.weight", "decoder.embeddings.make_embedding.emb_luts.0.weight")
-        self._row_adam = False               # (Engine.row_adam = True switches it on: measured slower, see above)
+        self._row_adam = False
+        self._lazy_dirty = False             # rows behind the step counter exist (an update has run since the last flush)
+        self._in_step = 0                    # > 0: inside forward / loss_backward / optim_step / a flush (reads of the arena are the engine's own)
+        self.lazy_roll = 16                  # every row is brought up to date at least every `lazy_roll` updates (<= LAZY_HIST / 4)
         self.row_tables = []
         if self.d.conditional:
             return
-        for n in names:          # (the flag arrays are always there -- 240 KB -- so that the switch can be set after construction)
+        for n in names:          # (the bookkeeping arrays are always there -- 0.5 MB -- so that the switch can be set after construction)
             off, (R, Cc) = self.offsets[n]
             if Cc % 4 or off % 4:
                 self._row_adam, self.row_tables = False, []
                 return
             self.row_tables.append(dict(name=n, off=off, R=R, C=Cc, end=off + R * Cc,
                                         flags=torch.zeros(R, dtype=torch.int32, device=self.dev),
+                                        last=torch.zeros(R, dtype=torch.int32, device=self.dev),
+                                        hist=torch.zeros(L.LAZY_HIST_WORDS, dtype=torch.int32, device=self.dev),
                                         rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev)))
+        self._row_adam = _os_env.get("VMMT_ROW_ADAM", "1") == "1"
 
     @property
     def row_adam(self):
@@ -283,19 +341,56 @@ class Engine(StepAPI):
 
     @row_adam.setter
     def row_adam(self, on):
-        """the switch may be set after construction: the cached launch plans carry (or omit) the row mark / zero / norm entries, and with
-        the bookkeeping OFF the dense kernels expect a fully cleared table gradient -- rows flagged by earlier batches still hold theirs
-        (vmmt_rows_zero clears the CURRENT batch's rows only).  So a change drops the plans and clears the tables' gradients and flags"""
+        """the switch may be set after construction: the cached launch plans carry (or omit) the row entries; switched OFF, every row is
+        brought up to date first and the dense kernels find fully cleared table gradients; switched ON, every row is current for the
+        step counter as it stands"""
         on = bool(on) and not self.d.conditional and bool(self.row_tables)
         if on == getattr(self, "_row_adam", False):
             return
-        self._row_adam = on
         if hasattr(self, "ws"):
+            self.flush_lazy_rows()          # (no-op unless the lazy path has run)
             self._flush_bg()
             self.drop_workspaces()
+        self._row_adam = on
+        if hasattr(self, "ws"):
+            self._lazy_reset(self._step_count)
             for t in self.row_tables:
                 self.flat_g[t["off"]:t["end"]].zero_()
-                t["flags"].zero_()
+
+    def _lazy_reset(self, n):
+        """every row of the tables is current for step n (fresh moments, a loaded optimiser state, after a flush)"""
+        for t in self.row_tables:
+            t["last"].fill_(int(n))
+            t["flags"].zero_()
+            t["hist"].zero_()
+            t["hist"][0] = int(n)
+        self._lazy_dirty = False
+
+    @property
+    def step_count(self):
+        """Adam's step counter (Optim.py: the optimiser's `state['step']`)"""
+        return self._step_count
+
+    @step_count.setter
+    def step_count(self, n):
+        """set from outside: a new Adam (0), a loaded optimiser state, a twin engine in a test.  The lazy tables follow: rows are
+        brought up to date for the OLD counter first, then declared current for the new one.  (The guard's roll-back of skipped steps
+        goes through _step_rollback: those steps moved nothing, a row's `last` is clamped instead.)"""
+        n = int(n)
+        if getattr(self, "row_tables", None) and hasattr(self, "ws"):
+            self.flush_lazy_rows()
+            self._lazy_reset(n)
+        self._step_count = n
+
+    def _step_rollback(self, n):
+        """the step counter goes BACK to n: the updates n + 1 .. were skipped on the device (guard word) and are numbered again.  They
+        are recorded as skipped in the tables' rings and moved nothing: a row that is 'current' for one of them is current for n"""
+        n = max(0, int(n))
+        if self.row_tables and n < self._step_count:
+            for t in self.row_tables:
+                t["last"].clamp_(max=n)
+                t["hist"][0] = n
+        self._step_count = n
 
     def dp_on(self):
         """collectives are part of the step: torch.distributed with > 1 rank (or the forced one-rank rehearsal, dp.GradSync)"""
@@ -304,14 +399,41 @@ class Engine(StepAPI):
     def rows_active(self):
         return bool(self.row_tables) and self.row_adam and not self.dp_on()
 
+    def flush_lazy_rows(self, stream=None):
+        """every row of the embedding tables up to date for the step counter (vmmt_rows_catchup, mode 1), on the current stream behind
+        both halves of the last update.  Called by everything that reads the tables outside a training step; no-op when nothing is behind."""
+        if not self.__dict__.get("_lazy_dirty") or not self.row_tables:
+            return
+        self._in_step += 1
+        try:
+            self._lazy_dirty = False
+            self.wait_background()
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            b1, b2, eps = self._adam_consts
+            for t in self.row_tables:
+                o = 4 * t["off"]
+                L.check(self.lib.vmmt_rows_catchup(self.flat_p.data_ptr() + o, None, self.flat_m.data_ptr() + o, self.flat_v.data_ptr() + o,
+                                                   t["R"], t["C"], None, t["last"].data_ptr(), t["hist"].data_ptr(), b1, b2, eps, 1, st),
+                        "vmmt_rows_catchup")
+        finally:
+            self._in_step -= 1
+
+    def lazy_errors(self):
+        """error words of the tables' rings (0 = no replay ever met an overwritten entry); synchronises"""
+        return [int(t["hist"][1].item()) for t in self.row_tables]
+
     def _row_mark_entries(self, plan, table_index, ids_ptr, n_ids):
-        """plan entries (training forward, off the critical path): flag the batch's rows of an embedding table and clear their
-        gradient rows, which the backward plan's scatter-add accumulates into"""
+        """plan entries (training forward, IN FRONT of the table's lookup): flag the batch's rows, bring them up to date and clear
+        their gradient rows, which the backward plan's scatter-add accumulates into"""
         if not self.rows_active():
             return
         t = self.row_tables[table_index]
-        self._call(plan, self.lib.vmmt_rows_mark, ids_ptr, n_ids, t["flags"].data_ptr(), t["R"])
-        self._call(plan, self.lib.vmmt_rows_zero, self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr())
+        o = 4 * t["off"]
+        b1, b2, eps = self._adam_consts
+        self._call(plan, self.lib.vmmt_rows_mark, ids_ptr, n_ids, t["flags"].data_ptr(), t["R"], t["hist"].data_ptr())
+        self._call(plan, self.lib.vmmt_rows_catchup, self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o,
+                   self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(), t["hist"].data_ptr(),
+                   b1, b2, eps, 0)
 
     def pp(self, name, r=0, c=0):
         o, shp = self.offsets[name]
@@ -324,7 +446,10 @@ class Engine(StepAPI):
         return self.flat_g.data_ptr() + (o + r * ld + c) * 4
 
     def wait_background(self, stream=None):
-        """`stream` (default: the current one) waits for the half of the last optimiser step that runs on the side stream"""
+        """`stream` (default: the current one) waits for the half of the last optimiser step that runs on the side stream; called from
+        outside a step (whoever is about to read parameters), the lazily updated embedding rows are brought up to date as well"""
+        if self.__dict__.get("_lazy_dirty") and not self._in_step:
+            self.flush_lazy_rows()
         self._flush_bg()
         for name in ("opt_side_done", "opt_gen_done"):
             ev = self.global_events.get(name)
@@ -685,7 +810,7 @@ class Engine(StepAPI):
         self.persistent_lstm = False
         self.seq_syncs = []
         self.drop_workspaces()
-        self.step_count = max(0, self.step_count - skipped)       # Adam's step counter: those updates never happened
+        self._step_rollback(self._step_count - skipped)           # Adam's step counter: those updates never happened
         if in_step:
             # called from optim_step: the step at hand ran its recurrences on the persistent kernels as well (they may have timed out
             # too, and the synchronisation above has just let them finish): the guard stays set through THIS update -- skipped on the
@@ -721,11 +846,15 @@ class Engine(StepAPI):
     def _publish_guard(self, stream):
         """end of an optimiser step, on the stream that carries its last Adam launch: clear the guard if the host has just dealt with it,
         refresh the host's pinned copy"""
-        with torch.cuda.stream(stream):
-            if getattr(self, "_guard_clear_pending", False):
+        if getattr(self, "_guard_clear_pending", False):
+            with torch.cuda.stream(stream):
                 self._guard.zero_()
-                self._guard_clear_pending = False
-                self.step_count = max(0, self.step_count - 1)      # (the update that was skipped with the guard still set)
+            self._guard_clear_pending = False
+            # (the update that was skipped with the guard still set.  Rare: the lazy tables' bookkeeping goes back with the device idle)
+            torch.cuda.synchronize(self.dev)
+            self._step_rollback(self._step_count - 1)
+            torch.cuda.synchronize(self.dev)
+        with torch.cuda.stream(stream):
             k = self._guard_pub % 3
             self._guard_host[k].copy_(self._guard, non_blocking=True)
             self._guard_events[k].record(stream)
@@ -848,8 +977,8 @@ class Engine(StepAPI):
             if name == "SUMSQ_ROWS":
                 k, slot = args
                 t = self.row_tables[k]
-                L.check(self.lib.vmmt_sumsq_rows(self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr(), t["rowsq"].data_ptr(),
-                                                 self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq_rows")
+                L.check(self.lib.vmmt_sumsq_rows(self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr(), t["hist"].data_ptr(),
+                                                 t["rowsq"].data_ptr(), self._sumsq.data_ptr(), slot, hs[sid]), "vmmt_sumsq_rows")
                 return
             if name == "KL_ALLREDUCE":
                 # (only the free-bits test reads the KL sum -- latent_bwd_kernel: without it the latent backward needs nothing from the other

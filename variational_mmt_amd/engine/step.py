@@ -27,6 +27,15 @@ class StepAPI(object):
         Tp = int(tgt.shape[0]) - 1
         if S > 256:
             raise RuntimeError("source length %d > 256 not supported by the attention kernels" % S)
+        if not training:
+            self.flush_lazy_rows()          # (evaluation plans look rows up without the lazy tables' mark / catch-up entries)
+        self._in_step += 1
+        try:
+            return self._forward(src, src_len, tgt, img_indices, training, eps, masks, table, tgt_len, n_tgt_tokens, S, B, Tp)
+        finally:
+            self._in_step -= 1
+
+    def _forward(self, src, src_len, tgt, img_indices, training, eps, masks, table, tgt_len, n_tgt_tokens, S, B, Tp):
         ws = self.workspace(B, S, Tp)
         st = self.stream()
         self.refresh_shadows(st)
@@ -114,14 +123,18 @@ class StepAPI(object):
         # the gradient arena was zeroed by the training forward plan (side stream); zero_grad=False is meaningless here
         if not ws.training:
             raise RuntimeError("loss_backward() after an eval-mode forward")
-        if ws._loss_patch is not None:          # fused generator: the statistics pass writes dO = dL/dO scaled by 1 / normalization
-            ii, pos = ws._loss_patch
-            fn, args, name, keep, sid = ws.plan_loss_train[ii]
-            ws.plan_loss_train[ii] = (fn, args[:pos] + (float(1.0 / norm),) + args[pos + 1:], name, keep, sid)
-        self._run(ws.plan_loss_train, ws.events)
-        plan = ws.backward_plan(1.0 / norm, bg, kl_mult, use_freebits, margin, bool(ws.training))
-        self._cur_ws = ws
-        self._run(plan, ws.events)
+        self._in_step += 1
+        try:
+            if ws._loss_patch is not None:          # fused generator: the statistics pass writes dO = dL/dO scaled by 1 / normalization
+                ii, pos = ws._loss_patch
+                fn, args, name, keep, sid = ws.plan_loss_train[ii]
+                ws.plan_loss_train[ii] = (fn, args[:pos] + (float(1.0 / norm),) + args[pos + 1:], name, keep, sid)
+            self._run(ws.plan_loss_train, ws.events)
+            plan = ws.backward_plan(1.0 / norm, bg, kl_mult, use_freebits, margin, bool(ws.training))
+            self._cur_ws = ws
+            self._run(plan, ws.events)
+        finally:
+            self._in_step -= 1
         return ws
 
     def read_stats(self, ws, batch_global=None, kl_mult=1.0, use_freebits=False, margin=0.0):
@@ -144,6 +157,13 @@ class StepAPI(object):
         The arena is updated in two halves: [encoder | inference networks] on the current stream (the next forward needs
         them first), [generator | attention | decoder] on the side stream, where it overlaps the next step's encoder
         phase; the forward plan waits on `opt_side_done` before it touches decoder-side weights."""
+        self._in_step += 1
+        try:
+            return self._optim_step(lr, max_grad_norm, beta1, beta2, eps, grad_scale)
+        finally:
+            self._in_step -= 1
+
+    def _optim_step(self, lr, max_grad_norm, beta1, beta2, eps, grad_scale):
         main = torch.cuda.current_stream(self.dev)
         st = main.cuda_stream
         self._flush_bg()                # (two updates without a forward between them)
@@ -165,7 +185,7 @@ class StepAPI(object):
                     if t["off"] > cur:
                         L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr() + 4 * cur, t["off"] - cur, self._sumsq.data_ptr(), slot, st), "vmmt_sumsq")
                         slot += 1
-                    L.check(self.lib.vmmt_sumsq_rows(self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr(),
+                    L.check(self.lib.vmmt_sumsq_rows(self.flat_g.data_ptr() + 4 * t["off"], t["R"], t["C"], t["flags"].data_ptr(), t["hist"].data_ptr(),
                                                      t["rowsq"].data_ptr(), self._sumsq.data_ptr(), 3 + self.row_tables.index(t), st), "vmmt_sumsq_rows")
                     cur = t["end"]
                 if self.n_opt > cur:
@@ -173,7 +193,7 @@ class StepAPI(object):
             else:
                 L.check(self.lib.vmmt_sumsq(self.flat_g.data_ptr(), self.n_opt, self._sumsq.data_ptr(), 0, st), "vmmt_sumsq")
         self._sumsq_by_plan = False
-        self.step_count += 1
+        self._step_count += 1
         split = self.offsets[self.first_enc_name][0]
         emb_fg = bool(self.d.conditional and self.cond_emb_fg)
         if emb_fg:
@@ -193,12 +213,21 @@ class StepAPI(object):
                 n_launch[0] += 1
 
         rows = self.rows_active()
+        if rows:
+            if (beta1, beta2, eps) != self._adam_consts:
+                # the replayed zero-gradient steps use the run's betas / eps: a change brings every row up to date under the old ones first
+                self.flush_lazy_rows()
+                self._adam_consts = (beta1, beta2, eps)
+                self.drop_workspaces()          # (the catch-up entries of the forward plans carry them)
+            self._lazy_dirty = True
+        roll = int(self.lazy_roll)
 
         def rows_step(t, stream):
             o = 4 * t["off"]
             L.check(self.lib.vmmt_adam_rows_step(self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o,
-                                                 self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), lr, beta1, beta2, eps,
-                                                 t_adam, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale, guard, stream),
+                                                 self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(),
+                                                 t["hist"].data_ptr(), lr, beta1, beta2, eps, t_adam, roll, float(max_grad_norm or 0.0),
+                                                 self._sumsq.data_ptr(), grad_scale, guard, stream),
                     "vmmt_adam_rows_step")
             n_launch[0] += 1
 
@@ -280,7 +309,7 @@ class StepAPI(object):
         guard = self._guard.data_ptr()
         n_launch = [0]
         dp.timed_wait("gradient_wait", self.finish_allreduce)      # the reduce-scatters of the backward plan
-        self.step_count += 1
+        self._step_count += 1
         segs = self.segments
         own = [dp.shard(lo, hi) for lo, hi in segs]
         if len(self._normed) != len(segs):      # (normally the backward plan normed every segment's shard behind its reduce-scatter)

@@ -183,6 +183,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
         # side-stream half of the last optimiser step (BG_FLUSH) and the side stream's own work, the decoder's input projection first
         early_head = bool(training and e.bg_after_head and not d.conditional and e.use_side_stream)
         if early_head:
+            e._row_mark_entries(P, 0, self.src.data_ptr(), MS)
             e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                     self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
             wih, bsum = e.sh["enc_wih_l0"], e.sh["enc_b_l0"]
@@ -192,15 +193,14 @@ class Workspace(BackwardPlan, ConditionalPlans):
             P.append((None, None, "BG_FLUSH", None, MAIN))
 
         def side_dec_gx():
+            if training:
+                # the lazily updated embedding tables (Engine._build_row_tables): flag this batch's rows, bring them up to date and clear
+                # their gradient rows IN FRONT of the lookup; this stream carried the table's share of the last update
+                e._row_mark_entries(P, 1, self.tgt_in.data_ptr(), M)
             e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                     self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
             we = e.sh["dec_wih_l0_e"]
             e._gemm(P, L.GEMM_NT, self.Xt.p(), self.Xt.ld, we.p(), we.ld, self.dec_gx[0].p(), self.dec_gx[0].ld, M, 4 * Hp, E, out_f32=1)
-            if training:
-                # row-wise gradient bookkeeping of the embedding tables: flag this batch's rows and clear their gradient rows -- for the
-                # backward plan's scatter-adds and the optimiser step; in front of `dec_gx`, which every later stream waits for
-                e._row_mark_entries(P, 1, self.tgt_in.data_ptr(), M)
-                e._row_mark_entries(P, 0, self.src.data_ptr(), MS)
             e._record(P, "dec_gx")
         # ---- side stream, underneath the encoder: zero the gradient arena (every gradient writer of the backward plan
         #      runs on the side stream), target embeddings and the time-parallel part of the decoder input projection
@@ -231,7 +231,7 @@ class Workspace(BackwardPlan, ConditionalPlans):
             # the generator weight gradient (first in the arena, a third of it) is WRITTEN by its one GEMM, not accumulated
             # ... together with the small accumulators of the backward plan (off the critical path instead of in front of
             # their users): one launch
-            if e.rows_active():        # the tables' gradient rows are cleared row by row (vmmt_rows_zero)
+            if e.rows_active():        # the tables' gradient rows are cleared row by row (vmmt_rows_catchup)
                 g_ranges, lo = [], e.offsets["generator.0.bias"][0]
                 for t in sorted(e.row_tables, key=lambda t: t["off"]):
                     g_ranges.append(e.flat_g[lo:t["off"]])
@@ -272,6 +272,8 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._sid = MAIN
         # a2 source embeddings
         if not early_head:
+            if training:
+                e._row_mark_entries(P, 0, self.src.data_ptr(), MS)
             e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                     self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
         # a3 encoder
