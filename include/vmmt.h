@@ -400,10 +400,13 @@ int vmmt_zero_multi(const vmmt_zero_desc* descs, int n, int total_chunks, void* 
 
 /* batch preparation in one launch: ids -> workspace, tgt[:-1] / tgt[1:] (Models.py:867, VILoss.py:205), lengths, image row
  * indices, statistics reset, optional eps ~ N(0,I) (eps may be NULL).  src [S][B], tgt [T][B], all int64 device arrays.
- * The workspace may hold more positions than the batch (S_ws >= S, T_ws >= T): the rest is filled with `pad`. */
+ * The workspace may hold more positions than the batch (S_ws >= S, T_ws >= T): the rest is filled with `pad`.
+ * flags_src / flags_tgt (optional, int32 [2][R_*]): row flags of the lazily updated embedding tables (see vmmt_rows_mark below) -- every
+ * row the batch looks up (o_src, o_tin: the pad row of bucketed positions included) is flagged for the update `gen` (>= 1). */
 int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const int64_t* src_len, const int64_t* idx, int S, int T, int B,
                        int S_ws, int T_ws, int pad, int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len, int64_t* o_idx,
-                       float* stats, float* eps, int64_t n_eps, uint64_t seed, void* stream);
+                       float* stats, float* eps, int64_t n_eps, uint64_t seed, int32_t* flags_src, int R_src, int32_t* flags_tgt,
+                       int R_tgt, int gen, void* stream);
 
 /* ---- beam search (translation) --------------------------------------------------------------------------------
  * One position of Beam.advance (onmt/translate/Beam.py:63-121) for all B sentences of a decoding batch of K*B rows
@@ -474,11 +477,14 @@ int vmmt_dp_norm_fold(const float* rows, int world, float* sumsq, int32_t* guard
  * later, with the dense kernel's arithmetic in the dense kernel's order -- parameters and moments are BIT-identical to vmmt_adam_step
  * on a gradient that is zero outside the batch's rows (tests/test_gpu_row_adam.py) -- and touch only the rows a batch uses plus a
  * rolling 1 / roll of the table per step (no row is ever more than ~roll steps behind, whatever the distribution of the ids).
- *   flags int32 [R]                      generation numbers: row r is flagged for update t when flags[r] == t; never cleared
+ *   flags int32 [2][R]                   generation numbers: row r is flagged for update t when flags[t & 1][r] == t; never cleared
+ *                                        (two arrays by parity: vmmt_prepare_batch flags the next batch while a half of the last update,
+ *                                        on another stream, still reads its own)
  *   last  int32 [R]                      the optimiser step each row is current for
  *   hist  int32 [VMMT_LAZY_HIST_WORDS]   [0] the last recorded step, [1] error word (0 = fine: a replay never met an overwritten
  *                                        entry), then a ring of VMMT_LAZY_HIST (step_size, 1 / sqrt(bc2), applied, step) entries
- *   vmmt_rows_mark      flags[ids[i]] = hist[0] + 1 (the next update)
+ *   vmmt_rows_mark      flags[g & 1][ids[i]] = g with g = hist[0] + 1, the next update (vmmt_prepare_batch does the same for a batch's
+ *                       source and target ids with the update number passed by the host)
  *   vmmt_rows_catchup   mode 0: flagged rows are brought up to step hist[0] and their gradient rows cleared (between vmmt_rows_mark and
  *                       the lookup / the backward's scatter-add); mode 1: EVERY row is brought up to hist[0] (flush: checkpoints,
  *                       evaluation, before the dense kernels take over)

@@ -260,3 +260,80 @@ def test_probe_reports_its_branch_and_attach_errors_are_fatal(tmp_path):
         assert r["log"] and r["log"][0][0] == "reduce_scatter" and r["log"][0][1] == ("native" if r["rs_native"] else "fallback"), r
         assert r["strict_raised"] == (not r["rs_native"]), r          # VMMT_DP_NATIVE=1: no silent fallback
         assert r["forced_fallback"] and r["attach_raised"] and r["dense_not_sharded"], r
+
+
+class _FakeRccl(object):
+    """stand-in for librccl in the bring-up protocol of dp._Rccl: the calls the stages make, each able to fail on chosen ranks"""
+    def __init__(self, rank, fail_uid=False, fail_init=False):
+        import ctypes as C
+        self.rank, self.fail_uid, self.fail_init, self.destroyed = rank, fail_uid, fail_init, 0
+
+        class _Fn(object):
+            def __init__(s, f):
+                s.f = f
+
+            def __call__(s, *a):
+                return s.f(*a)
+        self.ncclGetUniqueId = _Fn(lambda p: 1 if self.fail_uid else (C.memmove(p, b"\x07" * 128, 128) and 0))
+        self.ncclCommInitRank = _Fn(lambda pc, world, uid, rank: 5 if self.fail_init else self._init(pc, uid))
+        self.ncclCommDestroy = _Fn(self._destroy)
+        self.ncclGetErrorString = _Fn(lambda rc: b"stand-in error %d" % rc)
+        self.ncclReduceScatter = self.ncclAllGather = self.ncclAllReduce = _Fn(lambda *a: 0)
+
+    def _init(self, pc, uid):
+        import ctypes as C
+        assert bytes(uid.internal)[:1] in (b"\x07", b"")          # the id rank 0 drew reached this rank
+        C.cast(pc, C.POINTER(C.c_void_p))[0] = 0x1234
+        return 0
+
+    def _destroy(self, comm):
+        self.destroyed += 1
+        return 0
+
+
+def _worker_bringup(rank, world, port, out):
+    """whatever fails during the direct communicator's bring-up, on whichever rank, EVERY rank leaves it the same way
+    (an exception -> the run stays on torch.distributed) and none is left alone in a blocking call"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from variational_mmt_amd.dp import _Rccl
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    cases = {"fine": {}, "uid_fails_on_rank0": dict(fail_uid=(rank == 0)), "init_fails_on_rank1": dict(fail_init=(rank == 1)),
+             "library_missing_on_rank1": "missing" if rank == 1 else {}}
+    for name, kw in cases.items():
+        lib = kw if kw == "missing" else _FakeRccl(rank, **kw)
+        try:
+            r = _Rccl(dist, torch.device("cpu"), lib=lib)
+            res[name] = ("up", r.comm.value if r.comm else None)
+            r.close()
+            res[name] += (lib.destroyed,)
+        except RuntimeError as ex:
+            res[name] = ("raised", "this rank" in str(ex), getattr(lib, "destroyed", None))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+def test_direct_rccl_bringup_fails_on_every_rank_or_on_none(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 26100 + (os.getpid() % 700)
+    mp.spawn(_worker_bringup, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out)
+    assert r0["fine"] == ("up", 0x1234, 1) and r1["fine"] == ("up", 0x1234, 1)            # communicator created, destroyed by close()
+    for case, culprit in (("uid_fails_on_rank0", 0), ("init_fails_on_rank1", 1), ("library_missing_on_rank1", 1)):
+        for rank, r in enumerate((r0, r1)):
+            assert r[case][0] == "raised" and r[case][1] == (rank == culprit), (case, rank, r[case])
+    assert r0["init_fails_on_rank1"][2] == 1        # the rank whose communicator did come up destroys it again
+
+
+def test_direct_rccl_is_opt_in(monkeypatch):
+    """until a multi-GPU parity run has passed, a data-parallel job uses torch.distributed's collectives unless it asks for the direct calls"""
+    import inspect
+    from variational_mmt_amd import dp
+    src = inspect.getsource(dp.GradSync.__init__)
+    assert 'os.environ.get("VMMT_DP_DIRECT", "0") == "1"' in src

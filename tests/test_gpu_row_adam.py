@@ -26,7 +26,7 @@ def test_lazy_rows_kernels_bit_identical_to_dense_adam(R, Cc, roll):
     dense = dict(p=p0.clone(), m=torch.zeros_like(p0), v=torch.zeros_like(p0))
     lazy = dict(p=p0.clone(), m=torch.zeros_like(p0), v=torch.zeros_like(p0))
     grad_d, grad_l = torch.zeros_like(p0), torch.full_like(p0, 77.0)      # (the lazy path never reads a gradient row it has not cleared itself)
-    flags = torch.zeros(R, dtype=torch.int32, device=dev)
+    flags = torch.zeros(2 * R, dtype=torch.int32, device=dev)        # [parity of the update][row]
     last = torch.zeros(R, dtype=torch.int32, device=dev)
     hist = torch.zeros(L.LAZY_HIST_WORDS, dtype=torch.int32, device=dev)
     rowsq = torch.zeros(R, dtype=torch.float32, device=dev)
@@ -57,7 +57,7 @@ def test_lazy_rows_kernels_bit_identical_to_dense_adam(R, Cc, roll):
         L.check(lib.vmmt_rows_mark(ids_d.data_ptr(), ids_d.numel(), flags.data_ptr(), R, hist.data_ptr(), st), "mark")
         catchup(0)
         torch.cuda.synchronize()
-        assert int(hist[0]) == step - 1 and int((flags == step).sum()) >= rows.numel()
+        assert int(hist[0]) == step - 1 and int((flags.view(2, R)[step & 1] == step).sum()) >= rows.numel()
         assert (grad_l[rows] == 0).all()
         # the rows about to be looked up are current: equal to the dense parameters right now
         for k in ("p", "m", "v"):
@@ -113,7 +113,7 @@ def test_lazy_rows_ring_overrun_is_reported():
     R, Cc = 8, 8
     p = torch.ones(R, Cc, device=dev)
     m, v, g = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
-    flags = torch.zeros(R, dtype=torch.int32, device=dev)
+    flags = torch.zeros(2 * R, dtype=torch.int32, device=dev)
     last = torch.zeros(R, dtype=torch.int32, device=dev)
     hist = torch.zeros(L.LAZY_HIST_WORDS, dtype=torch.int32, device=dev)
     sq = torch.zeros(L.SUMSQ_SCRATCH, dtype=torch.float32, device=dev)
@@ -192,8 +192,8 @@ def test_engine_lazy_rows_equal_dense_over_many_steps(dtype):
         for e in (a, b):
             assert torch.equal(e.params[name][idle].cpu(), p[name][idle]), name
     names = [en[2] for en in a.workspace(6, 5, 5).plan_fwd_train]
-    assert names.count("vmmt_rows_mark") == 2 and names.count("vmmt_rows_catchup") == 2
-    for k in ("vmmt_rows_mark", "vmmt_rows_catchup"):
+    assert names.count("vmmt_rows_catchup") == 2           # (the rows are flagged by vmmt_prepare_batch)
+    for k in ("vmmt_rows_catchup",):
         assert names.index(k) < names.index("vmmt_gather_rows")       # in front of the lookups
         assert k not in [en[2] for en in a.workspace(6, 5, 5).plan_fwd_eval]
         assert k not in [en[2] for en in b.workspace(6, 5, 5).plan_fwd_train]

@@ -118,7 +118,7 @@ _SIGS = {
     "vmmt_image_loss": (i32, [i32, vp, i64, vp, i64, i32, i32, f32, vp, i64, vp, vp]),
     "vmmt_pack": (i32, [i32, vp, vp, i64, vp, i64, i32, i32, i32, vp]),
     "vmmt_pack_multi": (i32, [vp, i32, i32, vp]),
-    "vmmt_prepare_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, u64, vp]),
+    "vmmt_prepare_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, u64, vp, i32, vp, i32, i32, vp]),
     "vmmt_zero_multi": (i32, [vp, i32, i32, vp]),
     "vmmt_beam_advance_ws_bytes": (i64, [i32, i32, i32]),
     "vmmt_beam_advance": (i32, [vp, i64, i32, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp]),

@@ -373,11 +373,23 @@ __global__ void prepare_batch_kernel(const long long* __restrict__ src, const lo
                                      int S_ws, int T_ws, long long pad,
                                      long long* __restrict__ o_src, long long* __restrict__ o_tin, long long* __restrict__ o_y,
                                      long long* __restrict__ o_len, long long* __restrict__ o_idx, float* __restrict__ stats,
-                                     float* __restrict__ eps, long n_eps, unsigned long long seed) {
+                                     float* __restrict__ eps, long n_eps, unsigned long long seed, int* __restrict__ flags_src, int R_src,
+                                     int* __restrict__ flags_tgt, int R_tgt, int gen) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nS = (long)S * B, nT = (long)(T - 1) * B;
-  if (i < (long)S_ws * B) o_src[i] = i < nS ? src[i] : pad;
-  if (i < (long)(T_ws - 1) * B) { o_tin[i] = i < nT ? tgt[i] : pad; o_y[i] = i < nT ? tgt[i + B] : pad; }
+  // flags_*: the lazily updated embedding tables' row flags (optim.hip): every row this batch looks up -- the pad row of the bucketed
+  // positions included -- is flagged for the update `gen`, in the flag array of that update's parity (the other one may still be read by
+  // the half of update gen - 1 that runs on the side stream)
+  if (i < (long)S_ws * B) {
+    const long long id = i < nS ? src[i] : pad;
+    o_src[i] = id;
+    if (flags_src && id >= 0 && id < R_src) flags_src[(long)(gen & 1) * R_src + id] = gen;
+  }
+  if (i < (long)(T_ws - 1) * B) {
+    const long long id = i < nT ? tgt[i] : pad;
+    o_tin[i] = id; o_y[i] = i < nT ? tgt[i + B] : pad;
+    if (flags_tgt && id >= 0 && id < R_tgt) flags_tgt[(long)(gen & 1) * R_tgt + id] = gen;
+  }
   if (i < B) { o_len[i] = src_len[i]; o_idx[i] = idx[i]; }
   if (i < VMMT_STAT_COUNT) stats[i] = 0.f;
   if (eps && i < n_eps) {
@@ -694,9 +706,10 @@ extern "C" int vmmt_pack_multi(const vmmt_pack_desc* descs, int n, int total_chu
 
 extern "C" int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const int64_t* src_len, const int64_t* idx, int S, int T,
                                   int B, int S_ws, int T_ws, int pad, int64_t* o_src, int64_t* o_tin, int64_t* o_y, int64_t* o_len,
-                                  int64_t* o_idx, float* stats, float* eps, int64_t n_eps, uint64_t seed, void* stream) {
+                                  int64_t* o_idx, float* stats, float* eps, int64_t n_eps, uint64_t seed, int32_t* flags_src, int R_src,
+                                  int32_t* flags_tgt, int R_tgt, int gen, void* stream) {
   if (!src || !tgt || !src_len || !idx || !o_src || !o_tin || !o_y || !o_len || !o_idx || !stats || S <= 0 || T < 2 || B <= 0 ||
-      S_ws < S || T_ws < T)
+      S_ws < S || T_ws < T || ((flags_src || flags_tgt) && gen < 1) || (flags_src && R_src <= 0) || (flags_tgt && R_tgt <= 0))
     return VMMT_EINVAL;
   long n = (long)S_ws * B;
   if ((long)(T_ws - 1) * B > n) n = (long)(T_ws - 1) * B;
@@ -705,6 +718,6 @@ extern "C" int vmmt_prepare_batch(const int64_t* src, const int64_t* tgt, const 
   hipLaunchKernelGGL(prepare_batch_kernel, BLOCKS(n, 256), dim3(256), 0, ST, (const long long*)src, (const long long*)tgt,
                      (const long long*)src_len, (const long long*)idx, S, T, B, S_ws, T_ws, (long long)pad, (long long*)o_src,
                      (long long*)o_tin, (long long*)o_y,
-                     (long long*)o_len, (long long*)o_idx, stats, eps, (long)n_eps, (unsigned long long)seed);
+                     (long long*)o_len, (long long*)o_idx, stats, eps, (long)n_eps, (unsigned long long)seed, flags_src, R_src, flags_tgt, R_tgt, gen);
   return check_launch();
 }

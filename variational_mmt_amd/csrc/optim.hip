@@ -147,7 +147,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // zero-gradient step depends on nothing but the row's own m, v and the step's scalars, so it can be applied LATER, bit for bit:
 //   last[r]         the optimiser step row r is current for
 //   hist            a ring of the last VMMT_LAZY_HIST steps' scalars (step_size, 1 / sqrt(bias correction 2), applied or skipped)
-//   flags[r]        generation number: row r is "flagged" for the update t when flags[r] == t (nothing ever clears a flag)
+//   flags[t & 1][r] generation number: row r is "flagged" for the update t when flags[t & 1][r] == t (nothing ever clears a flag; two
+//                   arrays by the update's parity: the next batch is flagged while a half of the last update still reads its own)
 // rows_mark flags the batch's rows, rows_catchup replays the zero-gradient steps last + 1 .. t - 1 of the flagged rows in registers
 // (adam_elem with g = 0: the dense kernel's arithmetic in the dense kernel's order) in front of the lookup and clears their gradient rows,
 // the update touches the flagged rows -- and a ROLLING 1 / roll of the table (rows r % roll == t % roll), so that no row is ever more
@@ -160,14 +161,14 @@ __global__ void rows_mark_kernel(const long long* __restrict__ ids, long n, int*
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long long id = ids[i];
-  if (id >= 0 && id < R) flags[id] = hist[0] + 1;
+  if (id >= 0 && id < R) { const int gen = hist[0] + 1; flags[(long)(gen & 1) * R + id] = gen; }
 }
 
 // The row kernels share one shape: a workgroup owns a block of 64 rows -- every wave reads the block's flags / `last` words with one
 // coalesced load each and ballots the rows that have work -- and its waves take those rows in turn, a whole row per wave (C / 4 lanes x
 // 16 bytes per array and pass).  One wave per (row, chunk) over the whole table meant 60 000 waves of which 50 000 found nothing to do
 // after three dependent memory round trips each: 69 us for an update that moves 90 MB.
-#define VMMT_ROWS_WAVES 8
+#define VMMT_ROWS_WAVES 16
 
 // the scalars of the steps from + 1 .. from + n (n <= 64) out of the ring: lane j takes step from + 1 + j's entry -- ONE load per wave
 // instead of one per replayed step (a memory round trip of 1-3 us in every iteration of a loop whose arithmetic takes 0.2 us)
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_catchup_kernel(floa
   bool act = false;
   if (r0 + lane < R) {
     lst = last[r0 + lane];
-    act = MODE == 0 ? flags[r0 + lane] == upto + 1 : lst < upto;
+    act = MODE == 0 ? flags[(long)((upto + 1) & 1) * R + r0 + lane] == upto + 1 : lst < upto;
   }
   unsigned long long todo = __ballot(act);
   for (int k = 0; todo; ++k) {
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) adam_rows_kernel(float* 
   bool hg = false, act = false;
   if (r0 + lane < R) {
     lst = last[r0 + lane];
-    hg = flags[r0 + lane] == step;
+    hg = flags[(long)(step & 1) * R + r0 + lane] == step;
     act = hg || (roll > 0 && (r0 + lane) % roll == step % roll && lst < step);
   }
   unsigned long long todo = __ballot(act);
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_sumsq_kernel(const 
                                                                           const int* __restrict__ hist, float* __restrict__ rowsq) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r0 = blockIdx.x * 64;
   const int gen = hist[0] + 1;
-  const bool act = r0 + lane < R && flags[r0 + lane] == gen;
+  const bool act = r0 + lane < R && flags[(long)(gen & 1) * R + r0 + lane] == gen;
   if (wave == 0 && r0 + lane < R && !act) rowsq[r0 + lane] = 0.f;
   unsigned long long todo = __ballot(act);
   for (int k = 0; todo; ++k) {

@@ -28,44 +28,77 @@ class _Rccl(object):
     (GradSync._direct_selfcheck); any failure leaves the run on torch.distributed, with a line on stderr."""
     F32, I32, SUM, MAX = 7, 2, 0, 2
 
-    def __init__(self, dist, device):
+    def __init__(self, dist, device, lib=None):
+        """lib: a loaded librccl (tests/test_dp_gloo.py passes stand-ins that fail at chosen stages, to show that every rank takes
+        the same way out); default: the librccl.so of the running torch"""
         import ctypes as C
         import os as _os
         cand = [_os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "/opt/rocm/lib/librccl.so"]
-        self.lib = None
-        for c in cand:
+        self.lib, lib_ok = (lib if lib is not None and lib != "missing" else None), 1
+        for c in (cand if lib is None else []):
             try:
                 self.lib = C.CDLL(c)
                 break
             except OSError:
                 continue
-        if self.lib is None:
-            raise RuntimeError("librccl.so not found")
 
         class UniqueId(C.Structure):
             _fields_ = [("internal", C.c_char * 128)]
         L = self.lib
-        L.ncclGetUniqueId.argtypes, L.ncclGetUniqueId.restype = [C.POINTER(UniqueId)], C.c_int
-        L.ncclCommInitRank.argtypes, L.ncclCommInitRank.restype = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int], C.c_int
-        L.ncclCommDestroy.argtypes, L.ncclCommDestroy.restype = [C.c_void_p], C.c_int
-        L.ncclGetErrorString.argtypes, L.ncclGetErrorString.restype = [C.c_int], C.c_char_p
-        L.ncclReduceScatter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
-        L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        for f in (L.ncclReduceScatter, L.ncclAllGather, L.ncclAllReduce):
-            f.restype = C.c_int
+        try:
+            if L is None:
+                raise OSError("librccl.so not found")
+            L.ncclGetUniqueId.argtypes, L.ncclGetUniqueId.restype = [C.POINTER(UniqueId)], C.c_int
+            L.ncclCommInitRank.argtypes, L.ncclCommInitRank.restype = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int], C.c_int
+            L.ncclCommDestroy.argtypes, L.ncclCommDestroy.restype = [C.c_void_p], C.c_int
+            L.ncclGetErrorString.argtypes, L.ncclGetErrorString.restype = [C.c_int], C.c_char_p
+            L.ncclReduceScatter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+            L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            for f in (L.ncclReduceScatter, L.ncclAllGather, L.ncclAllReduce):
+                f.restype = C.c_int
+        except (OSError, AttributeError):          # (no library / a symbol missing on THIS rank: the stages below still run, and say so)
+            lib_ok = 0
         world, rank = dist.get_world_size(), dist.get_rank()
-        uid = UniqueId()
-        if rank == 0:
-            self._ok(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+        self.comm = None
+        self._dist, self._dev = dist, device
+        # Bring-up in STAGES, each agreed on through the process group that is already up, so that no rank is ever alone in a blocking
+        # call: (1) rank 0 draws the unique id; the broadcast is ALWAYS executed and carries a status byte in front of the id -- a rank 0
+        # that failed says so instead of leaving its peers in the broadcast; (2) every rank reports whether it is ready (library loaded,
+        # id received) and only if ALL are does anyone enter ncclCommInitRank; (3) the communicator is created on THIS engine's device
+        # (ncclCommInitRank binds to the calling thread's current device, which torch.cuda.synchronize(device) does not select).
+        uid, ready = UniqueId(), lib_ok
+        if rank == 0 and lib_ok:
+            try:
+                self._ok(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+            except Exception:           # noqa: BLE001
+                ready = 0
+        t = torch.frombuffer(bytearray(bytes([ready]) + bytes(uid)), dtype=torch.uint8).to(device)
         dist.broadcast(t, 0)
         raw = bytes(t.cpu().numpy().tobytes())
-        C.memmove(C.byref(uid), raw, 128)
-        self.comm = C.c_void_p()
-        torch.cuda.synchronize(device)
-        self._ok(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+        C.memmove(C.byref(uid), raw[1:], 128)
+        self._agree(ready and raw[0], "library + unique id", mine=bool(ready))
+        comm = C.c_void_p()
+        import contextlib
+        with (torch.cuda.device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()):
+            if torch.device(device).type == "cuda":
+                torch.cuda.synchronize(device)
+            rc = L.ncclCommInitRank(C.byref(comm), world, uid, rank)
+        if rc == 0:
+            self.comm = comm
+        self._agree(rc == 0, "ncclCommInitRank" + ("" if rc == 0 else ": " + L.ncclGetErrorString(rc).decode()))
         self.world, self.rank = world, rank
+        import atexit
+        atexit.register(self.close)         # (ncclCommDestroy on normal exit; GradSync.close() does it earlier)
+
+    def _agree(self, ok, what, mine=None):
+        """every rank learns whether ALL ranks passed the stage (one small all-reduce through torch.distributed); raises on every rank if not"""
+        mine = bool(ok) if mine is None else mine
+        v = torch.tensor([1 if ok else 0], device=self._dev, dtype=torch.int32)
+        self._dist.all_reduce(v, op=self._dist.ReduceOp.MIN)
+        if int(v.item()) != 1:
+            self.close()
+            raise RuntimeError("direct RCCL bring-up: stage '%s' failed on %s" % (what, "this rank" if not mine else "another rank"))
 
     def _ok(self, rc, what):
         if rc != 0:
@@ -129,8 +162,14 @@ class GradSync(object):
             self.rank = dist.get_rank()
             self.backend = dist.get_backend()
             self._direct = None
-            if direct is not False and self.backend == "nccl" and os.environ.get("VMMT_DP_NATIVE", "1") != "0" and self.flat.is_cuda:
+            # OPT-IN (VMMT_DP_DIRECT=1, or direct=True): the direct path has run with a world of ONE only (tests/test_gpu_nccl_world1.py,
+            # the one-GPU rehearsal) -- no node with two or more GPUs has been available to this project.  Until a multi-GPU parity run
+            # has passed, a data-parallel job uses torch.distributed's own tensor collectives unless it asks for the direct calls.
+            want = bool(direct) if direct is not None else os.environ.get("VMMT_DP_DIRECT", "0") == "1"
+            if want and self.backend == "nccl" and os.environ.get("VMMT_DP_NATIVE", "1") != "0" and self.flat.is_cuda:
                 self._direct_up()
+            else:
+                self._log("step collectives", "torch.distributed", "direct RCCL is opt-in: VMMT_DP_DIRECT=1" if not want else "backend %s" % self.backend)
             if engine is not None and getattr(engine, "dense_optimizer", False):
                 self.sharded = False               # torch's dense optimisers (-optim sgd|adagrad|adadelta) read the whole reduced gradient
             if engine is not None and engine.dp is None:
@@ -285,37 +324,45 @@ class GradSync(object):
         run stays on torch.distributed (every rank takes the same decision: the verdict is all-reduced through torch.distributed)"""
         dev = self.flat.device
         ok, why = 1, "ok"
+        r = None
         try:
-            r = _Rccl(self.dist, dev)
+            r = _Rccl(self.dist, dev)         # (staged: raises on EVERY rank or on none)
             n = 64
             base = (torch.arange(self.world * n, device=dev, dtype=torch.float32) * 0.25 + self.rank).contiguous()
-            a, b = base.clone(), base.clone()
-            r.reduce_scatter(a, n)
-            self.dist.reduce_scatter_tensor(b[self.rank * n:(self.rank + 1) * n], b.clone())
-            same = torch.equal(a[self.rank * n:(self.rank + 1) * n], b[self.rank * n:(self.rank + 1) * n])
-            a2, b2 = a.clone(), a.clone()
-            r.all_gather(a2, n)
-            self.dist.all_gather_into_tensor(b2, a[self.rank * n:(self.rank + 1) * n].clone())
-            same = same and torch.equal(a2, b2)
-            k1 = torch.tensor([1.5 + self.rank], device=dev)
-            k2 = k1.clone()
-            r.all_reduce(k1)
+            mine = slice(self.rank * n, (self.rank + 1) * n)
+            # torch.distributed's results FIRST, all of them: these calls are executed by every rank whatever happens to the direct ones
+            # below (a rank whose direct call raises goes straight to the verdict; it never leaves a peer alone in a torch collective)
+            b = base.clone()
+            self.dist.reduce_scatter_tensor(b[mine], base.clone())
+            b2 = torch.empty_like(base)
+            self.dist.all_gather_into_tensor(b2, b[mine].clone())
+            k2 = torch.tensor([1.5 + self.rank], device=dev)
             self.dist.all_reduce(k2)
-            g1 = torch.tensor([self.rank + 3], device=dev, dtype=torch.int32)
-            g2 = g1.clone()
-            r.all_reduce(g1, "max")
+            g2 = torch.tensor([self.rank + 3], device=dev, dtype=torch.int32)
             self.dist.all_reduce(g2, op=self.dist.ReduceOp.MAX)
-            rows = torch.zeros(self.world, 9, device=dev)
-            rows2 = torch.zeros(self.world, 9, device=dev)
             row = torch.arange(9, device=dev, dtype=torch.float32) + self.rank
-            r.all_gather_into(rows, row)
+            rows2 = torch.zeros(self.world, 9, device=dev)
             self.dist.all_gather_into_tensor(rows2.view(-1), row)
             torch.cuda.synchronize(dev)
-            same = same and torch.equal(k1, k2) and torch.equal(g1, g2) and torch.equal(rows, rows2)
+            a = base.clone()
+            r.reduce_scatter(a, n)
+            a2 = a.clone()
+            r.all_gather(a2, n)
+            k1 = torch.tensor([1.5 + self.rank], device=dev)
+            r.all_reduce(k1)
+            g1 = torch.tensor([self.rank + 3], device=dev, dtype=torch.int32)
+            r.all_reduce(g1, "max")
+            rows = torch.zeros(self.world, 9, device=dev)
+            r.all_gather_into(rows, row)
+            torch.cuda.synchronize(dev)
+            same = (torch.equal(a[mine], b[mine]) and torch.equal(a2, b2) and torch.equal(k1, k2) and torch.equal(g1, g2) and
+                    torch.equal(rows, rows2))
             if not same:
                 ok, why = 0, "results differ from torch.distributed"
         except Exception as ex:          # noqa: BLE001  (whatever went wrong: the run continues on torch.distributed)
-            ok, why, r = 0, "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:160] if str(ex) else ""), None
+            ok, why = 0, "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:160] if str(ex) else "")
+            if r is not None and r.comm is None:
+                r = None
         v = torch.tensor([ok], device=dev, dtype=torch.int32)
         self.dist.all_reduce(v, op=self.dist.ReduceOp.MIN)
         if int(v.item()) == 1:

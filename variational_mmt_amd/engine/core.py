@@ -23,7 +23,7 @@ def _behind_background(name):
         dd = self.__dict__
         if dd.get("_pending_bg") and not dd.get("_in_flush"):
             self.wait_background()
-        if dd.get("_lazy_dirty") and not dd.get("_in_step"):
+        if dd.get("_lazy_dirty") and not dd.get("_in_step") and not dd.get("_in_flush"):
             self.flush_lazy_rows()          # (the embedding tables' rows are brought up to date lazily: _build_row_tables)
         try:
             return dd[priv]
@@ -329,7 +329,7 @@ class Engine(StepAPI):
                 self._row_adam, self.row_tables = False, []
                 return
             self.row_tables.append(dict(name=n, off=off, R=R, C=Cc, end=off + R * Cc,
-                                        flags=torch.zeros(R, dtype=torch.int32, device=self.dev),
+                                        flags=torch.zeros(2 * R, dtype=torch.int32, device=self.dev),      # [parity of the update][row]
                                         last=torch.zeros(R, dtype=torch.int32, device=self.dev),
                                         hist=torch.zeros(L.LAZY_HIST_WORDS, dtype=torch.int32, device=self.dev),
                                         rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev)))
@@ -422,15 +422,22 @@ class Engine(StepAPI):
         """error words of the tables' rings (0 = no replay ever met an overwritten entry); synchronises"""
         return [int(t["hist"][1].item()) for t in self.row_tables]
 
+    def _row_flag_args(self, training):
+        """the row-flag arguments of vmmt_prepare_batch: a training batch flags the rows it looks up in both tables for the NEXT update
+        (the step counter is the host's: equal to the tables' own `hist[0]` except inside _step_rollback, which runs with the device idle)"""
+        if not (training and self.rows_active()):
+            return (None, 0, None, 0, 0)
+        s_, t_ = self.row_tables
+        return (s_["flags"].data_ptr(), s_["R"], t_["flags"].data_ptr(), t_["R"], self._step_count + 1)
+
     def _row_mark_entries(self, plan, table_index, ids_ptr, n_ids):
-        """plan entries (training forward, IN FRONT of the table's lookup): flag the batch's rows, bring them up to date and clear
-        their gradient rows, which the backward plan's scatter-add accumulates into"""
+        """plan entry (training forward, IN FRONT of the table's lookup): the rows the batch flagged (vmmt_prepare_batch) are brought up to
+        date and their gradient rows cleared, which the backward plan's scatter-add accumulates into"""
         if not self.rows_active():
             return
         t = self.row_tables[table_index]
         o = 4 * t["off"]
         b1, b2, eps = self._adam_consts
-        self._call(plan, self.lib.vmmt_rows_mark, ids_ptr, n_ids, t["flags"].data_ptr(), t["R"], t["hist"].data_ptr())
         self._call(plan, self.lib.vmmt_rows_catchup, self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o,
                    self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(), t["hist"].data_ptr(),
                    b1, b2, eps, 0)

@@ -51,11 +51,11 @@ class StepAPI(object):
         src_d, tgt_d, len_d, idx_d = dev64(src), dev64(tgt), dev64(src_len).reshape(-1), dev64(img_indices).reshape(-1)
         gen_eps = training and eps is None
         self.rng_counter += 1
-        L.check(self.lib.vmmt_prepare_batch(src_d.data_ptr(), tgt_d.data_ptr(), len_d.data_ptr(), idx_d.data_ptr(), S, Tp + 1, B,
+        L.check(self.lib.vmmt_prepare_batch(*((src_d.data_ptr(), tgt_d.data_ptr(), len_d.data_ptr(), idx_d.data_ptr(), S, Tp + 1, B,
                                             ws.S, ws.Tp + 1, PAD,
                                             ws.src.data_ptr(), ws.tgt_in.data_ptr(), ws.y.data_ptr(), ws.src_len.data_ptr(),
                                             ws.img_idx.data_ptr(), ws.stats.data_ptr(), ws.eps.p() if gen_eps else None,
-                                            B * d.z if gen_eps else 0, self.rng_counter, st), "vmmt_prepare_batch")
+                                            B * d.z if gen_eps else 0, self.rng_counter) + self._row_flag_args(training) + (st,))), "vmmt_prepare_batch")
         ws._inputs_keepalive = (src_d, tgt_d, len_d, idx_d)
         if d.conditional:
             if tgt_len is None:
