@@ -488,7 +488,8 @@ int vmmt_dp_norm_fold(const float* rows, int world, float* sumsq, int32_t* guard
  *   vmmt_rows_catchup   mode 0: flagged rows are brought up to step hist[0] and their gradient rows cleared (between vmmt_rows_mark and
  *                       the lookup / the backward's scatter-add); mode 1: EVERY row is brought up to hist[0] (flush: checkpoints,
  *                       evaluation, before the dense kernels take over)
- *   vmmt_sumsq_rows     ||g||^2 over the flagged rows into slot `slot` of the norm scratch (deterministic); rowsq f32 [R] scratch
+ *   vmmt_sumsq_rows     ||g||^2 over the flagged rows into slot `slot` of the norm scratch (deterministic, one launch); rowsq f32 [R]
+ *                       scratch: block sums + a self-resetting ticket in its first ceil(R / 64) + 1 words (zero before the first call)
  *   vmmt_adam_rows_step update `step` (= hist[0] + 1): flagged rows with their gradient, rows r % roll == step % roll without one
  *                       (roll = 0: none; <= VMMT_LAZY_HIST / 4), records the step in the ring.  skip: as vmmt_adam_step -- the step
  *                       is recorded as skipped and replays leave it out.  C % 4 == 0, p / g / m / v 16-byte aligned. */

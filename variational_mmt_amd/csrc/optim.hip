@@ -318,14 +318,20 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) adam_rows_kernel(float* 
   }
 }
 
-// ||g||^2 over the flagged rows (the other rows hold whatever an earlier step left): per-row sums by one wave each, then ONE workgroup
-// adds the R row sums in a fixed order into the slot total: deterministic, like sumsq_kernel
+// ||g||^2 over the flagged rows (the other rows hold whatever an earlier step left) in ONE launch: a workgroup adds the row sums of its
+// 64-row block in row order, leaves the block's sum in `blksq` and takes a ticket; the workgroup whose ticket is the last adds the block
+// sums in block order into the slot total: deterministic, like sumsq_kernel (same hand-off).  blksq: f32 [ceil(R / 64) + 1], the last
+// word is the ticket (zero before the first launch; it resets itself).
 __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_sumsq_kernel(const float* __restrict__ g, int R, int C, const int* __restrict__ flags,
-                                                                          const int* __restrict__ hist, float* __restrict__ rowsq) {
+                                                                          const int* __restrict__ hist, float* __restrict__ blksq,
+                                                                          float* __restrict__ total) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r0 = blockIdx.x * 64;
   const int gen = hist[0] + 1;
   const bool act = r0 + lane < R && flags[(long)(gen & 1) * R + r0 + lane] == gen;
-  if (wave == 0 && r0 + lane < R && !act) rowsq[r0 + lane] = 0.f;
+  __shared__ float rowsum[64];
+  __shared__ int is_last;
+  if (wave == 0) rowsum[lane] = 0.f;
+  __syncthreads();
   unsigned long long todo = __ballot(act);
   for (int k = 0; todo; ++k) {
     const int b = __ffsll((long long)todo) - 1;
@@ -335,24 +341,33 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_sumsq_kernel(const 
     float a = 0.f;
     for (int c = lane * 4; c < C; c += 256) { const f32x4 q = *reinterpret_cast<const f32x4*>(x + c); a += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]; }
     a = wave_sum(a);
-    if (lane == 0) rowsq[r0 + b] = a;
+    if (lane == 0) rowsum[b] = a;
   }
-}
-__global__ void __launch_bounds__(1024) rows_sumsq_total_kernel(const float* __restrict__ rowsq, int R, float* __restrict__ total) {
-  // a fixed order with independent loads in flight (a chain of 30 dependent loads per thread cost 17 us)
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int r = threadIdx.x;
-  for (; r + 3 * 1024 < R; r += 4 * 1024) { a0 += rowsq[r]; a1 += rowsq[r + 1024]; a2 += rowsq[r + 2048]; a3 += rowsq[r + 3072]; }
-  for (; r < R; r += 1024) a0 += rowsq[r];
-  float a = (a0 + a1) + (a2 + a3);
-  a = wave_sum(a);
-  __shared__ float red[16];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  const int nblk = (int)gridDim.x;
+  unsigned* ticket = reinterpret_cast<unsigned*>(blksq + nblk);
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int r = 0; r < 64; ++r) s += rowsum[r];
+    __hip_atomic_store(blksq + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == (unsigned)nblk - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // the block sums in block order: thread i takes blocks i, i + 1024, ... and the partial sums are folded in thread order
+  float s = 0.f;
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) s += __hip_atomic_load(blksq + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  s = wave_sum(s);
+  __shared__ float red[VMMT_ROWS_WAVES];
+  if (lane == 0) red[wave] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int k = 0; k < 16; ++k) t += red[k];
+    for (int k = 0; k < VMMT_ROWS_WAVES; ++k) t += red[k];
     *total = t;
+    *ticket = 0u;
   }
 }
 
@@ -440,8 +455,8 @@ extern "C" int vmmt_sumsq_rows(const float* g, int R, int C, const int32_t* flag
   using namespace vmmt;
   if (!g || !flags || !hist || !rowsq || !scratch || R <= 0 || C <= 0 || slot < 0 || slot >= VMMT_SUMSQ_SLOTS || (((uintptr_t)g) & 15) || C % 4 != 0)
     return VMMT_EINVAL;
-  hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64 * VMMT_ROWS_WAVES), 0, (hipStream_t)stream, g, R, C, flags, hist, rowsq);
-  hipLaunchKernelGGL(rows_sumsq_total_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rowsq, R, scratch + slot);
+  hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64 * VMMT_ROWS_WAVES), 0, (hipStream_t)stream, g, R, C, flags, hist, rowsq,
+                     scratch + slot);
   return check_launch();
 }
 
