@@ -226,6 +226,10 @@ def _worker_probe(rank, world, port, out):
     class _Broken(object):
         dp = None
         rng_counter = 0
+        row_tables = ()
+
+        def flush_lazy_rows(self):
+            pass
 
         def drop_workspaces(self):
             raise RuntimeError("boom")

@@ -168,8 +168,8 @@ class GradSync(object):
             want = bool(direct) if direct is not None else os.environ.get("VMMT_DP_DIRECT", "0") == "1"
             if want and self.backend == "nccl" and os.environ.get("VMMT_DP_NATIVE", "1") != "0" and self.flat.is_cuda:
                 self._direct_up()
-            else:
-                self._log("step collectives", "torch.distributed", "direct RCCL is opt-in: VMMT_DP_DIRECT=1" if not want else "backend %s" % self.backend)
+            elif self.backend == "nccl":
+                self._log("step collectives", "torch.distributed", "direct RCCL is opt-in: VMMT_DP_DIRECT=1" if not want else "VMMT_DP_NATIVE=0 / no device arena")
             if engine is not None and getattr(engine, "dense_optimizer", False):
                 self.sharded = False               # torch's dense optimisers (-optim sgd|adagrad|adadelta) read the whole reduced gradient
             if engine is not None and engine.dp is None:

@@ -28,8 +28,8 @@ class BackwardPlan(object):
         e._record(P, "bwd_begin")
         # ================= main: generator backward seed G^T, dO = G Wg ================================================
         e._sid = MAIN
-        # (the bias gradient = row sums of G^T comes out of the same kernel; the gradient arena was zeroed on the side stream in
-        #  front of `dec_gx`, which the main stream has waited for)
+        # (the bias gradient = row sums of G^T comes out of the same kernel; the gradient arena was zeroed by the forward plan on its side or
+        #  aux stream, behind the main stream's last join there: Workspace._assert_joined)
         fuse_db = True
         # entries that carry run-time scalars (1 / normalization, KL weights): patched per step by backward_plan(), so that
         # token normalisation (a different value every batch) does not rebuild the plan
@@ -126,14 +126,16 @@ class BackwardPlan(object):
         # gradients, so the few kernels that produce d h_y go out first and the recurrence gets a stream of its own (TGT); everything
         # else of this chain (image network, weight gradients of q / p, p's backward) runs next to it
         cond_first = bool(d.conditional and not rp)
-        # fixed prior: the KL / q(z|x) backward needs mu, sigma and the KL sum only -- it goes first, gated by the sample (and by the side
-        # stream's gradient zeroing: dec_gx is recorded behind it), the image term follows when the forward's image network is through
+        # fixed prior: the KL / q(z|x) backward needs mu, sigma and the KL sum only -- it goes first, gated by the sample and by the forward
+        # plan's gradient zeroing (`grad_zero`; no wait when that ran on this very stream), the image term follows when the forward's image
+        # network is through
         kl_first = bool(e.aux_early and e.aux_kl_first and not d.conditional and not rp)
         def aux_chain():
             e._sid = AUX
             if kl_first:
                 e._wait(P, "z_ready")
-                e._wait(P, "dec_gx")
+                if getattr(self, "_zero_sid", None) != AUX:
+                    e._wait(P, "grad_zero")
                 kl_and_q_backward()
             # the image term and the KL / q(z|x) backward depend on the forward only (mu_v, mu / sigma, the KL sum), not on the generator
             # loss: gated by the forward's image network (behind the step's gradient zeroing on the same stream) they start while the
@@ -143,7 +145,7 @@ class BackwardPlan(object):
                 # conditional model: the chain d h_y -> encoder_tgt's backward recurrence is the critical path of the whole backward and
                 # depends on the forward only (KL of q against p(z|x)): it starts behind the sample, 0.5 ms before the loss is through
                 e._wait(P, "z_ready")
-                e._wait(P, "dec_gx")
+                e._wait(P, "grad_zero")
                 kl_and_q_backward()
                 e._wait(P, "img_fwd")
             else:

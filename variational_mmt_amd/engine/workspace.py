@@ -244,6 +244,10 @@ class Workspace(BackwardPlan, ConditionalPlans):
             e._zero(P, g_ranges + [e._sumsq[:L.SUMSQ_SLOTS], self.dh1v32.t, self.dzt.t] +
                     ([self.dO32.t, self.lse, self.tok_nll] if compact else [] if self.gen_fused else [self.dO32.t]) +       # (fused generator: dO is stored, not accumulated)
                     [b.t for l in range(Lyr) for b in (self.dec_dcc[l], self.enc_dcc[l])])
+            # `grad_zero`: what accumulates into the gradient arena from another stream than this one waits for it (the backward plan's KL /
+            # q(z|x) chain on the aux stream; everything else of the backward is behind the forward plan's last join)
+            e._record(P, "grad_zero")
+            self._zero_sid = e._sid
             if compact:
                 self._compact_entry = len(P)
                 e._call(P, lib.vmmt_compact_nonpad, self.y.data_ptr(), M, PAD, M, self.gen_rows.data_ptr(), self.gen_cnt.data_ptr())
@@ -432,7 +436,37 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._wait(P, "img_fwd")
         if drop:
             e._call(P, lib.vmmt_mul, dt, self.AH.p(), self.AH.ld, self.out_mask.p(), self.out_mask.ld, self.O.p(), self.O.ld, M, H)
+        # the ONE wait above stands for three that used to be explicit (out_mask, opt_gen_done, the gradient zeroing): checked here, so that
+        # an edit that moves one of them to a stream `img_fwd` does not cover fails when the plan is built, not as a race
+        if not d.conditional and e.use_side_stream:
+            need = (["vmmt_zero_multi"] if training else []) + (["vmmt_dropout_mask"] if drop else []) + (["BG_FLUSH2"] if early_head else [])
+            self._assert_joined(P, need, "img_fwd")
         return P
+
+    @staticmethod
+    def _assert_joined(P, needed, event):
+        """walks a launch plan: `needed` (entry names) must all lie behind the record of `event` -- on the recording stream itself or on a
+        stream it had joined (a wait for an event recorded there) by then -- and the main stream must wait for `event` afterwards"""
+        have = {sid: set() for sid in range(4)}
+        snap, recorded_at, main_waits = {}, None, False
+        for k, (fn, args, name, _keep, sid) in enumerate(P):
+            if fn is None:
+                if name == "EV_RECORD":
+                    snap[args] = set(have[sid])
+                    if args == event:
+                        recorded_at = k
+                elif name == "EV_WAIT":
+                    have[sid] |= snap.get(args, set())
+                    if args == event and sid == 0 and recorded_at is not None:
+                        main_waits = True
+                else:
+                    have[sid].add(name)
+            else:
+                have[sid].add(name)
+        missing = [n for n in needed if n not in snap.get(event, set())]
+        if recorded_at is None or missing or not main_waits:
+            raise AssertionError("launch plan: %s is not behind `%s` (recorded: %s, main stream waits for it: %s) -- the main stream's one "
+                                 "join would not cover it" % (missing, event, recorded_at is not None, main_waits))
 
     def _plan_loss(self, training):
         """forward part of NMTVIModel1LossCompute._compute_loss (VILoss.py:217-513): statistics only."""
