@@ -14,13 +14,16 @@ from oracle import vi1_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("R,Cc,roll", [(301, 500, 7), (157, 1024, 16), (64, 24, 0), (911, 256, 3)])
-def test_lazy_rows_kernels_bit_identical_to_dense_adam(R, Cc, roll):
+@pytest.mark.parametrize("R,Cc,roll,steps,max_ids", [(301, 500, 7, 60, 40), (157, 1024, 16, 60, 40), (64, 24, 0, 60, 40), (911, 256, 3, 60, 40),
+                                                     # the benchmark's table and batch: every 64-row block has flagged AND rolling rows, its 16 waves
+                                                     # start at different times (round 6: a wave's share of the rows depended on `last`, which the
+                                                     # faster waves were already writing -- a row in a few thousand lost its update)
+                                                     (30011, 500, 16, 12, 5120)])
+def test_lazy_rows_kernels_bit_identical_to_dense_adam(R, Cc, roll, steps, max_ids):
     from variational_mmt_amd import _lib as L
     lib = L.lib()
     dev = torch.device("cuda")
     st = torch.cuda.current_stream().cuda_stream
-    steps = 60
     g = torch.Generator().manual_seed(3 + R)
     p0 = (torch.rand(R, Cc, generator=g) - 0.5).to(dev)
     dense = dict(p=p0.clone(), m=torch.zeros_like(p0), v=torch.zeros_like(p0))
@@ -49,7 +52,7 @@ def test_lazy_rows_kernels_bit_identical_to_dense_adam(R, Cc, roll):
         lr = 0.002 if step < 25 else 0.001                      # a learning-rate decay in the middle (replays read the step's scalars from the ring)
         max_norm = 5.0 if step % 3 else 0.02                    # clipping active on every third step
         hot = step % 11 < 8                                     # mostly a small hot set of rows (Zipf-like), sometimes any row
-        ids = torch.randint(0, R // 8 if hot else R, (int(torch.randint(1, 40, (1,), generator=g)),), generator=g)
+        ids = torch.randint(0, R // 8 if hot else R, (int(torch.randint(max(1, max_ids // 2), max_ids, (1,), generator=g)),), generator=g)
         if step % 7 == 0:
             ids = torch.cat([ids, ids[:3]])                     # duplicates in a batch
         rows = torch.unique(ids).to(dev)
@@ -74,7 +77,7 @@ def test_lazy_rows_kernels_bit_identical_to_dense_adam(R, Cc, roll):
         a, b = float(sq_d[0]), float(sq_l[3])
         assert abs(a - b) <= 2e-6 * a, (step, a, b)             # the same norm up to the order of summation
         # a step the guard word skips (a recurrence that timed out): nothing moves in either path, the ring records it as skipped
-        skipping = step in (13, 14, 40)
+        skipping = step in (13, 14, 40) or (steps < 13 and step == 7)
         skip[0] = 1 if skipping else 0
         n_skipped += skipping
         # the same clip coefficient for both (the bit-level claim is about the update, not about the norm's summation order)
@@ -90,7 +93,7 @@ def test_lazy_rows_kernels_bit_identical_to_dense_adam(R, Cc, roll):
             if roll:
                 assert (lr_[torch.arange(R, device=dev) % roll == step % roll] == step).all()
                 assert int((step - lr_).max()) <= 2 * roll + 1      # no row is ever further behind than the rolling period (twice: a row whose turn fell on a skipped step)
-        if step in (1, 17, 41, steps):                          # flush everything and compare the whole table
+        if step in (1, 5, 17, 41, steps):                       # flush everything and compare the whole table
             catchup(1)
             same(step)
             assert (last == step).all()

@@ -260,7 +260,9 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_catchup_kernel(floa
   bool act = false;
   if (r0 + lane < R) {
     lst = last[r0 + lane];
-    act = MODE == 0 ? flags[(long)((upto + 1) & 1) * R + r0 + lane] == upto + 1 : lst < upto;
+    // (which wave takes which row must not depend on `last`: the waves of a workgroup read it at different times, and a row another wave
+    //  has already finished would drop out of a late wave's ballot and shift every later row to another wave -- or to none)
+    act = MODE == 0 ? flags[(long)((upto + 1) & 1) * R + r0 + lane] == upto + 1 : true;
   }
   unsigned long long todo = __ballot(act);
   for (int k = 0; todo; ++k) {
@@ -268,6 +270,7 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_catchup_kernel(floa
     todo &= todo - 1;
     if (k % VMMT_ROWS_WAVES != wave) continue;
     const int from = __builtin_amdgcn_readlane(lst, b);
+    if (MODE == 1 && from >= upto) continue;
     lazy_row<false, MODE == 0>(p, g, m, v, (long)(r0 + b) * C, C, from, upto, hist, b1, b2, eps, false, 0.f, 0.f, 0.f);
     if (lane == 0 && from < upto) last[r0 + b] = upto;
   }
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) adam_rows_kernel(float* 
   if (r0 + lane < R) {
     lst = last[r0 + lane];
     hg = flags[(long)(step & 1) * R + r0 + lane] == step;
-    act = hg || (roll > 0 && (r0 + lane) % roll == step % roll && lst < step);
+    act = hg || (roll > 0 && (r0 + lane) % roll == step % roll);       // (not a function of `last`: see rows_catchup_kernel)
   }
   unsigned long long todo = __ballot(act);
   const unsigned long long with_g = __ballot(hg);
@@ -313,6 +316,7 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) adam_rows_kernel(float* 
     todo &= todo - 1;
     if (k % VMMT_ROWS_WAVES != wave) continue;
     const int from = __builtin_amdgcn_readlane(lst, b);
+    if (!((with_g >> b) & 1) && from >= step) continue;          // a rolling row that is up to date already
     lazy_row<true, false>(p, g, m, v, (long)(r0 + b) * C, C, from, step - 1, hist, b1, b2, eps, (with_g >> b) & 1, coef, step_size, inv_sqrt_bc2);
     if (lane == 0) last[r0 + b] = step;
   }
