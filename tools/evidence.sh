@@ -1,10 +1,10 @@
 #!/bin/bash
-# round evidence, one GPU box (usage: bash tools/evidence.sh r5): rocprofv3 kernel stats + timeline of `python bench.py` (default arguments,
+# round evidence, one GPU box (usage: bash tools/evidence.sh r6): rocprofv3 kernel stats + timeline of `python bench.py` (default arguments,
 # --config script, --config 5), PMC HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes), the bench lines (default with parity + cpu_baseline,
 # 100 steps, script, script at batch 40, config 5, conditional, ragged lengths, through the trainer), the non-profiled main-stream phase times,
 # and the data-parallel rehearsals one GPU allows: a ONE-rank RCCL process group (every collective through RCCL) and two ranks sharing the
 # GPU over gloo.  Everything lands under gpurun_out/; the summaries worth keeping are copied into profiles/ by hand.
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 NP="--no-cpu-baseline --no-parity"
@@ -27,7 +27,10 @@ timeout -k 10 300 python bench.py --lengths ragged $NP > gpurun_out/${TAG}_bench
 timeout -k 10 300 python bench.py --through-trainer > gpurun_out/${TAG}_bench_trainer.json 2>/dev/null &&
 timeout -k 10 300 python bench.py --through-trainer --config script > gpurun_out/${TAG}_bench_trainer_script.json 2>/dev/null &&
 timeout -k 10 300 python tools/phase_times.py > gpurun_out/${TAG}_phase_times.txt 2>&1 &&
-VMMT_DP_FORCE=1 timeout -k 10 300 python bench.py $NP > gpurun_out/${TAG}_bench_rccl_world1.json 2> gpurun_out/${TAG}_bench_rccl_world1.err &&
+timeout -k 10 300 python tools/hbm_kernels.py > gpurun_out/${TAG}_hbm_kernels.txt 2>&1 &&
+timeout -k 10 300 python tools/lazy_rows_bench.py > gpurun_out/${TAG}_lazy_rows_kernels.txt 2>&1 &&
+timeout -k 10 300 python tools/critical.py > gpurun_out/${TAG}_critical.txt 2>&1 &&
+VMMT_DP_FORCE=1 VMMT_DP_DIRECT=1 timeout -k 10 300 python bench.py $NP > gpurun_out/${TAG}_bench_rccl_world1.json 2> gpurun_out/${TAG}_bench_rccl_world1.err &&
 VMMT_BENCH_ONE_GPU=1 VMMT_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 3 $NP > gpurun_out/${TAG}_bench_2ranks_one_gpu_gloo.json 2> gpurun_out/${TAG}_bench_2ranks.err &&
 # the PMC passes LAST: profiles/traffic.json must be measured on the kernels the lines above ran (tools/traffic_key.py merge gpurun_out/traffic_${TAG}final_config2.json)
 timeout -k 10 400 bash tools/pmc.sh ${TAG}final --no-parity > gpurun_out/${TAG}_pmc.txt 2>&1 &&
