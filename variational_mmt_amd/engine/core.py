@@ -877,6 +877,11 @@ class Engine(StepAPI):
         if int(self._guard[0].item()) != 0 or any(self.lstm_seq_errors()):
             self._seq_timeout_fallback("check_async_errors")
         # ... or if a step was told fewer target tokens than its batch held (forward(n_tgt_tokens=)): the generator left rows out
+        # ... or if a replay of the lazily updated embedding tables met an overwritten entry of its ring of step scalars (a row further behind
+        # than VMMT_LAZY_HIST updates: the rolling update bounds that by lazy_roll; only a caller driving the kernels past it gets here)
+        if any(self.lazy_errors()):
+            raise RuntimeError("lazy embedding tables: a row was more than %d optimiser steps behind (ring overrun at step(s) %s): its "
+                               "parameters are wrong; lower Engine.lazy_roll or set Engine.row_adam = False" % (L.LAZY_HIST, self.lazy_errors()))
         short = [k for k, w in self.ws.items() if isinstance(w, Workspace) and getattr(w, "gen_cnt", None) is not None and int(w.gen_cnt[1].item())]
         if short:
             raise RuntimeError("forward(n_tgt_tokens=) was smaller than the number of non-pad targets in a batch of shape(s) %s: "
