@@ -199,6 +199,7 @@ int vmmt_lstm_seq_bwd(int dtype, int ndir, int nsteps, const vmmt_lstm_dir_bwd* 
 #define VMMT_STAT_IMG_LOGPROB 4  /* image log-prob as executed (H1): sum over batch of the per-sentence mean over D */
 #define VMMT_STAT_IMG_COS 5      /* sum_b cosine(mu_v_b, v_b)   (reported value = / B)                           */
 #define VMMT_STAT_GRAD_SUMSQ 6   /* ||g||^2 (written by vmmt_sumsq when pointed here)                            */
+#define VMMT_STAT_TICKET 7       /* a uint32 work word of vmmt_gen_fwd_combine_stats (zero between steps)              */
 #define VMMT_STAT_COUNT 8
 
 /* ---- attention ("general" Luong), one workgroup per sentence, source memory staged in LDS --------------------
@@ -281,6 +282,18 @@ int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, i
                          int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
                          float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride, const int32_t* rows,
                          void* stream);
+/* vmmt_gen_fwd_combine in two launches, same arguments: _stats writes everything but dO (what the dWg product waits for: c_s, O'_s; and
+ * lse, tok_nll, y32, the statistics -- folded by the launch's last workgroup: stats must hold VMMT_STAT_COUNT floats with
+ * stats[VMMT_STAT_TICKET] zero), _dO writes dO alone (the fold of the slices' partial accumulators; cs / Os are ignored) -- the training
+ * step issues the second one behind the point where the weight-gradient product starts. */
+int vmmt_gen_fwd_combine_stats(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
+                               int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
+                               float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride, const int32_t* rows,
+                               void* stream);
+int vmmt_gen_fwd_combine_dO(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
+                            int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
+                            float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride, const int32_t* rows,
+                            void* stream);
 int vmmt_gen_dW_finish(int dtype, const void* P, int64_t ldp, const float* cs, const void* O, int64_t ldo, const int* y32, int M, int V,
                        int K, float inv_norm, float* dW, int64_t lddw, float* dbias, int colsum_done, const int32_t* rows, void* stream);
 /* COMPACTED tokens (rows != NULL in the three calls above): pads carry loss weight zero (Loss.py:163-165) but a dense sweep spends FLOPs on

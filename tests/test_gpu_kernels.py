@@ -345,6 +345,19 @@ def test_generator_fused_pass_bf16(M, V, H, ramp):
     assert e1 <= 6e-3 * sc * max(1.0, W[:V].float().abs().max().item()), e1
     assert (y32[M:] == -1).all() and (y32[:M].cpu() == torch.where(y == 1, -1, y).int()).all()
     assert (Pw[M:] == 3.0).all() and (Pw[:, (V + 31) // 32 * 32:] == 3.0).all() and (Os[:, M:] == 0).all()
+    # the same fold in two launches (the training step: the dWg product starts between them): _stats leaves dO alone, _dO writes dO alone
+    dO2 = torch.full((M, H + 4), 7.0, device="cuda"); st2 = torch.zeros(8, device="cuda")
+    lse2, nll2, cs2, Os2, y322 = torch.zeros_like(lse), torch.zeros_like(nll), torch.zeros_like(cs), torch.zeros_like(Os), torch.zeros_like(y32)
+    L.check(lib.vmmt_gen_fwd_combine_stats(L.BF16, P(Wd), H, P(Od), H, P(yd), M, V, H, 1, inv_norm, P(ws), P(tl), P(lse2), P(nll2), P(y322),
+                                           P(dO2), H + 4, P(st2), P(cs2), P(Os2), H, Mk * H, None, None), "combine stats")
+    torch.cuda.synchronize()
+    assert (dO2 == 7.0).all() and torch.equal(lse2, lse) and torch.equal(nll2, nll) and torch.equal(cs2, cs) and torch.equal(Os2, Os)
+    assert torch.equal(st2[:7], st[:7]) and int(st2[L.STAT_TICKET].view(torch.int32)) == 0 and torch.equal(y322, y32)      # (the ticket resets itself)
+    keep = [t.clone() for t in (lse2, nll2, cs2, Os2, st2, y322)]
+    L.check(lib.vmmt_gen_fwd_combine_dO(L.BF16, P(Wd), H, P(Od), H, P(yd), M, V, H, 1, inv_norm, P(ws), P(tl), P(lse2), P(nll2), P(y322),
+                                        P(dO2), H + 4, P(st2), P(cs2), P(Os2), H, Mk * H, None, None), "combine dO")
+    torch.cuda.synchronize()
+    assert torch.equal(dO2, dO) and all(torch.equal(a_, b_) for a_, b_ in zip(keep, (lse2, nll2, cs2, Os2, st2, y322)))
     dW2 = torch.empty(V, H, device="cuda")
     for s_ in range(ns):
         v0, v1 = s_ * vps, min(V, (s_ + 1) * vps)

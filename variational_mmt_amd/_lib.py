@@ -16,6 +16,7 @@ GEMM_NT, GEMM_TN, GEMM_NN = 0, 1, 2
 TILE_128_ONE_PER_CU = 129
 (STAT_NLL, STAT_NWORDS, STAT_NCORRECT, STAT_KL_SUM, STAT_IMG_LOGPROB, STAT_IMG_COS, STAT_GRAD_SUMSQ) = range(7)
 STAT_COUNT = 8
+STAT_TICKET = 7          # vmmt.h: VMMT_STAT_TICKET (a work word of vmmt_gen_fwd_combine_stats)
 SUMSQ_SLOTS, SUMSQ_MAXBLOCKS = 8, 768
 SEQ_GUARD_WORD = 4 + 2 * 256                                        # vmmt.h: VMMT_SEQ_GUARD_WORD
 SUMSQ_SCRATCH = 2 * SUMSQ_SLOTS + SUMSQ_SLOTS * SUMSQ_MAXBLOCKS      # vmmt.h: VMMT_SUMSQ_SCRATCH
@@ -97,6 +98,8 @@ _SIGS = {
     "vmmt_gen_fused_ws_floats": (i64, [i32, i32, i32]),
     "vmmt_gen_fwd_dO": (i32, [i32, vp, i64, i32, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, i64, vp, vp]),
     "vmmt_gen_fwd_combine": (i32, [i32, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp]),
+    "vmmt_gen_fwd_combine_stats": (i32, [i32, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp]),
+    "vmmt_gen_fwd_combine_dO": (i32, [i32, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp]),
     "vmmt_compact_nonpad": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "vmmt_gen_fused_geometry": (i32, [i32, i32, i32, vp, vp, vp]),
     "vmmt_gen_dW_finish": (i32, [i32, vp, i64, vp, vp, i64, vp, i32, i32, i32, f32, vp, i64, vp, i32, vp, vp]),

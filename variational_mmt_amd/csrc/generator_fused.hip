@@ -1241,7 +1241,10 @@ __global__ void __launch_bounds__(256, 1) gen2w_kernel(Gen2Args a) {
 // combine of pass F: 8 tokens per workgroup (32 threads per token).  Folds the vocabulary slices' (ref, l, max, acc) and writes
 //   lse, tok_nll, the statistics (NLL, words, correct), y32 (targets as int32, -1 at pads; whole 32-token tiles),
 //   dO[m][h] = s_m (sum_s w_s acc_s[m][h] / l* - Wg[y_m][h]),  w_s = exp(ref_s - ref*).
-template <int D>
+// MODE 0: everything.  The training step runs the fold in TWO launches: MODE 1 -- the per-token results (lse, tok_nll, statistics, y32, c_s,
+// O'_s: what the dWg product waits for, 10 us) -- and MODE 2 -- dO, the fold of the slices' 63 MB of partial accumulators, which only the
+// main stream's backward chain needs: the weight-gradient product starts a launch earlier, beside the fold instead of behind it.
+template <int D, int MODE = 0>
 __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restrict__ p_acc, const float* __restrict__ p_ref,
                                                            const float* __restrict__ p_l, const float* __restrict__ p_max, long mpad, int nsplit,
                                                            const float* __restrict__ tgt_logit, const long long* __restrict__ y, int M, int pad,
@@ -1250,7 +1253,9 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
                                                            int* __restrict__ y32, float* __restrict__ dO, long lddo, float* __restrict__ blk_part,
                                                            const bf16_t* __restrict__ O, long ldo, float* __restrict__ cs,
                                                            bf16_t* __restrict__ Os, long ldos, long os_stride,
-                                                           const int* __restrict__ rows) {
+                                                           const int* __restrict__ rows, float* __restrict__ stats) {
+  // stats != NULL (MODE 1): the launch's LAST workgroup folds the statistics' partial sums itself (ticket: stats[VMMT_STAT_TICKET], zero
+  // between steps) -- no gen2_stats_kernel between this launch and the dWg product that waits for it.
   // rows != NULL: the launch's tokens are a compacted list -- token m is row rows[m] of O, y, lse, tok_nll and dO (< 0: no token: treated
   // as a pad); P, y32, c_s, O'_s, the partials and tgt_logit are indexed by m
   constexpr int MAXS = 16;
@@ -1288,20 +1293,20 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
       // slice s stored its softmax weights in units of exp(ref_s): dL/dlogit[m][v] = P[m][v] c_s[m] - [v == y_m] s_m
       const float c = live ? sc * __expf(r_s - ls) : 0.f;
       s_w[tk][sl] = w; s_c[tk][sl] = c;
-      if (cs && sl < nsplit) cs[(long)sl * mpad + m] = c;
+      if (MODE != 2 && cs && sl < nsplit) cs[(long)sl * mpad + m] = c;
       if (sl == 0) {
         const float tl = tgt_logit[m];
         nll = wv ? ls - tl : 0.f;
-        if (rmap >= 0) { lse[rmap] = ls; tok_nll[rmap] = nll; }
+        if (MODE != 2 && rmap >= 0) { lse[rmap] = ls; tok_nll[rmap] = nll; }
         nw = wv ? 1.f : 0.f;
         nc = (wv && tl >= mx) ? 1.f : 0.f;                  // accuracy: the target's logit is the row maximum (Loss.py:150-160)
-        y32[m] = wv ? (int)ym : -1;
+        if (MODE != 2) y32[m] = wv ? (int)ym : -1;
         s_invl[tk] = 1.f / l; s_sc[tk] = sc; s_y[tk] = (int)ym; s_row[tk] = rmap;
       }
     } else {
       s_w[tk][sl] = 0.f; s_c[tk][sl] = 0.f;
       if (sl == 0) {
-        if (m < ((M + 31) / 32) * 32) y32[m] = -1;
+        if (MODE != 2 && m < ((M + 31) / 32) * 32) y32[m] = -1;
         s_sc[tk] = 0.f; s_invl[tk] = 0.f; s_y[tk] = 0; s_row[tk] = -1;
       }
     }
@@ -1316,6 +1321,7 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
 #pragma unroll
   for (int c = 0; c < D / 128; ++c) {
     const int h = c * 128 + j * 4;
+    if constexpr (MODE != 1) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     // the slices' partials eight at a time: independent loads in flight (the kernel is latency-bound: 2.5 workgroups per CU)
     for (int s0 = 0; s0 < nsplit; s0 += 8) {
@@ -1338,7 +1344,8 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = sc * (v[e] * invl - w4[e]);
     if (srow >= 0) *reinterpret_cast<f32x4*>(dO + (long)srow * lddo + h) = v;
-    if (Os) {                                               // O'_s[m] = c_s[m] O[m] (bf16): the B operand of dWg = P_s^T O'_s
+    }
+    if (MODE != 2 && Os) {                                  // O'_s[m] = c_s[m] O[m] (bf16): the B operand of dWg = P_s^T O'_s
       const uint2 ob = *reinterpret_cast<const uint2*>(O + (long)(srow < 0 ? 0 : srow) * ldo + h);
       const float o4[4] = {__uint_as_float(ob.x << 16), __uint_as_float(ob.x & 0xffff0000u), __uint_as_float(ob.y << 16),
                            __uint_as_float(ob.y & 0xffff0000u)};
@@ -1353,15 +1360,51 @@ __global__ void __launch_bounds__(256) gen2_combine_kernel(const float* __restri
   }
   }
   }
-  if (tid < 128) {
+  if (MODE != 2 && tid < 128) {
     // statistics: per-wave partial sums into scratch, folded by gen2_stats_kernel (thousands of same-address atomics cost ~10-20 ns
     // each: with them this kernel took 70 us instead of 35)
     nll_t = wave_sum(nll_t); nw_t = wave_sum(nw_t); nc_t = wave_sum(nc_t);
     if ((tid & 63) == 0) {
       float* bp = blk_part + ((long)blockIdx.x * 2 + (tid >> 6)) * 3;
-      bp[0] = nll_t; bp[1] = nw_t; bp[2] = nc_t;
+      if (stats) {          // (read by another workgroup of this launch: write-through, at agent scope)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) __hip_atomic_store(bp + e, e == 0 ? nll_t : e == 1 ? nw_t : nc_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        bp[0] = nll_t; bp[1] = nw_t; bp[2] = nc_t;
+      }
     }
   }
+  if (MODE == 2 || !stats) return;
+  // every workgroup takes a ticket behind its partial sums (the hand-off of optim.hip's sumsq_kernel); the last one adds all of them in
+  // index order -- gen2_stats_kernel's order: the same bits
+  __shared__ int is_last;
+  __shared__ float red[4][3];
+  unsigned* ticket = reinterpret_cast<unsigned*>(stats + VMMT_STAT_TICKET);
+  __syncthreads();
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  float a[3] = {0.f, 0.f, 0.f};
+  const int n = (int)gridDim.x * 2;
+  for (int i = tid; i < n; i += 256)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) a[e] += __hip_atomic_load(blk_part + (long)i * 3 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int e = 0; e < 3; ++e) a[e] = wave_sum(a[e]);
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) red[tid >> 6][e] = a[e];
+  __syncthreads();
+  if (tid < 3) {
+    const int e = tid;
+    const int slot = e == 0 ? VMMT_STAT_NLL : e == 1 ? VMMT_STAT_NWORDS : VMMT_STAT_NCORRECT;
+    stats[slot] += red[0][e] + red[1][e] + red[2][e] + red[3][e];
+  }
+  if (tid == 0) *ticket = 0u;
 }
 
 // stats[NLL, NWORDS, NCORRECT] += the combine kernel's per-wave partial sums (one workgroup; fixed order: reproducible)
@@ -1603,13 +1646,15 @@ extern "C" int vmmt_gen_fwd_dO(int dtype, const void* W, int64_t ldw, int w_rows
 }
 
 // folds the slices of the sweep: lse, tok_nll, statistics, dO, y32 and (cs != NULL) c_s / O'_s for the dWg GEMM
-extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
-                                    int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
-                                    float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride,
-                                    const int32_t* rows, void* stream) {
+template <int MODE>
+static int g2_combine(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
+                      int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
+                      float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride,
+                      const int32_t* rows, void* stream) {
   using namespace vmmt;
-  if (!W || !O || !y || !ws || !tgt_logit || !lse || !tok_nll || !y32 || !dO || !stats || lddo < K || (lddo & 3) || (((uintptr_t)dO) & 15))
-    return VMMT_EINVAL;
+  if (!W || !O || !y || !ws || !tgt_logit) return VMMT_EINVAL;
+  if (MODE != 2 && (!lse || !tok_nll || !y32 || !stats)) return VMMT_EINVAL;
+  if (MODE != 1 && (!dO || lddo < K || (lddo & 3) || (((uintptr_t)dO) & 15))) return VMMT_EINVAL;
   if ((cs != nullptr) != (Os != nullptr)) return VMMT_EINVAL;
   if (cs && (ldos < K || (ldos & 3) || (((uintptr_t)Os) & 7) || os_stride < (int64_t)M * ldos)) return VMMT_EINVAL;
   if (!g2_applies(dtype, W, ldw, O, ldo, M, V, K)) return VMMT_EINVAL;
@@ -1623,20 +1668,39 @@ extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const
   float* blk_part = ws + (long)ns * mpad * (K + 3);
   const int mt = (M + 31) / 32 * 32;
   const int ncb = (mt + 8 * G2_COMBINE_GROUPS - 1) / (8 * G2_COMBINE_GROUPS);
-  if (K == 1024)
-    hipLaunchKernelGGL((gen2_combine_kernel<1024>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
-                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
-                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride, rows);
-  else if (K == 512)
-    hipLaunchKernelGGL((gen2_combine_kernel<512>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
-                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
-                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride, rows);
-  else
-    hipLaunchKernelGGL((gen2_combine_kernel<256>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,
-                       (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,
-                       (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride, rows);
-  hipLaunchKernelGGL(gen2_stats_kernel, dim3(1), dim3(256), 0, st, blk_part, ncb * 2, stats);
+#define VMMT_G2_COMBINE(D)                                                                                                              \
+  hipLaunchKernelGGL((gen2_combine_kernel<D, MODE>), dim3(ncb), dim3(256), 0, st, p_acc, p_ref, p_l, p_max, mpad, ns, tgt_logit,        \
+                     (const long long*)y, M, pad, inv_norm, (const bf16_t*)W, (long)ldw, lse, tok_nll, y32, dO, (long)lddo, blk_part,   \
+                     (const bf16_t*)O, (long)ldo, cs, (bf16_t*)Os, (long)ldos, (long)os_stride, rows, MODE == 1 ? stats : nullptr)
+  if (K == 1024) VMMT_G2_COMBINE(1024);
+  else if (K == 512) VMMT_G2_COMBINE(512);
+  else VMMT_G2_COMBINE(256);
+#undef VMMT_G2_COMBINE
+  if (MODE == 0) hipLaunchKernelGGL(gen2_stats_kernel, dim3(1), dim3(256), 0, st, blk_part, ncb * 2, stats);
   return check_launch();
+}
+
+extern "C" int vmmt_gen_fwd_combine(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
+                                    int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
+                                    float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride,
+                                    const int32_t* rows, void* stream) {
+  return g2_combine<0>(dtype, W, ldw, O, ldo, y, M, V, K, pad, inv_norm, ws, tgt_logit, lse, tok_nll, y32, dO, lddo, stats, cs, Os, ldos, os_stride,
+                       rows, stream);
+}
+// the same fold in two launches (same arguments; see gen2_combine_kernel): _stats leaves dO alone, _dO writes nothing but dO
+extern "C" int vmmt_gen_fwd_combine_stats(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
+                                          int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
+                                          float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride,
+                                          const int32_t* rows, void* stream) {
+  return g2_combine<1>(dtype, W, ldw, O, ldo, y, M, V, K, pad, inv_norm, ws, tgt_logit, lse, tok_nll, y32, dO, lddo, stats, cs, Os, ldos, os_stride,
+                       rows, stream);
+}
+extern "C" int vmmt_gen_fwd_combine_dO(int dtype, const void* W, int64_t ldw, const void* O, int64_t ldo, const int64_t* y, int M, int V, int K,
+                                       int pad, float inv_norm, float* ws, const float* tgt_logit, float* lse, float* tok_nll, int* y32,
+                                       float* dO, int64_t lddo, float* stats, float* cs, void* Os, int64_t ldos, int64_t os_stride,
+                                       const int32_t* rows, void* stream) {
+  return g2_combine<2>(dtype, W, ldw, O, ldo, y, M, V, K, pad, inv_norm, ws, tgt_logit, lse, tok_nll, y32, dO, lddo, stats, nullptr, nullptr, ldos,
+                       os_stride, rows, stream);
 }
 
 // what the dWg GEMMs (one per vocabulary slice: dWg[slice] = P[:, slice]^T O'_slice, plain vmmt_gemm calls) leave to do:

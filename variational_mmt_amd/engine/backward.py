@@ -186,9 +186,15 @@ class BackwardPlan(object):
             elif not rp:
                 kl_and_q_backward()
 
+        self._comb_dO_entry = None
+
         def main_head():
-            # main: dropout + tanh backward, linear_out, attention
+            # main: [dO: the second half of the sweep's fold,] dropout + tanh backward, linear_out, attention
             e._sid = MAIN
+            if self.gen_fused and getattr(self, "_combine_split", False):
+                self._comb_dO_entry = len(P)
+                self._patch["comb_dO"] = (len(P), 10)
+                e._call(P, lib.vmmt_gen_fwd_combine_dO, *self._combine_args)
             e._call(P, lib.vmmt_act_bwd, dt, L.ACT_TANH, self.dO32.p(), self.dO32.ld, 1, self.AH.p(), self.AH.ld,
                     self.out_mask.p() if drop else None, self.out_mask.ld if drop else 0, self.dPre.p(), self.dPre.ld, M, H)
             e._record(P, "dPre")

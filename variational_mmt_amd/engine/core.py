@@ -110,6 +110,7 @@ class Engine(StepAPI):
         self.aux_early = True
         self.aux_kl_first = True
         self.gen_db_in_gemm = True
+        self.split_combine = True    # the sweep's fold in two launches: the dWg product starts beside the fold of dO, not behind it
         self.lstm_db_in_gemm = True
         self.dec_grads_on_aux = True
         self.bwd_main_first = True      # issue order of the backward plan (see _plan_backward)
@@ -195,7 +196,7 @@ class Engine(StepAPI):
     # the schedule knobs an experiment may set through VMMT_ENGINE_ATTRS (name -> parser); everything else is refused
     _ATTR_KNOBS = dict(
         bg_adam_blocks=int, fg_adam_blocks=int, max_split_k=int, wgrad_target_tiles=int, lazy_roll=int, shape_bucket=int,
-        cond_aux_early=_knob_bool, cond_emb_fg=_knob_bool, aux_early=_knob_bool, aux_kl_first=_knob_bool, gen_db_in_gemm=_knob_bool,
+        cond_aux_early=_knob_bool, cond_emb_fg=_knob_bool, aux_early=_knob_bool, aux_kl_first=_knob_bool, gen_db_in_gemm=_knob_bool, split_combine=_knob_bool,
         lstm_db_in_gemm=_knob_bool, dec_grads_on_aux=_knob_bool, bwd_main_first=_knob_bool, bwd_layers_parallel=_knob_bool,
         group_wgrads=_knob_bool, use_side_stream=_knob_bool, use_aux_stream=_knob_bool, gen_compact=_knob_bool, q_parallel=_knob_bool,
         dec_gx_first=_knob_bool, zero_on_aux=_knob_bool, split_optim=_knob_bool, bg_after_head=_knob_bool, hold_back=_knob_bool,

@@ -488,10 +488,15 @@ class Workspace(BackwardPlan, ConditionalPlans):
             e._call(P, lib.vmmt_gen_fwd_dO, e.dt, wg.p(), wg.ld, wg.t.shape[0], e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(), self.M, d.vt,
                     Kp, self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.gen_P.data_ptr(), self.gen_ldp, None)
             self._loss_patch = (len(P), 10)
-            e._call(P, lib.vmmt_gen_fwd_combine, e.dt, wg.p(), wg.ld, O.p(), O.ld, self.y.data_ptr(), self.M, d.vt, Kp, PAD, 0.0,
-                    self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.lse.data_ptr(), self.tok_nll.data_ptr(),
-                    self.gen_y32.data_ptr(), self.dO32.p(), self.dO32.ld, self.stats.data_ptr(), self.gen_cs.data_ptr(),
-                    self.gen_Os.data_ptr(), self.gen_Os.shape[2], self.gen_Os.shape[1] * self.gen_Os.shape[2], None)
+            # the fold in two launches (Engine.split_combine): here what the dWg product waits for (c_s, O'_s) and the statistics; dO -- the
+            # fold of the slices' 63 MB of partial accumulators, which only the main stream's backward chain reads -- is the backward plan's
+            # first main-stream entry, BEHIND the point where the side stream's dWg starts (`bwd_begin`)
+            self._combine_args = (e.dt, wg.p(), wg.ld, O.p(), O.ld, self.y.data_ptr(), self.M, d.vt, Kp, PAD, 0.0,
+                                  self.gen_ws.data_ptr(), self.tgt_logit.data_ptr(), self.lse.data_ptr(), self.tok_nll.data_ptr(),
+                                  self.gen_y32.data_ptr(), self.dO32.p(), self.dO32.ld, self.stats.data_ptr(), self.gen_cs.data_ptr(),
+                                  self.gen_Os.data_ptr(), self.gen_Os.shape[2], self.gen_Os.shape[1] * self.gen_Os.shape[2], None)
+            self._combine_split = bool(e.split_combine)
+            e._call(P, lib.vmmt_gen_fwd_combine_stats if self._combine_split else lib.vmmt_gen_fwd_combine, *self._combine_args)
             return P
         e._call(P, lib.vmmt_gen_loss_fwd, e.dt, wg.p(), wg.ld, e.pp("generator.0.bias"), O.p(), O.ld, self.y.data_ptr(),
                 self.M, d.vt, _ru(d.hid, KPAD), PAD, self.part_max.data_ptr(), self.part_sum.data_ptr(), None,
@@ -553,6 +558,9 @@ class Workspace(BackwardPlan, ConditionalPlans):
         P = self.plan_bwd
         fn, args, name, keep, sid = P[self._finish_entry]
         P[self._finish_entry] = (fn, args[:7] + (self.gen_Mc,) + args[8:15] + (rows,), name, keep, sid)
+        if getattr(self, "_comb_dO_entry", None) is not None:          # (the second half of the fold: as the loss plan's entry, set_token_count)
+            fn, args, name, keep, sid = P[self._comb_dO_entry]
+            P[self._comb_dO_entry] = (fn, args[:6] + (self.gen_Mc,) + args[7:22] + (os_stride, rows), name, keep, sid)
         self._bwd_tokens = self.gen_Mc
 
     def backward_plan(self, inv_norm, batch_global, kl_mult, use_freebits, margin, drop):
