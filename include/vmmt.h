@@ -95,6 +95,12 @@ typedef struct vmmt_gemm_args {
                   column sums (colsum_out / colsum_out2) follow the same map */
   int c_col_blk, c_col_valid; /* the same for the N output columns (e.g. dW_out [H][2H] of GlobalAttention.py:187 from a [c ; r]
                   buffer whose halves are padded) */
+  const int64_t* a_row_ids; /* != NULL (layout NT, bf16, the 128 x 128 LDS-DMA configuration: K % 64 == 0, lda % 4 == 0; VMMT_EINVAL otherwise):
+                  row m of the A operand is row a_row_ids[m] of the TABLE at A (lda = the table's row stride) -- the embedding lookup
+                  (modules/Embeddings.py:169-188) as the A-operand fetch of the LSTM's input projection (Models.py:124-129): the product's
+                  LDS staging reads the table rows by token id, no [tokens x E] copy is written or read.  Every id must be a row of the
+                  table; a row stride that is not a multiple of 8 elements is fine (the LDS-DMA takes any 4-byte aligned source), the
+                  K - lda columns read beyond a row's end must be finite and meet zero columns of B */
 } vmmt_gemm_args;
 int vmmt_gemm(const vmmt_gemm_args* args, void* stream);
 int vmmt_gemm_colsum_applies(const vmmt_gemm_args* args);
@@ -511,6 +517,11 @@ int vmmt_dp_norm_fold(const float* rows, int world, float* sumsq, int32_t* guard
 int vmmt_rows_mark(const int64_t* ids, int64_t n, int32_t* flags, int R, const int32_t* hist, void* stream);
 int vmmt_rows_catchup(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last, int32_t* hist,
                       float beta1, float beta2, float eps, int mode, void* stream);
+/* mode 0 with a bf16 copy of every flagged row written behind its catch-up: shadow [R][ld_shadow] (ld_shadow >= C, a multiple of 8: 16-byte
+ * aligned rows; the columns beyond C are never written) -- the table the LSTM's input projection fetches its A operand from by token id
+ * (vmmt_gemm_args.a_row_ids): current for exactly the rows the batch looks up. */
+int vmmt_rows_catchup_shadow(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last, int32_t* hist,
+                             float beta1, float beta2, float eps, void* shadow_bf16, int64_t ld_shadow, void* stream);
 int vmmt_adam_rows_step(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last, int32_t* hist,
                         float lr, float beta1, float beta2, float eps, int step, int roll, float max_norm, const float* sumsq,
                         float grad_scale, const int32_t* skip, void* stream);

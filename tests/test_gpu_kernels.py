@@ -398,6 +398,52 @@ def test_gemm_per_row_block_b_operand():
     assert lib.vmmt_gemm(C.byref(bad), None) != 0                   # blocks must be whole tiles (multiples of 256 rows)
 
 
+def test_gemm_gathered_a_operand_equals_gather_then_gemm():
+    """vmmt_gemm_args.a_row_ids: row m of the A operand is row ids[m] of a table with UNPADDED rows (E = 500 elements: every other row
+    starts 8 bytes off a 16-byte boundary) -- the embedding lookup as the operand fetch of the LSTM's input projection
+    (modules/Embeddings.py:169-188 feeding Models.py:124-129).  Same bits as vmmt_gather_rows into a zero-padded buffer + the plain product."""
+    from variational_mmt_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(11)
+    T = torch.bfloat16
+    R, E, Kp, N = 3000, 500, 512, 640
+    for M in (1000, 5120, 37):                                     # partial last tile, the benchmark's token count, less than one tile
+        table32 = torch.randn(R, E, generator=g) * 0.5
+        table = torch.zeros(R + 64, E, dtype=T, device="cuda")    # (+ rows of slack: the last row's slab reads 12 elements beyond its end)
+        table[:R] = table32.to(T).cuda()
+        ids = torch.randint(0, R, (M,), generator=g)
+        ids[0], ids[-1] = R - 1, 0
+        idsd = ids.cuda()
+        W = torch.zeros(N, Kp, dtype=T, device="cuda")            # zero columns E .. Kp - 1: what the operand reads beyond a row meets zeros
+        W[:, :E] = (torch.randn(N, E, generator=g) * 0.5).to(T).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        X = torch.zeros(M, Kp, dtype=T, device="cuda")
+        X[:, :E] = table[idsd]
+        outs = []
+        for gathered in (False, True):
+            Cd = torch.full((M, N), 7.0, device="cuda")
+            if gathered:
+                a = L.GemmArgs(L.BF16, L.GEMM_NT, table.data_ptr(), E, W.data_ptr(), Kp, Cd.data_ptr(), N, M, N, Kp, 0, 0, bias.data_ptr(), N, 1, 0,
+                               L.ACT_NONE, 1, 0, 1.0, None, 1, 0, 0, 0, 0)
+                a.a_row_ids = idsd.data_ptr()
+            else:
+                a = L.GemmArgs(L.BF16, L.GEMM_NT, X.data_ptr(), Kp, W.data_ptr(), Kp, Cd.data_ptr(), N, M, N, Kp, 0, 0, bias.data_ptr(), N, 1, 0,
+                               L.ACT_NONE, 1, 0, 1.0, None, 1, 128, 0, 0, 0)
+            L.check(lib.vmmt_gemm(C.byref(a), None), "gemm")
+            torch.cuda.synchronize()
+            outs.append(Cd)
+        assert torch.equal(outs[0], outs[1]), (M, (outs[0] - outs[1]).abs().max().item())
+        want = X[:, :E].float() @ W[:, :E].float().t() + bias
+        assert (outs[1] - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+    # refused where the gathered loop does not apply: fp32, another layout, a reduction length that is not whole slabs
+    bad = L.GemmArgs(L.BF16, L.GEMM_NN, table.data_ptr(), E, W.data_ptr(), Kp, Cd.data_ptr(), N, M, N, Kp, 0, 0, None, 0, 0, 0, L.ACT_NONE, 1, 0, 1.0, None, 1, 0, 0, 0, 0)
+    bad.a_row_ids = idsd.data_ptr()
+    assert lib.vmmt_gemm(C.byref(bad), None) != 0
+    bad = L.GemmArgs(L.BF16, L.GEMM_NT, table.data_ptr(), E, W.data_ptr(), Kp, Cd.data_ptr(), N, M, N, E, 0, 0, None, 0, 0, 0, L.ACT_NONE, 1, 0, 1.0, None, 1, 0, 0, 0, 0)
+    bad.a_row_ids = idsd.data_ptr()
+    assert lib.vmmt_gemm(C.byref(bad), None) != 0
+
+
 def test_gemm_weighted_column_sums_of_the_k_strided_operand():
     """vmmt_gemm_args.colsum_w / colsum_out: colsum_out[m] += sum_k A[k][m] w_block(m)[k] out of the same pass as C = A^T B (the
     generator's bias gradient next to its weight gradient), where vmmt_gemm_colsum_applies() says so; the product itself unchanged"""

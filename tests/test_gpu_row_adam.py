@@ -195,11 +195,16 @@ def test_engine_lazy_rows_equal_dense_over_many_steps(dtype):
         for e in (a, b):
             assert torch.equal(e.params[name][idle].cpu(), p[name][idle]), name
     names = [en[2] for en in a.workspace(6, 5, 5).plan_fwd_train]
-    assert names.count("vmmt_rows_catchup") == 2           # (the rows are flagged by vmmt_prepare_batch)
-    for k in ("vmmt_rows_catchup",):
-        assert names.index(k) < names.index("vmmt_gather_rows")       # in front of the lookups
+    catchups = [n for n in names if n.startswith("vmmt_rows_catchup")]           # (the rows are flagged by vmmt_prepare_batch)
+    # bf16: the source table's catch-up also writes the rows' bf16 copy, which the encoder's input projection reads by token id
+    assert sorted(catchups) == (["vmmt_rows_catchup", "vmmt_rows_catchup_shadow"] if dtype == "bf16" else ["vmmt_rows_catchup"] * 2), catchups
+    assert names.index(catchups[0]) < names.index("vmmt_gather_rows") and names.index(catchups[0]) < names.index("gemm")      # in front of the lookups
+    for k in ("vmmt_rows_catchup", "vmmt_rows_catchup_shadow"):
         assert k not in [en[2] for en in a.workspace(6, 5, 5).plan_fwd_eval]
         assert k not in [en[2] for en in b.workspace(6, 5, 5).plan_fwd_train]
+    if dtype == "bf16":          # the fused lookup: no source gather in front of the first product, one gather less on the main stream
+        fused = [en for en in a.workspace(6, 5, 5).plan_fwd_train if en[2] == "gemm" and en[3].a_row_ids]
+        assert len(fused) == 1 and not any(en[3].a_row_ids for en in b.workspace(6, 5, 5).plan_fwd_train if en[2] == "gemm")
 
 
 def test_lazy_rows_switched_on_and_off_between_updates():

@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
                 ("out_f32", i32), ("accumulate", i32), ("alpha", f32), ("scatter_ids", vp), ("pad_id", i32),
                 ("tile", i32), ("split_k", i32), ("b_batch_rows", i32), ("b_batch_stride", i64),
                 ("colsum_w", vp), ("colsum_w_stride", i64), ("colsum_out", vp), ("colsum_out2", vp),
-                ("c_row_blk", i32), ("c_row_valid", i32), ("c_col_blk", i32), ("c_col_valid", i32)]
+                ("c_row_blk", i32), ("c_row_valid", i32), ("c_col_blk", i32), ("c_col_valid", i32), ("a_row_ids", vp)]
 
 
 class LstmDirFwd(C.Structure):
@@ -134,6 +134,7 @@ _SIGS = {
     "vmmt_dp_norm_fold": (i32, [vp, i32, vp, vp, vp]),
     "vmmt_rows_mark": (i32, [vp, i64, vp, i32, vp, vp]),
     "vmmt_rows_catchup": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, i32, vp]),
+    "vmmt_rows_catchup_shadow": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, vp, i64, vp]),
     "vmmt_adam_rows_step": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, f32, i32, i32, f32, vp, f32, vp, vp]),
     "vmmt_sumsq_rows": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp]),
 }

@@ -20,7 +20,7 @@ struct GemmEpi {
   const float* colsum_w; long colsum_w_stride; float* colsum_out; // K-strided A only: colsum_out[m] += sum_k A[k][m] w[k] (w per B block)
   float* colsum_out2;                                            // unit weights (colsum_w == NULL): a second destination of the same sums
   int rblk, rvalid, cblk, cvalid;                                // output row / column block map (vmmt_gemm_args.c_row_blk): 0 = identity
-};
+};   // (the gathered-A instantiation, EPI = 2, finds vmmt_gemm_args.a_row_ids in `scatter_ids`: one more field here costs every product 16 registers)
 
 // The epilogue runs as a few small, fully unrolled passes over the accumulator registers (static indices only:
 // a run-time-indexed accumulator would be demoted to scratch), with the run-time switches hoisted outside.
@@ -66,7 +66,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, f32x16 (&acc)[TI
     else if (e.accumulate) { VMMT_MAPPED(*p += v;) }
     else { VMMT_MAPPED(*p = v;) }
 #undef VMMT_MAPPED
-  } else if (e.scatter_ids) {
+  } else if (EPI != 2 && e.scatter_ids) {
     float* C = reinterpret_cast<float*>(e.C);
     VMMT_FOR_ACC(long long id = e.scatter_ids[row]; if (id != e.pad_id) atomicAdd(C + id * e.ldc + col, v);)
   } else if (e.atomic) {
@@ -130,8 +130,8 @@ __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, long lda, con
   } else if constexpr (GL == 1) {
     // plain column sums of A (unit weights) in the workgroups of the first column tile, every K split adds its share
     float* co = (epi.colsum_out && !epi.colsum_w && tn == 0) ? epi.colsum_out : nullptr;
-    gemm_mainloop_glds<BM, BN, NT / 64, A_KC, B_KC, TI, TJ>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, co, epi.colsum_out2,
-                                                            epi.rblk, epi.rvalid);
+    gemm_mainloop_glds<BM, BN, NT / 64, A_KC, B_KC, TI, TJ, true, EPI == 2>(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, aoff, boff, acc, smem_raw, co,
+                                                                            epi.colsum_out2, epi.rblk, epi.rvalid, epi.scatter_ids);   // (EPI = 2: the gathered-A instantiation)
   } else {
     gemm_mainloop<T, BM, BN, BK, NT, A_KC, B_KC, TI, TJ, LinearMap, LinearMap, DB>(A, lda, amap, B, ldb, bmap, kend, a_kmod,
                                                                                     b_kmod, aoff, boff, acc, smem, kbeg);
@@ -231,6 +231,14 @@ static int launch_layout(const vmmt_gemm_args* a, const GemmEpi& epi, hipStream_
   if constexpr (sizeof(T) == 2)
     gl_ok = a->K % 64 == 0 && a->K > 0 && a->lda % 8 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 &&
             ((((uintptr_t)a->A) | ((uintptr_t)a->B)) & 15) == 0;
+  if (a->a_row_ids) {          // gathered A operand: the two-stage 128 x 128 LDS-DMA loop, K-contiguous operands, table rows from 4-byte aligned addresses
+    if constexpr (sizeof(T) == 2 && A_KC && B_KC) {
+      if (a->K % 64 == 0 && a->K > 0 && a->lda % 4 == 0 && a->ldb % 8 == 0 && a->a_kmod == 0 && a->b_kmod == 0 && ((((uintptr_t)a->A) & 3) | (((uintptr_t)a->B) & 15)) == 0 &&
+          !epi.colsum_out && !epi.colsum_w && (a->tile == 0 || a->tile == 128))
+        return launch_cfg<T, 128, 128, 64, 64, A_KC, B_KC, 64, true, 1, 2>(a, epi, st);      // an instantiation of its own: the plain product keeps its registers
+    }
+    return VMMT_EINVAL;
+  }
   // With the LDS-DMA loop a 128 x 128 workgroup retires a 64-deep slab in ~0.55 us against ~0.4 us per 32-deep slab of the
   // 64 x 64 configuration, so for long reductions it is also the lower-LATENCY choice when there are fewer tiles than CUs
   // (M = 256 products of the inference networks at K = 2048: 20 us instead of 26-32 us); below K = 1024 the 64 x 64
@@ -387,6 +395,10 @@ static int gemm_make_epi(const vmmt_gemm_args* a, vmmt::GemmEpi& e) {
   e.b_batch_rows = a->b_batch_rows; e.b_batch_stride = (long)a->b_batch_stride;
   e.colsum_w = a->colsum_w; e.colsum_w_stride = (long)a->colsum_w_stride; e.colsum_out = a->colsum_out; e.colsum_out2 = a->colsum_out2;
   e.rblk = a->c_row_blk; e.rvalid = a->c_row_valid; e.cblk = a->c_col_blk; e.cvalid = a->c_col_valid;
+  if (a->a_row_ids) {
+    if (a->scatter_ids || a->split_k > 1) return VMMT_EINVAL;
+    e.scatter_ids = (const long long*)a->a_row_ids;              // (read as the A operand's row ids by the EPI = 2 instantiation, see GemmEpi)
+  }
   if (e.rblk < 0 || e.cblk < 0 || (e.rblk > 0 && (e.rvalid <= 0 || e.rvalid > e.rblk)) || (e.cblk > 0 && (e.cvalid <= 0 || e.cvalid > e.cblk)))
     return VMMT_EINVAL;
   if ((e.rblk | e.cblk) && (!a->out_f32 || a->scatter_ids || a->act != VMMT_ACT_NONE)) return VMMT_EINVAL;

@@ -34,7 +34,10 @@ struct GldsOperand {
   const char* src[PER];                          // per-lane source address of each of this wave's pieces (advanced every slab)
   long step;                                     // bytes per K slab
 
-  __device__ __forceinline__ void init(const bf16_t* P, long ld, int row0, int limit, int k0, int wave, int lane) {
+  // GATHER (K-contiguous operands): tile row r is row ids[row0 + r] of the table at P -- a gathered operand (vmmt_gemm_args.a_row_ids).  A
+  // template parameter, not a null check: the check alone cost the plain product 16 registers
+  template <bool GATHER = false>
+  __device__ __forceinline__ void init(const bf16_t* P, long ld, int row0, int limit, int k0, int wave, int lane, const long long* ids = nullptr) {
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int piece = wave * PER + j;
@@ -43,6 +46,8 @@ struct GldsOperand {
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int g = row0 + row;
         g = g < limit ? g : limit - 1;
+        if constexpr (GATHER) src[j] = reinterpret_cast<const char*>(P + (long)ids[g] * ld + k0 + chunk * 8);
+        else
         src[j] = reinterpret_cast<const char*>(P + (long)g * ld + k0 + chunk * 8);
       } else {
         // ROWS > 128: side-by-side sub-images of [64 k-rows][128 columns] (16 KiB each), 16 pieces per sub-image
@@ -171,12 +176,12 @@ __device__ __forceinline__ void glds_colsum128_slab(const char* As, int wave, in
 }
 
 // C_tile += A_tile * B_tile^T over k in [kbeg, kend), kend - kbeg a positive multiple of 64.
-template <int BM, int BN, int NW, bool A_KC, bool B_KC, int TI, int TJ, bool DBUF = true>
+template <int BM, int BN, int NW, bool A_KC, bool B_KC, int TI, int TJ, bool DBUF = true, bool GATHER_A = false>
 __device__ __forceinline__ void gemm_mainloop_glds(const bf16_t* __restrict__ A, long lda, int m0, int M, const bf16_t* __restrict__ B,
                                                    long ldb, int n0, int N, int kbeg, int kend, const int (&aoff)[TI],
                                                    const int (&boff)[TJ], f32x16 (&acc)[TI][TJ], char* __restrict__ smem,
                                                    float* __restrict__ colsum_out = nullptr, float* __restrict__ colsum_out2 = nullptr,
-                                                   int cs_blk = 0, int cs_valid = 0) {
+                                                   int cs_blk = 0, int cs_valid = 0, const long long* __restrict__ a_ids = nullptr) {
   constexpr int ABYTES = BM * GBK * 2, BBYTES = BN * GBK * 2, BUF = ABYTES + BBYTES;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   constexpr bool CS_OK = !A_KC && BM == 128 && NW == 4 && DBUF;   // the shape glds_colsum128_slab is written for
@@ -184,7 +189,7 @@ __device__ __forceinline__ void gemm_mainloop_glds(const bf16_t* __restrict__ A,
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
   GldsOperand<BM, A_KC, NW> ga;
   GldsOperand<BN, B_KC, NW> gb;
-  ga.init(A, lda, m0, M, kbeg, wave, lane);
+  ga.template init<GATHER_A && A_KC>(A, lda, m0, M, kbeg, wave, lane, a_ids);
   gb.init(B, ldb, n0, N, kbeg, wave, lane);
   GldsFrag<A_KC, TI> fa;
   GldsFrag<B_KC, TJ> fb;

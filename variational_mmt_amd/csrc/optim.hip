@@ -253,7 +253,8 @@ __device__ __forceinline__ void lazy_row(float* __restrict__ p, float* __restric
 template <int MODE>
 __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_catchup_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                                             float* __restrict__ v, int R, int C, const int* __restrict__ flags,
-                                                                            int* __restrict__ last, int* __restrict__ hist, float b1, float b2, float eps) {
+                                                                            int* __restrict__ last, int* __restrict__ hist, float b1, float b2, float eps,
+                                                                            bf16_t* __restrict__ shadow, long ld_shadow) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r0 = blockIdx.x * 64;
   const int upto = hist[0];
   int lst = upto;
@@ -273,6 +274,17 @@ __global__ void __launch_bounds__(64 * VMMT_ROWS_WAVES) rows_catchup_kernel(floa
     if (MODE == 1 && from >= upto) continue;
     lazy_row<false, MODE == 0>(p, g, m, v, (long)(r0 + b) * C, C, from, upto, hist, b1, b2, eps, false, 0.f, 0.f, 0.f);
     if (lane == 0 && from < upto) last[r0 + b] = upto;
+    if (MODE == 0 && shadow) {          // the row's compute copy (its own lanes wrote the row just now: the same addresses, in program order)
+      const float* pr = p + (long)(r0 + b) * C;
+      bf16_t* sr = shadow + (long)(r0 + b) * ld_shadow;
+      for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(pr + c);
+        uint2 o;
+        o.x = (uint32_t)f2bf(q[0]) | ((uint32_t)f2bf(q[1]) << 16);
+        o.y = (uint32_t)f2bf(q[2]) | ((uint32_t)f2bf(q[3]) << 16);
+        *reinterpret_cast<uint2*>(sr + c) = o;
+      }
+    }
   }
 }
 
@@ -435,8 +447,20 @@ extern "C" int vmmt_rows_catchup(float* p, float* g, float* m, float* v, int R, 
   using namespace vmmt;
   if (!lazy_rows_ok(p, g, m, v, R, C) || !last || !hist || (mode != 0 && mode != 1) || (mode == 0 && (!flags || !g))) return VMMT_EINVAL;
   const dim3 grid((unsigned)((R + 63) / 64)), block(64 * VMMT_ROWS_WAVES);
-  if (mode == 0) hipLaunchKernelGGL(rows_catchup_kernel<0>, grid, block, 0, (hipStream_t)stream, p, g, m, v, R, C, flags, last, hist, beta1, beta2, eps);
-  else hipLaunchKernelGGL(rows_catchup_kernel<1>, grid, block, 0, (hipStream_t)stream, p, g, m, v, R, C, flags, last, hist, beta1, beta2, eps);
+  if (mode == 0) hipLaunchKernelGGL(rows_catchup_kernel<0>, grid, block, 0, (hipStream_t)stream, p, g, m, v, R, C, flags, last, hist, beta1, beta2, eps,
+                                    (bf16_t*)nullptr, 0L);
+  else hipLaunchKernelGGL(rows_catchup_kernel<1>, grid, block, 0, (hipStream_t)stream, p, g, m, v, R, C, flags, last, hist, beta1, beta2, eps,
+                          (bf16_t*)nullptr, 0L);
+  return check_launch();
+}
+
+extern "C" int vmmt_rows_catchup_shadow(float* p, float* g, float* m, float* v, int R, int C, const int32_t* flags, int32_t* last, int32_t* hist,
+                                        float beta1, float beta2, float eps, void* shadow_bf16, int64_t ld_shadow, void* stream) {
+  using namespace vmmt;
+  if (!lazy_rows_ok(p, g, m, v, R, C) || !last || !hist || !flags || !g || !shadow_bf16 || ld_shadow < C || (ld_shadow & 7) || (((uintptr_t)shadow_bf16) & 15))
+    return VMMT_EINVAL;
+  hipLaunchKernelGGL(rows_catchup_kernel<0>, dim3((unsigned)((R + 63) / 64)), dim3(64 * VMMT_ROWS_WAVES), 0, (hipStream_t)stream, p, g, m, v, R, C, flags,
+                     last, hist, beta1, beta2, eps, (bf16_t*)shadow_bf16, (long)ld_shadow);
   return check_launch();
 }
 

@@ -132,6 +132,7 @@ class Engine(StepAPI):
         self.q_parallel = True    # q(z|x): scale branch on the side stream next to the location branch
         self.dec_gx_first = True  # side stream of the forward: the decoder's input projection in front of the gradient zeroing / masks
         self.zero_on_aux = True   # ... and the zeroing / masks on the AUX stream (idle at that point of the forward) instead of behind it
+        self.fuse_emb_gemm = True # the source embeddings as the gathered A operand of the encoder's first input projection (Engine.row_shadow)
         self.trace = None            # list -> _run appends (name, timing event) at every main-stream phase change
         self._kl_sum_needed = True   # set per step by Workspace.backward_plan: does the latent backward read the (global) KL sum?
         self.trace_only = None       # ... of these entry names only (every event costs the stream ~10 us: tools/phase_times.py COARSE=1)
@@ -199,7 +200,7 @@ class Engine(StepAPI):
         cond_aux_early=_knob_bool, cond_emb_fg=_knob_bool, aux_early=_knob_bool, aux_kl_first=_knob_bool, gen_db_in_gemm=_knob_bool, split_combine=_knob_bool,
         lstm_db_in_gemm=_knob_bool, dec_grads_on_aux=_knob_bool, bwd_main_first=_knob_bool, bwd_layers_parallel=_knob_bool,
         group_wgrads=_knob_bool, use_side_stream=_knob_bool, use_aux_stream=_knob_bool, gen_compact=_knob_bool, q_parallel=_knob_bool,
-        dec_gx_first=_knob_bool, zero_on_aux=_knob_bool, split_optim=_knob_bool, bg_after_head=_knob_bool, hold_back=_knob_bool,
+        dec_gx_first=_knob_bool, zero_on_aux=_knob_bool, fuse_emb_gemm=_knob_bool, split_optim=_knob_bool, bg_after_head=_knob_bool, hold_back=_knob_bool,
         fused_qnet=_knob_bool, qnet_split=_knob_bool, gen_fused=_knob_bool, persistent_lstm=_knob_bool, seq_fallback=_knob_bool,
         row_adam=_knob_bool, reparam_grad=_knob_bool)
     # environment switches of rounds 2-4 that became attributes (or went with their kernels) in round 5: setting one is a mistake worth a line
@@ -333,7 +334,7 @@ class Engine(StepAPI):
                                         flags=torch.zeros(2 * R, dtype=torch.int32, device=self.dev),      # [parity of the update][row]
                                         last=torch.zeros(R, dtype=torch.int32, device=self.dev),
                                         hist=torch.zeros(L.LAZY_HIST_WORDS, dtype=torch.int32, device=self.dev),
-                                        rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev)))
+                                        rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev), shadow=None))
         self._row_adam = _os_env.get("VMMT_ROW_ADAM", "1") == "1"
 
     @property
@@ -431,7 +432,7 @@ class Engine(StepAPI):
         s_, t_ = self.row_tables
         return (s_["flags"].data_ptr(), s_["R"], t_["flags"].data_ptr(), t_["R"], self._step_count + 1)
 
-    def _row_mark_entries(self, plan, table_index, ids_ptr, n_ids):
+    def _row_mark_entries(self, plan, table_index, ids_ptr, n_ids, with_shadow=False):
         """plan entry (training forward, IN FRONT of the table's lookup): the rows the batch flagged (vmmt_prepare_batch) are brought up to
         date and their gradient rows cleared, which the backward plan's scatter-add accumulates into"""
         if not self.rows_active():
@@ -439,9 +440,27 @@ class Engine(StepAPI):
         t = self.row_tables[table_index]
         o = 4 * t["off"]
         b1, b2, eps = self._adam_consts
+        sh = self.row_shadow(table_index) if with_shadow else None
+        if sh is not None:
+            self._call(plan, self.lib.vmmt_rows_catchup_shadow, self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o,
+                       self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(), t["hist"].data_ptr(),
+                       b1, b2, eps, sh.p(), sh.ld)
+            return
         self._call(plan, self.lib.vmmt_rows_catchup, self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.flat_m.data_ptr() + o,
                    self.flat_v.data_ptr() + o, t["R"], t["C"], t["flags"].data_ptr(), t["last"].data_ptr(), t["hist"].data_ptr(),
                    b1, b2, eps, 0)
+
+    def row_shadow(self, table_index):
+        """bf16 copy of an embedding table with 16-byte aligned rows (padded to whole K slabs, the padding zero), CURRENT FOR THE ROWS OF THE
+        BATCH ONLY: the catch-up of a training forward writes a row's copy behind bringing it up to date.  The table the encoder's first
+        input projection fetches its A operand from by token id (vmmt_gemm_args.a_row_ids): north_star's embedding lookup fused into the
+        LSTM gate GEMM.  None where that does not apply (fp32, the dense update)"""
+        if not (self.rows_active() and self.dt == L.BF16 and self.fuse_emb_gemm):
+            return None
+        t = self.row_tables[table_index]
+        if t["shadow"] is None:
+            t["shadow"] = Buf(t["R"] + 64, t["C"], torch.bfloat16, self.dev)       # (+ rows of slack behind the last one)
+        return t["shadow"]
 
     def pp(self, name, r=0, c=0):
         o, shp = self.offsets[name]
@@ -653,7 +672,7 @@ class Engine(StepAPI):
     # ------------------------------------------------------------------------------------------------ helpers
     def _gemm(self, plan, layout, A, lda, B, ldb, Cp, ldc, M, N, K, addend=None, ld_add=0, add_rows=0, add_is_T=0,
               act=L.ACT_NONE, out_f32=0, accumulate=0, alpha=1.0, a_kmod=0, b_kmod=0, scatter_ids=None, tile=0, split_k=0,
-              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None, group=None):
+              b_batch_rows=0, b_batch_stride=0, colsum=None, rmap=None, cmap=None, group=None, a_row_ids=None):
         """plan entry: one vmmt_gemm.  colsum = (w, w_stride, out[, out2]): the column sums of the K-strided A operand from the same
         pass (weighted by w, or plain with w = None), where the library offers them; returns whether they were attached.
         group (a list): the product is not issued but collected -- _gemm_group() sends the list out as ONE grid (vmmt_gemm_group)"""
@@ -675,6 +694,7 @@ class Engine(StepAPI):
         a = L.GemmArgs(self.dt, layout, A, lda, B, ldb, Cp, ldc, M, N, K, a_kmod, b_kmod, addend, ld_add, add_rows,
                        add_is_T, act, out_f32, accumulate, alpha, scatter_ids, PAD, tile, split_k, b_batch_rows, b_batch_stride,
                        None, 0, None, None)
+        a.a_row_ids = a_row_ids       # (NT: row m of A is row a_row_ids[m] of the table at A -- the embedding lookup as the product's operand fetch)
         # rmap / cmap = (blk, valid): output rows / columns computed in padded blocks, stored densely (vmmt_gemm_args.c_row_blk)
         if rmap is not None and rmap[0] != rmap[1]:
             a.c_row_blk, a.c_row_valid = rmap

@@ -182,13 +182,28 @@ class Workspace(BackwardPlan, ConditionalPlans):
         # (bg_after_head) the head of the main stream first -- source rows and the encoder's first input projection -- and only behind it the
         # side-stream half of the last optimiser step (BG_FLUSH) and the side stream's own work, the decoder's input projection first
         early_head = bool(training and e.bg_after_head and not d.conditional and e.use_side_stream)
-        if early_head:
-            e._row_mark_entries(P, 0, self.src.data_ptr(), MS)
+        # the source embeddings: the A operand of the encoder's first input projection is fetched from the table's bf16 copy by token id INSIDE
+        # the product (no lookup launch, no [S B x E] copy in front of it); the copy the backward multiplies (dW_ih) is gathered later, on
+        # the side stream.  Training plans of the lazily updated tables only: their catch-up keeps the copy current for the batch's rows
+        emb_tab = e.row_shadow(0) if training else None
+
+        def src_gather():
             e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                     self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
+
+        def enc_gx0():
             wih, bsum = e.sh["enc_wih_l0"], e.sh["enc_b_l0"]
-            e._gemm(P, L.GEMM_NT, self.Xs.p(), self.Xs.ld, wih.p(), wih.ld, self.enc_gx[0].p(), self.enc_gx[0].ld, MS, dirs * 4 * Hdp,
-                    E, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+            if emb_tab is not None:
+                e._gemm(P, L.GEMM_NT, emb_tab.p(), emb_tab.ld, wih.p(), wih.ld, self.enc_gx[0].p(), self.enc_gx[0].ld, MS, dirs * 4 * Hdp,
+                        E, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1, a_row_ids=self.src.data_ptr())
+            else:
+                e._gemm(P, L.GEMM_NT, self.Xs.p(), self.Xs.ld, wih.p(), wih.ld, self.enc_gx[0].p(), self.enc_gx[0].ld, MS, dirs * 4 * Hdp,
+                        E, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
+        if early_head:
+            e._row_mark_entries(P, 0, self.src.data_ptr(), MS, with_shadow=emb_tab is not None)
+            if emb_tab is None:
+                src_gather()
+            enc_gx0()
             e._record(P, "fwd_begin")
             P.append((None, None, "BG_FLUSH", None, MAIN))
 
@@ -277,14 +292,17 @@ class Workspace(BackwardPlan, ConditionalPlans):
         # a2 source embeddings
         if not early_head:
             if training:
-                e._row_mark_entries(P, 0, self.src.data_ptr(), MS)
-            e._call(P, lib.vmmt_gather_rows, dt, e.pp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E,
-                    self.src.data_ptr(), self.Xs.p(), self.Xs.ld, MS, E)
+                e._row_mark_entries(P, 0, self.src.data_ptr(), MS, with_shadow=emb_tab is not None)
+            if emb_tab is None:
+                src_gather()
         # a3 encoder
         x, xcols = self.Xs, E
         for l in range(Lyr):
             wih, bsum = e.sh["enc_wih_l%d" % l], e.sh["enc_b_l%d" % l]
-            if not (early_head and l == 0):
+            if l == 0:
+                if not early_head:
+                    enc_gx0()
+            else:
                 e._gemm(P, L.GEMM_NT, x.p(), x.ld, wih.p(), wih.ld, self.enc_gx[l].p(), self.enc_gx[l].ld, MS, dirs * 4 * Hdp,
                         xcols, addend=bsum.p(), ld_add=bsum.ld, add_rows=1, out_f32=1)
             seq = (L.LstmDirFwd * (S * dirs))()                 # the whole recurrence: step-major, then direction
@@ -370,6 +388,10 @@ class Workspace(BackwardPlan, ConditionalPlans):
         e._record(P, "z_ready")
         e._sid = SIDE
         e._wait(P, "z_ready")
+        if emb_tab is not None:
+            # the [S B x E] copy of the source embeddings for the backward's dW_ih product only: here, behind a wait that orders this stream
+            # behind the main stream's catch-up of the batch's rows, off every critical path (joined by `img_fwd`)
+            src_gather()
         if training and self.z_in_Xt:       # z over the decoder steps next to the target embeddings (see Xt): for the backward's dW_ih
             e._call(P, lib.vmmt_gather_rows, dt, self.z32.p(), self.z32.ld, self.zrep_ids.data_ptr(), self.Xt.p(0, self.Ep), self.Xt.ld, M, Z)
         e._call(P, lib.vmmt_gate_fwd, dt, self.z32.p(), e.pp("inf_net_image.gate_affine_transform.weight"),
