@@ -277,3 +277,29 @@ def test_lazy_rows_follow_a_step_counter_set_from_outside():
             u, w = getattr(x, what)[:n], getattr(b, what)[:n]
             assert (u - w).abs().max().item() <= 1e-5 * max(1.0, w.abs().max().item()), what          # (14 updates of float-atomic noise)
     assert a.lazy_errors() == [0, 0] and t.lazy_errors() == [0, 0]
+
+
+@pytest.mark.parametrize("rows", [False, True])
+def test_a_write_to_the_arena_from_outside_goes_behind_the_side_streams_half_of_the_update(rows):
+    """`engine.flat_m.zero_()` straight after optim_step() (Optim.py's mirror does that for a NEW Adam) must land behind the half of the update
+    that the side stream is still running -- with the dense tables as with the lazy ones.  The side stream is held up by a long sleep in
+    front of the update here, so that the order is the engine's doing and not the box's timing (the full suite caught this once as a
+    one-in-many failure of the dense twin in the test above)"""
+    from variational_mmt_amd.engine import Dims, Engine
+    c = O.Cfg(vs=97, vt=89, emb=24, hid=32, z=8, layers=1, brnn=True)
+    e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype="f32", device="cuda", seed=1)
+    e.row_adam = rows
+    e.load_state_dict(O.init_params(c, seed=2))
+    assert e.use_side_stream and e.split_optim
+    for step in range(2):
+        bt = O.synth_batch(c, 6, 5, 6, n_img=12, seed=40 + step, fixed_len=False)
+        e.set_image_table(bt["table"])
+        e.loss_backward(e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"]), normalization=6)
+        if step == 1:
+            with torch.cuda.stream(e.side_stream):
+                torch.cuda._sleep(200_000_000)          # ~0.1 s in front of the side stream's half
+        e.optim_step(lr=0.01, max_grad_norm=5.0)
+    e.flat_m.zero_()
+    e.flat_v.zero_()
+    torch.cuda.synchronize()
+    assert float(e.flat_m.abs().max()) == 0.0 and float(e.flat_v.abs().max()) == 0.0

@@ -14,17 +14,19 @@ from .workspace import Workspace
 
 
 def _behind_background(name):
-    """attribute that the side-stream half of an optimiser step writes (master parameters, Adam moments): reading it from outside issues
-    a held-back half first (Engine.bg_after_head) and orders the current stream behind it, so `engine.params[...]` after optim_step() is
-    the updated value in every mode"""
+    """attribute that the side-stream half of an optimiser step writes (master parameters, Adam moments): reading it from outside a step
+    issues a held-back half first (Engine.bg_after_head) and orders the current stream behind the side stream's half WHETHER HELD BACK OR
+    NOT (`_bg_open`: an update has put work on the side stream that the current stream has not waited for), so `engine.params[...]`,
+    `engine.flat_m.zero_()` or a `.cpu()` after optim_step() see -- and write behind -- the finished update in every mode"""
     priv = "_" + name
 
     def get(self):
         dd = self.__dict__
-        if dd.get("_pending_bg") and not dd.get("_in_flush"):
-            self.wait_background()
-        if dd.get("_lazy_dirty") and not dd.get("_in_step") and not dd.get("_in_flush"):
-            self.flush_lazy_rows()          # (the embedding tables' rows are brought up to date lazily: _build_row_tables)
+        if not dd.get("_in_flush"):
+            if dd.get("_pending_bg") or (dd.get("_bg_open") and not dd.get("_in_step")):
+                self.wait_background()
+            if dd.get("_lazy_dirty") and not dd.get("_in_step"):
+                self.flush_lazy_rows()          # (the embedding tables' rows are brought up to date lazily: _build_row_tables)
         try:
             return dd[priv]
         except KeyError:
@@ -482,6 +484,8 @@ class Engine(StepAPI):
             ev = self.global_events.get(name)
             if ev is not None:
                 (stream if stream is not None else torch.cuda.current_stream(self.dev)).wait_event(ev)
+        if stream is None:
+            self._bg_open = False
 
     def _flush_bg(self, after=None, parts=None, stream=None):
         """issue the side-stream half of the last optimiser step if it was held back (bg_after_head): its first `parts` pieces (default:

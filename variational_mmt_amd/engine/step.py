@@ -290,6 +290,7 @@ class StepAPI(object):
             self._publish_guard(main)
         self._adam_launches = max(1, n_launch[0])
         self.shadows_dirty = False
+        self._bg_open = bool(self.use_side_stream and self.split_optim)     # (a read of the arena from outside a step waits for the side stream's half)
 
     def _optim_step_sharded(self, lr, max_grad_norm, beta1, beta2, eps, grad_scale):
         """Data-parallel optimiser step with the state sharded over the ranks (dp.GradSync.sharded).  The backward plan has
@@ -356,3 +357,4 @@ class StepAPI(object):
         self._publish_guard(side)
         self._adam_launches = max(1, n_launch[0])
         self.shadows_dirty = False
+        self._bg_open = side is not main
