@@ -677,6 +677,13 @@ def main():
     # self-check of the schedule on THIS box: the step is 3.4 ms of kernel time packed into ~1.7 ms by three streams of different priority
     # and persistent kernels that need their workgroups co-resident.  A few steps with everything on ONE stream against a few steps as
     # scheduled: a box (a driver, a queue configuration) on which the packing is lost shows a ratio near 1 and the line says so
+    # the host's collector out of the timed regions: a full collection of a process that has imported torch walks ~10^6 objects (tens of
+    # ms, the length of the whole 20-step region); nothing the steps allocate is cyclic, reference counting frees it.  In FRONT of the
+    # self-check below, not behind it: the collection leaves the GPU idle for ~0.1 s, and a region that starts behind an idle gap ran its
+    # first ten steps 3-10 % slow (clock ramp: step_ms lists of round 5's first leases)
+    import gc
+    gc.collect()
+    gc.freeze()
     overlap = None
     if world == 1 and not a.no_side_stream and not a.no_overlap_probe:
         def timed_steps(n, first):
@@ -697,13 +704,7 @@ def main():
         packed = timed_steps(4, 3)
         overlap = {"one_stream_ms": round(serial, 3), "as_scheduled_ms": round(packed, 3), "ratio": round(serial / packed, 3),
                    "verdict": "streams overlap" if serial / packed > 1.12 else "NO OVERLAP: the side / aux streams' work does not run beside the main stream's on this box"}
-    # the host's collector out of the timed regions: a full collection of a process that has imported torch walks ~10^6 objects (tens of
-    # ms, the length of the whole 20-step region); nothing the steps allocate is cyclic, reference counting frees it
-    import gc
-    gc.collect()
-    gc.freeze()
-    # the W warm-up steps LAST, right in front of the timed region: the collection above leaves the GPU idle for ~0.1 s, and a region that
-    # starts behind an idle gap ran its first ten steps 3-10 % slow (clock ramp: step_ms lists of round 5's first leases)
+    # the W warm-up steps LAST, right in front of the timed region
     for i in range(n_warm):
         step(i)
     regions = []

@@ -72,3 +72,15 @@ def test_attention_backward_fits_beside_the_dwg_product(res):
     lite = _find(res, "attn_bwd_lite")
     assert 2 * dwg + lite <= 512, (dwg, lite)
     assert 3 * (256 + 128) * 64 * 2 + 6 * 32 * 40 * 2 <= 160 * 1024          # the product's three operand stages + P, dS and four tile buffers
+
+
+def test_small_elementwise_kernels_fit_beside_the_vocabulary_sweep(res):
+    """gen2p_kernel holds one wave per SIMD on 240 CUs; what it leaves of a SIMD's 512 registers per lane is what a kernel of another stream
+    may take to run there.  A kernel without LDS that needs more sat in the dispatcher until the sweep had ended (tools/probe_under_sweep.py:
+    80 us per launch against 5): the aux stream's small activation backward (4 elements per thread) stays inside that budget"""
+    free = 512 - _find(res, "gen2p_kernel", "Lb1")
+    assert free >= 24
+    for k, v in res.items():
+        if "act_bwd8_kernel" in k and "Li4E" in k:
+            assert _total(v) <= free, (k, v, free)
+    assert sum(1 for k in res if "act_bwd8_kernel" in k and "Li4E" in k) == 2

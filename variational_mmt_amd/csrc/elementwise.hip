@@ -152,38 +152,46 @@ __global__ void __launch_bounds__(256) mul8_kernel(const bf16_t* __restrict__ a,
   *reinterpret_cast<u32x4*>(out + (long)r * ldo + c) = o;
 }
 
-template <class TD>        // TD = float (a split-K accumulated gradient) or bf16_t
+// TD = float (a split-K accumulated gradient) or bf16_t; W = 8 or 4 elements per thread.  W = 4 is the form for the SMALL tensors of the
+// aux stream's chain (q(z|x) / image network backward), which runs beside the vocabulary sweep: gen2p_kernel leaves 24 registers per lane
+// free on its 240 CUs, and a kernel WITHOUT LDS that needs more than that was seen to sit in the dispatcher until the sweep had ended
+// (tools/probe_under_sweep.py: 80 us per launch against 5; the W = 8 form takes 29 registers, this one stays under 24: test_kernel_resources)
+template <class TD, int W>
 __global__ void __launch_bounds__(256) act_bwd8_kernel(int act, const TD* __restrict__ dy, long lddy, const bf16_t* __restrict__ y, long ldy,
-                                                       const bf16_t* __restrict__ mask, long ldm, bf16_t* __restrict__ out, long ldo, int R, int C8) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)R * C8) return;
-  const int r = (int)(i / C8), c = (int)(i - (long)r * C8) * 8;
-  float g[8];
+                                                       const bf16_t* __restrict__ mask, long ldm, bf16_t* __restrict__ out, long ldo, int R, int CW) {
+  typedef uint32_t uw __attribute__((ext_vector_type(W / 2)));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * CW) return;
+  const int r = i / CW, c = (i - r * CW) * W;
+  float g[W];
   if constexpr (sizeof(TD) == 4) {
-    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dy + (long)r * lddy + c), d1 = *reinterpret_cast<const f32x4*>(dy + (long)r * lddy + c + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { g[e] = d0[e]; g[4 + e] = d1[e]; }
+    for (int q = 0; q < W / 4; ++q) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (long)r * lddy + c + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[4 * q + e] = d[e];
+    }
   } else {
-    const u32x4 d = *reinterpret_cast<const u32x4*>(dy + (long)r * lddy + c);
+    const uw d = *reinterpret_cast<const uw*>(dy + (long)r * lddy + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { g[2 * e] = __uint_as_float(d[e] << 16); g[2 * e + 1] = __uint_as_float(d[e] & 0xffff0000u); }
+    for (int e = 0; e < W / 2; ++e) { g[2 * e] = __uint_as_float(d[e] << 16); g[2 * e + 1] = __uint_as_float(d[e] & 0xffff0000u); }
   }
   if (mask) {
-    const u32x4 m = *reinterpret_cast<const u32x4*>(mask + (long)r * ldm + c);
+    const uw m = *reinterpret_cast<const uw*>(mask + (long)r * ldm + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { g[2 * e] *= __uint_as_float(m[e] << 16); g[2 * e + 1] *= __uint_as_float(m[e] & 0xffff0000u); }
+    for (int e = 0; e < W / 2; ++e) { g[2 * e] *= __uint_as_float(m[e] << 16); g[2 * e + 1] *= __uint_as_float(m[e] & 0xffff0000u); }
   }
-  float yy[8];
+  float yy[W];
   if (y) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(y + (long)r * ldy + c);
+    const uw v = *reinterpret_cast<const uw*>(y + (long)r * ldy + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { yy[2 * e] = __uint_as_float(v[e] << 16); yy[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+    for (int e = 0; e < W / 2; ++e) { yy[2 * e] = __uint_as_float(v[e] << 16); yy[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) yy[e] = 0.f;
+    for (int e = 0; e < W; ++e) yy[e] = 0.f;
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
+  for (int e = 0; e < W; ++e) {
     switch (act) {
       case VMMT_ACT_RELU: g[e] = yy[e] > 0.f ? g[e] : 0.f; break;
       case VMMT_ACT_TANH: g[e] *= 1.f - yy[e] * yy[e]; break;
@@ -192,10 +200,10 @@ __global__ void __launch_bounds__(256) act_bwd8_kernel(int act, const TD* __rest
       default: break;
     }
   }
-  u32x4 o;
+  uw o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(g[2 * e]) | ((uint32_t)f2bf(g[2 * e + 1]) << 16);
-  *reinterpret_cast<u32x4*>(out + (long)r * ldo + c) = o;
+  for (int e = 0; e < W / 2; ++e) o[e] = (uint32_t)f2bf(g[2 * e]) | ((uint32_t)f2bf(g[2 * e + 1]) << 16);
+  *reinterpret_cast<uw*>(out + (long)r * ldo + c) = o;
 }
 
 // out = dy * mask * act'(y), with act' expressed through the activation OUTPUT y
@@ -619,10 +627,14 @@ extern "C" int vmmt_act_bwd(int dtype, int act, const void* dy, int64_t lddy, in
   if (!dy || !out || R < 0 || C < 0 || (act != VMMT_ACT_NONE && !y)) return VMMT_EINVAL;
   long n = (long)R * C;
   if (n == 0) return VMMT_OK;
-  const bool vec8 = dtype == VMMT_BF16 && C % 8 == 0 && lddy % (dy_f32 ? 4 : 8) == 0 && (!y || ldy % 8 == 0) && (!mask || ldm % 8 == 0) && ldo % 8 == 0 &&
+  const bool vec8 = dtype == VMMT_BF16 && n < (1l << 33) && C % 8 == 0 && lddy % (dy_f32 ? 4 : 8) == 0 && (!y || ldy % 8 == 0) && (!mask || ldm % 8 == 0) && ldo % 8 == 0 &&
                     ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)mask) | ((uintptr_t)out)) & 15) == 0;
-  if (vec8 && dy_f32) hipLaunchKernelGGL(act_bwd8_kernel<float>, BLOCKS(n / 8, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C / 8);
-  else if (vec8) hipLaunchKernelGGL(act_bwd8_kernel<bf16_t>, BLOCKS(n / 8, 256), dim3(256), 0, ST, act, (const bf16_t*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C / 8);
+  // (small tensors: 4 elements per thread -- the register budget beside the vocabulary sweep, see act_bwd8_kernel)
+  const bool small = n <= (1l << 20);
+  if (vec8 && dy_f32 && small) hipLaunchKernelGGL((act_bwd8_kernel<float, 4>), BLOCKS(n / 4, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C / 4);
+  else if (vec8 && dy_f32) hipLaunchKernelGGL((act_bwd8_kernel<float, 8>), BLOCKS(n / 8, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C / 8);
+  else if (vec8 && small) hipLaunchKernelGGL((act_bwd8_kernel<bf16_t, 4>), BLOCKS(n / 4, 256), dim3(256), 0, ST, act, (const bf16_t*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C / 4);
+  else if (vec8) hipLaunchKernelGGL((act_bwd8_kernel<bf16_t, 8>), BLOCKS(n / 8, 256), dim3(256), 0, ST, act, (const bf16_t*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C / 8);
   else if (dtype == VMMT_F32) hipLaunchKernelGGL((act_bwd_kernel<float, float>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const float*)y, (long)ldy, (const float*)mask, (long)ldm, (float*)out, (long)ldo, R, C);
   else if (dtype == VMMT_BF16 && dy_f32) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, float>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const float*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C);
   else if (dtype == VMMT_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, bf16_t>), BLOCKS(n, 256), dim3(256), 0, ST, act, (const bf16_t*)dy, (long)lddy, (const bf16_t*)y, (long)ldy, (const bf16_t*)mask, (long)ldm, (bf16_t*)out, (long)ldo, R, C);
