@@ -72,6 +72,9 @@ class NMTVIModel(nn.Module):
         return super(NMTVIModel, self).named_parameters(*args, **kwargs)
 
     def load_state_dict(self, state_dict, strict=True):
+        # (the copies below go into the arena through the aliasing nn.Parameters: behind the side stream's half of the last update, and
+        #  with every lazily updated embedding row brought up to date first -- a row loaded now must not be replayed for steps it was behind)
+        self.engine.wait_background()
         out = super(NMTVIModel, self).load_state_dict(state_dict, strict=strict)
         self.engine.shadows_dirty = True
         return out
