@@ -139,7 +139,7 @@ def _pair(c, p, dtype, **kw):
     from variational_mmt_amd.engine import Dims, Engine
     engines = {}
     for rows in (True, False):
-        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0), dtype=dtype, device="cuda", seed=1)
+        e = Engine(Dims(c.vs, c.vt, c.emb, c.hid, c.z, c.img, c.layers, c.brnn, 0.0, conditional=c.conditional), dtype=dtype, device="cuda", seed=1)
         e.row_adam = rows                       # (set before the first forward builds the plans)
         for k, v in kw.items():
             setattr(e, k, v)
@@ -149,45 +149,60 @@ def _pair(c, p, dtype, **kw):
     return engines
 
 
+@pytest.mark.parametrize("conditional", [False, True])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_engine_lazy_rows_equal_dense_over_many_steps(dtype):
+def test_engine_lazy_rows_equal_dense_over_many_steps(dtype, conditional):
     """the training step with the lazy tables against the same step with the dense zero-fill / norm / Adam: 24 updates on changing batches
     (rolling period 5: rows come round several times), an evaluation pass, a state_dict() in the middle, a learning-rate change and a
     second forward + backward without an update in between; parameters and moments agree to the run-to-run noise of the step itself
-    (float atomics in the gradient products), and rows no batch ever used did not move at all"""
-    c = O.Cfg(vs=97, vt=89, emb=24, hid=32, z=8, layers=1, brnn=True)
+    (float atomics in the gradient products), and rows no batch ever used did not move at all.  `conditional`: encoder_tgt looks the shared
+    target table up too -- by every target position and the pad fill of its transposed image, flagged by a launch of their own"""
+    c = O.Cfg(vs=97, vt=89, emb=24, hid=32, z=8, layers=1, brnn=True, conditional=conditional)
     p = O.init_params(c, seed=2)
     engines = _pair(c, p, dtype, lazy_roll=5)
     used_src, used_tgt = set(), set()
+    tl = lambda b_: dict(tgt_len=b_["tgt_len"]) if conditional else {}
     for step in range(24):
         bt = O.synth_batch(c, 6, 5 + step % 3, 6 + step % 2, n_img=12, seed=50 + step, fixed_len=False)
         used_src |= set(bt["src"].reshape(-1).tolist())
-        used_tgt |= set(bt["tgt"][:-1].reshape(-1).tolist())
+        used_tgt |= set((bt["tgt"] if conditional else bt["tgt"][:-1]).reshape(-1).tolist())
         for e in engines.values():
             e.set_image_table(bt["table"])
             if step == 4:        # a forward + backward whose gradients are thrown away (no update), then the real one
                 other = O.synth_batch(c, 6, 7, 6, n_img=12, seed=999, fixed_len=False)
-                ws = e.forward(other["src"], other["src_len"], other["tgt"], other["indices"], training=True, eps=other["eps"])
+                ws = e.forward(other["src"], other["src_len"], other["tgt"], other["indices"], training=True, eps=other["eps"], **tl(other))
                 e.loss_backward(ws, normalization=6)
-            ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"])
+            ws = e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=True, eps=bt["eps"], **tl(bt))
             e.loss_backward(ws, normalization=6)
             e.optim_step(lr=0.01 if step < 6 else 0.004, max_grad_norm=5.0 if step % 4 else 0.5)
             if step == 5:        # an evaluation pass between updates (validation inside an epoch): flushes
-                e.loss(e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=False))
+                e.loss(e.forward(bt["src"], bt["src_len"], bt["tgt"], bt["indices"], training=False, **tl(bt)))
             if step == 9:
                 sd = e.state_dict()                      # flushes
                 assert all(torch.isfinite(v).all() for v in sd.values())
         if step == 4:            # (the thrown-away batch's rows were flagged: they take a zero-gradient step like every other row)
             used_src |= set(other["src"].reshape(-1).tolist())
-            used_tgt |= set(other["tgt"][:-1].reshape(-1).tolist())
+            used_tgt |= set((other["tgt"] if conditional else other["tgt"][:-1]).reshape(-1).tolist())
+    if conditional:
+        used_tgt.add(O.PAD)
     torch.cuda.synchronize()
     a, b = engines[True], engines[False]
     assert a._lazy_dirty and a.lazy_errors() == [0, 0]
     tol = 5e-6 if dtype == "f32" else 2e-3
     for x, y, what in ((a.flat_p, b.flat_p, "p"), (a.flat_m, b.flat_m, "m"), (a.flat_v, b.flat_v, "v")):      # (reading the arena flushes)
         n = a.n_opt
-        err = (x[:n] - y[:n]).abs().max().item()
-        assert err <= tol * max(1.0, y[:n].abs().max().item()), (what, err)
+        err = (x[:n] - y[:n]).abs()
+        bound = tol * max(1.0, y[:n].abs().max().item())
+        for t in a.row_tables:          # the tables themselves: to the step's own run-to-run noise
+            assert err[t["off"]:t["end"]].max().item() <= bound, (what, t["name"], err[t["off"]:t["end"]].max().item())
+        if dtype == "f32":
+            assert err.max().item() <= bound, (what, err.max().item())
+        else:
+            # bf16, everything else: two DENSE runs of these 24 updates already differ by 1e-4 .. 3.4e-3 in a handful of elements of the image
+            # network's fc1 (tools' run-to-run matrix, LABNOTES round 6): float-atomic noise moves an activation across a bf16 rounding step
+            # or a ReLU gate, and Adam with eps 1e-9 turns a gradient of that size into a whole step of lr.  A few such elements, each
+            # by at most two steps of the largest lr -- anything systematic in the row update would show in the tables above
+            assert int((err > bound).sum()) <= 16 and err.max().item() <= 2e-2, (what, int((err > bound).sum()), err.max().item())
     assert not a._lazy_dirty and all(int((t["last"] != a.step_count).sum()) == 0 for t in a.row_tables)
     for name, used in (("encoder.embeddings.make_embedding.emb_luts.0.weight", used_src), ("decoder.embeddings.make_embedding.emb_luts.0.weight", used_tgt)):
         idle = [r for r in range(p[name].shape[0]) if r not in used]
@@ -195,6 +210,9 @@ def test_engine_lazy_rows_equal_dense_over_many_steps(dtype):
         for e in (a, b):
             assert torch.equal(e.params[name][idle].cpu(), p[name][idle]), name
     names = [en[2] for en in a.workspace(6, 5, 5).plan_fwd_train]
+    assert names.count("vmmt_rows_mark") == (1 if conditional else 0)            # (encoder_tgt's ids; everything else is flagged by vmmt_prepare_batch)
+    if conditional:
+        assert names.index("vmmt_rows_mark") < names.index("vmmt_rows_catchup")
     catchups = [n for n in names if n.startswith("vmmt_rows_catchup")]           # (the rows are flagged by vmmt_prepare_batch)
     # bf16: the source table's catch-up also writes the rows' bf16 copy, which the encoder's input projection reads by token id
     assert sorted(catchups) == (["vmmt_rows_catchup", "vmmt_rows_catchup_shadow"] if dtype == "bf16" else ["vmmt_rows_catchup"] * 2), catchups

@@ -63,6 +63,7 @@ class ConditionalPlans(object):
         #  it first in the background half and waiting for that alone was worth 3.524 -> 3.507 ms, this 3.518 -> 3.483)
         if not e.cond_emb_fg:
             e._wait(P, "side_fwd")
+        # (the lazily updated table: this batch's rows were brought up to date on THIS stream, in front of the decoder's lookup: Workspace.side_dec_gx)
         e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                 self.tgt_bt.data_ptr(), self.Yt.p(), self.Yt.ld, MT, E)
         x, xcols = self.Yt, E

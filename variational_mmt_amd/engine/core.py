@@ -317,16 +317,16 @@ class Engine(StepAPI):
             back after hundreds of steps and their replays, in front of the lookup, cost more than the traffic saved.)
           * everything that reads the tables from outside a training step -- state_dict(), `engine.params / flat_p / flat_m / flat_v`,
             evaluation and decoding plans, checkpoints, the dense optimisers, data parallelism -- flushes first (every row up to date).
-        Off under data parallelism (the flagged set would have to be the union over the ranks) and for the conditional model (two
-        streams flag rows of the shared target table).  `Engine.row_adam = False` restores the dense kernels."""
+        Off under data parallelism (the flagged set would have to be the union over the ranks).  The conditional model's encoder_tgt looks
+        the SHARED target table up as well (ModelConstructor.py:456-457): its ids are flagged by a launch of their own in front of the
+        table's one catch-up, which both lookups wait for (Workspace._plan_forward); off by default there (no gain measured).
+        `Engine.row_adam = False` restores the dense kernels."""
         names = ("encoder.embeddings.make_embedding.emb_luts.0.weight", "decoder.embeddings.make_embedding.emb_luts.0.weight")
         self._row_adam = False
         self._lazy_dirty = False             # rows behind the step counter exist (an update has run since the last flush)
         self._in_step = 0                    # > 0: inside forward / loss_backward / optim_step / a flush (reads of the arena are the engine's own)
         self.lazy_roll = 16                  # every row is brought up to date at least every `lazy_roll` updates (<= LAZY_HIST / 4)
         self.row_tables = []
-        if self.d.conditional:
-            return
         for n in names:          # (the bookkeeping arrays are always there -- 0.5 MB -- so that the switch can be set after construction)
             off, (R, Cc) = self.offsets[n]
             if Cc % 4 or off % 4:
@@ -337,7 +337,10 @@ class Engine(StepAPI):
                                         last=torch.zeros(R, dtype=torch.int32, device=self.dev),
                                         hist=torch.zeros(L.LAZY_HIST_WORDS, dtype=torch.int32, device=self.dev),
                                         rowsq=torch.zeros(R, dtype=torch.float32, device=self.dev), shadow=None))
-        self._row_adam = _os_env.get("VMMT_ROW_ADAM", "1") == "1"
+        # (the conditional model: built and tested -- tests/test_gpu_row_adam.py -- but level with the dense update there, 2.655-2.666 against
+        #  2.635-2.657 ms: the catch-up stands at the head of encoder_tgt's chain, that step's longest, for what the update's tail saves.
+        #  `engine.row_adam = True` switches it on)
+        self._row_adam = _os_env.get("VMMT_ROW_ADAM", "1") == "1" and not self.d.conditional
 
     @property
     def row_adam(self):
@@ -348,7 +351,7 @@ class Engine(StepAPI):
         """the switch may be set after construction: the cached launch plans carry (or omit) the row entries; switched OFF, every row is
         brought up to date first and the dense kernels find fully cleared table gradients; switched ON, every row is current for the
         step counter as it stands"""
-        on = bool(on) and not self.d.conditional and bool(self.row_tables)
+        on = bool(on) and bool(self.row_tables)
         if on == getattr(self, "_row_adam", False):
             return
         if hasattr(self, "ws"):

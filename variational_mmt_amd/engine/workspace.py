@@ -211,7 +211,24 @@ class Workspace(BackwardPlan, ConditionalPlans):
             if training:
                 # the lazily updated embedding tables (Engine._build_row_tables): flag this batch's rows, bring them up to date and clear
                 # their gradient rows IN FRONT of the lookup; this stream carried the table's share of the last update
-                e._row_mark_entries(P, 1, self.tgt_in.data_ptr(), M)
+                if d.conditional and e.rows_active():
+                    # encoder_tgt reads the same table by the transposed target's ids (every position, pad fill included): flagged by a
+                    # launch of their own in front of the table's ONE catch-up -- on the AUX stream, at the head of encoder_tgt's chain (the
+                    # conditional step's longest: behind this stream's share of the last update it started 0.1 ms later); this stream's
+                    # lookup waits for `tgt_rows`
+                    sid_ = e._sid
+                    e._sid = 2
+                    e._wait(P, "fwd_begin")
+                    if not e.cond_emb_fg:
+                        e._wait(P, "side_fwd")
+                    t_ = e.row_tables[1]
+                    e._call(P, lib.vmmt_rows_mark, self.tgt_bt.data_ptr(), self.MT, t_["flags"].data_ptr(), t_["R"], t_["hist"].data_ptr())
+                    e._row_mark_entries(P, 1, self.tgt_in.data_ptr(), M)
+                    e._record(P, "tgt_rows")
+                    e._sid = sid_
+                    e._wait(P, "tgt_rows")
+                else:
+                    e._row_mark_entries(P, 1, self.tgt_in.data_ptr(), M)
             e._call(P, lib.vmmt_gather_rows, dt, e.pp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E,
                     self.tgt_in.data_ptr(), self.Xt.p(), self.Xt.ld, M, E)
             we = e.sh["dec_wih_l0_e"]
