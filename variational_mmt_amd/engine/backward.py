@@ -36,6 +36,7 @@ class BackwardPlan(object):
         # (walking the vocabulary in 2-6 chunks, so that a chunk of G^T is consumed by dO / dWg while it is still in the Infinity
         #  Cache, was measured with tools/ab.py: 2.227-2.97 ms against 2.213 ms in one pass -- not kept)
         self._patch = {}
+        self._src_rows_normed = False
         if self.gen_fused:
             pass        # dO32 came out of the loss plan (vmmt_gen_fwd_dO); dWg / db: one GEMM + vmmt_gen_dW_finish on the side stream below
         elif fuse_db:
@@ -428,6 +429,11 @@ class BackwardPlan(object):
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, wih.p(), wih.ld, self.dXs.p(), self.dXs.ld, MS, E, dirs * 4 * Hdp, out_f32=1)
                 e._call(P, lib.vmmt_scatter_add_rows, self.dXs.p(), self.dXs.ld, self.src.data_ptr(), PAD,
                         e.gp("encoder.embeddings.make_embedding.emb_luts.0.weight"), E, MS, E)
+                if e.tail_norm_first and e.rows_active() and not e.dp_on():
+                    # the source table's flagged rows are final here: their norm right behind the scatter, beside the side stream's grid,
+                    # instead of in the step's tail behind the join
+                    P.append((None, (0, 3), "SUMSQ_ROWS", None, MAIN))
+                    self._src_rows_normed = True
                 e._sid = SIDE
 
             def alt():
@@ -532,10 +538,16 @@ class BackwardPlan(object):
         e._record(P, "side_done")
         e._sid = MAIN
         e._wait(P, "side_done")
-        if dec_on_aux:
+        # (tail_norm_first: the encoder segment's norm in front of the join with the aux stream -- whose own norms of the first half are the
+        #  last thing it runs -- instead of behind it; the update behind this plan needs both.  Not under data parallelism: the collectives'
+        #  issue order is part of the protocol)
+        norm_first = bool(dec_on_aux and getattr(e, "tail_norm_first", False) and not e.dp_on())
+        if dec_on_aux and not norm_first:
             e._wait(P, "aux_end")
         e._allreduce(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
-        e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight", 1)
+        e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight", 1, skip_rows=self._src_rows_normed)
+        if norm_first:
+            e._wait(P, "aux_end")
         return P
 
     # ------------------------------------------------------------------------------- conditional-prior variant (8f-1)

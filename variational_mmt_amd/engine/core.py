@@ -132,6 +132,7 @@ class Engine(StepAPI):
         self._masked_streams = []
         import os as _os
         self.q_parallel = True    # q(z|x): scale branch on the side stream next to the location branch
+        self.tail_norm_first = True   # backward plan: the encoder segment's norm in front of the main stream's join with the aux stream
         self.dec_gx_first = True  # side stream of the forward: the decoder's input projection in front of the gradient zeroing / masks
         self.zero_on_aux = True   # ... and the zeroing / masks on the AUX stream (idle at that point of the forward) instead of behind it
         self.fuse_emb_gemm = True # the source embeddings as the gathered A operand of the encoder's first input projection (Engine.row_shadow)
@@ -204,7 +205,7 @@ class Engine(StepAPI):
         group_wgrads=_knob_bool, use_side_stream=_knob_bool, use_aux_stream=_knob_bool, gen_compact=_knob_bool, q_parallel=_knob_bool,
         dec_gx_first=_knob_bool, zero_on_aux=_knob_bool, fuse_emb_gemm=_knob_bool, split_optim=_knob_bool, bg_after_head=_knob_bool, hold_back=_knob_bool,
         fused_qnet=_knob_bool, qnet_split=_knob_bool, gen_fused=_knob_bool, persistent_lstm=_knob_bool, seq_fallback=_knob_bool,
-        row_adam=_knob_bool, reparam_grad=_knob_bool)
+        row_adam=_knob_bool, reparam_grad=_knob_bool, tail_norm_first=_knob_bool)
     # environment switches of rounds 2-4 that became attributes (or went with their kernels) in round 5: setting one is a mistake worth a line
     _REMOVED_SWITCHES = frozenset((
         "VMMT_LATENT_ZX", "VMMT_FUSE_OUT_DROPOUT", "VMMT_DECODE_GRAPHS", "VMMT_BG_ADAM_BLOCKS", "VMMT_FG_ADAM_BLOCKS", "VMMT_MAX_SPLIT_K",
@@ -943,7 +944,7 @@ class Engine(StepAPI):
         hi = self.offsets[end_name][0] if end_name is not None else self.n_opt
         plan.append((None, (lo, min(hi, self.n_opt)), "ALLREDUCE", None, self._sid))
 
-    def _sumsq_entry(self, plan, first_name, end_name, slot):
+    def _sumsq_entry(self, plan, first_name, end_name, slot, skip_rows=False):
         """plan entry: ||g||^2 of an arena range into slot `slot` of the step's norm scratch (behind that range's all-reduce);
         every range has a slot of its own and Adam adds the slots in index order: the norm is bit-reproducible"""
         lo = self.offsets[first_name][0]
@@ -954,7 +955,8 @@ class Engine(StepAPI):
             # takes what lies in front of it (slot) and behind it (slot + 5: only the conditional model has parameters there)
             for k, t in enumerate(self.row_tables):
                 if lo <= t["off"] and t["end"] <= hi:
-                    plan.append((None, (k, 3 + k), "SUMSQ_ROWS", None, self._sid))
+                    if not skip_rows:           # (skip_rows: the table's flagged rows were normed earlier, right behind their last gradient)
+                        plan.append((None, (k, 3 + k), "SUMSQ_ROWS", None, self._sid))
                     if t["off"] > lo:
                         plan.append((None, (lo, t["off"], slot), "SUMSQ", None, self._sid))
                     if hi - t["end"] >= SEG_ALIGN:      # (less: only the segment's alignment padding follows)
