@@ -54,6 +54,15 @@ class BackwardPlan(object):
         # ================= aux: image term + its network (z is detached: independent of the text path) ==========
         rp = bool(e.reparam_grad)
         TGT = 3
+        # the decoder's parameter gradients and the first-half norm go to the AUX stream, which is idle once its own chain (image /
+        # q(z|x) networks) is through: behind the generator's products on the side stream they reached into the step's tail
+        dec_on_aux = bool(e.dec_grads_on_aux and not rp and not d.conditional and e.use_aux_stream)
+        # tail_norm_first: every piece of the gradient norm right behind the launch that completes its gradients, on that launch's stream,
+        # instead of as two chains of three norms behind the step's last products (the update needs all of them: 60 us of tail)
+        # (one-layer models: config 2 1.436-1.443 against 1.453-1.459 ms; the scripts' two layers measured 2.180-2.187 against 2.168-2.180 with the
+        #  pieces spread and level with only the main stream's two norms moved: they keep that form)
+        spread = bool(e.tail_norm_first and not e.dp_on() and dec_on_aux and d.layers == 1)
+        self._inf_normed = self._tgt_rows_normed = self._enc_dense_normed = False
         def kl_and_q_backward():
             # --- KL term -> q(z|x) networks (mu, sigma receive gradient only through the KL: H2) ------------------
             # data parallelism: free bits compares the GLOBAL batch-mean KL with the margin (VILoss.py:463-476), so the KL sum is
@@ -184,6 +193,9 @@ class BackwardPlan(object):
             elif kl_first:
                 e._allreduce(P, "inf_net_image.location.fc2.weight", None)     # inference networks: tail of the arena, done first
                 e._record(P, "aux_done")
+                if spread:
+                    e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None, 2)
+                    self._inf_normed = True
             elif not rp:
                 kl_and_q_backward()
 
@@ -285,9 +297,6 @@ class BackwardPlan(object):
         e._gemm(P, L.GEMM_TN, self.dQ.p(), self.dQ.ld, self.cat.p(0, Hp), self.cat.ld, e.gp("decoder.attn.linear_in.weight"), H,
                 H, H, M, out_f32=1, split_k=-1, group=grp)
         e._gemm_group(P, grp)
-        # the decoder's parameter gradients and the first-half norm go to the AUX stream, which is idle once its own chain (image /
-        # q(z|x) networks) is through: behind the generator's products on the side stream they reached into the step's tail
-        dec_on_aux = bool(e.dec_grads_on_aux and not rp and not d.conditional and e.use_aux_stream)
         # (the decoder's weight gradients held back until the encoder's backward recurrence is through -- both backward recurrences
         #  without guests, everything in the tail -- was measured in round 4: 1.80 against 1.735 ms per step; LABNOTES.md)
         # ================= decoder LSTM backward (main) + its parameter gradients (side / aux) ====================
@@ -365,6 +374,9 @@ class BackwardPlan(object):
                 e._gemm(P, L.GEMM_NN, dg.p(), dg.ld, we.p(), we.ld, self.dXt.p(), self.dXt.ld, M, E, 4 * Hp, out_f32=1)
                 e._call(P, lib.vmmt_scatter_add_rows, self.dXt.p(), self.dXt.ld, self.tgt_in.data_ptr(), PAD,
                         e.gp("decoder.embeddings.make_embedding.emb_luts.0.weight"), E, M, E)
+                if spread and dxt_side and e.rows_active():
+                    P.append((None, (1, 4), "SUMSQ_ROWS", None, SIDE))
+                    self._tgt_rows_normed = True
                 if dxt_side:
                     e._sid = AUX
             else:
@@ -395,9 +407,10 @@ class BackwardPlan(object):
             # gradient norm of everything that is final by now (attention, decoder, inference networks; the generator's went out behind
             # its own product): off the critical path, underneath the encoder chain
             e._sumsq_entry(P, "decoder.attn.linear_out.weight" if gen_norm_early else "generator.0.weight",
-                           "encoder.rnn.weight_ih_l%d" % (Lyr - 1), 0)
+                           "encoder.rnn.weight_ih_l%d" % (Lyr - 1), 0, skip_rows=self._tgt_rows_normed)
             e._wait(P, "aux_done")
-            e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None, 2)
+            if not self._inf_normed:
+                e._sumsq_entry(P, "inf_net_image.location.fc2.weight", None, 2)
         if dec_on_aux:
             e._sid = AUX
             e._wait(P, "side_first")
@@ -535,6 +548,11 @@ class BackwardPlan(object):
             finish_first_half()
         # join
         e._sid = SIDE
+        if spread and self._src_rows_normed:
+            # (the encoder's weight gradients are this stream's last products: their norm here, beside the main stream's scatter + row norm)
+            e._allreduce(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
+            e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight", 1, skip_rows=True)
+            self._enc_dense_normed = True
         e._record(P, "side_done")
         e._sid = MAIN
         e._wait(P, "side_done")
@@ -544,8 +562,9 @@ class BackwardPlan(object):
         norm_first = bool(dec_on_aux and getattr(e, "tail_norm_first", False) and not e.dp_on())
         if dec_on_aux and not norm_first:
             e._wait(P, "aux_end")
-        e._allreduce(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
-        e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight", 1, skip_rows=self._src_rows_normed)
+        if not self._enc_dense_normed:
+            e._allreduce(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight")
+            e._sumsq_entry(P, "encoder.rnn.weight_ih_l%d" % (Lyr - 1), "inf_net_image.location.fc2.weight", 1, skip_rows=self._src_rows_normed)
         if norm_first:
             e._wait(P, "aux_end")
         return P
