@@ -220,6 +220,15 @@ def test_engine_lazy_rows_equal_dense_over_many_steps(dtype, conditional):
     for k in ("vmmt_rows_catchup", "vmmt_rows_catchup_shadow"):
         assert k not in [en[2] for en in a.workspace(6, 5, 5).plan_fwd_eval]
         assert k not in [en[2] for en in b.workspace(6, 5, 5).plan_fwd_train]
+    if dtype == "bf16" and not conditional:
+        # the gradient norm's pieces sit behind the launches that complete their gradients, on those launches' streams (Engine.tail_norm_first):
+        # the tables' flagged rows right behind their scatter-adds, nothing but the two joins behind the main stream's last launch
+        bw = [(en[2], en[4]) for en in a.workspace(6, 5, 5).plan_bwd]
+        scat = [i for i, (n, _s) in enumerate(bw) if n == "vmmt_scatter_add_rows"]
+        assert len(scat) == 2 and all(bw[i + 1] == ("SUMSQ_ROWS", bw[i][1]) for i in scat), [bw[i:i + 2] for i in scat]
+        assert sorted(bw[i][1] for i in scat) == [0, 1]                       # source rows on the main stream, target rows on the side stream
+        last_launch = max(i for i, (n, s_) in enumerate(bw) if s_ == 0 and n not in ("EV_WAIT", "EV_RECORD"))
+        assert all(n == "EV_WAIT" for n, s_ in bw[last_launch + 1:] if s_ == 0) and bw[last_launch][0] == "SUMSQ_ROWS"
     if dtype == "bf16":          # the fused lookup: no source gather in front of the first product, one gather less on the main stream
         fused = [en for en in a.workspace(6, 5, 5).plan_fwd_train if en[2] == "gemm" and en[3].a_row_ids]
         assert len(fused) == 1 and not any(en[3].a_row_ids for en in b.workspace(6, 5, 5).plan_fwd_train if en[2] == "gemm")
