@@ -52,6 +52,8 @@ int vmmt_version(void);
  * onmt/TrainerMultimodal.py:624-705). */
 int vmmt_stream_create_masked(const uint32_t* mask, int words, int priority, void** stream);
 int vmmt_stream_destroy(void* stream);
+/* diagnostic (tools/probe_cu_mask.py): workgroup i of a grid of n (each `threads` wide, resident for hold_us) writes XCC id | HW_ID << 8 to out[i] */
+int vmmt_probe_where(uint32_t* out, int n_workgroups, int threads, int hold_us, void* stream);
 
 /* ---- generic fused GEMM --------------------------------------------------------------------------------------
  * C[m][n] (+)= act(alpha * sum_k A(m,k) B(n,k) + addend(m,n)).

@@ -68,6 +68,7 @@ _SIGS = {
     "vmmt_version": (i32, []),
     "vmmt_stream_create_masked": (i32, [vp, i32, i32, vp]),
     "vmmt_stream_destroy": (i32, [vp]),
+    "vmmt_probe_where": (i32, [vp, i32, i32, i32, vp]),
     "vmmt_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "vmmt_gemm_group": (i32, [C.POINTER(GemmArgs), i32, vp]),
     "vmmt_gemm_group_applies": (i32, [C.POINTER(GemmArgs), i32]),
