@@ -479,6 +479,14 @@ int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, void* stream
 int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16,
                    const int32_t* skip, void* stream);
+/* The same update over a range WITH A HOLE and a shadow that covers a PART of it, in one launch: the elements [0, span) without
+ * [hole_lo, hole_lo + hole_n) -- a lazily updated embedding table (vmmt_adam_rows_step) in the middle of an arena segment -- and the bf16 copy
+ * shadow_bf16[0 .. shadow_n) of the elements [shadow_lo, shadow_lo + shadow_n), which lie on one side of the hole.  All four offsets / lengths
+ * are multiples of 4.  The same bits as one vmmt_adam_step per piece: the step's last update (Optim.py:94-96) is a handful of small pieces
+ * whose launches, not their bytes, stood at the end of every step. */
+int vmmt_adam_step_ranges(float* p, const float* g, float* m, float* v, int64_t span, int64_t hole_lo, int64_t hole_n, float lr, float beta1,
+                          float beta2, float eps, int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks,
+                          void* shadow_bf16, int64_t shadow_lo, int64_t shadow_n, const int32_t* skip, void* stream);
 
 /* Data parallelism with the optimiser state sharded over the ranks (one process per GPU; the reference has no multi-GPU path,
  * train_mm_vi_model1.py:73-75 -- the norm reproduced is clip_grad_norm's over ALL gradients of the global batch, Optim.py:94-95):

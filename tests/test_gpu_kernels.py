@@ -93,6 +93,49 @@ def test_gemm_epilogues(dtype):
     assert (table.cpu().double() - want).abs().max().item() <= tol * 5
 
 
+@pytest.mark.parametrize("hole", [(0, 0), (4096, 30000), (0, 8192), (60000, 40000)])
+@pytest.mark.parametrize("shadow", [None, (100000, 20480), (1024, 2048)])
+def test_adam_ranges_equal_one_launch_per_piece(hole, shadow):
+    """vmmt_adam_step_ranges: a range with a hole (a lazily updated table) and a shadow over a part of it, in ONE launch -- the bits of one
+    vmmt_adam_step per piece; the hole's elements are not touched"""
+    L, lib = _lib()
+    torch.manual_seed(3)
+    n = 131072 + 8 + 3                       # (an odd tail behind the last whole group of four)
+    if shadow is not None and hole[1] and shadow[0] < hole[0] + hole[1] and hole[0] < shadow[0] + shadow[1]:
+        pytest.skip("the shadowed piece lies on one side of the hole")
+    base = [torch.randn(n).cuda(), (torch.randn(n) * 3).cuda(), (torch.rand(n) * 0.1).cuda(), (torch.rand(n) * 0.01).cuda()]
+    ss = torch.zeros(L.SUMSQ_SCRATCH, device="cuda")
+    L.check(lib.vmmt_sumsq(base[1].data_ptr(), n, ss.data_ptr(), 0, None), "sumsq")
+    args = (0.002, 0.9, 0.999, 1e-9, 7, 5.0)
+    # reference: one launch per piece
+    a = [t.clone() for t in base]
+    sh_a = torch.full((shadow[1] + 8,) if shadow else (8,), 9.0, device="cuda", dtype=torch.bfloat16)
+    cuts = sorted({0, n, hole[0], hole[0] + hole[1]} | ({shadow[0], shadow[0] + shadow[1]} if shadow else set()))
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        if hi <= lo or (hole[1] and hole[0] <= lo < hole[0] + hole[1]):
+            continue
+        shp = sh_a.data_ptr() if (shadow and lo == shadow[0]) else None
+        L.check(lib.vmmt_adam_step(a[0].data_ptr() + 4 * lo, a[1].data_ptr() + 4 * lo, a[2].data_ptr() + 4 * lo, a[3].data_ptr() + 4 * lo, hi - lo,
+                                   *args, ss.data_ptr(), 1.0, 0, shp, None, None), "adam")
+    b = [t.clone() for t in base]
+    sh_b = torch.full_like(sh_a, 9.0)
+    L.check(lib.vmmt_adam_step_ranges(b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), n, hole[0], hole[1], *args,
+                                      ss.data_ptr(), 1.0, 0, sh_b.data_ptr() if shadow else None, shadow[0] if shadow else 0,
+                                      shadow[1] if shadow else 0, None, None), "adam ranges")
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(sh_a, sh_b)
+    if hole[1]:
+        for x, y in zip(b, base):
+            assert torch.equal(x[hole[0]:hole[0] + hole[1]], y[hole[0]:hole[0] + hole[1]])
+    if shadow:
+        assert torch.equal(sh_b[:shadow[1]], b[0][shadow[0]:shadow[0] + shadow[1]].to(torch.bfloat16)) and (sh_b[shadow[1]:] == 9.0).all()
+    # arguments the kernel's vector groups cannot take
+    assert lib.vmmt_adam_step_ranges(b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), n, 6, 8, *args, ss.data_ptr(), 1.0, 0,
+                                     None, 0, 0, None, None) == 1          # VMMT_EINVAL
+
+
 def test_adam_and_sumsq():
     L, lib = _lib()
     torch.manual_seed(0)

@@ -131,6 +131,7 @@ _SIGS = {
     "vmmt_standardise_rows": (i32, [vp, i64, vp, vp, i64, i32, vp]),
     "vmmt_sumsq": (i32, [vp, i64, vp, i32, vp]),
     "vmmt_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp, vp, vp]),
+    "vmmt_adam_step_ranges": (i32, [vp, vp, vp, vp, i64, i64, i64, f32, f32, f32, f32, i32, f32, vp, f32, i32, vp, i64, i64, vp, vp]),
     "vmmt_dp_norm_pack": (i32, [vp, vp, vp, vp]),
     "vmmt_dp_norm_fold": (i32, [vp, i32, vp, vp, vp]),
     "vmmt_rows_mark": (i32, [vp, i64, vp, i32, vp, vp]),

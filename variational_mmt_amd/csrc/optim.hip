@@ -79,9 +79,14 @@ __device__ __forceinline__ void adam_elem(float& p, float ge, float& m, float& v
 
 // `shadow` (optional): bf16 compute copy of this parameter range with the SAME flat layout (a 2-D weight whose shadow rows are not padded):
 // written here, so that the shadow refresh does not have to read the 15 M-element generator weight back
+// (sh_lo, sh_n): the shadow covers elements [sh_lo, sh_lo + sh_n) of the range only (shadow[0] = element sh_lo);  (hole_lo, hole_n): the n
+// elements are those of [0, n + hole_n) WITHOUT [hole_lo, hole_lo + hole_n) -- a lazily updated embedding table in the middle of the range,
+// which vmmt_adam_rows_step updates: one launch for everything around it instead of one per piece (the pieces of the step's last update are
+// small: their launches, not their bytes, were the tail of the step).  All four are multiples of 4.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float step_size, float b1, float b2, float eps, float inv_sqrt_bc2, float max_norm,
-                            const float* __restrict__ sumsq, float grad_scale, bf16_t* __restrict__ shadow, int* __restrict__ skip) {
+                            const float* __restrict__ sumsq, float grad_scale, bf16_t* __restrict__ shadow, int* __restrict__ skip,
+                            long sh_lo, long sh_n, long hole_lo, long hole_n) {
   if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {      // vmmt.h: the step is not applied
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1);
     return;
@@ -95,10 +100,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     float c = max_norm / (nrm + 1e-6f);
     if (c < 1.f) coef *= c;
   }
-  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   long stride = (long)gridDim.x * blockDim.x * 4;
-  for (; i < n; i += stride) {
-    if (i + 3 < n) {
+  for (; j < n; j += stride) {
+    const long i = j < hole_lo ? j : j + hole_n;          // (logical -> arena index: the hole is skipped)
+    const bool sh = shadow && i >= sh_lo && i < sh_lo + sh_n;
+    if (j + 3 < n) {
 #ifndef VMMT_EXP_ADAMT
       // streamed once per step: non-temporal, so that 1.7 GB of optimiser traffic does not push the recurrences' exchange lines and
       // the GEMMs' operands out of the L2s (1.799 -> 1.780 ms per step, three same-box pairs)
@@ -123,18 +130,18 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
       *reinterpret_cast<f32x4*>(m + i) = mm;
       *reinterpret_cast<f32x4*>(v + i) = vv;
 #endif
-      if (shadow) {
+      if (sh) {
         typedef unsigned short us4 __attribute__((ext_vector_type(4)));
         const us4 h = {f2bf(pp[0]), f2bf(pp[1]), f2bf(pp[2]), f2bf(pp[3])};
-        *reinterpret_cast<us4*>(shadow + i) = h;
+        *reinterpret_cast<us4*>(shadow + (i - sh_lo)) = h;
       }
     } else {
-      for (long k = i; k < n; ++k) {
+      for (long k = i; k < i + (n - j); ++k) {              // (the range's last 1-3 elements: behind the hole, if there is one)
         float mk = m[k], vk = v[k], pk = p[k];
         adam_elem(pk, g[k] * coef, mk, vk, step_size, b1, b2, eps, inv_sqrt_bc2);
         m[k] = mk; v[k] = vk;
         p[k] = pk;
-        if (shadow) shadow[k] = f2bf(pk);
+        if (sh) shadow[k - sh_lo] = f2bf(pk);
       }
     }
   }
@@ -502,9 +509,30 @@ extern "C" int vmmt_sumsq(const float* g, int64_t n, float* scratch, int slot, v
   return check_launch();
 }
 
+static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                       float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16, int64_t sh_lo, int64_t sh_n,
+                       int64_t hole_lo, int64_t hole_n, const int32_t* skip, void* stream);
+
 extern "C" int vmmt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                               float eps, int step, float max_norm, const float* sumsq, float grad_scale, int max_blocks,
                               void* shadow_bf16, const int32_t* skip, void* stream) {
+  return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, step, max_norm, sumsq, grad_scale, max_blocks, shadow_bf16, 0, shadow_bf16 ? n : 0, n, 0,
+                     skip, stream);
+}
+
+extern "C" int vmmt_adam_step_ranges(float* p, const float* g, float* m, float* v, int64_t span, int64_t hole_lo, int64_t hole_n, float lr,
+                                     float beta1, float beta2, float eps, int step, float max_norm, const float* sumsq, float grad_scale,
+                                     int max_blocks, void* shadow_bf16, int64_t shadow_lo, int64_t shadow_n, const int32_t* skip, void* stream) {
+  if (span < 0 || hole_lo < 0 || hole_n < 0 || hole_lo + hole_n > span || ((hole_lo | hole_n) & 3)) return VMMT_EINVAL;
+  if (shadow_bf16 && (shadow_lo < 0 || shadow_n < 0 || shadow_lo + shadow_n > span || ((shadow_lo | shadow_n) & 3))) return VMMT_EINVAL;
+  if (shadow_bf16 && hole_n > 0 && shadow_lo < hole_lo + hole_n && hole_lo < shadow_lo + shadow_n) return VMMT_EINVAL;      // (the shadowed piece lies on one side of the hole)
+  return adam_launch(p, g, m, v, span - hole_n, lr, beta1, beta2, eps, step, max_norm, sumsq, grad_scale, max_blocks, shadow_bf16, shadow_lo,
+                     shadow_bf16 ? shadow_n : 0, hole_n > 0 ? hole_lo : span, hole_n, skip, stream);
+}
+
+static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                       float max_norm, const float* sumsq, float grad_scale, int max_blocks, void* shadow_bf16, int64_t sh_lo, int64_t sh_n,
+                       int64_t hole_lo, int64_t hole_n, const int32_t* skip, void* stream) {
   using namespace vmmt;
   if (!p || !g || !m || !v || n < 0 || step < 1 || (max_norm > 0.f && !sumsq)) return VMMT_EINVAL;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return VMMT_EINVAL;
@@ -517,7 +545,8 @@ extern "C" int vmmt_adam_step(float* p, const float* g, float* m, float* v, int6
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;   // throttle: a background update must not saturate HBM
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, step_size, beta1,
-                     beta2, eps, inv_sqrt_bc2, max_norm, sumsq, grad_scale, (bf16_t*)shadow_bf16, const_cast<int*>(skip));
+                     beta2, eps, inv_sqrt_bc2, max_norm, sumsq, grad_scale, (bf16_t*)shadow_bf16, const_cast<int*>(skip), (long)sh_lo, (long)sh_n,
+                     (long)hole_lo, (long)hole_n);
   return check_launch();
 }
 

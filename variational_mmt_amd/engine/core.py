@@ -132,6 +132,9 @@ class Engine(StepAPI):
         self._masked_streams = []
         import os as _os
         self.q_parallel = True    # q(z|x): scale branch on the side stream next to the location branch
+        # 2: the FOREGROUND half of the update (the step's tail) as one dense launch around its lazily updated table + the table's row-wise one
+        # (config 2: 1.438-1.443 against 1.449-1.456 ms per piece; the background half the same way: 1.472-1.476 -- its pieces stay; 1: both, 0: neither)
+        self.adam_one_launch = 2
         self.tail_norm_first = True   # backward plan: the encoder segment's norm in front of the main stream's join with the aux stream
         self.dec_gx_first = True  # side stream of the forward: the decoder's input projection in front of the gradient zeroing / masks
         self.zero_on_aux = True   # ... and the zeroing / masks on the AUX stream (idle at that point of the forward) instead of behind it
@@ -205,7 +208,7 @@ class Engine(StepAPI):
         group_wgrads=_knob_bool, use_side_stream=_knob_bool, use_aux_stream=_knob_bool, gen_compact=_knob_bool, q_parallel=_knob_bool,
         dec_gx_first=_knob_bool, zero_on_aux=_knob_bool, fuse_emb_gemm=_knob_bool, split_optim=_knob_bool, bg_after_head=_knob_bool, hold_back=_knob_bool,
         fused_qnet=_knob_bool, qnet_split=_knob_bool, gen_fused=_knob_bool, persistent_lstm=_knob_bool, seq_fallback=_knob_bool,
-        row_adam=_knob_bool, reparam_grad=_knob_bool, tail_norm_first=_knob_bool)
+        row_adam=_knob_bool, reparam_grad=_knob_bool, tail_norm_first=_knob_bool, adam_one_launch=int)
     # environment switches of rounds 2-4 that became attributes (or went with their kernels) in round 5: setting one is a mistake worth a line
     _REMOVED_SWITCHES = frozenset((
         "VMMT_LATENT_ZX", "VMMT_FUSE_OUT_DROPOUT", "VMMT_DECODE_GRAPHS", "VMMT_BG_ADAM_BLOCKS", "VMMT_FG_ADAM_BLOCKS", "VMMT_MAX_SPLIT_K",

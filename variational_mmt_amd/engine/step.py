@@ -238,6 +238,24 @@ class StepAPI(object):
             pieces = [(s_lo, s_hi, ("shadow", ptr)) for s_lo, s_hi, ptr in self._fused_shadows() if lo <= s_lo and s_hi <= hi]
             if rows:
                 pieces += [(t["off"], t["end"], ("rows", t)) for t in self.row_tables if lo <= t["off"] and t["end"] <= hi]
+            sh = [x for x in pieces if x[2][0] == "shadow"]
+            tb = [x for x in pieces if x[2][0] == "rows"]
+            one = int(self.adam_one_launch)
+            if (one == 1 or (one == 2 and stream == st) or (one == 3 and stream != st)) and hi > lo and len(sh) <= 1 and len(tb) <= 1:
+                # ONE dense launch for the whole range -- around the lazily updated table (a hole), the shadow attached to its piece -- and the
+                # table's row-wise launch: the update's pieces are small, their launches were the step's tail (vmmt_adam_step_ranges)
+                blocks = int(self.bg_adam_blocks) if stream != st else int(self.fg_adam_blocks)
+                h_lo, h_n = (tb[0][0] - lo, tb[0][1] - tb[0][0]) if tb else (0, 0)
+                s_ptr, s_lo, s_n = (sh[0][2][1], sh[0][0] - lo, sh[0][1] - sh[0][0]) if sh else (None, 0, 0)
+                if hi - lo - h_n > 0:
+                    L.check(self.lib.vmmt_adam_step_ranges(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
+                                                           self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, h_lo, h_n, lr,
+                                                           beta1, beta2, eps, t_adam, float(max_grad_norm or 0.0), self._sumsq.data_ptr(), grad_scale,
+                                                           blocks, s_ptr, s_lo, s_n, guard, stream), "vmmt_adam_step_ranges")
+                    n_launch[0] += 1
+                if tb:
+                    rows_step(tb[0][2][1], stream)
+                return
             cur = lo
             for p_lo, p_hi, (kind, what) in sorted(pieces, key=lambda x: x[0]):
                 adam_range(cur, p_lo, stream)
