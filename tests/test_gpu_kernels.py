@@ -772,3 +772,20 @@ def test_mul_and_act_bwd_vector_paths_equal_the_scalar_kernels():
     assert torch.equal(outs[512][0].cpu(), want)
     want_t = (dy32 * mk.float() * (1 - yv.float() ** 2)).to(T)
     assert (outs[512][1].cpu().float() - want_t.float()).abs().max().item() <= 2e-2 * want_t.float().abs().max().item()
+
+
+def test_probe_where_reports_xcd_and_cu_of_every_workgroup():
+    """vmmt_probe_where (diagnostic behind tools/probe_cu_mask.py): every workgroup of a resident grid reports the XCD and the CU it runs on --
+    8 XCDs, at most 256 distinct CUs, and a grid that outlasts its own dispatch spreads over most of them"""
+    L, lib = _lib()
+    n = 1024
+    out = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    L.check(lib.vmmt_probe_where(out.data_ptr(), n, 256, 100, None), "probe")
+    torch.cuda.synchronize()
+    v = out.cpu().numpy().astype("uint32")
+    assert (v != 0xFFFFFFFF).all()
+    xcc, hw = v & 15, v >> 8
+    assert set(xcc.tolist()) <= set(range(8)) and len(set(xcc.tolist())) == 8
+    cus = set(zip(xcc.tolist(), ((hw >> 13) & 7).tolist(), ((hw >> 12) & 1).tolist(), ((hw >> 8) & 15).tolist()))
+    assert 128 <= len(cus) <= 256
+    assert lib.vmmt_probe_where(out.data_ptr(), 0, 256, 100, None) == 1          # VMMT_EINVAL
