@@ -188,7 +188,9 @@ def test_engine_lazy_rows_equal_dense_over_many_steps(dtype, conditional):
     torch.cuda.synchronize()
     a, b = engines[True], engines[False]
     assert a._lazy_dirty and a.lazy_errors() == [0, 0]
-    tol = 5e-6 if dtype == "f32" else 2e-3
+    # f32: two DENSE runs of these 24 updates differ by up to 4e-6 (float atomics in the gradient products; tests/run_to_run_matrix.py), the lazy
+    # engine once by 4.95e-6 from the dense one: 2e-5 leaves that room and is two orders below what a row that missed one update would show (lr)
+    tol = 2e-5 if dtype == "f32" else 2e-3
     for x, y, what in ((a.flat_p, b.flat_p, "p"), (a.flat_m, b.flat_m, "m"), (a.flat_v, b.flat_v, "v")):      # (reading the arena flushes)
         n = a.n_opt
         err = (x[:n] - y[:n]).abs()
@@ -264,8 +266,8 @@ def test_lazy_rows_switched_on_and_off_between_updates():
             e.optim_step(lr=0.01, max_grad_norm=0.5)
     torch.cuda.synchronize()
     n = a.n_opt
-    assert (a.flat_p[:n] - b.flat_p[:n]).abs().max().item() <= 5e-6 * max(1.0, b.flat_p[:n].abs().max().item())
-    assert (a.flat_m[:n] - b.flat_m[:n]).abs().max().item() <= 5e-6 * max(1.0, b.flat_m[:n].abs().max().item())
+    assert (a.flat_p[:n] - b.flat_p[:n]).abs().max().item() <= 2e-5 * max(1.0, b.flat_p[:n].abs().max().item())
+    assert (a.flat_m[:n] - b.flat_m[:n]).abs().max().item() <= 2e-5 * max(1.0, b.flat_m[:n].abs().max().item())
 
 
 def test_lazy_rows_follow_a_step_counter_set_from_outside():
@@ -302,7 +304,7 @@ def test_lazy_rows_follow_a_step_counter_set_from_outside():
     for x in (a, t):
         for what in ("flat_p", "flat_m", "flat_v"):
             u, w = getattr(x, what)[:n], getattr(b, what)[:n]
-            assert (u - w).abs().max().item() <= 1e-5 * max(1.0, w.abs().max().item()), what          # (14 updates of float-atomic noise)
+            assert (u - w).abs().max().item() <= 2e-5 * max(1.0, w.abs().max().item()), what          # (14 updates of float-atomic noise)
     assert a.lazy_errors() == [0, 0] and t.lazy_errors() == [0, 0]
 
 
