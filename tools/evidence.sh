@@ -30,6 +30,7 @@ timeout -k 10 300 python tools/phase_times.py > gpurun_out/${TAG}_phase_times.tx
 timeout -k 10 300 python tools/hbm_kernels.py > gpurun_out/${TAG}_hbm_kernels.txt 2>&1 &&
 timeout -k 10 300 python tools/lazy_rows_bench.py > gpurun_out/${TAG}_lazy_rows_kernels.txt 2>&1 &&
 timeout -k 10 300 python tools/critical.py > gpurun_out/${TAG}_critical.txt 2>&1 &&
+(for t in dwg_layouts gemm_square wgrad_gemm gemm_vs_blas; do echo "== python tools/$t.py"; timeout -k 10 300 python tools/$t.py 2>&1 | grep -v amdgpu.ids; echo; done) > gpurun_out/${TAG}_gemm_products_alone.txt 2>&1 &&
 VMMT_DP_FORCE=1 VMMT_DP_DIRECT=1 timeout -k 10 300 python bench.py $NP > gpurun_out/${TAG}_bench_rccl_world1.json 2> gpurun_out/${TAG}_bench_rccl_world1.err &&
 VMMT_BENCH_ONE_GPU=1 VMMT_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 10 --warmup 3 $NP > gpurun_out/${TAG}_bench_2ranks_one_gpu_gloo.json 2> gpurun_out/${TAG}_bench_2ranks.err &&
 # the PMC passes LAST: profiles/traffic.json must be measured on the kernels the lines above ran (tools/traffic_key.py merge gpurun_out/traffic_${TAG}final_config2.json)
